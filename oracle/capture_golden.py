@@ -1,0 +1,398 @@
+"""TEST INFRASTRUCTURE ONLY -- generates tests/golden/*.npz by EXECUTING the reference's own
+classes in the dev container (the only place /root/reference exists).
+
+    python -m oracle.capture_golden            # rewrites every fixture
+
+Nothing of the reference is copied: its files are imported from /root/reference at run
+time, and only numbers (inputs, weights, outputs, gradients) are stored.  ``torch_geometric``
+is provided by the build-owned stand-in ``oracle/pyg_standin.py`` (PyG is not installed).
+
+Fixture inventory:
+  G1  DiffusionScheduler tables                         core/diffusion.py as-is
+  G2  GraphConvolution (no edge attr; + edge attr w/o loops)  core/graph_layers.py as-is
+  G2b GraphEncoder(use_edge_features=False)              models/encoders.py as-is
+  G4  MultiHeadAttention w/ float mask, SpatialAttention core/attention.py as-is
+  G5  DiffusionLayer add_noise/predict_noise/forward/sample (2-D input)  as-is
+  G6  FeatureEncoder, AdaptiveGraphPooling, GlobalAttentionPool          as-is
+  G7  DynamicGraphLayer (R1), GraphEncoder (R1+R2), GraphUNet (R1+R5), full model
+      forward/pretrain_step (R1-R5): reference leaf classes, repaired wiring
+All modules run in eval() (dropout off); random draws are injected by temporarily
+replacing torch.randn_like / torch.randint / torch.randperm / torch.randn.
+"""
+from __future__ import annotations
+
+import contextlib
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+REF_ROOT = "/root/reference"
+OUT_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def load_reference():
+    """Import the reference's hot-path modules without running its package __init__s."""
+    from . import pyg_standin
+    pyg_standin.install()
+    if "dgdm_histopath" not in sys.modules:
+        for name in ("dgdm_histopath", "dgdm_histopath.core", "dgdm_histopath.models", "dgdm_histopath.utils"):
+            m = types.ModuleType(name)
+            m.__path__ = [os.path.join(REF_ROOT, *name.split("."))]
+            sys.modules[name] = m
+    mods = {}
+    for short, full in dict(
+        attention="dgdm_histopath.core.attention", diffusion="dgdm_histopath.core.diffusion",
+        graph_layers="dgdm_histopath.core.graph_layers", encoders="dgdm_histopath.models.encoders",
+        dgdm_model="dgdm_histopath.models.dgdm_model").items():
+        mods[short] = importlib.import_module(full)
+    return types.SimpleNamespace(**mods)
+
+
+# ------------------------------------------------------------------------------ helpers
+def sd_np(module: nn.Module, prefix: str = "w."):
+    return {prefix + k: v.detach().numpy().copy() for k, v in module.state_dict().items()}
+
+
+def rand_graph(n, e, seed, self_loops=0, dups=0):
+    g = torch.Generator().manual_seed(seed)
+    ei = torch.randint(0, n, (2, e), generator=g)
+    if self_loops:
+        ei[1, :self_loops] = ei[0, :self_loops]
+    if dups:
+        ei[:, -dups:] = ei[:, :dups]
+    return ei
+
+
+def randomize_(module: nn.Module, seed: int, bias_scale=0.1):
+    """Give every bias / norm affine a non-trivial value so they are actually exercised."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in module.named_parameters():
+            if p.dim() == 1:
+                p.add_(bias_scale * torch.randn(p.shape, generator=g))
+
+
+@contextlib.contextmanager
+def injected_rng(randn_like=(), randint=(), randperm=(), randn=()):
+    """Replace torch's samplers by queues of pre-drawn tensors (consumed in call order)."""
+    q = dict(randn_like=list(randn_like), randint=list(randint), randperm=list(randperm), randn=list(randn))
+    orig = {k: getattr(torch, k) for k in q}
+
+    def mk(kind):
+        def f(*a, **kw):
+            if not q[kind]:
+                raise RuntimeError(f"injected {kind} queue exhausted")
+            return q[kind].pop(0).clone()
+        return f
+    try:
+        for k in q:
+            if q[k]:
+                setattr(torch, k, mk(k))
+        yield
+    finally:
+        for k, v in orig.items():
+            setattr(torch, k, v)
+
+
+def grads_of(loss, tensors):
+    gs = torch.autograd.grad(loss, tensors, allow_unused=True)
+    return [None if g is None else g.detach().numpy().copy() for g in gs]
+
+
+def save(name, **arrays):
+    os.makedirs(OUT_DIR, exist_ok=True)
+    arrays = {k: (v.detach().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in arrays.items() if v is not None}
+    np.savez_compressed(os.path.join(OUT_DIR, name + ".npz"), **arrays)
+    print(f"  wrote {name}.npz  ({sum(a.nbytes for a in arrays.values())/1e3:.1f} kB raw, {len(arrays)} arrays)")
+
+
+# ------------------------------------------------------------------------------ fixtures
+def g1_scheduler(ref):
+    out = {}
+    for T in (10, 20):
+        for sch in ("linear", "cosine", "sigmoid"):
+            s = ref.diffusion.DiffusionScheduler(T, schedule=sch)
+            for k in ("betas", "alphas", "alphas_cumprod", "alphas_cumprod_prev", "posterior_variance"):
+                out[f"{sch}.{T}.{k}"] = getattr(s, k)
+    save("g1_scheduler", **out)
+
+
+def g2_graph_conv(ref):
+    GC = ref.graph_layers.GraphConvolution
+    torch.manual_seed(21)
+    n, e = 16, 40
+    ei = rand_graph(n, e, 210, self_loops=3, dups=4)
+    conv = GC(12, 20); randomize_(conv, 211)
+    x = torch.randn(n, 12, requires_grad=True)
+    y = conv(x, ei)
+    gy = torch.randn(y.shape)
+    gx, gw, gb = grads_of((y * gy).sum(), [x, conv.node_lin.weight, conv.bias])
+    # variant: edge attributes, no self loops (runs as-is: no D1)
+    conv2 = GC(12, 20, edge_dim=5, add_self_loops=False); randomize_(conv2, 212)
+    ea = torch.randn(e, 5)
+    x2 = torch.randn(n, 12, requires_grad=True)
+    y2 = conv2(x2, ei, ea)
+    gx2, gw2, gwe2 = grads_of((y2 * gy).sum(), [x2, conv2.node_lin.weight, conv2.edge_lin.weight])
+    save("g2_graph_conv", edge_index=ei, x=x, gy=gy, y=y, gx=gx, gw=gw, gb=gb, **sd_np(conv, "a."),
+         edge_attr=ea, x2=x2, y2=y2, gx2=gx2, gw2=gw2, gwe2=gwe2, **sd_np(conv2, "b."))
+
+
+def g2b_plain_encoder(ref):
+    torch.manual_seed(22)
+    enc = ref.encoders.GraphEncoder(24, [24, 16, 8], 4, use_edge_features=False).eval()
+    randomize_(enc, 221)
+    n, e = 40, 120
+    ei = rand_graph(n, e, 220, self_loops=2, dups=3)
+    x = torch.randn(n, 24, requires_grad=True)
+    out = enc(x, ei)
+    gy = torch.randn(out["embeddings"].shape)
+    gx, gw0 = grads_of((out["embeddings"] * gy).sum(), [x, enc.graph_layers[0].node_lin.weight])
+    save("g2b_plain_encoder", edge_index=ei, x=x, gy=gy, embeddings=out["embeddings"], gx=gx, gw0=gw0,
+         **{f"layer{i}": t for i, t in enumerate(out["layer_outputs"])}, **sd_np(enc))
+
+
+def g4_attention(ref):
+    torch.manual_seed(24)
+    mha = ref.attention.MultiHeadAttention(64, 8).eval(); randomize_(mha, 241)
+    q = torch.randn(2, 20, 64, requires_grad=True)
+    mask = torch.randn(20, 20)
+    o, w = mha(q, attn_mask=mask)
+    go = torch.randn(o.shape)
+    gq, gwq = grads_of((o * go).sum(), [q, mha.q_proj.weight])
+    # cross-attention form used by GlobalAttentionPool: 1 query, separate key/value
+    tok = torch.randn(1, 1, 64)
+    kv = torch.randn(1, 13, 64)
+    o2, w2 = mha(tok, kv, kv)
+    save("g4_mha", q=q, mask=mask, out=o, weights=w, go=go, gq=gq, gwq=gwq, tok=tok, kv=kv, out2=o2, weights2=w2, **sd_np(mha))
+
+    C, H, n = 128, 8, 48
+    sa = ref.attention.SpatialAttention(C, H).eval(); randomize_(sa, 242)
+    x = torch.randn(1, n, C, requires_grad=True)
+    pos = torch.rand(1, n, 2) * 3.0 + 0.5  # not pre-normalised: exercises the min/max rule
+    o, w = sa(x, pos)
+    go = torch.randn(o.shape)
+    params = [x, sa.attention.q_proj.weight, sa.attention.k_proj.weight, sa.attention.v_proj.weight,
+              sa.attention.out_proj.weight, sa.norm.weight]
+    gx, gwq, gwk, gwv, gwo, gnw = grads_of((o * go).sum(), params)
+    w_sd = {k: v for k, v in sd_np(sa).items() if "pos_encoding" not in k and "spatial_proj" not in k}  # dead params
+    save("g4_spatial_attention", x=x[0], pos=pos[0], out=o[0], weights=w[0], go=go[0], gx=gx[0], gwq=gwq, gwk=gwk,
+         gwv=gwv, gwo=gwo, gnw=gnw, pe=sa.get_positional_encoding(pos)[0], **w_sd)
+
+
+def g5_diffusion(ref):
+    torch.manual_seed(25)
+    C, Hd, T = 32, 64, 10
+    dl = ref.diffusion.DiffusionLayer(C, Hd, num_timesteps=T).eval(); randomize_(dl, 251)
+    n = 30
+    x0 = torch.randn(n, C, requires_grad=True)
+    noise = torch.randn(n, C)
+    t = torch.tensor([7])
+    xn, pred = dl(x0, t, noise)  # 2-D form (R3) runs as-is
+    gp = torch.randn(pred.shape)
+    gx0, gw0, gte = grads_of((pred * gp).sum(), [x0, dl.denoise_net[0].weight, dl.time_embed[0].weight])
+    temb = dl.get_timestep_embedding(torch.tensor([0, 3, 9]))
+    # sample(): 6 inference steps over T=10 (repeats/skips timesteps like the reference's linspace().long())
+    steps = 6
+    g = torch.Generator().manual_seed(252)
+    x_init = torch.randn(n, C, generator=g)
+    step_noise = [torch.randn(n, C, generator=g) for _ in range(steps - 1)]
+    with injected_rng(randn=[x_init], randn_like=step_noise):
+        samp = dl.sample((n, C), torch.device("cpu"), num_inference_steps=steps)
+    save("g5_diffusion", x0=x0, noise=noise, t=t, x_noisy=xn, pred=pred, gp=gp, gx0=gx0, gw0=gw0, gte=gte, temb=temb,
+         x_init=x_init, step_noise=torch.stack(step_noise), sample=samp, steps=steps, T=T, **sd_np(dl))
+
+
+def g6_small_modules(ref):
+    torch.manual_seed(26)
+    fe = ref.encoders.FeatureEncoder(48, 32).eval(); randomize_(fe, 261)
+    x = torch.randn(25, 48, requires_grad=True)
+    y = fe(x); gy = torch.randn(y.shape)
+    gx, gw = grads_of((y * gy).sum(), [x, fe.encoder[0].weight])
+    save("g6_feature_encoder", x=x, y=y, gy=gy, gx=gx, gw=gw, **sd_np(fe))
+
+    pool = ref.graph_layers.AdaptiveGraphPooling(32).eval(); randomize_(pool, 262)
+    n, e = 21, 60
+    ei = rand_graph(n, e, 263, self_loops=2)
+    xp = torch.randn(n, 32, requires_grad=True); ea = torch.randn(e, 32)
+    px, pei, pea, perm = pool(xp, ei, ea)
+    gpx = torch.randn(px.shape)
+    gxp, = grads_of((px * gpx).sum(), [xp])
+    save("g6_pool", x=xp, edge_index=ei, edge_attr=ea, pooled_x=px, pooled_edge_index=pei, pooled_edge_attr=pea,
+         perm=perm, gpx=gpx, gx=gxp, **sd_np(pool))
+
+    gp = ref.dgdm_model.GlobalAttentionPool(32, 4).eval(); randomize_(gp, 264)
+    xg = torch.randn(33, 32, requires_grad=True)
+    batch = torch.cat([torch.zeros(9), torch.ones(14), torch.full((10,), 2)]).long()
+    out = gp(xg, batch); go = torch.randn(out.shape)
+    gxg, gtok = grads_of((out * go).sum(), [xg, gp.global_token])
+    save("g6_attention_pool", x=xg, batch=batch, out=out, go=go, gx=gxg, gtok=gtok, **sd_np(gp))
+
+
+# -- repaired wiring around reference leaf classes (R2, R5) -------------------------------------
+def build_repaired_model(ref, cfg):
+    """Reference DGDMModel with (R2) dim_proj wrappers in the graph encoder, (R5a/b) a
+    GraphUNet whose layers are constructed with edge_dim=32 and hidden-wide up_convs, and
+    (R3) a 2-D call into the diffusion layer.  Every nn.Module that computes anything is
+    a reference class; only constructor arguments / call shapes are repaired."""
+    GL, DM = ref.graph_layers, ref.dgdm_model
+
+    class LayerThenProj(nn.Module):  # R2 -- not a DynamicGraphLayer instance, so GraphEncoder.forward
+        def __init__(self, layer, proj):  # takes its "standard graph convolution" branch (encoders.py:262-264)
+            super().__init__(); self.layer, self.proj = layer, proj
+        def forward(self, x, edge_index, edge_attr):
+            return self.proj(self.layer(x, edge_index, edge_attr))
+
+    class RepairedUNet(GL.GraphUNet):  # R5a/R5b: constructor only; forward is the reference's
+        def __init__(self, c, depth=3):
+            nn.Module.__init__(self)
+            self.in_channels = self.hidden_channels = self.out_channels = c
+            self.depth, self.sum_res, self.act = depth, True, torch.nn.functional.relu
+            mk = lambda: GL.DynamicGraphLayer(c, 32, c)
+            self.down_convs = nn.ModuleList([mk() for _ in range(depth + 1)])
+            self.pools = nn.ModuleList([GL.AdaptiveGraphPooling(c, ratio=0.5) for _ in range(depth)])
+            self.bottom_conv = mk()
+            self.up_convs = nn.ModuleList([mk() for _ in range(depth)])
+            self.final_conv = nn.Linear(c, c)
+
+    class Repaired(DM.DGDMModel):
+        def _compute_diffusion_loss(self, node_embeddings, data):  # R3 (+ injected draws)
+            bsz = int(data.batch.max()) + 1
+            t = torch.randint(0, self.num_diffusion_steps, (bsz,))
+            losses = []
+            for i in range(bsz):
+                emb = node_embeddings[data.batch == i]
+                noisy, pred = self.diffusion_layer(emb, t[i:i + 1])  # 2-D, draws randn_like(noise)
+                target = torch.randn_like(emb)                       # dgdm_model.py:429
+                losses.append(torch.nn.functional.mse_loss(pred, target))
+            return {"diffusion_loss": torch.stack(losses).mean(), "noisy_embeddings": noisy.unsqueeze(0)}
+
+    m = Repaired(**cfg)
+    dims = [cfg["hidden_dims"][0]] + list(cfg["hidden_dims"])
+    for i in range(len(m.graph_encoder.graph_layers)):
+        din, dout = dims[i], dims[min(i + 1, len(dims) - 1)]
+        if din != dout:
+            m.graph_encoder.graph_layers[i] = LayerThenProj(m.graph_encoder.graph_layers[i], nn.Linear(din, dout))
+    if cfg.get("use_hierarchical", True):
+        m.hierarchical_processor = RepairedUNet(cfg["hidden_dims"][-1])
+    m.apply(m._init_weights)  # same init rule for the replaced parts (dgdm_model.py:259-269)
+    return m
+
+
+def repaired_state_to_oracle_keys(sd):
+    """graph_layers.i.layer.* -> graph_layers.i.*, graph_layers.i.proj.* -> dim_proj.i.*"""
+    out = {}
+    for k, v in sd.items():
+        parts = k.split(".")
+        if k.startswith("graph_encoder.graph_layers.") and parts[3] == "layer":
+            k = ".".join(parts[:3] + parts[4:])
+        elif k.startswith("graph_encoder.graph_layers.") and parts[3] == "proj":
+            k = ".".join(["graph_encoder", "dim_proj", parts[2]] + parts[4:])
+        out[k] = v
+    return out
+
+
+def small_batch(ref, sizes, feat, seed, edge_mult=3):
+    from torch_geometric.data import Data, Batch
+    gs = []
+    for gi, n in enumerate(sizes):
+        g = torch.Generator().manual_seed(seed + gi)
+        e_half = n * edge_mult // 2
+        u = torch.randint(0, n, (e_half,), generator=g); v = torch.randint(0, n - 1, (e_half,), generator=g)
+        v = v + (v >= u).long()  # u != v
+        ei = torch.stack([torch.stack([u, v]), torch.stack([v, u])], dim=2).reshape(2, -1)  # both directions, adjacent
+        ea = torch.randn(e_half, 32, generator=g).repeat_interleave(2, dim=0)
+        gs.append(Data(x=torch.randn(n, feat, generator=g), edge_index=ei, edge_attr=ea, pos=torch.rand(n, 2, generator=g) * 2.0))
+    return Batch.from_data_list(gs)
+
+
+def g7_repaired(ref):
+    GL = ref.graph_layers
+    torch.manual_seed(27)
+    # DynamicGraphLayer as-is code + R1 (zero attr rows for the loops, in the stand-in's propagate)
+    layer = GL.DynamicGraphLayer(24, 32, 16, num_heads=4).eval(); randomize_(layer, 271)
+    n, e = 18, 50
+    ei = rand_graph(n, e, 272, self_loops=2, dups=2); ea = torch.randn(e, 32)
+    x = torch.randn(n, 24, requires_grad=True)
+    y = layer(x, ei, ea); gy = torch.randn(y.shape)
+    gx, gw1, gwe1, gb2 = grads_of((y * gy).sum(), [x, layer.graph_conv1.node_lin.weight, layer.graph_conv1.edge_lin.weight,
+                                                    layer.graph_conv2.bias])
+    save("g7_dynamic_layer", x=x, edge_index=ei, edge_attr=ea, y=y, gy=gy, gx=gx, gw1=gw1, gwe1=gwe1, gb2=gb2, **sd_np(layer))
+
+    for tag, cfg, sizes in (
+        ("small", dict(node_features=40, hidden_dims=[64, 48, 32], num_diffusion_steps=10, attention_heads=2), (24, 40)),
+        ("base", dict(node_features=768, hidden_dims=[512, 256, 128], num_diffusion_steps=10, attention_heads=8), (24, 40)),
+    ):
+        torch.manual_seed(270)
+        m = build_repaired_model(ref, cfg).eval()
+        if tag == "base":
+            # weights come from the oracle's seeded initialiser so the 28 MB state_dict need not be stored
+            from . import dgdm_oracle as O
+            ocfg = O.OracleConfig(**cfg)
+            P = O.init_params(ocfg, seed=7, perturb=0.05)
+            inv = {}
+            for k in m.state_dict():
+                inv[repaired_state_to_oracle_keys({k: 0}).popitem()[0]] = k
+            sd = {inv[k]: v for k, v in P.items()}
+            missing = m.load_state_dict(sd, strict=False)
+            assert not missing.unexpected_keys and not missing.missing_keys, missing
+        else:
+            randomize_(m, 273, 0.05)
+        data = small_batch(ref, sizes, cfg["node_features"], 2740)
+        ntot, C = data.x.size(0), cfg["hidden_dims"][-1]
+        g = torch.Generator().manual_seed(275)
+        timesteps = torch.tensor([3, 8])
+        noise = [torch.randn(s, C, generator=g) for s in sizes]
+        target = [torch.randn(s, C, generator=g) for s in sizes]
+        rl = [t for pair in zip(noise, target) for t in pair]  # per graph: diffusion noise, then loss target
+        mask_idx = torch.randperm(ntot, generator=g)
+        mask_tok = torch.randn(cfg["node_features"], generator=g)
+
+        # (1) inference forward with embeddings + attention
+        out_inf = m(data, mode="inference", return_attention=True, return_embeddings=True)
+        # (2) pretrain_step with every draw injected
+        with injected_rng(randperm=[mask_idx], randn=[mask_tok], randint=[timesteps], randn_like=rl):
+            out_pre = m.pretrain_step(data, mask_ratio=0.15)
+        named = dict(m.named_parameters())
+        watch = ["feature_encoder.encoder.0.weight", "graph_encoder.graph_layers.0.graph_conv1.node_lin.weight",
+                 "graph_encoder.graph_layers.1.layer.graph_conv2.edge_lin.weight", "graph_encoder.graph_layers.1.proj.weight",
+                 "spatial_attention.attention.k_proj.weight", "hierarchical_processor.down_convs.2.graph_conv1.node_lin.weight",
+                 "hierarchical_processor.pools.0.score_net.0.weight", "hierarchical_processor.up_convs.1.output_proj.weight",
+                 "diffusion_layer.denoise_net.0.weight", "diffusion_layer.time_embed.0.weight", "graph_encoder.norm_layers.2.weight"]
+        gl = torch.autograd.grad(out_pre["total_pretrain_loss"], [named[k] for k in watch], allow_unused=True)
+        arrays = dict(x=data.x, edge_index=data.edge_index, edge_attr=data.edge_attr, pos=data.pos, batch=data.batch,
+                      timesteps=timesteps, noise=torch.cat(noise), noise_target=torch.cat(target),
+                      mask_indices=mask_idx[:int(ntot * 0.15)], mask_token=mask_tok,
+                      inf_graph_embedding=out_inf["graph_embedding"], inf_node_embeddings=out_inf["node_embeddings"],
+                      inf_attn0=out_inf["attention_weights"][0], inf_attn1=out_inf["attention_weights"][1],
+                      pre_diffusion_loss=out_pre["diffusion_loss"], pre_graph_embedding=out_pre["graph_embedding"],
+                      pre_noisy_embeddings=out_pre["noisy_embeddings"], cfg_json=np.array(__import__("json").dumps(cfg)))
+        for k, gk in zip(watch, gl):
+            ok = repaired_state_to_oracle_keys({k: 0}).popitem()[0]
+            if tag == "base":  # keep the fixture small: a checksum-like slice + norm
+                arrays["gradnorm." + ok] = gk.norm(); arrays["gradslice." + ok] = gk.flatten()[:256]
+            else:
+                arrays["grad." + ok] = gk
+        if tag == "small":
+            arrays.update({"w." + k: v for k, v in repaired_state_to_oracle_keys(sd_np(m, "")).items()
+                           if "pos_encoding" not in k})
+        else:
+            arrays["init_seed"] = 7; arrays["init_perturb"] = 0.05
+        save(f"g7_model_{tag}", **arrays)
+
+
+def main():
+    assert os.path.isdir(REF_ROOT), "golden capture needs /root/reference (dev container only)"
+    torch.set_num_threads(4)
+    ref = load_reference()
+    print("reference modules loaded from", REF_ROOT)
+    g1_scheduler(ref); g2_graph_conv(ref); g2b_plain_encoder(ref); g4_attention(ref)
+    g5_diffusion(ref); g6_small_modules(ref); g7_repaired(ref)
+
+
+if __name__ == "__main__":
+    main()
