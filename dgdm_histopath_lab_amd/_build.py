@@ -1,0 +1,76 @@
+"""Builds libdgdm_hip.so (hipcc, --offload-arch=gfx950) in-tree from csrc/*.hip.
+
+Cross-compiles without a GPU.  The .so is git-ignored but travels to the GPU box with the
+gpurun snapshot.  ``python -m dgdm_histopath_lab_amd._build`` or ``__graft_entry__.build()``.
+"""
+from __future__ import annotations
+
+import concurrent.futures as cf
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+LIB_DIR = os.path.join(PKG, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libdgdm_hip.so")
+FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
+         "-I", os.path.join(ROOT, "include"), "-I", CSRC]
+
+
+def _hipcc() -> str:
+    cand = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(cand):
+        raise RuntimeError("hipcc not found (need ROCm to build libdgdm_hip.so)")
+    return cand
+
+
+def _sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _digest() -> str:
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for root in (CSRC, os.path.join(ROOT, "include")):
+        for f in sorted(os.listdir(root)):
+            if f.endswith((".hip", ".hpp", ".h")):
+                h.update(f.encode()); h.update(open(os.path.join(root, f), "rb").read())
+    return h.hexdigest()
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    os.makedirs(LIB_DIR, exist_ok=True)
+    stamp = os.path.join(LIB_DIR, "build.sha256")
+    dig = _digest()
+    if not force and os.path.exists(LIB_PATH) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
+        return LIB_PATH
+    hipcc = _hipcc()
+    objdir = os.path.join(LIB_DIR, "obj")
+    os.makedirs(objdir, exist_ok=True)
+
+    def compile_one(src):
+        obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
+        cmd = [hipcc, *FLAGS, "-c", src, "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
+        if verbose and r.stderr.strip():
+            print(r.stderr, file=sys.stderr)
+        return obj
+
+    with cf.ThreadPoolExecutor(max_workers=4) as ex:
+        objs = list(ex.map(compile_one, _sources()))
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH, *objs], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    open(stamp, "w").write(dig)
+    if verbose:
+        print(f"built {LIB_PATH}")
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

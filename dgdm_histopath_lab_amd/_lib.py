@@ -1,0 +1,83 @@
+"""ctypes binding of libdgdm_hip.so (the C ABI declared in include/dgdm_hip.h).
+
+There is no CPU fallback: every op in this package goes through this library and raises
+``DGDMKernelError`` if it is missing or if a kernel reports an error.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libdgdm_hip.so")
+
+
+class DGDMKernelError(RuntimeError):
+    """Raised when libdgdm_hip.so is unavailable or a kernel entry point fails."""
+
+
+_i32, _i64, _sz, _p = C.c_int32, C.c_int64, C.c_size_t, C.c_void_p
+
+# name -> (restype, argtypes); mirrors include/dgdm_hip.h (tests check the two stay in sync)
+SIGNATURES = {
+    "dgdm_abi_version": (C.c_int, []),
+    "dgdm_error_string": (C.c_char_p, [C.c_int]),
+    "dgdm_csr_build_workspace_bytes": (_sz, [_i64, _i32, _i32]),
+    "dgdm_csr_build": (C.c_int, [_p, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _sz, _p]),
+    "dgdm_gcn_dinv": (C.c_int, [_p, _i32, _p, _p]),
+    "dgdm_csr_edge_weights": (C.c_int, [_p, _p, _p, _i32, _p, _p]),
+    "dgdm_spmm": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _p, _i64, _i32, _i32, _p, _i32, _p]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load(build_if_missing: bool = False) -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        if build_if_missing:
+            from . import _build
+            _build.build()
+        else:
+            raise DGDMKernelError(
+                f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
+                "Build it with `python -m dgdm_histopath_lab_amd._build`.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # e.g. missing libamdhip64
+        raise DGDMKernelError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise DGDMKernelError(f"{LIB_PATH} does not export {name}; rebuild the extension") from e
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        msg = load().dgdm_error_string(code).decode()
+        raise DGDMKernelError(f"{what} failed: {msg} (code {code})")
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr(device=None) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def require_cuda(*tensors: Optional[torch.Tensor]) -> None:
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise DGDMKernelError("dgdm_histopath_lab_amd ops run on the GPU only (HIP kernels, no CPU fallback); "
+                                  f"got a tensor on {t.device}")

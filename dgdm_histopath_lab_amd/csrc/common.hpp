@@ -1,0 +1,37 @@
+// Shared host/device helpers for libdgdm_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "dgdm_hip.h"
+
+#define DGDM_WAVE 64
+
+#define DGDM_REQUIRE(cond)                      \
+  do {                                          \
+    if (!(cond)) return DGDM_ERR_INVALID_ARG;   \
+  } while (0)
+
+static inline int dgdm_launch_status() {
+  return hipGetLastError() == hipSuccess ? DGDM_OK : DGDM_ERR_LAUNCH;
+}
+
+static inline size_t dgdm_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+static inline bool dgdm_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+__device__ __forceinline__ float4 f4_fma(float s, const float4 v, float4 a) {
+  a.x = fmaf(s, v.x, a.x); a.y = fmaf(s, v.y, a.y); a.z = fmaf(s, v.z, a.z); a.w = fmaf(s, v.w, a.w);
+  return a;
+}
+
+// wave64 reductions over the full wave (xor butterflies; result in every lane)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}

@@ -1,0 +1,223 @@
+// K1: edge list -> CSR (stable by edge id), GCN normalisation.  Integer work, bit-exact vs
+// oracle/csr_oracle.py.  Replaces core/graph_layers.py:76-84 index preparation.
+//
+// Pipeline (all on the caller's stream, no host sync):
+//   memset counts -> count keys (int atomics: order-free, exact) -> exclusive scan (+1 per row
+//   when loops are appended) -> unordered fill of a scratch CSR (atomic cursor) -> rank pass:
+//   every scratch entry counts the entries of its row with a smaller edge id and is written to
+//   that rank, which yields the stable (ascending edge id) order deterministically.
+// The self-loop entry of row i has the largest edge id of the row (E+i), so it is written
+// straight to the last slot and takes no part in the rank pass.
+#include "common.hpp"
+
+namespace {
+
+constexpr int SCAN_BLOCK = 1024;  // threads; one item per thread
+
+__global__ void k_count(const int64_t* __restrict__ keys, int64_t E, int32_t* __restrict__ cnt) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < E; i += stride) atomicAdd(&cnt[keys[i]], 1);
+}
+
+__device__ __forceinline__ int block_exclusive_scan(int v, int* total) {
+  // 1024 threads = 16 waves; wave-level inclusive scan then scan of wave totals in LDS
+  __shared__ int wsum[16];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) wsum[wid] = inc;
+  __syncthreads();
+  if (wid == 0) {
+    int s = lane < 16 ? wsum[lane] : 0;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+      int t = __shfl_up(s, o, 64);
+      if (lane >= o) s += t;
+    }
+    if (lane < 16) wsum[lane] = s;  // inclusive over waves
+  }
+  __syncthreads();
+  const int base = wid ? wsum[wid - 1] : 0;
+  *total = wsum[15];
+  __syncthreads();
+  return base + inc - v;
+}
+
+// pass 1: per-block totals of (cnt[i] + extra)
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_block_totals(const int32_t* __restrict__ cnt, int32_t N, int extra,
+                                                                  int32_t* __restrict__ block_tot) {
+  const int i = blockIdx.x * SCAN_BLOCK + threadIdx.x;
+  int v = i < N ? cnt[i] + extra : 0, tot;
+  block_exclusive_scan(v, &tot);
+  if (threadIdx.x == 0) block_tot[blockIdx.x] = tot;
+}
+
+// pass 2: one block scans the block totals in place (exclusive), chunk by chunk
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_totals(int32_t* __restrict__ block_tot, int nblocks) {
+  int carry = 0;
+  for (int base = 0; base < nblocks; base += SCAN_BLOCK) {
+    const int i = base + threadIdx.x;
+    int v = i < nblocks ? block_tot[i] : 0, tot;
+    int ex = block_exclusive_scan(v, &tot);
+    if (i < nblocks) block_tot[i] = carry + ex;
+    carry += tot;
+  }
+}
+
+// pass 3: rowptr[i] = block offset + in-block exclusive scan; rowptr[N] = total
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_write(const int32_t* __restrict__ cnt, int32_t N, int extra,
+                                                           const int32_t* __restrict__ block_tot, int32_t* __restrict__ rowptr) {
+  const int i = blockIdx.x * SCAN_BLOCK + threadIdx.x;
+  int v = i < N ? cnt[i] + extra : 0, tot;
+  int ex = block_exclusive_scan(v, &tot) + block_tot[blockIdx.x];
+  if (i < N) rowptr[i] = ex;
+  if (i == N - 1) rowptr[N] = ex + v;
+}
+
+__global__ void k_fill(const int64_t* __restrict__ keys, const int64_t* __restrict__ vals, int64_t E,
+                       const int32_t* __restrict__ rowptr, int32_t* __restrict__ cursor,
+                       int32_t* __restrict__ tcol, int32_t* __restrict__ teid) {
+  int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; e < E; e += stride) {
+    const int32_t k = (int32_t)keys[e];
+    const int32_t slot = rowptr[k] + atomicAdd(&cursor[k], 1);
+    tcol[slot] = (int32_t)vals[e];
+    teid[slot] = (int32_t)e;
+  }
+}
+
+// one thread per row: places the row's loop entry (if any) and ranks the scratch entries.
+// rows are short on tissue graphs (kNN, degree ~ 5-16); a long row costs O(deg^2) reads from L2.
+__global__ void k_rank(const int32_t* __restrict__ rowptr, int32_t N, int32_t E32, int add_loops,
+                       const int32_t* __restrict__ tcol, const int32_t* __restrict__ teid,
+                       int32_t* __restrict__ col, int32_t* __restrict__ eid) {
+  // thread per scratch entry would need the entry's row; instead a wave cooperates on rows:
+  // lane l of a wave takes entries l, l+64, ... of the row and counts smaller ids.
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (int r = wave; r < N; r += nwaves) {
+    const int s = rowptr[r];
+    const int n = rowptr[r + 1] - s - (add_loops ? 1 : 0);  // non-loop entries
+    for (int i = lane; i < n; i += 64) {
+      const int my = teid[s + i];
+      int rank = 0;
+      for (int j = 0; j < n; ++j) rank += (teid[s + j] < my) ? 1 : 0;
+      col[s + rank] = tcol[s + i];
+      eid[s + rank] = my;
+    }
+    if (add_loops && lane == 0) {
+      col[s + n] = r;
+      eid[s + n] = E32 + r;
+    }
+  }
+}
+
+__global__ void k_dinv(const int32_t* __restrict__ rowptr, int32_t N, float* __restrict__ dinv) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) {
+    const float deg = (float)(rowptr[i + 1] - rowptr[i]);
+    dinv[i] = deg > 0.f ? 1.0f / sqrtf(deg) : 0.f;  // deg^-1/2, inf -> 0 (graph_layers.py:82-83)
+  }
+}
+
+__global__ void k_edge_weights(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                               const float* __restrict__ dinv, int32_t N, float* __restrict__ w) {
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (int r = wave; r < N; r += nwaves) {
+    const int s = rowptr[r], e = rowptr[r + 1];
+    const float dr = dinv[r];
+    for (int p = s + lane; p < e; p += 64) w[p] = dinv[col[p]] * dr;
+  }
+}
+
+struct Workspace {
+  int32_t *cnt, *cursor, *block_tot, *tcol, *teid;
+  size_t bytes;
+};
+
+Workspace carve(void* base, int64_t E, int32_t N, int32_t add_loops) {
+  Workspace w;
+  const size_t n_entries = (size_t)E + (add_loops ? (size_t)N : 0);
+  const size_t nblk = ((size_t)N + SCAN_BLOCK - 1) / SCAN_BLOCK + 1;
+  char* p = static_cast<char*>(base);
+  size_t off = 0;
+  auto take = [&](size_t count) {
+    int32_t* r = reinterpret_cast<int32_t*>(p + off);
+    off += dgdm_align_up(count * sizeof(int32_t), 256);
+    return r;
+  };
+  w.cnt = take(N);
+  w.cursor = take(N);
+  w.block_tot = take(nblk);
+  w.tcol = take(n_entries);
+  w.teid = take(n_entries);
+  w.bytes = off;
+  return w;
+}
+
+}  // namespace
+
+extern "C" size_t dgdm_csr_build_workspace_bytes(int64_t E, int32_t N, int32_t add_loops) {
+  if (E < 0 || N < 0) return 0;
+  return carve(nullptr, E, N, add_loops).bytes;
+}
+
+extern "C" int dgdm_csr_build(const int64_t* edge_index, int64_t E, int32_t N, int32_t add_loops, int32_t by_src,
+                              int32_t* rowptr, int32_t* col, int32_t* eid,
+                              void* workspace, size_t workspace_bytes, void* stream_) {
+  DGDM_REQUIRE(E >= 0 && N >= 0 && rowptr);
+  DGDM_REQUIRE(E == 0 || edge_index);
+  const int64_t n_entries = E + (add_loops ? N : 0);
+  DGDM_REQUIRE(n_entries == 0 || (col && eid));
+  if (n_entries > 0x7fffffffLL) return DGDM_ERR_UNSUPPORTED;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (N == 0) {
+    (void)hipMemsetAsync(rowptr, 0, sizeof(int32_t), stream);
+    return dgdm_launch_status();
+  }
+  DGDM_REQUIRE(workspace);
+  Workspace w = carve(workspace, E, N, add_loops);
+  if (workspace_bytes < w.bytes) return DGDM_ERR_WORKSPACE;
+  const int64_t* keys = edge_index + (by_src ? 0 : E);
+  const int64_t* vals = edge_index + (by_src ? E : 0);
+  const int extra = add_loops ? 1 : 0;
+  const int nblk = (N + SCAN_BLOCK - 1) / SCAN_BLOCK;
+  // cnt and cursor are adjacent (both 256-B padded): one memset
+  (void)hipMemsetAsync(w.cnt, 0, (size_t)((char*)w.block_tot - (char*)w.cnt), stream);
+  const int eb = (int)((E + 255) / 256 < 4096 ? (E + 255) / 256 : 4096);
+  if (E > 0) hipLaunchKernelGGL(k_count, dim3(eb), dim3(256), 0, stream, keys, E, w.cnt);
+  hipLaunchKernelGGL(k_scan_block_totals, dim3(nblk), dim3(SCAN_BLOCK), 0, stream, w.cnt, N, extra, w.block_tot);
+  hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(SCAN_BLOCK), 0, stream, w.block_tot, nblk);
+  hipLaunchKernelGGL(k_scan_write, dim3(nblk), dim3(SCAN_BLOCK), 0, stream, w.cnt, N, extra, w.block_tot, rowptr);
+  if (E > 0) hipLaunchKernelGGL(k_fill, dim3(eb), dim3(256), 0, stream, keys, vals, E, rowptr, w.cursor, w.tcol, w.teid);
+  if (n_entries > 0) {
+    const int rb = (N + 3) / 4 < 8192 ? (N + 3) / 4 : 8192;  // 4 waves per block, one row per wave
+    hipLaunchKernelGGL(k_rank, dim3(rb), dim3(256), 0, stream, rowptr, N, (int32_t)E, extra, w.tcol, w.teid, col, eid);
+  }
+  return dgdm_launch_status();
+}
+
+extern "C" int dgdm_gcn_dinv(const int32_t* rowptr_dst, int32_t N, float* dinv, void* stream) {
+  DGDM_REQUIRE(N >= 0);
+  if (N == 0) return DGDM_OK;
+  DGDM_REQUIRE(rowptr_dst && dinv);
+  hipLaunchKernelGGL(k_dinv, dim3((N + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), rowptr_dst, N, dinv);
+  return dgdm_launch_status();
+}
+
+extern "C" int dgdm_csr_edge_weights(const int32_t* rowptr, const int32_t* col, const float* dinv, int32_t N,
+                                     float* w, void* stream) {
+  DGDM_REQUIRE(N >= 0);
+  if (N == 0) return DGDM_OK;
+  DGDM_REQUIRE(rowptr && col && dinv && w);
+  const int rb = (N + 3) / 4 < 8192 ? (N + 3) / 4 : 8192;
+  hipLaunchKernelGGL(k_edge_weights, dim3(rb), dim3(256), 0, static_cast<hipStream_t>(stream), rowptr, col, dinv, N, w);
+  return dgdm_launch_status();
+}

@@ -1,0 +1,120 @@
+// K2: CSR segmented gather-reduce  Y[r,:] = sum_{p in row r} w[p] * X[col[p],:] (+ bias).
+// Replaces MessagePassing.propagate's gather / norm-scale / scatter-add
+// (core/graph_layers.py:92,99-110).  HBM/L2-bandwidth bound: 16 B per lane coalesced row reads,
+// UNROLL source rows in flight per lane group, no atomics (a lane group owns its output row and
+// adds the entries in CSR order => bitwise reproducible).
+//
+// Geometry: a row of C floats is covered by LPR lanes x R float4 per lane (C = 4*LPR*R for the
+// exact fits; a tail predicate handles other C % 4 == 0 widths).  LPR < 64 packs 64/LPR rows
+// into one wavefront so narrow rows (C = 32, 128) still issue full 1-KiB wave loads.
+#include "common.hpp"
+
+namespace {
+
+template <int LPR, int R, int UNROLL>
+__global__ __launch_bounds__(256) void k_spmm(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                              const float* __restrict__ w, const float* __restrict__ X, int64_t ldx,
+                                              int32_t table_rows, float* __restrict__ Y, int64_t ldy, int32_t N, int32_t C,
+                                              const float* __restrict__ bias, int accumulate) {
+  constexpr int RPW = 64 / LPR;                 // rows per wave
+  const int lane = threadIdx.x & 63;
+  const int sub = lane / LPR, lir = lane % LPR;  // which row of the wave, lane inside the row
+  const int wave_global = (blockIdx.x * (blockDim.x >> 6)) + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * (blockDim.x >> 6);
+  const int c4 = C >> 2;                        // float4 per row
+
+  for (int row0 = wave_global * RPW; row0 < N; row0 += nwaves * RPW) {
+    const int row = row0 + sub;
+    if (row >= N) continue;
+    const int start = rowptr[row], end = rowptr[row + 1];
+    float4 acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    for (int p = start; p < end; p += UNROLL) {
+      int cc[UNROLL];
+      float ww[UNROLL];
+#pragma unroll
+      for (int j = 0; j < UNROLL; ++j) {
+        const int q = p + j < end ? p + j : end - 1;  // clamp: tail entries get weight 0
+        const int c = col[q];
+        const bool ok = (p + j < end) && (c < table_rows);
+        cc[j] = ok ? c : 0;
+        ww[j] = ok ? w[q] : 0.f;
+      }
+      float4 v[UNROLL][R];
+#pragma unroll
+      for (int j = 0; j < UNROLL; ++j) {
+        const float4* src = reinterpret_cast<const float4*>(X + (int64_t)cc[j] * ldx);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int k = lir + r * LPR;
+          v[j][r] = (k < c4) ? src[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < UNROLL; ++j)
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = f4_fma(ww[j], v[j][r], acc[r]);
+    }
+
+    float4* dst = reinterpret_cast<float4*>(Y + (int64_t)row * ldy);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int k = lir + r * LPR;
+      if (k < c4) {
+        float4 o = acc[r];
+        if (bias) {
+          const float4 b = reinterpret_cast<const float4*>(bias)[k];
+          o.x += b.x; o.y += b.y; o.z += b.z; o.w += b.w;
+        }
+        if (accumulate) {
+          const float4 y0 = dst[k];
+          o.x += y0.x; o.y += y0.y; o.z += y0.z; o.w += y0.w;
+        }
+        dst[k] = o;
+      }
+    }
+  }
+}
+
+template <int LPR, int R, int UNROLL>
+int launch(const int32_t* rowptr, const int32_t* col, const float* w, const float* X, int64_t ldx, int32_t table_rows,
+           float* Y, int64_t ldy, int32_t N, int32_t C, const float* bias, int accumulate, hipStream_t stream) {
+  constexpr int RPW = 64 / LPR;
+  const int64_t waves = ((int64_t)N + RPW - 1) / RPW;
+  int64_t blocks = (waves + 3) / 4;
+  if (blocks > 256 * 64) blocks = 256 * 64;  // grid-stride beyond that
+  hipLaunchKernelGGL((k_spmm<LPR, R, UNROLL>), dim3((unsigned)blocks), dim3(256), 0, stream, rowptr, col, w, X, ldx,
+                     table_rows, Y, ldy, N, C, bias, accumulate);
+  return dgdm_launch_status();
+}
+
+}  // namespace
+
+extern "C" int dgdm_spmm(const int32_t* rowptr, const int32_t* col, const float* w, const float* X, int64_t ldx,
+                         int32_t table_rows, float* Y, int64_t ldy, int32_t N, int32_t C, const float* bias,
+                         int32_t accumulate, void* stream_) {
+  DGDM_REQUIRE(N >= 0 && C > 0 && table_rows >= 0);
+  if (N == 0) return DGDM_OK;
+  DGDM_REQUIRE(rowptr && col && w && Y);
+  DGDM_REQUIRE(table_rows == 0 || X);
+  if ((C & 3) || C > 1024 || (ldx & 3) || (ldy & 3) || ldx < C || ldy < C) return DGDM_ERR_UNSUPPORTED;
+  if (!dgdm_aligned16(X) || !dgdm_aligned16(Y) || (bias && !dgdm_aligned16(bias))) return DGDM_ERR_UNSUPPORTED;
+  hipStream_t s = static_cast<hipStream_t>(stream_);
+  if (table_rows == 0) {  // nothing to gather: Y = 0 (or unchanged when accumulating)
+    if (bias) return DGDM_ERR_UNSUPPORTED;
+    if (!accumulate) (void)hipMemset2DAsync(Y, (size_t)ldy * sizeof(float), 0, (size_t)C * sizeof(float), (size_t)N, s);
+    return dgdm_launch_status();
+  }
+  const int c4 = C >> 2;
+#define GO(LPR, R, U) return launch<LPR, R, U>(rowptr, col, w, X, ldx, table_rows, Y, ldy, N, C, bias, accumulate, s)
+  if (c4 <= 8) GO(8, 1, 4);
+  if (c4 <= 16) GO(16, 1, 4);
+  if (c4 <= 32) GO(32, 1, 4);
+  if (c4 <= 64) GO(64, 1, 4);
+  if (c4 <= 128) GO(64, 2, 4);
+  if (c4 <= 192) GO(64, 3, 4);
+  GO(64, 4, 2);
+#undef GO
+}

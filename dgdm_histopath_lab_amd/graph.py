@@ -1,0 +1,145 @@
+"""Graph containers for the DGDM hot path.
+
+``GraphData`` / ``GraphBatch`` reproduce the batch layout the reference's data pipeline hands
+to ``DGDMModel.forward`` (torch_geometric ``Data`` / ``Batch.from_data_list``, used at
+data/datamodule.py:9,173 and tests/test_basic.py:238-255): node tensors concatenated, every
+graph's ``edge_index`` offset by the number of nodes before it, a sorted ``batch`` vector and
+``ptr`` offsets.  The model duck-types its input, so a real PyG ``Batch`` works as well.
+
+``GraphStructure`` is the device-side index set one (batched) edge list needs: CSR by
+destination (forward aggregation), CSR by source (backward), GCN weights -- built once per
+batch by the K1 kernels and reused by every graph convolution and its backward.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib
+
+
+class GraphData:
+    """One tissue graph: x [N,F], edge_index [2,E] int64 (row 0 = source, row 1 = destination),
+    optional edge_attr [E,32], pos [N,2], y."""
+
+    _fields = ("x", "edge_index", "edge_attr", "pos", "y", "batch", "ptr")
+
+    def __init__(self, x=None, edge_index=None, edge_attr=None, pos=None, y=None, **extra):
+        self.x, self.edge_index, self.edge_attr, self.pos, self.y = x, edge_index, edge_attr, pos, y
+        self.batch = None
+        self.ptr = None
+        for k, v in extra.items():
+            setattr(self, k, v)
+
+    @property
+    def num_nodes(self) -> int:
+        return 0 if self.x is None else self.x.size(0)
+
+    @property
+    def num_edges(self) -> int:
+        return 0 if self.edge_index is None else self.edge_index.size(1)
+
+    @property
+    def num_graphs(self) -> int:
+        return 1 if self.ptr is None else len(self.ptr) - 1
+
+    def _apply(self, fn):
+        out = self.__class__.__new__(self.__class__)
+        for k, v in self.__dict__.items():
+            setattr(out, k, fn(v) if isinstance(v, torch.Tensor) else v)
+        return out
+
+    def clone(self):
+        return self._apply(lambda t: t.clone())
+
+    def to(self, device, non_blocking: bool = False):
+        return self._apply(lambda t: t.to(device, non_blocking=non_blocking))
+
+    def pin_memory(self):
+        return self._apply(lambda t: t.pin_memory())
+
+
+class GraphBatch(GraphData):
+    """Block-diagonal batch of graphs (PyG collation rule)."""
+
+    @classmethod
+    def from_data_list(cls, graphs: Sequence[GraphData]) -> "GraphBatch":
+        if len(graphs) == 0:
+            raise ValueError("cannot batch an empty list of graphs")
+        xs, eis, eas, poss, ys, bvec, ptr = [], [], [], [], [], [], [0]
+        for g, d in enumerate(graphs):
+            n = d.x.size(0)
+            xs.append(d.x)
+            eis.append(d.edge_index + ptr[-1])
+            if d.edge_attr is not None:
+                eas.append(d.edge_attr)
+            if d.pos is not None:
+                poss.append(d.pos)
+            if getattr(d, "y", None) is not None:
+                ys.append(d.y.reshape(1, -1) if d.y.dim() <= 1 else d.y)
+            bvec.append(torch.full((n,), g, dtype=torch.long, device=d.x.device))
+            ptr.append(ptr[-1] + n)
+        for name, lst in (("edge_attr", eas), ("pos", poss)):
+            if lst and len(lst) != len(graphs):
+                raise ValueError(f"either every graph or no graph of a batch may carry {name}")
+        out = cls(x=torch.cat(xs), edge_index=torch.cat(eis, dim=1),
+                  edge_attr=torch.cat(eas) if eas else None, pos=torch.cat(poss) if poss else None,
+                  y=torch.cat(ys) if ys else None)
+        out.batch = torch.cat(bvec)
+        out.ptr = ptr  # host-side python ints: the per-graph node offsets
+        return out
+
+
+def graph_ptr(data, num_nodes: int) -> List[int]:
+    """Per-graph node offsets [B+1] as host ints.  Uses ``data.ptr`` when the batch carries it
+    (no device sync); otherwise derives it from the sorted ``batch`` vector (one sync, once per
+    batch -- the reference syncs B times per stage, dgdm_model.py:342,410,604).  ``batch=None``
+    means a single graph (repair R4)."""
+    ptr = getattr(data, "ptr", None)
+    if ptr is not None:
+        return [int(v) for v in (ptr.tolist() if isinstance(ptr, torch.Tensor) else ptr)]
+    batch = getattr(data, "batch", None)
+    if batch is None:
+        return [0, num_nodes]
+    counts = torch.bincount(batch)
+    return [0] + torch.cumsum(counts, 0).tolist()
+
+
+class GraphStructure:
+    """Device CSR/CSC + GCN weights of one edge list over ``num_nodes`` nodes (self loops added)."""
+
+    __slots__ = ("num_nodes", "num_edges", "num_entries", "rowptr", "col", "eid", "w",
+                 "rowptr_t", "col_t", "eid_t", "w_t", "dinv")
+
+    def __init__(self, edge_index: torch.Tensor, num_nodes: int, add_loops: bool = True):
+        _lib.require_cuda(edge_index)
+        lib = _lib.load()
+        if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.size(0) != 2:
+            raise ValueError(f"edge_index must be int64 [2,E], got {edge_index.dtype} {tuple(edge_index.shape)}")
+        ei = edge_index.contiguous()
+        dev = ei.device
+        E, N = ei.size(1), int(num_nodes)
+        n_ent = E + (N if add_loops else 0)
+        self.num_nodes, self.num_edges, self.num_entries = N, E, n_ent
+        i32 = dict(dtype=torch.int32, device=dev)
+        ws_bytes = lib.dgdm_csr_build_workspace_bytes(E, N, int(add_loops))
+        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+        st = _lib.stream_ptr(dev)
+        outs = []
+        for by_src in (0, 1):
+            rowptr = torch.empty(N + 1, **i32)
+            col = torch.empty(n_ent, **i32)
+            eid = torch.empty(n_ent, **i32)
+            _lib.check(lib.dgdm_csr_build(ei.data_ptr(), E, N, int(add_loops), by_src, rowptr.data_ptr(), col.data_ptr(),
+                                          eid.data_ptr(), ws.data_ptr(), ws_bytes, st), "dgdm_csr_build")
+            outs.append((rowptr, col, eid))
+        (self.rowptr, self.col, self.eid), (self.rowptr_t, self.col_t, self.eid_t) = outs
+        self.dinv = torch.empty(N, dtype=torch.float32, device=dev)
+        _lib.check(lib.dgdm_gcn_dinv(self.rowptr.data_ptr(), N, self.dinv.data_ptr(), st), "dgdm_gcn_dinv")
+        self.w = torch.empty(n_ent, dtype=torch.float32, device=dev)
+        self.w_t = torch.empty(n_ent, dtype=torch.float32, device=dev)
+        _lib.check(lib.dgdm_csr_edge_weights(self.rowptr.data_ptr(), self.col.data_ptr(), self.dinv.data_ptr(), N,
+                                             self.w.data_ptr(), st), "dgdm_csr_edge_weights")
+        _lib.check(lib.dgdm_csr_edge_weights(self.rowptr_t.data_ptr(), self.col_t.data_ptr(), self.dinv.data_ptr(), N,
+                                             self.w_t.data_ptr(), st), "dgdm_csr_edge_weights")

@@ -1,0 +1,70 @@
+"""Python wrappers (torch.autograd.Function) over the C ABI of libdgdm_hip.so.
+
+Every function here launches hand-written HIP kernels on the current torch stream through
+ctypes; tensors only provide device memory.  No CPU path exists.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+from .graph import GraphStructure
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        raise _lib.DGDMKernelError(f"HIP kernels compute in fp32, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ----------------------------------------------------------------------------- K2 SpMM
+def spmm_raw(rowptr, col, w, X, num_rows: int, *, table_rows: Optional[int] = None, out: Optional[torch.Tensor] = None,
+             bias: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+    """Y[r] = sum_p w[p] X[col[p]] (+bias): dgdm_spmm.  X may be a column-strided view
+    (row stride multiple of 4 floats); ``out`` likewise."""
+    _lib.require_cuda(X, rowptr, col, w)
+    lib = _lib.load()
+    if X.dim() != 2 or X.stride(1) != 1:
+        X = _f32c(X)
+    C = X.size(1)
+    if out is None:
+        out = torch.empty(num_rows, C, dtype=torch.float32, device=X.device)
+    assert out.stride(1) == 1 and out.size(1) == C and out.size(0) == num_rows
+    tr = X.size(0) if table_rows is None else table_rows
+    _lib.check(lib.dgdm_spmm(rowptr.data_ptr(), col.data_ptr(), w.data_ptr(), X.data_ptr() if X.numel() else None, X.stride(0) if X.size(0) > 1 else max(C, X.stride(0)), tr,
+                             out.data_ptr(), out.stride(0) if out.size(0) > 1 else max(C, out.stride(0)), num_rows, C, _lib.ptr(bias), int(accumulate),
+                             _lib.stream_ptr(X.device)), "dgdm_spmm")
+    return out
+
+
+class _Aggregate(torch.autograd.Function):
+    """Y = A_hat X with A_hat the GCN-normalised adjacency incl. self loops
+    (core/graph_layers.py:76-110); backward is the same kernel on the by-source CSR."""
+
+    @staticmethod
+    def forward(ctx, x, gs: GraphStructure, out):
+        ctx.gs = gs
+        return spmm_raw(gs.rowptr, gs.col, gs.w, x, gs.num_nodes, out=out)
+
+    @staticmethod
+    def backward(ctx, gy):
+        gs = ctx.gs
+        return spmm_raw(gs.rowptr_t, gs.col_t, gs.w_t, _f32c(gy), gs.num_nodes), None, None
+
+
+def aggregate(x: torch.Tensor, gs: GraphStructure, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    return _Aggregate.apply(x, gs, out)
+
+
+def aggregate_edge_attr(edge_attr: Optional[torch.Tensor], gs: GraphStructure) -> torch.Tensor:
+    """EA_hat[d] = sum_{e -> d} norm_e * edge_attr[e]  ([N, edge_dim]); the appended self-loop
+    entries carry a zero attribute row (repair R1) and ``edge_attr=None`` means zeros
+    (models/encoders.py:258-261).  Because ``edge_lin`` has no bias (graph_layers.py:49) the
+    per-edge term of GraphConvolution.message equals ``EA_hat @ W_e^T`` -- one 32-wide
+    aggregation per graph structure instead of an [E', C] intermediate per convolution."""
+    if edge_attr is None:
+        return None
+    ea = _f32c(edge_attr)
+    return spmm_raw(gs.rowptr, gs.eid, gs.w, ea, gs.num_nodes, table_rows=gs.num_edges)

@@ -1,0 +1,94 @@
+/*
+ * dgdm_hip.h -- C ABI of libdgdm_hip.so: the MI355X (gfx950) kernels under the DGDM hot path.
+ *
+ * The reference (danieleschmidt/dgdm-histopath-lab) has no FFI layer: its boundary is the Python
+ * class DGDMModel (models/dgdm_model.py:37) and every device kernel it runs comes from
+ * torch / torch-geometric.  This library is the build's own layer *below* that class; each entry
+ * point cites the reference code whose arithmetic it replaces.  INTEGRATION.md shows the ctypes
+ * binding a maintainer of the reference would add.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers to DEVICE memory (hipMalloc'ed or torch CUDA tensors), sizes as integers,
+ *     trailing `void* stream` = hipStream_t (NULL = default stream);
+ *   - returns DGDM_OK (0) or a negative DGDM_ERR_* code; never allocates, never synchronises,
+ *     no global state: re-entrant per stream; scratch memory is passed in by the caller and its
+ *     size is given by the matching *_workspace_bytes() query;
+ *   - float data is fp32 row-major; node/edge ids inside CSR structures are int32; the edge list
+ *     at the boundary is int64 [2,E] exactly as the reference holds it (graph_layers.py:77-81);
+ *   - arguments are checked on the host (null pointers, negative sizes, unsupported widths) before
+ *     any launch.
+ */
+#ifndef DGDM_HIP_H
+#define DGDM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DGDM_API __attribute__((visibility("default")))
+
+enum {
+  DGDM_OK = 0,
+  DGDM_ERR_INVALID_ARG = -1,   /* null pointer, negative size, bad enum */
+  DGDM_ERR_UNSUPPORTED = -2,   /* shape outside what the kernels are built for */
+  DGDM_ERR_WORKSPACE = -3,     /* workspace too small */
+  DGDM_ERR_LAUNCH = -4         /* hipGetLastError() != hipSuccess after a launch */
+};
+
+/* activation ids shared by the fused row kernels */
+enum { DGDM_ACT_NONE = 0, DGDM_ACT_GELU = 1, DGDM_ACT_RELU = 2, DGDM_ACT_SILU = 3 };
+
+DGDM_API int dgdm_abi_version(void);
+DGDM_API const char* dgdm_error_string(int code);
+
+/* ---------------------------------------------------------------------------------------------
+ * K1  edge list -> CSR.   Replaces the index preparation of GraphConvolution.forward
+ * (core/graph_layers.py:76-84: add_self_loops, degree) and fixes the scatter-add order of
+ * MessagePassing.propagate (graph_layers.py:92) to "ascending edge id inside each row".
+ *
+ * edge_index: int64 [2,E] row-major (row 0 = source, row 1 = destination).
+ * by_src = 0: rows are destinations, col = source ids   (forward aggregation)
+ * by_src = 1: rows are sources,      col = destination ids (backward aggregation)
+ * add_loops != 0: a loop edge (i,i) with edge id E+i is appended for every node (always the last
+ *   entry of row i).  n_entries = E + (add_loops ? N : 0).
+ * Outputs: rowptr int32 [N+1], col int32 [n_entries], eid int32 [n_entries] (original edge id of
+ *   each entry).  Bit-exact against oracle/csr_oracle.py::csr_by_key.
+ * Ids outside [0,N) are NOT checked on the device (the host boundary validates them,
+ * dgdm_model.py:684-690).
+ */
+DGDM_API size_t dgdm_csr_build_workspace_bytes(int64_t E, int32_t N, int32_t add_loops);
+DGDM_API int dgdm_csr_build(const int64_t* edge_index, int64_t E, int32_t N, int32_t add_loops, int32_t by_src,
+                            int32_t* rowptr, int32_t* col, int32_t* eid,
+                            void* workspace, size_t workspace_bytes, void* stream);
+
+/* GCN symmetric normalisation (graph_layers.py:80-84): deg = in-degree from the by-destination
+ * rowptr (self loops included when they were added), dinv = deg^-1/2 (0 where deg == 0). */
+DGDM_API int dgdm_gcn_dinv(const int32_t* rowptr_dst, int32_t N, float* dinv, void* stream);
+/* w[p] = dinv[row(p)] * dinv[col[p]] for every CSR entry p (works for either orientation). */
+DGDM_API int dgdm_csr_edge_weights(const int32_t* rowptr, const int32_t* col, const float* dinv, int32_t N,
+                                   float* w, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K2  CSR segmented gather-reduce  Y[r,:] = sum_{p in row r} w[p] * X[col[p],:]  (+ bias).
+ * Replaces MessagePassing.propagate's gather by edge_index[0] + `norm * msg` + scatter-add by
+ * edge_index[1] (graph_layers.py:92,99-110); with the by-source CSR it is the backward pass.
+ * No atomics: one wavefront (or a sub-wave lane group) owns a destination row and reduces its
+ * entries in CSR order, so results are bitwise reproducible.
+ *   X [table_rows, C] with leading dimension ldx (floats), Y [N, C] with ldy; C % 4 == 0, C <= 1024,
+ *   ldx/ldy % 4 == 0, 16-byte aligned bases.
+ *   entries whose col[p] >= table_rows contribute zero (used to aggregate edge attributes by
+ *   `eid`, where the appended self-loop entries have no attribute row: repair R1).
+ *   bias: nullable [C].   accumulate != 0: Y += result instead of Y = result.
+ */
+DGDM_API int dgdm_spmm(const int32_t* rowptr, const int32_t* col, const float* w,
+                       const float* X, int64_t ldx, int32_t table_rows,
+                       float* Y, int64_t ldy, int32_t N, int32_t C,
+                       const float* bias, int32_t accumulate, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DGDM_HIP_H */

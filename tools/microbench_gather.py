@@ -1,0 +1,59 @@
+"""North-star microbenchmark: message-passing gather (K2) at 10k nodes x 768 features, 50k edges
+(+10k self loops).  Algorithmic bytes per launch:
+(E+N)*C*4 gathered + N*C*4 written + (E+N)*8 (col+w) + (N+1)*4 = 215.6 MB at C=768."""
+import argparse
+import json
+import sys
+import os
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dgdm_histopath_lab_amd import GraphStructure, ops  # noqa: E402
+from dgdm_histopath_lab_amd.synthetic import synthetic_batch  # noqa: E402
+
+
+def algorithmic_bytes(n, e, c):
+    ent = e + n
+    return ent * c * 4 + n * c * 4 + ent * 8 + (n + 1) * 4
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--nodes", type=int, default=10000)
+    ap.add_argument("--edges", type=int, default=50000)
+    ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--iters", type=int, default=200)
+    ap.add_argument("--widths", type=int, nargs="*", default=[768, 512, 256, 128, 32])
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    b = synthetic_batch(0, a.batch, a.nodes, a.edges, 8)
+    n, e = b.x.size(0), b.edge_index.size(1)
+    gs = GraphStructure(b.edge_index.to(dev), n)
+    for c in a.widths:
+        x = torch.randn(n, c, device=dev)
+        y = torch.empty(n, c, device=dev)
+        for _ in range(10):
+            ops.spmm_raw(gs.rowptr, gs.col, gs.w, x, n, out=y)
+        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(); t0.record()
+        for _ in range(a.iters):
+            ops.spmm_raw(gs.rowptr, gs.col, gs.w, x, n, out=y)
+        t1.record(); torch.cuda.synchronize()
+        us = t0.elapsed_time(t1) * 1e3 / a.iters
+        by = algorithmic_bytes(n, e, c)
+        print(json.dumps(dict(kernel="dgdm_spmm", nodes=n, edges=e, C=c, us=round(us, 2), algorithmic_MB=round(by / 1e6, 1),
+                              GBps=round(by / us / 1e3, 1), frac_of_8TBps=round(by / us / 1e3 / 8000, 3))))
+    # CSR build cost (both orientations + weights)
+    ei = b.edge_index.to(dev)
+    for _ in range(3):
+        GraphStructure(ei, n)
+    torch.cuda.synchronize(); t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True); t0.record()
+    for _ in range(20):
+        GraphStructure(ei, n)
+    t1.record(); torch.cuda.synchronize()
+    print(json.dumps(dict(kernel="graph_structure_build", nodes=n, edges=e, us=round(t0.elapsed_time(t1) * 1e3 / 20, 1))))
+
+
+if __name__ == "__main__":
+    main()
