@@ -68,3 +68,37 @@ def aggregate_edge_attr(edge_attr: Optional[torch.Tensor], gs: GraphStructure) -
         return None
     ea = _f32c(edge_attr)
     return spmm_raw(gs.rowptr, gs.eid, gs.w, ea, gs.num_nodes, table_rows=gs.num_edges)
+
+
+# ----------------------------------------------------------------------------- K4 attention
+class AttnPlan:
+    """Per-batch descriptor of the variable-length attention launch: device ``ptr`` (int32 [B+1]),
+    tile counts.  Built once per batch from host-side graph offsets (no device sync)."""
+
+    __slots__ = ("ptr_host", "ptr_dev", "B", "N_tot", "num_q_tiles")
+
+    def __init__(self, ptr_host, device):
+        lib = _lib.load()
+        self.ptr_host = [int(v) for v in ptr_host]
+        self.B = len(self.ptr_host) - 1
+        self.N_tot = self.ptr_host[-1]
+        qb = lib.dgdm_spatial_attn_q_tile_rows()
+        self.num_q_tiles = sum((self.ptr_host[g + 1] - self.ptr_host[g] + qb - 1) // qb for g in range(self.B))
+        self.ptr_dev = torch.tensor(self.ptr_host, dtype=torch.int32).to(device, non_blocking=True)
+
+
+def spatial_attn_fwd_raw(q, k, v, pos, plan: AttnPlan, H: int, scale: float, inv_tau: float, variant: int = 0):
+    """q,k,v: [N_tot, H*16] views sharing one row stride (e.g. slices of a fused QKV buffer)."""
+    _lib.require_cuda(q, k, v, pos)
+    lib = _lib.load()
+    N, C = q.shape
+    assert C == H * 16, "spatial attention kernels are built for head_dim 16"
+    assert q.stride(1) == 1 and q.stride(0) == k.stride(0) == v.stride(0) and N == plan.N_tot
+    pos = _f32c(pos)
+    out = torch.empty(N, C, dtype=torch.float32, device=q.device)
+    lse2 = torch.empty(H, N, dtype=torch.float32, device=q.device)
+    _lib.check(lib.dgdm_spatial_attn_fwd_variant(q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), pos.data_ptr(),
+                                                 plan.ptr_dev.data_ptr(), plan.B, plan.num_q_tiles, N, H, scale, inv_tau,
+                                                 out.data_ptr(), out.stride(0), lse2.data_ptr(), variant,
+                                                 _lib.stream_ptr(q.device)), "dgdm_spatial_attn_fwd")
+    return out, lse2

@@ -88,6 +88,29 @@ DGDM_API int dgdm_spmm(const int32_t* rowptr, const int32_t* col, const float* w
                        float* Y, int64_t ldy, int32_t N, int32_t C,
                        const float* bias, int32_t accumulate, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * K4  fused variable-length spatial attention (head dim 16), forward.
+ * Replaces SpatialAttention.compute_spatial_bias + MultiHeadAttention.forward's
+ * QK^T/sqrt(d) + bias -> softmax -> .V (core/attention.py:261-283,135-157) for a whole batch in
+ * one launch; the [H,N,N] score tensor is never materialised.
+ *   Q,K,V: [N_tot, H*16] fp32 with row stride ld (floats) -- e.g. three column slices of one
+ *          [N_tot, 3*H*16] projection output; head h occupies columns h*16..h*16+15.
+ *   pos:   [N_tot, 2] raw coordinates; bias = -|pos_q - pos_k| * inv_tau  (attention.py:274-281).
+ *   ptr:   int32 [B+1] DEVICE array of per-graph node offsets; attention never crosses graphs.
+ *   num_q_tiles = sum_g ceil(n_g / dgdm_spatial_attn_q_tile_rows()), computed by the host.
+ *   O:     [N_tot, H*16] (row stride ldo).   lse2: [H, N_tot] log2-domain log-sum-exp of the
+ *          scaled+biased scores (m + log2 l), consumed by the backward kernels.
+ */
+DGDM_API int32_t dgdm_spatial_attn_q_tile_rows(void);
+DGDM_API int dgdm_spatial_attn_fwd(const float* Q, const float* K, const float* V, int64_t ld, const float* pos,
+                                   const int32_t* ptr, int32_t B, int32_t num_q_tiles, int32_t N_tot, int32_t H,
+                                   float scale, float inv_tau, float* O, int64_t ldo, float* lse2, void* stream);
+/* same, with an explicit tiling variant (0 = default) -- tuning/bench use only */
+DGDM_API int dgdm_spatial_attn_fwd_variant(const float* Q, const float* K, const float* V, int64_t ld, const float* pos,
+                                           const int32_t* ptr, int32_t B, int32_t num_q_tiles, int32_t N_tot, int32_t H,
+                                           float scale, float inv_tau, float* O, int64_t ldo, float* lse2, int32_t variant,
+                                           void* stream);
+
 #ifdef __cplusplus
 }
 #endif
