@@ -32,6 +32,8 @@ SIGNATURES = {
     "dgdm_spatial_attn_q_tile_rows": (_i32, []),
     "dgdm_spatial_attn_fwd": (C.c_int, [_p, _p, _p, _i64, _p, _p, _i32, _i32, _i32, _i32, C.c_float, C.c_float, _p, _i64, _p, _p]),
     "dgdm_spatial_attn_fwd_variant": (C.c_int, [_p, _p, _p, _i64, _p, _p, _i32, _i32, _i32, _i32, C.c_float, C.c_float, _p, _i64, _p, _i32, _p]),
+    "dgdm_spatial_attn_bwd": (C.c_int, [_p, _p, _p, _i64, _p, _p, _i64, _p, _p, _i32, _i32, _i32, _i32, C.c_float, C.c_float,
+                                        _p, _p, _p, _p, _i64, _p, _p]),
     "dgdm_spmm": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _p, _i64, _i32, _i32, _p, _i32, _p]),
 }
 

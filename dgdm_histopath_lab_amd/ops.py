@@ -102,3 +102,46 @@ def spatial_attn_fwd_raw(q, k, v, pos, plan: AttnPlan, H: int, scale: float, inv
                                                  out.data_ptr(), out.stride(0), lse2.data_ptr(), variant,
                                                  _lib.stream_ptr(q.device)), "dgdm_spatial_attn_fwd")
     return out, lse2
+
+
+def spatial_attn_bwd_raw(q, k, v, out, gout, pos, plan: AttnPlan, H: int, scale: float, inv_tau: float, lse2, dqkv):
+    """Writes dQ|dK|dV into the three column blocks of ``dqkv`` [N_tot, 3*H*16]."""
+    lib = _lib.load()
+    N, C = q.shape
+    gout = _f32c(gout)
+    delta = torch.empty(H, N, dtype=torch.float32, device=q.device)
+    assert out.stride(0) == gout.stride(0) and dqkv.stride(1) == 1
+    _lib.check(lib.dgdm_spatial_attn_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), out.data_ptr(), gout.data_ptr(),
+                                         out.stride(0), pos.data_ptr(), plan.ptr_dev.data_ptr(), plan.B, plan.num_q_tiles, N, H,
+                                         scale, inv_tau, lse2.data_ptr(), dqkv[:, :C].data_ptr(), dqkv[:, C:2 * C].data_ptr(),
+                                         dqkv[:, 2 * C:].data_ptr(), dqkv.stride(0), delta.data_ptr(),
+                                         _lib.stream_ptr(q.device)), "dgdm_spatial_attn_bwd")
+    return dqkv
+
+
+class _SpatialAttention(torch.autograd.Function):
+    """softmax(QK^T/sqrt(d) - dist/tau) V over a fused [N_tot, 3C] QKV buffer
+    (core/attention.py:135-157 + 261-283), per graph of the batch."""
+
+    @staticmethod
+    def forward(ctx, qkv, pos, plan: AttnPlan, H: int, scale: float, inv_tau: float):
+        qkv = _f32c(qkv)
+        C = qkv.size(1) // 3
+        pos = _f32c(pos)
+        out, lse2 = spatial_attn_fwd_raw(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], pos, plan, H, scale, inv_tau)
+        ctx.save_for_backward(qkv, out, lse2, pos)
+        ctx.meta = (plan, H, scale, inv_tau)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        qkv, out, lse2, pos = ctx.saved_tensors
+        plan, H, scale, inv_tau = ctx.meta
+        C = qkv.size(1) // 3
+        dqkv = torch.empty_like(qkv)
+        spatial_attn_bwd_raw(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], out, gout, pos, plan, H, scale, inv_tau, lse2, dqkv)
+        return dqkv, None, None, None, None, None
+
+
+def spatial_attention(qkv, pos, plan: AttnPlan, H: int, scale: float, inv_tau: float = 1.0):
+    return _SpatialAttention.apply(qkv, pos, plan, H, scale, inv_tau)

@@ -111,6 +111,18 @@ DGDM_API int dgdm_spatial_attn_fwd_variant(const float* Q, const float* K, const
                                            float scale, float inv_tau, float* O, int64_t ldo, float* lse2, int32_t variant,
                                            void* stream);
 
+/* K4 backward: dQ, dK, dV of the fused spatial attention (what autograd derives from
+ * core/attention.py:135-157 in the reference, with P recomputed per tile instead of stored).
+ *   O, dO: [N_tot, H*16] (row stride ldo); lse2 from the forward; dQ/dK/dV: [N_tot, H*16] with
+ *   row stride ldg (e.g. three column slices of one [N_tot, 3*H*16] gradient buffer).
+ *   delta_ws: float [H, N_tot] scratch (rowsum(dO*O), written by the dQ pass, read by the dK/dV pass).
+ * Two launches, no atomics: results are bitwise reproducible. */
+DGDM_API int dgdm_spatial_attn_bwd(const float* Q, const float* K, const float* V, int64_t ld, const float* O,
+                                   const float* dO, int64_t ldo, const float* pos, const int32_t* ptr, int32_t B,
+                                   int32_t num_q_tiles, int32_t N_tot, int32_t H, float scale, float inv_tau,
+                                   const float* lse2, float* dQ, float* dK, float* dV, int64_t ldg, float* delta_ws,
+                                   void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -33,7 +33,7 @@ def test_python_binding_matches_header(lib_path):
     assert sorted(_lib.SIGNATURES) == _declared()
     hdr = open(os.path.join(ROOT, "include", "dgdm_hip.h")).read()
     for name, (_, args) in _lib.SIGNATURES.items():
-        m = re.search(r"\b%s\s*\(([^;]*?)\)\s*;" % name, hdr, re.S)
+        m = re.search(r"DGDM_API[\w\s\*]+?\b%s\s*\(([^;]*?)\)\s*;" % name, hdr, re.S)
         assert m, name
         params = [p for p in m.group(1).split(",") if p.strip() and p.strip() != "void"]
         assert len(params) == len(args), f"{name}: header has {len(params)} params, binding {len(args)}"

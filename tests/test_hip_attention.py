@@ -76,3 +76,26 @@ def test_attn_forward_sharp_distribution_forces_rescale():
     o, _ = ops.spatial_attn_fwd_raw(d[:, :128], d[:, 128:256], d[:, 256:], pos.to(DEV), plan, H, 0.25, 1.0)
     ro, _ = dense_reference(qkv[:, :128], qkv[:, 128:256], qkv[:, 256:], pos, ptr, H, 1.0)
     assert_close(o, ro, 1e-4, "O sharp")
+
+
+@pytest.mark.parametrize("ptr,H", [([0, 1], 4), ([0, 17], 8), ([0, 65, 130, 131], 8), ([0, 200, 263], 2), ([0, 100], 1),
+                                    ([0, 333, 1000], 8), ([0, 129, 500], 16)])
+def test_attn_backward_matches_dense(ptr, H):
+    from dgdm_histopath_lab_amd import ops
+    qkv, pos = make(ptr, H, 3 * sum(ptr) + H)
+    C = H * 16
+    g = torch.Generator().manual_seed(1)
+    gout = torch.randn(ptr[-1], C, generator=g)
+    d = qkv.to(DEV).requires_grad_(True)
+    plan = ops.AttnPlan(ptr, DEV)
+    o = ops.spatial_attention(d, pos.to(DEV), plan, H, 0.25, 1.0)
+    o.backward(gout.to(DEV))
+    ro, gq, gk, gv = dense_reference(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], pos, ptr, H, 1.0, gout)
+    assert_close(o, ro, 1e-5, "O")
+    assert_close(d.grad[:, :C], gq, 2e-5, "dQ")
+    assert_close(d.grad[:, C:2 * C], gk, 2e-5, "dK")
+    assert_close(d.grad[:, 2 * C:], gv, 2e-5, "dV")
+    # no float atomics anywhere: a second run is bitwise identical
+    d2 = qkv.to(DEV).requires_grad_(True)
+    ops.spatial_attention(d2, pos.to(DEV), plan, H, 0.25, 1.0).backward(gout.to(DEV))
+    assert torch.equal(d.grad, d2.grad)
