@@ -6,3 +6,4 @@ from ._lib import DGDMKernelError  # noqa: F401
 from .graph import GraphBatch, GraphData, GraphStructure  # noqa: F401
 
 __version__ = "0.1.0"
+from .models.dgdm_model import DGDMModel, ModelConfigurationError, ModelInferenceError, ValidationError  # noqa: F401,E402

@@ -1,0 +1,145 @@
+"""Diffusion block of the DGDM hot path (K7/K8).
+
+Host-side mirror of the reference's ``core/diffusion.py`` (``DiffusionScheduler``,
+``DiffusionLayer`` with identical parameter names).  Differences in *how* it is computed:
+
+* the schedule tables live on the device (the reference re-uploads them on every call,
+  diffusion.py:131,134) and per-graph coefficients are gathered with the ``batch`` vector, so a
+  whole batch of graphs with different timesteps is one pass (the reference loops over graphs);
+* the ``[x_t | t_emb]`` concat (diffusion.py:165-170) is never built: the time half of the first
+  Linear is constant per graph, ``W[:, C:] @ t_emb_g + b`` is computed once per graph and added
+  as a per-graph bias.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch import Tensor
+
+
+class DiffusionScheduler:
+    """Beta schedules and derived tables (reference: diffusion.py:16-61)."""
+
+    def __init__(self, num_timesteps: int = 1000, beta_start: float = 0.0001, beta_end: float = 0.02, schedule: str = "cosine"):
+        self.num_timesteps, self.schedule = num_timesteps, schedule
+        T = num_timesteps
+        if schedule == "linear":
+            betas = torch.linspace(beta_start, beta_end, T)
+        elif schedule == "cosine":
+            s = 0.008
+            grid = torch.linspace(0, T, T + 1)
+            ac = torch.cos(((grid / T) + s) / (1 + s) * math.pi * 0.5) ** 2
+            ac = ac / ac[0]
+            betas = torch.clip(1 - (ac[1:] / ac[:-1]), 0, 0.999)
+        elif schedule == "sigmoid":  # the reference maps the sigmoid ramp onto [beta_start, beta_end] (diffusion.py:34,56-61)
+            betas = torch.sigmoid(torch.linspace(-6, 6, T)) * (beta_end - beta_start) + beta_start
+        else:
+            raise ValueError(f"Unknown schedule: {schedule}")
+        self.betas = betas
+        self.alphas = 1.0 - betas
+        self.alphas_cumprod = torch.cumprod(self.alphas, dim=0)
+        self.alphas_cumprod_prev = F.pad(self.alphas_cumprod[:-1], (1, 0), value=1.0)
+        self.posterior_variance = betas * (1.0 - self.alphas_cumprod_prev) / (1.0 - self.alphas_cumprod)
+        self._dev = {}
+
+    def on(self, device) -> dict:
+        key = str(device)
+        if key not in self._dev:
+            ac = self.alphas_cumprod.to(device)
+            self._dev[key] = dict(sqrt_ac=torch.sqrt(ac), sqrt_1mac=torch.sqrt(1.0 - ac), alphas=self.alphas.to(device),
+                                  alphas_cumprod=ac, posterior_variance=self.posterior_variance.to(device))
+        return self._dev[key]
+
+
+class DiffusionLayer(nn.Module):
+    """q-sample + time-conditioned noise predictor + DDPM sampler (reference: diffusion.py:64-275)."""
+
+    def __init__(self, node_dim: int, hidden_dim: int, num_timesteps: int = 1000, schedule: str = "cosine",
+                 conditioning_dim: Optional[int] = None):
+        super().__init__()
+        self.node_dim, self.hidden_dim, self.num_timesteps = node_dim, hidden_dim, num_timesteps
+        self.scheduler = DiffusionScheduler(num_timesteps, schedule=schedule)
+        self.time_embed = nn.Sequential(nn.Linear(128, hidden_dim), nn.SiLU(), nn.Linear(hidden_dim, hidden_dim))
+        self.denoise_net = nn.Sequential(
+            nn.Linear(node_dim + hidden_dim, hidden_dim * 2), nn.GroupNorm(8, hidden_dim * 2), nn.SiLU(), nn.Dropout(0.1),
+            nn.Linear(hidden_dim * 2, hidden_dim), nn.GroupNorm(8, hidden_dim), nn.SiLU(), nn.Dropout(0.1),
+            nn.Linear(hidden_dim, node_dim))
+        self.condition_net = nn.Linear(conditioning_dim, hidden_dim) if conditioning_dim is not None else None
+
+    def get_timestep_embedding(self, timesteps: Tensor, dim: int = 128) -> Tensor:
+        half = dim // 2
+        f = torch.exp(torch.arange(half, device=timesteps.device) * -(math.log(10000) / (half - 1)))
+        e = timesteps.float()[:, None] * f[None, :]
+        e = torch.cat([torch.sin(e), torch.cos(e)], dim=1)
+        return F.pad(e, (0, 1)) if dim % 2 == 1 else e
+
+    # -- batched (segment) forms: one timestep per graph, rows gathered with `seg` -----------
+    def add_noise_segments(self, x0: Tensor, noise: Tensor, timesteps: Tensor, seg: Tensor) -> Tensor:
+        tab = self.scheduler.on(x0.device)
+        a, b = tab["sqrt_ac"][timesteps][seg].unsqueeze(-1), tab["sqrt_1mac"][timesteps][seg].unsqueeze(-1)
+        return a * x0 + b * noise
+
+    def predict_noise_segments(self, x_noisy: Tensor, timesteps: Tensor, seg: Tensor) -> Tensor:
+        """x_noisy [N_tot, C]; timesteps [B]; seg [N_tot] graph id per row."""
+        C = self.node_dim
+        te = self.time_embed(self.get_timestep_embedding(timesteps))                  # [B, hidden]
+        lin0 = self.denoise_net[0]
+        per_graph = F.linear(te, lin0.weight[:, C:], lin0.bias)                      # time half of the concat + bias
+        h = F.linear(x_noisy, lin0.weight[:, :C]) + per_graph[seg]
+        for i in (1, 5):
+            gn, lin = self.denoise_net[i], self.denoise_net[i + 3]
+            h = self.denoise_net[i + 2](F.silu(F.group_norm(h, gn.num_groups, gn.weight, gn.bias, gn.eps)))
+            h = lin(h)
+        return h
+
+    # -- reference-shaped API (same graph for every row) --------------------------------------
+    def add_noise(self, x_start: Tensor, noise: Tensor, timesteps: Tensor) -> Tensor:
+        tab = self.scheduler.on(x_start.device)
+        a, b = tab["sqrt_ac"][timesteps], tab["sqrt_1mac"][timesteps]
+        while a.dim() < x_start.dim():
+            a, b = a.unsqueeze(-1), b.unsqueeze(-1)
+        return a * x_start + b * noise
+
+    def predict_noise(self, x_noisy: Tensor, timesteps: Tensor, condition: Optional[Tensor] = None) -> Tensor:
+        if condition is not None:
+            raise NotImplementedError("conditioning is not used by DGDMModel")
+        if x_noisy.dim() != 2:
+            raise ValueError("predict_noise expects [N, C] (the 3-D form cannot run in the reference: GroupNorm, D5)")
+        seg = torch.zeros(x_noisy.size(0), dtype=torch.long, device=x_noisy.device)
+        return self.predict_noise_segments(x_noisy, timesteps[:1], seg)
+
+    def forward(self, x_start: Tensor, timesteps: Optional[Tensor] = None, noise: Optional[Tensor] = None,
+                condition: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+        if timesteps is None:
+            timesteps = torch.randint(0, self.num_timesteps, (1,), device=x_start.device)
+        if noise is None:
+            noise = torch.randn_like(x_start)
+        x_noisy = self.add_noise(x_start, noise, timesteps[:1])
+        return x_noisy, self.predict_noise(x_noisy, timesteps, condition)
+
+    @torch.no_grad()
+    def sample(self, shape, device, condition: Optional[Tensor] = None, num_inference_steps: int = 50,
+               x_init: Optional[Tensor] = None, step_noise: Optional[List[Tensor]] = None) -> Tensor:
+        """DDPM ancestral sampling (reference: diffusion.py:214-275): timesteps =
+        linspace(T-1, 0, steps).long(), final step returns x0_hat without noise.  ``x_init`` /
+        ``step_noise`` inject the random draws (tests); the timestep table is read on the host
+        once, the loop itself issues no device->host sync."""
+        x = torch.randn(shape, device=device) if x_init is None else x_init.to(device)
+        tab = self.scheduler.on(device)
+        ts = torch.linspace(self.num_timesteps - 1, 0, num_inference_steps, dtype=torch.long).tolist()
+        seg = torch.zeros(x.size(0), dtype=torch.long, device=device)
+        for i, t in enumerate(ts):
+            tt = torch.full((1,), t, dtype=torch.long, device=device)
+            eps = self.predict_noise_segments(x, tt, seg)
+            ac, alpha = tab["alphas_cumprod"][t], tab["alphas"][t]
+            x0 = (x - torch.sqrt(1 - ac) * eps) / torch.sqrt(ac)
+            if i < len(ts) - 1:
+                z = torch.randn_like(x) if step_noise is None else step_noise[i].to(device)
+                x = torch.sqrt(alpha) * x0 + torch.sqrt(tab["posterior_variance"][t]) * z
+            else:
+                x = x0
+        return x

@@ -1,0 +1,198 @@
+"""Message-passing layers of the DGDM hot path on the HIP kernels (K1/K2).
+
+Host-side mirror of the reference's ``core/graph_layers.py`` (same class names, constructor
+arguments, parameter names -> identical ``state_dict`` keys); the arithmetic runs through
+``libdgdm_hip.so``:
+
+* the edge list is turned into CSR/CSC + GCN weights ONCE per (edge list, node count) by
+  ``GraphContext`` (K1) instead of once per convolution call (graph_layers.py:76-84);
+* ``GraphConvolution`` aggregates first and projects second,
+  ``out = [A_hat x | EA_hat] @ [W | W_e]^T + b``: A_hat(xW^T) == (A_hat x)W^T, and because
+  ``edge_lin`` has no bias (graph_layers.py:49) the per-edge term ``sum_e norm_e W_e a_e``
+  equals ``(sum_e norm_e a_e) W_e^T`` where the 32-wide aggregate EA_hat depends only on the
+  graph -- it is computed once per GraphContext (K2) and shared by every convolution;
+* self-loop edges carry a zero attribute row (repair R1, SURVEY.md 8(a')).
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple, Union
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch import Tensor
+
+from .. import ops
+from ..graph import GraphStructure
+
+
+class GraphContext:
+    """Everything the convolutions need from one edge list over ``num_nodes`` nodes."""
+
+    __slots__ = ("gs", "ea_hat", "num_nodes", "edge_index", "edge_attr")
+
+    def __init__(self, edge_index: Tensor, num_nodes: int, edge_attr: Optional[Tensor] = None, add_loops: bool = True):
+        self.gs = GraphStructure(edge_index, num_nodes, add_loops=add_loops)
+        self.ea_hat = ops.aggregate_edge_attr(edge_attr, self.gs)  # None when there are no attributes
+        self.num_nodes = num_nodes
+        self.edge_index, self.edge_attr = edge_index, edge_attr
+
+
+def _context(edge_index: Union[Tensor, GraphContext], x: Tensor, edge_attr: Optional[Tensor], add_loops=True) -> GraphContext:
+    if isinstance(edge_index, GraphContext):
+        return edge_index
+    return GraphContext(edge_index, x.size(0), edge_attr, add_loops)
+
+
+class GraphConvolution(nn.Module):
+    """GCN-style convolution with an edge-feature term (reference: graph_layers.py:19-110)."""
+
+    def __init__(self, in_channels: int, out_channels: int, edge_dim: Optional[int] = None, bias: bool = True,
+                 add_self_loops: bool = True, normalize: bool = True, **kwargs):
+        super().__init__()
+        if not normalize:
+            raise NotImplementedError("normalize=False is not on the DGDM path (never used by DGDMModel)")
+        self.in_channels, self.out_channels, self.edge_dim = in_channels, out_channels, edge_dim
+        self.add_self_loops, self.normalize = add_self_loops, normalize
+        self.node_lin = nn.Linear(in_channels, out_channels, bias=False)
+        self.edge_lin = nn.Linear(edge_dim, out_channels, bias=False) if edge_dim is not None else None
+        if bias:
+            self.bias = nn.Parameter(torch.zeros(out_channels))
+        else:
+            self.register_parameter("bias", None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        nn.init.xavier_uniform_(self.node_lin.weight)
+        if self.edge_lin is not None:
+            nn.init.xavier_uniform_(self.edge_lin.weight)
+        if self.bias is not None:
+            nn.init.zeros_(self.bias)
+
+    def forward(self, x: Tensor, edge_index: Union[Tensor, GraphContext], edge_attr: Optional[Tensor] = None, size=None) -> Tensor:
+        ctx = _context(edge_index, x, edge_attr, self.add_self_loops)
+        ax = ops.aggregate(x, ctx.gs)
+        out = F.linear(ax, self.node_lin.weight, self.bias)
+        if self.edge_lin is not None and ctx.ea_hat is not None:
+            out = torch.addmm(out, ctx.ea_hat, self.edge_lin.weight.t())
+        return out
+
+
+class DynamicGraphLayer(nn.Module):
+    """norm1(output_proj(GELU(conv2(GELU(conv1(x))))) + x)  (reference: graph_layers.py:113-247).
+
+    ``compute_dynamic_edges`` (:160-205) is evaluated and thrown away by the reference (:227-230):
+    it changes neither outputs nor gradients and is not executed here.  Its parameters
+    (``node_to_qkv``, ``edge_to_key``) and the unused ``norm2`` still exist so that reference
+    checkpoints load."""
+
+    def __init__(self, node_dim: int, edge_dim: int, hidden_dim: int, num_heads: int = 8, dropout: float = 0.1,
+                 use_layer_norm: bool = True):
+        super().__init__()
+        assert hidden_dim % num_heads == 0, "hidden_dim must be divisible by num_heads"
+        self.node_dim, self.edge_dim, self.hidden_dim, self.num_heads = node_dim, edge_dim, hidden_dim, num_heads
+        self.head_dim = hidden_dim // num_heads
+        self.node_to_qkv = nn.Linear(node_dim, hidden_dim * 3)   # dead in the reference forward
+        self.edge_to_key = nn.Linear(edge_dim, hidden_dim)       # dead in the reference forward
+        self.graph_conv1 = GraphConvolution(node_dim, hidden_dim, edge_dim)
+        self.graph_conv2 = GraphConvolution(hidden_dim, hidden_dim, edge_dim)
+        self.output_proj = nn.Linear(hidden_dim, node_dim)
+        self.dropout = nn.Dropout(dropout)
+        self.norm1 = nn.LayerNorm(node_dim) if use_layer_norm else nn.Identity()
+        self.norm2 = nn.LayerNorm(node_dim) if use_layer_norm else nn.Identity()  # unused (graph_layers.py:152)
+        self.activation = nn.GELU()
+
+    def forward(self, x: Tensor, edge_index: Union[Tensor, GraphContext], edge_attr: Optional[Tensor] = None) -> Tensor:
+        ctx = _context(edge_index, x, edge_attr)
+        h = self.dropout(self.activation(self.graph_conv1(x, ctx)))
+        h = self.dropout(self.activation(self.graph_conv2(h, ctx)))
+        return self.norm1(self.output_proj(h) + x)
+
+
+class AdaptiveGraphPooling(nn.Module):
+    """Top-k node pooling (reference: graph_layers.py:250-329).  k = max(1, int(ratio*N)) over ALL
+    nodes of the batch (the reference ignores ``batch``); kept nodes in ascending id order.
+
+    Sync-free variant of the edge filter: instead of compacting the edge list (data-dependent
+    size) the pooled ``edge_index`` keeps its E columns and dropped edges are marked with the
+    out-of-range id ``k``; the CSR builder ignores out-of-range edges, and ``eid`` still indexes
+    the un-compacted ``edge_attr``.  ``compact=True`` reproduces the reference's compacted
+    tensors (one host sync) for callers that need them."""
+
+    def __init__(self, in_channels: int, ratio: float = 0.5, min_score: Optional[float] = None, multiplier: float = 1.0,
+                 nonlinearity: str = "tanh"):
+        super().__init__()
+        if min_score is not None:
+            raise NotImplementedError("min_score pooling is not on the DGDM path")
+        self.in_channels, self.ratio, self.min_score, self.multiplier = in_channels, ratio, min_score, multiplier
+        self.score_net = nn.Sequential(nn.Linear(in_channels, in_channels // 2), nn.ReLU(), nn.Linear(in_channels // 2, 1))
+        self._nl = nonlinearity
+
+    def forward(self, x: Tensor, edge_index: Tensor, edge_attr: Optional[Tensor] = None, batch: Optional[Tensor] = None,
+                compact: bool = False) -> Tuple[Tensor, Tensor, Optional[Tensor], Tensor]:
+        s = self.score_net(x).squeeze(-1)
+        s = torch.tanh(s) if self._nl == "tanh" else (torch.softmax(s, 0) if self._nl == "softmax" else torch.sigmoid(s))
+        n = x.size(0)
+        k = max(1, int(self.ratio * n))
+        perm = torch.topk(s, k, sorted=False).indices.sort().values        # ascending node ids
+        pooled_x = x[perm] * s[perm].unsqueeze(-1) * self.multiplier
+        node_map = torch.full((n,), -1, dtype=torch.long, device=x.device)
+        node_map[perm] = torch.arange(k, device=x.device)
+        mapped = node_map[edge_index]
+        keep = (mapped[0] >= 0) & (mapped[1] >= 0)
+        if compact:  # reference layout (graph_layers.py:322-327); boolean indexing syncs
+            return pooled_x, mapped[:, keep], (edge_attr[keep] if edge_attr is not None else None), perm
+        pooled_ei = torch.where(keep.unsqueeze(0), mapped, torch.full_like(mapped, k))
+        return pooled_x, pooled_ei, edge_attr, perm
+
+
+class GraphUNet(nn.Module):
+    """Graph U-Net (reference: graph_layers.py:332-458) with the repairs that make it runnable:
+    R5a layers use the data's edge dim (32) instead of ``hidden_channels``; R5b ``up_convs`` take
+    ``hidden_channels`` inputs (sum skip).  ``strict_reference=True`` replicates D10: decoder level
+    j convolves with ``edge_indices[j+1]`` (the coarser graph's ids, graph_layers.py:453)."""
+
+    def __init__(self, in_channels: int, hidden_channels: int, out_channels: int, depth: int = 3, pool_ratios=None,
+                 sum_res: bool = True, act: str = "relu", edge_dim: int = 32, strict_reference: bool = True):
+        super().__init__()
+        if not sum_res:
+            raise NotImplementedError("sum_res=False cannot run in the reference either (D7)")
+        self.in_channels, self.hidden_channels, self.out_channels = in_channels, hidden_channels, out_channels
+        self.depth, self.sum_res, self.strict_reference = depth, sum_res, strict_reference
+        pool_ratios = pool_ratios or [0.5] * depth
+        self.act = {"relu": F.relu, "gelu": F.gelu}.get(act, F.elu)
+        mk = lambda cin: DynamicGraphLayer(cin, edge_dim, hidden_channels)
+        self.down_convs = nn.ModuleList([mk(in_channels)] + [mk(hidden_channels) for _ in range(depth)])
+        self.pools = nn.ModuleList([AdaptiveGraphPooling(hidden_channels, ratio=pool_ratios[i]) for i in range(depth)])
+        self.bottom_conv = mk(hidden_channels)
+        self.up_convs = nn.ModuleList([mk(hidden_channels) for _ in range(depth)])
+        self.final_conv = nn.Linear(hidden_channels, out_channels)
+
+    def forward(self, x: Tensor, edge_index: Union[Tensor, GraphContext], edge_attr: Optional[Tensor] = None,
+                batch: Optional[Tensor] = None, trace: Optional[dict] = None) -> Tensor:
+        ctx0 = _context(edge_index, x, edge_attr)
+        eis, eas = [ctx0.edge_index], [ctx0.edge_attr]
+        ctxs = {(0, x.size(0)): ctx0}
+
+        def level(k: int, n: int) -> GraphContext:
+            if (k, n) not in ctxs:
+                ctxs[(k, n)] = GraphContext(eis[k], n, eas[k])
+            return ctxs[(k, n)]
+
+        x = self.down_convs[0](x, ctx0)
+        xs, perms = [x], []
+        for i in range(self.depth):
+            x = self.down_convs[i + 1](self.act(x), level(i, x.size(0)))
+            xs.append(x)
+            x, ei, ea, perm = self.pools[i](x, eis[-1], eas[-1], batch)
+            eis.append(ei); eas.append(ea); perms.append(perm)
+            if trace is not None:
+                trace[f"perm{i}"] = perm
+        x = self.bottom_conv(self.act(x), level(self.depth, x.size(0)))
+        for i in range(self.depth):
+            j = self.depth - 1 - i
+            up = torch.zeros(xs[j + 1].size(0), x.size(1), device=x.device, dtype=x.dtype).index_copy(0, perms[j], x)
+            x = self.act(up + xs[j + 1])
+            lvl = j + 1 if self.strict_reference else j
+            x = self.up_convs[i](x, level(lvl, x.size(0)))
+        return self.final_conv(x)

@@ -14,10 +14,18 @@ namespace {
 
 constexpr int SCAN_BLOCK = 1024;  // threads; one item per thread
 
-__global__ void k_count(const int64_t* __restrict__ keys, int64_t E, int32_t* __restrict__ cnt) {
+// an edge takes part only if both endpoints are in [0, N): out-of-range ids mark dropped edges
+// (the sync-free top-k pooling keeps its edge arrays un-compacted) and can never index memory.
+__device__ __forceinline__ bool edge_ok(int64_t k, int64_t v, int32_t N) {
+  return (uint64_t)k < (uint64_t)N && (uint64_t)v < (uint64_t)N;
+}
+
+__global__ void k_count(const int64_t* __restrict__ keys, const int64_t* __restrict__ vals, int64_t E, int32_t N,
+                        int32_t* __restrict__ cnt) {
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (; i < E; i += stride) atomicAdd(&cnt[keys[i]], 1);
+  for (; i < E; i += stride)
+    if (edge_ok(keys[i], vals[i], N)) atomicAdd(&cnt[keys[i]], 1);
 }
 
 __device__ __forceinline__ int block_exclusive_scan(int v, int* total) {
@@ -79,12 +87,13 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_write(const int32_t* __rest
   if (i == N - 1) rowptr[N] = ex + v;
 }
 
-__global__ void k_fill(const int64_t* __restrict__ keys, const int64_t* __restrict__ vals, int64_t E,
+__global__ void k_fill(const int64_t* __restrict__ keys, const int64_t* __restrict__ vals, int64_t E, int32_t N,
                        const int32_t* __restrict__ rowptr, int32_t* __restrict__ cursor,
                        int32_t* __restrict__ tcol, int32_t* __restrict__ teid) {
   int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (; e < E; e += stride) {
+    if (!edge_ok(keys[e], vals[e], N)) continue;
     const int32_t k = (int32_t)keys[e];
     const int32_t slot = rowptr[k] + atomicAdd(&cursor[k], 1);
     tcol[slot] = (int32_t)vals[e];
@@ -192,11 +201,11 @@ extern "C" int dgdm_csr_build(const int64_t* edge_index, int64_t E, int32_t N, i
   // cnt and cursor are adjacent (both 256-B padded): one memset
   (void)hipMemsetAsync(w.cnt, 0, (size_t)((char*)w.block_tot - (char*)w.cnt), stream);
   const int eb = (int)((E + 255) / 256 < 4096 ? (E + 255) / 256 : 4096);
-  if (E > 0) hipLaunchKernelGGL(k_count, dim3(eb), dim3(256), 0, stream, keys, E, w.cnt);
+  if (E > 0) hipLaunchKernelGGL(k_count, dim3(eb), dim3(256), 0, stream, keys, vals, E, N, w.cnt);
   hipLaunchKernelGGL(k_scan_block_totals, dim3(nblk), dim3(SCAN_BLOCK), 0, stream, w.cnt, N, extra, w.block_tot);
   hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(SCAN_BLOCK), 0, stream, w.block_tot, nblk);
   hipLaunchKernelGGL(k_scan_write, dim3(nblk), dim3(SCAN_BLOCK), 0, stream, w.cnt, N, extra, w.block_tot, rowptr);
-  if (E > 0) hipLaunchKernelGGL(k_fill, dim3(eb), dim3(256), 0, stream, keys, vals, E, rowptr, w.cursor, w.tcol, w.teid);
+  if (E > 0) hipLaunchKernelGGL(k_fill, dim3(eb), dim3(256), 0, stream, keys, vals, E, N, rowptr, w.cursor, w.tcol, w.teid);
   if (n_entries > 0) {
     const int rb = (N + 3) / 4 < 8192 ? (N + 3) / 4 : 8192;  // 4 waves per block, one row per wave
     hipLaunchKernelGGL(k_rank, dim3(rb), dim3(256), 0, stream, rowptr, N, (int32_t)E, extra, w.tcol, w.teid, col, eid);

@@ -1,0 +1,413 @@
+"""DGDMModel on the MI355X HIP path -- the drop-in boundary.
+
+Mirror of the reference's ``models/dgdm_model.py:37-715``: same constructor (14 keyword
+arguments, same defaults and validation rules), same ``forward(data, mode, return_attention,
+return_embeddings) -> dict`` contract and output keys, same ``pretrain_step`` /
+``_compute_diffusion_loss`` / ``generate_embeddings`` methods, same ``state_dict`` key names
+(plus ``graph_encoder.dim_proj.*`` from repair R2), same exception types.
+
+What differs is how a batch is executed: one ``BatchPlan`` (CSR/CSC + GCN weights + aggregated
+edge attributes + per-graph offsets) is built per call by the K1/K2 kernels; the three Python
+loops over graphs of the reference (spatial attention dgdm_model.py:346-357, diffusion loss
+:419-431, attention pooling :607-613) become single batched launches; there is one host sync per
+forward (input validation) instead of >= 3*B.
+
+Build-only keyword arguments (absent => reference behaviour): ``strict_reference`` (D8/D10),
+and the random-draw injection hooks ``timesteps`` / ``noise`` / ``noise_target`` /
+``mask_indices`` / ``mask_token`` used by the parity tests.
+"""
+from __future__ import annotations
+
+import math
+import warnings
+from typing import Any, Dict, List, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch import Tensor
+
+from .. import _lib, ops
+from ..core.attention import MultiHeadAttention, SpatialAttention
+from ..core.diffusion import DiffusionLayer
+from ..core.graph_layers import GraphContext, GraphUNet
+from ..graph import graph_ptr
+from .decoders import ClassificationHead, RegressionHead
+from .encoders import FeatureEncoder, GraphEncoder
+
+
+class ValidationError(Exception):
+    """Input validation failure (reference: utils/validation.py:12)."""
+
+
+class ModelConfigurationError(Exception):
+    """Invalid constructor arguments (reference: dgdm_model.py:27)."""
+
+
+class ModelInferenceError(Exception):
+    """Any failure inside forward (reference: dgdm_model.py:32)."""
+
+
+def _check_int(v, lo=None, hi=None):
+    try:
+        iv = int(v)
+    except (ValueError, TypeError):
+        raise ValidationError(f"Invalid integer value: {v}")
+    if lo is not None and iv < lo:
+        raise ValidationError(f"Value too small: {iv} < {lo}")
+    if hi is not None and iv > hi:
+        raise ValidationError(f"Value too large: {iv} > {hi}")
+    return iv
+
+
+def _check_enum(v, allowed):
+    if v not in allowed:
+        raise ValidationError(f"Invalid choice: {v}. Allowed: {allowed}")
+
+
+class BatchPlan:
+    """Per-batch descriptor shared by every stage of one forward/backward."""
+
+    __slots__ = ("ptr", "num_graphs", "num_nodes", "seg", "attn", "ctx")
+
+    def __init__(self, data, device):
+        n = data.x.size(0)
+        self.ptr = graph_ptr(data, n)
+        self.num_graphs, self.num_nodes = len(self.ptr) - 1, n
+        batch = getattr(data, "batch", None)
+        self.seg = batch if batch is not None else torch.zeros(n, dtype=torch.long, device=device)  # R4
+        self.attn = ops.AttnPlan(self.ptr, device)
+        self.ctx = GraphContext(data.edge_index, n, getattr(data, "edge_attr", None))
+
+
+class DGDMModel(nn.Module):
+    def __init__(self, node_features: int = 768, hidden_dims: List[int] = [512, 256, 128], num_diffusion_steps: int = 10,
+                 attention_heads: int = 8, dropout: float = 0.1, graph_layers: int = 4, use_spatial_attention: bool = True,
+                 use_hierarchical: bool = True, diffusion_schedule: str = "cosine", activation: str = "gelu",
+                 normalization: str = "layer", pooling: str = "attention", num_classes: Optional[int] = None,
+                 regression_targets: int = 0, *, strict_reference: bool = True):
+        super().__init__()
+        try:
+            self._validate_configuration(node_features, hidden_dims, num_diffusion_steps, attention_heads, dropout,
+                                         graph_layers, diffusion_schedule, activation, normalization, pooling, num_classes,
+                                         regression_targets)
+        except Exception as e:
+            raise ModelConfigurationError(f"Invalid model configuration: {e}")
+        self.node_features, self.hidden_dims = node_features, hidden_dims
+        self.num_diffusion_steps, self.attention_heads, self.dropout = num_diffusion_steps, attention_heads, dropout
+        self.use_spatial_attention, self.use_hierarchical, self.pooling = use_spatial_attention, use_hierarchical, pooling
+        self.num_classes, self.regression_targets = num_classes, regression_targets
+        self.strict_reference = strict_reference
+        C = hidden_dims[-1]
+
+        self.feature_encoder = FeatureEncoder(node_features, hidden_dims[0], dropout=dropout, activation=activation,
+                                              normalization=normalization)
+        self.graph_encoder = GraphEncoder(hidden_dims[0], hidden_dims, num_layers=graph_layers, attention_heads=attention_heads,
+                                          dropout=dropout, activation=activation, normalization=normalization)
+        self.diffusion_layer = DiffusionLayer(node_dim=C, hidden_dim=C * 2, num_timesteps=num_diffusion_steps,
+                                              schedule=diffusion_schedule)
+        self.spatial_attention = SpatialAttention(C, attention_heads, dropout=dropout) if use_spatial_attention else None
+        self.hierarchical_processor = (GraphUNet(C, C, C, depth=3, strict_reference=strict_reference)
+                                       if use_hierarchical else None)
+        self.global_pool = self._create_pooling_layer(pooling, C, attention_heads)
+        self.classification_head = (ClassificationHead(C, num_classes, hidden_dims=[C // 2], dropout=dropout, activation=activation)
+                                    if num_classes is not None else None)
+        self.regression_head = (RegressionHead(C, regression_targets, hidden_dims=[C // 2], dropout=dropout, activation=activation)
+                                if regression_targets > 0 else None)
+        self.apply(self._init_weights)
+
+    # ------------------------------------------------------------------ configuration
+    @staticmethod
+    def _validate_configuration(node_features, hidden_dims, num_diffusion_steps, attention_heads, dropout, graph_layers,
+                                diffusion_schedule, activation, normalization, pooling, num_classes, regression_targets):
+        """Same rules as dgdm_model.py:192-242."""
+        _check_int(node_features, 1, 10000)
+        if not isinstance(hidden_dims, list) or len(hidden_dims) == 0:
+            raise ValidationError("hidden_dims must be a non-empty list")
+        for d in hidden_dims:
+            _check_int(d, 1, 10000)
+        for i in range(1, len(hidden_dims)):
+            if hidden_dims[i] > hidden_dims[i - 1]:
+                warnings.warn(f"Hidden dimension {i} ({hidden_dims[i]}) > previous ({hidden_dims[i-1]})")
+        _check_int(num_diffusion_steps, 1, 1000)
+        _check_enum(diffusion_schedule, ["linear", "cosine", "sigmoid"])
+        _check_int(attention_heads, 1, 32)
+        if hidden_dims[-1] % attention_heads != 0:
+            raise ValidationError(f"Hidden dim {hidden_dims[-1]} not divisible by attention heads {attention_heads}")
+        try:
+            dv = float(dropout)
+        except (ValueError, TypeError):
+            raise ValidationError(f"Invalid numeric value: {dropout}")
+        if not 0.0 <= dv <= 0.9:
+            raise ValidationError(f"dropout out of range: {dv}")
+        _check_int(graph_layers, 1, 20)
+        _check_enum(activation, ["relu", "gelu", "elu", "swish"])
+        _check_enum(normalization, ["layer", "batch", "instance", "graph"])
+        _check_enum(pooling, ["mean", "max", "attention", "set2set", "sort"])
+        if num_classes is not None:
+            _check_int(num_classes, 2, 1000)
+        _check_int(regression_targets, 0, 100)
+        # documented deviations: the reference leaks IndexError / ValueError / assert failures for these
+        if graph_layers > len(hidden_dims) + 1:
+            raise ValidationError(f"graph_layers={graph_layers} > len(hidden_dims)+1 cannot be built (reference: IndexError, D2)")
+        if activation == "swish":
+            raise ValidationError("activation 'swish' passes the reference's validation but not its FeatureEncoder")
+        if pooling == "sort":
+            raise ValidationError("Unknown pooling method: sort")
+        for d in hidden_dims:
+            if d % attention_heads != 0:
+                raise ValidationError(f"hidden dim {d} not divisible by attention heads {attention_heads} "
+                                      "(DynamicGraphLayer asserts this, graph_layers.py:135)")
+        if hidden_dims[-1] // attention_heads > 16:
+            raise ValidationError("the fused attention kernels support head_dim <= 16 "
+                                  f"(got {hidden_dims[-1]}/{attention_heads})")
+
+    @staticmethod
+    def _create_pooling_layer(pooling: str, hidden_dim: int, attention_heads: int) -> nn.Module:
+        if pooling == "mean":
+            return GlobalMeanPool()
+        if pooling == "max":
+            return GlobalMaxPool()
+        if pooling == "attention":
+            return GlobalAttentionPool(hidden_dim, attention_heads)
+        if pooling == "set2set":
+            return GlobalSet2SetPool(hidden_dim)
+        raise ValueError(f"Unknown pooling method: {pooling}")
+
+    @staticmethod
+    def _init_weights(module):
+        """dgdm_model.py:259-269: xavier-uniform Linear weights, zero biases, norms (1, 0)."""
+        if isinstance(module, nn.Linear):
+            nn.init.xavier_uniform_(module.weight)
+            if module.bias is not None:
+                nn.init.constant_(module.bias, 0)
+        elif isinstance(module, (nn.BatchNorm2d, nn.LayerNorm, nn.GroupNorm)):
+            nn.init.constant_(module.weight, 1)
+            nn.init.constant_(module.bias, 0)
+
+    # ------------------------------------------------------------------ validation
+    def _validate_forward_inputs(self, data, mode, return_attention, return_embeddings):
+        """dgdm_model.py:646-690.  The reference type-checks torch_geometric Data/Batch; this
+        build duck-types (anything with .x / .edge_index).  All device-side checks are folded
+        into ONE readback."""
+        for attr in ("x", "edge_index"):
+            if getattr(data, attr, None) is None:
+                raise ValidationError(f"Graph data missing required attribute: {attr}")
+        _check_enum(mode, ["inference", "pretrain", "finetune"])
+        for flag in (return_attention, return_embeddings):
+            if not isinstance(flag, (bool, int, float, str)):
+                raise ValidationError(f"Cannot convert to boolean: {type(flag).__name__}")
+        x, ei = data.x, data.edge_index
+        if x.dim() != 2:
+            raise ValidationError(f"Node features must be 2D, got shape {x.shape}")
+        if ei.dim() != 2 or ei.size(0) != 2:
+            raise ValidationError(f"Edge index must be 2xN, got shape {ei.shape}")
+        if x.size(1) != self.node_features:
+            raise ValidationError(f"Expected {self.node_features} node features, got {x.size(1)}")
+        if x.numel() == 0:
+            raise ValidationError("Input features are empty")
+        _lib.require_cuda(x, ei)
+        n = x.size(0)
+        flags = [torch.isnan(x).any(), torch.isinf(x).any()]
+        if ei.numel() > 0:
+            flags += [ei.max() > n - 1, ei.min() < 0]
+        f = torch.stack([t.to(torch.bool) for t in flags]).tolist()  # the one sync
+        if f[0]:
+            raise ValidationError("Node features contain NaN values")
+        if f[1]:
+            raise ValidationError("Node features contain infinity values")
+        if len(f) > 2 and f[2]:
+            raise ValidationError("Edge index contains invalid node indices")
+        if len(f) > 2 and f[3]:
+            raise ValidationError("Edge index contains negative node indices")
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, data, mode: str = "inference", return_attention: bool = False, return_embeddings: bool = False, *,
+                timesteps: Optional[Tensor] = None, noise: Optional[Tensor] = None, noise_target: Optional[Tensor] = None,
+                trace: Optional[dict] = None) -> Dict[str, Any]:
+        try:
+            self._validate_forward_inputs(data, mode, return_attention, return_embeddings)
+        except Exception as e:
+            raise ModelInferenceError(f"Input validation failed: {e}")
+        try:
+            plan = BatchPlan(data, data.x.device)
+            h = self.feature_encoder(data.x)
+            if trace is not None:
+                trace["feature_encoder"] = h
+        except Exception as e:
+            raise ModelInferenceError(f"Feature encoding failed: {e}")
+        try:
+            h = self.graph_encoder(h, plan.ctx)["embeddings"]
+            if trace is not None:
+                trace["graph_encoder"] = h
+        except Exception as e:
+            raise ModelInferenceError(f"Graph encoding failed: {e}")
+        try:
+            return self._forward_continue(h, data, plan, mode, return_attention, return_embeddings, timesteps, noise,
+                                          noise_target, trace)
+        except Exception as e:
+            raise ModelInferenceError(f"Forward pass failed: {e}")
+
+    def _forward_continue(self, h, data, plan: BatchPlan, mode, return_attention, return_embeddings, timesteps, noise,
+                          noise_target, trace):
+        outputs: Dict[str, Any] = {}
+        attention_weights = None
+        pos = getattr(data, "pos", None)
+        if self.spatial_attention is not None and pos is not None:
+            if return_attention:
+                attention_weights = self.spatial_attention.attention_weights(h, pos, plan.attn)
+            h = self.spatial_attention.forward_batch(h, pos, plan.attn)
+            if trace is not None:
+                trace["spatial_attention"] = h
+        if self.hierarchical_processor is not None:
+            h = self.hierarchical_processor(h, plan.ctx, None, plan.seg, trace=trace)
+            if trace is not None:
+                trace["graph_unet"] = h
+        if mode == "pretrain":
+            outputs.update(self._compute_diffusion_loss(h, data, plan=plan, timesteps=timesteps, noise=noise,
+                                                        noise_target=noise_target))
+        g = self.global_pool(h, plan.seg, plan=plan)
+        if self.classification_head is not None and mode in ("inference", "finetune"):
+            logits = self.classification_head(g)
+            outputs["classification_logits"] = logits
+            outputs["classification_probs"] = F.softmax(logits, dim=-1)
+        if self.regression_head is not None and mode in ("inference", "finetune"):
+            outputs["regression_outputs"] = self.regression_head(g)
+        outputs["graph_embedding"] = g
+        if return_embeddings:
+            outputs["node_embeddings"] = h
+        if return_attention and attention_weights is not None:
+            outputs["attention_weights"] = attention_weights
+        return outputs
+
+    def _compute_diffusion_loss(self, node_embeddings: Tensor, data, *, plan: Optional[BatchPlan] = None,
+                                timesteps: Optional[Tensor] = None, noise: Optional[Tensor] = None,
+                                noise_target: Optional[Tensor] = None) -> Dict[str, Tensor]:
+        """dgdm_model.py:405-445 (R3: the diffusion layer sees 2-D [N_g, C] rows), batched over
+        graphs.  ``strict_reference``: the target is a fresh ``randn_like`` (D8), else the
+        injected noise."""
+        plan = plan or BatchPlan(data, node_embeddings.device)
+        dev, B = node_embeddings.device, plan.num_graphs
+        if timesteps is None:
+            timesteps = torch.randint(0, self.num_diffusion_steps, (B,), device=dev)
+        if noise is None:
+            noise = torch.randn_like(node_embeddings)
+        dl = self.diffusion_layer
+        noisy = dl.add_noise_segments(node_embeddings, noise, timesteps, plan.seg)
+        pred = dl.predict_noise_segments(noisy, timesteps, plan.seg)
+        if self.strict_reference:
+            target = torch.randn_like(node_embeddings) if noise_target is None else noise_target
+        else:
+            target = noise
+        # mean over graphs of the per-graph MSE (dgdm_model.py:430-433)
+        sizes = torch.tensor([plan.ptr[g + 1] - plan.ptr[g] for g in range(B)], dtype=torch.float32).to(dev, non_blocking=True)
+        w = (1.0 / (sizes * node_embeddings.size(1) * B))[plan.seg]
+        loss = (((pred - target) ** 2).sum(dim=1) * w).sum()
+        last = slice(plan.ptr[B - 1], plan.ptr[B])
+        return {"diffusion_loss": loss, "noisy_embeddings": noisy[last].unsqueeze(0)}
+
+    # ------------------------------------------------------------------ pretraining
+    def pretrain_step(self, data, mask_ratio: float = 0.15, *, mask_indices: Optional[Tensor] = None,
+                      mask_token: Optional[Tensor] = None, **rng) -> Dict[str, Tensor]:
+        """dgdm_model.py:447-480: entity masking + forward(pretrain); total = diffusion_loss (the
+        reconstruction branch is unreachable in the reference: it tests the unmasked ``data``)."""
+        masked = self._apply_entity_masking(data, mask_ratio, mask_indices, mask_token)
+        outputs = self.forward(masked, mode="pretrain", **rng)
+        outputs["total_pretrain_loss"] = outputs["diffusion_loss"]
+        return outputs
+
+    def _apply_entity_masking(self, data, mask_ratio: float, mask_indices=None, mask_token=None):
+        """dgdm_model.py:482-506: randperm(N)[:int(r*N)] rows <- one fresh randn(F) token."""
+        n = data.x.size(0)
+        num_masked = int(n * mask_ratio)
+        masked = data.clone()
+        if num_masked > 0:
+            dev = data.x.device
+            if mask_indices is None:
+                mask_indices = torch.randperm(n, device=dev)[:num_masked]
+            if mask_token is None:
+                mask_token = torch.randn(data.x.size(1), device=dev)
+            node_mask = torch.zeros(n, dtype=torch.bool, device=dev)
+            node_mask[mask_indices] = True
+            masked.x[mask_indices] = mask_token.to(data.x.dtype)
+            masked.node_mask = node_mask
+        return masked
+
+    def generate_embeddings(self, data, layer: str = "final") -> Tensor:
+        with torch.no_grad():
+            out = self.forward(data, mode="inference", return_embeddings=True)
+            if layer == "final":
+                return out["graph_embedding"]
+            if layer == "node":
+                return out["node_embeddings"]
+            raise ValueError(f"Unknown layer: {layer}")
+
+
+# --------------------------------------------------------------------------- global pools
+def _num_graphs(batch: Optional[Tensor], plan) -> int:
+    if plan is not None:
+        return plan.num_graphs
+    return 1 if batch is None else int(batch.max().item()) + 1
+
+
+def _seg(x: Tensor, batch: Optional[Tensor]) -> Tensor:
+    return batch if batch is not None else torch.zeros(x.size(0), dtype=torch.long, device=x.device)
+
+
+class GlobalMeanPool(nn.Module):
+    """dgdm_model.py:552-567 as one segmented reduction."""
+
+    def forward(self, x: Tensor, batch: Optional[Tensor] = None, plan=None) -> Tensor:
+        B, seg = _num_graphs(batch, plan), _seg(x, batch)
+        s = torch.zeros(B, x.size(1), device=x.device, dtype=x.dtype).index_add_(0, seg, x)
+        cnt = torch.zeros(B, device=x.device, dtype=x.dtype).index_add_(0, seg, torch.ones_like(seg, dtype=x.dtype))
+        return s / cnt.clamp_min(1).unsqueeze(-1)
+
+
+class GlobalMaxPool(nn.Module):
+    """dgdm_model.py:570-585."""
+
+    def forward(self, x: Tensor, batch: Optional[Tensor] = None, plan=None) -> Tensor:
+        B, seg = _num_graphs(batch, plan), _seg(x, batch)
+        out = torch.full((B, x.size(1)), float("-inf"), device=x.device, dtype=x.dtype)
+        out = out.scatter_reduce(0, seg.unsqueeze(-1).expand_as(x), x, "amax")
+        return torch.where(torch.isinf(out), torch.zeros_like(out), out)
+
+
+class GlobalSet2SetPool(nn.Module):
+    """dgdm_model.py:618-642: the reference's "simplified Set2Set" is a mean; the LSTM is unused."""
+
+    def __init__(self, hidden_dim: int, num_layers: int = 2):
+        super().__init__()
+        self.hidden_dim, self.num_layers = hidden_dim, num_layers
+        self.lstm = nn.LSTM(hidden_dim, hidden_dim, num_layers, batch_first=True)
+        self._mean = GlobalMeanPool()
+
+    def forward(self, x: Tensor, batch: Optional[Tensor] = None, plan=None) -> Tensor:
+        return self._mean(x, batch, plan)
+
+
+class GlobalAttentionPool(nn.Module):
+    """One learned query per graph attends over that graph's nodes (dgdm_model.py:588-615), as a
+    segmented softmax over the whole batch instead of a Python loop with boolean masks."""
+
+    def __init__(self, hidden_dim: int, num_heads: int = 8):
+        super().__init__()
+        self.attention = MultiHeadAttention(hidden_dim, num_heads)
+        self.global_token = nn.Parameter(torch.randn(1, 1, hidden_dim))
+
+    def forward(self, x: Tensor, batch: Optional[Tensor] = None, plan=None) -> Tensor:
+        att = self.attention
+        B, seg = _num_graphs(batch, plan), _seg(x, batch)
+        H, d, C = att.num_heads, att.head_dim, att.embed_dim
+        q = att.q_proj(self.global_token.view(1, C)).view(1, H, d)
+        k = att.k_proj(x).view(-1, H, d)
+        v = att.v_proj(x).view(-1, H, d)
+        s = (k * q).sum(-1) / math.sqrt(d)                                         # [N, H]
+        idx = seg.unsqueeze(-1).expand_as(s)
+        m = torch.full((B, H), float("-inf"), device=x.device, dtype=x.dtype).scatter_reduce(0, idx, s.detach(), "amax")
+        e = torch.exp(s - m[seg])
+        den = torch.zeros(B, H, device=x.device, dtype=x.dtype).index_add_(0, seg, e)
+        p = att.attn_dropout(e / den[seg])
+        o = torch.zeros(B, H, d, device=x.device, dtype=x.dtype).index_add_(0, seg, p.unsqueeze(-1) * v)
+        return att.resid_dropout(att.out_proj(o.reshape(B, C)))

@@ -145,3 +145,67 @@ class _SpatialAttention(torch.autograd.Function):
 
 def spatial_attention(qkv, pos, plan: AttnPlan, H: int, scale: float, inv_tau: float = 1.0):
     return _SpatialAttention.apply(qkv, pos, plan, H, scale, inv_tau)
+
+
+# ----------------------------------------------------------------------------- K5 positional encoding
+class _AddPosEnc(torch.autograd.Function):
+    """x + sinusoid(pos) (core/attention.py:225-259,306); d/dx = identity, pos carries no grad."""
+
+    @staticmethod
+    def forward(ctx, x, pos, plan: AttnPlan):
+        return add_posenc_raw(x, pos, plan, x.size(1))
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None, None
+
+
+def add_posenc_raw(x: Optional[torch.Tensor], pos, plan: AttnPlan, C: int) -> torch.Tensor:
+    lib = _lib.load()
+    pos = _f32c(pos)
+    _lib.require_cuda(pos, x)
+    if x is not None:
+        x = _f32c(x)
+    N = pos.size(0)
+    out = torch.empty(N, C, dtype=torch.float32, device=pos.device)
+    ws = torch.empty(2 * max(plan.B, 1), dtype=torch.float32, device=pos.device)
+    _lib.check(lib.dgdm_add_posenc(_lib.ptr(x), x.stride(0) if x is not None else 0, pos.data_ptr(), plan.ptr_dev.data_ptr(),
+                                   plan.B, N, C, ws.data_ptr(), out.data_ptr(), out.stride(0), _lib.stream_ptr(pos.device)),
+               "dgdm_add_posenc")
+    return out
+
+
+def add_posenc(x, pos, plan: AttnPlan):
+    return _AddPosEnc.apply(x, pos, plan)
+
+
+def spatial_attention_mean_weights(qkv, pos, plan: AttnPlan, H: int, scale: float, inv_tau: float = 1.0):
+    """List of head-mean attention matrices [n_g, n_g], one per graph (no grad)."""
+    lib = _lib.load()
+    qkv, pos = _f32c(qkv), _f32c(pos)
+    C = qkv.size(1) // 3
+    q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+    _, lse2 = spatial_attn_fwd_raw(q, k, v, pos, plan, H, scale, inv_tau)
+    sizes = [plan.ptr_host[g + 1] - plan.ptr_host[g] for g in range(plan.B)]
+    offs = [0]
+    for n in sizes:
+        offs.append(offs[-1] + n * n)
+    W = torch.empty(max(offs[-1], 1), dtype=torch.float32, device=qkv.device)
+    off_dev = torch.tensor(offs[:-1], dtype=torch.int64).to(qkv.device)
+    _lib.check(lib.dgdm_spatial_attn_mean_weights(q.data_ptr(), k.data_ptr(), q.stride(0), pos.data_ptr(), plan.ptr_dev.data_ptr(),
+                                                  plan.B, plan.num_q_tiles, plan.N_tot, H, scale, inv_tau, lse2.data_ptr(),
+                                                  W.data_ptr(), off_dev.data_ptr(), _lib.stream_ptr(qkv.device)),
+               "dgdm_spatial_attn_mean_weights")
+    return [W[offs[g]:offs[g + 1]].view(sizes[g], sizes[g]) for g in range(plan.B)]
+
+
+_warned_attn_dropout = False
+
+
+def attention_dropout_unsupported(p: float) -> None:
+    """Placeholder until the in-kernel Philox dropout on attention weights lands."""
+    global _warned_attn_dropout
+    if not _warned_attn_dropout:
+        import warnings
+        warnings.warn(f"attention-weight dropout (p={p}) is not yet applied inside the fused attention kernel")
+        _warned_attn_dropout = True

@@ -56,8 +56,9 @@ DGDM_API const char* dgdm_error_string(int code);
  *   entry of row i).  n_entries = E + (add_loops ? N : 0).
  * Outputs: rowptr int32 [N+1], col int32 [n_entries], eid int32 [n_entries] (original edge id of
  *   each entry).  Bit-exact against oracle/csr_oracle.py::csr_by_key.
- * Ids outside [0,N) are NOT checked on the device (the host boundary validates them,
- * dgdm_model.py:684-690).
+ * Edges with an endpoint outside [0,N) are ignored (never dereferenced): the sync-free top-k
+ * pooling marks dropped edges that way instead of compacting the list (graph_layers.py:322-324),
+ * so col/eid are allocated for n_entries but only the first rowptr[N] entries are defined.
  */
 DGDM_API size_t dgdm_csr_build_workspace_bytes(int64_t E, int32_t N, int32_t add_loops);
 DGDM_API int dgdm_csr_build(const int64_t* edge_index, int64_t E, int32_t N, int32_t add_loops, int32_t by_src,
@@ -122,6 +123,26 @@ DGDM_API int dgdm_spatial_attn_bwd(const float* Q, const float* K, const float* 
                                    int32_t num_q_tiles, int32_t N_tot, int32_t H, float scale, float inv_tau,
                                    const float* lse2, float* dQ, float* dK, float* dV, int64_t ldg, float* delta_ws,
                                    void* stream);
+
+/* Head-mean attention weights per graph (what MultiHeadAttention returns with need_weights,
+ * core/attention.py:171-173; DGDMModel's `attention_weights` output, dgdm_model.py:360-361).
+ * W is one float buffer holding B dense [n_g, n_g] matrices, graph g at element offset
+ * w_offsets[g] (int64 DEVICE array [B]).  Uses lse2 from the forward. */
+DGDM_API int dgdm_spatial_attn_mean_weights(const float* Q, const float* K, int64_t ld, const float* pos, const int32_t* ptr,
+                                            int32_t B, int32_t num_q_tiles, int32_t N_tot, int32_t H, float scale,
+                                            float inv_tau, const float* lse2, float* W, const int64_t* w_offsets,
+                                            void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K5  out = x + sinusoidal_2d_posenc(pos)  for a whole batch.  Replaces
+ * SpatialAttention.get_positional_encoding + the add (core/attention.py:225-259,306): positions
+ * are min-max normalised with ONE global min/max per graph over both coordinates (+1e-8), C/4
+ * frequencies, channels [sin x, cos x, sin y, cos y] interleaved with stride 4.
+ *   x: nullable [N, C] (row stride ldx; NULL -> out = pe); pos [N,2]; ptr int32 [B+1] device;
+ *   minmax_ws: float [2*B] scratch; out [N, C] (row stride ldo).  C % 4 == 0.
+ */
+DGDM_API int dgdm_add_posenc(const float* x, int64_t ldx, const float* pos, const int32_t* ptr, int32_t B, int32_t N,
+                             int32_t C, float* minmax_ws, float* out, int64_t ldo, void* stream);
 
 #ifdef __cplusplus
 }

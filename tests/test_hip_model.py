@@ -1,0 +1,126 @@
+"""GPU parity of the product DGDMModel (HIP path) against (a) the golden vectors captured from
+the reference and (b) the CPU oracle on larger synthetic graphs.  eval() / dropout off, random
+draws injected.  Tolerance: the north star's 1e-3 (conftest.assert_close metric)."""
+import json
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import T, assert_close, load_golden, weights
+from oracle import dgdm_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = 1e-3
+
+
+def _model(cfgd, P):
+    from dgdm_histopath_lab_amd import DGDMModel
+    m = DGDMModel(**cfgd)
+    missing = m.load_state_dict({k: v for k, v in P.items()}, strict=True)
+    return m.to(DEV).eval()
+
+
+def _batch(g):
+    from dgdm_histopath_lab_amd import GraphBatch
+    b = GraphBatch(x=T(g["x"]), edge_index=T(g["edge_index"]), edge_attr=T(g["edge_attr"]), pos=T(g["pos"]))
+    b.batch = T(g["batch"])
+    return b.to(DEV)
+
+
+@pytest.mark.parametrize("tag", ["small", "base"])
+def test_model_matches_reference_golden(tag):
+    g = load_golden(f"g7_model_{tag}")
+    cfgd = json.loads(str(g["cfg_json"]))
+    cfg = O.OracleConfig(**cfgd)
+    if tag == "small":
+        P = weights(g)
+        P["spatial_attention.pos_encoding"] = torch.zeros(O.param_shapes(cfg)["spatial_attention.pos_encoding"])
+    else:
+        P = O.init_params(cfg, seed=int(g["init_seed"]), perturb=float(g["init_perturb"]))
+    m = _model(cfgd, P)
+    data = _batch(g)
+    out = m(data, mode="inference", return_attention=True, return_embeddings=True)
+    assert_close(out["graph_embedding"], g["inf_graph_embedding"], TOL, "graph_embedding")
+    assert_close(out["node_embeddings"], g["inf_node_embeddings"], TOL, "node_embeddings")
+    assert_close(out["attention_weights"][0], g["inf_attn0"], TOL, "attn0")
+    assert_close(out["attention_weights"][1], g["inf_attn1"], TOL, "attn1")
+
+    outp = m.pretrain_step(data, mask_ratio=0.15, mask_indices=T(g["mask_indices"]).to(DEV), mask_token=T(g["mask_token"]).to(DEV),
+                           timesteps=T(g["timesteps"]).to(DEV), noise=T(g["noise"]).to(DEV), noise_target=T(g["noise_target"]).to(DEV))
+    assert set(outp) >= {"diffusion_loss", "total_pretrain_loss", "graph_embedding", "noisy_embeddings"}
+    assert_close(outp["diffusion_loss"], g["pre_diffusion_loss"], TOL, "diffusion_loss")
+    assert_close(outp["graph_embedding"], g["pre_graph_embedding"], TOL, "pre_graph_embedding")
+    assert_close(outp["noisy_embeddings"], g["pre_noisy_embeddings"], TOL, "noisy_embeddings")
+    outp["total_pretrain_loss"].backward()
+    named = dict(m.named_parameters())
+    n = 0
+    for k in g:
+        if k.startswith("grad."):
+            assert_close(named[k[5:]].grad, g[k], TOL, k); n += 1
+        elif k.startswith("gradnorm."):
+            name = k[9:]
+            assert_close(named[name].grad.norm(), g[k], TOL, k)
+            assert_close(named[name].grad.flatten()[:256], g["gradslice." + name], TOL, "gradslice." + name); n += 1
+    assert n == 11
+    assert named["spatial_attention.pos_encoding"].grad is None  # dead parameters stay dead (D9)
+
+
+def test_model_matches_oracle_2k_nodes_all_params():
+    """cfg1-sized graphs (2 x 2000 nodes / 8000 edges), Base dims: every output and EVERY live
+    parameter gradient against the CPU oracle."""
+    from dgdm_histopath_lab_amd.synthetic import synthetic_batch
+    cfgd = dict(node_features=768, hidden_dims=[512, 256, 128], num_diffusion_steps=10, attention_heads=8)
+    cfg = O.OracleConfig(**cfgd)
+    P = O.init_params(cfg, seed=3, perturb=0.05)
+    batch = synthetic_batch(0, 2, 2000, 8000)
+    gen = torch.Generator().manual_seed(11)
+    n = batch.x.size(0)
+    rng = dict(timesteps=torch.tensor([2, 9]), noise=torch.randn(n, 128, generator=gen), noise_target=torch.randn(n, 128, generator=gen))
+    mask_idx = torch.randperm(n, generator=gen)[: int(n * 0.15)]
+    mask_tok = torch.randn(768, generator=gen)
+    torch.set_num_threads(16)
+    ref, gref = O.loss_and_grads(P, cfg, batch, mask_indices=mask_idx, mask_token=mask_tok, **rng)
+    m = _model(cfgd, P)
+    out = m.pretrain_step(batch.to(DEV), mask_indices=mask_idx.to(DEV), mask_token=mask_tok.to(DEV),
+                          **{k: v.to(DEV) for k, v in rng.items()})
+    assert_close(out["diffusion_loss"], ref["diffusion_loss"], TOL, "diffusion_loss")
+    assert_close(out["graph_embedding"], ref["graph_embedding"], TOL, "graph_embedding")
+    assert_close(out["noisy_embeddings"], ref["noisy_embeddings"], TOL, "noisy_embeddings")
+    out["total_pretrain_loss"].backward()
+    named = dict(m.named_parameters())
+    live = 0
+    for k, gr in gref.items():
+        got = named[k].grad
+        assert got is not None, k
+        if gr.abs().max() == 0:
+            assert got.abs().max() < 1e-7, k
+            continue
+        assert_close(got, gr, TOL, "grad " + k); live += 1
+    assert live > 100
+    for k, p in named.items():  # nothing receives a gradient that the oracle leaves dead
+        if k not in gref:
+            assert p.grad is None or p.grad.abs().max() == 0, k
+
+
+def test_model_error_contract():
+    from dgdm_histopath_lab_amd import DGDMModel, GraphData, ModelConfigurationError, ModelInferenceError
+    with pytest.raises(ModelConfigurationError):
+        DGDMModel(hidden_dims=[])
+    with pytest.raises(ModelConfigurationError):
+        DGDMModel(pooling="nope")
+    m = DGDMModel(node_features=32, hidden_dims=[32, 16], attention_heads=1, graph_layers=3).to(DEV).eval()
+    x = torch.randn(10, 32, device=DEV); ei = torch.randint(0, 10, (2, 20), device=DEV)
+    ok = m(GraphData(x=x, edge_index=ei, pos=torch.rand(10, 2, device=DEV)))
+    assert ok["graph_embedding"].shape == (1, 16)
+    bad = x.clone(); bad[0, 0] = float("nan")
+    with pytest.raises(ModelInferenceError, match="NaN"):
+        m(GraphData(x=bad, edge_index=ei))
+    with pytest.raises(ModelInferenceError, match="node features"):
+        m(GraphData(x=torch.randn(10, 31, device=DEV), edge_index=ei))
+    with pytest.raises(ModelInferenceError, match="invalid node indices"):
+        m(GraphData(x=x, edge_index=ei + 5))
+    with pytest.raises(ModelInferenceError):
+        m(GraphData(x=x.cpu(), edge_index=ei.cpu()))  # no CPU fallback
