@@ -115,7 +115,7 @@ class AdaptiveGraphPooling(nn.Module):
 
     Sync-free variant of the edge filter: instead of compacting the edge list (data-dependent
     size) the pooled ``edge_index`` keeps its E columns and dropped edges are marked with the
-    out-of-range id ``k``; the CSR builder ignores out-of-range edges, and ``eid`` still indexes
+    out-of-range id ``-1``; the CSR builder ignores out-of-range edges, and ``eid`` still indexes
     the un-compacted ``edge_attr``.  ``compact=True`` reproduces the reference's compacted
     tensors (one host sync) for callers that need them."""
 
@@ -138,11 +138,12 @@ class AdaptiveGraphPooling(nn.Module):
         pooled_x = x[perm] * s[perm].unsqueeze(-1) * self.multiplier
         node_map = torch.full((n,), -1, dtype=torch.long, device=x.device)
         node_map[perm] = torch.arange(k, device=x.device)
-        mapped = node_map[edge_index]
-        keep = (mapped[0] >= 0) & (mapped[1] >= 0)
+        alive = (edge_index[0] >= 0) & (edge_index[1] >= 0)            # edges dropped by an earlier level are -1
+        mapped = node_map[edge_index.clamp_min(0)]
+        keep = alive & (mapped[0] >= 0) & (mapped[1] >= 0)
         if compact:  # reference layout (graph_layers.py:322-327); boolean indexing syncs
             return pooled_x, mapped[:, keep], (edge_attr[keep] if edge_attr is not None else None), perm
-        pooled_ei = torch.where(keep.unsqueeze(0), mapped, torch.full_like(mapped, k))
+        pooled_ei = torch.where(keep.unsqueeze(0), mapped, torch.full_like(mapped, -1))
         return pooled_x, pooled_ei, edge_attr, perm
 
 
