@@ -90,7 +90,9 @@ class SpatialAttention(nn.Module):
         xp = ops.add_posenc(x, pos, plan)
         qkv = att.fused_qkv(xp)
         o = ops.spatial_attention(qkv, pos, plan, att.num_heads, 1.0 / math.sqrt(att.head_dim), 1.0 / self.temperature)
-        o = att.resid_dropout(att.out_proj(att.unpad_heads(o)))
+        o = ops.act_dropout(att.out_proj(att.unpad_heads(o)), ops.ACT_NONE, att.resid_dropout.p, att.training)
+        if ops.row_norm_supported(self.embed_dim, 1):
+            return ops.row_norm(o, self.norm.weight, self.norm.bias, res=x, eps=self.norm.eps)
         return self.norm(x + o)
 
     def attention_weights(self, x: Tensor, pos: Tensor, plan: ops.AttnPlan) -> List[Tensor]:

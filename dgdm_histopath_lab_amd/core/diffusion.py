@@ -20,6 +20,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch import Tensor
 
+from .. import ops
+
 
 class DiffusionScheduler:
     """Beta schedules and derived tables (reference: diffusion.py:16-61)."""
@@ -91,8 +93,12 @@ class DiffusionLayer(nn.Module):
         per_graph = F.linear(te, lin0.weight[:, C:], lin0.bias)                      # time half of the concat + bias
         h = F.linear(x_noisy, lin0.weight[:, :C]) + per_graph[seg]
         for i in (1, 5):
-            gn, lin = self.denoise_net[i], self.denoise_net[i + 3]
-            h = self.denoise_net[i + 2](F.silu(F.group_norm(h, gn.num_groups, gn.weight, gn.bias, gn.eps)))
+            gn, drop, lin = self.denoise_net[i], self.denoise_net[i + 2], self.denoise_net[i + 3]
+            if ops.row_norm_supported(h.size(1), gn.num_groups):
+                h = ops.row_norm(h, gn.weight, gn.bias, groups=gn.num_groups, eps=gn.eps, act=ops.ACT_SILU, drop_p=drop.p,
+                                 training=self.training)
+            else:  # group width not a multiple of 4 channels: separate GPU ops
+                h = drop(F.silu(F.group_norm(h, gn.num_groups, gn.weight, gn.bias, gn.eps)))
             h = lin(h)
         return h
 

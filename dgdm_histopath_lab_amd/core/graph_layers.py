@@ -104,9 +104,13 @@ class DynamicGraphLayer(nn.Module):
 
     def forward(self, x: Tensor, edge_index: Union[Tensor, GraphContext], edge_attr: Optional[Tensor] = None) -> Tensor:
         ctx = _context(edge_index, x, edge_attr)
-        h = self.dropout(self.activation(self.graph_conv1(x, ctx)))
-        h = self.dropout(self.activation(self.graph_conv2(h, ctx)))
-        return self.norm1(self.output_proj(h) + x)
+        p, tr = self.dropout.p, self.training
+        h = ops.act_dropout(self.graph_conv1(x, ctx), ops.ACT_GELU, p, tr)
+        h = ops.act_dropout(self.graph_conv2(h, ctx), ops.ACT_GELU, p, tr)
+        out = self.output_proj(h)
+        if isinstance(self.norm1, nn.LayerNorm) and ops.row_norm_supported(self.node_dim, 1):
+            return ops.row_norm(out, self.norm1.weight, self.norm1.bias, res=x, eps=self.norm1.eps)
+        return self.norm1(out + x)
 
 
 class AdaptiveGraphPooling(nn.Module):

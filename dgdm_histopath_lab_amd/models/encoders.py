@@ -8,6 +8,7 @@ import torch
 import torch.nn as nn
 from torch import Tensor
 
+from .. import ops
 from ..core.graph_layers import DynamicGraphLayer, GraphContext, GraphConvolution, _context
 
 EDGE_DIM = 32  # the reference hard-codes the edge feature width (encoders.py:183)
@@ -25,6 +26,18 @@ def _norm(kind: str, dim: int) -> nn.Module:
     if kind == "instance":
         return nn.InstanceNorm1d(dim)
     return nn.Identity()
+
+
+def _norm_act_dropout(h: Tensor, norm: nn.Module, act: nn.Module, drop: nn.Dropout, training: bool) -> Tensor:
+    """dropout(act(norm(h))): one fused HIP kernel for LayerNorm + {GELU, ReLU}; other norm kinds
+    (batch / instance / identity) run as separate GPU ops."""
+    aid = ops.act_id(act)
+    if isinstance(norm, nn.LayerNorm) and aid is not None and ops.row_norm_supported(h.size(1), 1):
+        return ops.row_norm(h, norm.weight, norm.bias, eps=norm.eps, act=aid, drop_p=drop.p, training=training)
+    h = norm(h)
+    if aid is not None and h.numel() % 4 == 0:
+        return ops.act_dropout(h, aid, drop.p, training)
+    return drop(act(h))
 
 
 class FeatureEncoder(nn.Module):
@@ -46,7 +59,12 @@ class FeatureEncoder(nn.Module):
         self.residual_proj = nn.Linear(input_dim, hidden_dim) if (use_residual and input_dim != hidden_dim) else None
 
     def forward(self, x: Tensor) -> Tensor:
-        h = self.encoder(x)
+        h = x
+        mods = list(self.encoder)
+        for i in range(0, len(mods), 4):  # (Linear, norm, act, dropout) quadruples
+            lin, norm, act, drop = mods[i:i + 4]
+            h = lin(h)
+            h = _norm_act_dropout(h, norm, act, drop, self.training)
         if self.use_residual:
             h = h + (self.residual_proj(x) if self.residual_proj is not None else x)
         return h
@@ -93,6 +111,6 @@ class GraphEncoder(nn.Module):
             h = layer(h, ctx)
             if str(i) in self.dim_proj:
                 h = self.dim_proj[str(i)](h)
-            h = self.dropout(self.activation(norm(h)))
+            h = _norm_act_dropout(h, norm, self.activation, self.dropout, self.training)
             outs.append(h)
         return {"embeddings": self.output_proj(h), "layer_outputs": outs, "num_nodes": x.size(0)}

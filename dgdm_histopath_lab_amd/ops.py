@@ -209,3 +209,116 @@ def attention_dropout_unsupported(p: float) -> None:
         import warnings
         warnings.warn(f"attention-weight dropout (p={p}) is not yet applied inside the fused attention kernel")
         _warned_attn_dropout = True
+
+
+# ----------------------------------------------------------------------------- K6/K7 fused row kernels
+ACT_NONE, ACT_GELU, ACT_RELU, ACT_SILU = 0, 1, 2, 3
+_ACT_IDS = {"none": ACT_NONE, "gelu": ACT_GELU, "relu": ACT_RELU, "silu": ACT_SILU}
+_seed_counter = 0
+
+
+def next_dropout_seed() -> int:
+    """Host-side counter-based seed (no device sync): reproducible under torch.manual_seed and the
+    order of calls; each dropout site of each step gets its own 32-bit stream id."""
+    global _seed_counter
+    _seed_counter += 1
+    return (torch.initial_seed() * 0x9E3779B1 + _seed_counter * 0x85EBCA6B) & 0xFFFFFFFF
+
+
+def act_id(module_or_name) -> Optional[int]:
+    if module_or_name is None:
+        return ACT_NONE
+    if isinstance(module_or_name, str):
+        return _ACT_IDS.get(module_or_name)
+    import torch.nn as nn
+    if isinstance(module_or_name, nn.GELU):
+        return ACT_GELU if getattr(module_or_name, "approximate", "none") == "none" else None
+    if isinstance(module_or_name, nn.ReLU):
+        return ACT_RELU
+    if isinstance(module_or_name, nn.SiLU):
+        return ACT_SILU
+    if isinstance(module_or_name, nn.Identity):
+        return ACT_NONE
+    return None
+
+
+def row_norm_supported(C: int, groups: int) -> bool:
+    return C % groups == 0 and (C // groups) % 4 == 0 and (C // groups) <= 1024
+
+
+class _RowNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, res, gamma, beta, groups: int, eps: float, act: int, drop_p: float, seed: int):
+        lib = _lib.load()
+        x = _f32c(x)
+        res = _f32c(res) if res is not None else None
+        gamma, beta = _f32c(gamma), _f32c(beta)
+        _lib.require_cuda(x, res, gamma, beta)
+        N, C = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty(N * groups, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        _lib.check(lib.dgdm_rownorm_fwd(x.data_ptr(), _lib.ptr(res), gamma.data_ptr(), beta.data_ptr(), N, C, groups, eps, act,
+                                        drop_p, seed, y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _lib.stream_ptr(x.device)),
+                   "dgdm_rownorm_fwd")
+        ctx.save_for_backward(x, res, gamma, beta, mean, rstd)
+        ctx.meta = (groups, act, drop_p, seed)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.load()
+        x, res, gamma, beta, mean, rstd = ctx.saved_tensors
+        groups, act, drop_p, seed = ctx.meta
+        gy = _f32c(gy)
+        N, C = x.shape
+        dx = torch.empty_like(x)
+        dg, db = torch.empty_like(gamma), torch.empty_like(beta)
+        wsb = lib.dgdm_rownorm_bwd_workspace_bytes(N, C, groups)
+        ws = torch.empty(max(wsb, 4) // 4, dtype=torch.float32, device=x.device)
+        _lib.check(lib.dgdm_rownorm_bwd(x.data_ptr(), _lib.ptr(res), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(),
+                                        rstd.data_ptr(), gy.data_ptr(), N, C, groups, act, drop_p, seed, dx.data_ptr(),
+                                        dg.data_ptr(), db.data_ptr(), ws.data_ptr(), wsb, _lib.stream_ptr(x.device)),
+                   "dgdm_rownorm_bwd")
+        return dx, (dx if res is not None else None), dg, db, None, None, None, None, None
+
+
+def row_norm(x, weight, bias, *, res=None, groups: int = 1, eps: float = 1e-5, act: int = ACT_NONE, drop_p: float = 0.0,
+             training: bool = False):
+    """dropout(act(norm_groups(x [+ res]) * weight + bias)) in one HIP kernel."""
+    p = float(drop_p) if training else 0.0
+    return _RowNorm.apply(x, res, weight, bias, groups, eps, act, p, next_dropout_seed() if p > 0 else 0)
+
+
+class _ActDropout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, act: int, drop_p: float, seed: int):
+        lib = _lib.load()
+        x = _f32c(x)
+        _lib.require_cuda(x)
+        y = torch.empty_like(x)
+        _lib.check(lib.dgdm_act_dropout_fwd(x.data_ptr(), x.numel(), act, drop_p, seed, y.data_ptr(), _lib.stream_ptr(x.device)),
+                   "dgdm_act_dropout_fwd")
+        ctx.save_for_backward(x)
+        ctx.meta = (act, drop_p, seed)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.load()
+        (x,) = ctx.saved_tensors
+        act, drop_p, seed = ctx.meta
+        gy = _f32c(gy)
+        dx = torch.empty_like(x)
+        _lib.check(lib.dgdm_act_dropout_bwd(x.data_ptr(), gy.data_ptr(), x.numel(), act, drop_p, seed, dx.data_ptr(),
+                                            _lib.stream_ptr(x.device)), "dgdm_act_dropout_bwd")
+        return dx, None, None, None
+
+
+def act_dropout(x, act: int = ACT_NONE, drop_p: float = 0.0, training: bool = False):
+    p = float(drop_p) if training else 0.0
+    if act == ACT_NONE and p == 0.0:
+        return x
+    if x.numel() % 4:
+        raise _lib.DGDMKernelError("act_dropout needs numel % 4 == 0")
+    return _ActDropout.apply(x, act, p, next_dropout_seed() if p > 0 else 0)

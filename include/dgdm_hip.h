@@ -144,6 +144,31 @@ DGDM_API int dgdm_spatial_attn_mean_weights(const float* Q, const float* K, int6
 DGDM_API int dgdm_add_posenc(const float* x, int64_t ldx, const float* pos, const int32_t* ptr, int32_t B, int32_t N,
                              int32_t C, float* minmax_ws, float* out, int64_t ldo, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * K6/K7  fused row normalisation  y = dropout(act(norm_G(x [+ res]) * gamma + beta)).
+ * G = 1: LayerNorm (models/encoders.py:73-83,267-269; LayerNorm(out + residual) at
+ * core/graph_layers.py:245 and core/attention.py:325).  G = 8: GroupNorm(8, C) on 2-D [N, C] rows
+ * + SiLU + dropout (core/diffusion.py:96-102).  x, res (nullable), y: contiguous [N, C];
+ * gamma, beta [C]; mean, rstd: [N*G] saved for the backward.  (C/G) % 4 == 0, C/G <= 1024.
+ * Dropout: element e is dropped iff hash(seed, e) < drop_p (16-bit threshold), kept values are
+ * scaled by 1/(1-p); the backward recomputes the mask from the same seed.
+ * Backward: dx (gradient wrt x and, identically, wrt res), dgamma, dbeta via a fixed-order
+ * two-stage reduction through `workspace` (no atomics). */
+DGDM_API int dgdm_rownorm_fwd(const float* x, const float* res, const float* gamma, const float* beta, int32_t N, int32_t C,
+                              int32_t G, float eps, int32_t act, float drop_p, uint32_t seed, float* y, float* mean,
+                              float* rstd, void* stream);
+DGDM_API size_t dgdm_rownorm_bwd_workspace_bytes(int32_t N, int32_t C, int32_t G);
+DGDM_API int dgdm_rownorm_bwd(const float* x, const float* res, const float* gamma, const float* beta, const float* mean,
+                              const float* rstd, const float* dy, int32_t N, int32_t C, int32_t G, int32_t act, float drop_p,
+                              uint32_t seed, float* dx, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
+                              void* stream);
+
+/* y = dropout(act(x)) and dx = dy * mask * act'(x) over n contiguous floats (n % 4 == 0):
+ * the GELU+dropout after each graph convolution (core/graph_layers.py:233-239). */
+DGDM_API int dgdm_act_dropout_fwd(const float* x, int64_t n, int32_t act, float drop_p, uint32_t seed, float* y, void* stream);
+DGDM_API int dgdm_act_dropout_bwd(const float* x, const float* dy, int64_t n, int32_t act, float drop_p, uint32_t seed,
+                                  float* dx, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,82 @@
+"""GPU parity of the fused row kernels (K6/K7) against torch CPU float64 references."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+ACTS = {0: lambda z: z, 1: F.gelu, 2: F.relu, 3: F.silu}
+
+
+@pytest.mark.parametrize("n,c,groups,act,with_res", [
+    (1000, 512, 1, 1, False), (777, 256, 1, 0, True), (5, 128, 1, 1, False), (4001, 128, 1, 0, True), (300, 48, 1, 2, False),
+    (4000, 512, 8, 3, False), (4000, 256, 8, 3, False), (33, 128, 8, 3, False), (64, 64, 8, 3, True), (10, 32, 8, 3, False),
+    (50, 768, 1, 1, False), (9, 1024, 1, 0, False), (20000, 128, 1, 1, True)])
+def test_rownorm_forward_backward(n, c, groups, act, with_res):
+    from dgdm_histopath_lab_amd import ops
+    g = torch.Generator().manual_seed(n + c)
+    x = torch.randn(n, c, generator=g) * 2 + 0.3
+    res = torch.randn(n, c, generator=g) if with_res else None
+    w = torch.randn(c, generator=g) * 0.5 + 1.0
+    b = torch.randn(c, generator=g) * 0.2
+    gy = torch.randn(n, c, generator=g)
+
+    def ref():
+        xs = [t.double().requires_grad_(True) if t is not None else None for t in (x, res, w, b)]
+        v = xs[0] + xs[1] if with_res else xs[0]
+        z = F.layer_norm(v, (c,), xs[2], xs[3], 1e-5) if groups == 1 else F.group_norm(v, groups, xs[2], xs[3], 1e-5)
+        y = ACTS[act](z)
+        y.backward(gy.double())
+        return y.detach(), xs
+    yr, xs = ref()
+    xd, wd, bd = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    rd = res.to(DEV).requires_grad_(True) if with_res else None
+    y = ops.row_norm(xd, wd, bd, res=rd, groups=groups, act=act)
+    y.backward(gy.to(DEV))
+    assert_close(y, yr, 1e-5, "y")
+    assert_close(xd.grad, xs[0].grad, 2e-5, "dx")
+    if with_res:
+        assert_close(rd.grad, xs[1].grad, 2e-5, "dres")
+    assert_close(wd.grad, xs[2].grad, 5e-5, "dgamma")
+    assert_close(bd.grad, xs[3].grad, 5e-5, "dbeta")
+
+
+def test_rownorm_dropout_statistics_and_backward_mask():
+    from dgdm_histopath_lab_amd import ops
+    torch.manual_seed(0)
+    n, c, p = 4096, 256, 0.1
+    x = torch.randn(n, c, device=DEV, requires_grad=True)
+    w = torch.ones(c, device=DEV, requires_grad=True); b = torch.zeros(c, device=DEV, requires_grad=True)
+    y0 = ops.row_norm(x, w, b, act=ops.ACT_GELU)
+    y = ops.row_norm(x, w, b, act=ops.ACT_GELU, drop_p=p, training=True)
+    dropped = (y == 0) & (y0 != 0)
+    frac = dropped.float().mean().item()
+    assert abs(frac - p) < 0.004, frac                     # ~1M Bernoulli draws
+    kept = ~dropped
+    assert_close(y[kept], y0[kept] / (1 - 6553 / 65536), 1e-5, "kept values scaled by 1/(1-p)")
+    # per-row / per-column drop rates are flat (no structure from the hash)
+    assert dropped.float().mean(0).sub(p).abs().max() < 0.03 and dropped.float().mean(1).sub(p).abs().max() < 0.08
+    y.backward(torch.ones_like(y))
+    g1 = x.grad.clone(); x.grad = None
+    y2 = ops.row_norm(x, w, b, act=ops.ACT_GELU, drop_p=p, training=True)
+    assert not torch.equal(y2 == 0, y == 0)                # a new call draws a new mask
+    assert (ops.row_norm(x, w, b, act=ops.ACT_GELU, drop_p=p, training=False) == y0).all()   # eval: no dropout
+    assert torch.isfinite(g1).all()
+
+
+@pytest.mark.parametrize("act", [0, 1, 2, 3])
+def test_act_dropout(act):
+    from dgdm_histopath_lab_amd import ops
+    g = torch.Generator().manual_seed(act)
+    x = torch.randn(1234, 64, generator=g); gy = torch.randn(1234, 64, generator=g)
+    xr = x.double().requires_grad_(True)
+    yr = ACTS[act](xr); yr.backward(gy.double())
+    xd = x.to(DEV).requires_grad_(True)
+    y = ops.act_dropout(xd, act, 0.0, False) if act else ops._ActDropout.apply(xd, 0, 0.0, 0)
+    y.backward(gy.to(DEV))
+    assert_close(y, yr, 1e-5, "y"); assert_close(xd.grad, xr.grad, 1e-5, "dx")
+    torch.manual_seed(1)
+    yd = ops.act_dropout(xd.detach().requires_grad_(True), act, 0.25, True)
+    assert abs((yd == 0).float().mean().item() - ((y == 0).float().mean().item() * 0.75 + 0.25)) < 0.01
