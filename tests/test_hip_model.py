@@ -82,7 +82,13 @@ def test_model_matches_oracle_2k_nodes_all_params():
     mask_idx = torch.randperm(n, generator=gen)[: int(n * 0.15)]
     mask_tok = torch.randn(768, generator=gen)
     torch.set_num_threads(16)
-    ref, gref = O.loss_and_grads(P, cfg, batch, mask_indices=mask_idx, mask_token=mask_tok, **rng)
+    # the arbiter runs in float64 (same oracle code): fp32-vs-fp32 would fold the CPU path's own
+    # rounding (~1e-3 on small cancelling gradients) into the comparison
+    b64 = types.SimpleNamespace(x=batch.x.double(), edge_index=batch.edge_index, edge_attr=batch.edge_attr.double(),
+                                pos=batch.pos.double(), batch=batch.batch)
+    P64 = {k: v.double() for k, v in P.items()}
+    ref, gref = O.loss_and_grads(P64, cfg, b64, mask_indices=mask_idx, mask_token=mask_tok.double(),
+                                 **{k: (v.double() if v.is_floating_point() else v) for k, v in rng.items()})
     m = _model(cfgd, P)
     out = m.pretrain_step(batch.to(DEV), mask_indices=mask_idx.to(DEV), mask_token=mask_tok.to(DEV),
                           **{k: v.to(DEV) for k, v in rng.items()})
