@@ -194,10 +194,18 @@ class GraphUNet(nn.Module):
             if trace is not None:
                 trace[f"perm{i}"] = perm
         x = self.bottom_conv(self.act(x), level(self.depth, x.size(0)))
+        if trace is not None:
+            trace["unet.bottom"] = x
+            for k, t in enumerate(xs):
+                trace[f"unet.xs{k}"] = t
         for i in range(self.depth):
             j = self.depth - 1 - i
             up = torch.zeros(xs[j + 1].size(0), x.size(1), device=x.device, dtype=x.dtype).index_copy(0, perms[j], x)
             x = self.act(up + xs[j + 1])
+            if trace is not None:
+                trace[f"unet.up{i}.in"] = x
             lvl = j + 1 if self.strict_reference else j
             x = self.up_convs[i](x, level(lvl, x.size(0)))
+            if trace is not None:
+                trace[f"unet.up{i}.out"] = x
         return self.final_conv(x)

@@ -358,13 +358,18 @@ def graph_unet(P, cfg: OracleConfig, x, edge_index, edge_attr, training=False, p
             trace[f"perm{i}"] = perm; trace[f"score{i}"] = score; trace[f"edge_index{i+1}"] = ei2
     g, e = level(depth, x.shape[0])
     x = dynamic_graph_layer(P, f"{pre}.bottom_conv", F.relu(x), g, e, p_drop, training)
+    if trace is not None:
+        trace["unet.bottom"] = x
+        for k, t in enumerate(xs): trace[f"unet.xs{k}"] = t
     for i in range(depth):
         j = depth - 1 - i
         up = torch.zeros(xs[j + 1].shape[0], x.shape[1], dtype=dtype).index_copy(0, perms[j], x)
         x = F.relu(up + xs[j + 1])
+        if trace is not None: trace[f"unet.up{i}.in"] = x
         lvl = j + 1 if cfg.strict_reference else j  # D10: graph_layers.py:453 uses edge_indices[j+1]
         gg, ee = level(lvl, x.shape[0])  # level-lvl edge list applied to x.shape[0] nodes
         x = dynamic_graph_layer(P, f"{pre}.up_convs.{i}", x, gg, ee, p_drop, training)
+        if trace is not None: trace[f"unet.up{i}.out"] = x
     return _lin(P, f"{pre}.final_conv", x)
 
 
@@ -556,9 +561,14 @@ def pretrain_step(P, cfg: OracleConfig, data, *, mask_indices=None, mask_token=N
 
 
 def loss_and_grads(P, cfg, data, **kw):
-    """Helper for tests/bench: run pretrain_step with grads on every parameter."""
+    """Helper for tests/bench: run pretrain_step with grads on every parameter (and on every
+    traced activation when a ``trace`` dict is passed)."""
     Pg = {k: v.detach().clone().requires_grad_(True) for k, v in P.items()}
     out = pretrain_step(Pg, cfg, data, **kw)
+    if kw.get("trace") is not None:
+        for t in kw["trace"].values():
+            if isinstance(t, torch.Tensor) and t.requires_grad:
+                t.retain_grad()
     out["total_pretrain_loss"].backward()
     grads = {k: v.grad for k, v in Pg.items() if v.grad is not None}
     return out, grads
