@@ -43,3 +43,20 @@ named = dict(m.named_parameters())
 for k in sorted(Pg):
     if ("up_convs.1" in k or "up_convs.2.graph_conv1" in k) and Pg[k].grad is not None and named[k].grad is not None:
         print("%-64s err %.2e |g| %.2e" % (k, rel(named[k].grad, Pg[k].grad), Pg[k].grad.norm().item()))
+print("---- relu/unpool seam between up1.out and up2.in")
+p0 = tr["perm0"].cpu()
+a_in, b_in = tr["unet.up2.in"].detach().cpu().double(), tr64["unet.up2.in"].detach()
+mism = ((a_in > 0) != (b_in > 0))
+print("relu mask mismatches:", mism.sum().item(), "of", mism.numel(), " | zero outputs gpu", (a_in == 0).sum().item(), "oracle", (b_in == 0).sum().item())
+rows = mism.any(1).nonzero().flatten()
+print("rows with mismatch:", rows[:20].tolist())
+ga, gb = tr["unet.up2.in"].grad.cpu().double(), tr64["unet.up2.in"].grad
+exp_a = (ga * (a_in > 0))[p0]; exp_b = (gb * (b_in > 0))[p0]
+print("gpu   grad(up1.out) vs own relu-gather recompute:", rel(tr["unet.up1.out"].grad, exp_a))
+print("oracle grad(up1.out) vs own relu-gather recompute:", rel(tr64["unet.up1.out"].grad.float(), exp_b))
+d = (tr["unet.up1.out"].grad.cpu().double() - tr64["unet.up1.out"].grad)
+print("rows of up1.out grad with large diff:", (d.norm(dim=1) > 1e-3 * tr64["unet.up1.out"].grad.norm(dim=1).clamp_min(1e-12)).sum().item(), "of", d.shape[0])
+rn = d.norm(dim=1); top = rn.topk(5)
+print("top diff rows", top.indices.tolist(), top.values.tolist(), "their |g|", tr64["unet.up1.out"].grad.norm(dim=1)[top.indices].tolist())
+mi = set(mask_idx.tolist()) if MASK else set()
+print("top rows -> level0 node ids", p0[top.indices].tolist(), "masked?", [int(p0[i]) in mi for i in top.indices.tolist()])
