@@ -187,13 +187,20 @@ class GraphUNet(nn.Module):
         x = self.down_convs[0](x, ctx0)
         xs, perms = [x], []
         for i in range(self.depth):
-            x = self.down_convs[i + 1](self.act(x), level(i, x.size(0)))
+            xr = self.act(x)
+            x = self.down_convs[i + 1](xr, level(i, x.size(0)))
             xs.append(x)
+            if trace is not None:
+                trace[f"relu.down{i}"] = xr
+                trace[f"relu.pool{i}"] = F.relu(self.pools[i].score_net[0](x))
             x, ei, ea, perm = self.pools[i](x, eis[-1], eas[-1], batch)
             eis.append(ei); eas.append(ea); perms.append(perm)
             if trace is not None:
                 trace[f"perm{i}"] = perm
-        x = self.bottom_conv(self.act(x), level(self.depth, x.size(0)))
+        xr = self.act(x)
+        if trace is not None:
+            trace["relu.bottom"] = xr
+        x = self.bottom_conv(xr, level(self.depth, x.size(0)))
         if trace is not None:
             trace["unet.bottom"] = x
             for k, t in enumerate(xs):
@@ -204,6 +211,7 @@ class GraphUNet(nn.Module):
             x = self.act(up + xs[j + 1])
             if trace is not None:
                 trace[f"unet.up{i}.in"] = x
+                trace[f"relu.up{i}"] = x
             lvl = j + 1 if self.strict_reference else j
             x = self.up_convs[i](x, level(lvl, x.size(0)))
             if trace is not None:

@@ -350,14 +350,20 @@ def graph_unet(P, cfg: OracleConfig, x, edge_index, edge_attr, training=False, p
     xs, perms = [x], []
     for i in range(depth):
         g, e = level(i, x.shape[0])  # graph_layers.py:420: edge_indices[-1] == level i here
-        x = dynamic_graph_layer(P, f"{pre}.down_convs.{i+1}", F.relu(x), g, e, p_drop, training)
+        xr = F.relu(x)
+        if trace is not None: trace[f"relu.down{i}"] = xr
+        x = dynamic_graph_layer(P, f"{pre}.down_convs.{i+1}", xr, g, e, p_drop, training)
         xs.append(x)
+        if trace is not None:
+            trace[f"relu.pool{i}"] = F.relu(_lin(P, f"{pre}.pools.{i}.score_net.0", x))
         x, ei2, ea2, perm, score = adaptive_pool(P, f"{pre}.pools.{i}", x, eis[-1], eas[-1])
         eis.append(ei2); eas.append(ea2); perms.append(perm)
         if trace is not None:
             trace[f"perm{i}"] = perm; trace[f"score{i}"] = score; trace[f"edge_index{i+1}"] = ei2
     g, e = level(depth, x.shape[0])
-    x = dynamic_graph_layer(P, f"{pre}.bottom_conv", F.relu(x), g, e, p_drop, training)
+    xr = F.relu(x)
+    if trace is not None: trace["relu.bottom"] = xr
+    x = dynamic_graph_layer(P, f"{pre}.bottom_conv", xr, g, e, p_drop, training)
     if trace is not None:
         trace["unet.bottom"] = x
         for k, t in enumerate(xs): trace[f"unet.xs{k}"] = t
@@ -365,7 +371,7 @@ def graph_unet(P, cfg: OracleConfig, x, edge_index, edge_attr, training=False, p
         j = depth - 1 - i
         up = torch.zeros(xs[j + 1].shape[0], x.shape[1], dtype=dtype).index_copy(0, perms[j], x)
         x = F.relu(up + xs[j + 1])
-        if trace is not None: trace[f"unet.up{i}.in"] = x
+        if trace is not None: trace[f"unet.up{i}.in"] = x; trace[f"relu.up{i}"] = x
         lvl = j + 1 if cfg.strict_reference else j  # D10: graph_layers.py:453 uses edge_indices[j+1]
         gg, ee = level(lvl, x.shape[0])  # level-lvl edge list applied to x.shape[0] nodes
         x = dynamic_graph_layer(P, f"{pre}.up_convs.{i}", x, gg, ee, p_drop, training)

@@ -68,47 +68,86 @@ def test_model_matches_reference_golden(tag):
     assert named["spatial_attention.pos_encoding"].grad is None  # dead parameters stay dead (D9)
 
 
-def test_model_matches_oracle_2k_nodes_all_params():
-    """cfg1-sized graphs (2 x 2000 nodes / 8000 edges), Base dims: every output and EVERY live
-    parameter gradient against the CPU oracle."""
+def _run_both(cfgd, seed0, trace):
+    """One pretrain_step (masking + injected draws) on the HIP path and on the float64 oracle.
+    The arbiter runs in float64 (same oracle code): fp32-vs-fp32 would fold the CPU path's own
+    rounding into the comparison."""
     from dgdm_histopath_lab_amd.synthetic import synthetic_batch
-    cfgd = dict(node_features=768, hidden_dims=[512, 256, 128], num_diffusion_steps=10, attention_heads=8)
     cfg = O.OracleConfig(**cfgd)
     P = O.init_params(cfg, seed=3, perturb=0.05)
-    batch = synthetic_batch(0, 2, 2000, 8000)
-    gen = torch.Generator().manual_seed(11)
+    batch = synthetic_batch(seed0, 2, 2000, 8000)
+    gen = torch.Generator().manual_seed(11 + seed0)
     n = batch.x.size(0)
     rng = dict(timesteps=torch.tensor([2, 9]), noise=torch.randn(n, 128, generator=gen), noise_target=torch.randn(n, 128, generator=gen))
     mask_idx = torch.randperm(n, generator=gen)[: int(n * 0.15)]
     mask_tok = torch.randn(768, generator=gen)
     torch.set_num_threads(16)
-    # the arbiter runs in float64 (same oracle code): fp32-vs-fp32 would fold the CPU path's own
-    # rounding (~1e-3 on small cancelling gradients) into the comparison
     b64 = types.SimpleNamespace(x=batch.x.double(), edge_index=batch.edge_index, edge_attr=batch.edge_attr.double(),
                                 pos=batch.pos.double(), batch=batch.batch)
-    P64 = {k: v.double() for k, v in P.items()}
-    ref, gref = O.loss_and_grads(P64, cfg, b64, mask_indices=mask_idx, mask_token=mask_tok.double(),
-                                 **{k: (v.double() if v.is_floating_point() else v) for k, v in rng.items()})
+    tr64 = {} if trace else None
+    ref, gref = O.loss_and_grads({k: v.double() for k, v in P.items()}, cfg, b64, mask_indices=mask_idx, mask_token=mask_tok.double(),
+                                 trace=tr64, **{k: (v.double() if v.is_floating_point() else v) for k, v in rng.items()})
     m = _model(cfgd, P)
-    out = m.pretrain_step(batch.to(DEV), mask_indices=mask_idx.to(DEV), mask_token=mask_tok.to(DEV),
+    tr = {} if trace else None
+    out = m.pretrain_step(batch.to(DEV), mask_indices=mask_idx.to(DEV), mask_token=mask_tok.to(DEV), trace=tr,
                           **{k: v.to(DEV) for k, v in rng.items()})
-    assert_close(out["diffusion_loss"], ref["diffusion_loss"], TOL, "diffusion_loss")
-    assert_close(out["graph_embedding"], ref["graph_embedding"], TOL, "graph_embedding")
-    assert_close(out["noisy_embeddings"], ref["noisy_embeddings"], TOL, "noisy_embeddings")
     out["total_pretrain_loss"].backward()
+    return m, out, ref, gref, tr, tr64
+
+
+def _assert_all_grads(m, gref, tol):
     named = dict(m.named_parameters())
     live = 0
     for k, gr in gref.items():
         got = named[k].grad
         assert got is not None, k
-        if gr.abs().max() == 0:
+        if gr.abs().max() < 1e-12:  # dead-by-construction (e.g. k_proj.bias: softmax is shift invariant)
             assert got.abs().max() < 1e-7, k
             continue
-        assert_close(got, gr, TOL, "grad " + k); live += 1
-    assert live > 100
-    for k, p in named.items():  # nothing receives a gradient that the oracle leaves dead
+        assert_close(got, gr, tol, "grad " + k); live += 1
+    for k, p in named.items():  # nothing receives a gradient that the oracle leaves dead (D9)
         if k not in gref:
             assert p.grad is None or p.grad.abs().max() == 0, k
+    return live
+
+
+def test_smooth_model_matches_oracle_2k_nodes_all_params():
+    """cfg1-sized graphs (2 x 2000 nodes / 8000 edges), Base dims, use_hierarchical=False: the
+    network is smooth (GELU / SiLU / softmax, no ReLU, no top-k), so EVERY live parameter gradient
+    must agree with the exact (float64) oracle well inside the 1e-3 contract."""
+    cfgd = dict(node_features=768, hidden_dims=[512, 256, 128], num_diffusion_steps=10, attention_heads=8, use_hierarchical=False)
+    m, out, ref, gref, _, _ = _run_both(cfgd, 0, trace=False)
+    for k in ("diffusion_loss", "graph_embedding", "noisy_embeddings"):
+        assert_close(out[k], ref[k], 1e-4, k)
+    assert _assert_all_grads(m, gref, 1e-4) > 60
+
+
+def test_full_model_matches_oracle_2k_nodes_all_params():
+    """Same with the graph U-Net (ReLU + top-k pooling: discrete decisions).  Outputs must agree to
+    1e-3 always.  Gradients of a ReLU network are discontinuous at the kinks: an element whose
+    pre-activation lies within fp32 rounding (~1e-6) of zero can fall on the other side than in
+    exact arithmetic, which perturbs upstream gradients by O(that element's share), for ANY fp32
+    implementation (measured: 2 of 512,000 decisions at this size).  So the kink decisions are
+    compared first (traced post-ReLU tensors and top-k perms); on an instance where they all
+    coincide every gradient must meet the 1e-3 contract; an instance with a flip is skipped
+    (next synthetic seed), at most 4 times."""
+    cfgd = dict(node_features=768, hidden_dims=[512, 256, 128], num_diffusion_steps=10, attention_heads=8)
+    for attempt in range(4):
+        m, out, ref, gref, tr, tr64 = _run_both(cfgd, 10 * attempt, trace=True)
+        for k in ("diffusion_loss", "graph_embedding", "noisy_embeddings"):
+            assert_close(out[k], ref[k], TOL, k)
+        for k in ("feature_encoder", "graph_encoder", "spatial_attention", "graph_unet"):
+            assert_close(tr[k], tr64[k], TOL, k)
+        flips = 0
+        for k, v in tr64.items():
+            if k.startswith("perm"):
+                assert torch.equal(tr[k].cpu(), v), f"{k}: top-k selection differs"      # bit-exact index work
+            if k.startswith("relu."):
+                flips += int(((tr[k].detach().cpu() > 0) != (v.detach() > 0)).sum())
+        if flips == 0:
+            assert _assert_all_grads(m, gref, TOL) > 100
+            return
+    pytest.fail("no kink-flip-free instance in 4 attempts")
 
 
 def test_model_error_contract():
