@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""Headline benchmark: slides/s of the DGDM hot path (pretrain_step forward + backward) on
+synthetic tissue graphs, MI355X HIP path.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1] per GPU; configs[2] is the same per-GPU work at 8 GPUs =>
+weak scaling): DGDM-Base (node_features=768, hidden=[512,256,128], T=10, heads=8, all defaults of
+DGDMModel incl. dropout 0.1, spatial attention, graph U-Net, attention pooling), training mode,
+batch of 4 synthetic graphs of 10 000 nodes / 50 000 directed edges per GPU, edge_attr [E,32],
+pos [N,2]; inputs resident in HBM before the timed region.  One step = entity masking +
+forward(pretrain) + backward of diffusion_loss (+ RCCL all-reduce of the flat gradient buffer when
+N > 1) + AdamW step.  fp32 throughout.
+
+Prints ONE JSON line (rank 0).  Extra objects: `roofline` (dominant kernel, HIP events on the
+launch stream inside the timed region), `gather_roofline` (the north star's message-passing
+gather at 10k x 768), `cpu_baseline` (the CPU oracle = port of the reference path, timed on the
+host cores on a bounded sample; rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+NODES, EDGES, FEATS, PER_GPU_BATCH = 10000, 50000, 768, 4
+MODEL_CFG = dict(node_features=FEATS, hidden_dims=[512, 256, 128], num_diffusion_steps=10, attention_heads=8)
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md, dense fp32 matrix peak
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md, HBM3E spec
+
+
+def attention_flops(num_graph_nodes, heads, head_dim, products):
+    """2*N^2*H*d FLOP per QK^T-sized product, `products` of them per kernel."""
+    return sum(2.0 * n * n * heads * head_dim * products for n in num_graph_nodes)
+
+
+def gather_bytes(n, e, c):
+    ent = e + n
+    return ent * c * 4 + n * c * 4 + ent * 8 + (n + 1) * 4
+
+
+def gather_microbench(dev, iters=200):
+    from dgdm_histopath_lab_amd import GraphStructure, ops
+    from dgdm_histopath_lab_amd.synthetic import synthetic_graph
+    g = synthetic_graph(0, NODES, EDGES, 8)
+    gs = GraphStructure(g.edge_index.to(dev), NODES)
+    x = torch.randn(NODES, FEATS, device=dev)
+    y = torch.empty_like(x)
+    for _ in range(20):
+        ops.spmm_raw(gs.rowptr, gs.col, gs.w, x, NODES, out=y)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); a.record()
+    for _ in range(iters):
+        ops.spmm_raw(gs.rowptr, gs.col, gs.w, x, NODES, out=y)
+    b.record(); torch.cuda.synchronize()
+    us = a.elapsed_time(b) * 1e3 / iters
+    by = gather_bytes(NODES, EDGES, FEATS)
+    return {"kernel": "dgdm_spmm (k_spmm<64,3,4>)", "workload": f"{NODES} nodes x {FEATS} feat, {EDGES}+{NODES} entries",
+            "bound": "hbm", "achieved": round(by / us / 1e3, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(by / us / 1e3 / HBM_PEAK_GBPS, 4), "traffic": None, "us_per_launch": round(us, 2),
+            "algorithmic_bytes": by}
+
+
+def cpu_baseline(nodes, edges):
+    """CPU oracle (port of the reference path incl. its dense attention + dropout) on ONE slide,
+    one fwd+bwd step after one warm-up step at a reduced size."""
+    from oracle import dgdm_oracle as O
+    from dgdm_histopath_lab_amd.synthetic import synthetic_batch
+    cores = os.cpu_count() or 1
+    threads = max(1, cores // 2) if cores > 16 else cores  # physical cores on SMT hosts
+    torch.set_num_threads(threads)
+    cfg = O.OracleConfig(**MODEL_CFG)
+    P = O.init_params(cfg, seed=0)
+
+    def step(n, e):
+        b = synthetic_batch(0, 1, n, e, FEATS)
+        idx = torch.randperm(n)[: int(0.15 * n)]
+        t0 = time.perf_counter()
+        O.loss_and_grads(P, cfg, b, mask_indices=idx, mask_token=torch.randn(FEATS), training=True)
+        return time.perf_counter() - t0
+    step(1000, 4000)  # warm-up (thread pool, allocator)
+    dt = step(nodes, edges)
+    return {"value": round(1.0 / dt, 5), "unit": "slides/s", "cores": threads, "kind": "port",
+            "sample": f"1 slide of {nodes} nodes / {edges} edges, 1 fwd+bwd step (training mode, dropout 0.1), "
+                      f"CPU oracle = restatement of the reference path, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="slides per GPU")
+    ap.add_argument("--nodes", type=int, default=NODES)
+    ap.add_argument("--edges", type=int, default=EDGES)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--eval-mode", action="store_true", help="dropout off (diagnostics only; not the headline)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py needs a GPU (the HIP path has no CPU fallback)", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import torch.distributed as dist
+    from dgdm_histopath_lab_amd import DGDMModel, ops
+    from dgdm_histopath_lab_amd.parallel import FlatGradAllReducer
+    from dgdm_histopath_lab_amd.synthetic import synthetic_batch
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    torch.manual_seed(0)
+    model = DGDMModel(**MODEL_CFG).to(dev)
+    model.train(not args.eval_mode)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-5)  # training/trainer.py:221-226 defaults
+    reducer = FlatGradAllReducer(model, world) if world > 1 else None
+    # rank r owns slides [r*B, (r+1)*B): independent units, no data-path collective
+    batch = synthetic_batch(rank * args.batch, args.batch, args.nodes, args.edges, FEATS).to(dev)
+    sizes = [args.nodes] * args.batch
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out = model.pretrain_step(batch, mask_ratio=0.15)
+        out["total_pretrain_loss"].backward()
+        if reducer is not None:
+            reducer.all_reduce()
+        opt.step()
+        return out["total_pretrain_loss"]
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ops.TIMERS.start(["attn_fwd", "attn_bwd_dq", "attn_bwd_dkv", "spmm_c512"])
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ops.TIMERS.stop()
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss_val = float(loss.item())
+
+    result = None
+    if rank == 0:
+        timers = ops.TIMERS.summary()
+        heads, hd = MODEL_CFG["attention_heads"], 16
+        flops = {"attn_fwd": attention_flops(sizes, heads, hd, 2), "attn_bwd_dq": attention_flops(sizes, heads, hd, 3),
+                 "attn_bwd_dkv": attention_flops(sizes, heads, hd, 4)}
+        kernels = {"attn_fwd": "k_attn_fwd<4,64>", "attn_bwd_dq": "k_attn_bwd_dq<4,64>", "attn_bwd_dkv": "k_attn_bwd_dkv<4,32>"}
+        dom = max((k for k in flops if k in timers), key=lambda k: timers[k][1])
+        ms = timers[dom][1]
+        tf = flops[dom] / (ms * 1e-3) / 1e12
+        roofline = {"kernel": kernels[dom], "bound": "mfma", "achieved": round(tf, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "ms_per_launch": round(ms, 4), "launches_timed": timers[dom][0], "algorithmic_flop": flops[dom],
+                    "other_kernels_ms": {k: round(v[1], 4) for k, v in timers.items() if k != dom}}
+        result = {
+            "metric": "slides/sec (DGDM fwd+bwd, 10k-node/768-feat graphs)", "value": round(world * args.batch * args.steps / dt, 3),
+            "unit": "slides/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"DGDM-Base pretrain_step fwd+bwd+AdamW, batch={args.batch} x {args.nodes}-node/{args.edges}-edge "
+                                   f"graphs per GPU, feat={FEATS}, edge_attr=32, T=10, heads=8, "
+                                   f"{'eval (dropout off)' if args.eval_mode else 'training mode (dropout 0.1)'}",
+                       "global_batch": world * args.batch, "parallelism": f"dp{world}", "final_loss": round(loss_val, 5)},
+            "roofline": roofline,
+        }
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        if not args.no_gather:
+            result["gather_roofline"] = gather_microbench(dev)
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(args.nodes, args.edges)
+        print(json.dumps(result), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -41,6 +41,10 @@ SIGNATURES = {
     "dgdm_rownorm_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, C.c_float, C.c_uint32, _p, _p, _p, _p, _sz, _p]),
     "dgdm_act_dropout_fwd": (C.c_int, [_p, _i64, _i32, C.c_float, C.c_uint32, _p, _p]),
     "dgdm_act_dropout_bwd": (C.c_int, [_p, _p, _i64, _i32, C.c_float, C.c_uint32, _p, _p]),
+    "dgdm_spatial_attn_bwd_dq": (C.c_int, [_p, _p, _p, _i64, _p, _p, _i64, _p, _p, _i32, _i32, _i32, _i32, C.c_float, C.c_float,
+                                           _p, _p, _i64, _p, _p]),
+    "dgdm_spatial_attn_bwd_dkv": (C.c_int, [_p, _p, _p, _i64, _p, _i64, _p, _p, _i32, _i32, _i32, _i32, C.c_float, C.c_float,
+                                            _p, _p, _p, _p, _i64, _p]),
     "dgdm_spmm": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _p, _i64, _i32, _i32, _p, _i32, _p]),
 }
 

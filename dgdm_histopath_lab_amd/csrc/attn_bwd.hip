@@ -306,30 +306,69 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv(const float* __restrict
 
 }  // namespace
 
+static int check_bwd_common(const void* Q, const void* K, const void* V, const void* dO, const void* pos, const void* ptr,
+                            const void* lse2, int64_t ld, int64_t ldo, int64_t ldg, int32_t B, int32_t N_tot, int32_t H,
+                            int32_t num_q_tiles) {
+  if (B < 0 || N_tot < 0 || H <= 0 || num_q_tiles < 0) return DGDM_ERR_INVALID_ARG;
+  if (N_tot == 0 || num_q_tiles == 0) return 1;  // nothing to do
+  if (!Q || !K || !V || !dO || !pos || !ptr || !lse2) return DGDM_ERR_INVALID_ARG;
+  if ((ld & 3) || (ldo & 3) || (ldg & 3) || ld < H * 16 || ldo < H * 16 || ldg < H * 16) return DGDM_ERR_UNSUPPORTED;
+  if (!dgdm_aligned16(Q) || !dgdm_aligned16(K) || !dgdm_aligned16(V) || !dgdm_aligned16(dO) ||
+      (reinterpret_cast<uintptr_t>(pos) & 7u))
+    return DGDM_ERR_UNSUPPORTED;
+  return DGDM_OK;
+}
+
+// pass 1: dQ (+ delta = rowsum(dO*O) into delta_ws)
+extern "C" int dgdm_spatial_attn_bwd_dq(const float* Q, const float* K, const float* V, int64_t ld, const float* O,
+                                        const float* dO, int64_t ldo, const float* pos, const int32_t* ptr, int32_t B,
+                                        int32_t num_q_tiles, int32_t N_tot, int32_t H, float scale, float inv_tau,
+                                        const float* lse2, float* dQ, int64_t ldg, float* delta_ws, void* stream_) {
+  int rc = check_bwd_common(Q, K, V, dO, pos, ptr, lse2, ld, ldo, ldg, B, N_tot, H, num_q_tiles);
+  if (rc != DGDM_OK) return rc > 0 ? DGDM_OK : rc;
+  DGDM_REQUIRE(O && dQ && delta_ws);
+  if (!dgdm_aligned16(O) || !dgdm_aligned16(dQ)) return DGDM_ERR_UNSUPPORTED;
+  hipStream_t s = static_cast<hipStream_t>(stream_);
+  const float qscale = scale * DGDM_LOG2E, bscale = inv_tau * DGDM_LOG2E;
+#define GO(HG, KB)                                                                                                  \
+  hipLaunchKernelGGL((k_attn_bwd_dq<HG, KB>), dim3(num_q_tiles, H / HG), dim3(256), 0, s, Q, K, V, ld, O, dO, ldo, \
+                     pos, ptr, B, lse2, qscale, bscale, scale, dQ, ldg, delta_ws, N_tot)
+  if (H % 4 == 0) GO(4, 64);
+  else if (H % 2 == 0) GO(2, 64);
+  else GO(1, 64);
+#undef GO
+  return dgdm_launch_status();
+}
+
+// pass 2: dK, dV (reads delta_ws written by pass 1 on the same stream)
+extern "C" int dgdm_spatial_attn_bwd_dkv(const float* Q, const float* K, const float* V, int64_t ld, const float* dO,
+                                         int64_t ldo, const float* pos, const int32_t* ptr, int32_t B, int32_t num_q_tiles,
+                                         int32_t N_tot, int32_t H, float scale, float inv_tau, const float* lse2,
+                                         const float* delta_ws, float* dK, float* dV, int64_t ldg, void* stream_) {
+  int rc = check_bwd_common(Q, K, V, dO, pos, ptr, lse2, ld, ldo, ldg, B, N_tot, H, num_q_tiles);
+  if (rc != DGDM_OK) return rc > 0 ? DGDM_OK : rc;
+  DGDM_REQUIRE(delta_ws && dK && dV);
+  if (!dgdm_aligned16(dK) || !dgdm_aligned16(dV)) return DGDM_ERR_UNSUPPORTED;
+  hipStream_t s = static_cast<hipStream_t>(stream_);
+  const float qscale = scale * DGDM_LOG2E, bscale = inv_tau * DGDM_LOG2E;
+#define GO(HG, QBK)                                                                                                 \
+  hipLaunchKernelGGL((k_attn_bwd_dkv<HG, QBK>), dim3(num_q_tiles, H / HG), dim3(256), 0, s, Q, K, V, ld, dO, ldo,  \
+                     pos, ptr, B, lse2, delta_ws, qscale, bscale, scale, dK, dV, ldg, N_tot)
+  if (H % 4 == 0) GO(4, 32);
+  else if (H % 2 == 0) GO(2, 64);
+  else GO(1, 64);
+#undef GO
+  return dgdm_launch_status();
+}
+
 extern "C" int dgdm_spatial_attn_bwd(const float* Q, const float* K, const float* V, int64_t ld, const float* O,
                                      const float* dO, int64_t ldo, const float* pos, const int32_t* ptr, int32_t B,
                                      int32_t num_q_tiles, int32_t N_tot, int32_t H, float scale, float inv_tau,
                                      const float* lse2, float* dQ, float* dK, float* dV, int64_t ldg, float* delta_ws,
-                                     void* stream_) {
-  DGDM_REQUIRE(B >= 0 && N_tot >= 0 && H > 0 && num_q_tiles >= 0);
-  if (N_tot == 0 || num_q_tiles == 0) return DGDM_OK;
-  DGDM_REQUIRE(Q && K && V && O && dO && pos && ptr && lse2 && dQ && dK && dV && delta_ws);
-  if ((ld & 3) || (ldo & 3) || (ldg & 3) || ld < H * 16 || ldo < H * 16 || ldg < H * 16) return DGDM_ERR_UNSUPPORTED;
-  if (!dgdm_aligned16(Q) || !dgdm_aligned16(K) || !dgdm_aligned16(V) || !dgdm_aligned16(O) || !dgdm_aligned16(dO) ||
-      !dgdm_aligned16(dQ) || !dgdm_aligned16(dK) || !dgdm_aligned16(dV) || (reinterpret_cast<uintptr_t>(pos) & 7u))
-    return DGDM_ERR_UNSUPPORTED;
-  hipStream_t s = static_cast<hipStream_t>(stream_);
-  const float qscale = scale * DGDM_LOG2E, bscale = inv_tau * DGDM_LOG2E;
-#define GO(HG, KB, QBK)                                                                                              \
-  do {                                                                                                               \
-    hipLaunchKernelGGL((k_attn_bwd_dq<HG, KB>), dim3(num_q_tiles, H / HG), dim3(256), 0, s, Q, K, V, ld, O, dO, ldo,  \
-                       pos, ptr, B, lse2, qscale, bscale, scale, dQ, ldg, delta_ws, N_tot);                          \
-    hipLaunchKernelGGL((k_attn_bwd_dkv<HG, QBK>), dim3(num_q_tiles, H / HG), dim3(256), 0, s, Q, K, V, ld, dO, ldo,   \
-                       pos, ptr, B, lse2, delta_ws, qscale, bscale, scale, dK, dV, ldg, N_tot);                      \
-  } while (0)
-  if (H % 4 == 0) GO(4, 64, 32);
-  else if (H % 2 == 0) GO(2, 64, 64);
-  else GO(1, 64, 64);
-#undef GO
-  return dgdm_launch_status();
+                                     void* stream) {
+  int rc = dgdm_spatial_attn_bwd_dq(Q, K, V, ld, O, dO, ldo, pos, ptr, B, num_q_tiles, N_tot, H, scale, inv_tau, lse2, dQ, ldg,
+                                    delta_ws, stream);
+  if (rc != DGDM_OK) return rc;
+  return dgdm_spatial_attn_bwd_dkv(Q, K, V, ld, dO, ldo, pos, ptr, B, num_q_tiles, N_tot, H, scale, inv_tau, lse2, delta_ws, dK,
+                                   dV, ldg, stream);
 }

@@ -13,6 +13,38 @@ from . import _lib
 from .graph import GraphStructure
 
 
+class KernelTimers:
+    """Optional per-kernel timing with HIP events recorded on the stream the kernels are launched
+    on (torch's current stream).  Used by bench.py for the roofline leg; off by default."""
+
+    def __init__(self):
+        self.enabled = False
+        self.events = {}
+
+    def start(self, names=None):
+        self.enabled, self.events, self.names = True, {}, (set(names) if names else None)
+
+    def stop(self):
+        self.enabled = False
+
+    def timed(self, name, fn):
+        if not self.enabled or (self.names is not None and name not in self.names):
+            return fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        r = fn()
+        b.record()
+        self.events.setdefault(name, []).append((a, b))
+        return r
+
+    def summary(self):
+        """name -> (launches, mean_ms).  Call after torch.cuda.synchronize()."""
+        return {k: (len(v), sum(a.elapsed_time(b) for a, b in v) / len(v)) for k, v in self.events.items()}
+
+
+TIMERS = KernelTimers()
+
+
 def _f32c(t: torch.Tensor) -> torch.Tensor:
     if t.dtype != torch.float32:
         raise _lib.DGDMKernelError(f"HIP kernels compute in fp32, got {t.dtype}")
@@ -33,9 +65,11 @@ def spmm_raw(rowptr, col, w, X, num_rows: int, *, table_rows: Optional[int] = No
         out = torch.empty(num_rows, C, dtype=torch.float32, device=X.device)
     assert out.stride(1) == 1 and out.size(1) == C and out.size(0) == num_rows
     tr = X.size(0) if table_rows is None else table_rows
-    _lib.check(lib.dgdm_spmm(rowptr.data_ptr(), col.data_ptr(), w.data_ptr(), X.data_ptr() if X.numel() else None, X.stride(0) if X.size(0) > 1 else max(C, X.stride(0)), tr,
-                             out.data_ptr(), out.stride(0) if out.size(0) > 1 else max(C, out.stride(0)), num_rows, C, _lib.ptr(bias), int(accumulate),
-                             _lib.stream_ptr(X.device)), "dgdm_spmm")
+    ldx = X.stride(0) if X.size(0) > 1 else max(C, X.stride(0))
+    ldy = out.stride(0) if out.size(0) > 1 else max(C, out.stride(0))
+    TIMERS.timed(f"spmm_c{C}", lambda: _lib.check(
+        lib.dgdm_spmm(rowptr.data_ptr(), col.data_ptr(), w.data_ptr(), X.data_ptr() if X.numel() else None, ldx, tr,
+                      out.data_ptr(), ldy, num_rows, C, _lib.ptr(bias), int(accumulate), _lib.stream_ptr(X.device)), "dgdm_spmm"))
     return out
 
 
@@ -97,10 +131,11 @@ def spatial_attn_fwd_raw(q, k, v, pos, plan: AttnPlan, H: int, scale: float, inv
     pos = _f32c(pos)
     out = torch.empty(N, C, dtype=torch.float32, device=q.device)
     lse2 = torch.empty(H, N, dtype=torch.float32, device=q.device)
-    _lib.check(lib.dgdm_spatial_attn_fwd_variant(q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), pos.data_ptr(),
-                                                 plan.ptr_dev.data_ptr(), plan.B, plan.num_q_tiles, N, H, scale, inv_tau,
-                                                 out.data_ptr(), out.stride(0), lse2.data_ptr(), variant,
-                                                 _lib.stream_ptr(q.device)), "dgdm_spatial_attn_fwd")
+    TIMERS.timed("attn_fwd", lambda: _lib.check(
+        lib.dgdm_spatial_attn_fwd_variant(q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), pos.data_ptr(),
+                                          plan.ptr_dev.data_ptr(), plan.B, plan.num_q_tiles, N, H, scale, inv_tau, out.data_ptr(),
+                                          out.stride(0), lse2.data_ptr(), variant, _lib.stream_ptr(q.device)),
+        "dgdm_spatial_attn_fwd"))
     return out, lse2
 
 
@@ -111,11 +146,17 @@ def spatial_attn_bwd_raw(q, k, v, out, gout, pos, plan: AttnPlan, H: int, scale:
     gout = _f32c(gout)
     delta = torch.empty(H, N, dtype=torch.float32, device=q.device)
     assert out.stride(0) == gout.stride(0) and dqkv.stride(1) == 1
-    _lib.check(lib.dgdm_spatial_attn_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), out.data_ptr(), gout.data_ptr(),
-                                         out.stride(0), pos.data_ptr(), plan.ptr_dev.data_ptr(), plan.B, plan.num_q_tiles, N, H,
-                                         scale, inv_tau, lse2.data_ptr(), dqkv[:, :C].data_ptr(), dqkv[:, C:2 * C].data_ptr(),
-                                         dqkv[:, 2 * C:].data_ptr(), dqkv.stride(0), delta.data_ptr(),
-                                         _lib.stream_ptr(q.device)), "dgdm_spatial_attn_bwd")
+    st = _lib.stream_ptr(q.device)
+    TIMERS.timed("attn_bwd_dq", lambda: _lib.check(
+        lib.dgdm_spatial_attn_bwd_dq(q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), out.data_ptr(), gout.data_ptr(),
+                                     out.stride(0), pos.data_ptr(), plan.ptr_dev.data_ptr(), plan.B, plan.num_q_tiles, N, H, scale,
+                                     inv_tau, lse2.data_ptr(), dqkv[:, :C].data_ptr(), dqkv.stride(0), delta.data_ptr(), st),
+        "dgdm_spatial_attn_bwd_dq"))
+    TIMERS.timed("attn_bwd_dkv", lambda: _lib.check(
+        lib.dgdm_spatial_attn_bwd_dkv(q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), gout.data_ptr(), out.stride(0),
+                                      pos.data_ptr(), plan.ptr_dev.data_ptr(), plan.B, plan.num_q_tiles, N, H, scale, inv_tau,
+                                      lse2.data_ptr(), delta.data_ptr(), dqkv[:, C:2 * C].data_ptr(), dqkv[:, 2 * C:].data_ptr(),
+                                      dqkv.stride(0), st), "dgdm_spatial_attn_bwd_dkv"))
     return dqkv
 
 

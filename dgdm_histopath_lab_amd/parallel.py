@@ -1,0 +1,86 @@
+"""Data-parallel harness for the DGDM hot path: one process per GPU, slides sharded across
+ranks, ONE all-reduce of a flat fp32 gradient buffer per step over RCCL/xGMI
+(`torch.distributed` backend "nccl" == RCCL on ROCm).
+
+The reference gets data parallelism implicitly from Lightning's DDP (cli/train.py:346-359) and
+would fail there: ~46 % of DGDMModel's parameters never receive a gradient (dead
+``node_to_qkv`` / ``edge_to_key`` / ``norm2`` / ``pos_encoding`` / ``spatial_proj``, SURVEY.md 2b,
+D9) and no ``find_unused_parameters`` is set.  Here only parameters that actually carry a gradient
+enter the buffer (Base: 14.6 MB instead of 28.5 MB).  Graphs never interact inside a batch
+(block-diagonal edges, per-graph attention / loss / pooling), so there is no data-path
+collective; the only exchange is the gradient sum.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+class FlatGradAllReducer:
+    """Average gradients across ranks with a single all-reduce.
+
+    The set of live parameters is fixed at the first call (same on every rank: same model, same
+    mode) and checked afterwards.  xGMI is point-to-point (7 links per GPU): one large message per
+    step keeps every link busy once instead of paying the per-collective latency ~100 times."""
+
+    def __init__(self, module: torch.nn.Module, world_size: Optional[int] = None, group=None):
+        self.params = [p for p in module.parameters() if p.requires_grad]
+        self.world = world_size if world_size is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
+        self.group = group
+        self.live: Optional[List[torch.nn.Parameter]] = None
+        self.flat: Optional[torch.Tensor] = None
+
+    def _setup(self):
+        self.live = [p for p in self.params if p.grad is not None]
+        n = sum(p.numel() for p in self.live)
+        ref = self.live[0]
+        self.flat = torch.empty(n, dtype=ref.grad.dtype, device=ref.grad.device)
+        self.views, off = [], 0
+        for p in self.live:
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+
+    @property
+    def nbytes(self) -> int:
+        return 0 if self.flat is None else self.flat.numel() * self.flat.element_size()
+
+    def all_reduce(self) -> None:
+        if self.world <= 1:
+            return
+        if self.live is None:
+            self._setup()
+        grads = [p.grad for p in self.live]
+        if any(g is None for g in grads) or any(p.grad is not None and all(p is not q for q in self.live) for p in self.params):
+            raise RuntimeError("the set of parameters receiving gradients changed between steps")
+        torch._foreach_copy_(self.views, grads)
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+        self.flat.div_(self.world)
+        torch._foreach_copy_(grads, self.views)
+
+
+def shard_slides(num_slides: int, rank: int, world: int) -> range:
+    """Contiguous equal shards (slides are independent units): rank r owns [r*B/W, (r+1)*B/W)."""
+    per = num_slides // world
+    extra = num_slides % world
+    start = rank * per + min(rank, extra)
+    return range(start, start + per + (1 if rank < extra else 0))
+
+
+def slide_cost(num_nodes: int, num_edges: int = 0, alpha: float = 1.0, beta: float = 2.0e4, gamma: float = 2.0e3) -> float:
+    """Per-slide step cost model: dense node attention ~ alpha*N^2, per-node GEMM/norm work ~ beta*N,
+    message passing ~ gamma*E (coefficients from the measured kernel times)."""
+    return alpha * num_nodes * num_nodes + beta * num_nodes + gamma * num_edges
+
+
+def balance_slides(costs: Sequence[float], world: int) -> List[List[int]]:
+    """Cost-aware sharding for mixed-size slide streams (BASELINE config 5): longest-processing-time
+    greedy -- heaviest slide first onto the least loaded rank.  Returns slide indices per rank."""
+    order = sorted(range(len(costs)), key=lambda i: -costs[i])
+    loads, bins = [0.0] * world, [[] for _ in range(world)]
+    for i in order:
+        r = min(range(world), key=lambda k: loads[k])
+        bins[r].append(i)
+        loads[r] += costs[i]
+    return bins

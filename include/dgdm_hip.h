@@ -123,6 +123,16 @@ DGDM_API int dgdm_spatial_attn_bwd(const float* Q, const float* K, const float* 
                                    int32_t num_q_tiles, int32_t N_tot, int32_t H, float scale, float inv_tau,
                                    const float* lse2, float* dQ, float* dK, float* dV, int64_t ldg, float* delta_ws,
                                    void* stream);
+/* the two passes of dgdm_spatial_attn_bwd as separate entry points (pass 2 must follow pass 1 on
+ * the same stream): lets a caller time or overlap them individually. */
+DGDM_API int dgdm_spatial_attn_bwd_dq(const float* Q, const float* K, const float* V, int64_t ld, const float* O,
+                                      const float* dO, int64_t ldo, const float* pos, const int32_t* ptr, int32_t B,
+                                      int32_t num_q_tiles, int32_t N_tot, int32_t H, float scale, float inv_tau,
+                                      const float* lse2, float* dQ, int64_t ldg, float* delta_ws, void* stream);
+DGDM_API int dgdm_spatial_attn_bwd_dkv(const float* Q, const float* K, const float* V, int64_t ld, const float* dO,
+                                       int64_t ldo, const float* pos, const int32_t* ptr, int32_t B, int32_t num_q_tiles,
+                                       int32_t N_tot, int32_t H, float scale, float inv_tau, const float* lse2,
+                                       const float* delta_ws, float* dK, float* dV, int64_t ldg, void* stream);
 
 /* Head-mean attention weights per graph (what MultiHeadAttention returns with need_weights,
  * core/attention.py:171-173; DGDMModel's `attention_weights` output, dgdm_model.py:360-361).

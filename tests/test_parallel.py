@@ -1,0 +1,68 @@
+"""N>1 path on CPU: world_size-2 gloo processes run the flat-buffer gradient all-reduce and the
+slide sharding helpers (the GPU path uses the same code with backend nccl == RCCL)."""
+import os
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from dgdm_histopath_lab_amd.parallel import FlatGradAllReducer, balance_slides, shard_slides, slide_cost
+
+
+class Tiny(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.a = torch.nn.Linear(6, 4)
+        self.dead = torch.nn.Linear(3, 3)      # never used: must not enter the buffer (D9)
+        self.b = torch.nn.Linear(4, 1, bias=False)
+
+    def forward(self, x):
+        return self.b(torch.tanh(self.a(x)))
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    m = Tiny()
+    red = FlatGradAllReducer(m, world)
+    data = torch.arange(24, dtype=torch.float32).view(4, 6) / 10.0
+    mine = data[list(shard_slides(4, rank, world))]
+    for _ in range(2):  # second step reuses the buffer
+        m.zero_grad(set_to_none=True)
+        m(mine).sum().backward()
+        red.all_reduce()
+    q.put((rank, {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}, red.nbytes))
+    dist.destroy_process_group()
+
+
+def test_flat_grad_all_reduce_two_ranks_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    torch.manual_seed(0)
+    m = Tiny()
+    data = torch.arange(24, dtype=torch.float32).view(4, 6) / 10.0
+    (m(data[:2]).sum() / 2 + m(data[2:]).sum() / 2).backward()  # mean over ranks of per-rank sums
+    for rank, grads, nbytes in res:
+        assert set(grads) == {"a.weight", "a.bias", "b.weight"}          # dead params stay out
+        assert nbytes == 4 * (24 + 4 + 4)
+        for k, g in grads.items():
+            torch.testing.assert_close(g, dict(m.named_parameters())[k].grad, rtol=1e-6, atol=1e-7)
+
+
+def test_sharding_helpers():
+    assert [list(shard_slides(32, r, 8)) for r in range(8)][3] == [12, 13, 14, 15]
+    assert sum(len(shard_slides(10, r, 4)) for r in range(4)) == 10 and list(shard_slides(10, 3, 4)) == [8, 9]
+    costs = [slide_cost(n, 5 * n) for n in (10000, 1000, 9000, 2000, 8000, 3000, 7000, 4000)]
+    bins = balance_slides(costs, 4)
+    loads = [sum(costs[i] for i in b) for b in bins]
+    assert sorted(i for b in bins for i in b) == list(range(8))
+    assert max(loads) / (sum(loads) / 4) < 1.25   # attention-dominated N^2 costs still balance
