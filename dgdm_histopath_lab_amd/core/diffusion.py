@@ -85,13 +85,18 @@ class DiffusionLayer(nn.Module):
         a, b = tab["sqrt_ac"][timesteps][seg].unsqueeze(-1), tab["sqrt_1mac"][timesteps][seg].unsqueeze(-1)
         return a * x0 + b * noise
 
-    def predict_noise_segments(self, x_noisy: Tensor, timesteps: Tensor, seg: Tensor) -> Tensor:
-        """x_noisy [N_tot, C]; timesteps [B]; seg [N_tot] graph id per row."""
+    def predict_noise_segments(self, x_noisy: Tensor, timesteps: Tensor, seg: Tensor, plan=None) -> Tensor:
+        """x_noisy [N_tot, C]; timesteps [B]; seg [N_tot] graph id per row; ``plan`` (ops.AttnPlan)
+        carries the per-graph row offsets for the segment kernels."""
         C = self.node_dim
         te = self.time_embed(self.get_timestep_embedding(timesteps))                  # [B, hidden]
         lin0 = self.denoise_net[0]
         per_graph = F.linear(te, lin0.weight[:, C:], lin0.bias)                      # time half of the concat + bias
-        h = F.linear(x_noisy, lin0.weight[:, :C]) + per_graph[seg]
+        h = F.linear(x_noisy, lin0.weight[:, :C])
+        if plan is not None and h.size(1) % 4 == 0:
+            h = ops.segment_bcast_add(h, per_graph, plan)
+        else:
+            h = h + per_graph[seg]
         for i in (1, 5):
             gn, drop, lin = self.denoise_net[i], self.denoise_net[i + 2], self.denoise_net[i + 3]
             if ops.row_norm_supported(h.size(1), gn.num_groups):

@@ -176,22 +176,32 @@ __global__ __launch_bounds__(256) void k_rownorm_bwd(const float* __restrict__ x
   }
 }
 
-// dgamma[c] = sum_slots partial[slot][c], dbeta[c] = sum_slots partial[slot][C + c]; fixed order.
-__global__ __launch_bounds__(256) void k_rownorm_reduce(const float* __restrict__ partial, int64_t slots, int C,
-                                                        float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  // block = 256 threads: 64 columns x 4 slot-lanes; grid.x covers 2C columns in chunks of 64
+// column sums over `slots` rows of a [slots][width] buffer, fixed order => reproducible.
+// grid = (ceil(width/64), nchunks): block (x, y) sums slot chunk y of 64 columns; 256 threads =
+// 64 columns x 4 slot-lanes.  Stage 1 writes [nchunks][width], stage 2 (nchunks == 1) the result.
+// split > 0 (final stage): columns [0, split) go to out, [split, width) to out1.
+__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ in, int64_t slots, int width, int64_t chunk,
+                                                float* __restrict__ out, int split, float* __restrict__ out1) {
   const int col = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+  const int64_t s0 = (int64_t)blockIdx.y * chunk;
+  const int64_t s1 = s0 + chunk < slots ? s0 + chunk : slots;
   float acc = 0.f;
-  if (col < 2 * C)
-    for (int64_t s = part; s < slots; s += 4) acc += partial[s * (2 * C) + col];
+  if (col < width)
+    for (int64_t s = s0 + part; s < s1; s += 4) acc += in[s * width + col];
   __shared__ float sm[4][64];
   sm[part][threadIdx.x & 63] = acc;
   __syncthreads();
-  if (part == 0 && col < 2 * C) {
+  if (part == 0 && col < width) {
     const float t = (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
-    if (col < C) dgamma[col] = t; else dbeta[col - C] = t;
+    if (split > 0) {
+      if (col < split) out[col] = t; else out1[col - split] = t;
+    } else {
+      out[(int64_t)blockIdx.y * width + col] = t;
+    }
   }
 }
+
+constexpr int REDUCE_CHUNKS = 32;
 
 struct Geo { int lpr, r; };
 bool geometry(int L, Geo* g) {
@@ -281,7 +291,7 @@ extern "C" size_t dgdm_rownorm_bwd_workspace_bytes(int32_t N, int32_t C, int32_t
   Geo geo;
   if (N <= 0 || C <= 0 || G <= 0 || C % G || !geometry(C / G, &geo)) return 0;
   const int64_t ng = bwd_lane_groups((int64_t)N * G, G, geo);
-  return (size_t)(ng / G) * 2 * C * sizeof(float);
+  return (size_t)(ng / G + REDUCE_CHUNKS + 1) * 2 * C * sizeof(float);  // partials + stage-1 sums + result row
 }
 
 extern "C" int dgdm_rownorm_bwd(const float* x, const float* res, const float* gamma, const float* beta, const float* mean,
@@ -306,7 +316,7 @@ extern "C" int dgdm_rownorm_bwd(const float* x, const float* res, const float* g
   const int L = C / G;
   const int64_t ng = bwd_lane_groups(rows, G, geo);
   const int64_t slots = ng / G;
-  if (workspace_bytes < (size_t)slots * 2 * C * sizeof(float)) return DGDM_ERR_WORKSPACE;
+  if (workspace_bytes < (size_t)(slots + REDUCE_CHUNKS + 1) * 2 * C * sizeof(float)) return DGDM_ERR_WORKSPACE;
   const int gpb = (64 / geo.lpr) * 4;
   const int64_t blocks = ng / gpb;
   float* partial = static_cast<float*>(workspace);
@@ -314,6 +324,13 @@ extern "C" int dgdm_rownorm_bwd(const float* x, const float* res, const float* g
   hipLaunchKernelGGL((k_rownorm_bwd<LPR_, R_, ACT_>), dim3((unsigned)blocks), dim3(256), 0, s, __VA_ARGS__)
   ROWNORM_DISPATCH(BWD, x, res, gamma, beta, mean, rstd, dy, rows, L, G, drop_p, seed, dx, partial, C);
 #undef BWD
-  hipLaunchKernelGGL(k_rownorm_reduce, dim3((2 * C + 63) / 64), dim3(256), 0, s, partial, slots, C, dgamma, dbeta);
+  // dgamma | dbeta = column sums of partial [slots][2C], two fixed-order stages
+  float* stage1 = partial + slots * 2 * C;
+  const int64_t chunk = (slots + REDUCE_CHUNKS - 1) / REDUCE_CHUNKS;
+  const int nch = (int)((slots + chunk - 1) / chunk);
+  hipLaunchKernelGGL(k_colsum, dim3((2 * C + 63) / 64, nch), dim3(256), 0, s, partial, slots, 2 * C, chunk, stage1, 0,
+                     (float*)nullptr);
+  hipLaunchKernelGGL(k_colsum, dim3((2 * C + 63) / 64, 1), dim3(256), 0, s, stage1, (int64_t)nch, 2 * C, (int64_t)nch, dgamma, C,
+                     dbeta);
   return dgdm_launch_status();
 }

@@ -1,0 +1,278 @@
+// Per-graph (segment) primitives over the node dimension of a batch; graphs are contiguous row
+// ranges [ptr[g], ptr[g+1]).  They replace the reference's Python loops over graphs with boolean
+// masks (models/dgdm_model.py:419-431, 607-613) and the gather/scatter torch would run for a
+// batched restatement (`per_graph[batch]` and its index_put backward: 7 ms/step measured).
+//
+//   dgdm_segment_bcast_add : out[n,:] = x[n,:] + src[seg(n),:]        (time-embedding bias, K7)
+//   dgdm_segment_sum       : out[g,:] = sum_{n in g} x[n,:]           (its backward; fixed order)
+//   dgdm_attn_pool_fwd/bwd : GlobalAttentionPool (K10): one learned query per graph attends over
+//                            the graph's nodes, softmax over the segment, per head.
+// All reductions are tree/two-stage reductions in a fixed order: no float atomics.
+#include "common.hpp"
+#include "rowmath.hpp"
+
+namespace {
+
+// ------------------------------------------------------------------ broadcast add
+__global__ __launch_bounds__(256) void k_segment_bcast_add(const float* __restrict__ x, const float* __restrict__ src,
+                                                           const int32_t* __restrict__ ptr, int B, int64_t n4total, int c4,
+                                                           float* __restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4total; i += stride) {
+    const int n = (int)(i / c4), k = (int)(i % c4);
+    int g = 0;
+    while (g + 1 < B && ptr[g + 1] <= n) ++g;
+    float4 v = reinterpret_cast<const float4*>(src)[(int64_t)g * c4 + k];
+    if (x) { const float4 t = reinterpret_cast<const float4*>(x)[i]; v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+    reinterpret_cast<float4*>(out)[i] = v;
+  }
+}
+
+// ------------------------------------------------------------------ segment sum
+// stage 1: block (chunk, g) sums rows [r0, r1) of graph g into part[g][chunk][C];
+// thread = (float4 column k, row lane): 256 threads cover `rl = 256 / c4p` rows at a time.
+__global__ __launch_bounds__(256) void k_segment_sum_stage1(const float* __restrict__ x, const int32_t* __restrict__ ptr, int c4,
+                                                            int c4p, int nchunks, float* __restrict__ part) {
+  const int g = blockIdx.y, chunk = blockIdx.x;
+  const int a = ptr[g], b = ptr[g + 1];
+  const int per = (b - a + nchunks - 1) / nchunks;
+  const int r0 = a + chunk * per, r1 = min(b, r0 + per);
+  const int k = threadIdx.x % c4p, rl = threadIdx.x / c4p, nrl = 256 / c4p;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (k < c4)
+    for (int r = r0 + rl; r < r1; r += nrl) {
+      const float4 t = reinterpret_cast<const float4*>(x)[(int64_t)r * c4 + k];
+      acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+    }
+  __shared__ float4 sm[256];
+  sm[threadIdx.x] = acc;
+  __syncthreads();
+  if (rl == 0 && k < c4) {
+    for (int j = 1; j < nrl; ++j) {  // fixed order
+      const float4 t = sm[j * c4p + k];
+      acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+    }
+    reinterpret_cast<float4*>(part)[((int64_t)g * nchunks + chunk) * c4 + k] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_segment_sum_stage2(const float* __restrict__ part, int c4, int nchunks, int64_t total4,
+                                                            float* __restrict__ out) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;  // over B * c4
+  if (i >= total4) return;
+  const int64_t g = i / c4;
+  const int k = (int)(i % c4);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int c = 0; c < nchunks; ++c) {
+    const float4 t = reinterpret_cast<const float4*>(part)[(g * nchunks + c) * c4 + k];
+    acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+  }
+  reinterpret_cast<float4*>(out)[i] = acc;
+}
+
+constexpr int SEG_CHUNKS = 64;
+
+// ------------------------------------------------------------------ attention pooling
+template <int D>
+__device__ __forceinline__ float dot_row(const float* __restrict__ row, const float* __restrict__ q) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < D; i += 4) {
+    const float4 t = *reinterpret_cast<const float4*>(row + i);
+    s = fmaf(t.x, q[i], s); s = fmaf(t.y, q[i + 1], s); s = fmaf(t.z, q[i + 2], s); s = fmaf(t.w, q[i + 3], s);
+  }
+  return s;
+}
+
+__device__ __forceinline__ float block_max(float v, float* sm) {
+  v = wave_max(v);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  v = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+  __syncthreads();
+  return v;
+}
+__device__ __forceinline__ float block_sum(float v, float* sm) {
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  v = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+  __syncthreads();
+  return v;
+}
+
+__device__ __forceinline__ float drop_factor(uint32_t seed, uint64_t e, uint32_t thresh, float keep_scale) {
+  const uint32_t a = hash32((uint32_t)e * 0x9E3779B1U ^ seed ^ ((uint32_t)(e >> 32) * 0x85EBCA6BU));
+  return (a & 0xFFFFu) >= thresh ? keep_scale : 0.f;
+}
+
+// grid (H, B), 256 threads.  qs = q_proj(global_token) * 1/sqrt(d)  [H*D].
+template <int D>
+__global__ __launch_bounds__(256) void k_attn_pool_fwd(const float* __restrict__ K, const float* __restrict__ V, int64_t ld,
+                                                       const float* __restrict__ qs, const int32_t* __restrict__ ptr, int H,
+                                                       float drop_p, uint32_t seed, float* __restrict__ P, float* __restrict__ out) {
+  const int h = blockIdx.x, g = blockIdx.y;
+  const int a = ptr[g], b = ptr[g + 1];
+  __shared__ float red[4];
+  __shared__ float accs[4][D];
+  float q[D];
+#pragma unroll
+  for (int i = 0; i < D; ++i) q[i] = qs[h * D + i];
+  float m = -INFINITY;
+  for (int n = a + threadIdx.x; n < b; n += 256) m = fmaxf(m, dot_row<D>(K + (int64_t)n * ld + h * D, q));
+  m = block_max(m, red);
+  float l = 0.f;
+  for (int n = a + threadIdx.x; n < b; n += 256) l += __expf(dot_row<D>(K + (int64_t)n * ld + h * D, q) - m);
+  l = block_sum(l, red);
+  const float inv = 1.0f / l;
+  const uint32_t thresh = (uint32_t)(drop_p * 65536.0f);
+  const float keep_scale = drop_p > 0.f ? 1.0f / (1.0f - (float)thresh / 65536.0f) : 1.0f;
+  float acc[D];
+#pragma unroll
+  for (int i = 0; i < D; ++i) acc[i] = 0.f;
+  for (int n = a + threadIdx.x; n < b; n += 256) {
+    const float p = __expf(dot_row<D>(K + (int64_t)n * ld + h * D, q) - m) * inv;
+    P[(int64_t)n * H + h] = p;
+    const float pm = drop_p > 0.f ? p * drop_factor(seed, (uint64_t)n * H + h, thresh, keep_scale) : p;
+    const float* vr = V + (int64_t)n * ld + h * D;
+#pragma unroll
+    for (int i = 0; i < D; i += 4) {
+      const float4 t = *reinterpret_cast<const float4*>(vr + i);
+      acc[i] = fmaf(pm, t.x, acc[i]); acc[i + 1] = fmaf(pm, t.y, acc[i + 1]);
+      acc[i + 2] = fmaf(pm, t.z, acc[i + 2]); acc[i + 3] = fmaf(pm, t.w, acc[i + 3]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    const float s = wave_sum(acc[i]);
+    if ((threadIdx.x & 63) == 0) accs[threadIdx.x >> 6][i] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < D)
+    out[((int64_t)g * H + h) * D + threadIdx.x] =
+        (accs[0][threadIdx.x] + accs[1][threadIdx.x]) + (accs[2][threadIdx.x] + accs[3][threadIdx.x]);
+}
+
+// grid (H, B).  dK = dS * qs, dV = Pm * dOut, dqs_part[g][h][:] = sum_n dS_n K_n.
+template <int D>
+__global__ __launch_bounds__(256) void k_attn_pool_bwd(const float* __restrict__ K, const float* __restrict__ V, int64_t ld,
+                                                       const float* __restrict__ qs, const int32_t* __restrict__ ptr, int H,
+                                                       float drop_p, uint32_t seed, const float* __restrict__ P,
+                                                       const float* __restrict__ out, const float* __restrict__ dout,
+                                                       float* __restrict__ dK, float* __restrict__ dV, int64_t ldg,
+                                                       float* __restrict__ dqs_part) {
+  const int h = blockIdx.x, g = blockIdx.y;
+  const int a = ptr[g], b = ptr[g + 1];
+  __shared__ float accs[4][D];
+  float q[D], go[D];
+  float delta = 0.f;
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    q[i] = qs[h * D + i];
+    go[i] = dout[((int64_t)g * H + h) * D + i];
+    delta = fmaf(go[i], out[((int64_t)g * H + h) * D + i], delta);
+  }
+  const uint32_t thresh = (uint32_t)(drop_p * 65536.0f);
+  const float keep_scale = drop_p > 0.f ? 1.0f / (1.0f - (float)thresh / 65536.0f) : 1.0f;
+  float dq[D];
+#pragma unroll
+  for (int i = 0; i < D; ++i) dq[i] = 0.f;
+  for (int n = a + threadIdx.x; n < b; n += 256) {
+    const float p = P[(int64_t)n * H + h];
+    const float f = drop_p > 0.f ? drop_factor(seed, (uint64_t)n * H + h, thresh, keep_scale) : 1.0f;
+    const float ds = p * (f * dot_row<D>(V + (int64_t)n * ld + h * D, go) - delta);
+    const float pm = p * f;
+    const float* kr = K + (int64_t)n * ld + h * D;
+    float* dkr = dK + (int64_t)n * ldg + h * D;
+    float* dvr = dV + (int64_t)n * ldg + h * D;
+#pragma unroll
+    for (int i = 0; i < D; i += 4) {
+      const float4 t = *reinterpret_cast<const float4*>(kr + i);
+      dq[i] = fmaf(ds, t.x, dq[i]); dq[i + 1] = fmaf(ds, t.y, dq[i + 1]);
+      dq[i + 2] = fmaf(ds, t.z, dq[i + 2]); dq[i + 3] = fmaf(ds, t.w, dq[i + 3]);
+      *reinterpret_cast<float4*>(dkr + i) = make_float4(ds * q[i], ds * q[i + 1], ds * q[i + 2], ds * q[i + 3]);
+      *reinterpret_cast<float4*>(dvr + i) = make_float4(pm * go[i], pm * go[i + 1], pm * go[i + 2], pm * go[i + 3]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    const float s = wave_sum(dq[i]);
+    if ((threadIdx.x & 63) == 0) accs[threadIdx.x >> 6][i] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < D)
+    dqs_part[((int64_t)g * H + h) * D + threadIdx.x] =
+        (accs[0][threadIdx.x] + accs[1][threadIdx.x]) + (accs[2][threadIdx.x] + accs[3][threadIdx.x]);
+}
+
+}  // namespace
+
+extern "C" int dgdm_segment_bcast_add(const float* x, const float* src, const int32_t* ptr, int32_t B, int32_t N, int32_t C,
+                                      float* out, void* stream) {
+  DGDM_REQUIRE(B >= 0 && N >= 0 && C > 0);
+  if (N == 0 || B == 0) return DGDM_OK;
+  DGDM_REQUIRE(src && ptr && out);
+  if ((C & 3) || !dgdm_aligned16(src) || !dgdm_aligned16(out) || (x && !dgdm_aligned16(x))) return DGDM_ERR_UNSUPPORTED;
+  const int64_t n4 = (int64_t)N * (C >> 2);
+  int64_t blocks = (n4 + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(k_segment_bcast_add, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x, src, ptr, B, n4,
+                     C >> 2, out);
+  return dgdm_launch_status();
+}
+
+extern "C" size_t dgdm_segment_sum_workspace_bytes(int32_t B, int32_t C) {
+  return (B <= 0 || C <= 0) ? 0 : (size_t)B * SEG_CHUNKS * C * sizeof(float);
+}
+
+extern "C" int dgdm_segment_sum(const float* x, const int32_t* ptr, int32_t B, int32_t C, float* out, void* workspace,
+                                size_t workspace_bytes, void* stream_) {
+  DGDM_REQUIRE(B >= 0 && C > 0);
+  if (B == 0) return DGDM_OK;
+  DGDM_REQUIRE(x && ptr && out && workspace);
+  if ((C & 3) || C > 1024 || !dgdm_aligned16(x) || !dgdm_aligned16(out) || !dgdm_aligned16(workspace)) return DGDM_ERR_UNSUPPORTED;
+  if (workspace_bytes < dgdm_segment_sum_workspace_bytes(B, C)) return DGDM_ERR_WORKSPACE;
+  hipStream_t s = static_cast<hipStream_t>(stream_);
+  const int c4 = C >> 2;
+  int c4p = 1;
+  while (c4p < c4) c4p <<= 1;  // threads per row: power of two >= c4 (<= 256)
+  float* part = static_cast<float*>(workspace);
+  hipLaunchKernelGGL(k_segment_sum_stage1, dim3(SEG_CHUNKS, B), dim3(256), 0, s, x, ptr, c4, c4p, SEG_CHUNKS, part);
+  const int64_t total4 = (int64_t)B * c4;
+  hipLaunchKernelGGL(k_segment_sum_stage2, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, part, c4, SEG_CHUNKS, total4, out);
+  return dgdm_launch_status();
+}
+
+#define POOL_DISPATCH(D_, KERNEL, ...)                                                                           \
+  switch (D_) {                                                                                                  \
+    case 4: hipLaunchKernelGGL((KERNEL<4>), dim3(H, B), dim3(256), 0, s, __VA_ARGS__); break;                    \
+    case 8: hipLaunchKernelGGL((KERNEL<8>), dim3(H, B), dim3(256), 0, s, __VA_ARGS__); break;                    \
+    case 16: hipLaunchKernelGGL((KERNEL<16>), dim3(H, B), dim3(256), 0, s, __VA_ARGS__); break;                  \
+    case 32: hipLaunchKernelGGL((KERNEL<32>), dim3(H, B), dim3(256), 0, s, __VA_ARGS__); break;                  \
+    default: return DGDM_ERR_UNSUPPORTED;                                                                        \
+  }
+
+extern "C" int dgdm_attn_pool_fwd(const float* K, const float* V, int64_t ld, const float* q_scaled, const int32_t* ptr, int32_t B,
+                                  int32_t H, int32_t D, float drop_p, uint32_t seed, float* P, float* out, void* stream_) {
+  DGDM_REQUIRE(B >= 0 && H > 0 && D > 0 && drop_p >= 0.f && drop_p < 1.f);
+  if (B == 0) return DGDM_OK;
+  DGDM_REQUIRE(K && V && q_scaled && ptr && P && out);
+  if ((ld & 3) || ld < (int64_t)H * D || !dgdm_aligned16(K) || !dgdm_aligned16(V)) return DGDM_ERR_UNSUPPORTED;
+  hipStream_t s = static_cast<hipStream_t>(stream_);
+  POOL_DISPATCH(D, k_attn_pool_fwd, K, V, ld, q_scaled, ptr, H, drop_p, seed, P, out);
+  return dgdm_launch_status();
+}
+
+extern "C" int dgdm_attn_pool_bwd(const float* K, const float* V, int64_t ld, const float* q_scaled, const int32_t* ptr, int32_t B,
+                                  int32_t H, int32_t D, float drop_p, uint32_t seed, const float* P, const float* out,
+                                  const float* dout, float* dK, float* dV, int64_t ldg, float* dq_partial, void* stream_) {
+  DGDM_REQUIRE(B >= 0 && H > 0 && D > 0 && drop_p >= 0.f && drop_p < 1.f);
+  if (B == 0) return DGDM_OK;
+  DGDM_REQUIRE(K && V && q_scaled && ptr && P && out && dout && dK && dV && dq_partial);
+  if ((ld & 3) || (ldg & 3) || ld < (int64_t)H * D || ldg < (int64_t)H * D || !dgdm_aligned16(K) || !dgdm_aligned16(V) ||
+      !dgdm_aligned16(dK) || !dgdm_aligned16(dV))
+    return DGDM_ERR_UNSUPPORTED;
+  hipStream_t s = static_cast<hipStream_t>(stream_);
+  POOL_DISPATCH(D, k_attn_pool_bwd, K, V, ld, q_scaled, ptr, H, drop_p, seed, P, out, dout, dK, dV, ldg, dq_partial);
+  return dgdm_launch_status();
+}

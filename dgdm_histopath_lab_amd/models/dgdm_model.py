@@ -294,7 +294,7 @@ class DGDMModel(nn.Module):
             noise = torch.randn_like(node_embeddings)
         dl = self.diffusion_layer
         noisy = dl.add_noise_segments(node_embeddings, noise, timesteps, plan.seg)
-        pred = dl.predict_noise_segments(noisy, timesteps, plan.seg)
+        pred = dl.predict_noise_segments(noisy, timesteps, plan.seg, plan.attn)
         if self.strict_reference:
             target = torch.randn_like(node_embeddings) if noise_target is None else noise_target
         else:
@@ -400,6 +400,12 @@ class GlobalAttentionPool(nn.Module):
         att = self.attention
         B, seg = _num_graphs(batch, plan), _seg(x, batch)
         H, d, C = att.num_heads, att.head_dim, att.embed_dim
+        if plan is not None and d in ops.POOL_HEAD_DIMS:   # fused segment-softmax kernel (K10)
+            q = att.q_proj(self.global_token.view(1, C)).view(C) * (1.0 / math.sqrt(d))
+            kv = F.linear(x, torch.cat([att.k_proj.weight, att.v_proj.weight]), torch.cat([att.k_proj.bias, att.v_proj.bias]))
+            o = ops.attn_pool(kv, q, plan.attn, H, d, att.attn_dropout.p, att.training)
+            return ops.act_dropout(att.out_proj(o), ops.ACT_NONE, att.resid_dropout.p, att.training) if (B * C) % 4 == 0 \
+                else att.resid_dropout(att.out_proj(o))
         q = att.q_proj(self.global_token.view(1, C)).view(1, H, d)
         k = att.k_proj(x).view(-1, H, d)
         v = att.v_proj(x).view(-1, H, d)

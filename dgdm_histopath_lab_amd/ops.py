@@ -363,3 +363,82 @@ def act_dropout(x, act: int = ACT_NONE, drop_p: float = 0.0, training: bool = Fa
     if x.numel() % 4:
         raise _lib.DGDMKernelError("act_dropout needs numel % 4 == 0")
     return _ActDropout.apply(x, act, p, next_dropout_seed() if p > 0 else 0)
+
+
+# ----------------------------------------------------------------------------- segment ops / K10 pooling
+def segment_sum_raw(x, plan: AttnPlan) -> torch.Tensor:
+    lib = _lib.load()
+    x = _f32c(x)
+    _lib.require_cuda(x)
+    C = x.size(1)
+    out = torch.empty(plan.B, C, dtype=torch.float32, device=x.device)
+    wsb = lib.dgdm_segment_sum_workspace_bytes(plan.B, C)
+    ws = torch.empty(max(wsb, 4) // 4, dtype=torch.float32, device=x.device)
+    _lib.check(lib.dgdm_segment_sum(x.data_ptr(), plan.ptr_dev.data_ptr(), plan.B, C, out.data_ptr(), ws.data_ptr(), wsb,
+                                    _lib.stream_ptr(x.device)), "dgdm_segment_sum")
+    return out
+
+
+class _SegmentBcastAdd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, src, plan: AttnPlan):
+        lib = _lib.load()
+        x, src = _f32c(x), _f32c(src)
+        _lib.require_cuda(x, src)
+        N, C = x.shape
+        out = torch.empty_like(x)
+        _lib.check(lib.dgdm_segment_bcast_add(x.data_ptr(), src.data_ptr(), plan.ptr_dev.data_ptr(), plan.B, N, C, out.data_ptr(),
+                                              _lib.stream_ptr(x.device)), "dgdm_segment_bcast_add")
+        ctx.plan = plan
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _f32c(g)
+        return g, segment_sum_raw(g, ctx.plan), None
+
+
+def segment_bcast_add(x, src, plan: AttnPlan):
+    """out[n] = x[n] + src[graph(n)]  (src [B, C]); backward of src is a fixed-order segment sum."""
+    return _SegmentBcastAdd.apply(x, src, plan)
+
+
+POOL_HEAD_DIMS = (4, 8, 16, 32)
+
+
+class _AttnPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, kv, q_scaled, plan: AttnPlan, H: int, D: int, drop_p: float, seed: int):
+        lib = _lib.load()
+        kv, q_scaled = _f32c(kv), _f32c(q_scaled)
+        _lib.require_cuda(kv, q_scaled)
+        N, C = kv.size(0), H * D
+        P = torch.empty(N, H, dtype=torch.float32, device=kv.device)
+        out = torch.empty(plan.B, C, dtype=torch.float32, device=kv.device)
+        _lib.check(lib.dgdm_attn_pool_fwd(kv.data_ptr(), kv[:, C:].data_ptr(), kv.stride(0), q_scaled.data_ptr(),
+                                          plan.ptr_dev.data_ptr(), plan.B, H, D, drop_p, seed, P.data_ptr(), out.data_ptr(),
+                                          _lib.stream_ptr(kv.device)), "dgdm_attn_pool_fwd")
+        ctx.save_for_backward(kv, q_scaled, P, out)
+        ctx.meta = (plan, H, D, drop_p, seed)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = _lib.load()
+        kv, q_scaled, P, out = ctx.saved_tensors
+        plan, H, D, drop_p, seed = ctx.meta
+        C = H * D
+        gout = _f32c(gout)
+        dkv = torch.empty_like(kv)
+        dq_part = torch.empty(plan.B, C, dtype=torch.float32, device=kv.device)
+        _lib.check(lib.dgdm_attn_pool_bwd(kv.data_ptr(), kv[:, C:].data_ptr(), kv.stride(0), q_scaled.data_ptr(),
+                                          plan.ptr_dev.data_ptr(), plan.B, H, D, drop_p, seed, P.data_ptr(), out.data_ptr(),
+                                          gout.data_ptr(), dkv.data_ptr(), dkv[:, C:].data_ptr(), dkv.stride(0), dq_part.data_ptr(),
+                                          _lib.stream_ptr(kv.device)), "dgdm_attn_pool_bwd")
+        return dkv, dq_part.sum(0), None, None, None, None, None
+
+
+def attn_pool(kv, q_scaled, plan: AttnPlan, H: int, D: int, drop_p: float = 0.0, training: bool = False):
+    """GlobalAttentionPool core: kv [N, 2*H*D] (K | V), q_scaled [H*D] -> [B, H*D]."""
+    p = float(drop_p) if training else 0.0
+    return _AttnPool.apply(kv, q_scaled, plan, H, D, p, next_dropout_seed() if p > 0 else 0)

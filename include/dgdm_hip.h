@@ -179,6 +179,31 @@ DGDM_API int dgdm_act_dropout_fwd(const float* x, int64_t n, int32_t act, float 
 DGDM_API int dgdm_act_dropout_bwd(const float* x, const float* dy, int64_t n, int32_t act, float drop_p, uint32_t seed,
                                   float* dx, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Per-graph (segment) primitives; graph g owns the contiguous rows [ptr[g], ptr[g+1]) (ptr: int32
+ * DEVICE array [B+1]).  They replace the reference's per-graph Python loops with boolean masks
+ * (models/dgdm_model.py:419-431, 607-613).
+ *   dgdm_segment_bcast_add: out[n,:] = x[n,:] (x nullable) + src[g(n),:]      src [B,C], out [N,C]
+ *   dgdm_segment_sum      : out[g,:] = sum_{n in g} x[n,:]  (two fixed-order stages, no atomics)
+ */
+DGDM_API int dgdm_segment_bcast_add(const float* x, const float* src, const int32_t* ptr, int32_t B, int32_t N, int32_t C,
+                                    float* out, void* stream);
+DGDM_API size_t dgdm_segment_sum_workspace_bytes(int32_t B, int32_t C);
+DGDM_API int dgdm_segment_sum(const float* x, const int32_t* ptr, int32_t B, int32_t C, float* out, void* workspace,
+                              size_t workspace_bytes, void* stream);
+
+/* K10  GlobalAttentionPool (models/dgdm_model.py:588-615): per graph, ONE query (the projected,
+ * 1/sqrt(D)-scaled global token, q_scaled [H*D]) attends over the graph's nodes:
+ *   out[g,h,:] = sum_n dropout(softmax_n(q_h . K[n,h,:]))[n] * V[n,h,:]
+ * K, V: [N, H*D] with row stride ld (two column blocks of one fused projection buffer);
+ * P [N,H]: pre-dropout probabilities saved for the backward; out [B, H*D].  D in {4,8,16,32}.
+ * Backward: dK, dV [N, H*D] (row stride ldg), dq_partial [B, H*D] (sum over graphs = d q_scaled). */
+DGDM_API int dgdm_attn_pool_fwd(const float* K, const float* V, int64_t ld, const float* q_scaled, const int32_t* ptr, int32_t B,
+                                int32_t H, int32_t D, float drop_p, uint32_t seed, float* P, float* out, void* stream);
+DGDM_API int dgdm_attn_pool_bwd(const float* K, const float* V, int64_t ld, const float* q_scaled, const int32_t* ptr, int32_t B,
+                                int32_t H, int32_t D, float drop_p, uint32_t seed, const float* P, const float* out,
+                                const float* dout, float* dK, float* dV, int64_t ldg, float* dq_partial, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -80,3 +80,43 @@ def test_act_dropout(act):
     torch.manual_seed(1)
     yd = ops.act_dropout(xd.detach().requires_grad_(True), act, 0.25, True)
     assert abs((yd == 0).float().mean().item() - ((y == 0).float().mean().item() * 0.75 + 0.25)) < 0.01
+
+
+def test_segment_bcast_add_and_sum():
+    from dgdm_histopath_lab_amd import ops
+    ptr = [0, 5, 5, 1300, 2000]  # includes an empty graph
+    plan = ops.AttnPlan(ptr, DEV)
+    g = torch.Generator().manual_seed(3)
+    for c in (4, 128, 512, 36):
+        x = torch.randn(2000, c, generator=g); src = torch.randn(4, c, generator=g); gy = torch.randn(2000, c, generator=g)
+        seg = torch.repeat_interleave(torch.arange(4), torch.tensor([5, 0, 1295, 700]))
+        xd, sd = x.to(DEV).requires_grad_(True), src.to(DEV).requires_grad_(True)
+        y = ops.segment_bcast_add(xd, sd, plan)
+        y.backward(gy.to(DEV))
+        assert_close(y, x + src[seg], 1e-6, "bcast")
+        assert_close(xd.grad, gy, 0, "dx")
+        assert_close(sd.grad, torch.zeros(4, c, dtype=torch.float64).index_add_(0, seg, gy.double()), 1e-5, "segment sum")
+
+
+@pytest.mark.parametrize("H,D", [(8, 16), (4, 8), (2, 32), (1, 4)])
+def test_attn_pool_matches_dense(H, D):
+    from dgdm_histopath_lab_amd import ops
+    ptr = [0, 9, 700, 1233]
+    plan = ops.AttnPlan(ptr, DEV)
+    C = H * D
+    g = torch.Generator().manual_seed(H * D)
+    kv = torch.randn(1233, 2 * C, generator=g); q = torch.randn(C, generator=g) * 0.5; go = torch.randn(3, C, generator=g)
+    kr, qr = kv.double().requires_grad_(True), q.double().requires_grad_(True)
+    outs = []
+    for i in range(3):
+        k = kr[ptr[i]:ptr[i + 1], :C].view(-1, H, D); v = kr[ptr[i]:ptr[i + 1], C:].view(-1, H, D)
+        p = torch.softmax((k * qr.view(1, H, D)).sum(-1), dim=0)
+        outs.append((p.unsqueeze(-1) * v).sum(0).reshape(C))
+    ref = torch.stack(outs); ref.backward(go.double())
+    kd, qd = kv.to(DEV).requires_grad_(True), q.to(DEV).requires_grad_(True)
+    out = ops.attn_pool(kd, qd, plan, H, D)
+    out.backward(go.to(DEV))
+    assert_close(out, ref, 1e-5, "out"); assert_close(kd.grad, kr.grad, 2e-5, "dkv"); assert_close(qd.grad, qr.grad, 2e-5, "dq")
+    torch.manual_seed(0)
+    od = ops.attn_pool(kd.detach(), qd.detach(), plan, H, D, 0.3, True)   # dropout path runs and changes the result
+    assert torch.isfinite(od).all() and not torch.allclose(od, out.detach())
