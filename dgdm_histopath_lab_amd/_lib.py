@@ -30,10 +30,10 @@ SIGNATURES = {
     "dgdm_gcn_dinv": (C.c_int, [_p, _i32, _p, _p]),
     "dgdm_csr_edge_weights": (C.c_int, [_p, _p, _p, _i32, _p, _p]),
     "dgdm_spatial_attn_q_tile_rows": (_i32, []),
-    "dgdm_spatial_attn_fwd": (C.c_int, [_p, _p, _p, _i64, _p, _p, _i32, _i32, _i32, _i32, C.c_float, C.c_float, _p, _i64, _p, _p]),
-    "dgdm_spatial_attn_fwd_variant": (C.c_int, [_p, _p, _p, _i64, _p, _p, _i32, _i32, _i32, _i32, C.c_float, C.c_float, _p, _i64, _p, _i32, _p]),
+    "dgdm_spatial_attn_fwd": (C.c_int, [_p, _p, _p, _i64, _p, _p, _i32, _i32, _i32, _i32, C.c_float, C.c_float, C.c_float, C.c_uint32, _p, _i64, _p, _p]),
+    "dgdm_spatial_attn_fwd_variant": (C.c_int, [_p, _p, _p, _i64, _p, _p, _i32, _i32, _i32, _i32, C.c_float, C.c_float, C.c_float, C.c_uint32, _p, _i64, _p, _i32, _p]),
     "dgdm_spatial_attn_bwd": (C.c_int, [_p, _p, _p, _i64, _p, _p, _i64, _p, _p, _i32, _i32, _i32, _i32, C.c_float, C.c_float,
-                                        _p, _p, _p, _p, _i64, _p, _p]),
+                                        _p, C.c_float, C.c_uint32, _p, _p, _p, _i64, _p, _p]),
     "dgdm_add_posenc": (C.c_int, [_p, _i64, _p, _p, _i32, _i32, _i32, _p, _p, _i64, _p]),
     "dgdm_spatial_attn_mean_weights": (C.c_int, [_p, _p, _i64, _p, _p, _i32, _i32, _i32, _i32, C.c_float, C.c_float, _p, _p, _p, _p]),
     "dgdm_rownorm_fwd": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, C.c_float, _i32, C.c_float, C.c_uint32, _p, _p, _p, _p]),
@@ -42,9 +42,9 @@ SIGNATURES = {
     "dgdm_act_dropout_fwd": (C.c_int, [_p, _i64, _i32, C.c_float, C.c_uint32, _p, _p]),
     "dgdm_act_dropout_bwd": (C.c_int, [_p, _p, _i64, _i32, C.c_float, C.c_uint32, _p, _p]),
     "dgdm_spatial_attn_bwd_dq": (C.c_int, [_p, _p, _p, _i64, _p, _p, _i64, _p, _p, _i32, _i32, _i32, _i32, C.c_float, C.c_float,
-                                           _p, _p, _i64, _p, _p]),
+                                           _p, C.c_float, C.c_uint32, _p, _i64, _p, _p]),
     "dgdm_spatial_attn_bwd_dkv": (C.c_int, [_p, _p, _p, _i64, _p, _i64, _p, _p, _i32, _i32, _i32, _i32, C.c_float, C.c_float,
-                                            _p, _p, _p, _p, _i64, _p]),
+                                            _p, _p, C.c_float, C.c_uint32, _p, _p, _i64, _p]),
     "dgdm_segment_bcast_add": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _p, _p]),
     "dgdm_segment_sum_workspace_bytes": (_sz, [_i32, _i32]),
     "dgdm_segment_sum": (C.c_int, [_p, _p, _i32, _i32, _p, _p, _sz, _p]),

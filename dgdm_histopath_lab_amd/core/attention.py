@@ -85,11 +85,10 @@ class SpatialAttention(nn.Module):
     def forward_batch(self, x: Tensor, pos: Tensor, plan: ops.AttnPlan) -> Tensor:
         """x [N_tot, C], pos [N_tot, 2]; attention is restricted to each graph of ``plan``."""
         att = self.attention
-        if att.training and att.dropout > 0:
-            ops.attention_dropout_unsupported(att.dropout)
         xp = ops.add_posenc(x, pos, plan)
         qkv = att.fused_qkv(xp)
-        o = ops.spatial_attention(qkv, pos, plan, att.num_heads, 1.0 / math.sqrt(att.head_dim), 1.0 / self.temperature)
+        o = ops.spatial_attention(qkv, pos, plan, att.num_heads, 1.0 / math.sqrt(att.head_dim), 1.0 / self.temperature,
+                                  att.attn_dropout.p, att.training)
         o = ops.act_dropout(att.out_proj(att.unpad_heads(o)), ops.ACT_NONE, att.resid_dropout.p, att.training)
         if ops.row_norm_supported(self.embed_dim, 1):
             return ops.row_norm(o, self.norm.weight, self.norm.bias, res=x, eps=self.norm.eps)

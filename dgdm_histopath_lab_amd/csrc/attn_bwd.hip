@@ -19,15 +19,16 @@ constexpr int TB = 64;  // rows owned by a workgroup (4 waves x 16): queries (dq
 constexpr float BIG = 1.0e30f;
 
 // ---------------------------------------------------------------------------------------- dQ
-template <int HG, int KB>
+template <int HG, int KB, bool DROP>
 __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq(const float* __restrict__ Q, const float* __restrict__ K,
                                                         const float* __restrict__ V, int64_t ld,
                                                         const float* __restrict__ Oa, const float* __restrict__ dO, int64_t ldo,
                                                         const float* __restrict__ pos, const int32_t* __restrict__ ptr, int B,
                                                         const float* __restrict__ L2, float qscale, float bscale, float scale,
                                                         float* __restrict__ dQ, int64_t ldg, float* __restrict__ delta,
-                                                        int N_tot) {
+                                                        int N_tot, float drop_p, uint32_t seed) {
   using T = AttnTile<KB>;
+  const DropCfg dc(drop_p);
   constexpr int NT = KB / 16;
   constexpr int F4 = KB * HG * 4 / 256;
   static_assert(KB % 16 == 0 && (KB * HG * 4) % 256 == 0, "staging must divide evenly");
@@ -132,6 +133,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq(const float* __restrict_
         f32x4 s = mfma16_k16(kf, qf[h], f32x4{0.f, 0.f, 0.f, 0.f});    // S'^T[key][q]
         f32x4 dp = mfma16_k16(vf, dof[h], f32x4{0.f, 0.f, 0.f, 0.f});  // dP^T[key][q]
         f32x4 ds;
+        if (DROP) dp *= drop_factors_qmajor(attn_head_seed(seed, n0, head0 + h), q_local, kb0 + 16 * t + 4 * G, dc);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float p = __builtin_amdgcn_exp2f(s[r] - bias[t][r] - l2[h]);
@@ -156,15 +158,17 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq(const float* __restrict_
 }
 
 // ------------------------------------------------------------------------------------- dK, dV
-template <int HG, int QBK>
+template <int HG, int QBK, bool DROP>
 __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv(const float* __restrict__ Q, const float* __restrict__ K,
                                                          const float* __restrict__ V, int64_t ld,
                                                          const float* __restrict__ dO, int64_t ldo,
                                                          const float* __restrict__ pos, const int32_t* __restrict__ ptr, int B,
                                                          const float* __restrict__ L2, const float* __restrict__ delta,
                                                          float qscale, float bscale, float scale, float* __restrict__ dK,
-                                                         float* __restrict__ dV, int64_t ldg, int N_tot) {
+                                                         float* __restrict__ dV, int64_t ldg, int N_tot, float drop_p,
+                                                         uint32_t seed) {
   using T = AttnTile<QBK>;
+  const DropCfg dc(drop_p);
   constexpr int NT = QBK / 16;
   constexpr int F4 = QBK * HG * 4 / 256;
   static_assert(QBK % 16 == 0 && (QBK * HG * 4) % 256 == 0, "staging must divide evenly");
@@ -277,11 +281,13 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv(const float* __restrict
         const f32x4 dq = *reinterpret_cast<const f32x4*>(&Ds[h * QBK + 16 * t + 4 * G]);
         f32x4 s = mfma16_k16(qa, kf[h], f32x4{0.f, 0.f, 0.f, 0.f});   // S'[q][key]
         f32x4 dp = mfma16_k16(ga, vf[h], f32x4{0.f, 0.f, 0.f, 0.f});  // dP[q][key]
-        f32x4 p, ds;
+        f32x4 p, ds, f = f32x4{1.f, 1.f, 1.f, 1.f};
+        if (DROP) f = drop_factors_kmajor(attn_head_seed(seed, n0, head0 + h), k_local, qb0 + 16 * t + 4 * G, dc);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           p[r] = __builtin_amdgcn_exp2f(s[r] - bias[t][r] - lq[r]);
-          ds[r] = p[r] * (dp[r] - dq[r]);
+          ds[r] = p[r] * (f[r] * dp[r] - dq[r]);
+          p[r] *= f[r];  // dV sees the dropped weights
         }
         const f32x4 gt = *reinterpret_cast<const f32x4*>(&Gt[T::tr(h, 16 * t + 4 * G, j)]);
         const f32x4 qt = *reinterpret_cast<const f32x4*>(&Qt[T::tr(h, 16 * t + 4 * G, j)]);
@@ -306,10 +312,10 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv(const float* __restrict
 
 }  // namespace
 
-static int check_bwd_common(const void* Q, const void* K, const void* V, const void* dO, const void* pos, const void* ptr,
+static int check_bwd_common(float drop_p, const void* Q, const void* K, const void* V, const void* dO, const void* pos, const void* ptr,
                             const void* lse2, int64_t ld, int64_t ldo, int64_t ldg, int32_t B, int32_t N_tot, int32_t H,
                             int32_t num_q_tiles) {
-  if (B < 0 || N_tot < 0 || H <= 0 || num_q_tiles < 0) return DGDM_ERR_INVALID_ARG;
+  if (B < 0 || N_tot < 0 || H <= 0 || num_q_tiles < 0 || !(drop_p >= 0.f && drop_p < 1.f)) return DGDM_ERR_INVALID_ARG;
   if (N_tot == 0 || num_q_tiles == 0) return 1;  // nothing to do
   if (!Q || !K || !V || !dO || !pos || !ptr || !lse2) return DGDM_ERR_INVALID_ARG;
   if ((ld & 3) || (ldo & 3) || (ldg & 3) || ld < H * 16 || ldo < H * 16 || ldg < H * 16) return DGDM_ERR_UNSUPPORTED;
@@ -323,16 +329,23 @@ static int check_bwd_common(const void* Q, const void* K, const void* V, const v
 extern "C" int dgdm_spatial_attn_bwd_dq(const float* Q, const float* K, const float* V, int64_t ld, const float* O,
                                         const float* dO, int64_t ldo, const float* pos, const int32_t* ptr, int32_t B,
                                         int32_t num_q_tiles, int32_t N_tot, int32_t H, float scale, float inv_tau,
-                                        const float* lse2, float* dQ, int64_t ldg, float* delta_ws, void* stream_) {
-  int rc = check_bwd_common(Q, K, V, dO, pos, ptr, lse2, ld, ldo, ldg, B, N_tot, H, num_q_tiles);
+                                        const float* lse2, float drop_p, uint32_t seed, float* dQ, int64_t ldg, float* delta_ws,
+                                        void* stream_) {
+  int rc = check_bwd_common(drop_p, Q, K, V, dO, pos, ptr, lse2, ld, ldo, ldg, B, N_tot, H, num_q_tiles);
   if (rc != DGDM_OK) return rc > 0 ? DGDM_OK : rc;
   DGDM_REQUIRE(O && dQ && delta_ws);
   if (!dgdm_aligned16(O) || !dgdm_aligned16(dQ)) return DGDM_ERR_UNSUPPORTED;
   hipStream_t s = static_cast<hipStream_t>(stream_);
   const float qscale = scale * DGDM_LOG2E, bscale = inv_tau * DGDM_LOG2E;
-#define GO(HG, KB)                                                                                                  \
-  hipLaunchKernelGGL((k_attn_bwd_dq<HG, KB>), dim3(num_q_tiles, H / HG), dim3(256), 0, s, Q, K, V, ld, O, dO, ldo, \
-                     pos, ptr, B, lse2, qscale, bscale, scale, dQ, ldg, delta_ws, N_tot)
+#define GO(HG, KB)                                                                                                        \
+  do {                                                                                                                    \
+    if (drop_p > 0.f)                                                                                                     \
+      hipLaunchKernelGGL((k_attn_bwd_dq<HG, KB, true>), dim3(num_q_tiles, H / HG), dim3(256), 0, s, Q, K, V, ld, O, dO,   \
+                         ldo, pos, ptr, B, lse2, qscale, bscale, scale, dQ, ldg, delta_ws, N_tot, drop_p, seed);         \
+    else                                                                                                                  \
+      hipLaunchKernelGGL((k_attn_bwd_dq<HG, KB, false>), dim3(num_q_tiles, H / HG), dim3(256), 0, s, Q, K, V, ld, O, dO,  \
+                         ldo, pos, ptr, B, lse2, qscale, bscale, scale, dQ, ldg, delta_ws, N_tot, 0.f, 0u);              \
+  } while (0)
   if (H % 4 == 0) GO(4, 64);
   else if (H % 2 == 0) GO(2, 64);
   else GO(1, 64);
@@ -344,16 +357,23 @@ extern "C" int dgdm_spatial_attn_bwd_dq(const float* Q, const float* K, const fl
 extern "C" int dgdm_spatial_attn_bwd_dkv(const float* Q, const float* K, const float* V, int64_t ld, const float* dO,
                                          int64_t ldo, const float* pos, const int32_t* ptr, int32_t B, int32_t num_q_tiles,
                                          int32_t N_tot, int32_t H, float scale, float inv_tau, const float* lse2,
-                                         const float* delta_ws, float* dK, float* dV, int64_t ldg, void* stream_) {
-  int rc = check_bwd_common(Q, K, V, dO, pos, ptr, lse2, ld, ldo, ldg, B, N_tot, H, num_q_tiles);
+                                         const float* delta_ws, float drop_p, uint32_t seed, float* dK, float* dV, int64_t ldg,
+                                         void* stream_) {
+  int rc = check_bwd_common(drop_p, Q, K, V, dO, pos, ptr, lse2, ld, ldo, ldg, B, N_tot, H, num_q_tiles);
   if (rc != DGDM_OK) return rc > 0 ? DGDM_OK : rc;
   DGDM_REQUIRE(delta_ws && dK && dV);
   if (!dgdm_aligned16(dK) || !dgdm_aligned16(dV)) return DGDM_ERR_UNSUPPORTED;
   hipStream_t s = static_cast<hipStream_t>(stream_);
   const float qscale = scale * DGDM_LOG2E, bscale = inv_tau * DGDM_LOG2E;
-#define GO(HG, QBK)                                                                                                 \
-  hipLaunchKernelGGL((k_attn_bwd_dkv<HG, QBK>), dim3(num_q_tiles, H / HG), dim3(256), 0, s, Q, K, V, ld, dO, ldo,  \
-                     pos, ptr, B, lse2, delta_ws, qscale, bscale, scale, dK, dV, ldg, N_tot)
+#define GO(HG, QBK)                                                                                                       \
+  do {                                                                                                                    \
+    if (drop_p > 0.f)                                                                                                     \
+      hipLaunchKernelGGL((k_attn_bwd_dkv<HG, QBK, true>), dim3(num_q_tiles, H / HG), dim3(256), 0, s, Q, K, V, ld, dO,    \
+                         ldo, pos, ptr, B, lse2, delta_ws, qscale, bscale, scale, dK, dV, ldg, N_tot, drop_p, seed);     \
+    else                                                                                                                  \
+      hipLaunchKernelGGL((k_attn_bwd_dkv<HG, QBK, false>), dim3(num_q_tiles, H / HG), dim3(256), 0, s, Q, K, V, ld, dO,   \
+                         ldo, pos, ptr, B, lse2, delta_ws, qscale, bscale, scale, dK, dV, ldg, N_tot, 0.f, 0u);          \
+  } while (0)
   if (H % 4 == 0) GO(4, 32);
   else if (H % 2 == 0) GO(2, 64);
   else GO(1, 64);
@@ -364,11 +384,11 @@ extern "C" int dgdm_spatial_attn_bwd_dkv(const float* Q, const float* K, const f
 extern "C" int dgdm_spatial_attn_bwd(const float* Q, const float* K, const float* V, int64_t ld, const float* O,
                                      const float* dO, int64_t ldo, const float* pos, const int32_t* ptr, int32_t B,
                                      int32_t num_q_tiles, int32_t N_tot, int32_t H, float scale, float inv_tau,
-                                     const float* lse2, float* dQ, float* dK, float* dV, int64_t ldg, float* delta_ws,
-                                     void* stream) {
-  int rc = dgdm_spatial_attn_bwd_dq(Q, K, V, ld, O, dO, ldo, pos, ptr, B, num_q_tiles, N_tot, H, scale, inv_tau, lse2, dQ, ldg,
-                                    delta_ws, stream);
+                                     const float* lse2, float drop_p, uint32_t seed, float* dQ, float* dK, float* dV, int64_t ldg,
+                                     float* delta_ws, void* stream) {
+  int rc = dgdm_spatial_attn_bwd_dq(Q, K, V, ld, O, dO, ldo, pos, ptr, B, num_q_tiles, N_tot, H, scale, inv_tau, lse2, drop_p, seed,
+                                    dQ, ldg, delta_ws, stream);
   if (rc != DGDM_OK) return rc;
-  return dgdm_spatial_attn_bwd_dkv(Q, K, V, ld, dO, ldo, pos, ptr, B, num_q_tiles, N_tot, H, scale, inv_tau, lse2, delta_ws, dK,
-                                   dV, ldg, stream);
+  return dgdm_spatial_attn_bwd_dkv(Q, K, V, ld, dO, ldo, pos, ptr, B, num_q_tiles, N_tot, H, scale, inv_tau, lse2, delta_ws, drop_p,
+                                   seed, dK, dV, ldg, stream);
 }

@@ -65,3 +65,51 @@ __device__ __forceinline__ float group_sum4(float v) {
   v += __shfl_xor(v, 32, 64);
   return v;
 }
+
+// ---- dropout on attention weights (core/attention.py:154: attn_dropout on softmax(S)) ----------
+// Counter-based: element (graph, head, q, k) is kept iff a 16-bit slice of
+// hash(seed, graph, head, q>>1, k) is >= drop_p * 65536; the low half serves even q, the high half
+// odd q.  Pairing along q lets the k-major kernel (dK/dV: queries in registers) derive two
+// elements per hash directly, and the q-major kernels (forward, dQ: keys in registers, queries on
+// adjacent lanes) split the four keys of a register quad between the even/odd lane of a query
+// pair and exchange the results with one DPP swap each -- 2 hashes per 4 elements everywhere.
+// The backward kernels regenerate exactly the forward's mask from (seed, indices).
+__device__ __forceinline__ uint32_t attn_hash(uint32_t hs, uint32_t qp, uint32_t k) {
+  uint32_t x = hs ^ (qp * 0x9E3779B1U) ^ (k * 0x85EBCA6BU);
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ uint32_t attn_head_seed(uint32_t seed, int n0, int head) {
+  return seed ^ ((uint32_t)n0 * 0xC2B2AE35U) ^ ((uint32_t)(head + 1) * 0x27D4EB2FU);
+}
+struct DropCfg {
+  uint32_t thresh;
+  float keep;
+  __device__ __forceinline__ DropCfg(float p) : thresh((uint32_t)(p * 65536.0f)), keep(1.0f / (1.0f - (float)((uint32_t)(p * 65536.0f)) / 65536.0f)) {}
+};
+// q-major: this lane is query `q_local` (lane bit 0 == q_local & 1), its register quad holds keys
+// k0 .. k0+3.  Returns the four keep-factors.
+__device__ __forceinline__ f32x4 drop_factors_qmajor(uint32_t hs, int q_local, int k0, const DropCfg& c) {
+  const bool odd = q_local & 1;
+  const uint32_t qp = (uint32_t)q_local >> 1, kk = (uint32_t)k0 + (odd ? 2u : 0u);
+  const uint32_t h0 = attn_hash(hs, qp, kk), h1 = attn_hash(hs, qp, kk + 1);
+  const uint32_t o0 = __shfl_xor(h0, 1, 64), o1 = __shfl_xor(h1, 1, 64);
+  const uint32_t u0 = odd ? o0 : h0, u1 = odd ? o1 : h1, u2 = odd ? h0 : o0, u3 = odd ? h1 : o1;
+  const int sh = odd ? 16 : 0;
+  f32x4 f;
+  f[0] = ((u0 >> sh) & 0xFFFFu) >= c.thresh ? c.keep : 0.f;
+  f[1] = ((u1 >> sh) & 0xFFFFu) >= c.thresh ? c.keep : 0.f;
+  f[2] = ((u2 >> sh) & 0xFFFFu) >= c.thresh ? c.keep : 0.f;
+  f[3] = ((u3 >> sh) & 0xFFFFu) >= c.thresh ? c.keep : 0.f;
+  return f;
+}
+// k-major: this lane is key `k_local`, its register quad holds queries q0 .. q0+3 (q0 even).
+__device__ __forceinline__ f32x4 drop_factors_kmajor(uint32_t hs, int k_local, int q0, const DropCfg& c) {
+  const uint32_t h0 = attn_hash(hs, (uint32_t)q0 >> 1, (uint32_t)k_local), h1 = attn_hash(hs, ((uint32_t)q0 >> 1) + 1, (uint32_t)k_local);
+  f32x4 f;
+  f[0] = (h0 & 0xFFFFu) >= c.thresh ? c.keep : 0.f;
+  f[1] = (h0 >> 16) >= c.thresh ? c.keep : 0.f;
+  f[2] = (h1 & 0xFFFFu) >= c.thresh ? c.keep : 0.f;
+  f[3] = (h1 >> 16) >= c.thresh ? c.keep : 0.f;
+  return f;
+}

@@ -18,14 +18,15 @@ namespace {
 constexpr int QB = 64;   // queries per workgroup (4 waves x 16)
 constexpr float NEG_BIG = -1.0e30f;
 
-template <int HG, int KB>
+template <int HG, int KB, bool DROP>
 __global__ __launch_bounds__(256, 2) void k_attn_fwd(const float* __restrict__ Q, const float* __restrict__ K,
                                                      const float* __restrict__ V, int64_t ld,
                                                      const float* __restrict__ pos, const int32_t* __restrict__ ptr, int B,
                                                      float qscale, float bscale, float* __restrict__ O, int64_t ldo,
-                                                     float* __restrict__ L2, int N_tot) {
+                                                     float* __restrict__ L2, int N_tot, float drop_p, uint32_t seed) {
   using T = AttnTile<KB>;
   constexpr int NT = KB / 16;                     // 16-key tiles per block
+  const DropCfg dc(drop_p);
   constexpr int F4_PER_THREAD = KB * HG * 4 / 256;  // float4 staged per thread per tensor
   static_assert(KB % 16 == 0 && (KB * HG * 4) % 256 == 0, "staging must divide evenly");
   __shared__ __attribute__((aligned(16))) float smem[2 * HG * T::HS + 2 * KB];
@@ -145,6 +146,11 @@ __global__ __launch_bounds__(256, 2) void k_attn_fwd(const float* __restrict__ Q
         }
       l[h] = fmaf(l[h], alpha, psum);
       oacc[h] *= alpha;
+      if (DROP) {  // the row sum above uses the un-dropped weights; only the P.V product sees the mask
+        const uint32_t hs = attn_head_seed(seed, n0, head0 + h);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) s[t] *= drop_factors_qmajor(hs, q_local, kb0 + 16 * t + 4 * G, dc);
+      }
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const f32x4 vf = *reinterpret_cast<const f32x4*>(&Vt[T::tr(h, 16 * t + 4 * G, j)]);
@@ -175,9 +181,9 @@ __global__ __launch_bounds__(256, 2) void k_attn_fwd(const float* __restrict__ Q
 // variant: 0 = default tiling; other values select alternative (HG, KB) tilings for tuning runs.
 extern "C" int dgdm_spatial_attn_fwd_variant(const float* Q, const float* K, const float* V, int64_t ld, const float* pos,
                                              const int32_t* ptr, int32_t B, int32_t num_q_tiles, int32_t N_tot, int32_t H,
-                                             float scale, float inv_tau, float* O, int64_t ldo, float* lse2, int32_t variant,
-                                             void* stream_) {
-  DGDM_REQUIRE(B >= 0 && N_tot >= 0 && H > 0 && num_q_tiles >= 0);
+                                             float scale, float inv_tau, float drop_p, uint32_t seed, float* O, int64_t ldo,
+                                             float* lse2, int32_t variant, void* stream_) {
+  DGDM_REQUIRE(B >= 0 && N_tot >= 0 && H > 0 && num_q_tiles >= 0 && drop_p >= 0.f && drop_p < 1.f);
   if (N_tot == 0 || num_q_tiles == 0) return DGDM_OK;
   DGDM_REQUIRE(Q && K && V && pos && ptr && O && lse2);
   if ((ld & 3) || (ldo & 3) || ld < H * 16 || ldo < H * 16) return DGDM_ERR_UNSUPPORTED;
@@ -186,9 +192,15 @@ extern "C" int dgdm_spatial_attn_fwd_variant(const float* Q, const float* K, con
     return DGDM_ERR_UNSUPPORTED;
   hipStream_t s = static_cast<hipStream_t>(stream_);
   const float qscale = scale * DGDM_LOG2E, bscale = inv_tau * DGDM_LOG2E;
-#define GO(HG, KB)                                                                                               \
-  hipLaunchKernelGGL((k_attn_fwd<HG, KB>), dim3(num_q_tiles, H / HG), dim3(256), 0, s, Q, K, V, ld, pos, ptr, B, \
-                     qscale, bscale, O, ldo, lse2, N_tot)
+#define GO(HG, KB)                                                                                                     \
+  do {                                                                                                                 \
+    if (drop_p > 0.f)                                                                                                  \
+      hipLaunchKernelGGL((k_attn_fwd<HG, KB, true>), dim3(num_q_tiles, H / HG), dim3(256), 0, s, Q, K, V, ld, pos, ptr, \
+                         B, qscale, bscale, O, ldo, lse2, N_tot, drop_p, seed);                                        \
+    else                                                                                                               \
+      hipLaunchKernelGGL((k_attn_fwd<HG, KB, false>), dim3(num_q_tiles, H / HG), dim3(256), 0, s, Q, K, V, ld, pos,    \
+                         ptr, B, qscale, bscale, O, ldo, lse2, N_tot, 0.f, 0u);                                        \
+  } while (0)
   if (H % 8 == 0 && variant == 1) GO(8, 32);
   else if (H % 8 == 0 && variant == 2) GO(8, 64);
   else if (H % 4 == 0 && variant == 3) GO(4, 32);
@@ -201,8 +213,10 @@ extern "C" int dgdm_spatial_attn_fwd_variant(const float* Q, const float* K, con
 
 extern "C" int dgdm_spatial_attn_fwd(const float* Q, const float* K, const float* V, int64_t ld, const float* pos,
                                      const int32_t* ptr, int32_t B, int32_t num_q_tiles, int32_t N_tot, int32_t H,
-                                     float scale, float inv_tau, float* O, int64_t ldo, float* lse2, void* stream) {
-  return dgdm_spatial_attn_fwd_variant(Q, K, V, ld, pos, ptr, B, num_q_tiles, N_tot, H, scale, inv_tau, O, ldo, lse2, 0, stream);
+                                     float scale, float inv_tau, float drop_p, uint32_t seed, float* O, int64_t ldo,
+                                     float* lse2, void* stream) {
+  return dgdm_spatial_attn_fwd_variant(Q, K, V, ld, pos, ptr, B, num_q_tiles, N_tot, H, scale, inv_tau, drop_p, seed, O, ldo, lse2,
+                                       0, stream);
 }
 
 extern "C" int32_t dgdm_spatial_attn_q_tile_rows(void) { return QB; }

@@ -121,7 +121,8 @@ class AttnPlan:
         self.ptr_dev = torch.tensor(self.ptr_host, dtype=torch.int32).to(device, non_blocking=True)
 
 
-def spatial_attn_fwd_raw(q, k, v, pos, plan: AttnPlan, H: int, scale: float, inv_tau: float, variant: int = 0):
+def spatial_attn_fwd_raw(q, k, v, pos, plan: AttnPlan, H: int, scale: float, inv_tau: float, variant: int = 0,
+                         drop_p: float = 0.0, seed: int = 0):
     """q,k,v: [N_tot, H*16] views sharing one row stride (e.g. slices of a fused QKV buffer)."""
     _lib.require_cuda(q, k, v, pos)
     lib = _lib.load()
@@ -133,13 +134,14 @@ def spatial_attn_fwd_raw(q, k, v, pos, plan: AttnPlan, H: int, scale: float, inv
     lse2 = torch.empty(H, N, dtype=torch.float32, device=q.device)
     TIMERS.timed("attn_fwd", lambda: _lib.check(
         lib.dgdm_spatial_attn_fwd_variant(q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), pos.data_ptr(),
-                                          plan.ptr_dev.data_ptr(), plan.B, plan.num_q_tiles, N, H, scale, inv_tau, out.data_ptr(),
-                                          out.stride(0), lse2.data_ptr(), variant, _lib.stream_ptr(q.device)),
+                                          plan.ptr_dev.data_ptr(), plan.B, plan.num_q_tiles, N, H, scale, inv_tau, drop_p, seed,
+                                          out.data_ptr(), out.stride(0), lse2.data_ptr(), variant, _lib.stream_ptr(q.device)),
         "dgdm_spatial_attn_fwd"))
     return out, lse2
 
 
-def spatial_attn_bwd_raw(q, k, v, out, gout, pos, plan: AttnPlan, H: int, scale: float, inv_tau: float, lse2, dqkv):
+def spatial_attn_bwd_raw(q, k, v, out, gout, pos, plan: AttnPlan, H: int, scale: float, inv_tau: float, lse2, dqkv,
+                         drop_p: float = 0.0, seed: int = 0):
     """Writes dQ|dK|dV into the three column blocks of ``dqkv`` [N_tot, 3*H*16]."""
     lib = _lib.load()
     N, C = q.shape
@@ -150,12 +152,12 @@ def spatial_attn_bwd_raw(q, k, v, out, gout, pos, plan: AttnPlan, H: int, scale:
     TIMERS.timed("attn_bwd_dq", lambda: _lib.check(
         lib.dgdm_spatial_attn_bwd_dq(q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), out.data_ptr(), gout.data_ptr(),
                                      out.stride(0), pos.data_ptr(), plan.ptr_dev.data_ptr(), plan.B, plan.num_q_tiles, N, H, scale,
-                                     inv_tau, lse2.data_ptr(), dqkv[:, :C].data_ptr(), dqkv.stride(0), delta.data_ptr(), st),
+                                     inv_tau, lse2.data_ptr(), drop_p, seed, dqkv[:, :C].data_ptr(), dqkv.stride(0), delta.data_ptr(), st),
         "dgdm_spatial_attn_bwd_dq"))
     TIMERS.timed("attn_bwd_dkv", lambda: _lib.check(
         lib.dgdm_spatial_attn_bwd_dkv(q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), gout.data_ptr(), out.stride(0),
                                       pos.data_ptr(), plan.ptr_dev.data_ptr(), plan.B, plan.num_q_tiles, N, H, scale, inv_tau,
-                                      lse2.data_ptr(), delta.data_ptr(), dqkv[:, C:2 * C].data_ptr(), dqkv[:, 2 * C:].data_ptr(),
+                                      lse2.data_ptr(), delta.data_ptr(), drop_p, seed, dqkv[:, C:2 * C].data_ptr(), dqkv[:, 2 * C:].data_ptr(),
                                       dqkv.stride(0), st), "dgdm_spatial_attn_bwd_dkv"))
     return dqkv
 
@@ -165,27 +167,34 @@ class _SpatialAttention(torch.autograd.Function):
     (core/attention.py:135-157 + 261-283), per graph of the batch."""
 
     @staticmethod
-    def forward(ctx, qkv, pos, plan: AttnPlan, H: int, scale: float, inv_tau: float):
+    def forward(ctx, qkv, pos, plan: AttnPlan, H: int, scale: float, inv_tau: float, drop_p: float, seed: int):
         qkv = _f32c(qkv)
         C = qkv.size(1) // 3
         pos = _f32c(pos)
-        out, lse2 = spatial_attn_fwd_raw(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], pos, plan, H, scale, inv_tau)
+        out, lse2 = spatial_attn_fwd_raw(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], pos, plan, H, scale, inv_tau, 0, drop_p, seed)
         ctx.save_for_backward(qkv, out, lse2, pos)
-        ctx.meta = (plan, H, scale, inv_tau)
+        ctx.meta = (plan, H, scale, inv_tau, drop_p, seed)
         return out
 
     @staticmethod
     def backward(ctx, gout):
         qkv, out, lse2, pos = ctx.saved_tensors
-        plan, H, scale, inv_tau = ctx.meta
+        plan, H, scale, inv_tau, drop_p, seed = ctx.meta
         C = qkv.size(1) // 3
         dqkv = torch.empty_like(qkv)
-        spatial_attn_bwd_raw(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], out, gout, pos, plan, H, scale, inv_tau, lse2, dqkv)
-        return dqkv, None, None, None, None, None
+        spatial_attn_bwd_raw(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], out, gout, pos, plan, H, scale, inv_tau, lse2, dqkv,
+                             drop_p, seed)
+        return dqkv, None, None, None, None, None, None, None
 
 
-def spatial_attention(qkv, pos, plan: AttnPlan, H: int, scale: float, inv_tau: float = 1.0):
-    return _SpatialAttention.apply(qkv, pos, plan, H, scale, inv_tau)
+def spatial_attention(qkv, pos, plan: AttnPlan, H: int, scale: float, inv_tau: float = 1.0, drop_p: float = 0.0,
+                      training: bool = False, seed: Optional[int] = None):
+    """dropout(softmax(QK^T*scale - dist*inv_tau)) V per graph; ``drop_p`` applies to the attention
+    weights (core/attention.py:154) in training mode."""
+    p = float(drop_p) if training else 0.0
+    if p > 0 and seed is None:
+        seed = next_dropout_seed()
+    return _SpatialAttention.apply(qkv, pos, plan, H, scale, inv_tau, p, seed or 0)
 
 
 # ----------------------------------------------------------------------------- K5 positional encoding
@@ -238,18 +247,6 @@ def spatial_attention_mean_weights(qkv, pos, plan: AttnPlan, H: int, scale: floa
                                                   W.data_ptr(), off_dev.data_ptr(), _lib.stream_ptr(qkv.device)),
                "dgdm_spatial_attn_mean_weights")
     return [W[offs[g]:offs[g + 1]].view(sizes[g], sizes[g]) for g in range(plan.B)]
-
-
-_warned_attn_dropout = False
-
-
-def attention_dropout_unsupported(p: float) -> None:
-    """Placeholder until the in-kernel Philox dropout on attention weights lands."""
-    global _warned_attn_dropout
-    if not _warned_attn_dropout:
-        import warnings
-        warnings.warn(f"attention-weight dropout (p={p}) is not yet applied inside the fused attention kernel")
-        _warned_attn_dropout = True
 
 
 # ----------------------------------------------------------------------------- K6/K7 fused row kernels

@@ -101,16 +101,20 @@ DGDM_API int dgdm_spmm(const int32_t* rowptr, const int32_t* col, const float* w
  *   num_q_tiles = sum_g ceil(n_g / dgdm_spatial_attn_q_tile_rows()), computed by the host.
  *   O:     [N_tot, H*16] (row stride ldo).   lse2: [H, N_tot] log2-domain log-sum-exp of the
  *          scaled+biased scores (m + log2 l), consumed by the backward kernels.
+ *   drop_p, seed: dropout on the attention weights (attention.py:154), applied to softmax(S) before
+ *          the product with V; the mask is a counter hash of (seed, graph, head, q, k) that the
+ *          backward kernels regenerate (pass the same drop_p/seed).  drop_p = 0 disables it.
  */
 DGDM_API int32_t dgdm_spatial_attn_q_tile_rows(void);
 DGDM_API int dgdm_spatial_attn_fwd(const float* Q, const float* K, const float* V, int64_t ld, const float* pos,
                                    const int32_t* ptr, int32_t B, int32_t num_q_tiles, int32_t N_tot, int32_t H,
-                                   float scale, float inv_tau, float* O, int64_t ldo, float* lse2, void* stream);
+                                   float scale, float inv_tau, float drop_p, uint32_t seed, float* O, int64_t ldo,
+                                   float* lse2, void* stream);
 /* same, with an explicit tiling variant (0 = default) -- tuning/bench use only */
 DGDM_API int dgdm_spatial_attn_fwd_variant(const float* Q, const float* K, const float* V, int64_t ld, const float* pos,
                                            const int32_t* ptr, int32_t B, int32_t num_q_tiles, int32_t N_tot, int32_t H,
-                                           float scale, float inv_tau, float* O, int64_t ldo, float* lse2, int32_t variant,
-                                           void* stream);
+                                           float scale, float inv_tau, float drop_p, uint32_t seed, float* O, int64_t ldo,
+                                           float* lse2, int32_t variant, void* stream);
 
 /* K4 backward: dQ, dK, dV of the fused spatial attention (what autograd derives from
  * core/attention.py:135-157 in the reference, with P recomputed per tile instead of stored).
@@ -121,18 +125,20 @@ DGDM_API int dgdm_spatial_attn_fwd_variant(const float* Q, const float* K, const
 DGDM_API int dgdm_spatial_attn_bwd(const float* Q, const float* K, const float* V, int64_t ld, const float* O,
                                    const float* dO, int64_t ldo, const float* pos, const int32_t* ptr, int32_t B,
                                    int32_t num_q_tiles, int32_t N_tot, int32_t H, float scale, float inv_tau,
-                                   const float* lse2, float* dQ, float* dK, float* dV, int64_t ldg, float* delta_ws,
-                                   void* stream);
+                                   const float* lse2, float drop_p, uint32_t seed, float* dQ, float* dK, float* dV, int64_t ldg,
+                                   float* delta_ws, void* stream);
 /* the two passes of dgdm_spatial_attn_bwd as separate entry points (pass 2 must follow pass 1 on
  * the same stream): lets a caller time or overlap them individually. */
 DGDM_API int dgdm_spatial_attn_bwd_dq(const float* Q, const float* K, const float* V, int64_t ld, const float* O,
                                       const float* dO, int64_t ldo, const float* pos, const int32_t* ptr, int32_t B,
                                       int32_t num_q_tiles, int32_t N_tot, int32_t H, float scale, float inv_tau,
-                                      const float* lse2, float* dQ, int64_t ldg, float* delta_ws, void* stream);
+                                      const float* lse2, float drop_p, uint32_t seed, float* dQ, int64_t ldg, float* delta_ws,
+                                      void* stream);
 DGDM_API int dgdm_spatial_attn_bwd_dkv(const float* Q, const float* K, const float* V, int64_t ld, const float* dO,
                                        int64_t ldo, const float* pos, const int32_t* ptr, int32_t B, int32_t num_q_tiles,
                                        int32_t N_tot, int32_t H, float scale, float inv_tau, const float* lse2,
-                                       const float* delta_ws, float* dK, float* dV, int64_t ldg, void* stream);
+                                       const float* delta_ws, float drop_p, uint32_t seed, float* dK, float* dV, int64_t ldg,
+                                       void* stream);
 
 /* Head-mean attention weights per graph (what MultiHeadAttention returns with need_weights,
  * core/attention.py:171-173; DGDMModel's `attention_weights` output, dgdm_model.py:360-361).

@@ -99,3 +99,61 @@ def test_attn_backward_matches_dense(ptr, H):
     d2 = qkv.to(DEV).requires_grad_(True)
     ops.spatial_attention(d2, pos.to(DEV), plan, H, 0.25, 1.0).backward(gout.to(DEV))
     assert torch.equal(d.grad, d2.grad)
+
+
+def test_attn_dropout_mask_consistent_between_forward_and_both_backward_kernels():
+    """Dropout on the attention weights: extract the kernel's own mask F (V = one-hot blocks), then
+    check O = (P*F)V and dQ/dK/dV against float64 autograd of the same masked formula: proves the dQ
+    (q-major) and dK/dV (k-major) kernels regenerate exactly the forward's mask."""
+    from dgdm_histopath_lab_amd import ops
+    ptr, H, p, seed = [0, 37, 100], 2, 0.25, 1234567
+    C, n = H * 16, ptr[-1]
+    qkv, pos = make(ptr, H, 99)
+    plan = ops.AttnPlan(ptr, DEV)
+    d = qkv.to(DEV)
+    q, k = d[:, :C], d[:, C:2 * C]
+    # dense probabilities per graph / head (float64)
+    P = torch.zeros(H, n, n, dtype=torch.float64)
+    for g in range(len(ptr) - 1):
+        sl = slice(ptr[g], ptr[g + 1]); m = ptr[g + 1] - ptr[g]
+        qg = qkv[sl, :C].double().view(m, H, 16).transpose(0, 1); kg = qkv[sl, C:2 * C].double().view(m, H, 16).transpose(0, 1)
+        pp = pos[sl].double()
+        P[:, sl, sl] = torch.softmax(qg @ kg.transpose(1, 2) / 4.0 - torch.norm(pp[:, None] - pp[None], dim=-1), dim=-1)
+    PF = torch.zeros_like(P)
+    for c in range((n + 15) // 16):          # 16 key columns per run through a one-hot V
+        v = torch.zeros(n, C)
+        for kk in range(16 * c, min(n, 16 * c + 16)):
+            v[kk, [h * 16 + (kk - 16 * c) for h in range(H)]] = 1.0
+        o, _ = ops.spatial_attn_fwd_raw(q, k, v.to(DEV), pos.to(DEV), plan, H, 0.25, 1.0, 0, p, seed)
+        o = o.cpu().double().view(n, H, 16)
+        w = min(16, n - 16 * c)
+        PF[:, :, 16 * c:16 * c + w] = o[:, :, :w].permute(1, 0, 2)
+    keep = 1.0 / (1.0 - int(p * 65536) / 65536)
+    inside = P > 0
+    F = torch.where(inside, PF / P.clamp_min(1e-300), torch.zeros_like(P))
+    isdrop, iskeep = (F.abs() < 1e-4), ((F - keep).abs() < 1e-3)
+    assert bool((isdrop | iskeep)[inside].all())
+    rate = isdrop[inside].double().mean().item()
+    assert abs(rate - p) < 0.02, rate
+    assert abs(isdrop[0][inside[0]].double().mean() - isdrop[1][inside[1]].double().mean()) < 0.03  # heads draw differently
+    assert not torch.equal(isdrop[0], isdrop[1])
+    Fm = torch.where(iskeep, torch.full_like(F, keep), torch.zeros_like(F))
+    # now a normal run with random V: forward + both backward kernels against the masked dense formula
+    g = torch.Generator().manual_seed(5)
+    gout = torch.randn(n, C, generator=g)
+    dq = qkv.to(DEV).requires_grad_(True)
+    o = ops.spatial_attention(dq, pos.to(DEV), plan, H, 0.25, 1.0, p, True, seed)
+    o.backward(gout.to(DEV))
+    r = qkv.double().clone().requires_grad_(True)
+    outs = []
+    for g_ in range(len(ptr) - 1):
+        sl = slice(ptr[g_], ptr[g_ + 1]); m = ptr[g_ + 1] - ptr[g_]
+        qg, kg, vg = (r[sl, i * C:(i + 1) * C].view(m, H, 16).transpose(0, 1) for i in range(3))
+        pp = pos[sl].double()
+        w = torch.softmax(qg @ kg.transpose(1, 2) / 4.0 - torch.norm(pp[:, None] - pp[None], dim=-1), dim=-1) * Fm[:, sl, sl]
+        outs.append((w @ vg).transpose(0, 1).reshape(m, C))
+    ro = torch.cat(outs); ro.backward(gout.double())
+    assert_close(o, ro, 1e-5, "O (dropout)")
+    assert_close(dq.grad[:, :C], r.grad[:, :C], 3e-5, "dQ (dropout)")
+    assert_close(dq.grad[:, C:2 * C], r.grad[:, C:2 * C], 3e-5, "dK (dropout)")
+    assert_close(dq.grad[:, 2 * C:], r.grad[:, 2 * C:], 3e-5, "dV (dropout)")
