@@ -124,7 +124,8 @@ def test_attn_dropout_mask_consistent_between_forward_and_both_backward_kernels(
         v = torch.zeros(n, C)
         for kk in range(16 * c, min(n, 16 * c + 16)):
             v[kk, [h * 16 + (kk - 16 * c) for h in range(H)]] = 1.0
-        o, _ = ops.spatial_attn_fwd_raw(q, k, v.to(DEV), pos.to(DEV), plan, H, 0.25, 1.0, 0, p, seed)
+        buf = d.clone(); buf[:, 2 * C:] = v.to(DEV)       # same row stride for Q, K and the probe V
+        o, _ = ops.spatial_attn_fwd_raw(buf[:, :C], buf[:, C:2 * C], buf[:, 2 * C:], pos.to(DEV), plan, H, 0.25, 1.0, 0, p, seed)
         o = o.cpu().double().view(n, H, 16)
         w = min(16, n - 16 * c)
         PF[:, :, 16 * c:16 * c + w] = o[:, :, :w].permute(1, 0, 2)
