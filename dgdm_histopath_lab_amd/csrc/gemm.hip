@@ -1,0 +1,311 @@
+// K3: fp32 MFMA GEMMs for the dense node-feature x weight contractions of the hot path
+// (every nn.Linear of models/encoders.py, core/graph_layers.py, core/attention.py,
+// core/diffusion.py).  The shapes are tall-skinny: M = nodes of the batch (5k .. 400k), K and N
+// <= 1024.  Exact fp32: v_mfma_f32_32x32x2_f32 (64 FLOP/clk/SIMD = the fp32 matrix peak).
+//
+//   dgdm_gemm_nt : C[M,N] (+)= A[M,K] . W[N,K]^T + bias      forward of nn.Linear
+//   dgdm_gemm_nn : C[M,K] (+)= A[M,N] . W[N,K]               dX of nn.Linear
+//   dgdm_gemm_tn : dW[N,K]  = dY[M,N]^T . X[M,K],  db[N] = colsum(dY)   (reduction over M)
+//
+// nt/nn share one kernel: a 128x128 output tile per 256-thread workgroup (4 waves, 64x64 each =
+// 2x2 MFMA tiles), K swept in 32-deep blocks staged through LDS with the reduction index
+// contiguous ([row][k], rows padded to 36 floats => conflict-free ds_read_b128), the next block's
+// global loads held in registers under the current block's MFMAs.  Each lane reads 4 consecutive k
+// per operand row with one b128 and feeds them to 4 MFMA steps; both operands use the same k
+// permutation, so the sum is unchanged.
+// tn: the reduction runs over M, so each workgroup takes one 128x128 tile of dW and one chunk of
+// rows and writes a partial tile; a second kernel sums the partials in chunk order (no atomics,
+// bitwise reproducible).  A virtual column of ones appended to X makes column K of the result the
+// bias gradient.
+#include "common.hpp"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 32, LDT = BK + 4;  // LDS row = 36 floats (144 B)
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// one 32-deep block: acc[mt][nt] += As[wave rows][k] * Bs[wave cols][k]
+__device__ __forceinline__ void mma_block(const float* __restrict__ As, const float* __restrict__ Bs, int arow0, int brow0,
+                                          int lane, f32x16 (&acc)[2][2]) {
+  const int i = lane & 31, kh = lane >> 5;
+#pragma unroll
+  for (int s = 0; s < BK / 8; ++s) {
+    f32x4v a[2], b[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      a[t] = *reinterpret_cast<const f32x4v*>(&As[(arow0 + t * 32 + i) * LDT + 8 * s + 4 * kh]);
+      b[t] = *reinterpret_cast<const f32x4v*>(&Bs[(brow0 + t * 32 + i) * LDT + 8 * s + 4 * kh]);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = mfma32(a[mt][e], b[nt][e], acc[mt][nt]);
+  }
+}
+
+// ---- staging helpers: a [rows x 32] tile whose global layout has the reduction index contiguous
+struct RowTile {  // 128 rows x 32 k, 1024 float4 -> 4 per thread
+  float4 v[4];
+  __device__ __forceinline__ void load(const float* __restrict__ P, int64_t ld, int row0, int nrows, int k0, int K, int tid) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + 256 * i, r = idx >> 3, c4 = idx & 7;
+      const int row = row0 + r, k = k0 + 4 * c4;
+      v[i] = (row < nrows && k < K) ? *reinterpret_cast<const float4*>(P + (int64_t)row * ld + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  __device__ __forceinline__ void store(float* __restrict__ S, int tid) const {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + 256 * i, r = idx >> 3, c4 = idx & 7;
+      *reinterpret_cast<float4*>(&S[r * LDT + 4 * c4]) = v[i];
+    }
+  }
+};
+// ---- a [32 k x 128 cols] tile whose global layout has the OUTPUT index contiguous (needs a
+// transpose into the [col][k] LDS image).  `ones_col` >= 0: that global column reads as 1.0.
+struct ColTile {
+  float4 v[4];
+  __device__ __forceinline__ void load(const float* __restrict__ P, int64_t ld, int k0, int K, int col0, int ncols, int tid,
+                                       int ones_col = -1) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + 256 * i, kr = idx >> 5, c4 = idx & 31;
+      const int k = k0 + kr, col = col0 + 4 * c4;
+      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (k < K) {
+        if (col + 3 < ncols) {
+          t = *reinterpret_cast<const float4*>(P + (int64_t)k * ld + col);
+        } else {  // ragged right edge (and the virtual ones column)
+          float e[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) e[j] = (col + j < ncols) ? P[(int64_t)k * ld + col + j] : ((col + j == ones_col) ? 1.0f : 0.f);
+          t = make_float4(e[0], e[1], e[2], e[3]);
+        }
+      }
+      v[i] = t;
+    }
+  }
+  __device__ __forceinline__ void store(float* __restrict__ S, int tid) const {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + 256 * i, kr = idx >> 5, c4 = idx & 31;
+      S[(4 * c4 + 0) * LDT + kr] = v[i].x;
+      S[(4 * c4 + 1) * LDT + kr] = v[i].y;
+      S[(4 * c4 + 2) * LDT + kr] = v[i].z;
+      S[(4 * c4 + 3) * LDT + kr] = v[i].w;
+    }
+  }
+};
+
+// C/D map of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+template <bool B_KCONTIG>
+__global__ __launch_bounds__(256, 2) void k_gemm_rows(const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
+                                                      int64_t ldb, float* __restrict__ C, int64_t ldc, int M, int N, int K,
+                                                      const float* __restrict__ bias, int accumulate) {
+  __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDT];
+  float* As = smem;
+  float* Bs = smem + BM * LDT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int wr = wave >> 1, wc = wave & 1;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  RowTile ta;
+  RowTile tbr;
+  ColTile tbc;
+  ta.load(A, lda, m0, M, 0, K, tid);
+  if (B_KCONTIG) tbr.load(B, ldb, n0, N, 0, K, tid); else tbc.load(B, ldb, 0, K, n0, N, tid);
+  for (int k0 = 0; k0 < K; k0 += BK) {
+    __syncthreads();
+    ta.store(As, tid);
+    if (B_KCONTIG) tbr.store(Bs, tid); else tbc.store(Bs, tid);
+    __syncthreads();
+    if (k0 + BK < K) {
+      ta.load(A, lda, m0, M, k0 + BK, K, tid);
+      if (B_KCONTIG) tbr.load(B, ldb, n0, N, k0 + BK, K, tid); else tbc.load(B, ldb, k0 + BK, K, n0, N, tid);
+    }
+    mma_block(As, Bs, wr * 64, wc * 64, lane, acc);
+  }
+
+  const int j = lane & 31, hi = lane >> 5;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int col = n0 + wc * 64 + nt * 32 + j;
+      if (col >= N) continue;
+      const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wr * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (row < M) {
+          float* dst = C + (int64_t)row * ldc + col;
+          const float v = acc[mt][nt][r] + bv;
+          *dst = accumulate ? *dst + v : v;
+        }
+      }
+    }
+}
+
+// dW partial: tile (n0, k0) of [N x Kext], rows [mc*chunk, (mc+1)*chunk)
+__global__ __launch_bounds__(256, 2) void k_gemm_tn_partial(const float* __restrict__ dY, int64_t ldy, const float* __restrict__ X,
+                                                            int64_t ldx, int M, int N, int K, int Kext, int chunk,
+                                                            float* __restrict__ partial) {
+  __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDT];
+  float* Ys = smem;             // [n][m]
+  float* Xs = smem + BM * LDT;  // [k][m]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n0 = blockIdx.x * BM, kk0 = blockIdx.y * BN, mc = blockIdx.z;
+  const int mbeg = mc * chunk, mend = min(M, mbeg + chunk);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int ones_col = Kext > K ? K : -1;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  ColTile ty, tx;
+  ty.load(dY, ldy, mbeg, mend, n0, N, tid);
+  tx.load(X, ldx, mbeg, mend, kk0, K, tid, ones_col);
+  for (int m = mbeg; m < mend; m += BK) {
+    __syncthreads();
+    ty.store(Ys, tid);
+    tx.store(Xs, tid);
+    __syncthreads();
+    if (m + BK < mend) {
+      ty.load(dY, ldy, m + BK, mend, n0, N, tid);
+      tx.load(X, ldx, m + BK, mend, kk0, K, tid, ones_col);
+    }
+    mma_block(Ys, Xs, wr * 64, wc * 64, lane, acc);
+  }
+  const int j = lane & 31, hi = lane >> 5;
+  float* P = partial + (int64_t)mc * N * Kext;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int col = kk0 + wc * 64 + nt * 32 + j;
+      if (col >= Kext) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = n0 + wr * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (row < N) P[(int64_t)row * Kext + col] = acc[mt][nt][r];
+      }
+    }
+}
+
+// dW[n][k] = sum_c partial[c][n][k] (k < K), db[n] = sum_c partial[c][n][K]; chunk order fixed.
+__global__ __launch_bounds__(256) void k_gemm_tn_reduce(const float* __restrict__ partial, int nchunks, int N, int K, int Kext,
+                                                        float* __restrict__ dW, int64_t lddw, float* __restrict__ db) {
+  const int64_t total = (int64_t)N * Kext;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += stride) {
+    float s = 0.f;
+    for (int c = 0; c < nchunks; ++c) s += partial[(int64_t)c * total + i];
+    const int n = (int)(i / Kext), k = (int)(i % Kext);
+    if (k < K) dW[(int64_t)n * lddw + k] = s;
+    else if (db) db[n] = s;
+  }
+}
+
+int tn_chunk_rows(int M, int N, int Kext) {
+  // enough workgroups to fill 256 CUs ~2x, chunks a multiple of BK rows, at most 256 chunks
+  const int tiles = ((N + BM - 1) / BM) * ((Kext + BN - 1) / BN);
+  int want = (512 + tiles - 1) / tiles;
+  if (want < 1) want = 1;
+  if (want > 256) want = 256;
+  int chunk = (M + want - 1) / want;
+  chunk = (chunk + BK - 1) / BK * BK;
+  if (chunk < 4 * BK) chunk = 4 * BK;
+  return chunk;
+}
+
+}  // namespace
+
+static int gemm_rows_check(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int32_t M, int32_t N,
+                           int32_t K, const float* bias, int kdim_a, int kdim_b_contig) {
+  if (M < 0 || N < 0 || K < 0) return DGDM_ERR_INVALID_ARG;
+  if (M == 0 || N == 0) return 1;
+  if (!A || !B || !C) return DGDM_ERR_INVALID_ARG;
+  if ((K & 3) || (lda & 3) || (ldb & 3) || lda < kdim_a || !dgdm_aligned16(A) || !dgdm_aligned16(B)) return DGDM_ERR_UNSUPPORTED;
+  if (ldc < N) return DGDM_ERR_INVALID_ARG;
+  (void)bias; (void)kdim_b_contig;
+  return DGDM_OK;
+}
+
+extern "C" int dgdm_gemm_nt(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* C, int64_t ldc,
+                            int32_t M, int32_t N, int32_t K, int32_t accumulate, void* stream) {
+  int rc = gemm_rows_check(A, lda, W, ldw, C, ldc, M, N, K, bias, K, 1);
+  if (rc != DGDM_OK) return rc > 0 ? DGDM_OK : rc;
+  if (ldw < K) return DGDM_ERR_INVALID_ARG;
+  hipLaunchKernelGGL((k_gemm_rows<true>), dim3((M + BM - 1) / BM, (N + BN - 1) / BN), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     A, lda, W, ldw, C, ldc, M, N, K, bias, accumulate);
+  return dgdm_launch_status();
+}
+
+// C[M, Kout] (+)= A[M, N] . W[N, Kout]   (W row-major with row stride ldw >= Kout)
+extern "C" int dgdm_gemm_nn(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc, int32_t M, int32_t N,
+                            int32_t Kout, int32_t accumulate, void* stream) {
+  // reduction index = N; output columns = Kout (loaded 4 at a time along W rows)
+  if (M < 0 || N < 0 || Kout < 0) return DGDM_ERR_INVALID_ARG;
+  if (M == 0 || Kout == 0) return DGDM_OK;
+  if (!A || !W || !C) return DGDM_ERR_INVALID_ARG;
+  if ((N & 3) || (lda & 3) || (ldw & 3) || lda < N || ldw < Kout || ldc < Kout || !dgdm_aligned16(A) || !dgdm_aligned16(W))
+    return DGDM_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL((k_gemm_rows<false>), dim3((M + BM - 1) / BM, (Kout + BN - 1) / BN), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), A, lda, W, ldw, C, ldc, M, Kout, N, (const float*)nullptr, accumulate);
+  return dgdm_launch_status();
+}
+
+extern "C" size_t dgdm_gemm_tn_workspace_bytes(int32_t M, int32_t N, int32_t K, int32_t with_bias) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  const int Kext = K + (with_bias ? 1 : 0);
+  const int chunk = tn_chunk_rows(M, N, Kext);
+  const int nchunks = (M + chunk - 1) / chunk;
+  return (size_t)nchunks * N * Kext * sizeof(float);
+}
+
+extern "C" int dgdm_gemm_tn(const float* dY, int64_t ldy, const float* X, int64_t ldx, float* dW, int64_t lddw, float* db, int32_t M,
+                            int32_t N, int32_t K, void* workspace, size_t workspace_bytes, void* stream_) {
+  if (M < 0 || N < 0 || K < 0) return DGDM_ERR_INVALID_ARG;
+  if (N == 0 || K == 0) return DGDM_OK;
+  if (!dW || lddw < K) return DGDM_ERR_INVALID_ARG;
+  hipStream_t s = static_cast<hipStream_t>(stream_);
+  if (M == 0) {
+    (void)hipMemset2DAsync(dW, (size_t)lddw * sizeof(float), 0, (size_t)K * sizeof(float), (size_t)N, s);
+    if (db) (void)hipMemsetAsync(db, 0, sizeof(float) * N, s);
+    return dgdm_launch_status();
+  }
+  if (!dY || !X || !workspace) return DGDM_ERR_INVALID_ARG;
+  if ((ldy & 3) || (ldx & 3) || (N & 3) || (K & 3) || ldy < N || ldx < K || !dgdm_aligned16(dY) || !dgdm_aligned16(X))
+    return DGDM_ERR_UNSUPPORTED;
+  const int Kext = K + (db ? 1 : 0);
+  const int chunk = tn_chunk_rows(M, N, Kext);
+  const int nchunks = (M + chunk - 1) / chunk;
+  if (workspace_bytes < (size_t)nchunks * N * Kext * sizeof(float)) return DGDM_ERR_WORKSPACE;
+  float* partial = static_cast<float*>(workspace);
+  hipLaunchKernelGGL(k_gemm_tn_partial, dim3((N + BM - 1) / BM, (Kext + BN - 1) / BN, nchunks), dim3(256), 0, s, dY, ldy, X, ldx, M, N,
+                     K, Kext, chunk, partial);
+  const int64_t total = (int64_t)N * Kext;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(k_gemm_tn_reduce, dim3((unsigned)blocks), dim3(256), 0, s, partial, nchunks, N, K, Kext, dW, lddw, db);
+  return dgdm_launch_status();
+}

@@ -439,3 +439,92 @@ def attn_pool(kv, q_scaled, plan: AttnPlan, H: int, D: int, drop_p: float = 0.0,
     """GlobalAttentionPool core: kv [N, 2*H*D] (K | V), q_scaled [H*D] -> [B, H*D]."""
     p = float(drop_p) if training else 0.0
     return _AttnPool.apply(kv, q_scaled, plan, H, D, p, next_dropout_seed() if p > 0 else 0)
+
+
+# ----------------------------------------------------------------------------- K3 dense contractions
+GEMM_MIN_ROWS = 256   # below this the launch is latency-bound either way: tiny per-graph GEMMs stay in torch
+
+
+def _rowmajor(t: torch.Tensor) -> torch.Tensor:
+    """2-D fp32 view with unit column stride and a row stride that keeps 16-B alignment."""
+    if t.dtype != torch.float32:
+        raise _lib.DGDMKernelError(f"HIP kernels compute in fp32, got {t.dtype}")
+    if t.dim() == 2 and t.stride(1) == 1 and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0 and t.stride(0) >= t.size(1):
+        return t
+    return t.contiguous()
+
+
+def gemm_nt_raw(a, w, bias=None, out=None, accumulate=False):
+    lib = _lib.load()
+    a, w = _rowmajor(a), _rowmajor(w)
+    M, K = a.shape
+    N = w.size(0)
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    TIMERS.timed("gemm_nt", lambda: _lib.check(
+        lib.dgdm_gemm_nt(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), _lib.ptr(bias), out.data_ptr(), out.stride(0), M, N, K,
+                         int(accumulate), _lib.stream_ptr(a.device)), "dgdm_gemm_nt"))
+    return out
+
+
+def gemm_nn_raw(a, w, out=None, accumulate=False):
+    """a [M,N] . w [N,K] -> [M,K]"""
+    lib = _lib.load()
+    a, w = _rowmajor(a), _rowmajor(w)
+    M, N = a.shape
+    K = w.size(1)
+    if out is None:
+        out = torch.empty(M, K, dtype=torch.float32, device=a.device)
+    TIMERS.timed("gemm_nn", lambda: _lib.check(
+        lib.dgdm_gemm_nn(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(), out.stride(0), M, N, K, int(accumulate),
+                         _lib.stream_ptr(a.device)), "dgdm_gemm_nn"))
+    return out
+
+
+def gemm_tn_raw(dy, x, with_bias: bool):
+    """dW [N,K] = dy[M,N]^T x[M,K]; db [N] = colsum(dy) (fixed-order split-M reduction)."""
+    lib = _lib.load()
+    dy, x = _rowmajor(dy), _rowmajor(x)
+    M, N = dy.shape
+    K = x.size(1)
+    dW = torch.empty(N, K, dtype=torch.float32, device=x.device)
+    db = torch.empty(N, dtype=torch.float32, device=x.device) if with_bias else None
+    wsb = lib.dgdm_gemm_tn_workspace_bytes(M, N, K, int(with_bias))
+    ws = torch.empty(max(wsb, 4) // 4, dtype=torch.float32, device=x.device)
+    TIMERS.timed("gemm_tn", lambda: _lib.check(
+        lib.dgdm_gemm_tn(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), dW.data_ptr(), dW.stride(0), _lib.ptr(db), M, N, K,
+                         ws.data_ptr(), wsb, _lib.stream_ptr(x.device)), "dgdm_gemm_tn"))
+    return dW, db
+
+
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return gemm_nt_raw(x, w, b)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gy = _rowmajor(gy)
+        dx = gemm_nn_raw(gy, w) if ctx.needs_input_grad[0] else None
+        dW = db = None
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dW, db = gemm_tn_raw(gy, x, ctx.has_bias)
+        return dx, dW, db
+
+
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y = x @ weight^T + bias on the fp32-MFMA GEMM kernels (forward, dX and dW/db).  Shapes the
+    kernels are not built for (fewer than GEMM_MIN_ROWS rows, K or N not a multiple of 4) go to
+    the library GEMM -- still on the GPU."""
+    if (x.dim() == 2 and x.is_cuda and x.size(0) >= GEMM_MIN_ROWS and x.size(1) % 4 == 0 and weight.size(0) % 4 == 0
+            and x.dtype == torch.float32):
+        return _Linear.apply(x, weight, bias)
+    return torch.nn.functional.linear(x, weight, bias)
+
+
+def lin(module, x: torch.Tensor) -> torch.Tensor:
+    """Apply an nn.Linear through `linear`."""
+    return linear(x, module.weight, module.bias)

@@ -210,6 +210,25 @@ DGDM_API int dgdm_attn_pool_bwd(const float* K, const float* V, int64_t ld, cons
                                 int32_t H, int32_t D, float drop_p, uint32_t seed, const float* P, const float* out,
                                 const float* dout, float* dK, float* dV, int64_t ldg, float* dq_partial, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * K3  fp32-MFMA GEMMs for the dense node-feature x weight contractions: every nn.Linear on the
+ * path (models/encoders.py:73-91,215; core/graph_layers.py:45-49,146; core/attention.py:44-49;
+ * core/diffusion.py:94-104) and its autograd.  Tall-skinny: M = nodes of the batch, N, K <= ~1k.
+ * Exact fp32 (v_mfma_f32_32x32x2_f32).  All matrices row-major with explicit row strides.
+ *   dgdm_gemm_nt: C[M,N] (+)= A[M,K] . W[N,K]^T + bias[N]      y = Linear(x)       K % 4 == 0
+ *   dgdm_gemm_nn: C[M,K] (+)= A[M,N] . W[N,K]                  dx = dy . W         N % 4 == 0
+ *   dgdm_gemm_tn: dW[N,K] = dY[M,N]^T . X[M,K]; db[N] = column sums of dY (db nullable)
+ *                 split over M into chunks whose partial tiles are summed in chunk order
+ *                 (workspace from dgdm_gemm_tn_workspace_bytes; no atomics).  N % 4 == K % 4 == 0.
+ */
+DGDM_API int dgdm_gemm_nt(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* C, int64_t ldc,
+                          int32_t M, int32_t N, int32_t K, int32_t accumulate, void* stream);
+DGDM_API int dgdm_gemm_nn(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc, int32_t M, int32_t N,
+                          int32_t Kout, int32_t accumulate, void* stream);
+DGDM_API size_t dgdm_gemm_tn_workspace_bytes(int32_t M, int32_t N, int32_t K, int32_t with_bias);
+DGDM_API int dgdm_gemm_tn(const float* dY, int64_t ldy, const float* X, int64_t ldx, float* dW, int64_t lddw, float* db, int32_t M,
+                          int32_t N, int32_t K, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

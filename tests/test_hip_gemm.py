@@ -1,0 +1,51 @@
+"""GPU parity of the fp32-MFMA GEMMs (K3) against float64 torch."""
+import pytest
+import torch
+
+from conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("m,k,n", [(1, 4, 4), (130, 36, 12), (1000, 768, 512), (4001, 544, 512), (2000, 160, 128), (777, 128, 384),
+                                   (5000, 288, 256), (300, 40, 64), (129, 1024, 260), (40000, 128, 128)])
+def test_gemm_nt_nn_tn(m, k, n):
+    from dgdm_histopath_lab_amd import ops
+    g = torch.Generator().manual_seed(m + k + n)
+    x = torch.randn(m, k, generator=g); w = torch.randn(n, k, generator=g) / k ** 0.5; b = torch.randn(n, generator=g)
+    gy = torch.randn(m, n, generator=g)
+    xd, wd, bd, gd = x.to(DEV), w.to(DEV), b.to(DEV), gy.to(DEV)
+    y = ops.gemm_nt_raw(xd, wd, bd)
+    assert_close(y, x.double() @ w.double().t() + b.double(), 1e-5, "nt")
+    y2 = ops.gemm_nt_raw(xd, wd, None, out=y.clone(), accumulate=True)
+    assert_close(y2, 2 * (x.double() @ w.double().t()) + b.double(), 1e-5, "nt accumulate")
+    dx = ops.gemm_nn_raw(gd, wd)
+    assert_close(dx, gy.double() @ w.double(), 1e-5, "nn")
+    dW, db = ops.gemm_tn_raw(gd, xd, True)
+    assert_close(dW, gy.double().t() @ x.double(), 1e-5, "tn dW")
+    assert_close(db, gy.double().sum(0), 1e-5, "tn db")
+    dW2, none = ops.gemm_tn_raw(gd, xd, False)
+    assert none is None and torch.equal(dW2, dW)            # fixed reduction order: bitwise reproducible
+
+
+def test_gemm_strided_operands_and_autograd():
+    from dgdm_histopath_lab_amd import ops
+    g = torch.Generator().manual_seed(0)
+    big = torch.randn(3000, 544 + 64, generator=g)           # A = column slice (row stride 608)
+    wbig = torch.randn(256, 800, generator=g) / 20           # W = column slice of a wider parameter
+    b = torch.randn(256, generator=g)
+    A = big[:, :544]; W = wbig[:, 128:128 + 544]
+    Ad = big.to(DEV)[:, :544].requires_grad_(True)
+    wfull = wbig.to(DEV).requires_grad_(True); bd = b.to(DEV).requires_grad_(True)
+    y = ops.linear(Ad, wfull[:, 128:128 + 544], bd)
+    gy = torch.randn(3000, 256, generator=g)
+    y.backward(gy.to(DEV))
+    Ar, Wr, br = A.double().requires_grad_(True), W.double().requires_grad_(True), b.double().requires_grad_(True)
+    yr = torch.nn.functional.linear(Ar, Wr, br); yr.backward(gy.double())
+    assert_close(y, yr, 1e-5, "y"); assert_close(Ad.grad, Ar.grad, 1e-5, "dA")
+    assert_close(wfull.grad[:, 128:128 + 544], Wr.grad, 1e-5, "dW slice"); assert_close(bd.grad, br.grad, 1e-5, "db")
+    assert wfull.grad[:, :128].abs().max() == 0
+    # shapes outside the kernel's domain fall back to the library GEMM but stay correct
+    small = torch.randn(7, 10, device=DEV); ws = torch.randn(3, 10, device=DEV)
+    assert_close(ops.linear(small, ws), small.double().cpu() @ ws.double().cpu().t(), 1e-5, "fallback")
