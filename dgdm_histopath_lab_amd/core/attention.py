@@ -55,7 +55,7 @@ class MultiHeadAttention(nn.Module):
             w = F.pad(w.view(3 * H, d, C), (0, 0, 0, KERNEL_HEAD_DIM - d)).reshape(3 * H * KERNEL_HEAD_DIM, C)
             if b is not None:
                 b = F.pad(b.view(3 * H, d), (0, KERNEL_HEAD_DIM - d)).reshape(-1)
-        return F.linear(x, w, b)
+        return ops.linear(x, w, b)
 
     def unpad_heads(self, o: Tensor) -> Tensor:
         if self.head_dim == KERNEL_HEAD_DIM:
@@ -89,7 +89,7 @@ class SpatialAttention(nn.Module):
         qkv = att.fused_qkv(xp)
         o = ops.spatial_attention(qkv, pos, plan, att.num_heads, 1.0 / math.sqrt(att.head_dim), 1.0 / self.temperature,
                                   att.attn_dropout.p, att.training)
-        o = ops.act_dropout(att.out_proj(att.unpad_heads(o)), ops.ACT_NONE, att.resid_dropout.p, att.training)
+        o = ops.act_dropout(ops.lin(att.out_proj, att.unpad_heads(o)), ops.ACT_NONE, att.resid_dropout.p, att.training)
         if ops.row_norm_supported(self.embed_dim, 1):
             return ops.row_norm(o, self.norm.weight, self.norm.bias, res=x, eps=self.norm.eps)
         return self.norm(x + o)

@@ -92,7 +92,7 @@ class DiffusionLayer(nn.Module):
         te = self.time_embed(self.get_timestep_embedding(timesteps))                  # [B, hidden]
         lin0 = self.denoise_net[0]
         per_graph = F.linear(te, lin0.weight[:, C:], lin0.bias)                      # time half of the concat + bias
-        h = F.linear(x_noisy, lin0.weight[:, :C])
+        h = ops.linear(x_noisy, lin0.weight[:, :C])
         if plan is not None and h.size(1) % 4 == 0:
             h = ops.segment_bcast_add(h, per_graph, plan)
         else:
@@ -104,7 +104,7 @@ class DiffusionLayer(nn.Module):
                                  training=self.training)
             else:  # group width not a multiple of 4 channels: separate GPU ops
                 h = drop(F.silu(F.group_norm(h, gn.num_groups, gn.weight, gn.bias, gn.eps)))
-            h = lin(h)
+            h = ops.lin(lin, h)
         return h
 
     # -- reference-shaped API (same graph for every row) --------------------------------------

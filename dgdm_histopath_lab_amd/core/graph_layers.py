@@ -71,11 +71,11 @@ class GraphConvolution(nn.Module):
 
     def forward(self, x: Tensor, edge_index: Union[Tensor, GraphContext], edge_attr: Optional[Tensor] = None, size=None) -> Tensor:
         ctx = _context(edge_index, x, edge_attr, self.add_self_loops)
-        ax = ops.aggregate(x, ctx.gs)
-        out = F.linear(ax, self.node_lin.weight, self.bias)
         if self.edge_lin is not None and ctx.ea_hat is not None:
-            out = torch.addmm(out, ctx.ea_hat, self.edge_lin.weight.t())
-        return out
+            # one contraction over K = C_in + edge_dim:  [A_hat x | EA_hat] . [W | W_e]^T + b
+            buf = ops.aggregate_concat(x, ctx.ea_hat, ctx.gs)
+            return ops.linear(buf, torch.cat([self.node_lin.weight, self.edge_lin.weight], dim=1), self.bias)
+        return ops.linear(ops.aggregate(x, ctx.gs), self.node_lin.weight, self.bias)
 
 
 class DynamicGraphLayer(nn.Module):
@@ -107,7 +107,7 @@ class DynamicGraphLayer(nn.Module):
         p, tr = self.dropout.p, self.training
         h = ops.act_dropout(self.graph_conv1(x, ctx), ops.ACT_GELU, p, tr)
         h = ops.act_dropout(self.graph_conv2(h, ctx), ops.ACT_GELU, p, tr)
-        out = self.output_proj(h)
+        out = ops.lin(self.output_proj, h)
         if isinstance(self.norm1, nn.LayerNorm) and ops.row_norm_supported(self.node_dim, 1):
             return ops.row_norm(out, self.norm1.weight, self.norm1.bias, res=x, eps=self.norm1.eps)
         return self.norm1(out + x)
@@ -134,7 +134,7 @@ class AdaptiveGraphPooling(nn.Module):
 
     def forward(self, x: Tensor, edge_index: Tensor, edge_attr: Optional[Tensor] = None, batch: Optional[Tensor] = None,
                 compact: bool = False) -> Tuple[Tensor, Tensor, Optional[Tensor], Tensor]:
-        s = self.score_net(x).squeeze(-1)
+        s = self.score_net[2](F.relu(ops.lin(self.score_net[0], x))).squeeze(-1)
         s = torch.tanh(s) if self._nl == "tanh" else (torch.softmax(s, 0) if self._nl == "softmax" else torch.sigmoid(s))
         n = x.size(0)
         k = max(1, int(self.ratio * n))
@@ -216,4 +216,4 @@ class GraphUNet(nn.Module):
             x = self.up_convs[i](x, level(lvl, x.size(0)))
             if trace is not None:
                 trace[f"unet.up{i}.out"] = x
-        return self.final_conv(x)
+        return ops.lin(self.final_conv, x)

@@ -402,7 +402,7 @@ class GlobalAttentionPool(nn.Module):
         H, d, C = att.num_heads, att.head_dim, att.embed_dim
         if plan is not None and d in ops.POOL_HEAD_DIMS:   # fused segment-softmax kernel (K10)
             q = att.q_proj(self.global_token.view(1, C)).view(C) * (1.0 / math.sqrt(d))
-            kv = F.linear(x, torch.cat([att.k_proj.weight, att.v_proj.weight]), torch.cat([att.k_proj.bias, att.v_proj.bias]))
+            kv = ops.linear(x, torch.cat([att.k_proj.weight, att.v_proj.weight]), torch.cat([att.k_proj.bias, att.v_proj.bias]))
             o = ops.attn_pool(kv, q, plan.attn, H, d, att.attn_dropout.p, att.training)
             return ops.act_dropout(att.out_proj(o), ops.ACT_NONE, att.resid_dropout.p, att.training) if (B * C) % 4 == 0 \
                 else att.resid_dropout(att.out_proj(o))

@@ -63,10 +63,10 @@ class FeatureEncoder(nn.Module):
         mods = list(self.encoder)
         for i in range(0, len(mods), 4):  # (Linear, norm, act, dropout) quadruples
             lin, norm, act, drop = mods[i:i + 4]
-            h = lin(h)
+            h = ops.lin(lin, h)
             h = _norm_act_dropout(h, norm, act, drop, self.training)
         if self.use_residual:
-            h = h + (self.residual_proj(x) if self.residual_proj is not None else x)
+            h = h + (ops.lin(self.residual_proj, x) if self.residual_proj is not None else x)
         return h
 
 
@@ -110,7 +110,7 @@ class GraphEncoder(nn.Module):
         for i, (layer, norm) in enumerate(zip(self.graph_layers, self.norm_layers)):
             h = layer(h, ctx)
             if str(i) in self.dim_proj:
-                h = self.dim_proj[str(i)](h)
+                h = ops.lin(self.dim_proj[str(i)], h)
             h = _norm_act_dropout(h, norm, self.activation, self.dropout, self.training)
             outs.append(h)
-        return {"embeddings": self.output_proj(h), "layer_outputs": outs, "num_nodes": x.size(0)}
+        return {"embeddings": ops.lin(self.output_proj, h), "layer_outputs": outs, "num_nodes": x.size(0)}

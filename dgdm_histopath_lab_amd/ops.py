@@ -92,6 +92,30 @@ def aggregate(x: torch.Tensor, gs: GraphStructure, out: Optional[torch.Tensor] =
     return _Aggregate.apply(x, gs, out)
 
 
+class _AggregateConcat(torch.autograd.Function):
+    """[A_hat x | EA_hat] as ONE [N, C + edge_dim] buffer: the SpMM writes its column block in place
+    (strided output), the aggregated edge attributes fill the rest.  Feeds the single contraction
+    [A_hat x | EA_hat] . [W | W_e]^T of GraphConvolution (core/graph_layers.py:89-110)."""
+
+    @staticmethod
+    def forward(ctx, x, ea_hat, gs: GraphStructure):
+        cin, ed = x.size(1), ea_hat.size(1)
+        buf = torch.empty(x.size(0), cin + ed, dtype=torch.float32, device=x.device)
+        buf[:, cin:] = ea_hat
+        spmm_raw(gs.rowptr, gs.col, gs.w, x, gs.num_nodes, out=buf[:, :cin])
+        ctx.gs, ctx.cin = gs, cin
+        return buf
+
+    @staticmethod
+    def backward(ctx, gbuf):
+        gs = ctx.gs
+        return spmm_raw(gs.rowptr_t, gs.col_t, gs.w_t, gbuf[:, :ctx.cin], gs.num_nodes), None, None
+
+
+def aggregate_concat(x: torch.Tensor, ea_hat: torch.Tensor, gs: GraphStructure) -> torch.Tensor:
+    return _AggregateConcat.apply(x, ea_hat, gs)
+
+
 def aggregate_edge_attr(edge_attr: Optional[torch.Tensor], gs: GraphStructure) -> torch.Tensor:
     """EA_hat[d] = sum_{e -> d} norm_e * edge_attr[e]  ([N, edge_dim]); the appended self-loop
     entries carry a zero attribute row (repair R1) and ``edge_attr=None`` means zeros
@@ -497,18 +521,31 @@ def gemm_tn_raw(dy, x, with_bias: bool):
     return dW, db
 
 
+# Which implementation runs the forward (nt) and input-gradient (nn) contractions: "own" = the
+# fp32-MFMA kernels of csrc/gemm.hip, "lib" = hipBLASLt through torch (a plain library GEMM; on
+# MI355X its large-shape nt/nn kernels are currently 20-40 % faster than ours, see
+# tools/microbench_gemm.py).  The weight/bias gradient (tn) always uses our split-M kernel
+# (1.3-2.8x faster than library GEMM + separate column sum, and bitwise reproducible).
+import os as _os
+GEMM_FWD_BACKEND = _os.environ.get("DGDM_GEMM", "lib")
+
+
 class _Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b):
         ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
-        return gemm_nt_raw(x, w, b)
+        if GEMM_FWD_BACKEND == "own":
+            return gemm_nt_raw(x, w, b)
+        return torch.nn.functional.linear(x, w, b)
 
     @staticmethod
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
         gy = _rowmajor(gy)
-        dx = gemm_nn_raw(gy, w) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = gemm_nn_raw(gy, w) if GEMM_FWD_BACKEND == "own" else gy @ w
         dW = db = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dW, db = gemm_tn_raw(gy, x, ctx.has_bias)
@@ -516,9 +553,9 @@ class _Linear(torch.autograd.Function):
 
 
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """y = x @ weight^T + bias on the fp32-MFMA GEMM kernels (forward, dX and dW/db).  Shapes the
-    kernels are not built for (fewer than GEMM_MIN_ROWS rows, K or N not a multiple of 4) go to
-    the library GEMM -- still on the GPU."""
+    """y = x @ weight^T + bias with our split-M kernel for dW/db (and, with DGDM_GEMM=own, our
+    MFMA kernels for y and dx).  Shapes the kernels are not built for (fewer than GEMM_MIN_ROWS rows,
+    K or N not a multiple of 4) go to the library GEMM -- still on the GPU."""
     if (x.dim() == 2 and x.is_cuda and x.size(0) >= GEMM_MIN_ROWS and x.size(1) % 4 == 0 and weight.size(0) % 4 == 0
             and x.dtype == torch.float32):
         return _Linear.apply(x, weight, bias)
