@@ -72,13 +72,22 @@ struct RowTile {  // 128 rows x 32 k, 1024 float4 -> 4 per thread
 };
 // ---- a [32 k x 128 cols] tile whose global layout has the OUTPUT index contiguous (needs a
 // transpose into the [col][k] LDS image).  `ones_col` >= 0: that global column reads as 1.0.
+// Thread map: per iteration a wave covers 8 k-rows x 8 float4 columns (lane = kr_lo + 8*c4_lo), so
+// a global request is 8 rows x 128 B and the transposed ds_write_b32 of one component lands on
+// banks {kr} + {0,16}: 2-way, which ds_write_b32 absorbs (the 2-rows-x-32-columns map was 16-way).
 struct ColTile {
+  __device__ static __forceinline__ void map(int tid, int i, int* kr, int* c4) {
+    const int lane = tid & 63, wave = tid >> 6;
+    *kr = 8 * i + (lane & 7);
+    *c4 = (lane >> 3) + 8 * wave;
+  }
   float4 v[4];
   __device__ __forceinline__ void load(const float* __restrict__ P, int64_t ld, int k0, int K, int col0, int ncols, int tid,
                                        int ones_col = -1) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int idx = tid + 256 * i, kr = idx >> 5, c4 = idx & 31;
+      int kr, c4;
+      map(tid, i, &kr, &c4);
       const int k = k0 + kr, col = col0 + 4 * c4;
       float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
       if (k < K) {
@@ -97,7 +106,8 @@ struct ColTile {
   __device__ __forceinline__ void store(float* __restrict__ S, int tid) const {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int idx = tid + 256 * i, kr = idx >> 5, c4 = idx & 31;
+      int kr, c4;
+      map(tid, i, &kr, &c4);
       S[(4 * c4 + 0) * LDT + kr] = v[i].x;
       S[(4 * c4 + 1) * LDT + kr] = v[i].y;
       S[(4 * c4 + 2) * LDT + kr] = v[i].z;
@@ -228,7 +238,7 @@ __global__ __launch_bounds__(256) void k_gemm_tn_reduce(const float* __restrict_
 int tn_chunk_rows(int M, int N, int Kext) {
   // enough workgroups to fill 256 CUs ~2x, chunks a multiple of BK rows, at most 256 chunks
   const int tiles = ((N + BM - 1) / BM) * ((Kext + BN - 1) / BN);
-  int want = (512 + tiles - 1) / tiles;
+  int want = (320 + tiles - 1) / tiles;
   if (want < 1) want = 1;
   if (want > 256) want = 256;
   int chunk = (M + want - 1) / want;
