@@ -25,8 +25,11 @@ def test_gemm_nt_nn_tn(m, k, n):
     dW, db = ops.gemm_tn_raw(gd, xd, True)
     assert_close(dW, gy.double().t() @ x.double(), 1e-5, "tn dW")
     assert_close(db, gy.double().sum(0), 1e-5, "tn db")
-    dW2, none = ops.gemm_tn_raw(gd, xd, False)
-    assert none is None and torch.equal(dW2, dW)            # fixed reduction order: bitwise reproducible
+    dW2, db2 = ops.gemm_tn_raw(gd, xd, True)
+    assert torch.equal(dW2, dW) and torch.equal(db2, db)    # fixed reduction order: bitwise reproducible
+    dW3, none = ops.gemm_tn_raw(gd, xd, False)
+    assert none is None
+    assert_close(dW3, gy.double().t() @ x.double(), 1e-5, "tn dW (no bias)")
 
 
 def test_gemm_strided_operands_and_autograd():
