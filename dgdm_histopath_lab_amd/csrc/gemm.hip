@@ -54,19 +54,27 @@ __device__ __forceinline__ void mma_block(const float* __restrict__ As, const fl
 // ---- staging helpers: a [rows x 32] tile whose global layout has the reduction index contiguous
 struct RowTile {  // 128 rows x 32 k, 1024 float4 -> 4 per thread
   float4 v[4];
+  unsigned okbits;  // validity of v[i]; applied in store() so the loads stay in flight under the MFMAs
   __device__ __forceinline__ void load(const float* __restrict__ P, int64_t ld, int row0, int nrows, int k0, int K, int tid) {
+    okbits = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int idx = tid + 256 * i, r = idx >> 3, c4 = idx & 7;
       const int row = row0 + r, k = k0 + 4 * c4;
-      v[i] = (row < nrows && k < K) ? *reinterpret_cast<const float4*>(P + (int64_t)row * ld + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+      // unconditional load from a clamped (always valid) address + register select: a predicated
+      // load makes hipcc branch around it and drain vmcnt(0) per element
+      const int rc = row < nrows ? row : nrows - 1, kc = k < K ? k : K - 4;
+      v[i] = *reinterpret_cast<const float4*>(P + (int64_t)rc * ld + kc);
+      okbits |= (row < nrows && k < K) ? (1u << i) : 0u;
     }
   }
   __device__ __forceinline__ void store(float* __restrict__ S, int tid) const {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int idx = tid + 256 * i, r = idx >> 3, c4 = idx & 7;
-      *reinterpret_cast<float4*>(&S[r * LDT + 4 * c4]) = v[i];
+      const bool ok = (okbits >> i) & 1u;
+      *reinterpret_cast<float4*>(&S[r * LDT + 4 * c4]) =
+          make_float4(ok ? v[i].x : 0.f, ok ? v[i].y : 0.f, ok ? v[i].z : 0.f, ok ? v[i].w : 0.f);
     }
   }
 };
@@ -82,25 +90,20 @@ struct ColTile {
     *c4 = (lane >> 3) + 8 * wave;
   }
   float4 v[4];
+  unsigned okbits;  // bit i: v[i] valid, bit 4+i: v[i].x is the virtual ones column
   __device__ __forceinline__ void load(const float* __restrict__ P, int64_t ld, int k0, int K, int col0, int ncols, int tid,
                                        int ones_col = -1) {
+    okbits = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       int kr, c4;
       map(tid, i, &kr, &c4);
       const int k = k0 + kr, col = col0 + 4 * c4;
-      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (k < K) {
-        if (col + 3 < ncols) {
-          t = *reinterpret_cast<const float4*>(P + (int64_t)k * ld + col);
-        } else {  // ragged right edge (and the virtual ones column)
-          float e[4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) e[j] = (col + j < ncols) ? P[(int64_t)k * ld + col + j] : ((col + j == ones_col) ? 1.0f : 0.f);
-          t = make_float4(e[0], e[1], e[2], e[3]);
-        }
-      }
-      v[i] = t;
+      // ncols % 4 == 0 and col % 4 == 0: a float4 is entirely inside or entirely outside.
+      const int kc = k < K ? k : K - 1, cc = col < ncols ? col : ncols - 4;
+      v[i] = *reinterpret_cast<const float4*>(P + (int64_t)kc * ld + cc);
+      okbits |= (k < K && col < ncols) ? (1u << i) : 0u;
+      okbits |= (col == ones_col && k < K) ? (16u << i) : 0u;   // the virtual ones column (bias gradient)
     }
   }
   __device__ __forceinline__ void store(float* __restrict__ S, int tid) const {
@@ -108,19 +111,20 @@ struct ColTile {
     for (int i = 0; i < 4; ++i) {
       int kr, c4;
       map(tid, i, &kr, &c4);
-      S[(4 * c4 + 0) * LDT + kr] = v[i].x;
-      S[(4 * c4 + 1) * LDT + kr] = v[i].y;
-      S[(4 * c4 + 2) * LDT + kr] = v[i].z;
-      S[(4 * c4 + 3) * LDT + kr] = v[i].w;
+      const bool ok = (okbits >> i) & 1u, one = (okbits >> (4 + i)) & 1u;
+      S[(4 * c4 + 0) * LDT + kr] = one ? 1.0f : (ok ? v[i].x : 0.f);
+      S[(4 * c4 + 1) * LDT + kr] = ok ? v[i].y : 0.f;
+      S[(4 * c4 + 2) * LDT + kr] = ok ? v[i].z : 0.f;
+      S[(4 * c4 + 3) * LDT + kr] = ok ? v[i].w : 0.f;
     }
   }
 };
 
 // C/D map of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-template <bool B_KCONTIG>
+template <bool B_KCONTIG, bool ACCUM>
 __global__ __launch_bounds__(256, 2) void k_gemm_rows(const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
                                                       int64_t ldb, float* __restrict__ C, int64_t ldc, int M, int N, int K,
-                                                      const float* __restrict__ bias, int accumulate) {
+                                                      const float* __restrict__ bias) {
   __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDT];
   float* As = smem;
   float* Bs = smem + BM * LDT;
@@ -158,16 +162,20 @@ __global__ __launch_bounds__(256, 2) void k_gemm_rows(const float* __restrict__ 
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
       const int col = n0 + wc * 64 + nt * 32 + j;
-      if (col >= N) continue;
-      const float bv = bias ? bias[col] : 0.f;
+      const int colc = col < N ? col : N - 1;
+      const float bv = bias ? bias[colc] : 0.f;
+      float old[16];
+      if (ACCUM) {  // all reads first (clamped addresses), then one wait
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wr * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          old[r] = C[(int64_t)(row < M ? row : M - 1) * ldc + colc];
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wr * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        if (row < M) {
-          float* dst = C + (int64_t)row * ldc + col;
-          const float v = acc[mt][nt][r] + bv;
-          *dst = accumulate ? *dst + v : v;
-        }
+        if (row < M && col < N) C[(int64_t)row * ldc + col] = acc[mt][nt][r] + bv + (ACCUM ? old[r] : 0.f);
       }
     }
 }
@@ -238,7 +246,7 @@ __global__ __launch_bounds__(256) void k_gemm_tn_reduce(const float* __restrict_
 int tn_chunk_rows(int M, int N, int Kext) {
   // enough workgroups to fill 256 CUs ~2x, chunks a multiple of BK rows, at most 256 chunks
   const int tiles = ((N + BM - 1) / BM) * ((Kext + BN - 1) / BN);
-  int want = (320 + tiles - 1) / tiles;
+  int want = (496 + tiles / 2) / tiles;   // ~2 workgroups per CU, all resident in one round
   if (want < 1) want = 1;
   if (want > 256) want = 256;
   int chunk = (M + want - 1) / want;
@@ -254,6 +262,7 @@ static int gemm_rows_check(const float* A, int64_t lda, const float* B, int64_t 
   if (M < 0 || N < 0 || K < 0) return DGDM_ERR_INVALID_ARG;
   if (M == 0 || N == 0) return 1;
   if (!A || !B || !C) return DGDM_ERR_INVALID_ARG;
+  if (K == 0) return DGDM_ERR_UNSUPPORTED;
   if ((K & 3) || (lda & 3) || (ldb & 3) || lda < kdim_a || !dgdm_aligned16(A) || !dgdm_aligned16(B)) return DGDM_ERR_UNSUPPORTED;
   if (ldc < N) return DGDM_ERR_INVALID_ARG;
   (void)bias; (void)kdim_b_contig;
@@ -265,8 +274,11 @@ extern "C" int dgdm_gemm_nt(const float* A, int64_t lda, const float* W, int64_t
   int rc = gemm_rows_check(A, lda, W, ldw, C, ldc, M, N, K, bias, K, 1);
   if (rc != DGDM_OK) return rc > 0 ? DGDM_OK : rc;
   if (ldw < K) return DGDM_ERR_INVALID_ARG;
-  hipLaunchKernelGGL((k_gemm_rows<true>), dim3((M + BM - 1) / BM, (N + BN - 1) / BN), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     A, lda, W, ldw, C, ldc, M, N, K, bias, accumulate);
+  const dim3 grid((M + BM - 1) / BM, (N + BN - 1) / BN);
+  if (accumulate)
+    hipLaunchKernelGGL((k_gemm_rows<true, true>), grid, dim3(256), 0, static_cast<hipStream_t>(stream), A, lda, W, ldw, C, ldc, M, N, K, bias);
+  else
+    hipLaunchKernelGGL((k_gemm_rows<true, false>), grid, dim3(256), 0, static_cast<hipStream_t>(stream), A, lda, W, ldw, C, ldc, M, N, K, bias);
   return dgdm_launch_status();
 }
 
@@ -277,10 +289,14 @@ extern "C" int dgdm_gemm_nn(const float* A, int64_t lda, const float* W, int64_t
   if (M < 0 || N < 0 || Kout < 0) return DGDM_ERR_INVALID_ARG;
   if (M == 0 || Kout == 0) return DGDM_OK;
   if (!A || !W || !C) return DGDM_ERR_INVALID_ARG;
-  if ((N & 3) || (lda & 3) || (ldw & 3) || lda < N || ldw < Kout || ldc < Kout || !dgdm_aligned16(A) || !dgdm_aligned16(W))
+  if ((N & 3) || (Kout & 3) || (lda & 3) || (ldw & 3) || lda < N || ldw < Kout || ldc < Kout || !dgdm_aligned16(A) || !dgdm_aligned16(W))
     return DGDM_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL((k_gemm_rows<false>), dim3((M + BM - 1) / BM, (Kout + BN - 1) / BN), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), A, lda, W, ldw, C, ldc, M, Kout, N, (const float*)nullptr, accumulate);
+  const dim3 grid((M + BM - 1) / BM, (Kout + BN - 1) / BN);
+  const float* nobias = nullptr;
+  if (accumulate)
+    hipLaunchKernelGGL((k_gemm_rows<false, true>), grid, dim3(256), 0, static_cast<hipStream_t>(stream), A, lda, W, ldw, C, ldc, M, Kout, N, nobias);
+  else
+    hipLaunchKernelGGL((k_gemm_rows<false, false>), grid, dim3(256), 0, static_cast<hipStream_t>(stream), A, lda, W, ldw, C, ldc, M, Kout, N, nobias);
   return dgdm_launch_status();
 }
 
