@@ -74,10 +74,14 @@ __device__ __forceinline__ float group_sum4(float v) {
 // adjacent lanes) split the four keys of a register quad between the even/odd lane of a query
 // pair and exchange the results with one DPP swap each -- 2 hashes per 4 elements everywhere.
 // The backward kernels regenerate exactly the forward's mask from (seed, indices).
-__device__ __forceinline__ uint32_t attn_hash(uint32_t hs, uint32_t qp, uint32_t k) {
-  uint32_t x = hs ^ (qp * 0x9E3779B1U) ^ (k * 0x85EBCA6BU);
+// hq = head_seed ^ (qp * 0x9E3779B1): the part that does not depend on the key (hoisted by callers)
+__device__ __forceinline__ uint32_t attn_hash_hq(uint32_t hq, uint32_t k) {
+  uint32_t x = hq ^ (k * 0x85EBCA6BU);
   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
   return x;
+}
+__device__ __forceinline__ uint32_t attn_hash(uint32_t hs, uint32_t qp, uint32_t k) {
+  return attn_hash_hq(hs ^ (qp * 0x9E3779B1U), k);
 }
 __device__ __forceinline__ uint32_t attn_head_seed(uint32_t seed, int n0, int head) {
   return seed ^ ((uint32_t)n0 * 0xC2B2AE35U) ^ ((uint32_t)(head + 1) * 0x27D4EB2FU);
@@ -89,10 +93,11 @@ struct DropCfg {
 };
 // q-major: this lane is query `q_local` (lane bit 0 == q_local & 1), its register quad holds keys
 // k0 .. k0+3.  Returns the four keep-factors.
-__device__ __forceinline__ f32x4 drop_factors_qmajor(uint32_t hs, int q_local, int k0, const DropCfg& c) {
+// `hq` = attn_head_seed(...) ^ ((q_local >> 1) * 0x9E3779B1), precomputed per (lane, head).
+__device__ __forceinline__ f32x4 drop_factors_qmajor(uint32_t hq, int q_local, int k0, const DropCfg& c) {
   const bool odd = q_local & 1;
-  const uint32_t qp = (uint32_t)q_local >> 1, kk = (uint32_t)k0 + (odd ? 2u : 0u);
-  const uint32_t h0 = attn_hash(hs, qp, kk), h1 = attn_hash(hs, qp, kk + 1);
+  const uint32_t kk = (uint32_t)k0 + (odd ? 2u : 0u);
+  const uint32_t h0 = attn_hash_hq(hq, kk), h1 = attn_hash_hq(hq, kk + 1);
   const uint32_t o0 = __shfl_xor(h0, 1, 64), o1 = __shfl_xor(h1, 1, 64);
   const uint32_t u0 = odd ? o0 : h0, u1 = odd ? o1 : h1, u2 = odd ? h0 : o0, u3 = odd ? h1 : o1;
   const int sh = odd ? 16 : 0;

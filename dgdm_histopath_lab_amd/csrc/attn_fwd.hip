@@ -53,10 +53,14 @@ __global__ __launch_bounds__(256, 2) void k_attn_fwd(const float* __restrict__ Q
   }
   const float2 pq = *reinterpret_cast<const float2*>(pos + 2 * (int64_t)q_row);
 
-  f32x4 oacc[HG];
+  f32x4 oacc[HG], oacc2[HG];
   float m[HG], l[HG];
+  uint32_t hq[HG];  // per-(lane, head) part of the dropout hash, hoisted out of the key loop
 #pragma unroll
-  for (int h = 0; h < HG; ++h) { oacc[h] = f32x4{0.f, 0.f, 0.f, 0.f}; m[h] = NEG_BIG; l[h] = 0.f; }
+  for (int h = 0; h < HG; ++h) {
+    oacc[h] = f32x4{0.f, 0.f, 0.f, 0.f}; oacc2[h] = f32x4{0.f, 0.f, 0.f, 0.f}; m[h] = NEG_BIG; l[h] = 0.f;
+    hq[h] = attn_head_seed(seed, n0, head0 + h) ^ (((uint32_t)q_local >> 1) * 0x9E3779B1U);
+  }
 
   // staging map: idx -> (key, h, part), part fastest => HG*64 contiguous bytes per key row
   float4 kreg[F4_PER_THREAD], vreg[F4_PER_THREAD];
@@ -118,19 +122,37 @@ __global__ __launch_bounds__(256, 2) void k_attn_fwd(const float* __restrict__ Q
       }
     }
 
+    // Software pipeline over the heads of the group: the S^T MFMAs of head h+1 are issued before the
+    // softmax VALU work of head h, so the matrix pipe has work in flight while the VALU runs (MFMA
+    // and VALU are separate pipes; in program order they only overlap when independent
+    // instructions sit next to each other).  Independent accumulator chains are interleaved
+    // (16x16x4: 32-cycle issue, 40-cycle dependent latency): the 4 key tiles of S^T, and two
+    // alternating accumulators (oacc / oacc2) for O^T.
+    f32x4 sbuf[2][NT];
+    auto qk = [&](int h, int buf) {
+      f32x4 kf[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        kf[t] = *reinterpret_cast<const f32x4*>(&Ks[T::rm(h, 16 * t + j, 4 * G)]);
+        sbuf[buf][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) sbuf[buf][t] = mfma16(kf[t][e], qf[h][e], sbuf[buf][t]);
+    };
+    qk(0, 0);
 #pragma unroll
     for (int h = 0; h < HG; ++h) {
-      f32x4 s[NT];
+      const int cur = h & 1;
+      if (h + 1 < HG) qk(h + 1, cur ^ 1);
+      f32x4 (&s)[NT] = sbuf[cur];
       float mx = NEG_BIG;
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        const f32x4 kf = *reinterpret_cast<const f32x4*>(&Ks[T::rm(h, 16 * t + j, 4 * G)]);
-        s[t] = mfma16_k16(kf, qf[h], f32x4{0.f, 0.f, 0.f, 0.f});
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          s[t][r] -= bias[t][r];
-          mx = fmaxf(mx, s[t][r]);
-        }
+        for (int r = 0; r < 4; ++r) s[t][r] -= bias[t][r];
+        mx = fmaxf(mx, fmaxf(fmaxf(s[t][0], s[t][1]), fmaxf(s[t][2], s[t][3])));
       }
       mx = group_max4(mx);
       const float m_new = fmaxf(m[h], mx);
@@ -146,20 +168,22 @@ __global__ __launch_bounds__(256, 2) void k_attn_fwd(const float* __restrict__ Q
         }
       l[h] = fmaf(l[h], alpha, psum);
       oacc[h] *= alpha;
+      oacc2[h] *= alpha;
       if (DROP) {  // the row sum above uses the un-dropped weights; only the P.V product sees the mask
-        const uint32_t hs = attn_head_seed(seed, n0, head0 + h);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) s[t] *= drop_factors_qmajor(hs, q_local, kb0 + 16 * t + 4 * G, dc);
+        for (int t = 0; t < NT; ++t) s[t] *= drop_factors_qmajor(hq[h], q_local, kb0 + 16 * t + 4 * G, dc);
       }
+      f32x4 vf[NT];
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const f32x4 vf = *reinterpret_cast<const f32x4*>(&Vt[T::tr(h, 16 * t + 4 * G, j)]);
-        // O^T[d=j][q] += sum_r V^T[d][key 4G+r] * P^T[key 4G+r][q]
-        oacc[h] = mfma16(vf[0], s[t][0], oacc[h]);
-        oacc[h] = mfma16(vf[1], s[t][1], oacc[h]);
-        oacc[h] = mfma16(vf[2], s[t][2], oacc[h]);
-        oacc[h] = mfma16(vf[3], s[t][3], oacc[h]);
-      }
+      for (int t = 0; t < NT; ++t) vf[t] = *reinterpret_cast<const f32x4*>(&Vt[T::tr(h, 16 * t + 4 * G, j)]);
+      // O^T[d=j][q] += sum_r V^T[d][key 4G+r] * P^T[key 4G+r][q]; even tiles -> oacc, odd -> oacc2
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          if (t & 1) oacc2[h] = mfma16(vf[t][r], s[t][r], oacc2[h]);
+          else oacc[h] = mfma16(vf[t][r], s[t][r], oacc[h]);
+        }
     }
   }
 
@@ -169,7 +193,8 @@ __global__ __launch_bounds__(256, 2) void k_attn_fwd(const float* __restrict__ Q
     const float lt = group_sum4(l[h]);
     const float inv = 1.0f / lt;
     if (q_ok) {
-      float4 o = make_float4(oacc[h][0] * inv, oacc[h][1] * inv, oacc[h][2] * inv, oacc[h][3] * inv);
+      const f32x4 os = oacc[h] + oacc2[h];
+      float4 o = make_float4(os[0] * inv, os[1] * inv, os[2] * inv, os[3] * inv);
       *reinterpret_cast<float4*>(O + (int64_t)(n0 + q_local) * ldo + (head0 + h) * 16 + 4 * G) = o;
       if (G == 0) L2[(int64_t)(head0 + h) * N_tot + n0 + q_local] = m[h] + log2f(lt);
     }
