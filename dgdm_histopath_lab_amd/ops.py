@@ -164,6 +164,33 @@ def spatial_attn_fwd_raw(q, k, v, pos, plan: AttnPlan, H: int, scale: float, inv
     return out, lse2
 
 
+LOG2E = 1.4426950408889634
+
+
+def split_pack(x: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
+    """[N, W] fp32 (W % 16 == 0, unit column stride) -> [N, W/16, 32] fp16 = [hi16 | lo16] of x*scale."""
+    lib = _lib.load()
+    N, W = x.shape
+    out = torch.empty(N, W // 16, 32, dtype=torch.float16, device=x.device)
+    _lib.check(lib.dgdm_attn_split_pack(x.data_ptr(), x.stride(0), N, W, scale, out.data_ptr(), _lib.stream_ptr(x.device)),
+               "dgdm_attn_split_pack")
+    return out
+
+
+def spatial_attn_h_fwd_raw(q, k, v, pos, plan: AttnPlan, H: int, scale: float, inv_tau: float, drop_p: float = 0.0, seed: int = 0):
+    """Split-fp16 forward; returns (out, lse2, (Qp, Kp, Vp)) -- the packed operands are reused by the backward."""
+    lib = _lib.load()
+    N, C = q.shape
+    qp, kp, vp = split_pack(q, scale * LOG2E), split_pack(k), split_pack(v)
+    out = torch.empty(N, C, dtype=torch.float32, device=q.device)
+    lse2 = torch.empty(H, N, dtype=torch.float32, device=q.device)
+    TIMERS.timed("attn_fwd", lambda: _lib.check(
+        lib.dgdm_spatial_attn_h_fwd(qp.data_ptr(), kp.data_ptr(), vp.data_ptr(), pos.data_ptr(), plan.ptr_dev.data_ptr(), plan.B,
+                                    plan.num_q_tiles, N, H, inv_tau, drop_p, seed, out.data_ptr(), out.stride(0), lse2.data_ptr(),
+                                    _lib.stream_ptr(q.device)), "dgdm_spatial_attn_h_fwd"))
+    return out, lse2, (qp, kp, vp)
+
+
 def spatial_attn_bwd_raw(q, k, v, out, gout, pos, plan: AttnPlan, H: int, scale: float, inv_tau: float, lse2, dqkv,
                          drop_p: float = 0.0, seed: int = 0):
     """Writes dQ|dK|dV into the three column blocks of ``dqkv`` [N_tot, 3*H*16]."""

@@ -149,6 +149,17 @@ DGDM_API int dgdm_spatial_attn_mean_weights(const float* Q, const float* K, int6
                                             float inv_tau, const float* lse2, float* W, const int64_t* w_offsets,
                                             void* stream);
 
+/* K4, split-fp16 path.  Same contract as dgdm_spatial_attn_fwd, but the two products run on the
+ * 16-bit matrix pipe with every fp32 operand carried as hi+lo halfs (csrc/attn_h.hpp): on gfx950 the
+ * fp32 MFMA cannot overlap with the softmax's fp32 VALU work, the fp16 MFMA can.
+ *   dgdm_attn_split_pack: X [N, ncols] fp32 (ncols % 16 == 0) -> out [N][ncols/16][32] halfs,
+ *                         [hi16 | lo16] of x*scale per 16-wide head.
+ *   Qp (pre-scaled by log2(e)/sqrt(d)), Kp, Vp: packed arrays [N_tot][H][32] halfs. */
+DGDM_API int dgdm_attn_split_pack(const float* X, int64_t ld, int32_t N, int32_t ncols, float scale, void* out_halfs, void* stream);
+DGDM_API int dgdm_spatial_attn_h_fwd(const void* Qp, const void* Kp, const void* Vp, const float* pos, const int32_t* ptr, int32_t B,
+                                     int32_t num_q_tiles, int32_t N_tot, int32_t H, float inv_tau, float drop_p, uint32_t seed,
+                                     float* O, int64_t ldo, float* lse2, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * K5  out = x + sinusoidal_2d_posenc(pos)  for a whole batch.  Replaces
  * SpatialAttention.get_positional_encoding + the add (core/attention.py:225-259,306): positions

@@ -25,6 +25,8 @@ for p in (0.0, 0.1):
     for var in variants:
         ms = t(lambda: ops.spatial_attn_fwd_raw(qkv[:, :C], qkv[:, C:2*C], qkv[:, 2*C:], pos, plan, H, 0.25, 1.0, var, p, 123))
         print(json.dumps(dict(kernel="fwd", variant=var, drop=p, ms=round(ms, 3), TF=round(2 * fl / ms / 1e9, 1))))
+    ms = t(lambda: ops.spatial_attn_h_fwd_raw(qkv[:, :C], qkv[:, C:2*C], qkv[:, 2*C:], pos, plan, H, 0.25, 1.0, p, 123))
+    print(json.dumps(dict(kernel="fwd split-fp16 (incl. packing)", drop=p, ms=round(ms, 3), TF=round(2 * fl / ms / 1e9, 1))))
     out, lse2 = ops.spatial_attn_fwd_raw(qkv[:, :C], qkv[:, C:2*C], qkv[:, 2*C:], pos, plan, H, 0.25, 1.0, 0, p, 123)
     dqkv = torch.empty_like(qkv)
     ops.TIMERS.start()
