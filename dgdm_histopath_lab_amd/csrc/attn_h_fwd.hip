@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void k_split_pack(const float* __restrict__ X,
 }
 
 template <int HG, int KB, bool DROP>
-__global__ __launch_bounds__(256, 2) void k_attn_h_fwd(const _Float16* __restrict__ Qp, const _Float16* __restrict__ Kp,
+__global__ __launch_bounds__(256) void k_attn_h_fwd(const _Float16* __restrict__ Qp, const _Float16* __restrict__ Kp,
                                                        const _Float16* __restrict__ Vp, int H, const float* __restrict__ pos,
                                                        const int32_t* __restrict__ ptr, int B, float bscale, float* __restrict__ O,
                                                        int64_t ldo, float* __restrict__ L2, int N_tot, float drop_p, uint32_t seed) {
@@ -212,7 +212,7 @@ extern "C" int dgdm_attn_split_pack(const float* X, int64_t ld, int32_t N, int32
 
 extern "C" int dgdm_spatial_attn_h_fwd(const void* Qp, const void* Kp, const void* Vp, const float* pos, const int32_t* ptr, int32_t B,
                                        int32_t num_q_tiles, int32_t N_tot, int32_t H, float inv_tau, float drop_p, uint32_t seed,
-                                       float* O, int64_t ldo, float* lse2, void* stream_) {
+                                       float* O, int64_t ldo, float* lse2, int32_t variant, void* stream_) {
   DGDM_REQUIRE(B >= 0 && N_tot >= 0 && H > 0 && num_q_tiles >= 0 && drop_p >= 0.f && drop_p < 1.f);
   if (N_tot == 0 || num_q_tiles == 0) return DGDM_OK;
   DGDM_REQUIRE(Qp && Kp && Vp && pos && ptr && O && lse2);
@@ -231,7 +231,10 @@ extern "C" int dgdm_spatial_attn_h_fwd(const void* Qp, const void* Kp, const voi
       hipLaunchKernelGGL((k_attn_h_fwd<HG, KB, false>), dim3(num_q_tiles, H / HG), dim3(256), 0, s, q, k, v, H, pos, ptr, B, \
                          bscale, O, ldo, lse2, N_tot, 0.f, 0u);                                                             \
   } while (0)
-  if (H % 4 == 0) GO(4, 64);
+  if (H % 4 == 0 && variant == 1) GO(4, 32);
+  else if (H % 2 == 0 && variant == 2) GO(2, 64);
+  else if (H % 2 == 0 && variant == 3) GO(2, 32);
+  else if (H % 4 == 0) GO(4, 64);
   else if (H % 2 == 0) GO(2, 64);
   else GO(1, 64);
 #undef GO

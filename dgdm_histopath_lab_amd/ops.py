@@ -177,17 +177,18 @@ def split_pack(x: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
     return out
 
 
-def spatial_attn_h_fwd_raw(q, k, v, pos, plan: AttnPlan, H: int, scale: float, inv_tau: float, drop_p: float = 0.0, seed: int = 0):
+def spatial_attn_h_fwd_raw(q, k, v, pos, plan: AttnPlan, H: int, scale: float, inv_tau: float, drop_p: float = 0.0, seed: int = 0,
+                           variant: int = 0, packed=None):
     """Split-fp16 forward; returns (out, lse2, (Qp, Kp, Vp)) -- the packed operands are reused by the backward."""
     lib = _lib.load()
     N, C = q.shape
-    qp, kp, vp = split_pack(q, scale * LOG2E), split_pack(k), split_pack(v)
+    qp, kp, vp = packed if packed is not None else (split_pack(q, scale * LOG2E), split_pack(k), split_pack(v))
     out = torch.empty(N, C, dtype=torch.float32, device=q.device)
     lse2 = torch.empty(H, N, dtype=torch.float32, device=q.device)
     TIMERS.timed("attn_fwd", lambda: _lib.check(
         lib.dgdm_spatial_attn_h_fwd(qp.data_ptr(), kp.data_ptr(), vp.data_ptr(), pos.data_ptr(), plan.ptr_dev.data_ptr(), plan.B,
                                     plan.num_q_tiles, N, H, inv_tau, drop_p, seed, out.data_ptr(), out.stride(0), lse2.data_ptr(),
-                                    _lib.stream_ptr(q.device)), "dgdm_spatial_attn_h_fwd"))
+                                    variant, _lib.stream_ptr(q.device)), "dgdm_spatial_attn_h_fwd"))
     return out, lse2, (qp, kp, vp)
 
 

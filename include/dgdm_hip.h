@@ -158,7 +158,7 @@ DGDM_API int dgdm_spatial_attn_mean_weights(const float* Q, const float* K, int6
 DGDM_API int dgdm_attn_split_pack(const float* X, int64_t ld, int32_t N, int32_t ncols, float scale, void* out_halfs, void* stream);
 DGDM_API int dgdm_spatial_attn_h_fwd(const void* Qp, const void* Kp, const void* Vp, const float* pos, const int32_t* ptr, int32_t B,
                                      int32_t num_q_tiles, int32_t N_tot, int32_t H, float inv_tau, float drop_p, uint32_t seed,
-                                     float* O, int64_t ldo, float* lse2, void* stream);
+                                     float* O, int64_t ldo, float* lse2, int32_t variant, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K5  out = x + sinusoidal_2d_posenc(pos)  for a whole batch.  Replaces
