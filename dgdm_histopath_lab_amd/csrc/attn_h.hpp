@@ -13,19 +13,33 @@
 // e = 0..7; C/D: lane l, reg r -> D[row = 4*(l>>4) + r][col = l&15]  (same C/D map as 16x16x4).
 // A product whose accumulator feeds the next product as B operand pairs two 16-row tiles:
 // reduction slot k = 8G + e  <->  row 16*t0 + 4G + e (e < 4), row 16*(t0+1) + 4G + e - 4 (e >= 4).
+//
+// Packed operand images (written once per launch by k_attn_pack, graph-block aligned: block b of
+// graph g holds its rows 64*b .. 64*b+63, rows past the graph end are zero), all in halfs:
+//   row image   R[blk][H][64][32]        [hi16 | lo16] per row (64 B)     -- A operand with the row
+//                                          on the MFMA row, or per-lane B operands (load_b_pair)
+//   transposed  T[blk][H][2][16][72]     part 0 = hi, 1 = lo; [d][row], row stride 72 halfs (144 B)
+//                                          so the 8-byte reads of a 32-lane group hit distinct banks
+// Both are straight, contiguous byte ranges per (block, head group), so the attention kernels stage
+// them with direct-to-LDS DMA (global_load_lds_dwordx4: no VGPRs, no VALU), double-buffered.
 #pragma once
 #include "attn_common.hpp"
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int HB = 64;                 // rows per packed block
+constexpr int R_HEAD = HB * 32;        // halfs per (block, head) in a row image      (4096 B)
+constexpr int T_STRIDE = HB + 8;       // halfs per d-row of a transposed image
+constexpr int T_PART = 16 * T_STRIDE;  // halfs per (block, head, part)
+constexpr int T_HEAD = 2 * T_PART;     // halfs per (block, head) in a transposed image (4608 B)
 
 __device__ __forceinline__ f32x4 mfma_h(f16x8 a, f16x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 
-// B-operand registers of a 16-wide row x given as packed [hi16 | lo16] halfs (64 B):
-// lane group G reads hi[8*(G&1) .. +7] for B1 and lo[8*(G&1) .. +7] for B2.
+// B-operand registers of a packed 16-wide row [hi16 | lo16]: lane group G reads hi[8*(G&1) .. +7]
+// for B1 and lo[8*(G&1) .. +7] for B2.
 __device__ __forceinline__ void load_b_pair(const _Float16* __restrict__ packed_row, int G, f16x8* b1, f16x8* b2) {
   *b1 = *reinterpret_cast<const f16x8*>(packed_row + 8 * (G & 1));
   *b2 = *reinterpret_cast<const f16x8*>(packed_row + 16 + 8 * (G & 1));
@@ -39,16 +53,42 @@ __device__ __forceinline__ f16x8 pack8(const f32x4 a, const f32x4 b) {
   return r;
 }
 
-// LDS images for a block of RB rows x HG heads (halfs):
-//   row image   R[h][row][32]      = [hi16 | lo16] per row (64 B): A operand with the row on the MFMA row
-//   transposed  T[h][d][RB + 8]    (one image for hi, one for lo): A operand with d on the MFMA row and
-//               the block's rows as reduction index; row stride RB+8 halfs (144 B at RB = 64) keeps
-//               the 8-byte reads of one 32-lane group on distinct banks.
-template <int RB>
-struct HTile {
-  static constexpr int RS = RB * 32;             // halfs per head in the row image
-  static constexpr int TS = RB + 8;              // row stride of a transposed image
-  static constexpr int TH = 16 * TS;             // halfs per head in a transposed image
-  __device__ static __forceinline__ int row(int h, int r, int e) { return h * RS + r * 32 + e; }
-  __device__ static __forceinline__ int tr(int h, int d, int r) { return h * TH + d * TS + r; }
-};
+// A operand of a transposed image for the tile pair (t0, t0+1): rows 16*t0 + 4G .. +3 and
+// 16*(t0+1) + 4G .. +3 of d-row `d` (two 8-byte LDS reads).
+__device__ __forceinline__ f16x8 load_t_pair(const _Float16* __restrict__ timg_part_head, int d, int t0, int G) {
+  const f16x4 a = *reinterpret_cast<const f16x4*>(timg_part_head + d * T_STRIDE + 16 * t0 + 4 * G);
+  const f16x4 b = *reinterpret_cast<const f16x4*>(timg_part_head + d * T_STRIDE + 16 * (t0 + 1) + 4 * G);
+  return f16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+
+// Asynchronous copy of BYTES contiguous bytes global -> LDS by a 256-thread workgroup: each wave
+// instruction moves 1 KiB (lane l: 16 B at offset piece*1024 + l*16; LDS destination = wave-uniform
+// base + l*16).  Completion: the issuing wave's vmcnt, then a workgroup barrier (hipcc emits
+// vmcnt(0) in front of __syncthreads()).
+template <int BYTES>
+__device__ __forceinline__ void dma_to_lds(const void* __restrict__ gsrc, void* lds_dst, int tid) {
+  static_assert(BYTES % 16 == 0, "16-byte granules");
+  constexpr int PIECES = (BYTES + 1023) / 1024;
+  const int lane = tid & 63, wave = tid >> 6;
+  const char* g = static_cast<const char*>(gsrc);
+  char* l = static_cast<char*>(lds_dst);
+#pragma unroll
+  for (int p0 = 0; p0 < PIECES; p0 += 4) {
+    const int p = p0 + wave;
+    if (p < PIECES && p * 1024 + lane * 16 < BYTES)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + p * 1024 + lane * 16),
+                                       (__attribute__((address_space(3))) void*)(l + p * 1024), 16, 0, 0);
+  }
+}
+
+// which graph / local block does packed block `blk` belong to (blocks are numbered graph by graph)
+__device__ __forceinline__ bool find_block(const int32_t* __restrict__ ptr, int B, int blk, int* n0, int* ng, int* lblk, int* blk0) {
+  int base = 0;
+  for (int g = 0; g < B; ++g) {
+    const int a = ptr[g], b = ptr[g + 1];
+    const int nb = (b - a + HB - 1) / HB;
+    if (blk < base + nb) { *n0 = a; *ng = b - a; *lblk = blk - base; *blk0 = base; return true; }
+    base += nb;
+  }
+  return false;
+}

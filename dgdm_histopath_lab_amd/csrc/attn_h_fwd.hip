@@ -1,67 +1,98 @@
 // K4 (split-fp16 path): operand packing + forward of the fused spatial attention.
-// Same algorithm, tiling and outputs as attn_fwd.hip (64 queries x 4 heads per workgroup, 64-key
-// blocks, online softmax in the log2 domain, distance bias shared by the head group, counter-hash
-// dropout); the two products run on v_mfma_f32_16x16x32_f16 with hi+lo operands (attn_h.hpp):
-//   S'^T = [K_hi|K_lo] . [Q'_hi|Q'_hi] + [K_hi|K_lo] . [Q'_lo|Q'_lo]   - bias   (C-in = -bias)
-//   O^T += V^T_hi . P + V^T_lo . P           (P = fp16(exp2(S' - m)), pairs of 16-key tiles)
-// which leaves the kernel bound by the softmax VALU work instead of MFMA + VALU.
+// Same algorithm and outputs as attn_fwd.hip (64 queries x HG heads per workgroup, 64-key blocks,
+// online softmax in the log2 domain, distance bias shared by the head group, counter-hash dropout);
+// differences that matter for speed on gfx950:
+//   * both products run on v_mfma_f32_16x16x32_f16 with hi+lo operands (attn_h.hpp):
+//       S'^T = [K_hi|K_lo].[Q'_hi|Q'_hi] + [K_hi|K_lo].[Q'_lo|Q'_lo]  with C-in = -bias
+//       O^T += V^T_hi.P + V^T_lo.P        (P = fp16(exp2(S' - m)), pairs of 16-key tiles)
+//     so the matrix work overlaps with the softmax VALU work (the fp32 MFMA cannot);
+//   * K / V^T / key positions are pre-packed, block-aligned images staged by direct-to-LDS DMA into a
+//     double buffer: no staging VGPRs, no staging VALU, one barrier per key block;
+//   * lazy running maximum: the cross-lane max exchange (two LDS round trips) and the rescale of
+//     O / l only happen when some lane's block maximum exceeds the running maximum by > 2^LAZY_THR.
 #include "attn_h.hpp"
 
 namespace {
 
-constexpr int QB = 64;
 constexpr float NEG_BIG = -1.0e30f;
+constexpr float LAZY_THR = 6.0f;  // exp2 arguments stay <= 6 between rescales: P <= 64, safe in fp16/fp32
 
-// X [N, ncols] fp32 (row stride ld) -> out [N][ncols/16][32] halfs = [hi16 | lo16] of x * scale
-__global__ __launch_bounds__(256) void k_split_pack(const float* __restrict__ X, int64_t ld, int64_t N, int ncols, float scale,
-                                                    _Float16* __restrict__ out) {
-  const int c4 = ncols >> 2;
-  const int64_t total = N * c4;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += stride) {
-    const int64_t n = i / c4;
-    const int k = (int)(i % c4);           // float4 index inside the row
-    const float4 v = *reinterpret_cast<const float4*>(X + n * ld + 4 * k);
-    const float x[4] = {v.x * scale, v.y * scale, v.z * scale, v.w * scale};
-    f16x4 hi, lo;
+// grid (NB, H, ntensors).  Tensor z: columns [col0 + z*cstride, +H*16) of X, scaled by (z == 0 ? scale0 : 1).
+__global__ __launch_bounds__(256) void k_attn_pack(const float* __restrict__ X, int64_t ld, int col0, int cstride, float scale0,
+                                                   const int32_t* __restrict__ ptr, int B, int H, _Float16* __restrict__ R,
+                                                   int64_t r_tensor_stride, _Float16* __restrict__ Tt, int64_t t_tensor_stride,
+                                                   const float* __restrict__ pos, float* __restrict__ pos_b,
+                                                   const float* __restrict__ Oin, int64_t ldo, float* __restrict__ delta_b) {
+  __shared__ __attribute__((aligned(16))) _Float16 sm[2][16][T_STRIDE];
+  const int blk = blockIdx.x, h = blockIdx.y, z = blockIdx.z;
+  int n0, ng, lblk, blk0;
+  if (!find_block(ptr, B, blk, &n0, &ng, &lblk, &blk0)) return;
+  const int tid = threadIdx.x, row = tid >> 2, part = tid & 3;
+  const int rl = lblk * HB + row;
+  const bool ok = rl < ng;
+  const int64_t node = n0 + (ok ? rl : ng - 1);
+  const float scale = z == 0 ? scale0 : 1.0f;
+  const float4 v = *reinterpret_cast<const float4*>(X + node * ld + col0 + z * cstride + h * 16 + part * 4);
+  const float x[4] = {ok ? v.x * scale : 0.f, ok ? v.y * scale : 0.f, ok ? v.z * scale : 0.f, ok ? v.w * scale : 0.f};
+  f16x4 hi, lo;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      hi[e] = (_Float16)x[e];
-      lo[e] = (_Float16)(x[e] - (float)hi[e]);
-    }
-    const int head = k >> 2, part = k & 3;  // 4 float4 per 16-wide head
-    _Float16* dst = out + (n * (ncols >> 4) + head) * 32 + part * 4;
-    *reinterpret_cast<f16x4*>(dst) = hi;
-    *reinterpret_cast<f16x4*>(dst + 16) = lo;
+  for (int e = 0; e < 4; ++e) {
+    hi[e] = (_Float16)x[e];
+    lo[e] = (_Float16)(x[e] - (float)hi[e]);
+    sm[0][part * 4 + e][row] = hi[e];
+    sm[1][part * 4 + e][row] = lo[e];
   }
+  _Float16* rrow = R + z * r_tensor_stride + (((int64_t)blk * H + h) * HB + row) * 32;
+  *reinterpret_cast<f16x4*>(rrow + part * 4) = hi;
+  *reinterpret_cast<f16x4*>(rrow + 16 + part * 4) = lo;
+  if (Oin) {  // delta = rowsum(dO * O) (attention backward), block layout [blk][H][64]
+    const float4 o = *reinterpret_cast<const float4*>(Oin + node * ldo + h * 16 + part * 4);
+    float d = x[0] * o.x + x[1] * o.y + x[2] * o.z + x[3] * o.w;
+    d += __shfl_xor(d, 1, 64);
+    d += __shfl_xor(d, 2, 64);
+    if (part == 0) delta_b[((int64_t)blk * H + h) * HB + row] = ok ? d : 0.f;
+  }
+  if (pos_b && z == 0 && h == 0 && tid < HB) {
+    const int r2 = lblk * HB + tid;
+    const float2 p = *reinterpret_cast<const float2*>(pos + 2 * (int64_t)(n0 + (r2 < ng ? r2 : ng - 1)));
+    *reinterpret_cast<float2*>(pos_b + ((int64_t)blk * HB + tid) * 2) = r2 < ng ? p : make_float2(0.f, 0.f);
+  }
+  __syncthreads();
+  const int d = tid >> 4, rc = tid & 15;
+  _Float16* tb = Tt + z * t_tensor_stride + ((int64_t)blk * H + h) * T_HEAD;
+  *reinterpret_cast<f16x4*>(tb + d * T_STRIDE + 4 * rc) = *reinterpret_cast<const f16x4*>(&sm[0][d][4 * rc]);
+  *reinterpret_cast<f16x4*>(tb + T_PART + d * T_STRIDE + 4 * rc) = *reinterpret_cast<const f16x4*>(&sm[1][d][4 * rc]);
 }
 
-template <int HG, int KB, bool DROP>
-__global__ __launch_bounds__(256) void k_attn_h_fwd(const _Float16* __restrict__ Qp, const _Float16* __restrict__ Kp,
-                                                       const _Float16* __restrict__ Vp, int H, const float* __restrict__ pos,
-                                                       const int32_t* __restrict__ ptr, int B, float bscale, float* __restrict__ O,
-                                                       int64_t ldo, float* __restrict__ L2, int N_tot, float drop_p, uint32_t seed) {
-  using T = HTile<KB>;
-  constexpr int NT = KB / 16;
-  constexpr int RS = T::RS + 16;                    // row-image head stride, +32 B so head slots differ in bank
-  constexpr int CH = KB * HG * 4 / 256;              // 16-byte chunks staged per thread per tensor
-  static_assert(NT % 2 == 0 && (KB * HG * 4) % 256 == 0, "tiling");
-  __shared__ __attribute__((aligned(16))) _Float16 smem[HG * RS + 2 * HG * T::TH + 4 * KB];
-  _Float16* Kimg = smem;
-  _Float16* Vth = smem + HG * RS;
-  _Float16* Vtl = Vth + HG * T::TH;
-  float* Ps = reinterpret_cast<float*>(Vtl + HG * T::TH);  // [KB][2] key positions
+template <int HG, bool DROP>
+__global__ __launch_bounds__(256) void k_attn_h_fwd(const _Float16* __restrict__ Rq, const _Float16* __restrict__ Rk,
+                                                    const _Float16* __restrict__ Tv, const float* __restrict__ pos_b, int H,
+                                                    const int32_t* __restrict__ ptr, int B, float bscale, float* __restrict__ O,
+                                                    int64_t ldo, float* __restrict__ lse2_b, float drop_p, uint32_t seed) {
+  constexpr int NT = HB / 16;
+  constexpr int RK_BYTES = HG * R_HEAD * 2, TV_BYTES = HG * T_HEAD * 2, POS_BYTES = HB * 8;
+  constexpr int BUF_BYTES = RK_BYTES + TV_BYTES + POS_BYTES;
+  __shared__ __attribute__((aligned(16))) char smem[2 * BUF_BYTES];
   const DropCfg dc(drop_p);
 
-  int n0, n1, ltile;
-  if (!find_graph(ptr, B, QB, blockIdx.x, &n0, &n1, &ltile)) return;
-  const int ng = n1 - n0;
+  int n0, ng, lblk, blk0;
+  if (!find_block(ptr, B, blockIdx.x, &n0, &ng, &lblk, &blk0)) return;
+  const int nbg = (ng + HB - 1) / HB;
   const int head0 = blockIdx.y * HG;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, G = lane >> 4;
-  const int q_local = ltile * QB + wave * 16 + j;
-  const int q_row = n0 + (q_local < ng ? q_local : ng - 1);
+  const int q_in_blk = wave * 16 + j;
+  const int q_local = lblk * HB + q_in_blk;
   const bool q_ok = q_local < ng;
+
+  auto stage = [&](int kb, int buf) {
+    const int64_t gb = (int64_t)(blk0 + kb) * H + head0;
+    char* base = smem + buf * BUF_BYTES;
+    dma_to_lds<RK_BYTES>(Rk + gb * R_HEAD, base, tid);
+    dma_to_lds<TV_BYTES>(Tv + gb * T_HEAD, base + RK_BYTES, tid);
+    dma_to_lds<POS_BYTES>(pos_b + (int64_t)(blk0 + kb) * HB * 2, base + RK_BYTES + TV_BYTES, tid);
+  };
+  stage(0, 0);
 
   f16x8 qb1[HG], qb2[HG];
   f32x4 oacc[HG], oacc2[HG];
@@ -69,60 +100,22 @@ __global__ __launch_bounds__(256) void k_attn_h_fwd(const _Float16* __restrict__
   uint32_t hq[HG];
 #pragma unroll
   for (int h = 0; h < HG; ++h) {
-    load_b_pair(Qp + ((int64_t)q_row * H + head0 + h) * 32, G, &qb1[h], &qb2[h]);
+    load_b_pair(Rq + (((int64_t)blockIdx.x * H + head0 + h) * HB + q_in_blk) * 32, G, &qb1[h], &qb2[h]);
     oacc[h] = f32x4{0.f, 0.f, 0.f, 0.f}; oacc2[h] = f32x4{0.f, 0.f, 0.f, 0.f}; m[h] = NEG_BIG; l[h] = 0.f;
     hq[h] = attn_head_seed(seed, n0, head0 + h) ^ (((uint32_t)q_local >> 1) * 0x9E3779B1U);
   }
-  const float2 pq = *reinterpret_cast<const float2*>(pos + 2 * (int64_t)q_row);
+  const float2 pq = *reinterpret_cast<const float2*>(pos_b + ((int64_t)blockIdx.x * HB + q_in_blk) * 2);
+  __syncthreads();  // block 0 landed (vmcnt(0) + barrier)
 
-  // staging: chunk idx -> (key, head, quarter); quarter 0/1 = hi[0..7]/hi[8..15], 2/3 = lo halves
-  uint4 kreg[CH], vreg[CH];
-  auto issue_loads = [&](int kb0) {
-#pragma unroll
-    for (int i = 0; i < CH; ++i) {
-      const int idx = tid + 256 * i;
-      const int key = idx / (HG * 4), c = idx % (HG * 4);
-      const int kl = kb0 + key;
-      const int64_t off = ((int64_t)(n0 + (kl < ng ? kl : ng - 1)) * H + head0) * 32 + c * 8;  // clamped: always valid
-      kreg[i] = *reinterpret_cast<const uint4*>(Kp + off);
-      vreg[i] = *reinterpret_cast<const uint4*>(Vp + off);
-    }
-  };
-  auto write_lds = [&](int kb0) {
-#pragma unroll
-    for (int i = 0; i < CH; ++i) {
-      const int idx = tid + 256 * i;
-      const int key = idx / (HG * 4), c = idx % (HG * 4);
-      const int h = c >> 2, quarter = c & 3;
-      const bool ok = kb0 + key < ng;   // masked keys: zeros (0 * garbage must not poison the accumulators)
-      uint4 kv = kreg[i], vv = vreg[i];
-      if (!ok) { kv = make_uint4(0, 0, 0, 0); vv = make_uint4(0, 0, 0, 0); }
-      *reinterpret_cast<uint4*>(&Kimg[h * RS + key * 32 + quarter * 8]) = kv;
-      _Float16* vt = (quarter & 2) ? Vtl : Vth;
-      const int d0 = (quarter & 1) * 8;
-      const uint32_t w[4] = {vv.x, vv.y, vv.z, vv.w};
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const uint16_t bits = (uint16_t)(w[e >> 1] >> (16 * (e & 1)));
-        reinterpret_cast<uint16_t*>(vt)[T::tr(h, d0 + e, key)] = bits;
-      }
-    }
-    if (tid < KB) {
-      const int kl = kb0 + tid;
-      const float2 p = *reinterpret_cast<const float2*>(pos + 2 * (int64_t)(n0 + (kl < ng ? kl : ng - 1)));
-      *reinterpret_cast<float2*>(&Ps[2 * tid]) = p;
-    }
-  };
+  for (int kb = 0; kb < nbg; ++kb) {
+    const int buf = kb & 1;
+    if (kb + 1 < nbg) stage(kb + 1, buf ^ 1);  // lands under this block's math; its buffer was released by the last barrier
+    const _Float16* Kimg = reinterpret_cast<const _Float16*>(smem + buf * BUF_BYTES);
+    const _Float16* Vimg = reinterpret_cast<const _Float16*>(smem + buf * BUF_BYTES + RK_BYTES);
+    const float* Ps = reinterpret_cast<const float*>(smem + buf * BUF_BYTES + RK_BYTES + TV_BYTES);
+    const int kb0 = kb * HB;
 
-  issue_loads(0);
-  for (int kb0 = 0; kb0 < ng; kb0 += KB) {
-    __syncthreads();
-    write_lds(kb0);
-    __syncthreads();
-    if (kb0 + KB < ng) issue_loads(kb0 + KB);
-
-    // minus the distance bias, as the C input of the first S MFMA (masked keys: -1e30)
-    f32x4 nbias[NT];
+    f32x4 nbias[NT];  // minus the distance bias = C input of the first S MFMA; masked keys: -1e30
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const float4 pa = *reinterpret_cast<const float4*>(&Ps[2 * (16 * t + 4 * G)]);
@@ -139,47 +132,46 @@ __global__ __launch_bounds__(256) void k_attn_h_fwd(const _Float16* __restrict__
 #pragma unroll
     for (int h = 0; h < HG; ++h) {
       f32x4 s[NT];
-      float mx = NEG_BIG;
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        const f16x8 kf = *reinterpret_cast<const f16x8*>(&Kimg[h * RS + (16 * t + j) * 32 + 8 * G]);
+        const f16x8 kf = *reinterpret_cast<const f16x8*>(Kimg + h * R_HEAD + (16 * t + j) * 32 + 8 * G);
         s[t] = mfma_h(kf, qb1[h], nbias[t]);
         s[t] = mfma_h(kf, qb2[h], s[t]);
       }
+      float mloc = fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3]));
 #pragma unroll
-      for (int t = 0; t < NT; ++t) mx = fmaxf(mx, fmaxf(fmaxf(s[t][0], s[t][1]), fmaxf(s[t][2], s[t][3])));
-      mx = group_max4(mx);
-      const float m_new = fmaxf(m[h], mx);
-      const float alpha = __builtin_amdgcn_exp2f(m[h] - m_new);
-      m[h] = m_new;
+      for (int t = 1; t < NT; ++t) mloc = fmaxf(mloc, fmaxf(fmaxf(s[t][0], s[t][1]), fmaxf(s[t][2], s[t][3])));
+      if (__any(mloc > m[h] + LAZY_THR)) {  // wave-uniform: rare after the first blocks
+        const float m_new = fmaxf(m[h], group_max4(mloc));
+        const float alpha = __builtin_amdgcn_exp2f(m[h] - m_new);
+        m[h] = m_new;
+        l[h] *= alpha;
+        oacc[h] *= alpha;
+        oacc2[h] *= alpha;
+      }
+      const float mh = m[h];
       float psum = 0.f;
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          s[t][r] = __builtin_amdgcn_exp2f(s[t][r] - m_new);
+          s[t][r] = __builtin_amdgcn_exp2f(s[t][r] - mh);
           psum += s[t][r];
         }
-      l[h] = fmaf(l[h], alpha, psum);
-      oacc[h] *= alpha;
-      oacc2[h] *= alpha;
+      l[h] += psum;
       if (DROP) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) s[t] *= drop_factors_qmajor(hq[h], q_local, kb0 + 16 * t + 4 * G, dc);
       }
+      const _Float16* vh = Vimg + h * T_HEAD;
 #pragma unroll
       for (int tp = 0; tp < NT / 2; ++tp) {
         const f16x8 pb = pack8(s[2 * tp], s[2 * tp + 1]);
-        const f16x4 a0 = *reinterpret_cast<const f16x4*>(&Vth[T::tr(h, j, 32 * tp + 4 * G)]);
-        const f16x4 a1 = *reinterpret_cast<const f16x4*>(&Vth[T::tr(h, j, 32 * tp + 16 + 4 * G)]);
-        const f16x4 b0 = *reinterpret_cast<const f16x4*>(&Vtl[T::tr(h, j, 32 * tp + 4 * G)]);
-        const f16x4 b1 = *reinterpret_cast<const f16x4*>(&Vtl[T::tr(h, j, 32 * tp + 16 + 4 * G)]);
-        const f16x8 vh = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-        const f16x8 vl = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
-        oacc[h] = mfma_h(vh, pb, oacc[h]);
-        oacc2[h] = mfma_h(vl, pb, oacc2[h]);
+        oacc[h] = mfma_h(load_t_pair(vh, j, 2 * tp, G), pb, oacc[h]);
+        oacc2[h] = mfma_h(load_t_pair(vh + T_PART, j, 2 * tp, G), pb, oacc2[h]);
       }
     }
+    __syncthreads();  // everyone is done with `buf`; the DMA of the next block has landed
   }
 
 #pragma unroll
@@ -190,53 +182,68 @@ __global__ __launch_bounds__(256) void k_attn_h_fwd(const _Float16* __restrict__
       const f32x4 os = oacc[h] + oacc2[h];
       *reinterpret_cast<float4*>(O + (int64_t)(n0 + q_local) * ldo + (head0 + h) * 16 + 4 * G) =
           make_float4(os[0] * inv, os[1] * inv, os[2] * inv, os[3] * inv);
-      if (G == 0) L2[(int64_t)(head0 + h) * N_tot + n0 + q_local] = m[h] + log2f(lt);
     }
+    if (G == 0) lse2_b[((int64_t)blockIdx.x * H + head0 + h) * HB + q_in_blk] = q_ok ? m[h] + log2f(lt) : 0.f;
   }
 }
 
 }  // namespace
 
-extern "C" int dgdm_attn_split_pack(const float* X, int64_t ld, int32_t N, int32_t ncols, float scale, void* out_halfs, void* stream) {
-  DGDM_REQUIRE(N >= 0 && ncols > 0);
-  if (N == 0) return DGDM_OK;
-  DGDM_REQUIRE(X && out_halfs);
-  if ((ncols & 15) || (ld & 3) || ld < ncols || !dgdm_aligned16(X) || !dgdm_aligned16(out_halfs)) return DGDM_ERR_UNSUPPORTED;
-  const int64_t total = (int64_t)N * (ncols >> 2);
-  int64_t blocks = (total + 255) / 256;
-  if (blocks > 16384) blocks = 16384;
-  hipLaunchKernelGGL(k_split_pack, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), X, ld, (int64_t)N, ncols,
-                     scale, static_cast<_Float16*>(out_halfs));
+extern "C" size_t dgdm_attn_pack_bytes(int32_t num_blocks, int32_t H, int32_t which) {
+  // which: 0 = row image, 1 = transposed image, 2 = [blk][64][2] positions, 3 = [blk][H][64] fp32 per-row scalars
+  const size_t nb = num_blocks > 0 ? num_blocks : 0, h = H > 0 ? H : 0;
+  switch (which) {
+    case 0: return nb * h * R_HEAD * 2;
+    case 1: return nb * h * T_HEAD * 2;
+    case 2: return nb * HB * 2 * sizeof(float);
+    case 3: return nb * h * HB * sizeof(float);
+    default: return 0;
+  }
+}
+
+// Packs `ntensors` column blocks of X (tensor z = columns [col0 + z*cstride, +H*16)) into row and
+// transposed images; tensor 0 is scaled by scale0.  pos_b (nullable): block-aligned positions.
+// O (nullable): when given, delta_b[blk][H][64] = rowsum(X_0 * O) (X_0 = dO in the backward).
+extern "C" int dgdm_attn_pack(const float* X, int64_t ld, int32_t col0, int32_t cstride, int32_t ntensors, float scale0,
+                              const int32_t* ptr, int32_t B, int32_t num_blocks, int32_t H, void* R, void* T, const float* pos,
+                              float* pos_b, const float* O, int64_t ldo, float* delta_b, void* stream) {
+  DGDM_REQUIRE(B >= 0 && num_blocks >= 0 && H > 0 && ntensors > 0 && ntensors <= 4);
+  if (num_blocks == 0 || B == 0) return DGDM_OK;
+  DGDM_REQUIRE(X && ptr && R && T);
+  DGDM_REQUIRE((pos == nullptr) == (pos_b == nullptr) && (O == nullptr) == (delta_b == nullptr));
+  if ((ld & 3) || (col0 & 3) || (cstride & 3) || !dgdm_aligned16(X) || !dgdm_aligned16(R) || !dgdm_aligned16(T) ||
+      (O && ((ldo & 3) || !dgdm_aligned16(O))))
+    return DGDM_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(k_attn_pack, dim3(num_blocks, H, ntensors), dim3(256), 0, static_cast<hipStream_t>(stream), X, ld, col0, cstride,
+                     scale0, ptr, B, H, static_cast<_Float16*>(R), (int64_t)num_blocks * H * R_HEAD, static_cast<_Float16*>(T),
+                     (int64_t)num_blocks * H * T_HEAD, pos, pos_b, O, ldo, delta_b);
   return dgdm_launch_status();
 }
 
-extern "C" int dgdm_spatial_attn_h_fwd(const void* Qp, const void* Kp, const void* Vp, const float* pos, const int32_t* ptr, int32_t B,
-                                       int32_t num_q_tiles, int32_t N_tot, int32_t H, float inv_tau, float drop_p, uint32_t seed,
-                                       float* O, int64_t ldo, float* lse2, int32_t variant, void* stream_) {
-  DGDM_REQUIRE(B >= 0 && N_tot >= 0 && H > 0 && num_q_tiles >= 0 && drop_p >= 0.f && drop_p < 1.f);
-  if (N_tot == 0 || num_q_tiles == 0) return DGDM_OK;
-  DGDM_REQUIRE(Qp && Kp && Vp && pos && ptr && O && lse2);
-  if ((ldo & 3) || ldo < H * 16 || !dgdm_aligned16(Qp) || !dgdm_aligned16(Kp) || !dgdm_aligned16(Vp) || !dgdm_aligned16(O) ||
-      (reinterpret_cast<uintptr_t>(pos) & 7u))
+extern "C" int dgdm_spatial_attn_h_fwd(const void* Rq, const void* Rk, const void* Tv, const float* pos_b, const int32_t* ptr,
+                                       int32_t B, int32_t num_blocks, int32_t H, float inv_tau, float drop_p, uint32_t seed, float* O,
+                                       int64_t ldo, float* lse2_b, void* stream_) {
+  DGDM_REQUIRE(B >= 0 && H > 0 && num_blocks >= 0 && drop_p >= 0.f && drop_p < 1.f);
+  if (num_blocks == 0 || B == 0) return DGDM_OK;
+  DGDM_REQUIRE(Rq && Rk && Tv && pos_b && ptr && O && lse2_b);
+  if ((ldo & 3) || ldo < H * 16 || !dgdm_aligned16(Rq) || !dgdm_aligned16(Rk) || !dgdm_aligned16(Tv) || !dgdm_aligned16(O) ||
+      !dgdm_aligned16(pos_b))
     return DGDM_ERR_UNSUPPORTED;
   hipStream_t s = static_cast<hipStream_t>(stream_);
   const float bscale = inv_tau * DGDM_LOG2E;
-  const _Float16 *q = static_cast<const _Float16*>(Qp), *k = static_cast<const _Float16*>(Kp), *v = static_cast<const _Float16*>(Vp);
-#define GO(HG, KB)                                                                                                          \
+  const _Float16 *q = static_cast<const _Float16*>(Rq), *k = static_cast<const _Float16*>(Rk), *v = static_cast<const _Float16*>(Tv);
+#define GO(HG)                                                                                                              \
   do {                                                                                                                      \
     if (drop_p > 0.f)                                                                                                       \
-      hipLaunchKernelGGL((k_attn_h_fwd<HG, KB, true>), dim3(num_q_tiles, H / HG), dim3(256), 0, s, q, k, v, H, pos, ptr, B,  \
-                         bscale, O, ldo, lse2, N_tot, drop_p, seed);                                                        \
+      hipLaunchKernelGGL((k_attn_h_fwd<HG, true>), dim3(num_blocks, H / HG), dim3(256), 0, s, q, k, v, pos_b, H, ptr, B,    \
+                         bscale, O, ldo, lse2_b, drop_p, seed);                                                             \
     else                                                                                                                    \
-      hipLaunchKernelGGL((k_attn_h_fwd<HG, KB, false>), dim3(num_q_tiles, H / HG), dim3(256), 0, s, q, k, v, H, pos, ptr, B, \
-                         bscale, O, ldo, lse2, N_tot, 0.f, 0u);                                                             \
+      hipLaunchKernelGGL((k_attn_h_fwd<HG, false>), dim3(num_blocks, H / HG), dim3(256), 0, s, q, k, v, pos_b, H, ptr, B,   \
+                         bscale, O, ldo, lse2_b, 0.f, 0u);                                                                  \
   } while (0)
-  if (H % 4 == 0 && variant == 1) GO(4, 32);
-  else if (H % 2 == 0 && variant == 2) GO(2, 64);
-  else if (H % 2 == 0 && variant == 3) GO(2, 32);
-  else if (H % 4 == 0) GO(4, 64);
-  else if (H % 2 == 0) GO(2, 64);
-  else GO(1, 64);
+  if (H % 4 == 0) GO(4);
+  else if (H % 2 == 0) GO(2);
+  else GO(1);
 #undef GO
   return dgdm_launch_status();
 }

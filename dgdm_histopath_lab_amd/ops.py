@@ -167,29 +167,60 @@ def spatial_attn_fwd_raw(q, k, v, pos, plan: AttnPlan, H: int, scale: float, inv
 LOG2E = 1.4426950408889634
 
 
-def split_pack(x: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
-    """[N, W] fp32 (W % 16 == 0, unit column stride) -> [N, W/16, 32] fp16 = [hi16 | lo16] of x*scale."""
-    lib = _lib.load()
-    N, W = x.shape
-    out = torch.empty(N, W // 16, 32, dtype=torch.float16, device=x.device)
-    _lib.check(lib.dgdm_attn_split_pack(x.data_ptr(), x.stride(0), N, W, scale, out.data_ptr(), _lib.stream_ptr(x.device)),
-               "dgdm_attn_split_pack")
-    return out
+class PackedOperands:
+    """Block-aligned fp16 hi+lo images of `ntensors` column blocks of one fp32 matrix (csrc/attn_h.hpp)."""
+
+    __slots__ = ("R", "T", "pos_b", "delta_b", "ntensors", "r_stride", "t_stride")
+
+    def r(self, z):
+        return self.R[z * self.r_stride:]
+
+    def t(self, z):
+        return self.T[z * self.t_stride:]
 
 
-def spatial_attn_h_fwd_raw(q, k, v, pos, plan: AttnPlan, H: int, scale: float, inv_tau: float, drop_p: float = 0.0, seed: int = 0,
-                           variant: int = 0, packed=None):
-    """Split-fp16 forward; returns (out, lse2, (Qp, Kp, Vp)) -- the packed operands are reused by the backward."""
+def attn_pack(x, col0: int, cstride: int, ntensors: int, scale0: float, plan: AttnPlan, H: int, pos=None, O=None) -> PackedOperands:
     lib = _lib.load()
-    N, C = q.shape
-    qp, kp, vp = packed if packed is not None else (split_pack(q, scale * LOG2E), split_pack(k), split_pack(v))
-    out = torch.empty(N, C, dtype=torch.float32, device=q.device)
-    lse2 = torch.empty(H, N, dtype=torch.float32, device=q.device)
+    dev, nb = x.device, plan.num_q_tiles
+    pk = PackedOperands()
+    pk.ntensors = ntensors
+    pk.r_stride = lib.dgdm_attn_pack_bytes(nb, H, 0) // 2
+    pk.t_stride = lib.dgdm_attn_pack_bytes(nb, H, 1) // 2
+    pk.R = torch.empty(max(ntensors * pk.r_stride, 8), dtype=torch.float16, device=dev)
+    pk.T = torch.empty(max(ntensors * pk.t_stride, 8), dtype=torch.float16, device=dev)
+    pk.pos_b = torch.empty(max(lib.dgdm_attn_pack_bytes(nb, H, 2) // 4, 4), dtype=torch.float32, device=dev) if pos is not None else None
+    pk.delta_b = torch.empty(max(lib.dgdm_attn_pack_bytes(nb, H, 3) // 4, 4), dtype=torch.float32, device=dev) if O is not None else None
+    _lib.check(lib.dgdm_attn_pack(x.data_ptr(), x.stride(0), col0, cstride, ntensors, scale0, plan.ptr_dev.data_ptr(), plan.B, nb, H,
+                                  pk.R.data_ptr(), pk.T.data_ptr(), _lib.ptr(pos), _lib.ptr(pk.pos_b), _lib.ptr(O),
+                                  O.stride(0) if O is not None else 0, _lib.ptr(pk.delta_b), _lib.stream_ptr(dev)), "dgdm_attn_pack")
+    return pk
+
+
+def spatial_attn_h_fwd_raw(qkv, pos, plan: AttnPlan, H: int, scale: float, inv_tau: float, drop_p: float = 0.0, seed: int = 0,
+                           packed: Optional[PackedOperands] = None):
+    """Split-fp16 forward over a fused [N, 3*H*16] QKV buffer; returns (out, lse2_b, packed)."""
+    lib = _lib.load()
+    N, C = qkv.size(0), H * 16
+    pk = packed if packed is not None else attn_pack(qkv, 0, C, 3, scale * LOG2E, plan, H, pos=pos)
+    out = torch.empty(N, C, dtype=torch.float32, device=qkv.device)
+    lse2_b = torch.empty(max(lib.dgdm_attn_pack_bytes(plan.num_q_tiles, H, 3) // 4, 4), dtype=torch.float32, device=qkv.device)
     TIMERS.timed("attn_fwd", lambda: _lib.check(
-        lib.dgdm_spatial_attn_h_fwd(qp.data_ptr(), kp.data_ptr(), vp.data_ptr(), pos.data_ptr(), plan.ptr_dev.data_ptr(), plan.B,
-                                    plan.num_q_tiles, N, H, inv_tau, drop_p, seed, out.data_ptr(), out.stride(0), lse2.data_ptr(),
-                                    variant, _lib.stream_ptr(q.device)), "dgdm_spatial_attn_h_fwd"))
-    return out, lse2, (qp, kp, vp)
+        lib.dgdm_spatial_attn_h_fwd(pk.r(0).data_ptr(), pk.r(1).data_ptr(), pk.t(2).data_ptr(), pk.pos_b.data_ptr(),
+                                    plan.ptr_dev.data_ptr(), plan.B, plan.num_q_tiles, H, inv_tau, drop_p, seed, out.data_ptr(),
+                                    out.stride(0), lse2_b.data_ptr(), _lib.stream_ptr(qkv.device)), "dgdm_spatial_attn_h_fwd"))
+    return out, lse2_b, pk
+
+
+def unblock_rows(xb: torch.Tensor, plan: AttnPlan, H: int) -> torch.Tensor:
+    """[blk][H][64] block layout -> [H, N_tot] (test/diagnostic helper)."""
+    v = xb[: plan.num_q_tiles * H * 64].view(plan.num_q_tiles, H, 64)
+    outs, blk = [], 0
+    for g in range(plan.B):
+        n = plan.ptr_host[g + 1] - plan.ptr_host[g]
+        nb = (n + 63) // 64
+        outs.append(v[blk:blk + nb].permute(1, 0, 2).reshape(H, nb * 64)[:, :n])
+        blk += nb
+    return torch.cat(outs, dim=1)
 
 
 def spatial_attn_bwd_raw(q, k, v, out, gout, pos, plan: AttnPlan, H: int, scale: float, inv_tau: float, lse2, dqkv,

@@ -149,16 +149,28 @@ DGDM_API int dgdm_spatial_attn_mean_weights(const float* Q, const float* K, int6
                                             float inv_tau, const float* lse2, float* W, const int64_t* w_offsets,
                                             void* stream);
 
-/* K4, split-fp16 path.  Same contract as dgdm_spatial_attn_fwd, but the two products run on the
- * 16-bit matrix pipe with every fp32 operand carried as hi+lo halfs (csrc/attn_h.hpp): on gfx950 the
- * fp32 MFMA cannot overlap with the softmax's fp32 VALU work, the fp16 MFMA can.
- *   dgdm_attn_split_pack: X [N, ncols] fp32 (ncols % 16 == 0) -> out [N][ncols/16][32] halfs,
- *                         [hi16 | lo16] of x*scale per 16-wide head.
- *   Qp (pre-scaled by log2(e)/sqrt(d)), Kp, Vp: packed arrays [N_tot][H][32] halfs. */
-DGDM_API int dgdm_attn_split_pack(const float* X, int64_t ld, int32_t N, int32_t ncols, float scale, void* out_halfs, void* stream);
-DGDM_API int dgdm_spatial_attn_h_fwd(const void* Qp, const void* Kp, const void* Vp, const float* pos, const int32_t* ptr, int32_t B,
-                                     int32_t num_q_tiles, int32_t N_tot, int32_t H, float inv_tau, float drop_p, uint32_t seed,
-                                     float* O, int64_t ldo, float* lse2, int32_t variant, void* stream);
+/* K4, split-fp16 path.  Same math as dgdm_spatial_attn_fwd/_bwd, but the products run on the 16-bit
+ * matrix pipe with every fp32 operand carried as hi+lo halfs (csrc/attn_h.hpp): on gfx950 the fp32
+ * MFMA cannot overlap with the softmax's fp32 VALU work, the fp16 MFMA can.  Operands are packed
+ * once per launch into graph-block-aligned images (64 rows per block, zero padded; block count =
+ * num_q_tiles of the fp32 path) that the kernels stage with direct-to-LDS DMA:
+ *   row image        R[blk][H][64][32] halfs  = [hi16 | lo16] per row
+ *   transposed image T[blk][H][2][16][72] halfs (part 0 hi, 1 lo; [d][row], padded row stride)
+ * dgdm_attn_pack_bytes(num_blocks, H, which): buffer sizes (which: 0 R, 1 T, 2 positions
+ * [blk][64][2] fp32, 3 per-row scalars [blk][H][64] fp32).
+ * dgdm_attn_pack: tensor z (z < ntensors) = columns [col0 + z*cstride, +H*16) of X [N_tot, *]; tensor 0
+ * is scaled by scale0 (Q: log2(e)/sqrt(d)); R/T hold ntensors images back to back.  pos/pos_b
+ * (nullable pair): block-aligned key/query positions.  O/delta_b (nullable pair): delta =
+ * rowsum(X_0 * O) for the backward (X_0 = dO). */
+DGDM_API size_t dgdm_attn_pack_bytes(int32_t num_blocks, int32_t H, int32_t which);
+DGDM_API int dgdm_attn_pack(const float* X, int64_t ld, int32_t col0, int32_t cstride, int32_t ntensors, float scale0,
+                            const int32_t* ptr, int32_t B, int32_t num_blocks, int32_t H, void* R, void* T, const float* pos,
+                            float* pos_b, const float* O, int64_t ldo, float* delta_b, void* stream);
+/* forward: Rq = row image of Q', Rk = row image of K, Tv = transposed image of V; O [N_tot, H*16]
+ * fp32 (row stride ldo); lse2_b [blk][H][64] (log2-domain log-sum-exp, block layout). */
+DGDM_API int dgdm_spatial_attn_h_fwd(const void* Rq, const void* Rk, const void* Tv, const float* pos_b, const int32_t* ptr,
+                                     int32_t B, int32_t num_blocks, int32_t H, float inv_tau, float drop_p, uint32_t seed, float* O,
+                                     int64_t ldo, float* lse2_b, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K5  out = x + sinusoidal_2d_posenc(pos)  for a whole batch.  Replaces

@@ -25,10 +25,11 @@ for p in (0.0, 0.1):
     for var in variants:
         ms = t(lambda: ops.spatial_attn_fwd_raw(qkv[:, :C], qkv[:, C:2*C], qkv[:, 2*C:], pos, plan, H, 0.25, 1.0, var, p, 123))
         print(json.dumps(dict(kernel="fwd", variant=var, drop=p, ms=round(ms, 3), TF=round(2 * fl / ms / 1e9, 1))))
-    packed = (ops.split_pack(qkv[:, :C], 0.25 * ops.LOG2E), ops.split_pack(qkv[:, C:2*C]), ops.split_pack(qkv[:, 2*C:]))
-    for var in (0, 1, 2, 3):
-        ms = t(lambda: ops.spatial_attn_h_fwd_raw(qkv[:, :C], qkv[:, C:2*C], qkv[:, 2*C:], pos, plan, H, 0.25, 1.0, p, 123, var, packed))
-        print(json.dumps(dict(kernel="fwd split-fp16", variant=var, drop=p, ms=round(ms, 3), TF=round(2 * fl / ms / 1e9, 1))))
+    ms = t(lambda: ops.attn_pack(qkv, 0, C, 3, 0.25 * ops.LOG2E, plan, H, pos=pos))
+    print(json.dumps(dict(kernel="attn_pack qkv", ms=round(ms, 3))))
+    packed = ops.attn_pack(qkv, 0, C, 3, 0.25 * ops.LOG2E, plan, H, pos=pos)
+    ms = t(lambda: ops.spatial_attn_h_fwd_raw(qkv, pos, plan, H, 0.25, 1.0, p, 123, packed))
+    print(json.dumps(dict(kernel="fwd split-fp16", drop=p, ms=round(ms, 3), TF=round(2 * fl / ms / 1e9, 1))))
     if os.environ.get("FWD_ONLY"): continue
     out, lse2 = ops.spatial_attn_fwd_raw(qkv[:, :C], qkv[:, C:2*C], qkv[:, 2*C:], pos, plan, H, 0.25, 1.0, 0, p, 123)
     dqkv = torch.empty_like(qkv)
