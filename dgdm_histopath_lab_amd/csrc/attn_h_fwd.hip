@@ -95,13 +95,15 @@ __global__ __launch_bounds__(256) void k_attn_h_fwd(const _Float16* __restrict__
   stage(0, 0);
 
   f16x8 qb1[HG], qb2[HG];
-  f32x4 oacc[HG], oacc2[HG];
-  float m[HG], l[HG];
+  f32x4 oacc[HG], oacc2[HG], lacc[HG];  // lacc: every register = sum over keys of the ROUNDED weights (ones . P)
+  float m[HG];
   uint32_t hq[HG];
+  const _Float16 one = (_Float16)1.0f;
+  const f16x8 ones = {one, one, one, one, one, one, one, one};
 #pragma unroll
   for (int h = 0; h < HG; ++h) {
     load_b_pair(Rq + (((int64_t)blockIdx.x * H + head0 + h) * HB + q_in_blk) * 32, G, &qb1[h], &qb2[h]);
-    oacc[h] = f32x4{0.f, 0.f, 0.f, 0.f}; oacc2[h] = f32x4{0.f, 0.f, 0.f, 0.f}; m[h] = NEG_BIG; l[h] = 0.f;
+    oacc[h] = f32x4{0.f, 0.f, 0.f, 0.f}; oacc2[h] = f32x4{0.f, 0.f, 0.f, 0.f}; lacc[h] = f32x4{0.f, 0.f, 0.f, 0.f}; m[h] = NEG_BIG;
     hq[h] = attn_head_seed(seed, n0, head0 + h) ^ (((uint32_t)q_local >> 1) * 0x9E3779B1U);
   }
   const float2 pq = *reinterpret_cast<const float2*>(pos_b + ((int64_t)blockIdx.x * HB + q_in_blk) * 2);
@@ -145,28 +147,28 @@ __global__ __launch_bounds__(256) void k_attn_h_fwd(const _Float16* __restrict__
         const float m_new = fmaxf(m[h], group_max4(mloc));
         const float alpha = __builtin_amdgcn_exp2f(m[h] - m_new);
         m[h] = m_new;
-        l[h] *= alpha;
+        lacc[h] *= alpha;
         oacc[h] *= alpha;
         oacc2[h] *= alpha;
       }
       const float mh = m[h];
-      float psum = 0.f;
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          s[t][r] = __builtin_amdgcn_exp2f(s[t][r] - mh);
-          psum += s[t][r];
-        }
-      l[h] += psum;
-      if (DROP) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) s[t] *= drop_factors_qmajor(hq[h], q_local, kb0 + 16 * t + 4 * G, dc);
-      }
+        for (int r = 0; r < 4; ++r) s[t][r] = __builtin_amdgcn_exp2f(s[t][r] - mh);
       const _Float16* vh = Vimg + h * T_HEAD;
 #pragma unroll
       for (int tp = 0; tp < NT / 2; ++tp) {
-        const f16x8 pb = pack8(s[2 * tp], s[2 * tp + 1]);
+        // the softmax denominator is summed from the SAME fp16-rounded weights that multiply V, on the
+        // matrix pipe (ones . P): numerator and denominator stay consistent, no VALU adds, and the
+        // result already covers all four lane groups of a query
+        f16x8 pb = pack8(s[2 * tp], s[2 * tp + 1]);
+        lacc[h] = mfma_h(ones, pb, lacc[h]);
+        if (DROP) {  // dropout applies to the normalised weights: mask only what multiplies V
+          s[2 * tp] *= drop_factors_qmajor(hq[h], q_local, kb0 + 32 * tp + 4 * G, dc);
+          s[2 * tp + 1] *= drop_factors_qmajor(hq[h], q_local, kb0 + 32 * tp + 16 + 4 * G, dc);
+          pb = pack8(s[2 * tp], s[2 * tp + 1]);
+        }
         oacc[h] = mfma_h(load_t_pair(vh, j, 2 * tp, G), pb, oacc[h]);
         oacc2[h] = mfma_h(load_t_pair(vh + T_PART, j, 2 * tp, G), pb, oacc2[h]);
       }
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(256) void k_attn_h_fwd(const _Float16* __restrict__
 
 #pragma unroll
   for (int h = 0; h < HG; ++h) {
-    const float lt = group_sum4(l[h]);
+    const float lt = lacc[h][0];
     const float inv = 1.0f / lt;
     if (q_ok) {
       const f32x4 os = oacc[h] + oacc2[h];
