@@ -175,4 +175,6 @@ def test_attn_split_fp16_forward_matches_dense(ptr, H, scale):
     mx, rel = assert_close(o, ro, 3e-4, "O")
     print(f"split-fp16 fwd: max abs {mx:.2e} rel-L2 {rel:.2e}")
     assert rel < 2e-4
-    assert_close(ops.unblock_rows(lse2_b, plan, H) * math.log(2.0), rl, 1e-5, "lse")   # the scores themselves are fp32-accurate
+    # the scores are fp32-accurate; the log-sum-exp is summed from the fp16-rounded weights (consistent with
+    # the numerator), i.e. exact up to ~2^-12 relative on the row sum
+    assert_close(ops.unblock_rows(lse2_b, plan, H) * math.log(2.0), rl, 3e-4, "lse")
