@@ -1,0 +1,323 @@
+// K4 backward, split-fp16 path (see attn_h.hpp / attn_h_fwd.hip).  Same two-pass, atomic-free
+// structure as attn_bwd.hip:
+//   k_attn_h_bwd_dq : per 64-query tile, sweeps key blocks:   dQ = scale * dS K
+//   k_attn_h_bwd_dkv: per 64-key tile, sweeps query blocks:   dV = (P*F)^T dO,  dK = scale * dS^T Q
+// with P = exp2(S' - lse2), dP = dO V^T, dS = P * (F*dP - delta)  (F = dropout keep factors).
+// Per score the VALU does one exp2, one multiply and half a convert: -bias - lse2 is the C input of
+// the S' MFMAs and -delta the C input of the dP MFMAs.  Operands come from the packed images written
+// by dgdm_attn_pack (Q', K, V from the forward's pack; dO + delta from a second pack call) and are
+// staged by direct-to-LDS DMA.
+#include "attn_h.hpp"
+
+namespace {
+
+constexpr float NEG_BIG = -1.0e30f;
+
+// ---------------------------------------------------------------------------------------- dQ
+// LDS per buffer: Rk | Rv | Tk | pos
+template <int HG, int NBUF, bool DROP>
+__global__ __launch_bounds__(256) void k_attn_h_bwd_dq(const _Float16* __restrict__ Rq, const _Float16* __restrict__ Rk,
+                                                       const _Float16* __restrict__ Rv, const _Float16* __restrict__ Tk,
+                                                       const _Float16* __restrict__ Rg, const float* __restrict__ pos_b,
+                                                       const float* __restrict__ lse2_b, const float* __restrict__ delta_b, int H,
+                                                       const int32_t* __restrict__ ptr, int B, float bscale, float scale,
+                                                       float* __restrict__ dQ, int64_t ldg, float drop_p, uint32_t seed) {
+  constexpr int NT = HB / 16;
+  constexpr int R_BYTES = HG * R_HEAD * 2, T_BYTES = HG * T_HEAD * 2, POS_BYTES = HB * 8;
+  constexpr int BUF_BYTES = 2 * R_BYTES + T_BYTES + POS_BYTES;
+  __shared__ __attribute__((aligned(16))) char smem[NBUF * BUF_BYTES];
+  const DropCfg dc(drop_p);
+
+  int n0, ng, lblk, blk0;
+  if (!find_block(ptr, B, blockIdx.x, &n0, &ng, &lblk, &blk0)) return;
+  const int nbg = (ng + HB - 1) / HB;
+  const int head0 = blockIdx.y * HG;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, G = lane >> 4;
+  const int q_in_blk = wave * 16 + j;
+  const int q_local = lblk * HB + q_in_blk;
+  const bool q_ok = q_local < ng;
+
+  auto stage = [&](int kb, int buf) {
+    const int64_t gb = (int64_t)(blk0 + kb) * H + head0;
+    char* base = smem + buf * BUF_BYTES;
+    dma_to_lds<R_BYTES>(Rk + gb * R_HEAD, base, tid);
+    dma_to_lds<R_BYTES>(Rv + gb * R_HEAD, base + R_BYTES, tid);
+    dma_to_lds<T_BYTES>(Tk + gb * T_HEAD, base + 2 * R_BYTES, tid);
+    dma_to_lds<POS_BYTES>(pos_b + (int64_t)(blk0 + kb) * HB * 2, base + 2 * R_BYTES + T_BYTES, tid);
+  };
+  stage(0, 0);
+
+  f16x8 qb1[HG], qb2[HG], gb1[HG], gb2[HG];
+  f32x4 dq[HG], dq2[HG];
+  float nl2[HG], ndl[HG];
+  uint32_t hq[HG];
+#pragma unroll
+  for (int h = 0; h < HG; ++h) {
+    const int64_t rowoff = (((int64_t)blockIdx.x * H + head0 + h) * HB + q_in_blk);
+    load_b_pair(Rq + rowoff * 32, G, &qb1[h], &qb2[h]);
+    load_b_pair(Rg + rowoff * 32, G, &gb1[h], &gb2[h]);
+    nl2[h] = -lse2_b[rowoff];
+    ndl[h] = -delta_b[rowoff];
+    dq[h] = f32x4{0.f, 0.f, 0.f, 0.f}; dq2[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+    hq[h] = attn_head_seed(seed, n0, head0 + h) ^ (((uint32_t)q_local >> 1) * 0x9E3779B1U);
+  }
+  const float2 pq = *reinterpret_cast<const float2*>(pos_b + ((int64_t)blockIdx.x * HB + q_in_blk) * 2);
+  __syncthreads();
+
+  for (int kb = 0; kb < nbg; ++kb) {
+    const int buf = NBUF == 2 ? (kb & 1) : 0;
+    if (NBUF == 2 && kb + 1 < nbg) stage(kb + 1, buf ^ 1);
+    const _Float16* Kimg = reinterpret_cast<const _Float16*>(smem + buf * BUF_BYTES);
+    const _Float16* Vimg = reinterpret_cast<const _Float16*>(smem + buf * BUF_BYTES + R_BYTES);
+    const _Float16* Ktim = reinterpret_cast<const _Float16*>(smem + buf * BUF_BYTES + 2 * R_BYTES);
+    const float* Ps = reinterpret_cast<const float*>(smem + buf * BUF_BYTES + 2 * R_BYTES + T_BYTES);
+    const int kb0 = kb * HB;
+
+    f32x4 nbias[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const float4 pa = *reinterpret_cast<const float4*>(&Ps[2 * (16 * t + 4 * G)]);
+      const float4 pb = *reinterpret_cast<const float4*>(&Ps[2 * (16 * t + 4 * G) + 4]);
+      const float kx[4] = {pa.x, pa.z, pb.x, pb.z}, ky[4] = {pa.y, pa.w, pb.y, pb.w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float dx = pq.x - kx[r], dy = pq.y - ky[r];
+        const float d = __builtin_amdgcn_sqrtf(fmaf(dx, dx, dy * dy)) * bscale;
+        nbias[t][r] = (kb0 + 16 * t + 4 * G + r < ng) ? -d : NEG_BIG;
+      }
+    }
+
+#pragma unroll
+    for (int h = 0; h < HG; ++h) {
+      f32x4 ds[NT];
+      const f32x4 cdl = DROP ? f32x4{0.f, 0.f, 0.f, 0.f} : f32x4{ndl[h], ndl[h], ndl[h], ndl[h]};
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const f16x8 kf = *reinterpret_cast<const f16x8*>(Kimg + h * R_HEAD + (16 * t + j) * 32 + 8 * G);
+        const f16x8 vf = *reinterpret_cast<const f16x8*>(Vimg + h * R_HEAD + (16 * t + j) * 32 + 8 * G);
+        f32x4 s = mfma_h(kf, qb1[h], nbias[t] + nl2[h]);  // S'^T - bias - lse2
+        s = mfma_h(kf, qb2[h], s);
+        f32x4 dp = mfma_h(vf, gb1[h], cdl);              // dP^T - delta
+        dp = mfma_h(vf, gb2[h], dp);
+        if (DROP) dp = dp * drop_factors_qmajor(hq[h], q_local, kb0 + 16 * t + 4 * G, dc) + ndl[h];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ds[t][r] = __builtin_amdgcn_exp2f(s[r]) * dp[r];
+      }
+      const _Float16* kt = Ktim + h * T_HEAD;
+#pragma unroll
+      for (int tp = 0; tp < NT / 2; ++tp) {
+        const f16x8 dsb = pack8(ds[2 * tp], ds[2 * tp + 1]);
+        dq[h] = mfma_h(load_t_pair(kt, j, 2 * tp, G), dsb, dq[h]);            // dQ^T[d=j][q] += K^T[d][key] dS^T[key][q]
+        dq2[h] = mfma_h(load_t_pair(kt + T_PART, j, 2 * tp, G), dsb, dq2[h]);
+      }
+    }
+    __syncthreads();
+    if (NBUF == 1 && kb + 1 < nbg) {
+      stage(kb + 1, 0);
+      __syncthreads();
+    }
+  }
+
+  if (q_ok) {
+#pragma unroll
+    for (int h = 0; h < HG; ++h) {
+      const f32x4 o = (dq[h] + dq2[h]) * scale;
+      *reinterpret_cast<float4*>(dQ + (int64_t)(n0 + q_local) * ldg + (head0 + h) * 16 + 4 * G) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------- dK, dV
+// LDS per buffer: Rq | Rg | Tg | Tq | lse2 [HG][64] | delta [HG][64] | pos
+template <int HG, int NBUF, bool DROP>
+__global__ __launch_bounds__(256) void k_attn_h_bwd_dkv(const _Float16* __restrict__ Rq, const _Float16* __restrict__ Tq,
+                                                        const _Float16* __restrict__ Rk, const _Float16* __restrict__ Rv,
+                                                        const _Float16* __restrict__ Rg, const _Float16* __restrict__ Tg,
+                                                        const float* __restrict__ pos_b, const float* __restrict__ lse2_b,
+                                                        const float* __restrict__ delta_b, int H, const int32_t* __restrict__ ptr,
+                                                        int B, float bscale, float kscale, float* __restrict__ dK,
+                                                        float* __restrict__ dV, int64_t ldg, float drop_p, uint32_t seed) {
+  constexpr int NT = HB / 16;
+  constexpr int R_BYTES = HG * R_HEAD * 2, T_BYTES = HG * T_HEAD * 2, SC_BYTES = HG * HB * 4, POS_BYTES = HB * 8;
+  constexpr int BUF_BYTES = 2 * R_BYTES + 2 * T_BYTES + 2 * SC_BYTES + POS_BYTES;
+  __shared__ __attribute__((aligned(16))) char smem[NBUF * BUF_BYTES];
+  const DropCfg dc(drop_p);
+
+  int n0, ng, lblk, blk0;
+  if (!find_block(ptr, B, blockIdx.x, &n0, &ng, &lblk, &blk0)) return;
+  const int nbg = (ng + HB - 1) / HB;
+  const int head0 = blockIdx.y * HG;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, G = lane >> 4;
+  const int k_in_blk = wave * 16 + j;
+  const int k_local = lblk * HB + k_in_blk;
+  const bool k_ok = k_local < ng;
+
+  auto stage = [&](int qb, int buf) {
+    const int64_t gb = (int64_t)(blk0 + qb) * H + head0;
+    char* base = smem + buf * BUF_BYTES;
+    dma_to_lds<R_BYTES>(Rq + gb * R_HEAD, base, tid);
+    dma_to_lds<R_BYTES>(Rg + gb * R_HEAD, base + R_BYTES, tid);
+    dma_to_lds<T_BYTES>(Tg + gb * T_HEAD, base + 2 * R_BYTES, tid);
+    dma_to_lds<T_BYTES>(Tq + gb * T_HEAD, base + 2 * R_BYTES + T_BYTES, tid);
+    dma_to_lds<SC_BYTES>(lse2_b + gb * HB, base + 2 * R_BYTES + 2 * T_BYTES, tid);
+    dma_to_lds<SC_BYTES>(delta_b + gb * HB, base + 2 * R_BYTES + 2 * T_BYTES + SC_BYTES, tid);
+    dma_to_lds<POS_BYTES>(pos_b + (int64_t)(blk0 + qb) * HB * 2, base + 2 * R_BYTES + 2 * T_BYTES + 2 * SC_BYTES, tid);
+  };
+  stage(0, 0);
+
+  f16x8 kb1[HG], kb2[HG], vb1[HG], vb2[HG];
+  f32x4 dk[HG], dk2[HG], dv[HG], dv2[HG];
+  uint32_t hs[HG];
+#pragma unroll
+  for (int h = 0; h < HG; ++h) {
+    const int64_t rowoff = (((int64_t)blockIdx.x * H + head0 + h) * HB + k_in_blk);
+    load_b_pair(Rk + rowoff * 32, G, &kb1[h], &kb2[h]);
+    load_b_pair(Rv + rowoff * 32, G, &vb1[h], &vb2[h]);
+    dk[h] = f32x4{0.f, 0.f, 0.f, 0.f}; dk2[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+    dv[h] = f32x4{0.f, 0.f, 0.f, 0.f}; dv2[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+    hs[h] = attn_head_seed(seed, n0, head0 + h);
+  }
+  const float2 pk = *reinterpret_cast<const float2*>(pos_b + ((int64_t)blockIdx.x * HB + k_in_blk) * 2);
+  __syncthreads();
+
+  for (int qb = 0; qb < nbg; ++qb) {
+    const int buf = NBUF == 2 ? (qb & 1) : 0;
+    if (NBUF == 2 && qb + 1 < nbg) stage(qb + 1, buf ^ 1);
+    const char* base = smem + buf * BUF_BYTES;
+    const _Float16* Qimg = reinterpret_cast<const _Float16*>(base);
+    const _Float16* Gimg = reinterpret_cast<const _Float16*>(base + R_BYTES);
+    const _Float16* Gtim = reinterpret_cast<const _Float16*>(base + 2 * R_BYTES);
+    const _Float16* Qtim = reinterpret_cast<const _Float16*>(base + 2 * R_BYTES + T_BYTES);
+    const float* Ls = reinterpret_cast<const float*>(base + 2 * R_BYTES + 2 * T_BYTES);
+    const float* Ds = Ls + HG * HB;
+    const float* Ps = Ds + HG * HB;
+    const int qb0 = qb * HB;
+
+    // lane (key=j, G), reg r <-> query 16t + 4G + r
+    f32x4 nbias[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const float4 pa = *reinterpret_cast<const float4*>(&Ps[2 * (16 * t + 4 * G)]);
+      const float4 pb = *reinterpret_cast<const float4*>(&Ps[2 * (16 * t + 4 * G) + 4]);
+      const float qx[4] = {pa.x, pa.z, pb.x, pb.z}, qy[4] = {pa.y, pa.w, pb.y, pb.w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float dx = pk.x - qx[r], dy = pk.y - qy[r];
+        const float d = __builtin_amdgcn_sqrtf(fmaf(dx, dx, dy * dy)) * bscale;
+        nbias[t][r] = (qb0 + 16 * t + 4 * G + r < ng) ? -d : NEG_BIG;  // masked queries contribute nothing
+      }
+    }
+
+#pragma unroll
+    for (int h = 0; h < HG; ++h) {
+      f32x4 p[NT], ds[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const f16x8 qa = *reinterpret_cast<const f16x8*>(Qimg + h * R_HEAD + (16 * t + j) * 32 + 8 * G);
+        const f16x8 ga = *reinterpret_cast<const f16x8*>(Gimg + h * R_HEAD + (16 * t + j) * 32 + 8 * G);
+        const f32x4 lq = *reinterpret_cast<const f32x4*>(&Ls[h * HB + 16 * t + 4 * G]);
+        const f32x4 dq = *reinterpret_cast<const f32x4*>(&Ds[h * HB + 16 * t + 4 * G]);
+        f32x4 s = mfma_h(qa, kb1[h], nbias[t] - lq);   // S'[q][key] - bias - lse2[q]
+        s = mfma_h(qa, kb2[h], s);
+        f32x4 dpv = mfma_h(ga, vb1[h], DROP ? f32x4{0.f, 0.f, 0.f, 0.f} : -dq);  // dP[q][key] - delta[q]
+        dpv = mfma_h(ga, vb2[h], dpv);
+        f32x4 f = f32x4{1.f, 1.f, 1.f, 1.f};
+        if (DROP) {
+          f = drop_factors_kmajor(hs[h], k_local, qb0 + 16 * t + 4 * G, dc);
+          dpv = dpv * f - dq;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pr = __builtin_amdgcn_exp2f(s[r]);
+          ds[t][r] = pr * dpv[r];
+          p[t][r] = DROP ? pr * f[r] : pr;   // dV sees the dropped weights
+        }
+      }
+      const _Float16* gt = Gtim + h * T_HEAD;
+      const _Float16* qt = Qtim + h * T_HEAD;
+#pragma unroll
+      for (int tp = 0; tp < NT / 2; ++tp) {
+        const f16x8 pb = pack8(p[2 * tp], p[2 * tp + 1]);
+        const f16x8 dsb = pack8(ds[2 * tp], ds[2 * tp + 1]);
+        dv[h] = mfma_h(load_t_pair(gt, j, 2 * tp, G), pb, dv[h]);              // dV^T[d=j][key] += dO^T[d][q] P[q][key]
+        dv2[h] = mfma_h(load_t_pair(gt + T_PART, j, 2 * tp, G), pb, dv2[h]);
+        dk[h] = mfma_h(load_t_pair(qt, j, 2 * tp, G), dsb, dk[h]);             // dK^T[d=j][key] += Q'^T[d][q] dS[q][key]
+        dk2[h] = mfma_h(load_t_pair(qt + T_PART, j, 2 * tp, G), dsb, dk2[h]);
+      }
+    }
+    __syncthreads();
+    if (NBUF == 1 && qb + 1 < nbg) {
+      stage(qb + 1, 0);
+      __syncthreads();
+    }
+  }
+
+  if (k_ok) {
+#pragma unroll
+    for (int h = 0; h < HG; ++h) {
+      const int64_t off = (int64_t)(n0 + k_local) * ldg + (head0 + h) * 16 + 4 * G;
+      const f32x4 a = (dk[h] + dk2[h]) * kscale, b = dv[h] + dv2[h];
+      *reinterpret_cast<float4*>(dK + off) = make_float4(a[0], a[1], a[2], a[3]);
+      *reinterpret_cast<float4*>(dV + off) = make_float4(b[0], b[1], b[2], b[3]);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int dgdm_spatial_attn_h_bwd_dq(const void* Rq, const void* Rk, const void* Rv, const void* Tk, const void* Rg,
+                                          const float* pos_b, const float* lse2_b, const float* delta_b, const int32_t* ptr, int32_t B,
+                                          int32_t num_blocks, int32_t H, float scale, float inv_tau, float drop_p, uint32_t seed,
+                                          float* dQ, int64_t ldg, void* stream_) {
+  DGDM_REQUIRE(B >= 0 && H > 0 && num_blocks >= 0 && drop_p >= 0.f && drop_p < 1.f);
+  if (num_blocks == 0 || B == 0) return DGDM_OK;
+  DGDM_REQUIRE(Rq && Rk && Rv && Tk && Rg && pos_b && lse2_b && delta_b && ptr && dQ);
+  if ((ldg & 3) || ldg < H * 16 || !dgdm_aligned16(dQ)) return DGDM_ERR_UNSUPPORTED;
+  hipStream_t s = static_cast<hipStream_t>(stream_);
+  const float bscale = inv_tau * DGDM_LOG2E;
+  auto h16 = [](const void* p) { return static_cast<const _Float16*>(p); };
+#define GO(HG, NBUF)                                                                                                             \
+  do {                                                                                                                           \
+    if (drop_p > 0.f)                                                                                                            \
+      hipLaunchKernelGGL((k_attn_h_bwd_dq<HG, NBUF, true>), dim3(num_blocks, H / HG), dim3(256), 0, s, h16(Rq), h16(Rk), h16(Rv), \
+                         h16(Tk), h16(Rg), pos_b, lse2_b, delta_b, H, ptr, B, bscale, scale, dQ, ldg, drop_p, seed);             \
+    else                                                                                                                         \
+      hipLaunchKernelGGL((k_attn_h_bwd_dq<HG, NBUF, false>), dim3(num_blocks, H / HG), dim3(256), 0, s, h16(Rq), h16(Rk),        \
+                         h16(Rv), h16(Tk), h16(Rg), pos_b, lse2_b, delta_b, H, ptr, B, bscale, scale, dQ, ldg, 0.f, 0u);         \
+  } while (0)
+  if (H % 4 == 0) GO(4, 1);
+  else if (H % 2 == 0) GO(2, 2);
+  else GO(1, 2);
+#undef GO
+  return dgdm_launch_status();
+}
+
+extern "C" int dgdm_spatial_attn_h_bwd_dkv(const void* Rq, const void* Tq, const void* Rk, const void* Rv, const void* Rg,
+                                           const void* Tg, const float* pos_b, const float* lse2_b, const float* delta_b,
+                                           const int32_t* ptr, int32_t B, int32_t num_blocks, int32_t H, float inv_tau, float drop_p,
+                                           uint32_t seed, float* dK, float* dV, int64_t ldg, void* stream_) {
+  DGDM_REQUIRE(B >= 0 && H > 0 && num_blocks >= 0 && drop_p >= 0.f && drop_p < 1.f);
+  if (num_blocks == 0 || B == 0) return DGDM_OK;
+  DGDM_REQUIRE(Rq && Tq && Rk && Rv && Rg && Tg && pos_b && lse2_b && delta_b && ptr && dK && dV);
+  if ((ldg & 3) || ldg < H * 16 || !dgdm_aligned16(dK) || !dgdm_aligned16(dV)) return DGDM_ERR_UNSUPPORTED;
+  hipStream_t s = static_cast<hipStream_t>(stream_);
+  const float bscale = inv_tau * DGDM_LOG2E;
+  const float kscale = 0.6931471805599453f;  // Q' carries scale*log2(e): dK = sum dS Q' / log2(e)
+  auto h16 = [](const void* p) { return static_cast<const _Float16*>(p); };
+#define GO(HG, NBUF)                                                                                                               \
+  do {                                                                                                                             \
+    if (drop_p > 0.f)                                                                                                              \
+      hipLaunchKernelGGL((k_attn_h_bwd_dkv<HG, NBUF, true>), dim3(num_blocks, H / HG), dim3(256), 0, s, h16(Rq), h16(Tq), h16(Rk),  \
+                         h16(Rv), h16(Rg), h16(Tg), pos_b, lse2_b, delta_b, H, ptr, B, bscale, kscale, dK, dV, ldg, drop_p, seed); \
+    else                                                                                                                           \
+      hipLaunchKernelGGL((k_attn_h_bwd_dkv<HG, NBUF, false>), dim3(num_blocks, H / HG), dim3(256), 0, s, h16(Rq), h16(Tq), h16(Rk), \
+                         h16(Rv), h16(Rg), h16(Tg), pos_b, lse2_b, delta_b, H, ptr, B, bscale, kscale, dK, dV, ldg, 0.f, 0u);      \
+  } while (0)
+  if (H % 4 == 0) GO(4, 1);
+  else if (H % 2 == 0) GO(2, 2);
+  else GO(1, 2);
+#undef GO
+  return dgdm_launch_status();
+}

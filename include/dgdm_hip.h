@@ -171,6 +171,17 @@ DGDM_API int dgdm_attn_pack(const float* X, int64_t ld, int32_t col0, int32_t cs
 DGDM_API int dgdm_spatial_attn_h_fwd(const void* Rq, const void* Rk, const void* Tv, const float* pos_b, const int32_t* ptr,
                                      int32_t B, int32_t num_blocks, int32_t H, float inv_tau, float drop_p, uint32_t seed, float* O,
                                      int64_t ldo, float* lse2_b, void* stream);
+/* backward: Rg/Tg = images of dO and delta_b = rowsum(dO*O) from a second dgdm_attn_pack call
+ * (ntensors = 1, scale0 = 1, O given); lse2_b from the forward.  dQ/dK/dV fp32 [N_tot, H*16], row
+ * stride ldg.  Same drop_p/seed as the forward.  Two launches, no atomics. */
+DGDM_API int dgdm_spatial_attn_h_bwd_dq(const void* Rq, const void* Rk, const void* Rv, const void* Tk, const void* Rg,
+                                        const float* pos_b, const float* lse2_b, const float* delta_b, const int32_t* ptr, int32_t B,
+                                        int32_t num_blocks, int32_t H, float scale, float inv_tau, float drop_p, uint32_t seed,
+                                        float* dQ, int64_t ldg, void* stream);
+DGDM_API int dgdm_spatial_attn_h_bwd_dkv(const void* Rq, const void* Tq, const void* Rk, const void* Rv, const void* Rg,
+                                         const void* Tg, const float* pos_b, const float* lse2_b, const float* delta_b,
+                                         const int32_t* ptr, int32_t B, int32_t num_blocks, int32_t H, float inv_tau, float drop_p,
+                                         uint32_t seed, float* dK, float* dV, int64_t ldg, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K5  out = x + sinusoidal_2d_posenc(pos)  for a whole batch.  Replaces

@@ -178,3 +178,24 @@ def test_attn_split_fp16_forward_matches_dense(ptr, H, scale):
     # the scores are fp32-accurate; the log-sum-exp is summed from the fp16-rounded weights (consistent with
     # the numerator), i.e. exact up to ~2^-12 relative on the row sum
     assert_close(ops.unblock_rows(lse2_b, plan, H) * math.log(2.0), rl, 3e-4, "lse")
+
+
+@pytest.mark.parametrize("ptr,H", [([0, 17], 8), ([0, 65, 130, 131], 8), ([0, 200, 263], 2), ([0, 100], 1), ([0, 333, 1000], 8),
+                                    ([0, 129, 500], 16)])
+def test_attn_split_fp16_backward_matches_dense(ptr, H):
+    from dgdm_histopath_lab_amd import ops
+    qkv, pos = make(ptr, H, 7 * sum(ptr) + H)
+    C = H * 16
+    g = torch.Generator().manual_seed(2)
+    gout = torch.randn(ptr[-1], C, generator=g)
+    d = qkv.to(DEV).requires_grad_(True)
+    plan = ops.AttnPlan(ptr, DEV)
+    o = ops._SpatialAttentionH.apply(d, pos.to(DEV), plan, H, 0.25, 1.0, 0.0, 0)
+    o.backward(gout.to(DEV))
+    ro, gq, gk, gv = dense_reference(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], pos, ptr, H, 1.0, gout)
+    errs = [assert_close(o, ro, 3e-4, "O"), assert_close(d.grad[:, :C], gq, 5e-4, "dQ"),
+            assert_close(d.grad[:, C:2 * C], gk, 5e-4, "dK"), assert_close(d.grad[:, 2 * C:], gv, 5e-4, "dV")]
+    print("split-fp16 bwd rel-L2: O %.1e dQ %.1e dK %.1e dV %.1e" % tuple(e[1] for e in errs))
+    d2 = qkv.to(DEV).requires_grad_(True)
+    ops._SpatialAttentionH.apply(d2, pos.to(DEV), plan, H, 0.25, 1.0, 0.0, 0).backward(gout.to(DEV))
+    assert torch.equal(d.grad, d2.grad)   # atomic-free: bitwise reproducible
