@@ -8,7 +8,8 @@ from dgdm_histopath_lab_amd import DGDMModel
 from dgdm_histopath_lab_amd.synthetic import synthetic_batch
 
 nodes, edges = int(sys.argv[1]) if len(sys.argv) > 1 else 2000, int(sys.argv[2]) if len(sys.argv) > 2 else 8000
-cfgd = dict(node_features=768, hidden_dims=[512, 256, 128], num_diffusion_steps=10, attention_heads=8)
+cfgd = dict(node_features=768, hidden_dims=[512, 256, 128], num_diffusion_steps=10, attention_heads=8,
+            use_hierarchical=os.environ.get("SMOOTH", "0") != "1")
 cfg = O.OracleConfig(**cfgd)
 P = O.init_params(cfg, seed=3, perturb=0.05)
 batch = synthetic_batch(0, 2, nodes, edges)
