@@ -21,7 +21,8 @@ __global__ __launch_bounds__(256) void k_attn_h_bwd_dq(const _Float16* __restric
                                                        const _Float16* __restrict__ Rg, const float* __restrict__ pos_b,
                                                        const float* __restrict__ lse2_b, const float* __restrict__ delta_b, int H,
                                                        const int32_t* __restrict__ ptr, int B, float bscale, float scale,
-                                                       float* __restrict__ dQ, int64_t ldg, float drop_p, uint32_t seed) {
+                                                       const float* __restrict__ unscale_dev, float* __restrict__ dQ, int64_t ldg,
+                                                       float drop_p, uint32_t seed) {
   constexpr int NT = HB / 16;
   constexpr int R_BYTES = HG * R_HEAD * 2, T_BYTES = HG * T_HEAD * 2, POS_BYTES = HB * 8;
   constexpr int BUF_BYTES = 2 * R_BYTES + T_BYTES + POS_BYTES;
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(256) void k_attn_h_bwd_dq(const _Float16* __restric
   if (q_ok) {
 #pragma unroll
     for (int h = 0; h < HG; ++h) {
-      const f32x4 o = (dq[h] + dq2[h]) * scale;
+      const f32x4 o = (dq[h] + dq2[h]) * (scale * unscale_dev[1]);
       *reinterpret_cast<float4*>(dQ + (int64_t)(n0 + q_local) * ldg + (head0 + h) * 16 + 4 * G) = make_float4(o[0], o[1], o[2], o[3]);
     }
   }
@@ -136,8 +137,9 @@ __global__ __launch_bounds__(256) void k_attn_h_bwd_dkv(const _Float16* __restri
                                                         const _Float16* __restrict__ Rg, const _Float16* __restrict__ Tg,
                                                         const float* __restrict__ pos_b, const float* __restrict__ lse2_b,
                                                         const float* __restrict__ delta_b, int H, const int32_t* __restrict__ ptr,
-                                                        int B, float bscale, float kscale, float* __restrict__ dK,
-                                                        float* __restrict__ dV, int64_t ldg, float drop_p, uint32_t seed) {
+                                                        int B, float bscale, float kscale, const float* __restrict__ unscale_dev,
+                                                        float* __restrict__ dK, float* __restrict__ dV, int64_t ldg, float drop_p,
+                                                        uint32_t seed) {
   constexpr int NT = HB / 16;
   constexpr int R_BYTES = HG * R_HEAD * 2, T_BYTES = HG * T_HEAD * 2, SC_BYTES = HG * HB * 4, POS_BYTES = HB * 8;
   constexpr int BUF_BYTES = 2 * R_BYTES + 2 * T_BYTES + 2 * SC_BYTES + POS_BYTES;
@@ -258,7 +260,8 @@ __global__ __launch_bounds__(256) void k_attn_h_bwd_dkv(const _Float16* __restri
 #pragma unroll
     for (int h = 0; h < HG; ++h) {
       const int64_t off = (int64_t)(n0 + k_local) * ldg + (head0 + h) * 16 + 4 * G;
-      const f32x4 a = (dk[h] + dk2[h]) * kscale, b = dv[h] + dv2[h];
+      const float un = unscale_dev[1];
+      const f32x4 a = (dk[h] + dk2[h]) * (kscale * un), b = (dv[h] + dv2[h]) * un;
       *reinterpret_cast<float4*>(dK + off) = make_float4(a[0], a[1], a[2], a[3]);
       *reinterpret_cast<float4*>(dV + off) = make_float4(b[0], b[1], b[2], b[3]);
     }
@@ -270,10 +273,10 @@ __global__ __launch_bounds__(256) void k_attn_h_bwd_dkv(const _Float16* __restri
 extern "C" int dgdm_spatial_attn_h_bwd_dq(const void* Rq, const void* Rk, const void* Rv, const void* Tk, const void* Rg,
                                           const float* pos_b, const float* lse2_b, const float* delta_b, const int32_t* ptr, int32_t B,
                                           int32_t num_blocks, int32_t H, float scale, float inv_tau, float drop_p, uint32_t seed,
-                                          float* dQ, int64_t ldg, void* stream_) {
+                                          const float* grad_scale2, float* dQ, int64_t ldg, void* stream_) {
   DGDM_REQUIRE(B >= 0 && H > 0 && num_blocks >= 0 && drop_p >= 0.f && drop_p < 1.f);
   if (num_blocks == 0 || B == 0) return DGDM_OK;
-  DGDM_REQUIRE(Rq && Rk && Rv && Tk && Rg && pos_b && lse2_b && delta_b && ptr && dQ);
+  DGDM_REQUIRE(Rq && Rk && Rv && Tk && Rg && pos_b && lse2_b && delta_b && ptr && dQ && grad_scale2);
   if ((ldg & 3) || ldg < H * 16 || !dgdm_aligned16(dQ)) return DGDM_ERR_UNSUPPORTED;
   hipStream_t s = static_cast<hipStream_t>(stream_);
   const float bscale = inv_tau * DGDM_LOG2E;
@@ -282,10 +285,10 @@ extern "C" int dgdm_spatial_attn_h_bwd_dq(const void* Rq, const void* Rk, const 
   do {                                                                                                                           \
     if (drop_p > 0.f)                                                                                                            \
       hipLaunchKernelGGL((k_attn_h_bwd_dq<HG, NBUF, true>), dim3(num_blocks, H / HG), dim3(256), 0, s, h16(Rq), h16(Rk), h16(Rv), \
-                         h16(Tk), h16(Rg), pos_b, lse2_b, delta_b, H, ptr, B, bscale, scale, dQ, ldg, drop_p, seed);             \
+                         h16(Tk), h16(Rg), pos_b, lse2_b, delta_b, H, ptr, B, bscale, scale, grad_scale2, dQ, ldg, drop_p, seed);             \
     else                                                                                                                         \
       hipLaunchKernelGGL((k_attn_h_bwd_dq<HG, NBUF, false>), dim3(num_blocks, H / HG), dim3(256), 0, s, h16(Rq), h16(Rk),        \
-                         h16(Rv), h16(Tk), h16(Rg), pos_b, lse2_b, delta_b, H, ptr, B, bscale, scale, dQ, ldg, 0.f, 0u);         \
+                         h16(Rv), h16(Tk), h16(Rg), pos_b, lse2_b, delta_b, H, ptr, B, bscale, scale, grad_scale2, dQ, ldg, 0.f, 0u);         \
   } while (0)
   if (H % 4 == 0) GO(4, 1);
   else if (H % 2 == 0) GO(2, 2);
@@ -297,10 +300,10 @@ extern "C" int dgdm_spatial_attn_h_bwd_dq(const void* Rq, const void* Rk, const 
 extern "C" int dgdm_spatial_attn_h_bwd_dkv(const void* Rq, const void* Tq, const void* Rk, const void* Rv, const void* Rg,
                                            const void* Tg, const float* pos_b, const float* lse2_b, const float* delta_b,
                                            const int32_t* ptr, int32_t B, int32_t num_blocks, int32_t H, float inv_tau, float drop_p,
-                                           uint32_t seed, float* dK, float* dV, int64_t ldg, void* stream_) {
+                                           uint32_t seed, const float* grad_scale2, float* dK, float* dV, int64_t ldg, void* stream_) {
   DGDM_REQUIRE(B >= 0 && H > 0 && num_blocks >= 0 && drop_p >= 0.f && drop_p < 1.f);
   if (num_blocks == 0 || B == 0) return DGDM_OK;
-  DGDM_REQUIRE(Rq && Tq && Rk && Rv && Rg && Tg && pos_b && lse2_b && delta_b && ptr && dK && dV);
+  DGDM_REQUIRE(Rq && Tq && Rk && Rv && Rg && Tg && pos_b && lse2_b && delta_b && ptr && dK && dV && grad_scale2);
   if ((ldg & 3) || ldg < H * 16 || !dgdm_aligned16(dK) || !dgdm_aligned16(dV)) return DGDM_ERR_UNSUPPORTED;
   hipStream_t s = static_cast<hipStream_t>(stream_);
   const float bscale = inv_tau * DGDM_LOG2E;
@@ -310,10 +313,10 @@ extern "C" int dgdm_spatial_attn_h_bwd_dkv(const void* Rq, const void* Tq, const
   do {                                                                                                                             \
     if (drop_p > 0.f)                                                                                                              \
       hipLaunchKernelGGL((k_attn_h_bwd_dkv<HG, NBUF, true>), dim3(num_blocks, H / HG), dim3(256), 0, s, h16(Rq), h16(Tq), h16(Rk),  \
-                         h16(Rv), h16(Rg), h16(Tg), pos_b, lse2_b, delta_b, H, ptr, B, bscale, kscale, dK, dV, ldg, drop_p, seed); \
+                         h16(Rv), h16(Rg), h16(Tg), pos_b, lse2_b, delta_b, H, ptr, B, bscale, kscale, grad_scale2, dK, dV, ldg, drop_p, seed); \
     else                                                                                                                           \
       hipLaunchKernelGGL((k_attn_h_bwd_dkv<HG, NBUF, false>), dim3(num_blocks, H / HG), dim3(256), 0, s, h16(Rq), h16(Tq), h16(Rk), \
-                         h16(Rv), h16(Rg), h16(Tg), pos_b, lse2_b, delta_b, H, ptr, B, bscale, kscale, dK, dV, ldg, 0.f, 0u);      \
+                         h16(Rv), h16(Rg), h16(Tg), pos_b, lse2_b, delta_b, H, ptr, B, bscale, kscale, grad_scale2, dK, dV, ldg, 0.f, 0u);      \
   } while (0)
   if (H % 4 == 0) GO(4, 1);
   else if (H % 2 == 0) GO(2, 2);

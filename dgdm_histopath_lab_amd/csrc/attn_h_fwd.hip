@@ -18,8 +18,39 @@ constexpr float NEG_BIG = -1.0e30f;
 constexpr float LAZY_THR = 6.0f;  // exp2 arguments stay <= 6 between rescales: P <= 64, safe in fp16/fp32
 
 // grid (NB, H, ntensors).  Tensor z: columns [col0 + z*cstride, +H*16) of X, scaled by (z == 0 ? scale0 : 1).
+// fp16 range guard for the backward: alpha = 2^k with alpha * max|x| in [target/2, target]; out = {alpha, 1/alpha}.
+// Two launches (block maxima, then the final max), no host round trip.
+__global__ __launch_bounds__(256) void k_amax_partial(const float* __restrict__ x, int64_t n4, float* __restrict__ part) {
+  float m = 0.f;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+  }
+  m = wave_max(m);
+  __shared__ float sm[4];
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+}
+__global__ __launch_bounds__(256) void k_amax_final(const float* __restrict__ part, int nparts, float target, float* __restrict__ out2) {
+  float m = 0.f;
+  for (int i = threadIdx.x; i < nparts; i += 256) m = fmaxf(m, part[i]);
+  m = wave_max(m);
+  __shared__ float sm[4];
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float amax = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+    float e = (amax > 0.f && amax < INFINITY) ? floorf(log2f(target / amax)) : 0.f;
+    e = fminf(fmaxf(e, -60.f), 60.f);
+    out2[0] = exp2f(e);
+    out2[1] = exp2f(-e);
+  }
+}
+
 __global__ __launch_bounds__(256) void k_attn_pack(const float* __restrict__ X, int64_t ld, int col0, int cstride, float scale0,
-                                                   const int32_t* __restrict__ ptr, int B, int H, _Float16* __restrict__ R,
+                                                   const float* __restrict__ scale_dev, const int32_t* __restrict__ ptr, int B, int H, _Float16* __restrict__ R,
                                                    int64_t r_tensor_stride, _Float16* __restrict__ Tt, int64_t t_tensor_stride,
                                                    const float* __restrict__ pos, float* __restrict__ pos_b,
                                                    const float* __restrict__ Oin, int64_t ldo, float* __restrict__ delta_b) {
@@ -31,7 +62,7 @@ __global__ __launch_bounds__(256) void k_attn_pack(const float* __restrict__ X, 
   const int rl = lblk * HB + row;
   const bool ok = rl < ng;
   const int64_t node = n0 + (ok ? rl : ng - 1);
-  const float scale = z == 0 ? scale0 : 1.0f;
+  const float scale = (z == 0 ? scale0 : 1.0f) * (scale_dev ? scale_dev[0] : 1.0f);
   const float4 v = *reinterpret_cast<const float4*>(X + node * ld + col0 + z * cstride + h * 16 + part * 4);
   const float x[4] = {ok ? v.x * scale : 0.f, ok ? v.y * scale : 0.f, ok ? v.z * scale : 0.f, ok ? v.w * scale : 0.f};
   f16x4 hi, lo;
@@ -206,8 +237,26 @@ extern "C" size_t dgdm_attn_pack_bytes(int32_t num_blocks, int32_t H, int32_t wh
 // Packs `ntensors` column blocks of X (tensor z = columns [col0 + z*cstride, +H*16)) into row and
 // transposed images; tensor 0 is scaled by scale0.  pos_b (nullable): block-aligned positions.
 // O (nullable): when given, delta_b[blk][H][64] = rowsum(X_0 * O) (X_0 = dO in the backward).
+extern "C" size_t dgdm_amax_scale_workspace_bytes(void) { return 1024 * sizeof(float); }
+
+// out2[0] = alpha = 2^k such that alpha * max|x| lies in (target/2, target]; out2[1] = 1/alpha.  x: n contiguous floats.
+extern "C" int dgdm_amax_pow2_scale(const float* x, int64_t n, float target, float* out2, void* workspace, size_t workspace_bytes,
+                                    void* stream) {
+  DGDM_REQUIRE(n >= 0 && out2 && workspace && target > 0.f);
+  if (workspace_bytes < dgdm_amax_scale_workspace_bytes()) return DGDM_ERR_WORKSPACE;
+  if (n > 0 && (!x || (n & 3) || !dgdm_aligned16(x))) return n > 0 && !x ? DGDM_ERR_INVALID_ARG : DGDM_ERR_UNSUPPORTED;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  float* part = static_cast<float*>(workspace);
+  const int64_t n4 = n >> 2;
+  int blocks = (int)((n4 + 255) / 256 < 1024 ? (n4 + 255) / 256 : 1024);
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(k_amax_partial, dim3(blocks), dim3(256), 0, s, x, n4, part);
+  hipLaunchKernelGGL(k_amax_final, dim3(1), dim3(256), 0, s, part, blocks, target, out2);
+  return dgdm_launch_status();
+}
+
 extern "C" int dgdm_attn_pack(const float* X, int64_t ld, int32_t col0, int32_t cstride, int32_t ntensors, float scale0,
-                              const int32_t* ptr, int32_t B, int32_t num_blocks, int32_t H, void* R, void* T, const float* pos,
+                              const float* scale_dev, const int32_t* ptr, int32_t B, int32_t num_blocks, int32_t H, void* R, void* T, const float* pos,
                               float* pos_b, const float* O, int64_t ldo, float* delta_b, void* stream) {
   DGDM_REQUIRE(B >= 0 && num_blocks >= 0 && H > 0 && ntensors > 0 && ntensors <= 4);
   if (num_blocks == 0 || B == 0) return DGDM_OK;
@@ -217,7 +266,7 @@ extern "C" int dgdm_attn_pack(const float* X, int64_t ld, int32_t col0, int32_t 
       (O && ((ldo & 3) || !dgdm_aligned16(O))))
     return DGDM_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(k_attn_pack, dim3(num_blocks, H, ntensors), dim3(256), 0, static_cast<hipStream_t>(stream), X, ld, col0, cstride,
-                     scale0, ptr, B, H, static_cast<_Float16*>(R), (int64_t)num_blocks * H * R_HEAD, static_cast<_Float16*>(T),
+                     scale0, scale_dev, ptr, B, H, static_cast<_Float16*>(R), (int64_t)num_blocks * H * R_HEAD, static_cast<_Float16*>(T),
                      (int64_t)num_blocks * H * T_HEAD, pos, pos_b, O, ldo, delta_b);
   return dgdm_launch_status();
 }

@@ -180,7 +180,8 @@ class PackedOperands:
         return self.T[z * self.t_stride:]
 
 
-def attn_pack(x, col0: int, cstride: int, ntensors: int, scale0: float, plan: AttnPlan, H: int, pos=None, O=None) -> PackedOperands:
+def attn_pack(x, col0: int, cstride: int, ntensors: int, scale0: float, plan: AttnPlan, H: int, pos=None, O=None,
+              scale_dev=None) -> PackedOperands:
     lib = _lib.load()
     dev, nb = x.device, plan.num_q_tiles
     pk = PackedOperands()
@@ -191,7 +192,8 @@ def attn_pack(x, col0: int, cstride: int, ntensors: int, scale0: float, plan: At
     pk.T = torch.empty(max(ntensors * pk.t_stride, 8), dtype=torch.float16, device=dev)
     pk.pos_b = torch.empty(max(lib.dgdm_attn_pack_bytes(nb, H, 2) // 4, 4), dtype=torch.float32, device=dev) if pos is not None else None
     pk.delta_b = torch.empty(max(lib.dgdm_attn_pack_bytes(nb, H, 3) // 4, 4), dtype=torch.float32, device=dev) if O is not None else None
-    _lib.check(lib.dgdm_attn_pack(x.data_ptr(), x.stride(0), col0, cstride, ntensors, scale0, plan.ptr_dev.data_ptr(), plan.B, nb, H,
+    _lib.check(lib.dgdm_attn_pack(x.data_ptr(), x.stride(0), col0, cstride, ntensors, scale0, _lib.ptr(scale_dev),
+                                  plan.ptr_dev.data_ptr(), plan.B, nb, H,
                                   pk.R.data_ptr(), pk.T.data_ptr(), _lib.ptr(pos), _lib.ptr(pk.pos_b), _lib.ptr(O),
                                   O.stride(0) if O is not None else 0, _lib.ptr(pk.delta_b), _lib.stream_ptr(dev)), "dgdm_attn_pack")
     return pk
@@ -218,17 +220,22 @@ def spatial_attn_h_bwd_raw(pk: PackedOperands, out, gout, plan: AttnPlan, H: int
     lib = _lib.load()
     C = H * 16
     gout = _f32c(gout)
-    gk = attn_pack(gout, 0, C, 1, 1.0, plan, H, O=out)
     st = _lib.stream_ptr(out.device)
+    # fp16 range guard (device side): dO is packed as alpha*dO, results are multiplied by 1/alpha
+    gs = torch.empty(2, dtype=torch.float32, device=out.device)
+    wsb = lib.dgdm_amax_scale_workspace_bytes()
+    ws = torch.empty(wsb // 4, dtype=torch.float32, device=out.device)
+    _lib.check(lib.dgdm_amax_pow2_scale(gout.data_ptr(), gout.numel(), 256.0, gs.data_ptr(), ws.data_ptr(), wsb, st), "dgdm_amax_pow2_scale")
+    gk = attn_pack(gout, 0, C, 1, 1.0, plan, H, O=out, scale_dev=gs)
     TIMERS.timed("attn_bwd_dq", lambda: _lib.check(
         lib.dgdm_spatial_attn_h_bwd_dq(pk.r(0).data_ptr(), pk.r(1).data_ptr(), pk.r(2).data_ptr(), pk.t(1).data_ptr(), gk.r(0).data_ptr(),
                                        pk.pos_b.data_ptr(), lse2_b.data_ptr(), gk.delta_b.data_ptr(), plan.ptr_dev.data_ptr(), plan.B,
-                                       plan.num_q_tiles, H, scale, inv_tau, drop_p, seed, dqkv[:, :C].data_ptr(), dqkv.stride(0), st),
+                                       plan.num_q_tiles, H, scale, inv_tau, drop_p, seed, gs.data_ptr(), dqkv[:, :C].data_ptr(), dqkv.stride(0), st),
         "dgdm_spatial_attn_h_bwd_dq"))
     TIMERS.timed("attn_bwd_dkv", lambda: _lib.check(
         lib.dgdm_spatial_attn_h_bwd_dkv(pk.r(0).data_ptr(), pk.t(0).data_ptr(), pk.r(1).data_ptr(), pk.r(2).data_ptr(), gk.r(0).data_ptr(),
                                         gk.t(0).data_ptr(), pk.pos_b.data_ptr(), lse2_b.data_ptr(), gk.delta_b.data_ptr(),
-                                        plan.ptr_dev.data_ptr(), plan.B, plan.num_q_tiles, H, inv_tau, drop_p, seed,
+                                        plan.ptr_dev.data_ptr(), plan.B, plan.num_q_tiles, H, inv_tau, drop_p, seed, gs.data_ptr(),
                                         dqkv[:, C:2 * C].data_ptr(), dqkv[:, 2 * C:].data_ptr(), dqkv.stride(0), st),
         "dgdm_spatial_attn_h_bwd_dkv"))
     return dqkv

@@ -159,12 +159,19 @@ DGDM_API int dgdm_spatial_attn_mean_weights(const float* Q, const float* K, int6
  * dgdm_attn_pack_bytes(num_blocks, H, which): buffer sizes (which: 0 R, 1 T, 2 positions
  * [blk][64][2] fp32, 3 per-row scalars [blk][H][64] fp32).
  * dgdm_attn_pack: tensor z (z < ntensors) = columns [col0 + z*cstride, +H*16) of X [N_tot, *]; tensor 0
- * is scaled by scale0 (Q: log2(e)/sqrt(d)); R/T hold ntensors images back to back.  pos/pos_b
+ * is scaled by scale0 (Q: log2(e)/sqrt(d)) times *scale_dev (nullable device scalar); R/T hold ntensors images back to back.  pos/pos_b
  * (nullable pair): block-aligned key/query positions.  O/delta_b (nullable pair): delta =
  * rowsum(X_0 * O) for the backward (X_0 = dO). */
 DGDM_API size_t dgdm_attn_pack_bytes(int32_t num_blocks, int32_t H, int32_t which);
+/* fp16 range guard: out2 = {alpha, 1/alpha}, alpha = 2^k with alpha*max|x| in (target/2, target] (x: n
+ * contiguous floats, n % 4 == 0).  The backward is linear in dO, so dO is packed as alpha*dO (scale_dev =
+ * out2) and the kernels multiply their results by out2[1]: gradients of 1e-6 would otherwise sit below
+ * fp16's normal range.  Device-side only, no host round trip. */
+DGDM_API size_t dgdm_amax_scale_workspace_bytes(void);
+DGDM_API int dgdm_amax_pow2_scale(const float* x, int64_t n, float target, float* out2, void* workspace, size_t workspace_bytes,
+                                  void* stream);
 DGDM_API int dgdm_attn_pack(const float* X, int64_t ld, int32_t col0, int32_t cstride, int32_t ntensors, float scale0,
-                            const int32_t* ptr, int32_t B, int32_t num_blocks, int32_t H, void* R, void* T, const float* pos,
+                            const float* scale_dev, const int32_t* ptr, int32_t B, int32_t num_blocks, int32_t H, void* R, void* T, const float* pos,
                             float* pos_b, const float* O, int64_t ldo, float* delta_b, void* stream);
 /* forward: Rq = row image of Q', Rk = row image of K, Tv = transposed image of V; O [N_tot, H*16]
  * fp32 (row stride ldo); lse2_b [blk][H][64] (log2-domain log-sum-exp, block layout). */
@@ -173,15 +180,16 @@ DGDM_API int dgdm_spatial_attn_h_fwd(const void* Rq, const void* Rk, const void*
                                      int64_t ldo, float* lse2_b, void* stream);
 /* backward: Rg/Tg = images of dO and delta_b = rowsum(dO*O) from a second dgdm_attn_pack call
  * (ntensors = 1, scale0 = 1, O given); lse2_b from the forward.  dQ/dK/dV fp32 [N_tot, H*16], row
- * stride ldg.  Same drop_p/seed as the forward.  Two launches, no atomics. */
+ * stride ldg.  Same drop_p/seed as the forward.  grad_scale2 = the {alpha, 1/alpha} pair dO was packed
+ * with (dgdm_amax_pow2_scale).  Two launches, no atomics. */
 DGDM_API int dgdm_spatial_attn_h_bwd_dq(const void* Rq, const void* Rk, const void* Rv, const void* Tk, const void* Rg,
                                         const float* pos_b, const float* lse2_b, const float* delta_b, const int32_t* ptr, int32_t B,
                                         int32_t num_blocks, int32_t H, float scale, float inv_tau, float drop_p, uint32_t seed,
-                                        float* dQ, int64_t ldg, void* stream);
+                                        const float* grad_scale2, float* dQ, int64_t ldg, void* stream);
 DGDM_API int dgdm_spatial_attn_h_bwd_dkv(const void* Rq, const void* Tq, const void* Rk, const void* Rv, const void* Rg,
                                          const void* Tg, const float* pos_b, const float* lse2_b, const float* delta_b,
                                          const int32_t* ptr, int32_t B, int32_t num_blocks, int32_t H, float inv_tau, float drop_p,
-                                         uint32_t seed, float* dK, float* dV, int64_t ldg, void* stream);
+                                         uint32_t seed, const float* grad_scale2, float* dK, float* dV, int64_t ldg, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K5  out = x + sinusoidal_2d_posenc(pos)  for a whole batch.  Replaces

@@ -186,14 +186,17 @@ def test_attn_split_fp16_forward_matches_dense(ptr, H, scale):
     assert_close(ops.unblock_rows(lse2_b, plan, H) * math.log(2.0), rl, 3e-4, "lse")
 
 
-@pytest.mark.parametrize("ptr,H", [([0, 17], 8), ([0, 65, 130, 131], 8), ([0, 200, 263], 2), ([0, 100], 1), ([0, 333, 1000], 8),
-                                    ([0, 129, 500], 16)])
-def test_attn_split_fp16_backward_matches_dense(ptr, H):
+@pytest.mark.parametrize("ptr,H,gscale", [([0, 17], 8, 1.0), ([0, 65, 130, 131], 8, 1.0), ([0, 200, 263], 2, 1.0), ([0, 100], 1, 1.0),
+                                           ([0, 333, 1000], 8, 1.0), ([0, 129, 500], 16, 1.0), ([0, 333, 1000], 8, 1e-7),
+                                           ([0, 333, 1000], 8, 3e4)])
+def test_attn_split_fp16_backward_matches_dense(ptr, H, gscale):
+    """gscale: incoming gradients far below / above fp16's range (1e-7, 3e4) exercise the device-side
+    power-of-two scaling of dO."""
     from dgdm_histopath_lab_amd import ops
     qkv, pos = make(ptr, H, 7 * sum(ptr) + H)
     C = H * 16
     g = torch.Generator().manual_seed(2)
-    gout = torch.randn(ptr[-1], C, generator=g)
+    gout = torch.randn(ptr[-1], C, generator=g) * gscale
     d = qkv.to(DEV).requires_grad_(True)
     plan = ops.AttnPlan(ptr, DEV)
     o = ops._SpatialAttentionH.apply(d, pos.to(DEV), plan, H, 0.25, 1.0, 0.0, 0)
