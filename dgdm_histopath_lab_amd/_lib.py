@@ -60,9 +60,9 @@ SIGNATURES = {
     "dgdm_attn_pack": (C.c_int, [_p, _i64, _i32, _i32, _i32, C.c_float, _p, _p, _i32, _i32, _i32, _p, _p, _p, _p, _p, _i64, _p, _p]),
     "dgdm_spatial_attn_h_fwd": (C.c_int, [_p, _p, _p, _p, _p, _i32, _i32, _i32, C.c_float, C.c_float, C.c_uint32, _p, _i64, _p, _p]),
     "dgdm_spatial_attn_h_bwd_dq": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, C.c_float, C.c_float, C.c_float,
-                                             C.c_uint32, _p, _p, _i64, _p]),
+                                             C.c_uint32, _p, _p, _i64, _i32, _p]),
     "dgdm_spatial_attn_h_bwd_dkv": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, C.c_float, C.c_float,
-                                              C.c_uint32, _p, _p, _p, _i64, _p]),
+                                              C.c_uint32, _p, _p, _p, _i64, _i32, _p]),
     "dgdm_spmm": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _p, _i64, _i32, _i32, _p, _i32, _p]),
 }
 

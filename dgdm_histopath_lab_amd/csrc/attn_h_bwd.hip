@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void k_attn_h_bwd_dkv(const _Float16* __restri
 extern "C" int dgdm_spatial_attn_h_bwd_dq(const void* Rq, const void* Rk, const void* Rv, const void* Tk, const void* Rg,
                                           const float* pos_b, const float* lse2_b, const float* delta_b, const int32_t* ptr, int32_t B,
                                           int32_t num_blocks, int32_t H, float scale, float inv_tau, float drop_p, uint32_t seed,
-                                          const float* grad_scale2, float* dQ, int64_t ldg, void* stream_) {
+                                          const float* grad_scale2, float* dQ, int64_t ldg, int32_t variant, void* stream_) {
   DGDM_REQUIRE(B >= 0 && H > 0 && num_blocks >= 0 && drop_p >= 0.f && drop_p < 1.f);
   if (num_blocks == 0 || B == 0) return DGDM_OK;
   DGDM_REQUIRE(Rq && Rk && Rv && Tk && Rg && pos_b && lse2_b && delta_b && ptr && dQ && grad_scale2);
@@ -290,7 +290,10 @@ extern "C" int dgdm_spatial_attn_h_bwd_dq(const void* Rq, const void* Rk, const 
       hipLaunchKernelGGL((k_attn_h_bwd_dq<HG, NBUF, false>), dim3(num_blocks, H / HG), dim3(256), 0, s, h16(Rq), h16(Rk),        \
                          h16(Rv), h16(Tk), h16(Rg), pos_b, lse2_b, delta_b, H, ptr, B, bscale, scale, grad_scale2, dQ, ldg, 0.f, 0u);         \
   } while (0)
-  if (H % 4 == 0) GO(4, 1);
+  if (H % 2 == 0 && variant == 1) GO(2, 2);
+  else if (H % 4 == 0 && variant == 2) GO(4, 2);
+  else if (H % 2 == 0 && variant == 3) GO(2, 1);
+  else if (H % 4 == 0) GO(4, 1);
   else if (H % 2 == 0) GO(2, 2);
   else GO(1, 2);
 #undef GO
@@ -300,7 +303,8 @@ extern "C" int dgdm_spatial_attn_h_bwd_dq(const void* Rq, const void* Rk, const 
 extern "C" int dgdm_spatial_attn_h_bwd_dkv(const void* Rq, const void* Tq, const void* Rk, const void* Rv, const void* Rg,
                                            const void* Tg, const float* pos_b, const float* lse2_b, const float* delta_b,
                                            const int32_t* ptr, int32_t B, int32_t num_blocks, int32_t H, float inv_tau, float drop_p,
-                                           uint32_t seed, const float* grad_scale2, float* dK, float* dV, int64_t ldg, void* stream_) {
+                                           uint32_t seed, const float* grad_scale2, float* dK, float* dV, int64_t ldg, int32_t variant,
+                                           void* stream_) {
   DGDM_REQUIRE(B >= 0 && H > 0 && num_blocks >= 0 && drop_p >= 0.f && drop_p < 1.f);
   if (num_blocks == 0 || B == 0) return DGDM_OK;
   DGDM_REQUIRE(Rq && Tq && Rk && Rv && Rg && Tg && pos_b && lse2_b && delta_b && ptr && dK && dV && grad_scale2);
@@ -318,7 +322,10 @@ extern "C" int dgdm_spatial_attn_h_bwd_dkv(const void* Rq, const void* Tq, const
       hipLaunchKernelGGL((k_attn_h_bwd_dkv<HG, NBUF, false>), dim3(num_blocks, H / HG), dim3(256), 0, s, h16(Rq), h16(Tq), h16(Rk), \
                          h16(Rv), h16(Rg), h16(Tg), pos_b, lse2_b, delta_b, H, ptr, B, bscale, kscale, grad_scale2, dK, dV, ldg, 0.f, 0u);      \
   } while (0)
-  if (H % 4 == 0) GO(4, 1);
+  if (H % 2 == 0 && variant == 1) GO(2, 2);
+  else if (H % 4 == 0 && variant == 2) GO(4, 2);
+  else if (H % 2 == 0 && variant == 3) GO(2, 1);
+  else if (H % 4 == 0) GO(4, 1);
   else if (H % 2 == 0) GO(2, 2);
   else GO(1, 2);
 #undef GO

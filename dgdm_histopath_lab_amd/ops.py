@@ -215,7 +215,7 @@ def spatial_attn_h_fwd_raw(qkv, pos, plan: AttnPlan, H: int, scale: float, inv_t
 
 
 def spatial_attn_h_bwd_raw(pk: PackedOperands, out, gout, plan: AttnPlan, H: int, scale: float, inv_tau: float, lse2_b, dqkv,
-                           drop_p: float = 0.0, seed: int = 0):
+                           drop_p: float = 0.0, seed: int = 0, dq_variant: int = 0, dkv_variant: int = 0):
     """Split-fp16 backward: packs dO (+ delta), then the dQ pass and the dK/dV pass."""
     lib = _lib.load()
     C = H * 16
@@ -230,13 +230,13 @@ def spatial_attn_h_bwd_raw(pk: PackedOperands, out, gout, plan: AttnPlan, H: int
     TIMERS.timed("attn_bwd_dq", lambda: _lib.check(
         lib.dgdm_spatial_attn_h_bwd_dq(pk.r(0).data_ptr(), pk.r(1).data_ptr(), pk.r(2).data_ptr(), pk.t(1).data_ptr(), gk.r(0).data_ptr(),
                                        pk.pos_b.data_ptr(), lse2_b.data_ptr(), gk.delta_b.data_ptr(), plan.ptr_dev.data_ptr(), plan.B,
-                                       plan.num_q_tiles, H, scale, inv_tau, drop_p, seed, gs.data_ptr(), dqkv[:, :C].data_ptr(), dqkv.stride(0), st),
+                                       plan.num_q_tiles, H, scale, inv_tau, drop_p, seed, gs.data_ptr(), dqkv[:, :C].data_ptr(), dqkv.stride(0), dq_variant, st),
         "dgdm_spatial_attn_h_bwd_dq"))
     TIMERS.timed("attn_bwd_dkv", lambda: _lib.check(
         lib.dgdm_spatial_attn_h_bwd_dkv(pk.r(0).data_ptr(), pk.t(0).data_ptr(), pk.r(1).data_ptr(), pk.r(2).data_ptr(), gk.r(0).data_ptr(),
                                         gk.t(0).data_ptr(), pk.pos_b.data_ptr(), lse2_b.data_ptr(), gk.delta_b.data_ptr(),
                                         plan.ptr_dev.data_ptr(), plan.B, plan.num_q_tiles, H, inv_tau, drop_p, seed, gs.data_ptr(),
-                                        dqkv[:, C:2 * C].data_ptr(), dqkv[:, 2 * C:].data_ptr(), dqkv.stride(0), st),
+                                        dqkv[:, C:2 * C].data_ptr(), dqkv[:, 2 * C:].data_ptr(), dqkv.stride(0), dkv_variant, st),
         "dgdm_spatial_attn_h_bwd_dkv"))
     return dqkv
 

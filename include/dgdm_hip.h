@@ -181,15 +181,16 @@ DGDM_API int dgdm_spatial_attn_h_fwd(const void* Rq, const void* Rk, const void*
 /* backward: Rg/Tg = images of dO and delta_b = rowsum(dO*O) from a second dgdm_attn_pack call
  * (ntensors = 1, scale0 = 1, O given); lse2_b from the forward.  dQ/dK/dV fp32 [N_tot, H*16], row
  * stride ldg.  Same drop_p/seed as the forward.  grad_scale2 = the {alpha, 1/alpha} pair dO was packed
- * with (dgdm_amax_pow2_scale).  Two launches, no atomics. */
+ * with (dgdm_amax_pow2_scale).  variant: tiling selector (0 = default).  Two launches, no atomics. */
 DGDM_API int dgdm_spatial_attn_h_bwd_dq(const void* Rq, const void* Rk, const void* Rv, const void* Tk, const void* Rg,
                                         const float* pos_b, const float* lse2_b, const float* delta_b, const int32_t* ptr, int32_t B,
                                         int32_t num_blocks, int32_t H, float scale, float inv_tau, float drop_p, uint32_t seed,
-                                        const float* grad_scale2, float* dQ, int64_t ldg, void* stream);
+                                        const float* grad_scale2, float* dQ, int64_t ldg, int32_t variant, void* stream);
 DGDM_API int dgdm_spatial_attn_h_bwd_dkv(const void* Rq, const void* Tq, const void* Rk, const void* Rv, const void* Rg,
                                          const void* Tg, const float* pos_b, const float* lse2_b, const float* delta_b,
                                          const int32_t* ptr, int32_t B, int32_t num_blocks, int32_t H, float inv_tau, float drop_p,
-                                         uint32_t seed, const float* grad_scale2, float* dK, float* dV, int64_t ldg, void* stream);
+                                         uint32_t seed, const float* grad_scale2, float* dK, float* dV, int64_t ldg, int32_t variant,
+                                         void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K5  out = x + sinusoidal_2d_posenc(pos)  for a whole batch.  Replaces

@@ -33,13 +33,15 @@ for p in (0.0, 0.1):
     if os.environ.get("FWD_ONLY"): continue
     outh, lse2_b, pk = ops.spatial_attn_h_fwd_raw(qkv, pos, plan, H, 0.25, 1.0, p, 123, packed)
     dq2 = torch.empty_like(qkv)
-    ops.TIMERS.start()
-    for _ in range(6):
-        ops.spatial_attn_h_bwd_raw(pk, outh, gout, plan, H, 0.25, 1.0, lse2_b, dq2, p, 123)
-    torch.cuda.synchronize(); ops.TIMERS.stop()
-    for k, (cnt, ms) in ops.TIMERS.summary().items():
-        prod = 3 if k.endswith("dq") else 4
-        print(json.dumps(dict(kernel=k + " split-fp16", drop=p, ms=round(ms, 3), TF=round(prod * fl / ms / 1e9, 1))))
+    for var in (0, 1, 2, 3):
+        ops.TIMERS.start()
+        for _ in range(6):
+            ops.spatial_attn_h_bwd_raw(pk, outh, gout, plan, H, 0.25, 1.0, lse2_b, dq2, p, 123, var, var)
+        torch.cuda.synchronize(); ops.TIMERS.stop()
+        for k, (cnt, ms) in ops.TIMERS.summary().items():
+            prod = 3 if k.endswith("dq") else 4
+            print(json.dumps(dict(kernel=k + " split-fp16", variant=var, drop=p, ms=round(ms, 3), TF=round(prod * fl / ms / 1e9, 1))))
+    if os.environ.get("SPLIT_ONLY"): continue
     out, lse2 = ops.spatial_attn_fwd_raw(qkv[:, :C], qkv[:, C:2*C], qkv[:, 2*C:], pos, plan, H, 0.25, 1.0, 0, p, 123)
     dqkv = torch.empty_like(qkv)
     ops.TIMERS.start()
