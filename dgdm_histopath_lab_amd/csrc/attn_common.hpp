@@ -76,8 +76,12 @@ __device__ __forceinline__ float group_sum4(float v) {
 // The backward kernels regenerate exactly the forward's mask from (seed, indices).
 // hq = head_seed ^ (qp * 0x9E3779B1): the part that does not depend on the key (hoisted by callers)
 __device__ __forceinline__ uint32_t attn_hash_hq(uint32_t hq, uint32_t k) {
+  // one multiply round: the inputs are already spread by odd-constant multiplies (q>>1, k, head, graph,
+  // seed); the 32-bit v_mul_lo_u32 is quarter rate on gfx950, and on the fp16 path the kernels are
+  // VALU-bound, so a second round would cost ~10 % of the kernel for no visible gain in mask quality
+  // (rate, per-head / per-row / adjacent-key independence are checked in tests/test_hip_attention.py).
   uint32_t x = hq ^ (k * 0x85EBCA6BU);
-  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  x ^= x >> 15; x *= 0x2c1b3c6dU; x ^= x >> 13;
   return x;
 }
 __device__ __forceinline__ uint32_t attn_hash(uint32_t hs, uint32_t qp, uint32_t k) {

@@ -322,11 +322,10 @@ extern "C" int dgdm_spatial_attn_h_bwd_dkv(const void* Rq, const void* Tq, const
       hipLaunchKernelGGL((k_attn_h_bwd_dkv<HG, NBUF, false>), dim3(num_blocks, H / HG), dim3(256), 0, s, h16(Rq), h16(Tq), h16(Rk), \
                          h16(Rv), h16(Rg), h16(Tg), pos_b, lse2_b, delta_b, H, ptr, B, bscale, kscale, grad_scale2, dK, dV, ldg, 0.f, 0u);      \
   } while (0)
-  if (H % 2 == 0 && variant == 1) GO(2, 2);
+  if (H % 4 == 0 && variant == 1) GO(4, 1);
   else if (H % 4 == 0 && variant == 2) GO(4, 2);
   else if (H % 2 == 0 && variant == 3) GO(2, 1);
-  else if (H % 4 == 0) GO(4, 1);
-  else if (H % 2 == 0) GO(2, 2);
+  else if (H % 2 == 0) GO(2, 2);   // default: 2 heads per group, double-buffered (lowest register pressure)
   else GO(1, 2);
 #undef GO
   return dgdm_launch_status();

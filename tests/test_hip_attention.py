@@ -142,6 +142,12 @@ def test_attn_dropout_mask_consistent_between_forward_and_both_backward_kernels(
     assert abs(rate - p) < 0.02, rate
     assert abs(isdrop[0][inside[0]].double().mean() - isdrop[1][inside[1]].double().mean()) < 0.03  # heads draw differently
     assert not torch.equal(isdrop[0], isdrop[1])
+    # no structure along keys / queries: drops of adjacent keys (and adjacent queries) are uncorrelated
+    dk = isdrop[:, :37, :37].double()
+    for a, b in ((dk[:, :, :-1], dk[:, :, 1:]), (dk[:, :-1, :], dk[:, 1:, :])):
+        corr = ((a - a.mean()) * (b - b.mean())).mean() / (a.std() * b.std())
+        assert abs(corr) < 0.06, corr
+    assert (dk.mean(dim=1) - p).abs().max() < 0.25 and (dk.mean(dim=2) - p).abs().max() < 0.25
     Fm = torch.where(iskeep, torch.full_like(F, keep), torch.zeros_like(F))
     # now a normal run with random V: forward + both backward kernels against the masked dense formula
     g = torch.Generator().manual_seed(5)
