@@ -18,6 +18,7 @@
 // bitwise reproducible).  A virtual column of ones appended to X makes column K of the result the
 // bias gradient.
 #include "common.hpp"
+#include "colsum.hpp"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
@@ -30,10 +31,13 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
-// one 32-deep block: acc[mt][nt] += As[wave rows][k] * Bs[wave cols][k]
+// one 32-deep block: acc[mt][nt] += As[wave rows][k] * Bs[wave cols][k].
+// live_m / live_n (wave-uniform, 0..2): how many of the wave's two 32-row / 32-column sub-tiles
+// intersect the matrix; empty ones are skipped (ragged edges of small outputs).
 __device__ __forceinline__ void mma_block(const float* __restrict__ As, const float* __restrict__ Bs, int arow0, int brow0,
-                                          int lane, f32x16 (&acc)[2][2]) {
+                                          int lane, f32x16 (&acc)[2][2], int live_m = 2, int live_n = 2) {
   const int i = lane & 31, kh = lane >> 5;
+  if (live_m == 0 || live_n == 0) return;
 #pragma unroll
   for (int s = 0; s < BK / 8; ++s) {
     f32x4v a[2], b[2];
@@ -42,12 +46,22 @@ __device__ __forceinline__ void mma_block(const float* __restrict__ As, const fl
       a[t] = *reinterpret_cast<const f32x4v*>(&As[(arow0 + t * 32 + i) * LDT + 8 * s + 4 * kh]);
       b[t] = *reinterpret_cast<const f32x4v*>(&Bs[(brow0 + t * 32 + i) * LDT + 8 * s + 4 * kh]);
     }
+    if (live_m == 2 && live_n == 2) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
+      for (int e = 0; e < 4; ++e)
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = mfma32(a[mt][e], b[nt][e], acc[mt][nt]);
+          for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = mfma32(a[mt][e], b[nt][e], acc[mt][nt]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc[0][0] = mfma32(a[0][e], b[0][e], acc[0][0]);
+        if (live_n == 2) acc[0][1] = mfma32(a[0][e], b[1][e], acc[0][1]);
+        if (live_m == 2) acc[1][0] = mfma32(a[1][e], b[0][e], acc[1][0]);
+        if (live_m == 2 && live_n == 2) acc[1][1] = mfma32(a[1][e], b[1][e], acc[1][1]);
+      }
+    }
   }
 }
 
@@ -79,7 +93,7 @@ struct RowTile {  // 128 rows x 32 k, 1024 float4 -> 4 per thread
   }
 };
 // ---- a [32 k x 128 cols] tile whose global layout has the OUTPUT index contiguous (needs a
-// transpose into the [col][k] LDS image).  `ones_col` >= 0: that global column reads as 1.0.
+// transpose into the [col][k] LDS image).
 // Thread map: per iteration a wave covers 8 k-rows x 8 float4 columns (lane = kr_lo + 8*c4_lo), so
 // a global request is 8 rows x 128 B and the transposed ds_write_b32 of one component lands on
 // banks {kr} + {0,16}: 2-way, which ds_write_b32 absorbs (the 2-rows-x-32-columns map was 16-way).
@@ -90,9 +104,8 @@ struct ColTile {
     *c4 = (lane >> 3) + 8 * wave;
   }
   float4 v[4];
-  unsigned okbits;  // bit i: v[i] valid, bit 4+i: v[i].x is the virtual ones column
-  __device__ __forceinline__ void load(const float* __restrict__ P, int64_t ld, int k0, int K, int col0, int ncols, int tid,
-                                       int ones_col = -1) {
+  unsigned okbits;  // bit i: v[i] valid
+  __device__ __forceinline__ void load(const float* __restrict__ P, int64_t ld, int k0, int K, int col0, int ncols, int tid) {
     okbits = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -103,7 +116,6 @@ struct ColTile {
       const int kc = k < K ? k : K - 1, cc = col < ncols ? col : ncols - 4;
       v[i] = *reinterpret_cast<const float4*>(P + (int64_t)kc * ld + cc);
       okbits |= (k < K && col < ncols) ? (1u << i) : 0u;
-      okbits |= (col == ones_col && k < K) ? (16u << i) : 0u;   // the virtual ones column (bias gradient)
     }
   }
   __device__ __forceinline__ void store(float* __restrict__ S, int tid) const {
@@ -111,8 +123,8 @@ struct ColTile {
     for (int i = 0; i < 4; ++i) {
       int kr, c4;
       map(tid, i, &kr, &c4);
-      const bool ok = (okbits >> i) & 1u, one = (okbits >> (4 + i)) & 1u;
-      S[(4 * c4 + 0) * LDT + kr] = one ? 1.0f : (ok ? v[i].x : 0.f);
+      const bool ok = (okbits >> i) & 1u;
+      S[(4 * c4 + 0) * LDT + kr] = ok ? v[i].x : 0.f;
       S[(4 * c4 + 1) * LDT + kr] = ok ? v[i].y : 0.f;
       S[(4 * c4 + 2) * LDT + kr] = ok ? v[i].z : 0.f;
       S[(4 * c4 + 3) * LDT + kr] = ok ? v[i].w : 0.f;
@@ -180,9 +192,12 @@ __global__ __launch_bounds__(256, 2) void k_gemm_rows(const float* __restrict__ 
     }
 }
 
-// dW partial: tile (n0, k0) of [N x Kext], rows [mc*chunk, (mc+1)*chunk)
+// dW partial: tile (n0, kk0) of [N x K], rows [mc*chunk, (mc+1)*chunk).  Partial row of chunk mc:
+// [N*K dW elements | N bias sums (if with_bias)].  The k-tile-0 workgroups also sum dY over their
+// rows -- the dY tile is already in LDS as [n][m] -- so the bias gradient costs no extra pass over
+// dY and no extra MFMA tile.
 __global__ __launch_bounds__(256, 2) void k_gemm_tn_partial(const float* __restrict__ dY, int64_t ldy, const float* __restrict__ X,
-                                                            int64_t ldx, int M, int N, int K, int Kext, int chunk,
+                                                            int64_t ldx, int M, int N, int K, int chunk, int with_bias,
                                                             float* __restrict__ partial) {
   __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDT];
   float* Ys = smem;             // [n][m]
@@ -191,7 +206,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_partial(const float* __restr
   const int n0 = blockIdx.x * BM, kk0 = blockIdx.y * BN, mc = blockIdx.z;
   const int mbeg = mc * chunk, mend = min(M, mbeg + chunk);
   const int wr = wave >> 1, wc = wave & 1;
-  const int ones_col = Kext > K ? K : -1;
+  const int live_m = min(2, max(0, (N - (n0 + wr * 64) + 31) / 32)), live_n = min(2, max(0, (K - (kk0 + wc * 64) + 31) / 32));
+  const bool do_bias = with_bias && blockIdx.y == 0;
   f32x16 acc[2][2];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -199,9 +215,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_partial(const float* __restr
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  float bsum = 0.f;  // threads (2n, 2n+1): sum of dY[m, n0 + n] over the even / odd 16-m halves of every block
   ColTile ty, tx;
   ty.load(dY, ldy, mbeg, mend, n0, N, tid);
-  tx.load(X, ldx, mbeg, mend, kk0, K, tid, ones_col);
+  tx.load(X, ldx, mbeg, mend, kk0, K, tid);
   for (int m = mbeg; m < mend; m += BK) {
     __syncthreads();
     ty.store(Ys, tid);
@@ -209,43 +226,63 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_partial(const float* __restr
     __syncthreads();
     if (m + BK < mend) {
       ty.load(dY, ldy, m + BK, mend, n0, N, tid);
-      tx.load(X, ldx, m + BK, mend, kk0, K, tid, ones_col);
+      tx.load(X, ldx, m + BK, mend, kk0, K, tid);
     }
-    mma_block(Ys, Xs, wr * 64, wc * 64, lane, acc);
+    if (do_bias) {
+      const float* row = &Ys[(tid >> 1) * LDT + 16 * (tid & 1)];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(row + 4 * q);
+        bsum += (v.x + v.y) + (v.z + v.w);
+      }
+    }
+    mma_block(Ys, Xs, wr * 64, wc * 64, lane, acc, live_m, live_n);
   }
   const int j = lane & 31, hi = lane >> 5;
-  float* P = partial + (int64_t)mc * N * Kext;
+  const int64_t width = (int64_t)N * K + (with_bias ? N : 0);
+  float* P = partial + (int64_t)mc * width;
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
       const int col = kk0 + wc * 64 + nt * 32 + j;
-      if (col >= Kext) continue;
+      if (col >= K) continue;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = n0 + wr * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        if (row < N) P[(int64_t)row * Kext + col] = acc[mt][nt][r];
+        if (row < N) P[(int64_t)row * K + col] = acc[mt][nt][r];
       }
     }
-}
-
-// dW[n][k] = sum_c partial[c][n][k] (k < K), db[n] = sum_c partial[c][n][K]; chunk order fixed.
-__global__ __launch_bounds__(256) void k_gemm_tn_reduce(const float* __restrict__ partial, int nchunks, int N, int K, int Kext,
-                                                        float* __restrict__ dW, int64_t lddw, float* __restrict__ db) {
-  const int64_t total = (int64_t)N * Kext;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += stride) {
-    float s = 0.f;
-    for (int c = 0; c < nchunks; ++c) s += partial[(int64_t)c * total + i];
-    const int n = (int)(i / Kext), k = (int)(i % Kext);
-    if (k < K) dW[(int64_t)n * lddw + k] = s;
-    else if (db) db[n] = s;
+  if (do_bias) {
+    bsum += __shfl_xor(bsum, 1, 64);
+    const int n = n0 + (tid >> 1);
+    if ((tid & 1) == 0 && n < N) P[(int64_t)N * K + n] = bsum;
   }
 }
 
-int tn_chunk_rows(int M, int N, int Kext) {
+// dW[n][k] / db[n] = sum over slots of in[slot][n*K + k] / in[slot][N*K + n]; fixed order.
+__global__ __launch_bounds__(256) void k_gemm_tn_final(const float* __restrict__ in, int slots, int64_t width, int N, int K,
+                                                       float* __restrict__ dW, int64_t lddw, float* __restrict__ db) {
+  const int64_t col = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+  const int part = threadIdx.x >> 6;
+  float acc = 0.f;
+  if (col < width)
+    for (int s = part; s < slots; s += 4) acc += in[(int64_t)s * width + col];
+  __shared__ float sm[4][64];
+  sm[part][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (part == 0 && col < width) {
+    const float t = (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+    const int64_t nk = (int64_t)N * K;
+    if (col < nk) dW[(col / K) * lddw + col % K] = t; else db[col - nk] = t;
+  }
+}
+
+constexpr int TN_STAGE_SLOTS = 16;   // more than 32 chunks: first fold them into <= 16 partial sums
+
+int tn_chunk_rows(int M, int N, int K) {
   // enough workgroups to fill 256 CUs ~2x, chunks a multiple of BK rows, at most 256 chunks
-  const int tiles = ((N + BM - 1) / BM) * ((Kext + BN - 1) / BN);
+  const int tiles = ((N + BM - 1) / BM) * ((K + BN - 1) / BN);
   int want = (496 + tiles / 2) / tiles;   // ~2 workgroups per CU, all resident in one round
   if (want < 1) want = 1;
   if (want > 256) want = 256;
@@ -302,10 +339,10 @@ extern "C" int dgdm_gemm_nn(const float* A, int64_t lda, const float* W, int64_t
 
 extern "C" size_t dgdm_gemm_tn_workspace_bytes(int32_t M, int32_t N, int32_t K, int32_t with_bias) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
-  const int Kext = K + (with_bias ? 1 : 0);
-  const int chunk = tn_chunk_rows(M, N, Kext);
+  const int chunk = tn_chunk_rows(M, N, K);
   const int nchunks = (M + chunk - 1) / chunk;
-  return (size_t)nchunks * N * Kext * sizeof(float);
+  const size_t width = (size_t)N * K + (with_bias ? N : 0);
+  return (size_t)(nchunks + (nchunks > 32 ? TN_STAGE_SLOTS : 0)) * width * sizeof(float);
 }
 
 extern "C" int dgdm_gemm_tn(const float* dY, int64_t ldy, const float* X, int64_t ldx, float* dW, int64_t lddw, float* db, int32_t M,
@@ -322,16 +359,25 @@ extern "C" int dgdm_gemm_tn(const float* dY, int64_t ldy, const float* X, int64_
   if (!dY || !X || !workspace) return DGDM_ERR_INVALID_ARG;
   if ((ldy & 3) || (ldx & 3) || (N & 3) || (K & 3) || ldy < N || ldx < K || !dgdm_aligned16(dY) || !dgdm_aligned16(X))
     return DGDM_ERR_UNSUPPORTED;
-  const int Kext = K + (db ? 1 : 0);
-  const int chunk = tn_chunk_rows(M, N, Kext);
+  const int chunk = tn_chunk_rows(M, N, K);
   const int nchunks = (M + chunk - 1) / chunk;
-  if (workspace_bytes < (size_t)nchunks * N * Kext * sizeof(float)) return DGDM_ERR_WORKSPACE;
+  const int64_t width = (int64_t)N * K + (db ? N : 0);
+  if (width > 0x7fffffffLL) return DGDM_ERR_UNSUPPORTED;
+  const bool staged = nchunks > 32;
+  if (workspace_bytes < (size_t)(nchunks + (staged ? TN_STAGE_SLOTS : 0)) * width * sizeof(float)) return DGDM_ERR_WORKSPACE;
   float* partial = static_cast<float*>(workspace);
-  hipLaunchKernelGGL(k_gemm_tn_partial, dim3((N + BM - 1) / BM, (Kext + BN - 1) / BN, nchunks), dim3(256), 0, s, dY, ldy, X, ldx, M, N,
-                     K, Kext, chunk, partial);
-  const int64_t total = (int64_t)N * Kext;
-  int64_t blocks = (total + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(k_gemm_tn_reduce, dim3((unsigned)blocks), dim3(256), 0, s, partial, nchunks, N, K, Kext, dW, lddw, db);
+  hipLaunchKernelGGL(k_gemm_tn_partial, dim3((N + BM - 1) / BM, (K + BN - 1) / BN, nchunks), dim3(256), 0, s, dY, ldy, X, ldx, M, N, K,
+                     chunk, db ? 1 : 0, partial);
+  const float* fin = partial;
+  int slots = nchunks;
+  if (staged) {
+    float* stage = partial + (int64_t)nchunks * width;
+    const int64_t per = (nchunks + TN_STAGE_SLOTS - 1) / TN_STAGE_SLOTS;
+    slots = (int)((nchunks + per - 1) / per);
+    hipLaunchKernelGGL(k_colsum, dim3((unsigned)((width + 63) / 64), slots), dim3(256), 0, s, partial, (int64_t)nchunks, (int)width, per,
+                       stage, 0, (float*)nullptr);
+    fin = stage;
+  }
+  hipLaunchKernelGGL(k_gemm_tn_final, dim3((unsigned)((width + 63) / 64)), dim3(256), 0, s, fin, slots, width, N, K, dW, lddw, db);
   return dgdm_launch_status();
 }
