@@ -35,12 +35,23 @@ sys.path.insert(0, ROOT)
 NODES, EDGES, FEATS, PER_GPU_BATCH = 10000, 50000, 768, 4
 MODEL_CFG = dict(node_features=FEATS, hidden_dims=[512, 256, 128], num_diffusion_steps=10, attention_heads=8)
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md, dense fp32 matrix peak
+FP16_MFMA_PEAK_TFLOPS = 2516.6  # MI355X_MICROARCH.md, dense fp16 matrix peak
+PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")  # tools/pmc_traffic.py, separate --pmc passes
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md, HBM3E spec
 
 
 def attention_flops(num_graph_nodes, heads, head_dim, products):
     """2*N^2*H*d FLOP per QK^T-sized product, `products` of them per kernel."""
     return sum(2.0 * n * n * heads * head_dim * products for n in num_graph_nodes)
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (same command, same sizes), or None."""
+    try:
+        with open(PMC_TRAFFIC) as f:
+            return json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def gather_bytes(n, e, c):
@@ -66,7 +77,7 @@ def gather_microbench(dev, iters=200):
     by = gather_bytes(NODES, EDGES, FEATS)
     return {"kernel": "dgdm_spmm (k_spmm<64,3,4>)", "workload": f"{NODES} nodes x {FEATS} feat, {EDGES}+{NODES} entries",
             "bound": "hbm", "achieved": round(by / us / 1e3, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": round(by / us / 1e3 / HBM_PEAK_GBPS, 4), "traffic": None, "us_per_launch": round(us, 2),
+            "frac": round(by / us / 1e3 / HBM_PEAK_GBPS, 4), "traffic": pmc_traffic("k_spmm<64, 3, 4>"), "us_per_launch": round(us, 2),
             "algorithmic_bytes": by}
 
 
@@ -173,14 +184,25 @@ def main():
         heads, hd = MODEL_CFG["attention_heads"], 16
         flops = {"attn_fwd": attention_flops(sizes, heads, hd, 2), "attn_bwd_dq": attention_flops(sizes, heads, hd, 3),
                  "attn_bwd_dkv": attention_flops(sizes, heads, hd, 4)}
-        kernels = {"attn_fwd": "k_attn_fwd<4,64>", "attn_bwd_dq": "k_attn_bwd_dq<4,64>", "attn_bwd_dkv": "k_attn_bwd_dkv<4,32>"}
+        split = ops.ATTN_PRECISION == "fp16x2"
+        kernels = ({"attn_fwd": "k_attn_h_fwd<4,1>", "attn_bwd_dq": "k_attn_h_bwd_dq<4,1,1>", "attn_bwd_dkv": "k_attn_h_bwd_dkv<2,2,1>"}
+                   if split else {"attn_fwd": "k_attn_fwd<4,64>", "attn_bwd_dq": "k_attn_bwd_dq<4,64>", "attn_bwd_dkv": "k_attn_bwd_dkv<4,32>"})
         dom = max((k for k in flops if k in timers), key=lambda k: timers[k][1])
         ms = timers[dom][1]
         tf = flops[dom] / (ms * 1e-3) / 1e12
+        # `achieved`: algorithmic fp32 FLOP of the reference's products (2*N^2*H*d each) per second, priced against
+        # the dense fp32 matrix peak (the arithmetic type of the path).  The split-fp16 kernels issue every product
+        # as two v_mfma_f32_16x16x32_f16 on [hi|lo] operand pairs = 4x the algorithmic FLOP on the fp16 pipe;
+        # `issued_*` prices THAT against the fp16 peak.  Neither pipe is the limiter: the kernel is bound by the
+        # softmax/dropout VALU work per score (attention section).
         roofline = {"kernel": kernels[dom], "bound": "mfma", "achieved": round(tf, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(kernels[dom]),
                     "ms_per_launch": round(ms, 4), "launches_timed": timers[dom][0], "algorithmic_flop": flops[dom],
                     "other_kernels_ms": {k: round(v[1], 4) for k, v in timers.items() if k != dom}}
+        if split:
+            roofline.update({"mfma_dtype": "f16 hi+lo split, fp32 accumulate", "issued_flop": 4 * flops[dom],
+                             "issued_tflops": round(4 * tf, 1), "issued_frac_of_f16_peak": round(4 * tf / FP16_MFMA_PEAK_TFLOPS, 4),
+                             "limiter": "VALU (exp2, dropout hash, fp16 packing) -- see DESIGN.md"})
         result = {
             "metric": "slides/sec (DGDM fwd+bwd, 10k-node/768-feat graphs)", "value": round(world * args.batch * args.steps / dt, 3),
             "unit": "slides/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
