@@ -54,6 +54,10 @@ SIGNATURES = {
     "dgdm_gemm_nn": (C.c_int, [_p, _i64, _p, _i64, _p, _i64, _i32, _i32, _i32, _i32, _p]),
     "dgdm_gemm_tn_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
     "dgdm_gemm_tn": (C.c_int, [_p, _i64, _p, _i64, _p, _i64, _p, _i32, _i32, _i32, _p, _sz, _p]),
+    "dgdm_gemm_nt_bf16x3": (C.c_int, [_p, _i64, _p, _i64, _p, _p, _i64, _i32, _i32, _i32, _i32, _p]),
+    "dgdm_gemm_nn_bf16x3": (C.c_int, [_p, _i64, _p, _i64, _p, _i64, _i32, _i32, _i32, _i32, _p]),
+    "dgdm_gemm_tn_bf16x3_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
+    "dgdm_gemm_tn_bf16x3": (C.c_int, [_p, _i64, _p, _i64, _p, _i64, _p, _i32, _i32, _i32, _p, _sz, _p]),
     "dgdm_attn_pack_bytes": (_sz, [_i32, _i32, _i32]),
     "dgdm_amax_scale_workspace_bytes": (_sz, []),
     "dgdm_amax_pow2_scale": (C.c_int, [_p, _i64, C.c_float, _p, _p, _sz, _p]),

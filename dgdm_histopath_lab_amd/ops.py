@@ -596,20 +596,27 @@ def _rowmajor(t: torch.Tensor) -> torch.Tensor:
     return t.contiguous()
 
 
-def gemm_nt_raw(a, w, bias=None, out=None, accumulate=False):
+def _gemm_entry(lib, name: str, math: str):
+    if math not in ("fp32", "bf16x3"):
+        raise ValueError(f"GEMM math must be 'fp32' or 'bf16x3', got {math!r}")
+    return getattr(lib, name if math == "fp32" else name + "_bf16x3")
+
+
+def gemm_nt_raw(a, w, bias=None, out=None, accumulate=False, math="fp32"):
     lib = _lib.load()
     a, w = _rowmajor(a), _rowmajor(w)
     M, K = a.shape
     N = w.size(0)
     if out is None:
         out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    fn = _gemm_entry(lib, "dgdm_gemm_nt", math)
     TIMERS.timed("gemm_nt", lambda: _lib.check(
-        lib.dgdm_gemm_nt(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), _lib.ptr(bias), out.data_ptr(), out.stride(0), M, N, K,
-                         int(accumulate), _lib.stream_ptr(a.device)), "dgdm_gemm_nt"))
+        fn(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), _lib.ptr(bias), out.data_ptr(), out.stride(0), M, N, K,
+           int(accumulate), _lib.stream_ptr(a.device)), "dgdm_gemm_nt"))
     return out
 
 
-def gemm_nn_raw(a, w, out=None, accumulate=False):
+def gemm_nn_raw(a, w, out=None, accumulate=False, math="fp32"):
     """a [M,N] . w [N,K] -> [M,K]"""
     lib = _lib.load()
     a, w = _rowmajor(a), _rowmajor(w)
@@ -617,13 +624,14 @@ def gemm_nn_raw(a, w, out=None, accumulate=False):
     K = w.size(1)
     if out is None:
         out = torch.empty(M, K, dtype=torch.float32, device=a.device)
+    fn = _gemm_entry(lib, "dgdm_gemm_nn", math)
     TIMERS.timed("gemm_nn", lambda: _lib.check(
-        lib.dgdm_gemm_nn(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(), out.stride(0), M, N, K, int(accumulate),
-                         _lib.stream_ptr(a.device)), "dgdm_gemm_nn"))
+        fn(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(), out.stride(0), M, N, K, int(accumulate),
+           _lib.stream_ptr(a.device)), "dgdm_gemm_nn"))
     return out
 
 
-def gemm_tn_raw(dy, x, with_bias: bool):
+def gemm_tn_raw(dy, x, with_bias: bool, math="fp32"):
     """dW [N,K] = dy[M,N]^T x[M,K]; db [N] = colsum(dy) (fixed-order split-M reduction)."""
     lib = _lib.load()
     dy, x = _rowmajor(dy), _rowmajor(x)
@@ -631,21 +639,26 @@ def gemm_tn_raw(dy, x, with_bias: bool):
     K = x.size(1)
     dW = torch.empty(N, K, dtype=torch.float32, device=x.device)
     db = torch.empty(N, dtype=torch.float32, device=x.device) if with_bias else None
-    wsb = lib.dgdm_gemm_tn_workspace_bytes(M, N, K, int(with_bias))
+    fn = _gemm_entry(lib, "dgdm_gemm_tn", math)
+    wsb = (lib.dgdm_gemm_tn_workspace_bytes if math == "fp32" else lib.dgdm_gemm_tn_bf16x3_workspace_bytes)(M, N, K, int(with_bias))
     ws = torch.empty(max(wsb, 4) // 4, dtype=torch.float32, device=x.device)
     TIMERS.timed("gemm_tn", lambda: _lib.check(
-        lib.dgdm_gemm_tn(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), dW.data_ptr(), dW.stride(0), _lib.ptr(db), M, N, K,
-                         ws.data_ptr(), wsb, _lib.stream_ptr(x.device)), "dgdm_gemm_tn"))
+        fn(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), dW.data_ptr(), dW.stride(0), _lib.ptr(db), M, N, K,
+           ws.data_ptr(), wsb, _lib.stream_ptr(x.device)), "dgdm_gemm_tn"))
     return dW, db
 
 
-# Which implementation runs the forward (nt) and input-gradient (nn) contractions: "own" = the
-# fp32-MFMA kernels of csrc/gemm.hip, "lib" = hipBLASLt through torch (a plain library GEMM; on
-# MI355X its large-shape nt/nn kernels are currently 20-40 % faster than ours, see
-# tools/microbench_gemm.py).  The weight/bias gradient (tn) always uses our split-M kernel
-# (1.3-2.8x faster than library GEMM + separate column sum, and bitwise reproducible).
+# Which implementation runs the dense contractions (env DGDM_GEMM):
+#   "bf16x3" (default) csrc/gemm3.hip: exact three-way bf16 split of every fp32 operand, six bf16
+#            MFMAs per product, fp32 accumulate -- fp32-level accuracy at 2-2.5x the fp32 matrix rate;
+#   "own"    csrc/gemm.hip: fp32 MFMA for all three contractions;
+#   "lib"    hipBLASLt (through torch) for y and dx, csrc/gemm.hip's split-M kernel for dW/db.
+# The weight/bias gradient never goes to the library: its split-M kernel is 1.3-2.8x faster than a
+# library GEMM plus a separate column sum, and bitwise reproducible.
 import os as _os
-GEMM_FWD_BACKEND = _os.environ.get("DGDM_GEMM", "lib")
+GEMM_FWD_BACKEND = _os.environ.get("DGDM_GEMM", "bf16x3")
+if GEMM_FWD_BACKEND not in ("bf16x3", "own", "lib"):
+    raise ValueError(f"DGDM_GEMM must be bf16x3, own or lib, got {GEMM_FWD_BACKEND!r}")
 
 
 class _Linear(torch.autograd.Function):
@@ -653,26 +666,26 @@ class _Linear(torch.autograd.Function):
     def forward(ctx, x, w, b):
         ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
-        if GEMM_FWD_BACKEND == "own":
-            return gemm_nt_raw(x, w, b)
-        return torch.nn.functional.linear(x, w, b)
+        if GEMM_FWD_BACKEND == "lib":
+            return torch.nn.functional.linear(x, w, b)
+        return gemm_nt_raw(x, w, b, math="bf16x3" if GEMM_FWD_BACKEND == "bf16x3" else "fp32")
 
     @staticmethod
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
         gy = _rowmajor(gy)
+        math = "bf16x3" if GEMM_FWD_BACKEND == "bf16x3" else "fp32"
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = gemm_nn_raw(gy, w) if GEMM_FWD_BACKEND == "own" else gy @ w
+            dx = gy @ w if GEMM_FWD_BACKEND == "lib" else gemm_nn_raw(gy, w, math=math)
         dW = db = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            dW, db = gemm_tn_raw(gy, x, ctx.has_bias)
+            dW, db = gemm_tn_raw(gy, x, ctx.has_bias, math=math)
         return dx, dW, db
 
 
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """y = x @ weight^T + bias with our split-M kernel for dW/db (and, with DGDM_GEMM=own, our
-    MFMA kernels for y and dx).  Shapes the kernels are not built for (fewer than GEMM_MIN_ROWS rows,
+    """y = x @ weight^T + bias on the kernels DGDM_GEMM selects.  Shapes the kernels are not built for (fewer than GEMM_MIN_ROWS rows,
     K or N not a multiple of 4) go to the library GEMM -- still on the GPU."""
     if (x.dim() == 2 and x.is_cuda and x.size(0) >= GEMM_MIN_ROWS and x.size(1) % 4 == 0 and weight.size(0) % 4 == 0
             and x.dtype == torch.float32):

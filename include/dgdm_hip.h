@@ -272,6 +272,19 @@ DGDM_API size_t dgdm_gemm_tn_workspace_bytes(int32_t M, int32_t N, int32_t K, in
 DGDM_API int dgdm_gemm_tn(const float* dY, int64_t ldy, const float* X, int64_t ldx, float* dW, int64_t lddw, float* db, int32_t M,
                           int32_t N, int32_t K, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same three contractions on the 16-bit matrix pipe with fp32-level accuracy: every fp32 operand
+ * is split exactly into three bf16 values (x = h + m + l) on its way into LDS and a product is the
+ * six bf16 MFMAs whose terms are not below 2^-26 of it, accumulated in fp32 (csrc/gemm3.hip).
+ * Same arguments, constraints, determinism and error codes as the fp32-MFMA entry points above;
+ * results agree with them to fp32 rounding (a few 1e-7 relative to sum |a.b|).  2-2.5x faster. */
+DGDM_API int dgdm_gemm_nt_bf16x3(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* C, int64_t ldc,
+                                 int32_t M, int32_t N, int32_t K, int32_t accumulate, void* stream);
+DGDM_API int dgdm_gemm_nn_bf16x3(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc, int32_t M, int32_t N,
+                                 int32_t K, int32_t accumulate, void* stream);
+DGDM_API size_t dgdm_gemm_tn_bf16x3_workspace_bytes(int32_t M, int32_t N, int32_t K, int32_t with_bias);
+DGDM_API int dgdm_gemm_tn_bf16x3(const float* dY, int64_t ldy, const float* X, int64_t ldx, float* dW, int64_t lddw, float* db,
+                                 int32_t M, int32_t N, int32_t K, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

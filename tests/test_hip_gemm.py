@@ -1,4 +1,4 @@
-"""GPU parity of the fp32-MFMA GEMMs (K3) against float64 torch."""
+"""GPU parity of the GEMMs (K3: fp32 MFMA, and the exact bf16x3 split on the 16-bit pipe) against float64 torch."""
 import pytest
 import torch
 
@@ -8,28 +8,53 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
+MATHS = ["fp32", "bf16x3"]
+
+
+@pytest.mark.parametrize("math", MATHS)
 @pytest.mark.parametrize("m,k,n", [(1, 4, 4), (130, 36, 12), (1000, 768, 512), (4001, 544, 512), (2000, 160, 128), (777, 128, 384),
                                    (5000, 288, 256), (300, 40, 64), (129, 1024, 260), (40000, 128, 128)])
-def test_gemm_nt_nn_tn(m, k, n):
+def test_gemm_nt_nn_tn(m, k, n, math):
     from dgdm_histopath_lab_amd import ops
     g = torch.Generator().manual_seed(m + k + n)
     x = torch.randn(m, k, generator=g); w = torch.randn(n, k, generator=g) / k ** 0.5; b = torch.randn(n, generator=g)
     gy = torch.randn(m, n, generator=g)
     xd, wd, bd, gd = x.to(DEV), w.to(DEV), b.to(DEV), gy.to(DEV)
-    y = ops.gemm_nt_raw(xd, wd, bd)
+    y = ops.gemm_nt_raw(xd, wd, bd, math=math)
     assert_close(y, x.double() @ w.double().t() + b.double(), 1e-5, "nt")
-    y2 = ops.gemm_nt_raw(xd, wd, None, out=y.clone(), accumulate=True)
+    y2 = ops.gemm_nt_raw(xd, wd, None, out=y.clone(), accumulate=True, math=math)
     assert_close(y2, 2 * (x.double() @ w.double().t()) + b.double(), 1e-5, "nt accumulate")
-    dx = ops.gemm_nn_raw(gd, wd)
+    dx = ops.gemm_nn_raw(gd, wd, math=math)
     assert_close(dx, gy.double() @ w.double(), 1e-5, "nn")
-    dW, db = ops.gemm_tn_raw(gd, xd, True)
+    dW, db = ops.gemm_tn_raw(gd, xd, True, math=math)
     assert_close(dW, gy.double().t() @ x.double(), 1e-5, "tn dW")
     assert_close(db, gy.double().sum(0), 1e-5, "tn db")
-    dW2, db2 = ops.gemm_tn_raw(gd, xd, True)
+    dW2, db2 = ops.gemm_tn_raw(gd, xd, True, math=math)
     assert torch.equal(dW2, dW) and torch.equal(db2, db)    # fixed reduction order: bitwise reproducible
-    dW3, none = ops.gemm_tn_raw(gd, xd, False)
+    dW3, none = ops.gemm_tn_raw(gd, xd, False, math=math)
     assert none is None
     assert_close(dW3, gy.double().t() @ x.double(), 1e-5, "tn dW (no bias)")
+
+
+def test_bf16x3_matches_fp32_mfma_accuracy():
+    """The split GEMM's error against fp64 is of the size of the fp32-MFMA kernel's own (accumulation
+    rounding), also for operands spanning many binades and for gradient-sized (1e-6) values."""
+    from dgdm_histopath_lab_amd import ops
+    g = torch.Generator().manual_seed(5)
+    m, k, n = 4096, 768, 512
+    for scale_x, scale_g in [(1.0, 1.0), (1e3, 1e-6), (1e-4, 1e4)]:
+        x = (torch.randn(m, k, generator=g) * torch.exp2(torch.randint(-12, 12, (m, k), generator=g).float()) * scale_x).to(DEV)
+        w = (torch.randn(n, k, generator=g) / k ** 0.5).to(DEV)
+        gy = (torch.randn(m, n, generator=g) * scale_g).to(DEV)
+        ref_y = x.double() @ w.double().t()
+        ref_dx = gy.double() @ w.double()
+        ref_dw = gy.double().t() @ x.double()
+        err = {}
+        for math in MATHS:
+            y = ops.gemm_nt_raw(x, w, None, math=math); dx = ops.gemm_nn_raw(gy, w, math=math); dw, _ = ops.gemm_tn_raw(gy, x, False, math=math)
+            err[math] = [float((a.double() - r).abs().max() / r.abs().max()) for a, r in ((y, ref_y), (dx, ref_dx), (dw, ref_dw))]
+        for e3, e32 in zip(err["bf16x3"], err["fp32"]):
+            assert e3 < 2e-6 and e3 < 4 * e32 + 2e-7, (scale_x, scale_g, err)
 
 
 def test_gemm_strided_operands_and_autograd():

@@ -19,9 +19,10 @@ for (m, k, n) in shapes:
     x = torch.randn(m, k, device=dev); w = torch.randn(n, k, device=dev); b = torch.randn(n, device=dev); gy = torch.randn(m, n, device=dev)
     fl = 2.0 * m * k * n
     r = dict(M=m, K=k, N=n)
-    for name, ours, lib in (("nt", lambda: ops.gemm_nt_raw(x, w, b), lambda: torch.nn.functional.linear(x, w, b)),
-                            ("nn", lambda: ops.gemm_nn_raw(gy, w), lambda: gy @ w),
-                            ("tn", lambda: ops.gemm_tn_raw(gy, x, True), lambda: (gy.t() @ x, gy.sum(0)))):
-        a, l = t(ours), t(lib)
-        r[name] = f"{a:7.1f}us {fl/a/1e6:6.1f}TF | lib {l:7.1f}us {fl/l/1e6:6.1f}TF"
+    for name, ours, x3, lib in (
+            ("nt", lambda: ops.gemm_nt_raw(x, w, b), lambda: ops.gemm_nt_raw(x, w, b, math="bf16x3"), lambda: torch.nn.functional.linear(x, w, b)),
+            ("nn", lambda: ops.gemm_nn_raw(gy, w), lambda: ops.gemm_nn_raw(gy, w, math="bf16x3"), lambda: gy @ w),
+            ("tn", lambda: ops.gemm_tn_raw(gy, x, True), lambda: ops.gemm_tn_raw(gy, x, True, math="bf16x3"), lambda: (gy.t() @ x, gy.sum(0)))):
+        a, c, l = t(ours), t(x3), t(lib)
+        r[name] = f"fp32 {a:6.1f}us {fl/a/1e6:5.1f}TF | bf16x3 {c:6.1f}us {fl/c/1e6:5.1f}TF | lib {l:6.1f}us {fl/l/1e6:5.1f}TF"
     print(json.dumps(r))
