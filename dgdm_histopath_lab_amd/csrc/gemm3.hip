@@ -13,12 +13,16 @@
 // accumulation itself (tests/test_hip_gemm.py measures both against fp64).
 // 6 MFMAs at 16x the fp32 rate = 2.67x the fp32 matrix peak (419 TFLOP/s-equivalent).
 //
-// Tiling as gemm.hip: 128x128 output tile per 256-thread workgroup, 4 waves x (2x2) 32x32 tiles,
-// 32-deep k blocks, next block's global loads in registers under the current block's MFMAs.  The
-// split happens on the way from registers to LDS (v_cvt_pk_bf16_f32 + packed subtract: 4.5 VALU
-// per element, issued in the shadow of the other resident workgroup's MFMAs); the LDS image of an
-// operand is three planes [3][128 rows][32 k] of bf16 with 80-byte rows, which makes the
-// ds_read_b128 operand reads of all four lane groups conflict-free.
+// Tiling: 128x128 output tile per 256-thread workgroup, 4 waves x (2x2) 32x32 tiles.  The reduction
+// advances in 16-deep stages (one MFMA k step) through a double-buffered LDS image with ONE barrier
+// per stage: while a wave issues the 24 MFMAs of stage s from LDS[s & 1] it splits stage s+1 from
+// registers (v_cvt_pk_bf16_f32 + packed subtract, 4.5 VALU per element -- they issue in the 24 free
+// cycles of each 32-cycle MFMA) into LDS[(s+1) & 1], and the global loads of stage s+3 are in flight
+// in a third register set.  (A first version with one LDS buffer and a convert phase between two
+// barriers ran the two resident workgroups of a CU in lockstep: PMC showed the matrix pipe 39 % busy.)
+// LDS image of an operand stage: three planes [3][128 rows][16 k] of bf16 with 48-byte rows, which
+// makes the ds_read_b128 operand reads of all four lane groups conflict-free; 72 KiB per workgroup,
+// two workgroups per CU.
 // Non-finite inputs: Inf - Inf in the residual turns an Inf operand into NaN (the model rejects
 // non-finite features before any GEMM, models/dgdm_model.py:278-283 in the reference).
 #include "common.hpp"
@@ -31,10 +35,11 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 32;
-constexpr int RSB = 80;                 // bytes per LDS row: 32 bf16 + 16 B pad
-constexpr int PLANE = BM * RSB;         // bytes per plane (10240)
-constexpr int OPERAND = 3 * PLANE;      // bytes per operand image (30720)
+constexpr int BM = 128, BN = 128, KS = 16;   // KS = reduction depth of a stage
+constexpr int RSB = 48;                      // bytes per LDS row: 16 bf16 + 16 B pad
+constexpr int PLANE = BM * RSB;              // 6144
+constexpr int OPERAND = 3 * PLANE;           // 18432
+constexpr int STAGE = 2 * OPERAND;           // 36864 (A image, then B image)
 
 __device__ __forceinline__ f32x16 mfma_bf(bf16x8 a, bf16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
@@ -54,133 +59,225 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned* h, unsign
   *l = cvt_pk(ar - __uint_as_float(mm << 16), br - __uint_as_float(mm & 0xffff0000u));
 }
 
-// one 32-deep block: acc[mt][nt] += A(wave rows, k) . B(wave cols, k), six bf16 products per term
-__device__ __forceinline__ void mma_block3(const char* __restrict__ As, const char* __restrict__ Bs, int arow0, int brow0, int lane,
-                                           f32x16 (&acc)[2][2], int live_m = 2, int live_n = 2) {
-  if (live_m == 0 || live_n == 0) return;
-  const int i = lane & 31, kh = lane >> 5;
+// ---- one stage (16 k) of an operand whose global layout has the reduction index contiguous:
+// element (o, k) at P[(o0 + o) * ld + k], 128 output rows.  2 float4 per thread.
+struct RowStage {
+  float4 v[2];
+  unsigned ok;
+  template <bool BIAS>
+  __device__ __forceinline__ void store_one(char* __restrict__ S, int tid, int j, float (&)[4]) const {
+    const int r = (tid >> 2) + 64 * j, c4 = tid & 3;
+    const bool g = (ok >> j) & 1u;
+    uint2 h, m, l;
+    split_pair(g ? v[j].x : 0.f, g ? v[j].y : 0.f, &h.x, &m.x, &l.x);
+    split_pair(g ? v[j].z : 0.f, g ? v[j].w : 0.f, &h.y, &m.y, &l.y);
+    char* dst = S + r * RSB + 8 * c4;
+    *reinterpret_cast<uint2*>(dst) = h;
+    *reinterpret_cast<uint2*>(dst + PLANE) = m;
+    *reinterpret_cast<uint2*>(dst + 2 * PLANE) = l;
+  }
+};
+
+// ---- one stage of an operand whose global layout has the OUTPUT index contiguous: element (o, k) at
+// P[k * ld + o0 + o]; transposed into the [o][k] image.  A thread holds the two k rows of one k pair
+// for 4 output columns, so a column's pair packs into one dword: ds_write_b32 at [col][pair], banks
+// {pair} + {0,16} per 32-lane half = 2-way, which ds_write_b32 absorbs.
+struct ColStage {
+  float4 v[2];
+  unsigned ok;
+  // half: columns 2*half, 2*half + 1.  BIAS: also add the two (masked) values of each column to bs
+  // (sum over this thread's valid k rows: the bias gradient of the dW kernel).
+  template <bool BIAS>
+  __device__ __forceinline__ void store_one(char* __restrict__ S, int tid, int half, float (&bs)[4]) const {
+    const bool g0 = ok & 1u, g1 = (ok >> 1) & 1u;
+    const float a4[4] = {v[0].x, v[0].y, v[0].z, v[0].w}, b4[4] = {v[1].x, v[1].y, v[1].z, v[1].w};
 #pragma unroll
-  for (int s = 0; s < BK / 16; ++s) {
-    bf16x8 a[3][2], b[3][2];
+    for (int jj = 0; jj < 2; ++jj) {
+      const int j = 2 * half + jj;
+      unsigned h, m, l;
+      const float x0 = g0 ? a4[j] : 0.f, x1 = g1 ? b4[j] : 0.f;
+      if (BIAS) bs[j] += x0 + x1;
+      split_pair(x0, x1, &h, &m, &l);
+      char* dst = S + (4 * (tid >> 3) + j) * RSB + 4 * (tid & 7);
+      *reinterpret_cast<unsigned*>(dst) = h;
+      *reinterpret_cast<unsigned*>(dst + PLANE) = m;
+      *reinterpret_cast<unsigned*>(dst + 2 * PLANE) = l;
+    }
+  }
+};
+
+// Stage loaders: per-thread addresses are set up once and advanced by a constant per stage (the
+// straightforward index arithmetic costs ~10 VALU per load in 64-bit multiplies, and VALU slots are
+// what this kernel lives on).  Stages are loaded strictly in order.  Loads past the end of the
+// reduction range keep a valid address and are masked (ok = 0), so the main loop needs no branches.
+struct RowLoader {
+  const float* p[2];   // row base of this thread's two rows (clamped to the last valid row)
+  int k, kend;         // k of this thread's float4 in the next stage to load
+  unsigned rowok;
+  __device__ __forceinline__ void init(const float* __restrict__ P, int64_t ld, int o0, int on, int kbeg, int kend_, int /*klim*/, int tid) {
+    rowok = 0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = o0 + (tid >> 2) + 64 * j;
+      p[j] = P + (int64_t)(row < on ? row : on - 1) * ld;
+      rowok |= row < on ? (1u << j) : 0u;
+    }
+    k = kbeg + 4 * (tid & 3);
+    kend = kend_;
+  }
+  __device__ __forceinline__ void next(RowStage& R) {
+    const bool kin = k < kend;
+    const int kc = kin ? k : kend - 4;
+    R.v[0] = *reinterpret_cast<const float4*>(p[0] + kc);
+    R.v[1] = *reinterpret_cast<const float4*>(p[1] + kc);
+    R.ok = kin ? rowok : 0u;
+    k += KS;
+  }
+};
+
+struct ColLoader {
+  const float* p[2];   // address of this thread's float4 in k rows k, k+1 of the next stage (clamped below klim)
+  int k, kend, klim;   // klim: number of k rows that exist in memory (>= kend)
+  int64_t step;
+  bool colok;
+  __device__ __forceinline__ void init(const float* __restrict__ P, int64_t ld, int o0, int on, int kbeg, int kend_, int klim_, int tid) {
+    const int col = o0 + 4 * (tid >> 3);
+    colok = col < on;
+    k = kbeg + 2 * (tid & 7);
+    kend = kend_;
+    klim = klim_;
+    step = (int64_t)KS * ld;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) p[i] = P + (int64_t)(k + i < klim ? k + i : klim - 1) * ld + (colok ? col : on - 4);
+  }
+  __device__ __forceinline__ void next(ColStage& R) {
+    R.v[0] = *reinterpret_cast<const float4*>(p[0]);
+    R.v[1] = *reinterpret_cast<const float4*>(p[1]);
+    R.ok = colok ? ((k < kend ? 1u : 0u) | (k + 1 < kend ? 2u : 0u)) : 0u;
+    p[0] += (k + KS < klim) ? step : 0;       // stop advancing at the end of memory; those stages are masked anyway
+    p[1] += (k + 1 + KS < klim) ? step : 0;
+    k += KS;
+  }
+};
+
+template <bool KC> struct StageOf { typedef RowStage type; typedef RowLoader loader; };
+template <> struct StageOf<false> { typedef ColStage type; typedef ColLoader loader; };
+
+// operand fragments of one stage: planes h, m, l of the wave's two 32-row sub-tiles
+struct Frag {
+  bf16x8 f[3][2];
+  __device__ __forceinline__ void read(const char* __restrict__ img, int row0, int lane) {
 #pragma unroll
     for (int p = 0; p < 3; ++p)
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        a[p][t] = *reinterpret_cast<const bf16x8*>(As + p * PLANE + (arow0 + t * 32 + i) * RSB + 32 * s + 16 * kh);
-        b[p][t] = *reinterpret_cast<const bf16x8*>(Bs + p * PLANE + (brow0 + t * 32 + i) * RSB + 32 * s + 16 * kh);
-      }
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      if (mt >= live_m) continue;
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        if (nt >= live_n) continue;
-        f32x16 c = acc[mt][nt];
-        c = mfma_bf(a[1][mt], b[1][nt], c);   // smallest terms first
-        c = mfma_bf(a[0][mt], b[2][nt], c);
-        c = mfma_bf(a[2][mt], b[0][nt], c);
-        c = mfma_bf(a[0][mt], b[1][nt], c);
-        c = mfma_bf(a[1][mt], b[0][nt], c);
-        c = mfma_bf(a[0][mt], b[0][nt], c);
-        acc[mt][nt] = c;
-      }
-    }
+      for (int t = 0; t < 2; ++t)
+        f[p][t] = *reinterpret_cast<const bf16x8*>(img + p * PLANE + (row0 + t * 32 + (lane & 31)) * RSB + 16 * (lane >> 5));
   }
+};
+
+__device__ __forceinline__ f32x16 mma6(const Frag& a, const Frag& b, int mt, int nt, f32x16 c) {
+  c = mfma_bf(a.f[1][mt], b.f[1][nt], c);   // smallest terms first
+  c = mfma_bf(a.f[0][mt], b.f[2][nt], c);
+  c = mfma_bf(a.f[2][mt], b.f[0][nt], c);
+  c = mfma_bf(a.f[0][mt], b.f[1][nt], c);
+  c = mfma_bf(a.f[1][mt], b.f[0][nt], c);
+  c = mfma_bf(a.f[0][mt], b.f[0][nt], c);
+  return c;
 }
 
-// ---- a [128 rows x 32 k] tile whose global layout has the reduction index contiguous
-struct RowTile3 {
-  float4 v[4];
-  unsigned okbits;
-  __device__ __forceinline__ void load(const float* __restrict__ P, int64_t ld, int row0, int nrows, int k0, int K, int tid) {
-    okbits = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int idx = tid + 256 * i, r = idx >> 3, c4 = idx & 7;
-      const int row = row0 + r, k = k0 + 4 * c4;
-      const int rc = row < nrows ? row : nrows - 1, kc = k < K ? k : K - 4;   // clamped address, masked at store time
-      v[i] = *reinterpret_cast<const float4*>(P + (int64_t)rc * ld + kc);
-      okbits |= (row < nrows && k < K) ? (1u << i) : 0u;
-    }
-  }
-  __device__ __forceinline__ void store(char* __restrict__ S, int tid) const {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int idx = tid + 256 * i, r = idx >> 3, c4 = idx & 7;
-      const bool ok = (okbits >> i) & 1u;
-      const float x = ok ? v[i].x : 0.f, y = ok ? v[i].y : 0.f, z = ok ? v[i].z : 0.f, w = ok ? v[i].w : 0.f;
-      uint2 h, m, l;
-      split_pair(x, y, &h.x, &m.x, &l.x);
-      split_pair(z, w, &h.y, &m.y, &l.y);
-      char* dst = S + r * RSB + 8 * c4;
-      *reinterpret_cast<uint2*>(dst) = h;
-      *reinterpret_cast<uint2*>(dst + PLANE) = m;
-      *reinterpret_cast<uint2*>(dst + 2 * PLANE) = l;
-    }
-  }
-};
+// The reduction loop shared by the three contractions.
+//   acc[mt][nt] += sum over k in [kbeg, kend) of A(a0 + wave rows, k) * B(b0 + wave cols, k)
+// A_KC / B_KC: the operand's global layout has k contiguous (RowStage) or the output index (ColStage).
+// BIAS: also accumulate per-thread column sums of the A operand (ColStage only) into bs.
+template <bool A_KC, bool B_KC, bool BIAS>
+__device__ __forceinline__ void mainloop3(const float* __restrict__ A, int64_t lda, int a0, int an, const float* __restrict__ B,
+                                          int64_t ldb, int b0, int bn, int kbeg, int kend, int klim, char* __restrict__ smem,
+                                          f32x16 (&acc)[2][2], int live_m, int live_n, float (&bs)[4]) {
+  typedef typename StageOf<A_KC>::type SA;
+  typedef typename StageOf<B_KC>::type SB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int arow0 = (wave >> 1) * 64, brow0 = (wave & 1) * 64;
+  const int nst = (kend - kbeg + KS - 1) / KS;
+  const bool full = live_m == 2 && live_n == 2;
+  SA ra0, ra1, ra2;
+  SB rb0, rb1, rb2;
+  typename StageOf<A_KC>::loader la;
+  typename StageOf<B_KC>::loader lb;
+  la.init(A, lda, a0, an, kbeg, kend, klim, tid);
+  lb.init(B, ldb, b0, bn, kbeg, kend, klim, tid);
+  la.next(ra0); lb.next(rb0);
+  la.next(ra1); lb.next(rb1);
+  la.next(ra2); lb.next(rb2);
+  float unused[4];
+  ra0.template store_one<BIAS>(smem, tid, 0, bs); ra0.template store_one<BIAS>(smem, tid, 1, bs);
+  rb0.template store_one<false>(smem + OPERAND, tid, 0, unused); rb0.template store_one<false>(smem + OPERAND, tid, 1, unused);
+  __syncthreads();
 
-// ---- a [32 k x 128 cols] tile whose global layout has the OUTPUT index contiguous: transposed into
-// the [col][k] image.  A thread holds two pairs of adjacent k rows (i = 2q, 2q+1) of 4 columns, so a
-// column's two k values pack into one dword: ds_write_b32 at [col][k pair], banks {pair} + {0,16}
-// per 32-lane half = 2-way, which ds_write_b32 absorbs.
-struct ColTile3 {
-  __device__ static __forceinline__ void map(int tid, int i, int* kr, int* c4) {
-    const int lane = tid & 63, wave = tid >> 6;
-    *kr = 16 * (i >> 1) + 2 * (lane & 7) + (i & 1);
-    *c4 = (lane >> 3) + 8 * wave;
+  // Issue order of one stage.  A wave issues in order, and a wave stalled at an MFMA that waits for the
+  // matrix pipe cannot issue the VALU work behind it -- so the split is placed in the issue slots
+  // between consecutive MFMAs (each holds the port for 8 of the 32 pipe cycles): fragment reads
+  // and the global loads first, a block of VALU under the LDS latency, then MFMA : VALU : DS-write
+  // round robin.  Without this the compiler emits MFMA runs followed by VALU runs and the two
+  // workgroups of a CU fall into lockstep (both in their MFMA run, then both in their VALU run).
+#define DGDM_STAGE_SCHEDULE                                            \
+  __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);                  \
+  __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);                   \
+  __builtin_amdgcn_sched_group_barrier(0x002, 20, 0);                  \
+  _Pragma("unroll") for (int g__ = 0; g__ < 24; ++g__) {               \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                 \
+    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                 \
+    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                 \
   }
-  float4 v[4];
-  unsigned okbits;
-  __device__ __forceinline__ void load(const float* __restrict__ P, int64_t ld, int k0, int K, int col0, int ncols, int tid) {
-    okbits = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int kr, c4;
-      map(tid, i, &kr, &c4);
-      const int k = k0 + kr, col = col0 + 4 * c4;
-      const int kc = k < K ? k : K - 1, cc = col < ncols ? col : ncols - 4;
-      v[i] = *reinterpret_cast<const float4*>(P + (int64_t)kc * ld + cc);
-      okbits |= (k < K && col < ncols) ? (1u << i) : 0u;
-    }
+
+  // stage s: MFMAs from LDS[s & 1]; split set `cv` (stage s+1) into LDS[(s+1) & 1]; reload set `ld` with stage s+3
+#define DGDM_STAGE(s_, ld_a, ld_b, cv_a, cv_b)                                                     \
+  {                                                                                                \
+    const int s__ = (s_);                                                                          \
+    const char* cur = smem + (s__ & 1) * STAGE;                                                    \
+    char* nxt = smem + ((s__ & 1) ^ 1) * STAGE;                                                    \
+    la.next(ld_a);                                                                                 \
+    lb.next(ld_b);                                                                                 \
+    Frag fa, fb;                                                                                   \
+    fa.read(cur, arow0, lane);                                                                     \
+    fb.read(cur + OPERAND, brow0, lane);                                                           \
+    if (full) {                                                                                    \
+      acc[0][0] = mma6(fa, fb, 0, 0, acc[0][0]);                                                   \
+      cv_a.template store_one<BIAS>(nxt, tid, 0, bs);                                              \
+      acc[0][1] = mma6(fa, fb, 0, 1, acc[0][1]);                                                   \
+      cv_a.template store_one<BIAS>(nxt, tid, 1, bs);                                              \
+      acc[1][0] = mma6(fa, fb, 1, 0, acc[1][0]);                                                   \
+      cv_b.template store_one<false>(nxt + OPERAND, tid, 0, unused);                               \
+      acc[1][1] = mma6(fa, fb, 1, 1, acc[1][1]);                                                   \
+      cv_b.template store_one<false>(nxt + OPERAND, tid, 1, unused);                               \
+      DGDM_STAGE_SCHEDULE                                                                          \
+    } else {                                                                                       \
+      if (live_m > 0 && live_n > 0) acc[0][0] = mma6(fa, fb, 0, 0, acc[0][0]);                     \
+      if (live_m > 0 && live_n > 1) acc[0][1] = mma6(fa, fb, 0, 1, acc[0][1]);                     \
+      if (live_m > 1 && live_n > 0) acc[1][0] = mma6(fa, fb, 1, 0, acc[1][0]);                     \
+      if (live_m > 1 && live_n > 1) acc[1][1] = mma6(fa, fb, 1, 1, acc[1][1]);                     \
+      cv_a.template store_one<BIAS>(nxt, tid, 0, bs); cv_a.template store_one<BIAS>(nxt, tid, 1, bs);  \
+      cv_b.template store_one<false>(nxt + OPERAND, tid, 0, unused);                               \
+      cv_b.template store_one<false>(nxt + OPERAND, tid, 1, unused);                               \
+    }                                                                                              \
+    __syncthreads();                                                                               \
   }
-  // sum over this thread's valid k rows of each of its 4 columns (bias gradient of the dW kernel)
-  __device__ __forceinline__ void add_colsum(float (&s)[4]) const {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const bool ok = (okbits >> i) & 1u;
-      s[0] += ok ? v[i].x : 0.f; s[1] += ok ? v[i].y : 0.f; s[2] += ok ? v[i].z : 0.f; s[3] += ok ? v[i].w : 0.f;
-    }
+
+  for (int s = 0; s < nst; s += 3) {
+    DGDM_STAGE(s, ra0, rb0, ra1, rb1)
+    if (s + 1 >= nst) break;
+    DGDM_STAGE(s + 1, ra1, rb1, ra2, rb2)
+    if (s + 2 >= nst) break;
+    DGDM_STAGE(s + 2, ra2, rb2, ra0, rb0)
   }
-  __device__ __forceinline__ void store(char* __restrict__ S, int tid) const {
-    const int lane = tid & 63, wave = tid >> 6;
-    const int c4 = (lane >> 3) + 8 * wave;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const bool ok0 = (okbits >> (2 * q)) & 1u, ok1 = (okbits >> (2 * q + 1)) & 1u;
-      const float4 a = v[2 * q], b = v[2 * q + 1];
-      const float a4[4] = {a.x, a.y, a.z, a.w}, b4[4] = {b.x, b.y, b.z, b.w};
-      const int kpair = 8 * q + (lane & 7);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        unsigned h, m, l;
-        split_pair(ok0 ? a4[j] : 0.f, ok1 ? b4[j] : 0.f, &h, &m, &l);
-        char* dst = S + (4 * c4 + j) * RSB + 4 * kpair;
-        *reinterpret_cast<unsigned*>(dst) = h;
-        *reinterpret_cast<unsigned*>(dst + PLANE) = m;
-        *reinterpret_cast<unsigned*>(dst + 2 * PLANE) = l;
-      }
-    }
-  }
-};
+#undef DGDM_STAGE
+#undef DGDM_STAGE_SCHEDULE
+}
 
 template <bool B_KCONTIG, bool ACCUM>
 __global__ __launch_bounds__(256, 2) void k_gemm3_rows(const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
                                                        int64_t ldb, float* __restrict__ C, int64_t ldc, int M, int N, int K,
                                                        const float* __restrict__ bias) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * OPERAND];
-  char* As = smem;
-  char* Bs = smem + OPERAND;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   const int wr = wave >> 1, wc = wave & 1;
@@ -192,23 +289,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm3_rows(const float* __restrict__
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-  RowTile3 ta;
-  RowTile3 tbr;
-  ColTile3 tbc;
-  ta.load(A, lda, m0, M, 0, K, tid);
-  if (B_KCONTIG) tbr.load(B, ldb, n0, N, 0, K, tid); else tbc.load(B, ldb, 0, K, n0, N, tid);
-  for (int k0 = 0; k0 < K; k0 += BK) {
-    __syncthreads();
-    ta.store(As, tid);
-    if (B_KCONTIG) tbr.store(Bs, tid); else tbc.store(Bs, tid);
-    __syncthreads();
-    if (k0 + BK < K) {
-      ta.load(A, lda, m0, M, k0 + BK, K, tid);
-      if (B_KCONTIG) tbr.load(B, ldb, n0, N, k0 + BK, K, tid); else tbc.load(B, ldb, k0 + BK, K, n0, N, tid);
-    }
-    mma_block3(As, Bs, wr * 64, wc * 64, lane, acc, live_m, live_n);
-  }
+  float nobs[4] = {0.f, 0.f, 0.f, 0.f};
+  mainloop3<true, B_KCONTIG, false>(A, lda, m0, M, B, ldb, n0, N, 0, K, K, smem, acc, live_m, live_n, nobs);
 
   const int j = lane & 31, hi = lane >> 5;
 #pragma unroll
@@ -236,18 +318,16 @@ __global__ __launch_bounds__(256, 2) void k_gemm3_rows(const float* __restrict__
 
 // dW partial: tile (n0, kk0) of [N x K], rows [mc*chunk, (mc+1)*chunk); partial row of chunk mc =
 // [N*K dW elements | N bias sums (if with_bias)], as k_gemm_tn_partial of gemm.hip.
+template <bool BIAS>
 __global__ __launch_bounds__(256, 2) void k_gemm3_tn_partial(const float* __restrict__ dY, int64_t ldy, const float* __restrict__ X,
                                                              int64_t ldx, int M, int N, int K, int chunk, int with_bias,
                                                              float* __restrict__ partial) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * OPERAND];
-  char* Ys = smem;            // [n][m]
-  char* Xs = smem + OPERAND;  // [k][m]
+  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n0 = blockIdx.x * BM, kk0 = blockIdx.y * BN, mc = blockIdx.z;
   const int mbeg = mc * chunk, mend = min(M, mbeg + chunk);
   const int wr = wave >> 1, wc = wave & 1;
   const int live_m = min(2, max(0, (N - (n0 + wr * 64) + 31) / 32)), live_n = min(2, max(0, (K - (kk0 + wc * 64) + 31) / 32));
-  const bool do_bias = with_bias && blockIdx.y == 0;
   f32x16 acc[2][2];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -256,21 +336,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm3_tn_partial(const float* __rest
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
   float bs[4] = {0.f, 0.f, 0.f, 0.f};
-  ColTile3 ty, tx;
-  ty.load(dY, ldy, mbeg, mend, n0, N, tid);
-  tx.load(X, ldx, mbeg, mend, kk0, K, tid);
-  for (int m = mbeg; m < mend; m += BK) {
-    __syncthreads();
-    ty.store(Ys, tid);
-    tx.store(Xs, tid);
-    if (do_bias) ty.add_colsum(bs);
-    __syncthreads();
-    if (m + BK < mend) {
-      ty.load(dY, ldy, m + BK, mend, n0, N, tid);
-      tx.load(X, ldx, m + BK, mend, kk0, K, tid);
-    }
-    mma_block3(Ys, Xs, wr * 64, wc * 64, lane, acc, live_m, live_n);
-  }
+  mainloop3<false, false, BIAS>(dY, ldy, n0, N, X, ldx, kk0, K, mbeg, mend, M, smem, acc, live_m, live_n, bs);
+
   const int j = lane & 31, hi = lane >> 5;
   const int64_t width = (int64_t)N * K + (with_bias ? N : 0);
   float* P = partial + (int64_t)mc * width;
@@ -286,15 +353,15 @@ __global__ __launch_bounds__(256, 2) void k_gemm3_tn_partial(const float* __rest
         if (row < N) P[(int64_t)row * K + col] = acc[mt][nt][r];
       }
     }
-  if (do_bias) {  // the 8 lanes (lane & 7) of one c4 hold the k rows of the same 4 columns
+  if (BIAS && blockIdx.y == 0) {  // the 8 threads (tid & 7) of one column group hold the k pairs of the same 4 columns
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       bs[q] += __shfl_xor(bs[q], 1, 64);
       bs[q] += __shfl_xor(bs[q], 2, 64);
       bs[q] += __shfl_xor(bs[q], 4, 64);
     }
-    const int n = n0 + 4 * ((lane >> 3) + 8 * wave);
-    if ((lane & 7) == 0 && n < N) *reinterpret_cast<float4*>(&P[(int64_t)N * K + n]) = make_float4(bs[0], bs[1], bs[2], bs[3]);
+    const int n = n0 + 4 * (tid >> 3);
+    if ((tid & 7) == 0 && n < N) *reinterpret_cast<float4*>(&P[(int64_t)N * K + n]) = make_float4(bs[0], bs[1], bs[2], bs[3]);
   }
 }
 
@@ -317,6 +384,7 @@ __global__ __launch_bounds__(256) void k_gemm3_tn_final(const float* __restrict_
 }
 
 constexpr int TN3_STAGE_SLOTS = 16;
+constexpr int LDS_BYTES = 2 * STAGE;   // 73728: above the 64 KiB static limit, so dynamic
 
 int tn3_chunk_rows(int M, int N, int K) {
   const int tiles = ((N + BM - 1) / BM) * ((K + BN - 1) / BN);
@@ -324,12 +392,30 @@ int tn3_chunk_rows(int M, int N, int K) {
   if (want < 1) want = 1;
   if (want > 256) want = 256;
   int chunk = (M + want - 1) / want;
-  chunk = (chunk + BK - 1) / BK * BK;
-  if (chunk < 4 * BK) chunk = 4 * BK;
+  chunk = (chunk + 2 * KS - 1) / (2 * KS) * (2 * KS);
+  if (chunk < 8 * KS) chunk = 8 * KS;
   return chunk;
 }
 
+// 72 KiB of dynamic LDS needs the opt-in once per kernel (per process; one device per process)
+template <typename Kern>
+int allow_big_lds(Kern kern) {
+  static int status = 1;   // 1 = not asked yet
+  if (status == 1)
+    status = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess
+                 ? DGDM_OK : DGDM_ERR_LAUNCH;
+  return status;
+}
+
 }  // namespace
+
+template <typename Kern>
+static int launch_rows(Kern kern, dim3 grid, hipStream_t s, const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
+                       int M, int N, int K, const float* bias) {
+  if (allow_big_lds(kern) != DGDM_OK) return DGDM_ERR_LAUNCH;
+  hipLaunchKernelGGL(kern, grid, dim3(256), LDS_BYTES, s, A, lda, B, ldb, C, ldc, M, N, K, bias);
+  return dgdm_launch_status();
+}
 
 extern "C" int dgdm_gemm_nt_bf16x3(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* C, int64_t ldc,
                                    int32_t M, int32_t N, int32_t K, int32_t accumulate, void* stream) {
@@ -341,11 +427,8 @@ extern "C" int dgdm_gemm_nt_bf16x3(const float* A, int64_t lda, const float* W, 
   if (lda < K || ldw < K || ldc < N) return DGDM_ERR_INVALID_ARG;
   const dim3 grid((M + BM - 1) / BM, (N + BN - 1) / BN);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (accumulate)
-    hipLaunchKernelGGL((k_gemm3_rows<true, true>), grid, dim3(256), 0, s, A, lda, W, ldw, C, ldc, M, N, K, bias);
-  else
-    hipLaunchKernelGGL((k_gemm3_rows<true, false>), grid, dim3(256), 0, s, A, lda, W, ldw, C, ldc, M, N, K, bias);
-  return dgdm_launch_status();
+  return accumulate ? launch_rows(k_gemm3_rows<true, true>, grid, s, A, lda, W, ldw, C, ldc, M, N, K, bias)
+                    : launch_rows(k_gemm3_rows<true, false>, grid, s, A, lda, W, ldw, C, ldc, M, N, K, bias);
 }
 
 extern "C" int dgdm_gemm_nn_bf16x3(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc, int32_t M, int32_t N,
@@ -359,11 +442,8 @@ extern "C" int dgdm_gemm_nn_bf16x3(const float* A, int64_t lda, const float* W, 
   const dim3 grid((M + BM - 1) / BM, (Kout + BN - 1) / BN);
   const float* nobias = nullptr;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (accumulate)
-    hipLaunchKernelGGL((k_gemm3_rows<false, true>), grid, dim3(256), 0, s, A, lda, W, ldw, C, ldc, M, Kout, N, nobias);
-  else
-    hipLaunchKernelGGL((k_gemm3_rows<false, false>), grid, dim3(256), 0, s, A, lda, W, ldw, C, ldc, M, Kout, N, nobias);
-  return dgdm_launch_status();
+  return accumulate ? launch_rows(k_gemm3_rows<false, true>, grid, s, A, lda, W, ldw, C, ldc, M, Kout, N, nobias)
+                    : launch_rows(k_gemm3_rows<false, false>, grid, s, A, lda, W, ldw, C, ldc, M, Kout, N, nobias);
 }
 
 extern "C" size_t dgdm_gemm_tn_bf16x3_workspace_bytes(int32_t M, int32_t N, int32_t K, int32_t with_bias) {
@@ -395,8 +475,14 @@ extern "C" int dgdm_gemm_tn_bf16x3(const float* dY, int64_t ldy, const float* X,
   const bool staged = nchunks > 32;
   if (workspace_bytes < (size_t)(nchunks + (staged ? TN3_STAGE_SLOTS : 0)) * width * sizeof(float)) return DGDM_ERR_WORKSPACE;
   float* partial = static_cast<float*>(workspace);
-  hipLaunchKernelGGL(k_gemm3_tn_partial, dim3((N + BM - 1) / BM, (K + BN - 1) / BN, nchunks), dim3(256), 0, s, dY, ldy, X, ldx, M, N, K,
-                     chunk, db ? 1 : 0, partial);
+  const dim3 grid((N + BM - 1) / BM, (K + BN - 1) / BN, nchunks);
+  if (db) {
+    if (allow_big_lds(k_gemm3_tn_partial<true>) != DGDM_OK) return DGDM_ERR_LAUNCH;
+    hipLaunchKernelGGL(k_gemm3_tn_partial<true>, grid, dim3(256), LDS_BYTES, s, dY, ldy, X, ldx, M, N, K, chunk, 1, partial);
+  } else {
+    if (allow_big_lds(k_gemm3_tn_partial<false>) != DGDM_OK) return DGDM_ERR_LAUNCH;
+    hipLaunchKernelGGL(k_gemm3_tn_partial<false>, grid, dim3(256), LDS_BYTES, s, dY, ldy, X, ldx, M, N, K, chunk, 0, partial);
+  }
   const float* fin = partial;
   int slots = nchunks;
   if (staged) {
