@@ -54,6 +54,16 @@ SIGNATURES = {
     "dgdm_gemm_nn": (C.c_int, [_p, _i64, _p, _i64, _p, _i64, _i32, _i32, _i32, _i32, _p]),
     "dgdm_gemm_tn_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
     "dgdm_gemm_tn": (C.c_int, [_p, _i64, _p, _i64, _p, _i64, _p, _i32, _i32, _i32, _p, _sz, _p]),
+    "dgdm_pool_score_fwd": (C.c_int, [_p, _i64, _p, _p, _i32, _i32, _p, _p]),
+    "dgdm_pool_score_bwd_workspace_bytes": (_sz, [_i32, _i32]),
+    "dgdm_pool_score_bwd": (C.c_int, [_p, _i64, _p, _p, _p, _i32, _i32, _p, _i64, _p, _p, _p, _sz, _p]),
+    "dgdm_topk_perm_workspace_bytes": (_sz, [_i32]),
+    "dgdm_topk_perm": (C.c_int, [_p, _i32, _i32, _p, _p, _p, _sz, _p]),
+    "dgdm_pool_gather_fwd": (C.c_int, [_p, _i64, _p, _p, _i32, _i32, C.c_float, _p, _i64, _p]),
+    "dgdm_pool_gather_bwd": (C.c_int, [_p, _i64, _p, _i64, _p, _p, _i32, _i32, C.c_float, _p, _i64, _p, _p]),
+    "dgdm_edge_relabel": (C.c_int, [_p, _i64, _p, _i32, _p, _p]),
+    "dgdm_unpool_add_relu_fwd": (C.c_int, [_p, _i64, _p, _i64, _p, _i32, _i32, _p, _i64, _p]),
+    "dgdm_unpool_add_relu_bwd": (C.c_int, [_p, _i64, _p, _i64, _p, _i32, _i32, _p, _i64, _p, _i64, _p]),
     "dgdm_gemm_nt_bf16x3": (C.c_int, [_p, _i64, _p, _i64, _p, _p, _i64, _i32, _i32, _i32, _i32, _p]),
     "dgdm_gemm_nn_bf16x3": (C.c_int, [_p, _i64, _p, _i64, _p, _i64, _i32, _i32, _i32, _i32, _p]),
     "dgdm_gemm_tn_bf16x3_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),

@@ -133,11 +133,26 @@ class AdaptiveGraphPooling(nn.Module):
         self._nl = nonlinearity
 
     def forward(self, x: Tensor, edge_index: Tensor, edge_attr: Optional[Tensor] = None, batch: Optional[Tensor] = None,
-                compact: bool = False) -> Tuple[Tensor, Tensor, Optional[Tensor], Tensor]:
-        s = self.score_net[2](F.relu(ops.lin(self.score_net[0], x))).squeeze(-1)
-        s = torch.tanh(s) if self._nl == "tanh" else (torch.softmax(s, 0) if self._nl == "softmax" else torch.sigmoid(s))
+                compact: bool = False, return_node_map: bool = False):
         n = x.size(0)
         k = max(1, int(self.ratio * n))
+        h = ops.lin(self.score_net[0], x)
+        w2, b2 = self.score_net[2].weight, self.score_net[2].bias
+        fused = (x.is_cuda and self._nl == "tanh" and x.dtype == torch.float32 and ops.pool_supported(x.size(1), h.size(1))
+                 and n < 2 ** 31)
+        if fused:   # K9 kernels: no host sync, no data-dependent shapes
+            s = ops.pool_score(h, w2, b2)
+            perm, node_map = ops.topk_perm(s, k)
+            pooled_x = ops.pool_gather(x, s, perm, node_map, self.multiplier)
+            mapped_keep = ops.edge_relabel(edge_index, node_map)     # dropped edges (now or earlier) are (-1, -1)
+            if compact:  # reference layout (graph_layers.py:322-327); boolean indexing syncs
+                keep = mapped_keep[0] >= 0
+                out = (pooled_x, mapped_keep[:, keep], (edge_attr[keep] if edge_attr is not None else None), perm)
+            else:
+                out = (pooled_x, mapped_keep, edge_attr, perm)
+            return out + (node_map,) if return_node_map else out
+        s = F.linear(F.relu(h), w2, b2).squeeze(-1)
+        s = torch.tanh(s) if self._nl == "tanh" else (torch.softmax(s, 0) if self._nl == "softmax" else torch.sigmoid(s))
         perm = torch.topk(s, k, sorted=False).indices.sort().values        # ascending node ids
         pooled_x = x[perm] * s[perm].unsqueeze(-1) * self.multiplier
         node_map = torch.full((n,), -1, dtype=torch.long, device=x.device)
@@ -145,10 +160,11 @@ class AdaptiveGraphPooling(nn.Module):
         alive = (edge_index[0] >= 0) & (edge_index[1] >= 0)            # edges dropped by an earlier level are -1
         mapped = node_map[edge_index.clamp_min(0)]
         keep = alive & (mapped[0] >= 0) & (mapped[1] >= 0)
-        if compact:  # reference layout (graph_layers.py:322-327); boolean indexing syncs
-            return pooled_x, mapped[:, keep], (edge_attr[keep] if edge_attr is not None else None), perm
-        pooled_ei = torch.where(keep.unsqueeze(0), mapped, torch.full_like(mapped, -1))
-        return pooled_x, pooled_ei, edge_attr, perm
+        if compact:
+            out = (pooled_x, mapped[:, keep], (edge_attr[keep] if edge_attr is not None else None), perm)
+        else:
+            out = (pooled_x, torch.where(keep.unsqueeze(0), mapped, torch.full_like(mapped, -1)), edge_attr, perm)
+        return out + (node_map.to(torch.int32),) if return_node_map else out
 
 
 class GraphUNet(nn.Module):
@@ -185,7 +201,7 @@ class GraphUNet(nn.Module):
             return ctxs[(k, n)]
 
         x = self.down_convs[0](x, ctx0)
-        xs, perms = [x], []
+        xs, perms, nmaps = [x], [], []
         for i in range(self.depth):
             xr = self.act(x)
             x = self.down_convs[i + 1](xr, level(i, x.size(0)))
@@ -193,8 +209,8 @@ class GraphUNet(nn.Module):
             if trace is not None:
                 trace[f"relu.down{i}"] = xr
                 trace[f"relu.pool{i}"] = F.relu(self.pools[i].score_net[0](x))
-            x, ei, ea, perm = self.pools[i](x, eis[-1], eas[-1], batch)
-            eis.append(ei); eas.append(ea); perms.append(perm)
+            x, ei, ea, perm, nmap = self.pools[i](x, eis[-1], eas[-1], batch, return_node_map=True)
+            eis.append(ei); eas.append(ea); perms.append(perm); nmaps.append(nmap)
             if trace is not None:
                 trace[f"perm{i}"] = perm
         xr = self.act(x)
@@ -207,8 +223,11 @@ class GraphUNet(nn.Module):
                 trace[f"unet.xs{k}"] = t
         for i in range(self.depth):
             j = self.depth - 1 - i
-            up = torch.zeros(xs[j + 1].size(0), x.size(1), device=x.device, dtype=x.dtype).index_copy(0, perms[j], x)
-            x = self.act(up + xs[j + 1])
+            if self.act is F.relu and x.is_cuda and x.dtype == torch.float32 and x.size(1) % 4 == 0:
+                x = ops.unpool_add_relu(x, xs[j + 1], nmaps[j])       # K9: gather by node_map, no zero fill
+            else:
+                up = torch.zeros(xs[j + 1].size(0), x.size(1), device=x.device, dtype=x.dtype).index_copy(0, perms[j], x)
+                x = self.act(up + xs[j + 1])
             if trace is not None:
                 trace[f"unet.up{i}.in"] = x
                 trace[f"relu.up{i}"] = x

@@ -696,3 +696,137 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
 def lin(module, x: torch.Tensor) -> torch.Tensor:
     """Apply an nn.Linear through `linear`."""
     return linear(x, module.weight, module.bias)
+
+
+# ----------------------------------------------------------------------------- K9 top-k pooling / unpooling
+def pool_supported(C: int, C2: int) -> bool:
+    """Shapes the K9 kernels are built for (C = node width, C2 = width of the score MLP's hidden layer)."""
+    return C % 4 == 0 and C2 % 4 == 0 and C2 <= 256 and 256 % (C2 // 4) == 0
+
+
+class _PoolScore(torch.autograd.Function):
+    """s = tanh(w2 . relu(h) + b2); h [N, C2] is the first score layer's output (a GEMM through `lin`)."""
+
+    @staticmethod
+    def forward(ctx, h, w2, b2):
+        lib = _lib.load()
+        h = _rowmajor(h)
+        w2c, b2c = _f32c(w2.reshape(-1)), _f32c(b2.reshape(-1))
+        N, C2 = h.shape
+        s = torch.empty(N, dtype=torch.float32, device=h.device)
+        _lib.check(lib.dgdm_pool_score_fwd(h.data_ptr(), h.stride(0), w2c.data_ptr(), b2c.data_ptr(), N, C2, s.data_ptr(),
+                                           _lib.stream_ptr(h.device)), "dgdm_pool_score_fwd")
+        ctx.save_for_backward(h, w2c, s)
+        ctx.w2_shape, ctx.b2_shape = w2.shape, b2.shape
+        return s
+
+    @staticmethod
+    def backward(ctx, ds):
+        lib = _lib.load()
+        h, w2c, s = ctx.saved_tensors
+        N, C2 = h.shape
+        ds = _f32c(ds)
+        dh = torch.empty_like(h)
+        dw2 = torch.empty(C2, dtype=torch.float32, device=h.device)
+        db2 = torch.empty(1, dtype=torch.float32, device=h.device)
+        wsb = lib.dgdm_pool_score_bwd_workspace_bytes(N, C2)
+        ws = torch.empty(max(wsb, 4) // 4, dtype=torch.float32, device=h.device)
+        _lib.check(lib.dgdm_pool_score_bwd(h.data_ptr(), h.stride(0), w2c.data_ptr(), s.data_ptr(), ds.data_ptr(), N, C2, dh.data_ptr(),
+                                           dh.stride(0), dw2.data_ptr(), db2.data_ptr(), ws.data_ptr(), wsb, _lib.stream_ptr(h.device)),
+                   "dgdm_pool_score_bwd")
+        return dh, dw2.view(ctx.w2_shape), db2.view(ctx.b2_shape)
+
+
+def pool_score(h, w2, b2):
+    return _PoolScore.apply(h, w2, b2)
+
+
+def topk_perm(s: torch.Tensor, k: int):
+    """Exact top-k of the scores: (perm int64 [k] ascending node ids, node_map int32 [N] new id or -1).
+    No host synchronisation; ties at the k-th value keep the lowest ids."""
+    lib = _lib.load()
+    s = _f32c(s.detach())
+    N = s.numel()
+    perm = torch.empty(k, dtype=torch.int64, device=s.device)
+    node_map = torch.empty(N, dtype=torch.int32, device=s.device)
+    wsb = lib.dgdm_topk_perm_workspace_bytes(N)
+    ws = torch.empty(max(wsb, 4), dtype=torch.uint8, device=s.device)
+    _lib.check(lib.dgdm_topk_perm(s.data_ptr(), N, k, perm.data_ptr(), node_map.data_ptr(), ws.data_ptr(), wsb, _lib.stream_ptr(s.device)),
+               "dgdm_topk_perm")
+    return perm, node_map
+
+
+class _PoolGather(torch.autograd.Function):
+    """out[j] = x[perm[j]] * s[perm[j]] * mult"""
+
+    @staticmethod
+    def forward(ctx, x, s, perm, node_map, mult):
+        lib = _lib.load()
+        x, s = _rowmajor(x), _f32c(s)
+        k, C = perm.numel(), x.size(1)
+        out = torch.empty(k, C, dtype=torch.float32, device=x.device)
+        _lib.check(lib.dgdm_pool_gather_fwd(x.data_ptr(), x.stride(0), s.data_ptr(), perm.data_ptr(), k, C, float(mult), out.data_ptr(),
+                                            out.stride(0), _lib.stream_ptr(x.device)), "dgdm_pool_gather_fwd")
+        ctx.save_for_backward(x, s, node_map)
+        ctx.mult = float(mult)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        x, s, node_map = ctx.saved_tensors
+        g = _rowmajor(g)
+        N, C = x.shape
+        dx = torch.empty(N, C, dtype=torch.float32, device=x.device)
+        ds = torch.empty(N, dtype=torch.float32, device=x.device)
+        _lib.check(lib.dgdm_pool_gather_bwd(g.data_ptr(), g.stride(0), x.data_ptr(), x.stride(0), s.data_ptr(), node_map.data_ptr(), N, C,
+                                            ctx.mult, dx.data_ptr(), dx.stride(0), ds.data_ptr(), _lib.stream_ptr(x.device)),
+                   "dgdm_pool_gather_bwd")
+        return dx, ds, None, None, None
+
+
+def pool_gather(x, s, perm, node_map, mult: float = 1.0):
+    return _PoolGather.apply(x, s, perm, node_map, mult)
+
+
+def edge_relabel(edge_index: torch.Tensor, node_map: torch.Tensor) -> torch.Tensor:
+    """[2, E] int64 -> [2, E] int64 in the pooled numbering; edges with a dropped end become (-1, -1)."""
+    lib = _lib.load()
+    ei = edge_index.contiguous()
+    out = torch.empty_like(ei)
+    _lib.check(lib.dgdm_edge_relabel(ei.data_ptr(), ei.size(1), node_map.data_ptr(), node_map.numel(), out.data_ptr(),
+                                     _lib.stream_ptr(ei.device)), "dgdm_edge_relabel")
+    return out
+
+
+class _UnpoolAddRelu(torch.autograd.Function):
+    """relu(skip + unpool(xc)): unpool = zero-fill + index write of the reference (graph_layers.py:441-444)."""
+
+    @staticmethod
+    def forward(ctx, xc, skip, node_map):
+        lib = _lib.load()
+        xc, skip = _rowmajor(xc), _rowmajor(skip)
+        N, C = skip.shape
+        out = torch.empty(N, C, dtype=torch.float32, device=skip.device)
+        _lib.check(lib.dgdm_unpool_add_relu_fwd(xc.data_ptr(), xc.stride(0), skip.data_ptr(), skip.stride(0), node_map.data_ptr(), N, C,
+                                                out.data_ptr(), out.stride(0), _lib.stream_ptr(skip.device)), "dgdm_unpool_add_relu_fwd")
+        ctx.save_for_backward(out, node_map)
+        ctx.k = xc.size(0)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        out, node_map = ctx.saved_tensors
+        g = _rowmajor(g)
+        N, C = out.shape
+        dskip = torch.empty(N, C, dtype=torch.float32, device=out.device)
+        dxc = torch.empty(ctx.k, C, dtype=torch.float32, device=out.device)
+        _lib.check(lib.dgdm_unpool_add_relu_bwd(g.data_ptr(), g.stride(0), out.data_ptr(), out.stride(0), node_map.data_ptr(), N, C,
+                                                dskip.data_ptr(), dskip.stride(0), dxc.data_ptr(), dxc.stride(0),
+                                                _lib.stream_ptr(out.device)), "dgdm_unpool_add_relu_bwd")
+        return dxc, dskip, None
+
+
+def unpool_add_relu(xc, skip, node_map):
+    return _UnpoolAddRelu.apply(xc, skip, node_map)

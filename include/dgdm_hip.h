@@ -285,6 +285,42 @@ DGDM_API size_t dgdm_gemm_tn_bf16x3_workspace_bytes(int32_t M, int32_t N, int32_
 DGDM_API int dgdm_gemm_tn_bf16x3(const float* dY, int64_t ldy, const float* X, int64_t ldx, float* dW, int64_t lddw, float* db,
                                  int32_t M, int32_t N, int32_t K, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * K9  top-k node pooling and unpooling of the graph U-Net
+ * replaces: AdaptiveGraphPooling.forward -- core/graph_layers.py:285-329 (score MLP tail, topk,
+ *           mask.nonzero, x[perm] * score, edge filter + relabel) and the unpool / skip / activation
+ *           of GraphUNet.forward -- core/graph_layers.py:441-448.
+ *   dgdm_pool_score_fwd : s[i] = tanh(w2 . relu(h[i]) + b2[0]);  h [N, C] = first score layer's output
+ *   dgdm_pool_score_bwd : dh, dw2 [C], db2 [1] from ds (fixed-order reductions)
+ *   dgdm_topk_perm      : exact top-k of s.  perm [k] int64 = kept node ids in ascending order,
+ *                         node_map [N] int32 = new id or -1.  Ties at the k-th value keep the lowest
+ *                         ids.  Integer work: bit-exact and deterministic.  0 <= k <= N.
+ *   dgdm_pool_gather_fwd: out[j] = x[perm[j]] * s[perm[j]] * mult
+ *   dgdm_pool_gather_bwd: dx [N, C] (zero rows for dropped nodes) and ds [N] from g [k, C]
+ *   dgdm_edge_relabel   : out[:, e] = node_map[edge_index[:, e]] if both ends are kept, else (-1, -1);
+ *                         ids outside [0, N) (dropped at an earlier level) stay dropped.  int64 [2, E].
+ *   dgdm_unpool_add_relu_fwd : out[i] = relu(skip[i] + (node_map[i] >= 0 ? xc[node_map[i]] : 0))
+ *   dgdm_unpool_add_relu_bwd : dskip[i] = g[i] * [out[i] > 0];  dxc[node_map[i]] = dskip[i]
+ * All row pointers: C % 4 == 0, row strides % 4 == 0, 16-byte aligned. */
+DGDM_API int dgdm_pool_score_fwd(const float* h, int64_t ldh, const float* w2, const float* b2, int32_t N, int32_t C, float* s,
+                                 void* stream);
+DGDM_API size_t dgdm_pool_score_bwd_workspace_bytes(int32_t N, int32_t C);
+DGDM_API int dgdm_pool_score_bwd(const float* h, int64_t ldh, const float* w2, const float* s, const float* ds, int32_t N, int32_t C,
+                                 float* dh, int64_t lddh, float* dw2, float* db2, void* workspace, size_t workspace_bytes,
+                                 void* stream);
+DGDM_API size_t dgdm_topk_perm_workspace_bytes(int32_t N);
+DGDM_API int dgdm_topk_perm(const float* s, int32_t N, int32_t k, int64_t* perm, int32_t* node_map, void* workspace,
+                            size_t workspace_bytes, void* stream);
+DGDM_API int dgdm_pool_gather_fwd(const float* x, int64_t ldx, const float* s, const int64_t* perm, int32_t k, int32_t C, float mult,
+                                  float* out, int64_t ldo, void* stream);
+DGDM_API int dgdm_pool_gather_bwd(const float* g, int64_t ldg, const float* x, int64_t ldx, const float* s, const int32_t* node_map,
+                                  int32_t N, int32_t C, float mult, float* dx, int64_t lddx, float* ds, void* stream);
+DGDM_API int dgdm_edge_relabel(const int64_t* edge_index, int64_t E, const int32_t* node_map, int32_t N, int64_t* out, void* stream);
+DGDM_API int dgdm_unpool_add_relu_fwd(const float* xc, int64_t ldxc, const float* skip, int64_t lds, const int32_t* node_map, int32_t N,
+                                      int32_t C, float* out, int64_t ldo, void* stream);
+DGDM_API int dgdm_unpool_add_relu_bwd(const float* g, int64_t ldg, const float* out, int64_t ldo, const int32_t* node_map, int32_t N,
+                                      int32_t C, float* dskip, int64_t ldds, float* dxc, int64_t lddxc, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,111 @@
+"""GPU parity of the K9 pooling kernels: index work bit-exact against the numpy oracle
+(oracle/csr_oracle.py: topk_pool_indices, which restates graph_layers.py:306-324), float work against
+float64 torch."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _oracle(scores, ei, ratio):
+    from oracle.csr_oracle import topk_pool_indices
+    return topk_pool_indices(scores, ei, ratio)
+
+
+@pytest.mark.parametrize("n,ratio,kind", [(1, 0.5, "rand"), (2, 0.5, "rand"), (7, 0.5, "rand"), (1024, 0.5, "rand"), (1025, 0.5, "rand"),
+                                          (40000, 0.5, "rand"), (40000, 0.5, "tanh"), (5000, 0.25, "ties"), (3000, 0.5, "allsame"),
+                                          (4097, 0.9, "signed0"), (100000, 0.1, "rand"), (2048, 1.0, "rand")])
+def test_topk_perm_bit_exact(n, ratio, kind):
+    from dgdm_histopath_lab_amd import ops
+    g = torch.Generator().manual_seed(n)
+    if kind == "rand":
+        s = torch.randn(n, generator=g)
+    elif kind == "tanh":
+        s = torch.tanh(3 * torch.randn(n, generator=g))          # saturates: many exact +-1 ties
+    elif kind == "ties":
+        s = torch.randint(-3, 4, (n,), generator=g).float() / 4   # 7 distinct values
+    elif kind == "allsame":
+        s = torch.full((n,), 0.25)
+    else:
+        s = torch.randn(n, generator=g)
+        s[::3] = 0.0; s[1::3] = -0.0                              # -0 and +0 compare equal
+    k = max(1, int(ratio * n))
+    ei = torch.randint(0, n, (2, 4 * n + 3), generator=g)
+    ref = _oracle(s.numpy(), ei.numpy(), ratio)
+    perm, node_map = ops.topk_perm(s.to(DEV), k)
+    assert perm.dtype == torch.int64 and node_map.dtype == torch.int32
+    assert np.array_equal(perm.cpu().numpy(), ref["perm"])
+    assert np.array_equal(node_map.cpu().numpy().astype(np.int64), ref["node_map"])
+    out = ops.edge_relabel(ei.to(DEV), node_map).cpu().numpy()
+    keep = out[0] >= 0
+    assert np.array_equal(keep, out[1] >= 0)
+    assert np.array_equal(np.nonzero(keep)[0], ref["edge_keep"])
+    assert np.array_equal(out[:, keep], ref["edge_index"])
+    assert (out[:, ~keep] == -1).all()
+    # a second level: already-dropped edges (-1) stay dropped
+    if k > 1:
+        s2 = torch.randn(k, generator=g)
+        k2 = max(1, k // 2)
+        perm2, node_map2 = ops.topk_perm(s2.to(DEV), k2)
+        out2 = ops.edge_relabel(torch.from_numpy(out).to(DEV), node_map2).cpu().numpy()
+        ref2 = _oracle(s2.numpy(), ref["edge_index"], k2 / k if int((k2 / k) * k) == k2 else 0.5)
+        if ref2["perm"].shape[0] == k2:
+            assert np.array_equal(perm2.cpu().numpy(), ref2["perm"])
+            keep2 = out2[0] >= 0
+            assert np.array_equal(out2[:, keep2], ref2["edge_index"])
+        assert (out2[:, ~keep] == -1).all()
+
+
+@pytest.mark.parametrize("n,c,c2", [(1, 128, 64), (777, 128, 64), (20000, 128, 64), (5000, 256, 128), (300, 64, 32)])
+def test_pool_score_gather_unpool_against_fp64(n, c, c2):
+    from dgdm_histopath_lab_amd import ops
+    g = torch.Generator().manual_seed(n + c)
+    x = torch.randn(n, c, generator=g); h = torch.randn(n, c2, generator=g)
+    w2 = torch.randn(1, c2, generator=g) / c2 ** 0.5; b2 = torch.randn(1, generator=g)
+    skip = torch.randn(n, c, generator=g)
+    k = max(1, n // 2)
+    xd = x.to(DEV).requires_grad_(True); hd = h.to(DEV).requires_grad_(True)
+    w2d = w2.to(DEV).requires_grad_(True); b2d = b2.to(DEV).requires_grad_(True); skd = skip.to(DEV).requires_grad_(True)
+    s = ops.pool_score(hd, w2d, b2d)
+    perm, nmap = ops.topk_perm(s, k)
+    pooled = ops.pool_gather(xd, s, perm, nmap, 1.0)
+    up = ops.unpool_add_relu(pooled * 0.5, skd, nmap)
+    gy = torch.randn(n, c, generator=g)
+    (up * gy.to(DEV)).sum().backward()
+    # float64 restatement of the reference chain (graph_layers.py:298-316, 441-448) on the SAME perm
+    X, H, W2, B2, SK = (t.double().requires_grad_(True) for t in (x, h, w2, b2, skip))
+    sr = torch.tanh(torch.nn.functional.linear(torch.relu(H), W2, B2).squeeze(-1))
+    p = perm.cpu()
+    pooled_r = X[p] * sr[p].unsqueeze(-1)
+    up_r = torch.relu(torch.zeros(n, c, dtype=torch.float64).index_copy(0, p, pooled_r * 0.5) + SK)
+    (up_r * gy.double()).sum().backward()
+    assert_close(s, sr, 1e-5, "score"); assert_close(pooled, pooled_r, 1e-5, "pooled"); assert_close(up, up_r, 1e-5, "unpool")
+    for name, a, b in (("dx", xd.grad, X.grad), ("dh", hd.grad, H.grad), ("dw2", w2d.grad, W2.grad), ("db2", b2d.grad, B2.grad),
+                       ("dskip", skd.grad, SK.grad)):
+        assert_close(a, b, 2e-5, name)
+
+
+def test_pooling_module_matches_torch_path():
+    """AdaptiveGraphPooling on the K9 kernels == its torch restatement (same module, kernels off)."""
+    from dgdm_histopath_lab_amd import ops
+    from dgdm_histopath_lab_amd.core import AdaptiveGraphPooling
+    torch.manual_seed(0)
+    pool = AdaptiveGraphPooling(128).to(DEV)
+    n = 3000
+    x = torch.randn(n, 128, device=DEV); ei = torch.randint(0, n, (2, 9000), device=DEV); ea = torch.randn(9000, 32, device=DEV)
+    a = pool(x, ei, ea, None, return_node_map=True)
+    saved = ops.pool_supported
+    try:
+        ops.pool_supported = lambda *_: False
+        b = pool(x, ei, ea, None, return_node_map=True)
+    finally:
+        ops.pool_supported = saved
+    assert torch.equal(a[3], b[3]) and torch.equal(a[1], b[1]) and torch.equal(a[4], b[4])
+    assert_close(a[0], b[0].double(), 1e-5, "pooled x")
+    ac, bc = pool(x, ei, ea, None, compact=True), None
+    keep = a[1][0] >= 0
+    assert torch.equal(ac[1], a[1][:, keep]) and torch.equal(ac[2], ea[keep])
