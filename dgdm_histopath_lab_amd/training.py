@@ -1,0 +1,345 @@
+"""Training / inference harness around DGDMModel with the interface of the reference's
+``DGDMTrainer`` (dgdm_histopath/training/trainer.py:21-358) and the output dictionary of
+``DGDMPredictor.predict_graph`` (evaluation/predictor.py:188-257) -- without PyTorch Lightning:
+one process per GPU, gradients exchanged by one RCCL all-reduce of the live-gradient buffer
+(parallel.FlatGradAllReducer).
+
+What is kept exactly (file:line of the reference):
+  * phase switch by epoch: epochs < pretrain_epochs run ``model.pretrain_step`` (+ the contrastive
+    term only when the outputs carry ``node_embeddings`` -- they never do, D9), later epochs the
+    supervised step with the diffusion-loss fallback (trainer.py:91-175);
+  * AdamW(lr, weight_decay) + CosineAnnealingLR(T_max=total_steps, eta_min=0.01*lr) or OneCycleLR,
+    stepped once per optimizer step; learning rate x0.1 when the finetune phase starts
+    (trainer.py:217-271);
+  * scalar names of the log (``train/total_loss``, ``train/diffusion_loss``, ``train/phase`` ...);
+  * ``save_model`` checkpoint layout {model_state_dict, hyperparameters, epoch, global_step}
+    (trainer.py:348-358); ``load_checkpoint`` also accepts a Lightning ``.ckpt`` of the reference
+    trainer ({"state_dict": {"model.<key>": ...}, "hyper_parameters": ...}).
+"""
+from __future__ import annotations
+
+import math
+from typing import Any, Dict, Iterable, List, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.optim import AdamW
+from torch.optim.lr_scheduler import CosineAnnealingLR, OneCycleLR
+
+
+class DiffusionLoss(nn.Module):
+    """Elementwise loss between predicted and target noise with an optional per-row mask and reduction
+    (training/losses.py:15-70)."""
+
+    def __init__(self, loss_type: str = "mse", reduction: str = "mean"):
+        super().__init__()
+        if loss_type not in ("mse", "l1", "huber"):
+            raise ValueError(f"Unknown loss type: {loss_type}")
+        self.loss_type, self.reduction = loss_type, reduction
+
+    def forward(self, predicted: torch.Tensor, target: torch.Tensor, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        fn = {"mse": F.mse_loss, "l1": F.l1_loss, "huber": F.smooth_l1_loss}[self.loss_type]
+        loss = fn(predicted, target, reduction="none")
+        if mask is not None:
+            loss = loss * mask.unsqueeze(-1)
+        return loss.mean() if self.reduction == "mean" else (loss.sum() if self.reduction == "sum" else loss)
+
+
+class ContrastiveLoss(nn.Module):
+    """InfoNCE over nodes with same-graph positives (training/losses.py:73-214).  O(N^2) memory: only
+    for small batches; unreachable from the reference's pretraining step (D9), kept for the API."""
+
+    def __init__(self, temperature: float = 0.1, similarity_function: str = "cosine", reduction: str = "mean"):
+        super().__init__()
+        if similarity_function not in ("cosine", "dot"):
+            raise ValueError(f"Unknown similarity function: {similarity_function}")
+        self.temperature, self.similarity_function, self.reduction = temperature, similarity_function, reduction
+
+    def forward(self, embeddings: torch.Tensor, batch_indices: torch.Tensor) -> torch.Tensor:
+        z = F.normalize(embeddings, dim=1)                       # the reference normalises for both similarity kinds
+        sim = (z @ z.t() / self.temperature).exp()
+        same = batch_indices.unsqueeze(0) == batch_indices.unsqueeze(1)
+        same.fill_diagonal_(False)
+        pos = (sim * same).sum(1).clamp_min(1e-8)
+        loss = -(pos / sim.sum(1)).log()[same.any(1)]
+        return loss.mean() if self.reduction == "mean" else (loss.sum() if self.reduction == "sum" else loss)
+
+
+class DGDMTrainer(nn.Module):
+    """Drop-in for the reference's Lightning module; drive it with ``fit`` or call the ``*_step``
+    hooks from your own loop."""
+
+    def __init__(self, model: nn.Module, learning_rate: float = 1e-4, weight_decay: float = 1e-5, pretrain_epochs: int = 50,
+                 finetune_epochs: int = 50, masking_ratio: float = 0.15, diffusion_noise_schedule: str = "cosine",
+                 use_contrastive_loss: bool = True, contrastive_temperature: float = 0.1, scheduler_type: str = "cosine",
+                 warmup_steps: int = 1000, **kwargs):
+        super().__init__()
+        self.model = model
+        self.learning_rate, self.weight_decay = learning_rate, weight_decay
+        self.pretrain_epochs, self.finetune_epochs = pretrain_epochs, finetune_epochs
+        self.masking_ratio = masking_ratio
+        self.use_contrastive_loss = use_contrastive_loss
+        self.scheduler_type, self.warmup_steps = scheduler_type, warmup_steps
+        self.diffusion_loss = DiffusionLoss()
+        self.contrastive_loss = ContrastiveLoss(temperature=contrastive_temperature) if use_contrastive_loss else None
+        self.hparams: Dict[str, Any] = dict(learning_rate=learning_rate, weight_decay=weight_decay, pretrain_epochs=pretrain_epochs,
+                                            finetune_epochs=finetune_epochs, masking_ratio=masking_ratio,
+                                            diffusion_noise_schedule=diffusion_noise_schedule,
+                                            use_contrastive_loss=use_contrastive_loss, contrastive_temperature=contrastive_temperature,
+                                            scheduler_type=scheduler_type, warmup_steps=warmup_steps, **kwargs)
+        self.current_phase = "pretrain"
+        self.current_epoch = 0
+        self.global_step = 0
+        self.logged: Dict[str, float] = {}          # latest value of every logged scalar
+        self._optimizer: Optional[torch.optim.Optimizer] = None
+        self._scheduler = None
+
+    # ------------------------------------------------------------------ logging sink
+    def log(self, name: str, value, **_):
+        self.logged[name] = float(value.detach()) if torch.is_tensor(value) else float(value)
+
+    def log_dict(self, d: Dict[str, Any], **_):
+        for k, v in d.items():
+            self.log(k, v)
+
+    @property
+    def device(self) -> torch.device:
+        return next(self.model.parameters()).device
+
+    def optimizers(self):
+        return self._optimizer
+
+    # ------------------------------------------------------------------ steps (trainer.py:87-216)
+    def forward(self, batch, mode: str = "inference") -> Dict[str, torch.Tensor]:
+        return self.model(batch, mode=mode, return_attention=True, return_embeddings=True)
+
+    def training_step(self, batch, batch_idx: int = 0) -> torch.Tensor:
+        if self.current_epoch < self.pretrain_epochs:
+            return self._pretrain_step(batch, batch_idx)
+        return self._finetune_step(batch, batch_idx)
+
+    def _pretrain_step(self, batch, batch_idx: int = 0) -> torch.Tensor:
+        outputs = self.model.pretrain_step(batch, mask_ratio=self.masking_ratio)
+        total = outputs["total_pretrain_loss"]
+        if self.contrastive_loss is not None and "node_embeddings" in outputs:
+            c = self.contrastive_loss(outputs["node_embeddings"], batch.batch)
+            total = total + c
+            self.log("train/contrastive_loss", c)
+        self.log("train/total_loss", total)
+        self.log("train/diffusion_loss", outputs["diffusion_loss"])
+        if "reconstruction_loss" in outputs:
+            self.log("train/reconstruction_loss", outputs["reconstruction_loss"])
+        self.log("train/phase", 0.0)
+        return total
+
+    def _supervised_terms(self, outputs, batch, prefix: str, metrics: Dict[str, torch.Tensor]):
+        total, n = 0.0, 0
+        y = getattr(batch, "y", None)
+        if "classification_logits" in outputs and y is not None and getattr(self.model, "classification_head", None) is not None:
+            loss = self.model.classification_head.compute_loss(outputs["classification_logits"], y)
+            acc = (outputs["classification_logits"].argmax(1) == y).float().mean()
+            metrics[f"{prefix}classification_loss" if prefix == "train/" else "val_loss"] = loss
+            metrics[f"{prefix}accuracy" if prefix == "train/" else "val_accuracy"] = acc
+            total, n = total + loss, n + 1
+        rt = getattr(batch, "regression_targets", None)
+        if "regression_outputs" in outputs and rt is not None and getattr(self.model, "regression_head", None) is not None:
+            loss = self.model.regression_head.compute_loss(outputs["regression_outputs"], rt)
+            metrics[f"{prefix}regression_loss" if prefix == "train/" else "val_regression_loss"] = loss
+            if prefix != "train/":
+                metrics["val_mae"] = F.l1_loss(outputs["regression_outputs"], rt)
+            total, n = total + loss, n + 1
+        return total, n
+
+    def _finetune_step(self, batch, batch_idx: int = 0) -> torch.Tensor:
+        outputs = self.forward(batch, mode="finetune")
+        metrics: Dict[str, torch.Tensor] = {}
+        total, n = self._supervised_terms(outputs, batch, "train/", metrics)
+        self.log_dict(metrics)
+        if n == 0:  # no supervised targets: fall back to the diffusion objective (trainer.py:164-170)
+            total = self.model._compute_diffusion_loss(outputs["node_embeddings"], batch)["diffusion_loss"]
+            self.log("train/diffusion_loss", total)
+        self.log("train/total_loss", total)
+        self.log("train/phase", 1.0)
+        return total
+
+    @torch.no_grad()
+    def validation_step(self, batch, batch_idx: int = 0) -> Dict[str, torch.Tensor]:
+        outputs = self.forward(batch, mode="inference")
+        metrics: Dict[str, torch.Tensor] = {}
+        self._supervised_terms(outputs, batch, "val/", metrics)
+        self.log_dict(metrics)
+        return metrics
+
+    def test_step(self, batch, batch_idx: int = 0):
+        return self.validation_step(batch, batch_idx)
+
+    @torch.no_grad()
+    def predict_step(self, batch, batch_idx: int = 0) -> Dict[str, Any]:
+        outputs = self.forward(batch, mode="inference")
+        pred: Dict[str, Any] = {"graph_embeddings": outputs["graph_embedding"], "node_embeddings": outputs.get("node_embeddings")}
+        if "classification_probs" in outputs:
+            pred["classification_probs"] = outputs["classification_probs"]
+            pred["predicted_classes"] = outputs["classification_logits"].argmax(1)
+        if "regression_outputs" in outputs:
+            pred["regression_predictions"] = outputs["regression_outputs"]
+        if "attention_weights" in outputs:
+            pred["attention_weights"] = outputs["attention_weights"]
+        return pred
+
+    # ------------------------------------------------------------------ optimiser / schedule (trainer.py:217-271)
+    def configure_optimizers(self, total_steps: int):
+        """``total_steps`` = Lightning's ``trainer.estimated_stepping_batches``."""
+        opt = AdamW(self.model.parameters(), lr=self.learning_rate, weight_decay=self.weight_decay)
+        if self.scheduler_type == "cosine":
+            sched = CosineAnnealingLR(opt, T_max=total_steps, eta_min=self.learning_rate * 0.01)
+        elif self.scheduler_type == "onecycle":
+            sched = OneCycleLR(opt, max_lr=self.learning_rate, total_steps=total_steps, pct_start=0.1)
+        else:
+            sched = None
+        self._optimizer, self._scheduler = opt, sched
+        return opt if sched is None else {"optimizer": opt, "lr_scheduler": {"scheduler": sched, "interval": "step", "frequency": 1}}
+
+    def on_train_epoch_start(self):
+        phase = "pretrain" if self.current_epoch < self.pretrain_epochs else "finetune"
+        if phase != self.current_phase:
+            self.current_phase = phase
+            if phase == "finetune" and self._optimizer is not None:
+                for group in self._optimizer.param_groups:
+                    group["lr"] = group["lr"] * 0.1
+
+    def on_validation_epoch_end(self):
+        if self._optimizer is not None:
+            self.log("learning_rate", self._optimizer.param_groups[0]["lr"])
+
+    # ------------------------------------------------------------------ loop
+    def fit(self, train_loader: Iterable, val_loader: Optional[Iterable] = None, max_epochs: Optional[int] = None,
+            steps_per_epoch: Optional[int] = None, grad_reducer=None, on_step=None) -> List[float]:
+        """Runs ``max_epochs`` (default pretrain + finetune epochs) over ``train_loader`` (re-iterable;
+        batches already on the model's device or exposing ``.to``).  ``grad_reducer``: an object
+        with ``all_reduce()`` called between backward and the optimizer step (data parallel).
+        Returns the per-step training losses."""
+        max_epochs = self.pretrain_epochs + self.finetune_epochs if max_epochs is None else max_epochs
+        if steps_per_epoch is None:
+            steps_per_epoch = len(train_loader)  # type: ignore[arg-type]
+        if self._optimizer is None:
+            self.configure_optimizers(max_epochs * steps_per_epoch)
+        losses: List[float] = []
+        dev = self.device
+        for epoch in range(self.current_epoch, max_epochs):
+            self.current_epoch = epoch
+            self.on_train_epoch_start()
+            self.model.train()
+            for i, batch in enumerate(train_loader):
+                if i >= steps_per_epoch:
+                    break
+                batch = batch.to(dev) if hasattr(batch, "to") else batch
+                self._optimizer.zero_grad(set_to_none=True)
+                loss = self.training_step(batch, i)
+                loss.backward()
+                if grad_reducer is not None:
+                    grad_reducer.all_reduce()
+                self._optimizer.step()
+                if self._scheduler is not None:
+                    self._scheduler.step()
+                self.global_step += 1
+                losses.append(loss.detach())
+                if on_step is not None:
+                    on_step(self, loss)
+            if val_loader is not None:
+                self.model.eval()
+                for i, batch in enumerate(val_loader):
+                    self.validation_step(batch.to(dev) if hasattr(batch, "to") else batch, i)
+                self.on_validation_epoch_end()
+            self.current_epoch = epoch + 1
+        return [float(l) for l in losses]
+
+    @torch.no_grad()
+    def generate_embeddings(self, dataloader) -> Dict[str, Any]:
+        self.model.eval()
+        embs, labels, ids = [], [], []
+        for batch in dataloader:
+            batch = batch.to(self.device) if hasattr(batch, "to") else batch
+            embs.append(self.forward(batch, mode="inference")["graph_embedding"].cpu())
+            if getattr(batch, "y", None) is not None:
+                labels.append(batch.y.cpu())
+            if getattr(batch, "slide_id", None) is not None:
+                ids.extend(batch.slide_id)
+        return {"embeddings": torch.cat(embs, 0), "labels": torch.cat(labels, 0) if labels else None, "slide_ids": ids}
+
+    # ------------------------------------------------------------------ construction / checkpoints (trainer.py:335-358)
+    @classmethod
+    def from_config(cls, config: Dict[str, Any]) -> "DGDMTrainer":
+        from .models import DGDMModel
+        return cls(model=DGDMModel(**config.get("model", {})), **config.get("training", {}))
+
+    def save_model(self, filepath: str):
+        torch.save({"model_state_dict": self.model.state_dict(), "hyperparameters": dict(self.hparams), "epoch": self.current_epoch,
+                    "global_step": self.global_step}, filepath)
+
+    def load_checkpoint(self, filepath: str, strict: bool = False, map_location=None) -> Dict[str, Any]:
+        """Loads a ``save_model`` file or a Lightning checkpoint of the reference trainer.  ``strict=False``
+        by default: this model has ``graph_encoder.dim_proj.*`` (repair R2) which reference files lack."""
+        ckpt = torch.load(filepath, map_location=map_location or "cpu", weights_only=False)
+        if "model_state_dict" in ckpt:
+            state = ckpt["model_state_dict"]
+        elif "state_dict" in ckpt:  # Lightning: keys carry the attribute name of the wrapped model
+            state = {k[len("model."):]: v for k, v in ckpt["state_dict"].items() if k.startswith("model.")}
+        else:
+            raise ValueError("not a DGDM checkpoint: expected 'model_state_dict' or 'state_dict'")
+        missing, unexpected = self.model.load_state_dict(state, strict=strict)
+        self.current_epoch = int(ckpt.get("epoch", 0))
+        self.global_step = int(ckpt.get("global_step", 0))
+        return {"missing_keys": list(missing), "unexpected_keys": list(unexpected),
+                "hyperparameters": ckpt.get("hyperparameters", ckpt.get("hyper_parameters", {}))}
+
+
+def closed_form_lr(step: int, base_lr: float, total_steps: int, finetune_start_step: Optional[int] = None) -> float:
+    """Learning rate after ``step`` scheduler steps under the reference's cosine recipe
+    (eta_min = 0.01*lr, T_max = total_steps), ignoring the x0.1 at the finetune switch when
+    ``finetune_start_step`` is None.  CosineAnnealingLR is recursive, so scaling the group lr by 0.1
+    at step s multiplies only the (lr - eta_min) excursion that the recursion carries forward."""
+    eta_min = 0.01 * base_lr
+    cos = lambda t: eta_min + (base_lr - eta_min) * (1 + math.cos(math.pi * t / total_steps)) / 2
+    if finetune_start_step is None or step < finetune_start_step:
+        return cos(step)
+    # recursion: lr_{t+1} - eta_min = (lr_t - eta_min) * (1 + cos(pi (t+1)/T)) / (1 + cos(pi t/T))
+    lr = 0.1 * cos(finetune_start_step)
+    for t in range(finetune_start_step, step):
+        lr = eta_min + (lr - eta_min) * (1 + math.cos(math.pi * (t + 1) / total_steps)) / (1 + math.cos(math.pi * t / total_steps))
+    return lr
+
+
+@torch.no_grad()
+def predict_graph(model: nn.Module, graph, return_attention: bool = False, return_embeddings: bool = False) -> Dict[str, Any]:
+    """The dictionary ``DGDMPredictor.predict_graph`` returns (evaluation/predictor.py:188-257) for one
+    graph: numpy arrays, python scalars, per-class / per-target entries, graph statistics."""
+    model.eval()
+    dev = next(model.parameters()).device
+    graph = graph.to(dev) if hasattr(graph, "to") else graph
+    out = model(graph, mode="inference", return_attention=return_attention, return_embeddings=return_embeddings)
+    pred: Dict[str, Any] = {}
+    if "classification_probs" in out:
+        probs = out["classification_probs"].cpu().numpy()
+        pred["classification_probs"] = probs
+        pred["predicted_class"] = int(np.argmax(probs))
+        pred["confidence"] = float(np.max(probs))
+        for i, p in enumerate(probs.reshape(-1) if probs.ndim > 1 and probs.shape[0] == 1 else probs):
+            pred[f"class_{i}_prob"] = float(p) if np.ndim(p) == 0 else p
+    if "regression_outputs" in out:
+        reg = out["regression_outputs"].cpu().numpy()
+        pred["regression_outputs"] = reg
+        for i, r in enumerate(reg.reshape(-1) if reg.ndim > 1 and reg.shape[0] == 1 else reg):
+            pred[f"regression_target_{i}"] = float(r) if np.ndim(r) == 0 else r
+    if "graph_embedding" in out:
+        pred["graph_embedding"] = out["graph_embedding"].cpu().numpy()
+    if return_embeddings and "node_embeddings" in out:
+        pred["node_embeddings"] = out["node_embeddings"].cpu().numpy()
+    if return_attention and "attention_weights" in out:
+        aw = out["attention_weights"]
+        pred["attention_weights"] = [a.cpu().numpy() for a in aw] if isinstance(aw, (list, tuple)) else aw.cpu().numpy()
+    n_nodes = getattr(graph, "num_nodes", None)
+    pred["num_nodes"] = int(n_nodes if n_nodes is not None else graph.x.size(0))
+    pred["num_edges"] = int(graph.edge_index.size(1)) // 2   # undirected graph stored in both directions
+    return pred
