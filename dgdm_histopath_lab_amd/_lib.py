@@ -64,6 +64,14 @@ SIGNATURES = {
     "dgdm_edge_relabel": (C.c_int, [_p, _i64, _p, _i32, _p, _p]),
     "dgdm_unpool_add_relu_fwd": (C.c_int, [_p, _i64, _p, _i64, _p, _i32, _i32, _p, _i64, _p]),
     "dgdm_unpool_add_relu_bwd": (C.c_int, [_p, _i64, _p, _i64, _p, _i32, _i32, _p, _i64, _p, _i64, _p]),
+    "dgdm_knn2d": (C.c_int, [_p, _i32, _i32, _p, _p, _p]),
+    "dgdm_row_sqnorm": (C.c_int, [_p, _i64, _i32, _i32, _p, _p]),
+    "dgdm_knn_gram_workspace_bytes": (_sz, [_i32, _i32]),
+    "dgdm_knn_gram": (C.c_int, [_p, _i64, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _sz, _p]),
+    "dgdm_pair_cosine": (C.c_int, [_p, _i64, _p, _p, _i32, _i32, _i32, _p, _p]),
+    "dgdm_edge_dedup_workspace_bytes": (_sz, [_i32, _i32, _i32]),
+    "dgdm_edge_dedup_count": (C.c_int, [_p, _p, _i32, _p, _p, _i32, _i32, C.c_float, _p, _sz, _p, _p]),
+    "dgdm_edge_emit": (C.c_int, [_p, _p, _i32, _p, _p, _i32, _i32, C.c_float, _p, _i64, _i32, _p, _p, _p, _p, _p]),
     "dgdm_gemm_nt_bf16x3": (C.c_int, [_p, _i64, _p, _i64, _p, _p, _i64, _i32, _i32, _i32, _i32, _p]),
     "dgdm_gemm_nn_bf16x3": (C.c_int, [_p, _i64, _p, _i64, _p, _i64, _i32, _i32, _i32, _i32, _p]),
     "dgdm_gemm_tn_bf16x3_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),

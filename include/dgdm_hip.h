@@ -321,6 +321,48 @@ DGDM_API int dgdm_unpool_add_relu_fwd(const float* xc, int64_t ldxc, const float
 DGDM_API int dgdm_unpool_add_relu_bwd(const float* g, int64_t ldg, const float* out, int64_t ldo, const int32_t* node_map, int32_t N,
                                       int32_t C, float* dskip, int64_t ldds, float* dxc, int64_t lddxc, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * K11  tissue-graph edge construction (the step upstream of the model)
+ * replaces: TissueGraphBuilder._create_spatial_edges / _create_morphological_edges /
+ *           _remove_duplicate_edges and the edge part of _to_pytorch_geometric --
+ *           preprocessing/tissue_graph_builder.py:286-357, 384-402 (scikit-learn kNN + Python loops).
+ *   dgdm_knn2d       : for every 2-D point the K nearest points (itself included), ascending by
+ *                      (distance, index): idx int32 [N, K], dist float [N, K].  1 <= K <= min(N, 33).
+ *                      d^2 = fl(fl(dx*dx) + fl(dy*dy)), d = sqrt correctly rounded: a float32 CPU
+ *                      restatement reproduces both outputs bit for bit.
+ *   dgdm_row_sqnorm  : sq[i] = |x_i|^2
+ *   dgdm_knn_gram    : feature-space kNN of the query rows [q0, q0+B) from a Gram block
+ *                      GT[j][q] = x_j . x_(q0+q)  (float [N, ldg >= B], from dgdm_gemm_nt*):
+ *                      writes rows q0..q0+B-1 of idx int32 [N, K] and of sim float [N, K]
+ *                      (cosine similarity of the pair, from the Gram value).  Same ordering rule as
+ *                      dgdm_knn2d.
+ *   dgdm_pair_cosine : sim[i][p] = cos(x_i, x_idx[i][p]) recomputed from a direct dot product in a
+ *                      fixed order: bitwise symmetric in the pair (the Gram value is not), which the
+ *                      duplicate rule of dgdm_edge_dedup_count relies on.
+ *   dgdm_edge_dedup_count : thresholded spatial (weight exp(-10 d)) and morphological (cosine)
+ *                      candidates in the reference's order -> duplicates removed per undirected pair
+ *                      (heaviest wins, earliest on ties; output order = first occurrence of the pair)
+ *                      -> *n_edges (device int64) = number of kept pairs U.  Column 0 of both
+ *                      neighbour tables is skipped as "self" exactly as the reference does.
+ *   dgdm_edge_emit   : after the caller has read U: edge_index int64 [2, 2U] (both directions,
+ *                      consecutive), edge_attr float [2U, edge_dim] ([d, w, 0..] / [cos, 0..]),
+ *                      edge_type int64 [2U] (0 spatial, 1 morphological), edge_weight [2U] or NULL.
+ *                      Must follow dgdm_edge_dedup_count on the same, untouched workspace. */
+DGDM_API int dgdm_knn2d(const float* coords, int32_t N, int32_t K, int32_t* idx, float* dist, void* stream);
+DGDM_API int dgdm_row_sqnorm(const float* X, int64_t ldx, int32_t N, int32_t F, float* sq, void* stream);
+DGDM_API size_t dgdm_knn_gram_workspace_bytes(int32_t B, int32_t K);
+DGDM_API int dgdm_knn_gram(const float* GT, int64_t ldg, const float* sq, int32_t N, int32_t q0, int32_t B, int32_t K, int32_t* idx,
+                           float* sim, void* workspace, size_t workspace_bytes, void* stream);
+DGDM_API int dgdm_pair_cosine(const float* X, int64_t ldx, const float* sq, const int32_t* idx, int32_t N, int32_t K, int32_t F,
+                              float* sim, void* stream);
+DGDM_API size_t dgdm_edge_dedup_workspace_bytes(int32_t N, int32_t Ks1, int32_t Km1);
+DGDM_API int dgdm_edge_dedup_count(const int32_t* sidx, const float* sdist, int32_t Ks1, const int32_t* midx, const float* msim,
+                                   int32_t Km1, int32_t N, float threshold, void* workspace, size_t workspace_bytes, int64_t* n_edges,
+                                   void* stream);
+DGDM_API int dgdm_edge_emit(const int32_t* sidx, const float* sdist, int32_t Ks1, const int32_t* midx, const float* msim, int32_t Km1,
+                            int32_t N, float threshold, const void* workspace, int64_t U, int32_t edge_dim, int64_t* edge_index,
+                            float* edge_attr, int64_t* edge_type, float* edge_weight, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
