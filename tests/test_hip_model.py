@@ -87,17 +87,19 @@ def test_model_matches_reference_golden(tag, attn, monkeypatch):
     assert named["spatial_attention.pos_encoding"].grad is None  # dead parameters stay dead (D9)
 
 
-def _run_both(cfgd, seed0, trace):
+def _run_both(cfgd, seed0, trace, nodes=2000, edges=8000):
     """One pretrain_step (masking + injected draws) on the HIP path and on the float64 oracle.
     The arbiter runs in float64 (same oracle code): fp32-vs-fp32 would fold the CPU path's own
     rounding into the comparison."""
     from dgdm_histopath_lab_amd.synthetic import synthetic_batch
     cfg = O.OracleConfig(**cfgd)
     P = O.init_params(cfg, seed=3, perturb=0.05)
-    batch = synthetic_batch(seed0, 2, 2000, 8000)
+    batch = synthetic_batch(seed0, 2, nodes, edges)
     gen = torch.Generator().manual_seed(11 + seed0)
     n = batch.x.size(0)
-    rng = dict(timesteps=torch.tensor([2, 9]), noise=torch.randn(n, 128, generator=gen), noise_target=torch.randn(n, 128, generator=gen))
+    c_last, T = cfgd["hidden_dims"][-1], cfgd["num_diffusion_steps"]
+    rng = dict(timesteps=torch.tensor([2, T - 1]), noise=torch.randn(n, c_last, generator=gen),
+               noise_target=torch.randn(n, c_last, generator=gen))
     mask_idx = torch.randperm(n, generator=gen)[: int(n * 0.15)]
     mask_tok = torch.randn(768, generator=gen)
     torch.set_num_threads(16)
@@ -188,6 +190,41 @@ def test_full_model_matches_oracle_2k_nodes_all_params(attn, monkeypatch):
             assert _assert_all_grads(m, gref, TOL) > 100
             return
     pytest.fail("no kink-flip-free instance in 4 attempts")
+
+
+def test_large_config_matches_oracle_all_params():
+    """BASELINE configs[3] dims (DGDM-Large: hidden [1024, 512, 256], 16 heads, T = 20) on 2 x 600-node
+    graphs, smooth variant: every live gradient against the float64 oracle."""
+    cfgd = dict(node_features=768, hidden_dims=[1024, 512, 256], num_diffusion_steps=20, attention_heads=16, use_hierarchical=False)
+    m, out, ref, gref, _, _ = _run_both(cfgd, 5, trace=False, nodes=600, edges=3000)
+    for k in ("diffusion_loss", "graph_embedding", "noisy_embeddings"):
+        assert_close(out[k], ref[k], 1e-4, k)
+    assert _assert_all_grads(m, gref, 2e-4) > 60
+
+
+def test_large_config_full_size_graph_is_an_independent_unit():
+    """configs[3] at full size (one 50 000-node / 300 000-edge graph, DGDM-Large incl. the hierarchical U-Net):
+    the step runs, everything is finite, and -- size-independent property of the path -- a graph's embedding
+    does not depend on what else is in the batch (block-diagonal edges, per-graph attention / pooling;
+    checked without the U-Net, whose top-k ranks nodes over the whole batch, graph_layers.py:306-310)."""
+    from dgdm_histopath_lab_amd import DGDMModel, GraphBatch
+    from dgdm_histopath_lab_amd.synthetic import synthetic_graph
+    torch.manual_seed(0)
+    big = synthetic_graph(0, 50000, 300000, 768)
+    small = synthetic_graph(1, 3000, 12000, 768)
+    cfg = dict(node_features=768, hidden_dims=[1024, 512, 256], num_diffusion_steps=20, attention_heads=16)
+    m = DGDMModel(**cfg).to(DEV)
+    out = m.pretrain_step(GraphBatch.from_data_list([big]).to(DEV))
+    out["total_pretrain_loss"].backward()
+    assert torch.isfinite(out["total_pretrain_loss"])
+    live = [p.grad for p in m.parameters() if p.grad is not None]
+    assert len(live) > 60 and all(torch.isfinite(g).all() for g in live)
+    del out, live
+    m2 = DGDMModel(use_hierarchical=False, **cfg).to(DEV).eval()
+    with torch.no_grad():
+        alone = m2(GraphBatch.from_data_list([big]).to(DEV), mode="inference")["graph_embedding"]
+        both = m2(GraphBatch.from_data_list([small, big]).to(DEV), mode="inference")["graph_embedding"]
+    assert_close(both[1:2], alone.double(), 1e-5, "embedding of the 50k graph alone vs in a batch")
 
 
 def test_model_error_contract():
