@@ -191,7 +191,8 @@ class DGDMTrainer(nn.Module):
     # ------------------------------------------------------------------ optimiser / schedule (trainer.py:217-271)
     def configure_optimizers(self, total_steps: int):
         """``total_steps`` = Lightning's ``trainer.estimated_stepping_batches``."""
-        opt = AdamW(self.model.parameters(), lr=self.learning_rate, weight_decay=self.weight_decay)
+        on_gpu = next(self.model.parameters()).is_cuda
+        opt = AdamW(self.model.parameters(), lr=self.learning_rate, weight_decay=self.weight_decay, fused=True if on_gpu else None)
         if self.scheduler_type == "cosine":
             sched = CosineAnnealingLR(opt, T_max=total_steps, eta_min=self.learning_rate * 0.01)
         elif self.scheduler_type == "onecycle":
