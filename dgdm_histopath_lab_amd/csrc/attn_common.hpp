@@ -75,20 +75,30 @@ __device__ __forceinline__ float group_sum4(float v) {
 // pair and exchange the results with one DPP swap each -- 2 hashes per 4 elements everywhere.
 // The backward kernels regenerate exactly the forward's mask from (seed, indices).
 // hq = head_seed ^ (qp * 0x9E3779B1): the part that does not depend on the key (hoisted by callers)
+// Counter hash of (seed, graph, head, query pair, key) -> 32 bits = two 16-bit uniform lanes (even / odd
+// query of the pair).  The kernels are VALU-bound and the mask costs more than the softmax itself, so the
+// per-element part is kept to 7 issue slots: the 32-bit v_mul_lo_u32 is quarter rate on gfx950, the 24-bit
+// v_mul_u32_u24 is full rate, and node indices are < 2^24:
+//     x = hs ^ mul24(q >> 1, C3) ^ mul24(k, C1);  x ^= x >> 16;  x = mul24(x, C2);  x ^= x >> 12
+// with hs = a full 32-bit finaliser of (seed, graph offset, head), computed once per head.  Statistics
+// (tools / tests): drop rate within 1e-4 of p, correlations between adjacent keys, queries, diagonals,
+// heads, seeds all <= 5e-3 (the previous two-multiply hash: the same level), row / column rates binomial.
+__device__ __forceinline__ uint32_t attn_fmix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x85EBCA6BU; x ^= x >> 13; x *= 0xC2B2AE35U; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ uint32_t attn_head_seed(uint32_t seed, int n0, int head) {
+  return attn_fmix32(seed ^ ((uint32_t)n0 * 0xC2B2AE35U) ^ ((uint32_t)(head + 1) * 0x27D4EB2FU));
+}
+// per-(head, query pair) part, hoisted out of the key loop where the query is fixed per lane
+__device__ __forceinline__ uint32_t attn_hq(uint32_t hs, int q_local) { return hs ^ __umul24((uint32_t)q_local >> 1, 0x79B1A5U); }
 __device__ __forceinline__ uint32_t attn_hash_hq(uint32_t hq, uint32_t k) {
-  // one multiply round: the inputs are already spread by odd-constant multiplies (q>>1, k, head, graph,
-  // seed); the 32-bit v_mul_lo_u32 is quarter rate on gfx950, and on the fp16 path the kernels are
-  // VALU-bound, so a second round would cost ~10 % of the kernel for no visible gain in mask quality
-  // (rate, per-head / per-row / adjacent-key independence are checked in tests/test_hip_attention.py).
-  uint32_t x = hq ^ (k * 0x85EBCA6BU);
-  x ^= x >> 15; x *= 0x2c1b3c6dU; x ^= x >> 13;
+  uint32_t x = hq ^ __umul24(k, 0x5BCA6BU);
+  x ^= x >> 16; x = __umul24(x, 0x3C6D2BU); x ^= x >> 12;
   return x;
 }
 __device__ __forceinline__ uint32_t attn_hash(uint32_t hs, uint32_t qp, uint32_t k) {
-  return attn_hash_hq(hs ^ (qp * 0x9E3779B1U), k);
-}
-__device__ __forceinline__ uint32_t attn_head_seed(uint32_t seed, int n0, int head) {
-  return seed ^ ((uint32_t)n0 * 0xC2B2AE35U) ^ ((uint32_t)(head + 1) * 0x27D4EB2FU);
+  return attn_hash_hq(hs ^ __umul24(qp, 0x79B1A5U), k);
 }
 struct DropCfg {
   uint32_t thresh;
@@ -97,7 +107,7 @@ struct DropCfg {
 };
 // q-major: this lane is query `q_local` (lane bit 0 == q_local & 1), its register quad holds keys
 // k0 .. k0+3.  Returns the four keep-factors.
-// `hq` = attn_head_seed(...) ^ ((q_local >> 1) * 0x9E3779B1), precomputed per (lane, head).
+// `hq` = attn_hq(attn_head_seed(...), q_local), precomputed per (lane, head).
 __device__ __forceinline__ f32x4 drop_factors_qmajor(uint32_t hq, int q_local, int k0, const DropCfg& c) {
   const bool odd = q_local & 1;
   const uint32_t kk = (uint32_t)k0 + (odd ? 2u : 0u);

@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_fwd(const float* __restrict__ Q
 #pragma unroll
   for (int h = 0; h < HG; ++h) {
     oacc[h] = f32x4{0.f, 0.f, 0.f, 0.f}; oacc2[h] = f32x4{0.f, 0.f, 0.f, 0.f}; m[h] = NEG_BIG; l[h] = 0.f;
-    hq[h] = attn_head_seed(seed, n0, head0 + h) ^ (((uint32_t)q_local >> 1) * 0x9E3779B1U);
+    hq[h] = attn_hq(attn_head_seed(seed, n0, head0 + h), q_local);
   }
 
   // staging map: idx -> (key, h, part), part fastest => HG*64 contiguous bytes per key row

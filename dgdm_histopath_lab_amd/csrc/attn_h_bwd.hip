@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void k_attn_h_bwd_dq(const _Float16* __restric
     nl2[h] = -lse2_b[rowoff];
     ndl[h] = -delta_b[rowoff];
     dq[h] = f32x4{0.f, 0.f, 0.f, 0.f}; dq2[h] = f32x4{0.f, 0.f, 0.f, 0.f};
-    hq[h] = attn_head_seed(seed, n0, head0 + h) ^ (((uint32_t)q_local >> 1) * 0x9E3779B1U);
+    hq[h] = attn_hq(attn_head_seed(seed, n0, head0 + h), q_local);
   }
   const float2 pq = *reinterpret_cast<const float2*>(pos_b + ((int64_t)blockIdx.x * HB + q_in_blk) * 2);
   __syncthreads();

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void k_attn_pack(const float* __restrict__ X, 
 }
 
 template <int HG, bool DROP>
-__global__ __launch_bounds__(256) void k_attn_h_fwd(const _Float16* __restrict__ Rq, const _Float16* __restrict__ Rk,
+__global__ __launch_bounds__(256, 2) void k_attn_h_fwd(const _Float16* __restrict__ Rq, const _Float16* __restrict__ Rk,
                                                     const _Float16* __restrict__ Tv, const float* __restrict__ pos_b, int H,
                                                     const int32_t* __restrict__ ptr, int B, float bscale, float* __restrict__ O,
                                                     int64_t ldo, float* __restrict__ lse2_b, float drop_p, uint32_t seed) {
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void k_attn_h_fwd(const _Float16* __restrict__
   for (int h = 0; h < HG; ++h) {
     load_b_pair(Rq + (((int64_t)blockIdx.x * H + head0 + h) * HB + q_in_blk) * 32, G, &qb1[h], &qb2[h]);
     oacc[h] = f32x4{0.f, 0.f, 0.f, 0.f}; oacc2[h] = f32x4{0.f, 0.f, 0.f, 0.f}; lacc[h] = f32x4{0.f, 0.f, 0.f, 0.f}; m[h] = NEG_BIG;
-    hq[h] = attn_head_seed(seed, n0, head0 + h) ^ (((uint32_t)q_local >> 1) * 0x9E3779B1U);
+    hq[h] = attn_hq(attn_head_seed(seed, n0, head0 + h), q_local);
   }
   const float2 pq = *reinterpret_cast<const float2*>(pos_b + ((int64_t)blockIdx.x * HB + q_in_blk) * 2);
   __syncthreads();  // block 0 landed (vmcnt(0) + barrier)
