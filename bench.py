@@ -128,8 +128,12 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py needs a GPU (the HIP path has no CPU fallback)", file=sys.stderr)
         sys.exit(2)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # rehearsal knobs (not used by the driver): all ranks on one GPU over gloo, to exercise the N > 1 code path on a 1-GPU box
+    one_device = os.environ.get("DGDM_BENCH_ONE_DEVICE") == "1"
+    backend = os.environ.get("DGDM_BENCH_DIST_BACKEND", "nccl")
+    dev_index = 0 if one_device else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
 
     import torch.distributed as dist
     from dgdm_histopath_lab_amd import DGDMModel, ops
@@ -138,7 +142,10 @@ def main():
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     torch.manual_seed(0)
     model = DGDMModel(**MODEL_CFG).to(dev)

@@ -34,6 +34,7 @@ class FlatGradAllReducer:
 
     def _setup(self):
         self.live = [p for p in self.params if p.grad is not None]
+        self._live_ids = {id(p) for p in self.live}
         n = sum(p.numel() for p in self.live)
         ref = self.live[0]
         self.flat = torch.empty(n, dtype=ref.grad.dtype, device=ref.grad.device)
@@ -52,7 +53,7 @@ class FlatGradAllReducer:
         if self.live is None:
             self._setup()
         grads = [p.grad for p in self.live]
-        if any(g is None for g in grads) or any(p.grad is not None and all(p is not q for q in self.live) for p in self.params):
+        if any(g is None for g in grads) or any(p.grad is not None and id(p) not in self._live_ids for p in self.params):
             raise RuntimeError("the set of parameters receiving gradients changed between steps")
         torch._foreach_copy_(self.views, grads)
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
