@@ -116,6 +116,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--eval-mode", action="store_true", help="dropout off (diagnostics only; not the headline)")
+    ap.add_argument("--mixed", action="store_true",
+                    help="BASELINE configs[4] shape instead of the headline: a stream of batches whose graphs have 1k..10k nodes "
+                         "(E = 5 N), 8 different batches resident in HBM and cycled; reported under config.workload, not comparable "
+                         "with the fixed-size number")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -156,10 +160,24 @@ def main():
     # rank r owns slides [r*B, (r+1)*B): independent units, no data-path collective
     batch = synthetic_batch(rank * args.batch, args.batch, args.nodes, args.edges, FEATS).to(dev)
     sizes = [args.nodes] * args.batch
+    stream = None
+    if args.mixed:
+        from dgdm_histopath_lab_amd import GraphBatch
+        from dgdm_histopath_lab_amd.synthetic import synthetic_graph
+        g = torch.Generator().manual_seed(77 + rank)
+        stream = []
+        for b in range(8):
+            ns = torch.randint(1000, 10001, (args.batch,), generator=g).tolist()
+            stream.append(GraphBatch.from_data_list([synthetic_graph(1000 * rank + 10 * b + i, n, 5 * n, FEATS) for i, n in enumerate(ns)]).to(dev))
+        step_no = [0]
 
     def step():
         opt.zero_grad(set_to_none=True)
-        out = model.pretrain_step(batch, mask_ratio=0.15)
+        cur = batch
+        if stream is not None:
+            cur = stream[step_no[0] % len(stream)]
+            step_no[0] += 1
+        out = model.pretrain_step(cur, mask_ratio=0.15)
         out["total_pretrain_loss"].backward()
         if reducer is not None:
             reducer.all_reduce()
@@ -207,7 +225,9 @@ def main():
                     "unit": "TFLOP/s", "frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(kernels[dom]),
                     "ms_per_launch": round(ms, 4), "launches_timed": timers[dom][0], "algorithmic_flop": flops[dom],
                     "other_kernels_ms": {k: round(v[1], 4) for k, v in timers.items() if k != dom}}
-        if split:
+        if args.mixed:   # launches differ in size from step to step: no single algorithmic FLOP count per launch
+            roofline = {"note": "not computed for the mixed-size stream; see the fixed-size headline run"}
+        elif split:
             roofline.update({"mfma_dtype": "f16 hi+lo split, fp32 accumulate", "issued_flop": 4 * flops[dom],
                              "issued_tflops": round(4 * tf, 1), "issued_frac_of_f16_peak": round(4 * tf / FP16_MFMA_PEAK_TFLOPS, 4),
                              "limiter": "VALU (exp2, dropout hash, fp16 packing) -- see DESIGN.md"})
@@ -216,8 +236,11 @@ def main():
             "unit": "slides/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"DGDM-Base pretrain_step fwd+bwd+AdamW, batch={args.batch} x {args.nodes}-node/{args.edges}-edge "
-                                   f"graphs per GPU, feat={FEATS}, edge_attr=32, T=10, heads=8, "
+            "config": {"workload": (f"MIXED-SIZE STREAM (configs[4]): DGDM-Base pretrain_step fwd+bwd+AdamW, batch={args.batch} graphs of "
+                                    f"1k..10k nodes (E = 5 N) per GPU, 8 batches cycled, feat={FEATS}, edge_attr=32, T=10, heads=8, "
+                                    if args.mixed else
+                                    f"DGDM-Base pretrain_step fwd+bwd+AdamW, batch={args.batch} x {args.nodes}-node/{args.edges}-edge "
+                                    f"graphs per GPU, feat={FEATS}, edge_attr=32, T=10, heads=8, ") +
                                    f"{'eval (dropout off)' if args.eval_mode else 'training mode (dropout 0.1)'}",
                        "global_batch": world * args.batch, "parallelism": f"dp{world}", "final_loss": round(loss_val, 5)},
             "roofline": roofline,
