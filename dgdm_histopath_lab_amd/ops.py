@@ -141,6 +141,8 @@ class AttnPlan:
         self.ptr_host = [int(v) for v in ptr_host]
         self.B = len(self.ptr_host) - 1
         self.N_tot = self.ptr_host[-1]
+        if max((self.ptr_host[g + 1] - self.ptr_host[g] for g in range(self.B)), default=0) >= 1 << 24:
+            raise _lib.DGDMKernelError("graphs of 2^24 nodes or more are not supported (24-bit index arithmetic in the attention kernels)")
         qb = lib.dgdm_spatial_attn_q_tile_rows()
         self.num_q_tiles = sum((self.ptr_host[g + 1] - self.ptr_host[g] + qb - 1) // qb for g in range(self.B))
         self.ptr_dev = torch.tensor(self.ptr_host, dtype=torch.int32).to(device, non_blocking=True)
