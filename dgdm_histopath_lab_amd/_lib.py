@@ -54,6 +54,8 @@ SIGNATURES = {
     "dgdm_gemm_nn": (C.c_int, [_p, _i64, _p, _i64, _p, _i64, _i32, _i32, _i32, _i32, _p]),
     "dgdm_gemm_tn_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
     "dgdm_gemm_tn": (C.c_int, [_p, _i64, _p, _i64, _p, _i64, _p, _i32, _i32, _i32, _p, _sz, _p]),
+    "dgdm_seed_epoch_advance": (C.c_int, [_p]),
+    "dgdm_seed_epoch_set": (C.c_int, [C.c_uint32, _p]),
     "dgdm_pool_score_fwd": (C.c_int, [_p, _i64, _p, _p, _i32, _i32, _p, _p]),
     "dgdm_pool_score_bwd_workspace_bytes": (_sz, [_i32, _i32]),
     "dgdm_pool_score_bwd": (C.c_int, [_p, _i64, _p, _p, _p, _i32, _i32, _p, _i64, _p, _p, _p, _sz, _p]),

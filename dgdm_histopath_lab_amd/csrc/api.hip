@@ -13,3 +13,33 @@ extern "C" const char* dgdm_error_string(int code) {
     default: return "unknown dgdm error code";
   }
 }
+
+// ---------------------------------------------------------------- dropout seed epoch (see common.hpp)
+__device__ uint32_t g_dgdm_seed_epoch = 0;
+
+const uint32_t* dgdm_seed_epoch_ptr() {
+  static const uint32_t* cached[64] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64) dev = 0;
+  if (!cached[dev]) {
+    void* p = nullptr;
+    (void)hipGetSymbolAddress(&p, HIP_SYMBOL(g_dgdm_seed_epoch));
+    cached[dev] = static_cast<const uint32_t*>(p);
+  }
+  return cached[dev];
+}
+
+namespace {
+__global__ void k_seed_epoch(uint32_t* p, uint32_t value, int set) { *p = set ? value : *p + 1u; }
+}  // namespace
+
+extern "C" int dgdm_seed_epoch_advance(void* stream) {
+  hipLaunchKernelGGL(k_seed_epoch, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), const_cast<uint32_t*>(dgdm_seed_epoch_ptr()), 0u, 0);
+  return dgdm_launch_status();
+}
+
+extern "C" int dgdm_seed_epoch_set(uint32_t value, void* stream) {
+  hipLaunchKernelGGL(k_seed_epoch, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), const_cast<uint32_t*>(dgdm_seed_epoch_ptr()), value, 1);
+  return dgdm_launch_status();
+}

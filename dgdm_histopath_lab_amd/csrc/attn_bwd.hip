@@ -26,7 +26,8 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq(const float* __restrict_
                                                         const float* __restrict__ pos, const int32_t* __restrict__ ptr, int B,
                                                         const float* __restrict__ L2, float qscale, float bscale, float scale,
                                                         float* __restrict__ dQ, int64_t ldg, float* __restrict__ delta,
-                                                        int N_tot, float drop_p, uint32_t seed) {
+                                                        int N_tot, float drop_p, DgdmSeed seed_in) {
+  const uint32_t seed = seed_in.value();
   using T = AttnTile<KB>;
   const DropCfg dc(drop_p);
   constexpr int NT = KB / 16;
@@ -166,7 +167,8 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv(const float* __restrict
                                                          const float* __restrict__ L2, const float* __restrict__ delta,
                                                          float qscale, float bscale, float scale, float* __restrict__ dK,
                                                          float* __restrict__ dV, int64_t ldg, int N_tot, float drop_p,
-                                                         uint32_t seed) {
+                                                         DgdmSeed seed_in) {
+  const uint32_t seed = seed_in.value();
   using T = AttnTile<QBK>;
   const DropCfg dc(drop_p);
   constexpr int NT = QBK / 16;
@@ -341,10 +343,10 @@ extern "C" int dgdm_spatial_attn_bwd_dq(const float* Q, const float* K, const fl
   do {                                                                                                                    \
     if (drop_p > 0.f)                                                                                                     \
       hipLaunchKernelGGL((k_attn_bwd_dq<HG, KB, true>), dim3(num_q_tiles, H / HG), dim3(256), 0, s, Q, K, V, ld, O, dO,   \
-                         ldo, pos, ptr, B, lse2, qscale, bscale, scale, dQ, ldg, delta_ws, N_tot, drop_p, seed);         \
+                         ldo, pos, ptr, B, lse2, qscale, bscale, scale, dQ, ldg, delta_ws, N_tot, drop_p, dgdm_seed_arg(seed));         \
     else                                                                                                                  \
       hipLaunchKernelGGL((k_attn_bwd_dq<HG, KB, false>), dim3(num_q_tiles, H / HG), dim3(256), 0, s, Q, K, V, ld, O, dO,  \
-                         ldo, pos, ptr, B, lse2, qscale, bscale, scale, dQ, ldg, delta_ws, N_tot, 0.f, 0u);              \
+                         ldo, pos, ptr, B, lse2, qscale, bscale, scale, dQ, ldg, delta_ws, N_tot, 0.f, dgdm_seed_arg(0u));              \
   } while (0)
   if (H % 4 == 0) GO(4, 64);
   else if (H % 2 == 0) GO(2, 64);
@@ -369,10 +371,10 @@ extern "C" int dgdm_spatial_attn_bwd_dkv(const float* Q, const float* K, const f
   do {                                                                                                                    \
     if (drop_p > 0.f)                                                                                                     \
       hipLaunchKernelGGL((k_attn_bwd_dkv<HG, QBK, true>), dim3(num_q_tiles, H / HG), dim3(256), 0, s, Q, K, V, ld, dO,    \
-                         ldo, pos, ptr, B, lse2, delta_ws, qscale, bscale, scale, dK, dV, ldg, N_tot, drop_p, seed);     \
+                         ldo, pos, ptr, B, lse2, delta_ws, qscale, bscale, scale, dK, dV, ldg, N_tot, drop_p, dgdm_seed_arg(seed));     \
     else                                                                                                                  \
       hipLaunchKernelGGL((k_attn_bwd_dkv<HG, QBK, false>), dim3(num_q_tiles, H / HG), dim3(256), 0, s, Q, K, V, ld, dO,   \
-                         ldo, pos, ptr, B, lse2, delta_ws, qscale, bscale, scale, dK, dV, ldg, N_tot, 0.f, 0u);          \
+                         ldo, pos, ptr, B, lse2, delta_ws, qscale, bscale, scale, dK, dV, ldg, N_tot, 0.f, dgdm_seed_arg(0u));          \
   } while (0)
   if (H % 4 == 0) GO(4, 32);
   else if (H % 2 == 0) GO(2, 64);

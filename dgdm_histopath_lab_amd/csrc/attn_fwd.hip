@@ -23,7 +23,8 @@ __global__ __launch_bounds__(256, 2) void k_attn_fwd(const float* __restrict__ Q
                                                      const float* __restrict__ V, int64_t ld,
                                                      const float* __restrict__ pos, const int32_t* __restrict__ ptr, int B,
                                                      float qscale, float bscale, float* __restrict__ O, int64_t ldo,
-                                                     float* __restrict__ L2, int N_tot, float drop_p, uint32_t seed) {
+                                                     float* __restrict__ L2, int N_tot, float drop_p, DgdmSeed seed_in) {
+  const uint32_t seed = seed_in.value();
   using T = AttnTile<KB>;
   constexpr int NT = KB / 16;                     // 16-key tiles per block
   const DropCfg dc(drop_p);
@@ -221,10 +222,10 @@ extern "C" int dgdm_spatial_attn_fwd_variant(const float* Q, const float* K, con
   do {                                                                                                                 \
     if (drop_p > 0.f)                                                                                                  \
       hipLaunchKernelGGL((k_attn_fwd<HG, KB, true>), dim3(num_q_tiles, H / HG), dim3(256), 0, s, Q, K, V, ld, pos, ptr, \
-                         B, qscale, bscale, O, ldo, lse2, N_tot, drop_p, seed);                                        \
+                         B, qscale, bscale, O, ldo, lse2, N_tot, drop_p, dgdm_seed_arg(seed));                                        \
     else                                                                                                               \
       hipLaunchKernelGGL((k_attn_fwd<HG, KB, false>), dim3(num_q_tiles, H / HG), dim3(256), 0, s, Q, K, V, ld, pos,    \
-                         ptr, B, qscale, bscale, O, ldo, lse2, N_tot, 0.f, 0u);                                        \
+                         ptr, B, qscale, bscale, O, ldo, lse2, N_tot, 0.f, dgdm_seed_arg(0u));                                        \
   } while (0)
   if (H % 8 == 0 && variant == 1) GO(8, 32);
   else if (H % 8 == 0 && variant == 2) GO(8, 64);

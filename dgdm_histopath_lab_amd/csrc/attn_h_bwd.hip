@@ -22,7 +22,8 @@ __global__ __launch_bounds__(256) void k_attn_h_bwd_dq(const _Float16* __restric
                                                        const float* __restrict__ lse2_b, const float* __restrict__ delta_b, int H,
                                                        const int32_t* __restrict__ ptr, int B, float bscale, float scale,
                                                        const float* __restrict__ unscale_dev, float* __restrict__ dQ, int64_t ldg,
-                                                       float drop_p, uint32_t seed) {
+                                                       float drop_p, DgdmSeed seed_in) {
+  const uint32_t seed = seed_in.value();
   constexpr int NT = HB / 16;
   constexpr int R_BYTES = HG * R_HEAD * 2, T_BYTES = HG * T_HEAD * 2, POS_BYTES = HB * 8;
   constexpr int BUF_BYTES = 2 * R_BYTES + T_BYTES + POS_BYTES;
@@ -139,7 +140,8 @@ __global__ __launch_bounds__(256) void k_attn_h_bwd_dkv(const _Float16* __restri
                                                         const float* __restrict__ delta_b, int H, const int32_t* __restrict__ ptr,
                                                         int B, float bscale, float kscale, const float* __restrict__ unscale_dev,
                                                         float* __restrict__ dK, float* __restrict__ dV, int64_t ldg, float drop_p,
-                                                        uint32_t seed) {
+                                                        DgdmSeed seed_in) {
+  const uint32_t seed = seed_in.value();
   constexpr int NT = HB / 16;
   constexpr int R_BYTES = HG * R_HEAD * 2, T_BYTES = HG * T_HEAD * 2, SC_BYTES = HG * HB * 4, POS_BYTES = HB * 8;
   constexpr int BUF_BYTES = 2 * R_BYTES + 2 * T_BYTES + 2 * SC_BYTES + POS_BYTES;
@@ -285,10 +287,10 @@ extern "C" int dgdm_spatial_attn_h_bwd_dq(const void* Rq, const void* Rk, const 
   do {                                                                                                                           \
     if (drop_p > 0.f)                                                                                                            \
       hipLaunchKernelGGL((k_attn_h_bwd_dq<HG, NBUF, true>), dim3(num_blocks, H / HG), dim3(256), 0, s, h16(Rq), h16(Rk), h16(Rv), \
-                         h16(Tk), h16(Rg), pos_b, lse2_b, delta_b, H, ptr, B, bscale, scale, grad_scale2, dQ, ldg, drop_p, seed);             \
+                         h16(Tk), h16(Rg), pos_b, lse2_b, delta_b, H, ptr, B, bscale, scale, grad_scale2, dQ, ldg, drop_p, dgdm_seed_arg(seed));             \
     else                                                                                                                         \
       hipLaunchKernelGGL((k_attn_h_bwd_dq<HG, NBUF, false>), dim3(num_blocks, H / HG), dim3(256), 0, s, h16(Rq), h16(Rk),        \
-                         h16(Rv), h16(Tk), h16(Rg), pos_b, lse2_b, delta_b, H, ptr, B, bscale, scale, grad_scale2, dQ, ldg, 0.f, 0u);         \
+                         h16(Rv), h16(Tk), h16(Rg), pos_b, lse2_b, delta_b, H, ptr, B, bscale, scale, grad_scale2, dQ, ldg, 0.f, dgdm_seed_arg(0u));         \
   } while (0)
   if (H % 2 == 0 && variant == 1) GO(2, 2);
   else if (H % 4 == 0 && variant == 2) GO(4, 2);
@@ -317,10 +319,10 @@ extern "C" int dgdm_spatial_attn_h_bwd_dkv(const void* Rq, const void* Tq, const
   do {                                                                                                                             \
     if (drop_p > 0.f)                                                                                                              \
       hipLaunchKernelGGL((k_attn_h_bwd_dkv<HG, NBUF, true>), dim3(num_blocks, H / HG), dim3(256), 0, s, h16(Rq), h16(Tq), h16(Rk),  \
-                         h16(Rv), h16(Rg), h16(Tg), pos_b, lse2_b, delta_b, H, ptr, B, bscale, kscale, grad_scale2, dK, dV, ldg, drop_p, seed); \
+                         h16(Rv), h16(Rg), h16(Tg), pos_b, lse2_b, delta_b, H, ptr, B, bscale, kscale, grad_scale2, dK, dV, ldg, drop_p, dgdm_seed_arg(seed)); \
     else                                                                                                                           \
       hipLaunchKernelGGL((k_attn_h_bwd_dkv<HG, NBUF, false>), dim3(num_blocks, H / HG), dim3(256), 0, s, h16(Rq), h16(Tq), h16(Rk), \
-                         h16(Rv), h16(Rg), h16(Tg), pos_b, lse2_b, delta_b, H, ptr, B, bscale, kscale, grad_scale2, dK, dV, ldg, 0.f, 0u);      \
+                         h16(Rv), h16(Rg), h16(Tg), pos_b, lse2_b, delta_b, H, ptr, B, bscale, kscale, grad_scale2, dK, dV, ldg, 0.f, dgdm_seed_arg(0u));      \
   } while (0)
   if (H % 4 == 0 && variant == 1) GO(4, 1);
   else if (H % 4 == 0 && variant == 2) GO(4, 2);

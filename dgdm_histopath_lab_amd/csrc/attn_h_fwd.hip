@@ -99,7 +99,8 @@ template <int HG, bool DROP>
 __global__ __launch_bounds__(256, 2) void k_attn_h_fwd(const _Float16* __restrict__ Rq, const _Float16* __restrict__ Rk,
                                                     const _Float16* __restrict__ Tv, const float* __restrict__ pos_b, int H,
                                                     const int32_t* __restrict__ ptr, int B, float bscale, float* __restrict__ O,
-                                                    int64_t ldo, float* __restrict__ lse2_b, float drop_p, uint32_t seed) {
+                                                    int64_t ldo, float* __restrict__ lse2_b, float drop_p, DgdmSeed seed_in) {
+  const uint32_t seed = seed_in.value();
   constexpr int NT = HB / 16;
   constexpr int RK_BYTES = HG * R_HEAD * 2, TV_BYTES = HG * T_HEAD * 2, POS_BYTES = HB * 8;
   constexpr int BUF_BYTES = RK_BYTES + TV_BYTES + POS_BYTES;
@@ -287,10 +288,10 @@ extern "C" int dgdm_spatial_attn_h_fwd(const void* Rq, const void* Rk, const voi
   do {                                                                                                                      \
     if (drop_p > 0.f)                                                                                                       \
       hipLaunchKernelGGL((k_attn_h_fwd<HG, true>), dim3(num_blocks, H / HG), dim3(256), 0, s, q, k, v, pos_b, H, ptr, B,    \
-                         bscale, O, ldo, lse2_b, drop_p, seed);                                                             \
+                         bscale, O, ldo, lse2_b, drop_p, dgdm_seed_arg(seed));                                                             \
     else                                                                                                                    \
       hipLaunchKernelGGL((k_attn_h_fwd<HG, false>), dim3(num_blocks, H / HG), dim3(256), 0, s, q, k, v, pos_b, H, ptr, B,   \
-                         bscale, O, ldo, lse2_b, 0.f, 0u);                                                                  \
+                         bscale, O, ldo, lse2_b, 0.f, dgdm_seed_arg(0u));                                                                  \
   } while (0)
   if (H % 4 == 0) GO(4);
   else if (H % 2 == 0) GO(2);

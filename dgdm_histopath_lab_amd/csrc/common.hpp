@@ -35,3 +35,17 @@ __device__ __forceinline__ float wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
+
+// Dropout seeds.  Every dropout site passes its seed by value (so a forward kernel and the backward
+// kernels that recompute its mask agree by construction).  A kernel launch recorded in a HIP graph
+// replays with the recorded value; to give each replay fresh masks the kernels fold in a per-device
+// step counter ("seed epoch") that lives in device memory and is advanced by a kernel of its own
+// (dgdm_seed_epoch_advance, once per training step, before the forward).  Epoch 0 (the default, and the
+// only value outside graph replay) leaves the seed unchanged.
+struct DgdmSeed {
+  uint32_t base;
+  const uint32_t* epoch;
+  __device__ __forceinline__ uint32_t value() const { return base ^ (epoch[0] * 0x9E3779B9U); }
+};
+const uint32_t* dgdm_seed_epoch_ptr();   // api.hip: address of the current device's counter
+static inline DgdmSeed dgdm_seed_arg(uint32_t seed) { return DgdmSeed{seed, dgdm_seed_epoch_ptr()}; }

@@ -10,7 +10,8 @@ namespace {
 
 template <int ACT, bool BWD>
 __global__ __launch_bounds__(256) void k_act_dropout(const float* __restrict__ x, const float* __restrict__ dy, int64_t n4,
-                                                     float drop_p, uint32_t seed, float* __restrict__ out) {
+                                                     float drop_p, DgdmSeed seed_in, float* __restrict__ out) {
+  const uint32_t seed = seed_in.value();
   const uint32_t thresh = (uint32_t)(drop_p * 65536.0f);
   const float keep_scale = drop_p > 0.f ? 1.0f / (1.0f - (float)thresh / 65536.0f) : 1.0f;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -40,7 +41,7 @@ int launch(const float* x, const float* dy, int64_t n, int32_t act, float drop_p
   const int64_t n4 = n >> 2;
   int64_t blocks = (n4 + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-#define GO(A) hipLaunchKernelGGL((k_act_dropout<A, BWD>), dim3((unsigned)blocks), dim3(256), 0, s, x, dy, n4, drop_p, seed, out)
+#define GO(A) hipLaunchKernelGGL((k_act_dropout<A, BWD>), dim3((unsigned)blocks), dim3(256), 0, s, x, dy, n4, drop_p, dgdm_seed_arg(seed), out)
   switch (act) {
     case DGDM_ACT_GELU: GO(DGDM_ACT_GELU); break;
     case DGDM_ACT_RELU: GO(DGDM_ACT_RELU); break;

@@ -31,8 +31,9 @@ __device__ __forceinline__ float seg_sum(float v) {
 template <int LPR, int R, int ACT>
 __global__ __launch_bounds__(256) void k_rownorm_fwd(const float* __restrict__ x, const float* __restrict__ res,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                     int64_t rows, int L, int G, float eps, float drop_p, uint32_t seed,
+                                                     int64_t rows, int L, int G, float eps, float drop_p, DgdmSeed seed_in,
                                                      float* __restrict__ y, float* __restrict__ mean_o, float* __restrict__ rstd_o) {
+  const uint32_t seed = seed_in.value();
   constexpr int GPW = 64 / LPR;  // pseudo-rows per wave
   const int lane = threadIdx.x & 63, sub = lane / LPR, lir = lane % LPR;
   const int64_t ngroups = (int64_t)gridDim.x * (blockDim.x >> 6) * GPW;
@@ -101,7 +102,8 @@ __global__ __launch_bounds__(256) void k_rownorm_bwd(const float* __restrict__ x
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
                                                      const float* __restrict__ dy, int64_t rows, int L, int G, float drop_p,
-                                                     uint32_t seed, float* __restrict__ dx, float* __restrict__ partial, int C) {
+                                                     DgdmSeed seed_in, float* __restrict__ dx, float* __restrict__ partial, int C) {
+  const uint32_t seed = seed_in.value();
   constexpr int GPW = 64 / LPR;
   const int lane = threadIdx.x & 63, sub = lane / LPR, lir = lane % LPR;
   const int64_t ngroups = (int64_t)gridDim.x * (blockDim.x >> 6) * GPW;  // multiple of G (host guarantees)
@@ -258,7 +260,7 @@ extern "C" int dgdm_rownorm_fwd(const float* x, const float* res, const float* g
   if (blocks > 16384) blocks = 16384;
 #define FWD(LPR_, R_, ACT_, ...) \
   hipLaunchKernelGGL((k_rownorm_fwd<LPR_, R_, ACT_>), dim3((unsigned)blocks), dim3(256), 0, s, __VA_ARGS__)
-  ROWNORM_DISPATCH(FWD, x, res, gamma, beta, rows, L, G, eps, drop_p, seed, y, mean, rstd);
+  ROWNORM_DISPATCH(FWD, x, res, gamma, beta, rows, L, G, eps, drop_p, dgdm_seed_arg(seed), y, mean, rstd);
 #undef FWD
   return dgdm_launch_status();
 }
@@ -298,7 +300,7 @@ extern "C" int dgdm_rownorm_bwd(const float* x, const float* res, const float* g
   float* partial = static_cast<float*>(workspace);
 #define BWD(LPR_, R_, ACT_, ...) \
   hipLaunchKernelGGL((k_rownorm_bwd<LPR_, R_, ACT_>), dim3((unsigned)blocks), dim3(256), 0, s, __VA_ARGS__)
-  ROWNORM_DISPATCH(BWD, x, res, gamma, beta, mean, rstd, dy, rows, L, G, drop_p, seed, dx, partial, C);
+  ROWNORM_DISPATCH(BWD, x, res, gamma, beta, mean, rstd, dy, rows, L, G, drop_p, dgdm_seed_arg(seed), dx, partial, C);
 #undef BWD
   // dgamma | dbeta = column sums of partial [slots][2C], two fixed-order stages
   float* stage1 = partial + slots * 2 * C;

@@ -110,7 +110,8 @@ __device__ __forceinline__ float drop_factor(uint32_t seed, uint64_t e, uint32_t
 template <int D>
 __global__ __launch_bounds__(256) void k_attn_pool_fwd(const float* __restrict__ K, const float* __restrict__ V, int64_t ld,
                                                        const float* __restrict__ qs, const int32_t* __restrict__ ptr, int H,
-                                                       float drop_p, uint32_t seed, float* __restrict__ P, float* __restrict__ out) {
+                                                       float drop_p, DgdmSeed seed_in, float* __restrict__ P, float* __restrict__ out) {
+  const uint32_t seed = seed_in.value();
   const int h = blockIdx.x, g = blockIdx.y;
   const int a = ptr[g], b = ptr[g + 1];
   __shared__ float red[4];
@@ -157,10 +158,11 @@ __global__ __launch_bounds__(256) void k_attn_pool_fwd(const float* __restrict__
 template <int D>
 __global__ __launch_bounds__(256) void k_attn_pool_bwd(const float* __restrict__ K, const float* __restrict__ V, int64_t ld,
                                                        const float* __restrict__ qs, const int32_t* __restrict__ ptr, int H,
-                                                       float drop_p, uint32_t seed, const float* __restrict__ P,
+                                                       float drop_p, DgdmSeed seed_in, const float* __restrict__ P,
                                                        const float* __restrict__ out, const float* __restrict__ dout,
                                                        float* __restrict__ dK, float* __restrict__ dV, int64_t ldg,
                                                        float* __restrict__ dqs_part) {
+  const uint32_t seed = seed_in.value();
   const int h = blockIdx.x, g = blockIdx.y;
   const int a = ptr[g], b = ptr[g + 1];
   __shared__ float accs[4][D];
@@ -259,7 +261,7 @@ extern "C" int dgdm_attn_pool_fwd(const float* K, const float* V, int64_t ld, co
   DGDM_REQUIRE(K && V && q_scaled && ptr && P && out);
   if ((ld & 3) || ld < (int64_t)H * D || !dgdm_aligned16(K) || !dgdm_aligned16(V)) return DGDM_ERR_UNSUPPORTED;
   hipStream_t s = static_cast<hipStream_t>(stream_);
-  POOL_DISPATCH(D, k_attn_pool_fwd, K, V, ld, q_scaled, ptr, H, drop_p, seed, P, out);
+  POOL_DISPATCH(D, k_attn_pool_fwd, K, V, ld, q_scaled, ptr, H, drop_p, dgdm_seed_arg(seed), P, out);
   return dgdm_launch_status();
 }
 
@@ -273,6 +275,6 @@ extern "C" int dgdm_attn_pool_bwd(const float* K, const float* V, int64_t ld, co
       !dgdm_aligned16(dK) || !dgdm_aligned16(dV))
     return DGDM_ERR_UNSUPPORTED;
   hipStream_t s = static_cast<hipStream_t>(stream_);
-  POOL_DISPATCH(D, k_attn_pool_bwd, K, V, ld, q_scaled, ptr, H, drop_p, seed, P, out, dout, dK, dV, ldg, dq_partial);
+  POOL_DISPATCH(D, k_attn_pool_bwd, K, V, ld, q_scaled, ptr, H, drop_p, dgdm_seed_arg(seed), P, out, dout, dK, dV, ldg, dq_partial);
   return dgdm_launch_status();
 }

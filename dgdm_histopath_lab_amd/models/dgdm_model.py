@@ -98,6 +98,7 @@ class DGDMModel(nn.Module):
         self.use_spatial_attention, self.use_hierarchical, self.pooling = use_spatial_attention, use_hierarchical, pooling
         self.num_classes, self.regression_targets = num_classes, regression_targets
         self.strict_reference = strict_reference
+        self.validate_inputs = True
         C = hidden_dims[-1]
 
         self.feature_encoder = FeatureEncoder(node_features, hidden_dims[0], dropout=dropout, activation=activation,
@@ -225,10 +226,11 @@ class DGDMModel(nn.Module):
     def forward(self, data, mode: str = "inference", return_attention: bool = False, return_embeddings: bool = False, *,
                 timesteps: Optional[Tensor] = None, noise: Optional[Tensor] = None, noise_target: Optional[Tensor] = None,
                 trace: Optional[dict] = None) -> Dict[str, Any]:
-        try:
-            self._validate_forward_inputs(data, mode, return_attention, return_embeddings)
-        except Exception as e:
-            raise ModelInferenceError(f"Input validation failed: {e}")
+        if self.validate_inputs:   # callers that validated the batch themselves (e.g. before replaying a recorded step) may switch it off
+            try:
+                self._validate_forward_inputs(data, mode, return_attention, return_embeddings)
+            except Exception as e:
+                raise ModelInferenceError(f"Input validation failed: {e}")
         try:
             plan = BatchPlan(data, data.x.device)
             h = self.feature_encoder(data.x)
@@ -300,7 +302,7 @@ class DGDMModel(nn.Module):
         else:
             target = noise
         # mean over graphs of the per-graph MSE (dgdm_model.py:430-433)
-        sizes = torch.tensor([plan.ptr[g + 1] - plan.ptr[g] for g in range(B)], dtype=torch.float32).to(dev, non_blocking=True)
+        sizes = ops.device_constant([plan.ptr[g + 1] - plan.ptr[g] for g in range(B)], torch.float32, dev)
         w = (1.0 / (sizes * node_embeddings.size(1) * B))[plan.seg]
         loss = (((pred - target) ** 2).sum(dim=1) * w).sum()
         last = slice(plan.ptr[B - 1], plan.ptr[B])
@@ -317,19 +319,29 @@ class DGDMModel(nn.Module):
         return outputs
 
     def _apply_entity_masking(self, data, mask_ratio: float, mask_indices=None, mask_token=None):
-        """dgdm_model.py:482-506: randperm(N)[:int(r*N)] rows <- one fresh randn(F) token."""
+        """dgdm_model.py:482-506: randperm(N)[:int(r*N)] rows <- one fresh randn(F) token.
+
+        A uniformly random subset of exactly int(r*N) nodes is what the reference draws; here it is the set of the
+        int(r*N) largest of N uniform variates, selected by the exact top-k kernel (K9) -- the same distribution
+        over subsets, with no host synchronisation, no sort and no scatter (torch.randperm + index_put cannot be
+        recorded in a HIP graph either).  Injected ``mask_indices`` take the indexed path."""
         n = data.x.size(0)
         num_masked = int(n * mask_ratio)
         masked = data.clone()
         if num_masked > 0:
             dev = data.x.device
-            if mask_indices is None:
-                mask_indices = torch.randperm(n, device=dev)[:num_masked]
             if mask_token is None:
                 mask_token = torch.randn(data.x.size(1), device=dev)
-            node_mask = torch.zeros(n, dtype=torch.bool, device=dev)
-            node_mask[mask_indices] = True
-            masked.x[mask_indices] = mask_token.to(data.x.dtype)
+            if mask_indices is None and data.x.is_cuda and n < 2 ** 31:
+                _, node_map = ops.topk_perm(torch.rand(n, device=dev), num_masked)
+                node_mask = node_map >= 0
+                masked.x = torch.where(node_mask.unsqueeze(1), mask_token.to(data.x.dtype), data.x)
+            else:
+                if mask_indices is None:
+                    mask_indices = torch.randperm(n, device=dev)[:num_masked]
+                node_mask = torch.zeros(n, dtype=torch.bool, device=dev)
+                node_mask[mask_indices] = True
+                masked.x[mask_indices] = mask_token.to(data.x.dtype)
             masked.node_mask = node_mask
         return masked
 

@@ -130,6 +130,22 @@ def aggregate_edge_attr(edge_attr: Optional[torch.Tensor], gs: GraphStructure) -
 
 
 # ----------------------------------------------------------------------------- K4 attention
+_DEVICE_CONSTANTS: dict = {}
+
+
+def device_constant(values, dtype: torch.dtype, device) -> torch.Tensor:
+    """Small host-known constant (graph offsets, per-graph sizes) as a device tensor, cached by value: the same
+    batch layout comes back every step, and a cached tensor means no host-to-device copy inside the step -- which a
+    HIP graph capture of the step could not record."""
+    key = (tuple(values), dtype, str(device))
+    t = _DEVICE_CONSTANTS.get(key)
+    if t is None:
+        if len(_DEVICE_CONSTANTS) > 4096:
+            _DEVICE_CONSTANTS.clear()
+        t = _DEVICE_CONSTANTS[key] = torch.tensor(list(values), dtype=dtype).to(device)
+    return t
+
+
 class AttnPlan:
     """Per-batch descriptor of the variable-length attention launch: device ``ptr`` (int32 [B+1]),
     tile counts.  Built once per batch from host-side graph offsets (no device sync)."""
@@ -145,7 +161,7 @@ class AttnPlan:
             raise _lib.DGDMKernelError("graphs of 2^24 nodes or more are not supported (24-bit index arithmetic in the attention kernels)")
         qb = lib.dgdm_spatial_attn_q_tile_rows()
         self.num_q_tiles = sum((self.ptr_host[g + 1] - self.ptr_host[g] + qb - 1) // qb for g in range(self.B))
-        self.ptr_dev = torch.tensor(self.ptr_host, dtype=torch.int32).to(device, non_blocking=True)
+        self.ptr_dev = device_constant(self.ptr_host, torch.int32, device)
 
 
 def spatial_attn_fwd_raw(q, k, v, pos, plan: AttnPlan, H: int, scale: float, inv_tau: float, variant: int = 0,
@@ -385,7 +401,7 @@ def spatial_attention_mean_weights(qkv, pos, plan: AttnPlan, H: int, scale: floa
     for n in sizes:
         offs.append(offs[-1] + n * n)
     W = torch.empty(max(offs[-1], 1), dtype=torch.float32, device=qkv.device)
-    off_dev = torch.tensor(offs[:-1], dtype=torch.int64).to(qkv.device)
+    off_dev = device_constant(offs[:-1], torch.int64, qkv.device)
     _lib.check(lib.dgdm_spatial_attn_mean_weights(q.data_ptr(), k.data_ptr(), q.stride(0), pos.data_ptr(), plan.ptr_dev.data_ptr(),
                                                   plan.B, plan.num_q_tiles, plan.N_tot, H, scale, inv_tau, lse2.data_ptr(),
                                                   W.data_ptr(), off_dev.data_ptr(), _lib.stream_ptr(qkv.device)),

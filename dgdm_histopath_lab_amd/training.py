@@ -344,3 +344,4 @@ def predict_graph(model: nn.Module, graph, return_attention: bool = False, retur
     pred["num_nodes"] = int(n_nodes if n_nodes is not None else graph.x.size(0))
     pred["num_edges"] = int(graph.edge_index.size(1)) // 2   # undirected graph stored in both directions
     return pred
+

@@ -44,6 +44,16 @@ enum { DGDM_ACT_NONE = 0, DGDM_ACT_GELU = 1, DGDM_ACT_RELU = 2, DGDM_ACT_SILU = 
 DGDM_API int dgdm_abi_version(void);
 DGDM_API const char* dgdm_error_string(int code);
 
+/* Dropout seed epoch.  Every dropout entry point takes its seed by value; forward and backward of one
+ * site agree because they are given the same value.  A launch recorded in a HIP graph replays with the
+ * recorded value, so the kernels additionally XOR in a per-device counter held in device memory:
+ *   effective seed = seed ^ (epoch * 0x9E3779B9).
+ * dgdm_seed_epoch_advance enqueues epoch += 1 (record it once per training step, before the forward, in
+ * the captured graph); dgdm_seed_epoch_set enqueues epoch = value.  The counter starts at 0, where the
+ * effective seed equals the seed: callers that never touch it see no change. */
+DGDM_API int dgdm_seed_epoch_advance(void* stream);
+DGDM_API int dgdm_seed_epoch_set(uint32_t value, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * K1  edge list -> CSR.   Replaces the index preparation of GraphConvolution.forward
  * (core/graph_layers.py:76-84: add_self_loops, degree) and fixes the scatter-add order of

@@ -120,3 +120,35 @@ def test_attn_pool_matches_dense(H, D):
     torch.manual_seed(0)
     od = ops.attn_pool(kd.detach(), qd.detach(), plan, H, D, 0.3, True)   # dropout path runs and changes the result
     assert torch.isfinite(od).all() and not torch.allclose(od, out.detach())
+
+
+def test_seed_epoch_changes_dropout_masks_and_zero_is_identity():
+    """dgdm_seed_epoch_*: epoch 0 leaves every dropout site unchanged (all other tests run there); another epoch
+    gives another mask for the same by-value seed, identically in forward and backward."""
+    from dgdm_histopath_lab_amd import _lib, ops
+    lib = _lib.load()
+    st = _lib.stream_ptr(torch.device(DEV))
+    x = torch.randn(4096, 64, device=DEV)
+    seed = 1234
+
+    def fwd():
+        y = torch.empty_like(x)
+        _lib.check(lib.dgdm_act_dropout_fwd(x.data_ptr(), x.numel(), ops.ACT_NONE, 0.25, seed, y.data_ptr(), st), "fwd")
+        return y
+
+    def bwd():
+        g = torch.ones_like(x); dx = torch.empty_like(x)
+        _lib.check(lib.dgdm_act_dropout_bwd(x.data_ptr(), g.data_ptr(), x.numel(), ops.ACT_NONE, 0.25, seed, dx.data_ptr(), st), "bwd")
+        return dx
+    try:
+        y0, y0b = fwd(), fwd()
+        assert torch.equal(y0, y0b)
+        _lib.check(lib.dgdm_seed_epoch_advance(st), "advance")
+        y1, d1 = fwd(), bwd()
+        assert not torch.equal(y1 == 0, y0 == 0)                       # another mask ...
+        assert abs((y1 == 0).float().mean().item() - 0.25) < 0.01       # ... at the same rate
+        assert torch.equal(d1 == 0, y1 == 0)                            # backward recomputes the forward's mask
+        _lib.check(lib.dgdm_seed_epoch_set(0, st), "set")
+        assert torch.equal(fwd(), y0)
+    finally:
+        _lib.check(lib.dgdm_seed_epoch_set(0, st), "set")

@@ -178,3 +178,4 @@ def test_trainer_runs_real_model_and_predicts(tmp_path):
             "regression_target_1", "graph_embedding", "node_embeddings", "num_nodes", "num_edges"} <= set(pa)
     assert pa["num_nodes"] == 200 and pa["num_edges"] == 400
     assert (pa["graph_embedding"] == pb["graph_embedding"]).all()       # same weights, eval mode: bitwise reproducible
+
