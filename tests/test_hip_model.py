@@ -119,11 +119,14 @@ def _run_both(cfgd, seed0, trace, nodes=2000, edges=8000):
 def _assert_all_grads(m, gref, tol):
     named = dict(m.named_parameters())
     live = 0
+    gmax = max(float(g.abs().max()) for g in gref.values())
     for k, gr in gref.items():
         got = named[k].grad
+        if got is None and gr.abs().max() == 0:   # e.g. edge_lin with edge_attr=None: the oracle multiplies by zeros, the kernels skip the term
+            continue
         assert got is not None, k
-        if gr.abs().max() < 1e-12:  # dead-by-construction (e.g. k_proj.bias: softmax is shift invariant)
-            assert got.abs().max() < 1e-7, k
+        if gr.abs().max() < 1e-12:  # dead-by-construction (e.g. k_proj.bias: softmax is shift invariant): rounding noise only
+            assert got.abs().max() < max(1e-7, 1e-5 * gmax), k
             continue
         assert_close(got, gr, tol, "grad " + k); live += 1
     for k, p in named.items():  # nothing receives a gradient that the oracle leaves dead (D9)
@@ -225,6 +228,47 @@ def test_large_config_full_size_graph_is_an_independent_unit():
         alone = m2(GraphBatch.from_data_list([big]).to(DEV), mode="inference")["graph_embedding"]
         both = m2(GraphBatch.from_data_list([small, big]).to(DEV), mode="inference")["graph_embedding"]
     assert_close(both[1:2], alone.double(), 1e-5, "embedding of the 50k graph alone vs in a batch")
+
+
+@pytest.mark.parametrize("variant", ["ragged", "no_edge_attr", "no_pos"])
+def test_ragged_batches_and_missing_optional_fields_match_oracle(variant):
+    """Graph sizes around the kernels' tile edges (1, 2, 63, 64, 65, 130, 777 nodes), one graph without any edge,
+    duplicate edges and pre-existing self loops; optional fields absent (edge_attr None -> zeros, encoders.py:258-261;
+    pos None -> no spatial attention, dgdm_model.py:341).  Smooth model, every live gradient against float64."""
+    from dgdm_histopath_lab_amd import GraphBatch, GraphData
+    cfgd = dict(node_features=96, hidden_dims=[128, 64, 64], num_diffusion_steps=10, attention_heads=4, use_hierarchical=False)
+    cfg = O.OracleConfig(**cfgd)
+    P = O.init_params(cfg, seed=11, perturb=0.05)
+    gen = torch.Generator().manual_seed(21)
+    graphs = []
+    for gi, n in enumerate([1, 2, 63, 64, 65, 130, 777]):
+        e = 0 if gi == 2 else (0 if n == 1 else 3 * n)
+        ei = torch.randint(0, n, (2, e), generator=gen)
+        if e >= 8:
+            ei[:, 1] = ei[:, 0]                 # duplicate edge
+            ei[1, 2] = ei[0, 2]                 # pre-existing self loop
+        graphs.append(GraphData(x=torch.randn(n, 96, generator=gen), edge_index=ei,
+                                edge_attr=None if variant == "no_edge_attr" else torch.randn(e, 32, generator=gen),
+                                pos=None if variant == "no_pos" else torch.rand(n, 2, generator=gen)))
+    batch = GraphBatch.from_data_list(graphs)
+    n = batch.x.size(0)
+    B = len(graphs)
+    rng = dict(timesteps=torch.randint(0, 10, (B,), generator=gen), noise=torch.randn(n, 64, generator=gen),
+               noise_target=torch.randn(n, 64, generator=gen))
+    mask_idx = torch.randperm(n, generator=gen)[: int(n * 0.15)]
+    mask_tok = torch.randn(96, generator=gen)
+    b64 = types.SimpleNamespace(x=batch.x.double(), edge_index=batch.edge_index,
+                                edge_attr=None if batch.edge_attr is None else batch.edge_attr.double(),
+                                pos=None if batch.pos is None else batch.pos.double(), batch=batch.batch)
+    ref, gref = O.loss_and_grads({k: v.double() for k, v in P.items()}, cfg, b64, mask_indices=mask_idx, mask_token=mask_tok.double(),
+                                 **{k: (v.double() if v.is_floating_point() else v) for k, v in rng.items()})
+    m = _model(cfgd, P)
+    out = m.pretrain_step(batch.to(DEV), mask_indices=mask_idx.to(DEV), mask_token=mask_tok.to(DEV), **{k: v.to(DEV) for k, v in rng.items()})
+    out["total_pretrain_loss"].backward()
+    for k in ("diffusion_loss", "graph_embedding", "noisy_embeddings"):
+        assert_close(out[k], ref[k], 1e-4, k)
+    assert out["graph_embedding"].shape == (B, 64)
+    assert _assert_all_grads(m, gref, 5e-4) > 40          # k_proj gradients are near-cancelling sums: half the 1e-3 contract
 
 
 def test_model_error_contract():
