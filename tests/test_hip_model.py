@@ -271,6 +271,36 @@ def test_ragged_batches_and_missing_optional_fields_match_oracle(variant):
     assert _assert_all_grads(m, gref, 5e-4) > 40          # k_proj gradients are near-cancelling sums: half the 1e-3 contract
 
 
+@pytest.mark.parametrize("sizes", [[1], [2, 1], [5], [3, 9, 1, 17]])
+def test_tiny_batches_through_the_unet_match_oracle(sizes):
+    """The hierarchical path at degenerate sizes: top-k levels shrink to k = max(1, int(0.5 N)) = 1 node, graphs lose
+    all their edges after pooling (graph_layers.py:298-327).  Forward outputs against the oracle; backward must run."""
+    from dgdm_histopath_lab_amd import GraphBatch, GraphData
+    cfgd = dict(node_features=32, hidden_dims=[32, 32, 32], num_diffusion_steps=10, attention_heads=2)
+    cfg = O.OracleConfig(**cfgd)
+    P = O.init_params(cfg, seed=4, perturb=0.05)
+    gen = torch.Generator().manual_seed(sum(sizes))
+    graphs = []
+    for n in sizes:
+        e = 0 if n == 1 else 2 * n
+        graphs.append(GraphData(x=torch.randn(n, 32, generator=gen), edge_index=torch.randint(0, n, (2, e), generator=gen),
+                                edge_attr=torch.randn(e, 32, generator=gen), pos=torch.rand(n, 2, generator=gen)))
+    batch = GraphBatch.from_data_list(graphs)
+    n, B = batch.x.size(0), len(sizes)
+    rng = dict(timesteps=torch.randint(0, 10, (B,), generator=gen), noise=torch.randn(n, 32, generator=gen),
+               noise_target=torch.randn(n, 32, generator=gen))
+    b64 = types.SimpleNamespace(x=batch.x.double(), edge_index=batch.edge_index, edge_attr=batch.edge_attr.double(),
+                                pos=batch.pos.double(), batch=batch.batch)
+    ref = O.forward({k: v.double() for k, v in P.items()}, cfg, b64, mode="pretrain",
+                    **{k: (v.double() if v.is_floating_point() else v) for k, v in rng.items()})
+    m = _model(cfgd, P)
+    out = m(batch.to(DEV), mode="pretrain", **{k: v.to(DEV) for k, v in rng.items()})
+    for k in ("diffusion_loss", "graph_embedding"):
+        assert_close(out[k], ref[k], TOL, k)
+    out["diffusion_loss"].backward()
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
+
+
 def test_model_error_contract():
     from dgdm_histopath_lab_amd import DGDMModel, GraphData, ModelConfigurationError, ModelInferenceError
     with pytest.raises(ModelConfigurationError):
