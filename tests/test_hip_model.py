@@ -87,18 +87,18 @@ def test_model_matches_reference_golden(tag, attn, monkeypatch):
     assert named["spatial_attention.pos_encoding"].grad is None  # dead parameters stay dead (D9)
 
 
-def _run_both(cfgd, seed0, trace, nodes=2000, edges=8000):
+def _run_both(cfgd, seed0, trace, nodes=2000, edges=8000, graphs=2):
     """One pretrain_step (masking + injected draws) on the HIP path and on the float64 oracle.
     The arbiter runs in float64 (same oracle code): fp32-vs-fp32 would fold the CPU path's own
     rounding into the comparison."""
     from dgdm_histopath_lab_amd.synthetic import synthetic_batch
     cfg = O.OracleConfig(**cfgd)
     P = O.init_params(cfg, seed=3, perturb=0.05)
-    batch = synthetic_batch(seed0, 2, nodes, edges)
+    batch = synthetic_batch(seed0, graphs, nodes, edges)
     gen = torch.Generator().manual_seed(11 + seed0)
     n = batch.x.size(0)
     c_last, T = cfgd["hidden_dims"][-1], cfgd["num_diffusion_steps"]
-    rng = dict(timesteps=torch.tensor([2, T - 1]), noise=torch.randn(n, c_last, generator=gen),
+    rng = dict(timesteps=torch.tensor([2, T - 1][:graphs]), noise=torch.randn(n, c_last, generator=gen),
                noise_target=torch.randn(n, c_last, generator=gen))
     mask_idx = torch.randperm(n, generator=gen)[: int(n * 0.15)]
     mask_tok = torch.randn(768, generator=gen)
@@ -299,6 +299,40 @@ def test_tiny_batches_through_the_unet_match_oracle(sizes):
         assert_close(out[k], ref[k], TOL, k)
     out["diffusion_loss"].backward()
     assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
+
+
+def test_forward_matches_oracle_at_the_headline_graph_size():
+    """One BASELINE configs[1] graph (10 000 nodes / 50 000 edges, 768 features, Base dims) through encoder, spatial
+    attention, diffusion loss and attention pooling: forward outputs against the float64 oracle (the U-Net is left out because a single top-k flip among 10 000 scores would move a node)."""
+    from dgdm_histopath_lab_amd.synthetic import synthetic_batch
+    cfgd = dict(node_features=768, hidden_dims=[512, 256, 128], num_diffusion_steps=10, attention_heads=8, use_hierarchical=False)
+    cfg = O.OracleConfig(**cfgd)
+    P = O.init_params(cfg, seed=3, perturb=0.05)
+    batch = synthetic_batch(0, 1, 10000, 50000)
+    gen = torch.Generator().manual_seed(99)
+    n = batch.x.size(0)
+    rng = dict(timesteps=torch.tensor([4]), noise=torch.randn(n, 128, generator=gen), noise_target=torch.randn(n, 128, generator=gen))
+    torch.set_num_threads(32)
+    b64 = types.SimpleNamespace(x=batch.x.double(), edge_index=batch.edge_index, edge_attr=batch.edge_attr.double(),
+                                pos=batch.pos.double(), batch=batch.batch)
+    with torch.no_grad():
+        ref = O.forward({k: v.double() for k, v in P.items()}, cfg, b64, mode="pretrain", return_embeddings=True,
+                        **{k: (v.double() if v.is_floating_point() else v) for k, v in rng.items()})
+        m = _model(cfgd, P)
+        out = m(batch.to(DEV), mode="pretrain", return_embeddings=True, **{k: v.to(DEV) for k, v in rng.items()})
+    for k in ("diffusion_loss", "graph_embedding", "node_embeddings", "noisy_embeddings"):
+        assert_close(out[k], ref[k], 2e-4, k)
+
+
+def test_gradients_match_oracle_at_the_headline_graph_size():
+    """The same graph, one full pretrain_step (masking, forward, backward): every live parameter gradient against the
+    float64 oracle (dense 10 000 x 10 000 x 8 attention in float64 on the host: ~10 s on the GPU box's cores)."""
+    cfgd = dict(node_features=768, hidden_dims=[512, 256, 128], num_diffusion_steps=10, attention_heads=8, use_hierarchical=False)
+    torch.set_num_threads(32)
+    m, out, ref, gref, _, _ = _run_both(cfgd, 7, trace=False, nodes=10000, edges=50000, graphs=1)
+    for k in ("diffusion_loss", "graph_embedding", "noisy_embeddings"):
+        assert_close(out[k], ref[k], 2e-4, k)
+    assert _assert_all_grads(m, gref, 5e-4) > 60
 
 
 def test_model_error_contract():
