@@ -3,15 +3,13 @@
 // _to_pytorch_geometric, preprocessing/tissue_graph_builder.py:269-414, which run scikit-learn
 // NearestNeighbors + cosine_similarity and Python loops on the CPU).
 //
-//   dgdm_knn2d            K nearest points (self included) of every 2-D coordinate, brute force through
-//                         LDS tiles, ascending by (distance, index); squared distances are formed as
-//                         fl(fl(dx*dx) + fl(dy*dy)) (no FMA contraction), so a float32 CPU restatement
-//                         reproduces indices and distances bit for bit
+//   dgdm_knn2d            K nearest points (self included) of every 2-D coordinate, brute force, one wave per
+//                         query with the running top-K spread over its lanes, ascending by (distance, index);
+//                         squared distances are formed as fl(fl(dx*dx) + fl(dy*dy)) (no FMA contraction), so a
+//                         float32 CPU restatement reproduces indices and distances bit for bit
 //   dgdm_row_sqnorm       ||x_i||^2
-//   dgdm_knn_gram_partial / dgdm_knn_gram_merge
-//                         K nearest rows in feature space from a Gram block G^T[j][q] = x_j . x_q
-//                         (produced by the GEMM kernels): d^2 = |x_q|^2 + |x_j|^2 - 2 G, candidates
-//                         split into segments (parallelism), merged in index order (same tie rule)
+//   dgdm_knn_gram         K nearest rows in feature space from Gram rows G[q][j] = x_q . x_j (produced by the
+//                         GEMM kernels): d^2 = |x_q|^2 + |x_j|^2 - 2 G, same wave-per-query selection
 //   dgdm_edge_candidates  spatial (weight exp(-10 d) >= thr) and morphological (cosine >= thr)
 //                         candidates in the reference's enumeration order
 //   dgdm_edge_dedup_*     key = sorted (src, tgt): keep the heaviest candidate (earliest wins ties),
@@ -24,49 +22,60 @@
 
 namespace {
 
-// branch-free stable insertion of (d, i, g) into an ascending list (strict <: equal keys keep scan order)
-template <int KMAX, bool WITH_G>
-__device__ __forceinline__ void list_insert(float (&bd)[KMAX], int (&bi)[KMAX], float (&bg)[KMAX], float d, int i, float g) {
-  bool sw = false;   // once the insertion point is found every later slot just shifts (equal keys keep their order)
-#pragma unroll
-  for (int p = 0; p < KMAX; ++p) {
-    sw = sw || d < bd[p];
-    const float td = bd[p]; const int ti = bi[p];
-    bd[p] = sw ? d : td; bi[p] = sw ? i : ti;
-    d = sw ? td : d; i = sw ? ti : i;
-    if (WITH_G) { const float tg = bg[p]; bg[p] = sw ? g : tg; g = sw ? tg : g; }
+// Wave-cooperative top-K: one wave per query.  The current K best (d2, index, g) live one per lane (lane i = i-th
+// best, lanes >= K hold +inf), so the threshold is a readlane away.  Each iteration the 64 lanes score 64
+// consecutive candidates; a ballot finds the few that beat the threshold (K ln(N/K) of N over the whole scan),
+// and those are inserted one at a time in index order: position = number of kept entries <= the candidate
+// (existing equals stay in front: ties keep ascending index), the tail shifts one lane up.
+struct TopK {
+  float d;
+  int i;
+  float g;
+  __device__ __forceinline__ void init() { d = __builtin_inff(); i = -1; g = 0.f; }
+  __device__ __forceinline__ float threshold(int K) const { return __shfl(d, K - 1, 64); }
+  // all lanes call; (cd, ci, cg) are wave-uniform
+  __device__ __forceinline__ void insert(float cd, int ci, float cg, int lane) {
+    const unsigned long long le = __ballot(d <= cd);
+    const int p = __popcll(le);                       // kept entries that stay in front (the list is sorted: a prefix)
+    const float ud = __shfl_up(d, 1, 64), ug = __shfl_up(g, 1, 64);
+    const int ui = __shfl_up(i, 1, 64);
+    if (lane == p) { d = cd; i = ci; g = cg; }
+    else if (lane > p) { d = ud; i = ui; g = ug; }
   }
-}
-
-constexpr int KNN_TILE = 1024;
-
-template <int KMAX>
-__global__ __launch_bounds__(128) void k_knn2d(const float* __restrict__ coords, int N, int K, int32_t* __restrict__ idx,
-                                                float* __restrict__ dist) {
-  __shared__ float2 tile[KNN_TILE];
-  const int q = blockIdx.x * 128 + threadIdx.x;
-  const float2 me = q < N ? reinterpret_cast<const float2*>(coords)[q] : make_float2(0.f, 0.f);
-  float bd[KMAX], bg[KMAX];
-  int bi[KMAX];
-#pragma unroll
-  for (int p = 0; p < KMAX; ++p) { bd[p] = __builtin_inff(); bi[p] = -1; bg[p] = 0.f; }
-  for (int t0 = 0; t0 < N; t0 += KNN_TILE) {
-    __syncthreads();
-    for (int t = threadIdx.x; t < KNN_TILE; t += 128)
-      if (t0 + t < N) tile[t] = reinterpret_cast<const float2*>(coords)[t0 + t];
-    __syncthreads();
-    const int lim = min(KNN_TILE, N - t0);
-    for (int t = 0; t < lim; ++t) {
-      const float dx = __fsub_rn(me.x, tile[t].x), dy = __fsub_rn(me.y, tile[t].y);
-      const float d2 = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
-      if (d2 < bd[KMAX - 1]) list_insert<KMAX, false>(bd, bi, bg, d2, t0 + t, 0.f);
+  __device__ __forceinline__ void offer(float cd, int ci, float cg, int K, int lane) {
+    float thr = threshold(K);
+    unsigned long long m = __ballot(cd < thr);
+    while (m) {                                        // wave-uniform loop over the candidates that qualify, lowest index first
+      const int src = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      const float sd = __shfl(cd, src, 64);
+      if (sd < thr) {                                  // the threshold may have dropped since the ballot
+        insert(sd, __shfl(ci, src, 64), __shfl(cg, src, 64), lane);
+        thr = threshold(K);
+      }
     }
   }
-  if (q < N) {
-#pragma unroll
-    for (int p = 0; p < KMAX; ++p)
-      if (p < K) { idx[(int64_t)q * K + p] = bi[p]; dist[(int64_t)q * K + p] = sqrtf(bd[p]); }
+};
+
+__global__ __launch_bounds__(256) void k_knn2d(const float* __restrict__ coords, int N, int K, int32_t* __restrict__ idx,
+                                                float* __restrict__ dist) {
+  const int lane = threadIdx.x & 63;
+  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= N) return;                                  // whole wave
+  const float2 me = reinterpret_cast<const float2*>(coords)[q];
+  TopK best;
+  best.init();
+  for (int j0 = 0; j0 < N; j0 += 64) {
+    const int j = j0 + lane;
+    float d2 = __builtin_inff();
+    if (j < N) {
+      const float2 c = reinterpret_cast<const float2*>(coords)[j];
+      const float dx = __fsub_rn(me.x, c.x), dy = __fsub_rn(me.y, c.y);
+      d2 = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
+    }
+    best.offer(d2, j, 0.f, K, lane);
   }
+  if (lane < K) { idx[(int64_t)q * K + lane] = best.i; dist[(int64_t)q * K + lane] = sqrtf(best.d); }
 }
 
 __global__ __launch_bounds__(256) void k_row_sqnorm(const float* __restrict__ X, int64_t ldx, int N, int F, float* __restrict__ sq) {
@@ -82,58 +91,32 @@ __global__ __launch_bounds__(256) void k_row_sqnorm(const float* __restrict__ X,
   if (sub == 0 && row < N) sq[row] = acc;
 }
 
-// partial[(seg * B + q) * KMAX + p] = p-th nearest candidate of query q0 + q among rows [seg*per, (seg+1)*per)
-struct KnnRec { float d2; int32_t idx; float g; };
-
-template <int KMAX>
-__global__ __launch_bounds__(128) void k_knn_gram_partial(const float* __restrict__ GT, int64_t ldg, const float* __restrict__ sq, int N,
-                                                          int q0, int B, int per, KnnRec* __restrict__ partial) {
-  const int q = blockIdx.x * 128 + threadIdx.x, seg = blockIdx.y;
+// feature-space kNN of query q0 + q from its Gram row G[q][j] = x_(q0+q) . x_j (row-major, contiguous over j)
+__global__ __launch_bounds__(256) void k_knn_gram(const float* __restrict__ G, int64_t ldg, const float* __restrict__ sq, int N, int q0,
+                                                   int B, int K, int32_t* __restrict__ idx, float* __restrict__ sim) {
+  const int lane = threadIdx.x & 63;
+  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (q >= B) return;
   const float sqq = sq[q0 + q];
-  float bd[KMAX], bg[KMAX];
-  int bi[KMAX];
-#pragma unroll
-  for (int p = 0; p < KMAX; ++p) { bd[p] = __builtin_inff(); bi[p] = -1; bg[p] = 0.f; }
-  const int j0 = seg * per, j1 = min(N, j0 + per);
-  for (int j = j0; j < j1; ++j) {
-    const float g = GT[(int64_t)j * ldg + q];          // consecutive threads = consecutive queries: coalesced
-    float d2 = fmaxf(sqq + sq[j] - 2.f * g, 0.f);
-    if (j == q0 + q) d2 = 0.f;                           // the point itself
-    if (d2 < bd[KMAX - 1]) list_insert<KMAX, true>(bd, bi, bg, d2, j, g);
-  }
-  KnnRec* out = partial + ((int64_t)seg * B + q) * KMAX;
-#pragma unroll
-  for (int p = 0; p < KMAX; ++p) out[p] = KnnRec{bd[p], bi[p], bg[p]};
-}
-
-template <int KMAX>
-__global__ __launch_bounds__(128) void k_knn_gram_merge(const KnnRec* __restrict__ partial, int nseg, int q0, int B, int K,
-                                                        const float* __restrict__ sq, int32_t* __restrict__ idx,
-                                                        float* __restrict__ sim) {
-  const int q = blockIdx.x * 128 + threadIdx.x;
-  if (q >= B) return;
-  float bd[KMAX], bg[KMAX];
-  int bi[KMAX];
-#pragma unroll
-  for (int p = 0; p < KMAX; ++p) { bd[p] = __builtin_inff(); bi[p] = -1; bg[p] = 0.f; }
-  for (int s = 0; s < nseg; ++s) {   // segments in index order, each list ascending: the (distance, index) order survives
-    const KnnRec* in = partial + ((int64_t)s * B + q) * KMAX;
-    for (int p = 0; p < KMAX; ++p) {
-      const KnnRec r = in[p];
-      if (r.idx < 0 || !(r.d2 < bd[KMAX - 1])) break;
-      list_insert<KMAX, true>(bd, bi, bg, r.d2, r.idx, r.g);
+  const float* row = G + (int64_t)q * ldg;
+  TopK best;
+  best.init();
+  for (int j0 = 0; j0 < N; j0 += 64) {
+    const int j = j0 + lane;
+    float d2 = __builtin_inff(), g = 0.f;
+    if (j < N) {
+      g = row[j];
+      d2 = fmaxf(sqq + sq[j] - 2.f * g, 0.f);
+      if (j == q0 + q) d2 = 0.f;                         // the point itself
     }
+    best.offer(d2, j, g, K, lane);
   }
-  const float nq = sqrtf(sq[q0 + q]);
-#pragma unroll
-  for (int p = 0; p < KMAX; ++p)
-    if (p < K) {
-      const int j = bi[p];
-      idx[(int64_t)(q0 + q) * K + p] = j;
-      const float nj = j >= 0 ? sqrtf(sq[j]) : 0.f;
-      sim[(int64_t)(q0 + q) * K + p] = (nq > 0.f && nj > 0.f) ? bg[p] / (nq * nj) : 0.f;
-    }
+  if (lane < K) {
+    const int j = best.i;
+    const float nq = sqrtf(sqq), nj = j >= 0 ? sqrtf(sq[j]) : 0.f;
+    idx[(int64_t)(q0 + q) * K + lane] = j;
+    sim[(int64_t)(q0 + q) * K + lane] = (nq > 0.f && nj > 0.f) ? best.g / (nq * nj) : 0.f;
+  }
 }
 
 // cosine similarity of every (row, neighbour) pair from a direct dot product in a fixed order: the
@@ -334,8 +317,6 @@ __global__ __launch_bounds__(256) void k_edge_emit(const int32_t* __restrict__ w
   }
 }
 
-int kmax_of(int K) { return K <= 9 ? 9 : (K <= 17 ? 17 : (K <= 33 ? 33 : 0)); }
-
 inline int64_t table_capacity(int64_t L) {
   int64_t cap = 1024;
   while (cap < 2 * L) cap <<= 1;
@@ -367,13 +348,8 @@ extern "C" int dgdm_knn2d(const float* coords, int32_t N, int32_t K, int32_t* id
   if (N == 0) return DGDM_OK;
   if (!coords || !idx || !dist) return DGDM_ERR_INVALID_ARG;
   if (K > N) return DGDM_ERR_INVALID_ARG;
-  const int km = kmax_of(K);
-  if (!km || (reinterpret_cast<uintptr_t>(coords) & 7u)) return DGDM_ERR_UNSUPPORTED;
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  const dim3 grid((N + 127) / 128);
-  if (km == 9) hipLaunchKernelGGL(k_knn2d<9>, grid, dim3(128), 0, s, coords, N, K, idx, dist);
-  else if (km == 17) hipLaunchKernelGGL(k_knn2d<17>, grid, dim3(128), 0, s, coords, N, K, idx, dist);
-  else hipLaunchKernelGGL(k_knn2d<33>, grid, dim3(128), 0, s, coords, N, K, idx, dist);
+  if (K > 64 || (reinterpret_cast<uintptr_t>(coords) & 7u)) return DGDM_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(k_knn2d, dim3((N + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), coords, N, K, idx, dist);
   return dgdm_launch_status();
 }
 
@@ -386,33 +362,20 @@ extern "C" int dgdm_row_sqnorm(const float* X, int64_t ldx, int32_t N, int32_t F
   return dgdm_launch_status();
 }
 
-constexpr int GRAM_SEGMENTS = 16;
-
 extern "C" size_t dgdm_knn_gram_workspace_bytes(int32_t B, int32_t K) {
-  const int km = kmax_of(K);
-  if (B <= 0 || !km) return 0;
-  return (size_t)GRAM_SEGMENTS * B * km * sizeof(KnnRec);
+  (void)B; (void)K;
+  return 0;   // the wave-cooperative selection needs no scratch (kept in the ABI for callers sized against it)
 }
 
-extern "C" int dgdm_knn_gram(const float* GT, int64_t ldg, const float* sq, int32_t N, int32_t q0, int32_t B, int32_t K, int32_t* idx,
+extern "C" int dgdm_knn_gram(const float* G, int64_t ldg, const float* sq, int32_t N, int32_t q0, int32_t B, int32_t K, int32_t* idx,
                              float* sim, void* workspace, size_t workspace_bytes, void* stream) {
+  (void)workspace; (void)workspace_bytes;
   if (N < 0 || B < 0 || q0 < 0 || K < 1 || q0 + B > N) return DGDM_ERR_INVALID_ARG;
   if (B == 0) return DGDM_OK;
-  if (!GT || !sq || !idx || !sim || !workspace || ldg < B) return DGDM_ERR_INVALID_ARG;
+  if (!G || !sq || !idx || !sim || ldg < N) return DGDM_ERR_INVALID_ARG;
   if (K > N) return DGDM_ERR_INVALID_ARG;
-  const int km = kmax_of(K);
-  if (!km) return DGDM_ERR_UNSUPPORTED;
-  if (workspace_bytes < dgdm_knn_gram_workspace_bytes(B, K)) return DGDM_ERR_WORKSPACE;
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  KnnRec* partial = static_cast<KnnRec*>(workspace);
-  const int per = (N + GRAM_SEGMENTS - 1) / GRAM_SEGMENTS;
-  const int nseg = (N + per - 1) / per;
-  const dim3 g1((B + 127) / 128, nseg), g2((B + 127) / 128);
-#define DGDM_KNN_LAUNCH(KM)                                                                                             \
-  hipLaunchKernelGGL(k_knn_gram_partial<KM>, g1, dim3(128), 0, s, GT, ldg, sq, N, q0, B, per, partial);                 \
-  hipLaunchKernelGGL(k_knn_gram_merge<KM>, g2, dim3(128), 0, s, partial, nseg, q0, B, K, sq, idx, sim);
-  if (km == 9) { DGDM_KNN_LAUNCH(9) } else if (km == 17) { DGDM_KNN_LAUNCH(17) } else { DGDM_KNN_LAUNCH(33) }
-#undef DGDM_KNN_LAUNCH
+  if (K > 64) return DGDM_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(k_knn_gram, dim3((B + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), G, ldg, sq, N, q0, B, K, idx, sim);
   return dgdm_launch_status();
 }
 

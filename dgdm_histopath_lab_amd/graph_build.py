@@ -63,11 +63,11 @@ class TissueGraphBuilder:
         B = min(self.query_block, n)
         wsb = lib.dgdm_knn_gram_workspace_bytes(B, K)
         ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=x.device)
-        gt = torch.empty(n, B, dtype=torch.float32, device=x.device)
+        g = torch.empty(B, n, dtype=torch.float32, device=x.device)
         for q0 in range(0, n, B):
             b = min(B, n - q0)
-            ops.gemm_nt_raw(x, x[q0:q0 + b], None, out=gt[:, :b], math=self.gemm_math)      # GT[j][q] = x_j . x_(q0+q)
-            _lib.check(lib.dgdm_knn_gram(gt.data_ptr(), gt.stride(0), sq.data_ptr(), n, q0, b, K, idx.data_ptr(), sim.data_ptr(),
+            ops.gemm_nt_raw(x[q0:q0 + b], x, None, out=g[:b], math=self.gemm_math)          # G[q][j] = x_(q0+q) . x_j
+            _lib.check(lib.dgdm_knn_gram(g.data_ptr(), g.stride(0), sq.data_ptr(), n, q0, b, K, idx.data_ptr(), sim.data_ptr(),
                                          ws.data_ptr(), wsb, st), "dgdm_knn_gram")
         # bitwise-symmetric similarities for the duplicate rule (and a direct dot product instead of the Gram value)
         _lib.check(lib.dgdm_pair_cosine(x.data_ptr(), x.stride(0), sq.data_ptr(), idx.data_ptr(), n, K, f, sim.data_ptr(), st),

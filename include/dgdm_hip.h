@@ -337,12 +337,12 @@ DGDM_API int dgdm_unpool_add_relu_bwd(const float* g, int64_t ldg, const float* 
  *           _remove_duplicate_edges and the edge part of _to_pytorch_geometric --
  *           preprocessing/tissue_graph_builder.py:286-357, 384-402 (scikit-learn kNN + Python loops).
  *   dgdm_knn2d       : for every 2-D point the K nearest points (itself included), ascending by
- *                      (distance, index): idx int32 [N, K], dist float [N, K].  1 <= K <= min(N, 33).
+ *                      (distance, index): idx int32 [N, K], dist float [N, K].  1 <= K <= min(N, 64).
  *                      d^2 = fl(fl(dx*dx) + fl(dy*dy)), d = sqrt correctly rounded: a float32 CPU
  *                      restatement reproduces both outputs bit for bit.
  *   dgdm_row_sqnorm  : sq[i] = |x_i|^2
- *   dgdm_knn_gram    : feature-space kNN of the query rows [q0, q0+B) from a Gram block
- *                      GT[j][q] = x_j . x_(q0+q)  (float [N, ldg >= B], from dgdm_gemm_nt*):
+ *   dgdm_knn_gram    : feature-space kNN of the query rows [q0, q0+B) from their Gram rows
+ *                      G[q][j] = x_(q0+q) . x_j  (float [B, ldg >= N], from dgdm_gemm_nt*):
  *                      writes rows q0..q0+B-1 of idx int32 [N, K] and of sim float [N, K]
  *                      (cosine similarity of the pair, from the Gram value).  Same ordering rule as
  *                      dgdm_knn2d.
@@ -361,7 +361,7 @@ DGDM_API int dgdm_unpool_add_relu_bwd(const float* g, int64_t ldg, const float* 
 DGDM_API int dgdm_knn2d(const float* coords, int32_t N, int32_t K, int32_t* idx, float* dist, void* stream);
 DGDM_API int dgdm_row_sqnorm(const float* X, int64_t ldx, int32_t N, int32_t F, float* sq, void* stream);
 DGDM_API size_t dgdm_knn_gram_workspace_bytes(int32_t B, int32_t K);
-DGDM_API int dgdm_knn_gram(const float* GT, int64_t ldg, const float* sq, int32_t N, int32_t q0, int32_t B, int32_t K, int32_t* idx,
+DGDM_API int dgdm_knn_gram(const float* G, int64_t ldg, const float* sq, int32_t N, int32_t q0, int32_t B, int32_t K, int32_t* idx,
                            float* sim, void* workspace, size_t workspace_bytes, void* stream);
 DGDM_API int dgdm_pair_cosine(const float* X, int64_t ldx, const float* sq, const int32_t* idx, int32_t N, int32_t K, int32_t F,
                               float* sim, void* stream);
