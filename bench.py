@@ -81,6 +81,35 @@ def gather_microbench(dev, iters=200):
             "algorithmic_bytes": by}
 
 
+def projection_microbench(dev, iters=50):
+    """The largest dense contraction of the step (FeatureEncoder first layer: [4 x 10k, 768] x [512, 768]^T) on the
+    shipped GEMM kernel: algorithmic fp32 FLOP against the fp32 matrix peak, issued bf16 FLOP (6 MFMAs per product
+    term, csrc/gemm3.hip) against the bf16 peak."""
+    from dgdm_histopath_lab_amd import ops
+    m, k, n = NODES * PER_GPU_BATCH, FEATS, 512
+    x = torch.randn(m, k, device=dev); w = torch.randn(n, k, device=dev) / k ** 0.5; b = torch.randn(n, device=dev)
+    math = "bf16x3" if ops.GEMM_FWD_BACKEND == "bf16x3" else "fp32"
+    y = torch.empty(m, n, device=dev)
+    for _ in range(5):
+        ops.gemm_nt_raw(x, w, b, out=y, math=math)
+    a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); a.record()
+    for _ in range(iters):
+        ops.gemm_nt_raw(x, w, b, out=y, math=math)
+    e.record(); torch.cuda.synchronize()
+    us = a.elapsed_time(e) * 1e3 / iters
+    fl = 2.0 * m * k * n
+    tf = fl / us / 1e6
+    out = {"kernel": "dgdm_gemm_nt_bf16x3 (k_gemm3_rows<true,false>)" if math == "bf16x3" else "dgdm_gemm_nt (k_gemm_rows)",
+           "workload": f"[{m}, {k}] x [{n}, {k}]^T + bias", "bound": "mfma", "achieved": round(tf, 1), "peak": FP32_MFMA_PEAK_TFLOPS,
+           "unit": "TFLOP/s", "frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4), "us_per_launch": round(us, 1), "algorithmic_flop": fl,
+           "traffic": None}   # the committed PMC pass averages this kernel over all shapes of a step: not comparable per launch
+    if math == "bf16x3":
+        out.update({"mfma_dtype": "bf16 x3 exact split, fp32 accumulate", "issued_tflops": round(6 * tf, 1),
+                    "issued_frac_of_bf16_peak": round(6 * tf / FP16_MFMA_PEAK_TFLOPS, 4)})
+    return out
+
+
 def cpu_baseline(nodes, edges):
     """CPU oracle (port of the reference path incl. its dense attention + dropout) on ONE slide,
     one fwd+bwd step after one warm-up step at a reduced size."""
@@ -251,6 +280,7 @@ def main():
     if rank == 0:
         if not args.no_gather:
             result["gather_roofline"] = gather_microbench(dev)
+            result["projection_roofline"] = projection_microbench(dev)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.nodes, args.edges)
         print(json.dumps(result), flush=True)
