@@ -365,25 +365,37 @@ __global__ __launch_bounds__(256, 2) void k_gemm3_tn_partial(const float* __rest
   }
 }
 
-// dW[n][k] / db[n] = sum over slots of in[slot][n*K + k] / in[slot][N*K + n]; fixed order.
+// dW[n][k] / db[n] = sum over slots of in[slot][n*K + k] / in[slot][N*K + n]; fixed order: thread (column, part)
+// adds slots part, part + PARTS, ... in order, the PARTS partial sums are added in order.  256 / PARTS columns per
+// block: 4 parts for a few chunks, 16 parts when a small output was cut into hundreds of row chunks (one launch
+// instead of a staged column sum plus a final pass).
+template <int PARTS>
 __global__ __launch_bounds__(256) void k_gemm3_tn_final(const float* __restrict__ in, int slots, int64_t width, int N, int K,
                                                         float* __restrict__ dW, int64_t lddw, float* __restrict__ db) {
-  const int64_t col = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
-  const int part = threadIdx.x >> 6;
-  float acc = 0.f;
-  if (col < width)
-    for (int s = part; s < slots; s += 4) acc += in[(int64_t)s * width + col];
-  __shared__ float sm[4][64];
-  sm[part][threadIdx.x & 63] = acc;
+  constexpr int COLS = 256 / PARTS;
+  const int c = threadIdx.x % COLS, part = threadIdx.x / COLS;
+  const int64_t col = (int64_t)blockIdx.x * COLS + c;
+  float a0 = 0.f, a1 = 0.f;
+  if (col < width) {
+    int s = part;
+    for (; s + PARTS < slots; s += 2 * PARTS) {       // two independent loads in flight
+      a0 += in[(int64_t)s * width + col];
+      a1 += in[(int64_t)(s + PARTS) * width + col];
+    }
+    if (s < slots) a0 += in[(int64_t)s * width + col];
+  }
+  __shared__ float sm[PARTS][COLS];
+  sm[part][c] = a0 + a1;
   __syncthreads();
   if (part == 0 && col < width) {
-    const float t = (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+    float t = sm[0][c];
+#pragma unroll
+    for (int p = 1; p < PARTS; ++p) t += sm[p][c];
     const int64_t nk = (int64_t)N * K;
     if (col < nk) dW[(col / K) * lddw + col % K] = t; else db[col - nk] = t;
   }
 }
 
-constexpr int TN3_STAGE_SLOTS = 16;
 constexpr int LDS_BYTES = 2 * STAGE;   // 73728: above the 64 KiB static limit, so dynamic
 
 int tn3_chunk_rows(int M, int N, int K) {
@@ -451,7 +463,7 @@ extern "C" size_t dgdm_gemm_tn_bf16x3_workspace_bytes(int32_t M, int32_t N, int3
   const int chunk = tn3_chunk_rows(M, N, K);
   const int nchunks = (M + chunk - 1) / chunk;
   const size_t width = (size_t)N * K + (with_bias ? N : 0);
-  return (size_t)(nchunks + (nchunks > 32 ? TN3_STAGE_SLOTS : 0)) * width * sizeof(float);
+  return (size_t)nchunks * width * sizeof(float);
 }
 
 extern "C" int dgdm_gemm_tn_bf16x3(const float* dY, int64_t ldy, const float* X, int64_t ldx, float* dW, int64_t lddw, float* db,
@@ -472,8 +484,7 @@ extern "C" int dgdm_gemm_tn_bf16x3(const float* dY, int64_t ldy, const float* X,
   const int nchunks = (M + chunk - 1) / chunk;
   const int64_t width = (int64_t)N * K + (db ? N : 0);
   if (width > 0x7fffffffLL) return DGDM_ERR_UNSUPPORTED;
-  const bool staged = nchunks > 32;
-  if (workspace_bytes < (size_t)(nchunks + (staged ? TN3_STAGE_SLOTS : 0)) * width * sizeof(float)) return DGDM_ERR_WORKSPACE;
+  if (workspace_bytes < (size_t)nchunks * width * sizeof(float)) return DGDM_ERR_WORKSPACE;
   float* partial = static_cast<float*>(workspace);
   const dim3 grid((N + BM - 1) / BM, (K + BN - 1) / BN, nchunks);
   if (db) {
@@ -483,16 +494,9 @@ extern "C" int dgdm_gemm_tn_bf16x3(const float* dY, int64_t ldy, const float* X,
     if (allow_big_lds(k_gemm3_tn_partial<false>) != DGDM_OK) return DGDM_ERR_LAUNCH;
     hipLaunchKernelGGL(k_gemm3_tn_partial<false>, grid, dim3(256), LDS_BYTES, s, dY, ldy, X, ldx, M, N, K, chunk, 0, partial);
   }
-  const float* fin = partial;
-  int slots = nchunks;
-  if (staged) {
-    float* stage = partial + (int64_t)nchunks * width;
-    const int64_t per = (nchunks + TN3_STAGE_SLOTS - 1) / TN3_STAGE_SLOTS;
-    slots = (int)((nchunks + per - 1) / per);
-    hipLaunchKernelGGL(k_colsum, dim3((unsigned)((width + 63) / 64), slots), dim3(256), 0, s, partial, (int64_t)nchunks, (int)width, per,
-                       stage, 0, (float*)nullptr);
-    fin = stage;
-  }
-  hipLaunchKernelGGL(k_gemm3_tn_final, dim3((unsigned)((width + 63) / 64)), dim3(256), 0, s, fin, slots, width, N, K, dW, lddw, db);
+  if (nchunks > 32)
+    hipLaunchKernelGGL(k_gemm3_tn_final<16>, dim3((unsigned)((width + 15) / 16)), dim3(256), 0, s, partial, nchunks, width, N, K, dW, lddw, db);
+  else
+    hipLaunchKernelGGL(k_gemm3_tn_final<4>, dim3((unsigned)((width + 63) / 64)), dim3(256), 0, s, partial, nchunks, width, N, K, dW, lddw, db);
   return dgdm_launch_status();
 }
