@@ -15,6 +15,22 @@ static inline int dgdm_launch_status() {
   return hipGetLastError() == hipSuccess ? DGDM_OK : DGDM_ERR_LAUNCH;
 }
 
+// Device-side fill used instead of hipMemsetAsync: memset nodes recorded by stream capture did not
+// re-execute on graph replay on this runtime (counters kept their previous values and the dependent
+// scatter ran out of bounds), a kernel node always does.  `bytes` must be a multiple of 4.
+static __global__ void k_dgdm_fill32(uint32_t* __restrict__ p, size_t n, uint32_t v) {
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) p[i] = v;
+}
+static inline void dgdm_fill_async(void* p, uint8_t byte, size_t bytes, hipStream_t s) {
+  const size_t n = bytes / 4;
+  if (n == 0) return;
+  const size_t blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(k_dgdm_fill32, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, s,
+                     static_cast<uint32_t*>(p), n, 0x01010101u * byte);
+}
+
 static inline size_t dgdm_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 static inline bool dgdm_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

@@ -188,7 +188,7 @@ extern "C" int dgdm_csr_build(const int64_t* edge_index, int64_t E, int32_t N, i
   if (n_entries > 0x7fffffffLL) return DGDM_ERR_UNSUPPORTED;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   if (N == 0) {
-    (void)hipMemsetAsync(rowptr, 0, sizeof(int32_t), stream);
+    dgdm_fill_async(rowptr, 0, sizeof(int32_t), stream);
     return dgdm_launch_status();
   }
   DGDM_REQUIRE(workspace);
@@ -199,7 +199,7 @@ extern "C" int dgdm_csr_build(const int64_t* edge_index, int64_t E, int32_t N, i
   const int extra = add_loops ? 1 : 0;
   const int nblk = (N + SCAN_BLOCK - 1) / SCAN_BLOCK;
   // cnt and cursor are adjacent (both 256-B padded): one memset
-  (void)hipMemsetAsync(w.cnt, 0, (size_t)((char*)w.block_tot - (char*)w.cnt), stream);
+  dgdm_fill_async(w.cnt, 0, (size_t)((char*)w.block_tot - (char*)w.cnt), stream);
   const int eb = (int)((E + 255) / 256 < 4096 ? (E + 255) / 256 : 4096);
   if (E > 0) hipLaunchKernelGGL(k_count, dim3(eb), dim3(256), 0, stream, keys, vals, E, N, w.cnt);
   hipLaunchKernelGGL(k_scan_block_totals, dim3(nblk), dim3(SCAN_BLOCK), 0, stream, w.cnt, N, extra, w.block_tot);

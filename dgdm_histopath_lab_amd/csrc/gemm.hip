@@ -353,7 +353,7 @@ extern "C" int dgdm_gemm_tn(const float* dY, int64_t ldy, const float* X, int64_
   hipStream_t s = static_cast<hipStream_t>(stream_);
   if (M == 0) {
     (void)hipMemset2DAsync(dW, (size_t)lddw * sizeof(float), 0, (size_t)K * sizeof(float), (size_t)N, s);
-    if (db) (void)hipMemsetAsync(db, 0, sizeof(float) * N, s);
+    if (db) dgdm_fill_async(db, 0, sizeof(float) * N, s);
     return dgdm_launch_status();
   }
   if (!dY || !X || !workspace) return DGDM_ERR_INVALID_ARG;

@@ -405,7 +405,7 @@ extern "C" int dgdm_edge_dedup_count(const int32_t* sidx, const float* sdist, in
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int ks = Ks1 - 1, km = Km1 - 1;
   const int64_t L = (int64_t)N * (ks + km);
-  if (L == 0) { (void)hipMemsetAsync(n_edges, 0, sizeof(int64_t), s); return dgdm_launch_status(); }
+  if (L == 0) { dgdm_fill_async(n_edges, 0, sizeof(int64_t), s); return dgdm_launch_status(); }
   if (!sidx || !sdist || !midx || !msim || !workspace) return DGDM_ERR_INVALID_ARG;
   if (L >= 0x7fffffffLL) return DGDM_ERR_UNSUPPORTED;
   const DedupLayout l = dedup_layout(L);

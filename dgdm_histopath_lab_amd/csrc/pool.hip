@@ -391,8 +391,8 @@ extern "C" int dgdm_pool_score_bwd(const float* h, int64_t ldh, const float* w2,
   if (!dw2 || !db2) return DGDM_ERR_INVALID_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream_);
   if (N == 0) {
-    (void)hipMemsetAsync(dw2, 0, sizeof(float) * C, st);
-    (void)hipMemsetAsync(db2, 0, sizeof(float), st);
+    dgdm_fill_async(dw2, 0, sizeof(float) * C, st);
+    dgdm_fill_async(db2, 0, sizeof(float), st);
     return dgdm_launch_status();
   }
   if (!h || !w2 || !s || !ds || !dh || !workspace) return DGDM_ERR_INVALID_ARG;
@@ -425,7 +425,7 @@ extern "C" int dgdm_topk_perm(const float* s, int32_t N, int32_t k, int64_t* per
   if (workspace_bytes < dgdm_topk_perm_workspace_bytes(N)) return DGDM_ERR_WORKSPACE;
   hipStream_t st = static_cast<hipStream_t>(stream_);
   if (k == 0) {
-    (void)hipMemsetAsync(node_map, 0xff, sizeof(int32_t) * N, st);
+    dgdm_fill_async(node_map, 0xff, sizeof(int32_t) * N, st);
     return dgdm_launch_status();
   }
   const int nb = (N + CP_ITEMS - 1) / CP_ITEMS;
@@ -433,7 +433,7 @@ extern "C" int dgdm_topk_perm(const float* s, int32_t N, int32_t k, int64_t* per
   SelectState* states = reinterpret_cast<SelectState*>(hist + 4 * 256);
   uint32_t* counts = reinterpret_cast<uint32_t*>(states + 8);
   uint32_t* bases = counts + 2 * nb;
-  (void)hipMemsetAsync(hist, 0, 4 * 256 * sizeof(uint32_t), st);
+  dgdm_fill_async(hist, 0, 4 * 256 * sizeof(uint32_t), st);
   const int hb = min(nb * 4, 1024);
   for (int pass = 0; pass < 4; ++pass)
     hipLaunchKernelGGL(k_topk_hist, dim3(hb), dim3(256), 0, st, s, N, k, pass, hist, states);

@@ -280,8 +280,8 @@ extern "C" int dgdm_rownorm_bwd(const float* x, const float* res, const float* g
   if (rc != DGDM_OK) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream_);
   if (N == 0) {
-    if (dgamma) (void)hipMemsetAsync(dgamma, 0, sizeof(float) * C, s);
-    if (dbeta) (void)hipMemsetAsync(dbeta, 0, sizeof(float) * C, s);
+    if (dgamma) dgdm_fill_async(dgamma, 0, sizeof(float) * C, s);
+    if (dbeta) dgdm_fill_async(dbeta, 0, sizeof(float) * C, s);
     return dgdm_launch_status();
   }
   DGDM_REQUIRE(mean && rstd && dy && dx && dgamma && dbeta && workspace);

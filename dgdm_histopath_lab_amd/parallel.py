@@ -43,6 +43,10 @@ class FlatGradAllReducer:
             self.views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
 
+    def reset(self) -> None:
+        """Forget the live set (call on every rank at the same step, e.g. when the training phase changes)."""
+        self.live, self.flat = None, None
+
     @property
     def nbytes(self) -> int:
         return 0 if self.flat is None else self.flat.numel() * self.flat.element_size()

@@ -67,6 +67,23 @@ class ContrastiveLoss(nn.Module):
         return loss.mean() if self.reduction == "mean" else (loss.sum() if self.reduction == "sum" else loss)
 
 
+class _Scalars(dict):
+    """Latest value of every logged scalar.  Values logged as device tensors are kept as tensors (no host sync in
+    the step) and converted to float when read."""
+
+    def __getitem__(self, k):
+        return float(dict.__getitem__(self, k))
+
+    def get(self, k, default=None):
+        return self[k] if k in self else default
+
+    def items(self):
+        return [(k, self[k]) for k in self]
+
+    def values(self):
+        return [self[k] for k in self]
+
+
 class DGDMTrainer(nn.Module):
     """Drop-in for the reference's Lightning module; drive it with ``fit`` or call the ``*_step``
     hooks from your own loop."""
@@ -92,13 +109,14 @@ class DGDMTrainer(nn.Module):
         self.current_phase = "pretrain"
         self.current_epoch = 0
         self.global_step = 0
-        self.logged: Dict[str, float] = {}          # latest value of every logged scalar
+        self.logged: Dict[str, float] = _Scalars()  # latest value of every logged scalar
+        self._graphed: Optional["GraphedPretrainStep"] = None
         self._optimizer: Optional[torch.optim.Optimizer] = None
         self._scheduler = None
 
     # ------------------------------------------------------------------ logging sink
     def log(self, name: str, value, **_):
-        self.logged[name] = float(value.detach()) if torch.is_tensor(value) else float(value)
+        dict.__setitem__(self.logged, name, value.detach() if torch.is_tensor(value) else float(value))
 
     def log_dict(self, d: Dict[str, Any], **_):
         for k, v in d.items():
@@ -208,7 +226,10 @@ class DGDMTrainer(nn.Module):
             self.current_phase = phase
             if phase == "finetune" and self._optimizer is not None:
                 for group in self._optimizer.param_groups:
-                    group["lr"] = group["lr"] * 0.1
+                    if torch.is_tensor(group["lr"]):
+                        group["lr"].mul_(0.1)       # device-side learning rate of a recorded step: keep its address
+                    else:
+                        group["lr"] = group["lr"] * 0.1
 
     def on_validation_epoch_end(self):
         if self._optimizer is not None:
@@ -216,10 +237,12 @@ class DGDMTrainer(nn.Module):
 
     # ------------------------------------------------------------------ loop
     def fit(self, train_loader: Iterable, val_loader: Optional[Iterable] = None, max_epochs: Optional[int] = None,
-            steps_per_epoch: Optional[int] = None, grad_reducer=None, on_step=None) -> List[float]:
+            steps_per_epoch: Optional[int] = None, grad_reducer=None, on_step=None, graphed: bool = False) -> List[float]:
         """Runs ``max_epochs`` (default pretrain + finetune epochs) over ``train_loader`` (re-iterable;
         batches already on the model's device or exposing ``.to``).  ``grad_reducer``: an object
         with ``all_reduce()`` called between backward and the optimizer step (data parallel).
+        ``graphed``: replay the pretrain step from HIP graphs (GraphedPretrainStep) for batches that share the
+        layout of the first one; other batches and the finetune phase run eagerly.
         Returns the per-step training losses."""
         max_epochs = self.pretrain_epochs + self.finetune_epochs if max_epochs is None else max_epochs
         if steps_per_epoch is None:
@@ -230,18 +253,37 @@ class DGDMTrainer(nn.Module):
         dev = self.device
         for epoch in range(self.current_epoch, max_epochs):
             self.current_epoch = epoch
+            phase_before = self.current_phase
             self.on_train_epoch_start()
+            if self.current_phase != phase_before:
+                # other parameters carry gradients from here on: drop the recorded step (and its gradient buffers) and
+                # let the reducer rebuild its flat buffer -- every rank switches at the same epoch
+                self._graphed = None
+                self._optimizer.zero_grad(set_to_none=True)
+                if hasattr(grad_reducer, "reset"):
+                    grad_reducer.reset()
             self.model.train()
             for i, batch in enumerate(train_loader):
                 if i >= steps_per_epoch:
                     break
                 batch = batch.to(dev) if hasattr(batch, "to") else batch
-                self._optimizer.zero_grad(set_to_none=True)
-                loss = self.training_step(batch, i)
-                loss.backward()
-                if grad_reducer is not None:
-                    grad_reducer.all_reduce()
-                self._optimizer.step()
+                loss = None
+                if graphed and self.current_phase == "pretrain":
+                    if self._graphed is None:
+                        self._graphed = GraphedPretrainStep(self.model, self._optimizer, grad_reducer=grad_reducer,
+                                                            step_fn=lambda b: self._pretrain_step(b))
+                    try:
+                        loss = self._graphed(batch)
+                    except BatchLayoutError:    # another batch layout: eager step below
+                        loss = None
+                if loss is None:
+                    # gradients recorded by a graphed step must keep their addresses: zero them in place
+                    self._optimizer.zero_grad(set_to_none=self._graphed is None)
+                    loss = self.training_step(batch, i)
+                    loss.backward()
+                    if grad_reducer is not None:
+                        grad_reducer.all_reduce()
+                    self._optimizer.step()
                 if self._scheduler is not None:
                     self._scheduler.step()
                 self.global_step += 1
@@ -294,6 +336,152 @@ class DGDMTrainer(nn.Module):
         self.global_step = int(ckpt.get("global_step", 0))
         return {"missing_keys": list(missing), "unexpected_keys": list(unexpected),
                 "hyperparameters": ckpt.get("hyperparameters", ckpt.get("hyper_parameters", {}))}
+
+
+class BatchLayoutError(ValueError):
+    """A batch does not have the tensor shapes / per-graph node offsets a recorded step was captured for."""
+
+
+class GraphedPretrainStep:
+    """``pretrain_step -> backward [-> gradient all-reduce] -> AdamW step`` recorded once as HIP graphs and
+    replayed for every later batch of the same shape (same tensor shapes and per-graph node offsets).
+
+    A step of the path is ~1000 short kernel launches; replaying them from a graph removes the host from
+    the loop (the step is then bounded by the kernels alone, which matters most for small batches).  The
+    work is the same as the eager step: entity masking draws fresh variates on every replay (torch's
+    generator is graph-aware), and the dropout sites fold in the device-side seed epoch, advanced by a
+    kernel at the head of the graph (csrc/common.hpp, DgdmSeed).
+
+    * ``optimizer`` must be a fused AdamW; it is switched to ``capturable`` (device-side step count and
+      learning rate).  Set the learning rate with :meth:`set_lr` (an asynchronous fill, no host sync).
+    * the first ``warmup`` calls run eagerly on a side stream (they are real training steps), the next call
+      records, every later call replays.  A batch of another shape raises ``BatchLayoutError`` (a ``ValueError``) -- run it eagerly.
+    * ``validate=True`` keeps the model's input checks (NaN / inf / edge range, one host readback per batch) in
+      front of every step, as the eager forward has them; the recorded region itself cannot hold a readback.
+    * with ``grad_reducer`` the graph is split around the collective: [forward+backward] -> all-reduce
+      (eager, RCCL) -> [optimizer step].
+    """
+
+    def __init__(self, model: nn.Module, optimizer: torch.optim.Optimizer, mask_ratio: float = 0.15, grad_reducer=None,
+                 warmup: int = 2, step_fn=None, validate: bool = True):
+        from . import _lib
+        self._lib = _lib
+        self.validate = validate
+        self.model, self.opt, self.mask_ratio, self.reducer, self.warmup = model, optimizer, mask_ratio, grad_reducer, warmup
+        self.step_fn = step_fn or (lambda batch: model.pretrain_step(batch, mask_ratio=self.mask_ratio)["total_pretrain_loss"])
+        self.dev = next(model.parameters()).device
+        if self.dev.type != "cuda":
+            raise _lib.DGDMKernelError("GraphedPretrainStep records HIP graphs: the model must live on the GPU")
+        for group in optimizer.param_groups:
+            if not group.get("fused"):
+                raise ValueError("GraphedPretrainStep needs a fused optimizer (torch.optim.AdamW(..., fused=True))")
+            group["capturable"] = True
+            if not isinstance(group["lr"], torch.Tensor):
+                group["lr"] = torch.tensor(float(group["lr"]), dtype=torch.float32, device=self.dev)
+        for st in optimizer.state.values():          # an optimizer that already stepped keeps its count on the host
+            if isinstance(st.get("step"), torch.Tensor) and not st["step"].is_cuda:
+                st["step"] = st["step"].to(self.dev)
+        self.static = None
+        self._signature = None
+        self._graphs: List[torch.cuda.CUDAGraph] = []
+        self._loss = None
+        self._calls = 0
+        self._side = torch.cuda.Stream(self.dev)
+
+    # ------------------------------------------------------------------ static inputs
+    @staticmethod
+    def _sig(batch):
+        sig = []
+        for k, v in sorted(batch.__dict__.items()):
+            if isinstance(v, torch.Tensor):
+                sig.append((k, tuple(v.shape), v.dtype))
+            elif k == "ptr" and v is not None:
+                sig.append((k, tuple(int(i) for i in v)))
+        return tuple(sig)
+
+    def _load(self, batch):
+        sig = self._sig(batch)
+        if self.static is None:
+            self.static, self._signature = batch.clone(), sig
+            return
+        if sig != self._signature:
+            raise BatchLayoutError("GraphedPretrainStep: batch layout differs from the recorded one (tensor shapes or per-graph node "
+                             "offsets); run this batch through the eager step")
+        for k, v in batch.__dict__.items():
+            if isinstance(v, torch.Tensor):
+                getattr(self.static, k).copy_(v, non_blocking=True)
+
+    def set_lr(self, lr: float, group: int = 0) -> None:
+        self.opt.param_groups[group]["lr"].fill_(float(lr))
+
+    # ------------------------------------------------------------------ the step
+    def _advance_seed(self):
+        self._lib.check(self._lib.load().dgdm_seed_epoch_advance(self._lib.stream_ptr(self.dev)), "dgdm_seed_epoch_advance")
+
+    def _forward_backward(self):
+        self._advance_seed()
+        loss = self.step_fn(self.static)
+        loss.backward()
+        return loss.detach()
+
+    def _eager(self):
+        loss = self._forward_backward()
+        if self.reducer is not None:
+            self.reducer.all_reduce()
+        self.opt.step()
+        return loss
+
+    def _record(self):
+        # gradients allocated while recording live in the graph's pool and are overwritten (not accumulated) by each
+        # replay; nothing may free them afterwards (no zero_grad(set_to_none=True) between replayed steps)
+        self.opt.zero_grad(set_to_none=True)
+        g1 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g1):
+            self._loss = self._forward_backward()
+            if self.reducer is None:
+                self.opt.step()
+        self._graphs = [g1]
+        if self.reducer is not None:
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2, pool=g1.pool()):
+                self.opt.step()
+            self._graphs.append(g2)
+
+    def __call__(self, batch) -> torch.Tensor:
+        """One training step on ``batch``; returns the (detached, device) loss of this step."""
+        check = getattr(self.model, "_validate_forward_inputs", None)
+        if self.validate and check is not None:
+            try:
+                check(batch, "pretrain", False, False)
+            except Exception as e:
+                from .models.dgdm_model import ModelInferenceError
+                raise ModelInferenceError(f"Input validation failed: {e}")
+        had = getattr(self.model, "validate_inputs", None)
+        if had is not None:
+            self.model.validate_inputs = False
+        try:
+            return self._step(batch)
+        finally:
+            if had is not None:
+                self.model.validate_inputs = had
+
+    def _step(self, batch) -> torch.Tensor:
+        self._load(batch)
+        self._calls += 1
+        if self._calls <= self.warmup:
+            self._side.wait_stream(torch.cuda.current_stream(self.dev))
+            with torch.cuda.stream(self._side):
+                self.opt.zero_grad(set_to_none=True)
+                loss = self._eager()
+            torch.cuda.current_stream(self.dev).wait_stream(self._side)
+            return loss
+        if not self._graphs:
+            self._record()          # recording launches nothing: the step itself is the replay below
+        self._graphs[0].replay()
+        if self.reducer is not None:
+            self.reducer.all_reduce()
+            self._graphs[1].replay()
+        return self._loss.clone()     # the recorded loss tensor is overwritten by the next replay
 
 
 def closed_form_lr(step: int, base_lr: float, total_steps: int, finetune_start_step: Optional[int] = None) -> float:

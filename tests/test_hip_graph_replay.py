@@ -1,0 +1,131 @@
+"""HIP-graph replay of the path: library-side buffer fills must re-execute on every replay (hipMemsetAsync
+nodes did not on this runtime, csrc/common.hpp dgdm_fill_async), and a recorded training step must do the
+work of the eager one."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _capture(fn, warm=2):
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(warm):
+            fn()
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = fn()
+    return g, out
+
+
+def test_index_kernels_replay_exactly():
+    from dgdm_histopath_lab_amd import GraphStructure, ops
+    torch.manual_seed(0)
+    n = 800
+    ei = torch.randint(0, n, (2, 3200), device=DEV)
+    want = GraphStructure(ei, n)
+    scores = torch.randn(n, device=DEV)
+    want_perm, want_map = ops.topk_perm(scores, 400)
+    g1, got = _capture(lambda: GraphStructure(ei, n))
+    g2, (perm, nmap) = _capture(lambda: ops.topk_perm(scores, 400))
+    for _ in range(3):       # counters and histograms are zeroed by the graph itself: every replay gives the same index sets
+        g1.replay(); g2.replay()
+        torch.cuda.synchronize()
+        for name in ("rowptr", "col", "eid", "rowptr_t", "col_t", "eid_t"):
+            assert torch.equal(getattr(got, name), getattr(want, name)), name
+        assert torch.equal(perm, want_perm) and torch.equal(nmap, want_map)
+
+
+def _small_model(dropout):
+    from dgdm_histopath_lab_amd import DGDMModel
+    torch.manual_seed(0)
+    return DGDMModel(node_features=64, hidden_dims=[64, 32, 32], num_diffusion_steps=10, attention_heads=4, dropout=dropout).to(DEV).train()
+
+
+def test_recorded_step_follows_the_eager_trajectory():
+    """No random draw in the step (eval mode: every dropout site off; deterministic objective): replayed and eager steps
+    must walk the same parameter trajectory (fp32 atomics in the reductions: not bitwise)."""
+    from dgdm_histopath_lab_amd.synthetic import synthetic_batch
+    from dgdm_histopath_lab_amd.training import GraphedPretrainStep
+    batches = [synthetic_batch(3 + 5 * i, 2, 400, 1600, 64).to(DEV) for i in range(2)]
+    objective = lambda model: (lambda b: model(b, mode="inference")["graph_embedding"].pow(2).mean())
+    a, b = _small_model(0.0).eval(), _small_model(0.0).eval()
+    opt_a = torch.optim.AdamW(a.parameters(), lr=1e-3, weight_decay=1e-5, fused=True)
+    opt_b = torch.optim.AdamW(b.parameters(), lr=1e-3, weight_decay=1e-5, fused=True)
+    step = GraphedPretrainStep(a, opt_a, step_fn=objective(a))
+    init = [p.detach().clone() for p in b.parameters()]
+    la, lb = [], []
+    for i in range(7):
+        if i == 4:
+            step.set_lr(5e-4)
+            for g in opt_b.param_groups:
+                g["lr"] = 5e-4
+        la.append(float(step(batches[i % 2])))
+        opt_b.zero_grad(set_to_none=True)
+        loss = objective(b)(batches[i % 2])
+        loss.backward()
+        opt_b.step()
+        lb.append(float(loss.detach()))
+    assert step._graphs and step._calls == 7
+    assert la == pytest.approx(lb, rel=2e-4)
+    # Adam divides by |g|: elements whose gradient is at rounding level may step either way, so compare the gradients
+    # element-wise and the parameters in aggregate (difference between the runs vs distance travelled)
+    diff = moved = 0.0
+    live = 0
+    gmax = max(float(p.grad.abs().max()) for p in b.parameters() if p.grad is not None)
+    for pa, pb, p0 in zip(a.parameters(), b.parameters(), init):
+        if pb.grad is None:
+            assert pa.grad is None and torch.equal(pa, pb)
+            continue
+        scale = float(pb.grad.abs().max())
+        if scale < 1e-5 * gmax:      # mathematically zero gradient (e.g. a bias in front of a normalisation): pure rounding
+            continue
+        live += 1
+        assert torch.allclose(pa.grad, pb.grad, rtol=5e-3, atol=5e-3 * scale + 1e-9)
+        diff += float((pa.detach() - pb.detach()).abs().sum())
+        moved += float((pb.detach() - p0).abs().sum())
+    assert live > 20 and moved > 0 and diff < 0.02 * moved
+
+
+def test_recorded_pretrain_step_draws_fresh_masks_and_rejects_other_layouts():
+    from dgdm_histopath_lab_amd import BatchLayoutError, ModelInferenceError
+    from dgdm_histopath_lab_amd.synthetic import synthetic_batch
+    from dgdm_histopath_lab_amd.training import GraphedPretrainStep
+    m = _small_model(0.1)
+    opt = torch.optim.AdamW(m.parameters(), lr=0.0, weight_decay=0.0, fused=True)      # lr 0: the parameters stay put
+    step = GraphedPretrainStep(m, opt)
+    batch = synthetic_batch(3, 2, 400, 1600, 64).to(DEV)
+    losses = [float(step(batch)) for _ in range(8)]
+    assert all(l == l and abs(l) < 1e3 for l in losses)
+    assert len(set(losses[3:])) == len(losses[3:])          # same weights, same batch: only the random draws differ
+    with pytest.raises(BatchLayoutError):
+        step(synthetic_batch(3, 2, 300, 1200, 64).to(DEV))
+    bad = batch.clone()
+    bad.x[5, 7] = float("nan")
+    with pytest.raises(ModelInferenceError):
+        step(bad)
+    assert m.validate_inputs is True
+
+
+def test_trainer_fit_with_recorded_pretrain_steps():
+    from dgdm_histopath_lab_amd.synthetic import synthetic_batch
+    from dgdm_histopath_lab_amd.training import DGDMTrainer
+    from dgdm_histopath_lab_amd import DGDMModel
+    torch.manual_seed(0)
+    model = DGDMModel(node_features=64, hidden_dims=[64, 32, 32], num_diffusion_steps=10, attention_heads=4, num_classes=3).to(DEV)
+    batches = []
+    for i in range(3):
+        b = synthetic_batch(10 * i, 2, 300 if i < 2 else 200, 1200 if i < 2 else 800, 64).to(DEV)   # the third has another layout
+        b.y = torch.tensor([0, 2], device=DEV)
+        batches.append(b)
+    tr = DGDMTrainer(model, learning_rate=1e-3, pretrain_epochs=3, finetune_epochs=1)
+    losses = tr.fit(batches, graphed=True)
+    assert len(losses) == 12 and all(l == l for l in losses)
+    assert tr.current_phase == "finetune" and tr._graphed is None
+    assert {"train/diffusion_loss", "train/classification_loss", "train/total_loss"} <= set(tr.logged)
+    from dgdm_histopath_lab_amd.training import closed_form_lr
+    lr = float(tr.optimizers().param_groups[0]["lr"])
+    assert lr == pytest.approx(closed_form_lr(12, 1e-3, 12, 9), rel=1e-4)
