@@ -8,6 +8,15 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
+@pytest.fixture(autouse=True)
+def _seed_epoch_back_to_zero():
+    """Recorded steps advance the device-side dropout seed epoch; every other test assumes epoch 0."""
+    yield
+    from dgdm_histopath_lab_amd import _lib
+    _lib.check(_lib.load().dgdm_seed_epoch_set(0, _lib.stream_ptr(torch.device(DEV))), "dgdm_seed_epoch_set")
+    torch.cuda.synchronize()
+
+
 def _capture(fn, warm=2):
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())

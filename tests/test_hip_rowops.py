@@ -141,6 +141,7 @@ def test_seed_epoch_changes_dropout_masks_and_zero_is_identity():
         _lib.check(lib.dgdm_act_dropout_bwd(x.data_ptr(), g.data_ptr(), x.numel(), ops.ACT_NONE, 0.25, seed, dx.data_ptr(), st), "bwd")
         return dx
     try:
+        _lib.check(lib.dgdm_seed_epoch_set(0, st), "set")
         y0, y0b = fwd(), fwd()
         assert torch.equal(y0, y0b)
         _lib.check(lib.dgdm_seed_epoch_advance(st), "advance")
