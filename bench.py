@@ -167,6 +167,7 @@ def main():
     # rehearsal knobs (not used by the driver): all ranks on one GPU over gloo, to exercise the N > 1 code path on a 1-GPU box
     one_device = os.environ.get("DGDM_BENCH_ONE_DEVICE") == "1"
     backend = os.environ.get("DGDM_BENCH_DIST_BACKEND", "nccl")
+    force_dist = os.environ.get("DGDM_BENCH_FORCE_DIST") == "1"     # one rank, but through RCCL and the split recording
     dev_index = 0 if one_device else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -176,8 +177,11 @@ def main():
     from dgdm_histopath_lab_amd.parallel import FlatGradAllReducer
     from dgdm_histopath_lab_amd.synthetic import synthetic_batch
 
-    if world > 1:
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -188,7 +192,7 @@ def main():
     model.train(not args.eval_mode)
     # training/trainer.py:221-226 defaults; fused=True: one multi-tensor kernel instead of ~10 foreach launches
     opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-5, fused=True)
-    reducer = FlatGradAllReducer(model, world) if world > 1 else None
+    reducer = FlatGradAllReducer(model, world, always=force_dist) if (world > 1 or force_dist) else None
     # rank r owns slides [r*B, (r+1)*B): independent units, no data-path collective
     batch = synthetic_batch(rank * args.batch, args.batch, args.nodes, args.edges, FEATS).to(dev)
     sizes = [args.nodes] * args.batch
@@ -294,7 +298,7 @@ def main():
                        "global_batch": world * args.batch, "parallelism": f"dp{world}", "final_loss": round(loss_val, 5)},
             "roofline": roofline,
         }
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

@@ -25,7 +25,8 @@ class FlatGradAllReducer:
     mode) and checked afterwards.  xGMI is point-to-point (7 links per GPU): one large message per
     step keeps every link busy once instead of paying the per-collective latency ~100 times."""
 
-    def __init__(self, module: torch.nn.Module, world_size: Optional[int] = None, group=None):
+    def __init__(self, module: torch.nn.Module, world_size: Optional[int] = None, group=None, always: bool = False):
+        self.always = always          # issue the collective even with one rank (rehearsals of the N > 1 path)
         self.params = [p for p in module.parameters() if p.requires_grad]
         self.world = world_size if world_size is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
         self.group = group
@@ -52,7 +53,7 @@ class FlatGradAllReducer:
         return 0 if self.flat is None else self.flat.numel() * self.flat.element_size()
 
     def all_reduce(self) -> None:
-        if self.world <= 1:
+        if self.world <= 1 and not self.always:
             return
         if self.live is None:
             self._setup()

@@ -435,15 +435,19 @@ class GraphedPretrainStep:
         # gradients allocated while recording live in the graph's pool and are overwritten (not accumulated) by each
         # replay; nothing may free them afterwards (no zero_grad(set_to_none=True) between replayed steps)
         self.opt.zero_grad(set_to_none=True)
+        # thread_local: the communicator's watchdog thread polls events of earlier collectives; that must not
+        # invalidate the recording (and nothing of those collectives may still be in flight when it starts)
+        torch.cuda.synchronize(self.dev)
+        mode = dict(capture_error_mode="thread_local")
         g1 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g1):
+        with torch.cuda.graph(g1, **mode):
             self._loss = self._forward_backward()
             if self.reducer is None:
                 self.opt.step()
         self._graphs = [g1]
         if self.reducer is not None:
             g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g2, pool=g1.pool()):
+            with torch.cuda.graph(g2, pool=g1.pool(), **mode):
                 self.opt.step()
             self._graphs.append(g2)
 
