@@ -25,8 +25,11 @@ _i32, _i64, _sz, _p = C.c_int32, C.c_int64, C.c_size_t, C.c_void_p
 SIGNATURES = {
     "dgdm_abi_version": (C.c_int, []),
     "dgdm_error_string": (C.c_char_p, [C.c_int]),
+    "dgdm_validate_inputs": (C.c_int, [_p, _i64, _p, _i64, _i64, _p, _p]),
     "dgdm_csr_build_workspace_bytes": (_sz, [_i64, _i32, _i32]),
     "dgdm_csr_build": (C.c_int, [_p, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _sz, _p]),
+    "dgdm_csr_build_pair_workspace_bytes": (_sz, [_i64, _i32, _i32]),
+    "dgdm_csr_build_pair": (C.c_int, [_p, _i64, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "dgdm_gcn_dinv": (C.c_int, [_p, _i32, _p, _p]),
     "dgdm_csr_edge_weights": (C.c_int, [_p, _p, _p, _i32, _p, _p]),
     "dgdm_spatial_attn_q_tile_rows": (_i32, []),
@@ -78,6 +81,8 @@ SIGNATURES = {
     "dgdm_gemm_nn_bf16x3": (C.c_int, [_p, _i64, _p, _i64, _p, _i64, _i32, _i32, _i32, _i32, _p]),
     "dgdm_gemm_tn_bf16x3_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
     "dgdm_gemm_tn_bf16x3": (C.c_int, [_p, _i64, _p, _i64, _p, _i64, _p, _i32, _i32, _i32, _p, _sz, _p]),
+    "dgdm_gemm_tn_split": (C.c_int, [_p, _i64, _p, _i64, _p, _i64, _i32, _p, _i64, _p, _i32, _i32, _i32, _p, _sz, _p]),
+    "dgdm_gemm_tn_split_bf16x3": (C.c_int, [_p, _i64, _p, _i64, _p, _i64, _i32, _p, _i64, _p, _i32, _i32, _i32, _p, _sz, _p]),
     "dgdm_attn_pack_bytes": (_sz, [_i32, _i32, _i32]),
     "dgdm_amax_scale_workspace_bytes": (_sz, []),
     "dgdm_amax_pow2_scale": (C.c_int, [_p, _i64, C.c_float, _p, _p, _sz, _p]),
@@ -88,6 +93,7 @@ SIGNATURES = {
     "dgdm_spatial_attn_h_bwd_dkv": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, C.c_float, C.c_float,
                                               C.c_uint32, _p, _p, _p, _i64, _i32, _p]),
     "dgdm_spmm": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _p, _i64, _i32, _i32, _p, _i32, _p]),
+    "dgdm_spmm_concat": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _p, _i64, _i32, _p, _i64, _i32, _i32, _p]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -73,6 +73,9 @@ class GraphConvolution(nn.Module):
         ctx = _context(edge_index, x, edge_attr, self.add_self_loops)
         if self.edge_lin is not None and ctx.ea_hat is not None:
             # one contraction over K = C_in + edge_dim:  [A_hat x | EA_hat] . [W | W_e]^T + b
+            if (x.size(0) >= ops.GEMM_MIN_ROWS and x.size(1) % 4 == 0 and self.out_channels % 4 == 0 and ctx.ea_hat.size(1) % 4 == 0
+                    and x.dtype == torch.float32):
+                return ops.graph_conv_linear(x, ctx.ea_hat, ctx.gs, self.node_lin.weight, self.edge_lin.weight, self.bias)
             buf = ops.aggregate_concat(x, ctx.ea_hat, ctx.gs)
             return ops.linear(buf, torch.cat([self.node_lin.weight, self.edge_lin.weight], dim=1), self.bias)
         return ops.linear(ops.aggregate(x, ctx.gs), self.node_lin.weight, self.bias)

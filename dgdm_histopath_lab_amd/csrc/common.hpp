@@ -31,6 +31,18 @@ static inline void dgdm_fill_async(void* p, uint8_t byte, size_t bytes, hipStrea
                      static_cast<uint32_t*>(p), n, 0x01010101u * byte);
 }
 
+// rows x cols floats of a matrix with leading dimension ld (floats) <- 0
+static __global__ void k_dgdm_zero2d(float* __restrict__ p, int64_t ld, int cols, int64_t rows) {
+  const int64_t n = rows * cols, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += stride) p[(i / cols) * ld + i % cols] = 0.f;
+}
+static inline void dgdm_fill2d_async(float* p, int64_t ld, int cols, int64_t rows, hipStream_t s) {
+  const int64_t n = rows * cols;
+  if (n <= 0) return;
+  const int64_t blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(k_dgdm_zero2d, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, s, p, ld, cols, rows);
+}
+
 static inline size_t dgdm_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 static inline bool dgdm_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

@@ -146,6 +146,125 @@ __global__ void k_edge_weights(const int32_t* __restrict__ rowptr, const int32_t
   }
 }
 
+// ---- both orientations of one edge list in one pipeline (5 launches instead of 17) ------------------
+// o = 0: rows are destinations (forward), o = 1: rows are sources (backward).  Same results, bit for bit, as two
+// dgdm_csr_build calls + dgdm_gcn_dinv + two dgdm_csr_edge_weights calls.
+struct PairArrays {
+  int32_t *cnt[2], *cursor[2], *tcol[2], *teid[2];
+  int32_t *rowptr[2], *col[2], *eid[2];
+  float* w[2];
+};
+
+__global__ void k_count_pair(const int64_t* __restrict__ ei, int64_t E, int32_t N, int32_t* __restrict__ cnt_dst,
+                             int32_t* __restrict__ cnt_src) {
+  int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; e < E; e += stride) {
+    const int64_t s = ei[e], d = ei[E + e];
+    if (edge_ok(s, d, N)) {
+      atomicAdd(&cnt_dst[d], 1);
+      atomicAdd(&cnt_src[s], 1);
+    }
+  }
+}
+
+// block o scans the N row counts of orientation o (four per thread and iteration, running carry); block 0 also
+// writes dinv from the in-degrees it is looking at (k_dinv's formula)
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_pair(PairArrays a, int32_t N, int extra, float* __restrict__ dinv) {
+  const int o = blockIdx.x;
+  const int32_t* __restrict__ cnt = a.cnt[o];
+  int32_t* __restrict__ rowptr = a.rowptr[o];
+  int carry = 0;
+  for (int base = 0; base < N; base += 4 * SCAN_BLOCK) {
+    const int i = base + 4 * threadIdx.x;
+    int v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = i + j < N ? cnt[i + j] + extra : 0;
+    int tot;
+    int ex = carry + block_exclusive_scan(v[0] + v[1] + v[2] + v[3], &tot);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (i + j < N) {
+        rowptr[i + j] = ex;
+        if (o == 0) dinv[i + j] = v[j] > 0 ? 1.0f / sqrtf((float)v[j]) : 0.f;
+      }
+      ex += v[j];
+    }
+    carry += tot;
+  }
+  if (threadIdx.x == 0) rowptr[N] = carry;
+}
+
+__global__ void k_fill_pair(const int64_t* __restrict__ ei, int64_t E, int32_t N, PairArrays a) {
+  int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; e < E; e += stride) {
+    const int64_t s64 = ei[e], d64 = ei[E + e];
+    if (!edge_ok(s64, d64, N)) continue;
+    const int32_t s = (int32_t)s64, d = (int32_t)d64;
+    const int32_t slot_d = a.rowptr[0][d] + atomicAdd(&a.cursor[0][d], 1);
+    a.tcol[0][slot_d] = s;
+    a.teid[0][slot_d] = (int32_t)e;
+    const int32_t slot_s = a.rowptr[1][s] + atomicAdd(&a.cursor[1][s], 1);
+    a.tcol[1][slot_s] = d;
+    a.teid[1][slot_s] = (int32_t)e;
+  }
+}
+
+// k_rank for both orientations (blockIdx.y) + the GCN weight of every entry, w[p] = dinv[col[p]] * dinv[row]
+__global__ void k_rank_pair(PairArrays a, int32_t N, int32_t E32, int add_loops, const float* __restrict__ dinv) {
+  const int o = blockIdx.y;
+  const int32_t* __restrict__ rowptr = a.rowptr[o];
+  const int32_t* __restrict__ tcol = a.tcol[o];
+  const int32_t* __restrict__ teid = a.teid[o];
+  int32_t* __restrict__ col = a.col[o];
+  int32_t* __restrict__ eid = a.eid[o];
+  float* __restrict__ w = a.w[o];
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (int r = wave; r < N; r += nwaves) {
+    const int s = rowptr[r];
+    const int n = rowptr[r + 1] - s - (add_loops ? 1 : 0);
+    const float dr = dinv[r];
+    for (int i = lane; i < n; i += 64) {
+      const int my = teid[s + i];
+      int rank = 0;
+      for (int j = 0; j < n; ++j) rank += (teid[s + j] < my) ? 1 : 0;
+      const int c = tcol[s + i];
+      col[s + rank] = c;
+      eid[s + rank] = my;
+      w[s + rank] = dinv[c] * dr;
+    }
+    if (add_loops && lane == 0) {
+      col[s + n] = r;
+      eid[s + n] = E32 + r;
+      w[s + n] = dr * dr;
+    }
+  }
+}
+
+struct PairWorkspace {
+  int32_t *cnt[2], *cursor[2], *tcol[2], *teid[2];
+  size_t counters_bytes, bytes;
+};
+
+PairWorkspace carve_pair(void* base, int64_t E, int32_t N, int32_t add_loops) {
+  PairWorkspace w;
+  const size_t n_entries = (size_t)E + (add_loops ? (size_t)N : 0);
+  char* p = static_cast<char*>(base);
+  size_t off = 0;
+  auto take = [&](size_t count) {
+    int32_t* r = reinterpret_cast<int32_t*>(p + off);
+    off += dgdm_align_up(count * sizeof(int32_t), 256);
+    return r;
+  };
+  w.cnt[0] = take(N); w.cnt[1] = take(N); w.cursor[0] = take(N); w.cursor[1] = take(N);
+  w.counters_bytes = off;  // the four counter arrays are adjacent: one fill
+  w.tcol[0] = take(n_entries); w.tcol[1] = take(n_entries); w.teid[0] = take(n_entries); w.teid[1] = take(n_entries);
+  w.bytes = off;
+  return w;
+}
+
 struct Workspace {
   int32_t *cnt, *cursor, *block_tot, *tcol, *teid;
   size_t bytes;
@@ -228,5 +347,45 @@ extern "C" int dgdm_csr_edge_weights(const int32_t* rowptr, const int32_t* col, 
   DGDM_REQUIRE(rowptr && col && dinv && w);
   const int rb = (N + 3) / 4 < 8192 ? (N + 3) / 4 : 8192;
   hipLaunchKernelGGL(k_edge_weights, dim3(rb), dim3(256), 0, static_cast<hipStream_t>(stream), rowptr, col, dinv, N, w);
+  return dgdm_launch_status();
+}
+
+extern "C" size_t dgdm_csr_build_pair_workspace_bytes(int64_t E, int32_t N, int32_t add_loops) {
+  if (E < 0 || N < 0) return 0;
+  return carve_pair(nullptr, E, N, add_loops).bytes;
+}
+
+extern "C" int dgdm_csr_build_pair(const int64_t* edge_index, int64_t E, int32_t N, int32_t add_loops,
+                                   int32_t* rowptr_dst, int32_t* col_dst, int32_t* eid_dst, float* w_dst,
+                                   int32_t* rowptr_src, int32_t* col_src, int32_t* eid_src, float* w_src, float* dinv,
+                                   void* workspace, size_t workspace_bytes, void* stream_) {
+  DGDM_REQUIRE(E >= 0 && N >= 0 && rowptr_dst && rowptr_src);
+  DGDM_REQUIRE(E == 0 || edge_index);
+  const int64_t n_entries = E + (add_loops ? N : 0);
+  DGDM_REQUIRE(n_entries == 0 || (col_dst && eid_dst && w_dst && col_src && eid_src && w_src));
+  if (n_entries > 0x7fffffffLL) return DGDM_ERR_UNSUPPORTED;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (N == 0) {
+    dgdm_fill_async(rowptr_dst, 0, sizeof(int32_t), stream);
+    dgdm_fill_async(rowptr_src, 0, sizeof(int32_t), stream);
+    return dgdm_launch_status();
+  }
+  DGDM_REQUIRE(workspace && dinv);
+  const PairWorkspace ws = carve_pair(workspace, E, N, add_loops);
+  if (workspace_bytes < ws.bytes) return DGDM_ERR_WORKSPACE;
+  PairArrays a;
+  for (int o = 0; o < 2; ++o) { a.cnt[o] = ws.cnt[o]; a.cursor[o] = ws.cursor[o]; a.tcol[o] = ws.tcol[o]; a.teid[o] = ws.teid[o]; }
+  a.rowptr[0] = rowptr_dst; a.col[0] = col_dst; a.eid[0] = eid_dst; a.w[0] = w_dst;
+  a.rowptr[1] = rowptr_src; a.col[1] = col_src; a.eid[1] = eid_src; a.w[1] = w_src;
+  const int extra = add_loops ? 1 : 0;
+  dgdm_fill_async(ws.cnt[0], 0, ws.counters_bytes, stream);
+  const int eb = (int)((E + 255) / 256 < 4096 ? (E + 255) / 256 : 4096);
+  if (E > 0) hipLaunchKernelGGL(k_count_pair, dim3(eb), dim3(256), 0, stream, edge_index, E, N, ws.cnt[0], ws.cnt[1]);
+  hipLaunchKernelGGL(k_scan_pair, dim3(2), dim3(SCAN_BLOCK), 0, stream, a, N, extra, dinv);
+  if (E > 0) hipLaunchKernelGGL(k_fill_pair, dim3(eb), dim3(256), 0, stream, edge_index, E, N, a);
+  if (n_entries > 0) {
+    const int rb = (N + 3) / 4 < 8192 ? (N + 3) / 4 : 8192;
+    hipLaunchKernelGGL(k_rank_pair, dim3(rb, 2), dim3(256), 0, stream, a, N, (int32_t)E, extra, dinv);
+  }
   return dgdm_launch_status();
 }

@@ -262,7 +262,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_partial(const float* __restr
 
 // dW[n][k] / db[n] = sum over slots of in[slot][n*K + k] / in[slot][N*K + n]; fixed order.
 __global__ __launch_bounds__(256) void k_gemm_tn_final(const float* __restrict__ in, int slots, int64_t width, int N, int K,
-                                                       float* __restrict__ dW, int64_t lddw, float* __restrict__ db) {
+                                                       float* __restrict__ dW, int64_t lddw, float* __restrict__ db, int K0,
+                                                       float* __restrict__ dW1, int64_t ld1) {
   const int64_t col = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
   const int part = threadIdx.x >> 6;
   float acc = 0.f;
@@ -274,7 +275,13 @@ __global__ __launch_bounds__(256) void k_gemm_tn_final(const float* __restrict__
   if (part == 0 && col < width) {
     const float t = (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
     const int64_t nk = (int64_t)N * K;
-    if (col < nk) dW[(col / K) * lddw + col % K] = t; else db[col - nk] = t;
+    if (col < nk) {      // columns [0, K0) of dW go to dW, [K0, K) to dW1 (two parameters behind one contraction)
+      const int64_t n = col / K;
+      const int k = (int)(col % K);
+      if (k < K0) dW[n * lddw + k] = t; else dW1[n * ld1 + (k - K0)] = t;
+    } else {
+      db[col - nk] = t;
+    }
   }
 }
 
@@ -345,14 +352,15 @@ extern "C" size_t dgdm_gemm_tn_workspace_bytes(int32_t M, int32_t N, int32_t K, 
   return (size_t)(nchunks + (nchunks > 32 ? TN_STAGE_SLOTS : 0)) * width * sizeof(float);
 }
 
-extern "C" int dgdm_gemm_tn(const float* dY, int64_t ldy, const float* X, int64_t ldx, float* dW, int64_t lddw, float* db, int32_t M,
-                            int32_t N, int32_t K, void* workspace, size_t workspace_bytes, void* stream_) {
+static int tn_impl(const float* dY, int64_t ldy, const float* X, int64_t ldx, float* dW, int64_t lddw, int32_t K0, float* dW1, int64_t ld1,
+                   float* db, int32_t M, int32_t N, int32_t K, void* workspace, size_t workspace_bytes, void* stream_) {
   if (M < 0 || N < 0 || K < 0) return DGDM_ERR_INVALID_ARG;
   if (N == 0 || K == 0) return DGDM_OK;
-  if (!dW || lddw < K) return DGDM_ERR_INVALID_ARG;
+  if (K0 < 0 || K0 > K || (K0 > 0 && (!dW || lddw < K0)) || (K0 < K && (!dW1 || ld1 < K - K0))) return DGDM_ERR_INVALID_ARG;
   hipStream_t s = static_cast<hipStream_t>(stream_);
   if (M == 0) {
-    (void)hipMemset2DAsync(dW, (size_t)lddw * sizeof(float), 0, (size_t)K * sizeof(float), (size_t)N, s);
+    dgdm_fill2d_async(dW, lddw, K0, N, s);
+    dgdm_fill2d_async(dW1, ld1, K - K0, N, s);
     if (db) dgdm_fill_async(db, 0, sizeof(float) * N, s);
     return dgdm_launch_status();
   }
@@ -378,6 +386,16 @@ extern "C" int dgdm_gemm_tn(const float* dY, int64_t ldy, const float* X, int64_
                        stage, 0, (float*)nullptr);
     fin = stage;
   }
-  hipLaunchKernelGGL(k_gemm_tn_final, dim3((unsigned)((width + 63) / 64)), dim3(256), 0, s, fin, slots, width, N, K, dW, lddw, db);
+  hipLaunchKernelGGL(k_gemm_tn_final, dim3((unsigned)((width + 63) / 64)), dim3(256), 0, s, fin, slots, width, N, K, dW, lddw, db, K0, dW1, ld1);
   return dgdm_launch_status();
+}
+
+extern "C" int dgdm_gemm_tn(const float* dY, int64_t ldy, const float* X, int64_t ldx, float* dW, int64_t lddw, float* db, int32_t M,
+                            int32_t N, int32_t K, void* workspace, size_t workspace_bytes, void* stream) {
+  return tn_impl(dY, ldy, X, ldx, dW, lddw, K, nullptr, 0, db, M, N, K, workspace, workspace_bytes, stream);
+}
+
+extern "C" int dgdm_gemm_tn_split(const float* dY, int64_t ldy, const float* X, int64_t ldx, float* dW0, int64_t ld0, int32_t K0, float* dW1,
+                            int64_t ld1, float* db, int32_t M, int32_t N, int32_t K, void* workspace, size_t workspace_bytes, void* stream) {
+  return tn_impl(dY, ldy, X, ldx, dW0, ld0, K0, dW1, ld1, db, M, N, K, workspace, workspace_bytes, stream);
 }

@@ -15,7 +15,8 @@ template <int LPR, int R, int UNROLL>
 __global__ __launch_bounds__(256) void k_spmm(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                               const float* __restrict__ w, const float* __restrict__ X, int64_t ldx,
                                               int32_t table_rows, float* __restrict__ Y, int64_t ldy, int32_t N, int32_t C,
-                                              const float* __restrict__ bias, int accumulate) {
+                                              const float* __restrict__ bias, int accumulate,
+                                              const float* __restrict__ tail, int64_t ldt, int tail_c4) {
   constexpr int RPW = 64 / LPR;                 // rows per wave
   const int lane = threadIdx.x & 63;
   const int sub = lane / LPR, lir = lane % LPR;  // which row of the wave, lane inside the row
@@ -75,40 +76,48 @@ __global__ __launch_bounds__(256) void k_spmm(const int32_t* __restrict__ rowptr
         dst[k] = o;
       }
     }
+    if (tail) {  // Y[row, C : C + 4*tail_c4) = tail[row, :]  (the [A_hat x | EA_hat] operand of a graph convolution)
+      const float4* t = reinterpret_cast<const float4*>(tail + (int64_t)row * ldt);
+      for (int k = lir; k < tail_c4; k += LPR) dst[c4 + k] = t[k];
+    }
   }
 }
 
 template <int LPR, int R, int UNROLL>
 int launch(const int32_t* rowptr, const int32_t* col, const float* w, const float* X, int64_t ldx, int32_t table_rows,
-           float* Y, int64_t ldy, int32_t N, int32_t C, const float* bias, int accumulate, hipStream_t stream) {
+           float* Y, int64_t ldy, int32_t N, int32_t C, const float* bias, int accumulate, const float* tail, int64_t ldt,
+           int tail_c4, hipStream_t stream) {
   constexpr int RPW = 64 / LPR;
   const int64_t waves = ((int64_t)N + RPW - 1) / RPW;
   int64_t blocks = (waves + 3) / 4;
   if (blocks > 256 * 64) blocks = 256 * 64;  // grid-stride beyond that
   hipLaunchKernelGGL((k_spmm<LPR, R, UNROLL>), dim3((unsigned)blocks), dim3(256), 0, stream, rowptr, col, w, X, ldx,
-                     table_rows, Y, ldy, N, C, bias, accumulate);
+                     table_rows, Y, ldy, N, C, bias, accumulate, tail, ldt, tail_c4);
   return dgdm_launch_status();
 }
 
 }  // namespace
 
-extern "C" int dgdm_spmm(const int32_t* rowptr, const int32_t* col, const float* w, const float* X, int64_t ldx,
+static int spmm_dispatch(const int32_t* rowptr, const int32_t* col, const float* w, const float* X, int64_t ldx,
                          int32_t table_rows, float* Y, int64_t ldy, int32_t N, int32_t C, const float* bias,
-                         int32_t accumulate, void* stream_) {
-  DGDM_REQUIRE(N >= 0 && C > 0 && table_rows >= 0);
+                         int32_t accumulate, const float* tail, int64_t ldt, int32_t Ct, void* stream_) {
+  DGDM_REQUIRE(N >= 0 && C > 0 && table_rows >= 0 && Ct >= 0);
   if (N == 0) return DGDM_OK;
   DGDM_REQUIRE(rowptr && col && w && Y);
   DGDM_REQUIRE(table_rows == 0 || X);
-  if ((C & 3) || C > 1024 || (ldx & 3) || (ldy & 3) || ldx < C || ldy < C) return DGDM_ERR_UNSUPPORTED;
+  DGDM_REQUIRE(Ct == 0 || tail);
+  if ((C & 3) || C > 1024 || (ldx & 3) || (ldy & 3) || ldx < C || ldy < C + Ct) return DGDM_ERR_UNSUPPORTED;
   if (!dgdm_aligned16(X) || !dgdm_aligned16(Y) || (bias && !dgdm_aligned16(bias))) return DGDM_ERR_UNSUPPORTED;
+  if (Ct && ((Ct & 3) || (ldt & 3) || ldt < Ct || !dgdm_aligned16(tail) || accumulate)) return DGDM_ERR_UNSUPPORTED;
   hipStream_t s = static_cast<hipStream_t>(stream_);
   if (table_rows == 0) {  // nothing to gather: Y = 0 (or unchanged when accumulating)
-    if (bias) return DGDM_ERR_UNSUPPORTED;
-    if (!accumulate) (void)hipMemset2DAsync(Y, (size_t)ldy * sizeof(float), 0, (size_t)C * sizeof(float), (size_t)N, s);
+    if (bias || Ct) return DGDM_ERR_UNSUPPORTED;
+    if (!accumulate) dgdm_fill2d_async(Y, ldy, C, N, s);
     return dgdm_launch_status();
   }
   const int c4 = C >> 2;
-#define GO(LPR, R, U) return launch<LPR, R, U>(rowptr, col, w, X, ldx, table_rows, Y, ldy, N, C, bias, accumulate, s)
+  if (!Ct) tail = nullptr;
+#define GO(LPR, R, U) return launch<LPR, R, U>(rowptr, col, w, X, ldx, table_rows, Y, ldy, N, C, bias, accumulate, tail, ldt, Ct >> 2, s)
   if (c4 <= 8) GO(8, 1, 4);
   if (c4 <= 16) GO(16, 1, 4);
   if (c4 <= 32) GO(32, 1, 4);
@@ -117,4 +126,16 @@ extern "C" int dgdm_spmm(const int32_t* rowptr, const int32_t* col, const float*
   if (c4 <= 192) GO(64, 3, 4);
   GO(64, 4, 2);
 #undef GO
+}
+
+extern "C" int dgdm_spmm(const int32_t* rowptr, const int32_t* col, const float* w, const float* X, int64_t ldx,
+                         int32_t table_rows, float* Y, int64_t ldy, int32_t N, int32_t C, const float* bias,
+                         int32_t accumulate, void* stream) {
+  return spmm_dispatch(rowptr, col, w, X, ldx, table_rows, Y, ldy, N, C, bias, accumulate, nullptr, 0, 0, stream);
+}
+
+extern "C" int dgdm_spmm_concat(const int32_t* rowptr, const int32_t* col, const float* w, const float* X, int64_t ldx,
+                                int32_t table_rows, const float* tail, int64_t ldt, int32_t Ct, float* Y, int64_t ldy,
+                                int32_t N, int32_t C, void* stream) {
+  return spmm_dispatch(rowptr, col, w, X, ldx, table_rows, Y, ldy, N, C, nullptr, 0, tail, ldt, Ct, stream);
 }

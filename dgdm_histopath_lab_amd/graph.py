@@ -112,7 +112,8 @@ class GraphStructure:
     __slots__ = ("num_nodes", "num_edges", "num_entries", "rowptr", "col", "eid", "w",
                  "rowptr_t", "col_t", "eid_t", "w_t", "dinv")
 
-    def __init__(self, edge_index: torch.Tensor, num_nodes: int, add_loops: bool = True):
+    def __init__(self, edge_index: torch.Tensor, num_nodes: int, add_loops: bool = True, pipeline: str = "pair"):
+        """``pipeline``: "pair" (dgdm_csr_build_pair) or "single" (one entry point per array set; same results)."""
         _lib.require_cuda(edge_index)
         lib = _lib.load()
         if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.size(0) != 2:
@@ -123,22 +124,29 @@ class GraphStructure:
         n_ent = E + (N if add_loops else 0)
         self.num_nodes, self.num_edges, self.num_entries = N, E, n_ent
         i32 = dict(dtype=torch.int32, device=dev)
-        ws_bytes = lib.dgdm_csr_build_workspace_bytes(E, N, int(add_loops))
-        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
         st = _lib.stream_ptr(dev)
-        outs = []
-        for by_src in (0, 1):
-            rowptr = torch.empty(N + 1, **i32)
-            col = torch.empty(n_ent, **i32)
-            eid = torch.empty(n_ent, **i32)
-            _lib.check(lib.dgdm_csr_build(ei.data_ptr(), E, N, int(add_loops), by_src, rowptr.data_ptr(), col.data_ptr(),
-                                          eid.data_ptr(), ws.data_ptr(), ws_bytes, st), "dgdm_csr_build")
-            outs.append((rowptr, col, eid))
-        (self.rowptr, self.col, self.eid), (self.rowptr_t, self.col_t, self.eid_t) = outs
+        self.rowptr, self.rowptr_t = torch.empty(N + 1, **i32), torch.empty(N + 1, **i32)
+        self.col, self.col_t = torch.empty(n_ent, **i32), torch.empty(n_ent, **i32)
+        self.eid, self.eid_t = torch.empty(n_ent, **i32), torch.empty(n_ent, **i32)
         self.dinv = torch.empty(N, dtype=torch.float32, device=dev)
-        _lib.check(lib.dgdm_gcn_dinv(self.rowptr.data_ptr(), N, self.dinv.data_ptr(), st), "dgdm_gcn_dinv")
         self.w = torch.empty(n_ent, dtype=torch.float32, device=dev)
         self.w_t = torch.empty(n_ent, dtype=torch.float32, device=dev)
+        if pipeline == "pair":       # both orientations, dinv and the weights in five launches
+            ws_bytes = lib.dgdm_csr_build_pair_workspace_bytes(E, N, int(add_loops))
+            ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+            _lib.check(lib.dgdm_csr_build_pair(ei.data_ptr(), E, N, int(add_loops), self.rowptr.data_ptr(), self.col.data_ptr(),
+                                               self.eid.data_ptr(), self.w.data_ptr(), self.rowptr_t.data_ptr(), self.col_t.data_ptr(),
+                                               self.eid_t.data_ptr(), self.w_t.data_ptr(), self.dinv.data_ptr(), ws.data_ptr(),
+                                               ws_bytes, st), "dgdm_csr_build_pair")
+            return
+        if pipeline != "single":
+            raise ValueError(f"unknown CSR pipeline {pipeline!r}")
+        ws_bytes = lib.dgdm_csr_build_workspace_bytes(E, N, int(add_loops))
+        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+        for by_src, (rowptr, col, eid) in enumerate(((self.rowptr, self.col, self.eid), (self.rowptr_t, self.col_t, self.eid_t))):
+            _lib.check(lib.dgdm_csr_build(ei.data_ptr(), E, N, int(add_loops), by_src, rowptr.data_ptr(), col.data_ptr(),
+                                          eid.data_ptr(), ws.data_ptr(), ws_bytes, st), "dgdm_csr_build")
+        _lib.check(lib.dgdm_gcn_dinv(self.rowptr.data_ptr(), N, self.dinv.data_ptr(), st), "dgdm_gcn_dinv")
         _lib.check(lib.dgdm_csr_edge_weights(self.rowptr.data_ptr(), self.col.data_ptr(), self.dinv.data_ptr(), N,
                                              self.w.data_ptr(), st), "dgdm_csr_edge_weights")
         _lib.check(lib.dgdm_csr_edge_weights(self.rowptr_t.data_ptr(), self.col_t.data_ptr(), self.dinv.data_ptr(), N,

@@ -209,10 +209,16 @@ class DGDMModel(nn.Module):
             raise ValidationError("Input features are empty")
         _lib.require_cuda(x, ei)
         n = x.size(0)
-        flags = [torch.isnan(x).any(), torch.isinf(x).any()]
-        if ei.numel() > 0:
-            flags += [ei.max() > n - 1, ei.min() < 0]
-        f = torch.stack([t.to(torch.bool) for t in flags]).tolist()  # the one sync
+        if x.dtype == torch.float32 and x.is_contiguous() and ei.dtype == torch.int64 and ei.is_contiguous():
+            flags = torch.empty(4, dtype=torch.int32, device=x.device)
+            _lib.check(_lib.load().dgdm_validate_inputs(x.data_ptr(), x.numel(), ei.data_ptr(), ei.numel(), n, flags.data_ptr(),
+                                                        _lib.stream_ptr(x.device)), "dgdm_validate_inputs")
+            f = [bool(v) for v in flags.tolist()]  # the one sync
+        else:
+            flags = [torch.isnan(x).any(), torch.isinf(x).any()]
+            if ei.numel() > 0:
+                flags += [ei.max() > n - 1, ei.min() < 0]
+            f = torch.stack([t.to(torch.bool) for t in flags]).tolist()  # the one sync
         if f[0]:
             raise ValidationError("Node features contain NaN values")
         if f[1]:

@@ -649,21 +649,32 @@ def gemm_nn_raw(a, w, out=None, accumulate=False, math="fp32"):
     return out
 
 
-def gemm_tn_raw(dy, x, with_bias: bool, math="fp32"):
-    """dW [N,K] = dy[M,N]^T x[M,K]; db [N] = colsum(dy) (fixed-order split-M reduction)."""
+def gemm_tn_raw(dy, x, with_bias: bool, math="fp32", split: Optional[int] = None):
+    """dW [N,K] = dy[M,N]^T x[M,K]; db [N] = colsum(dy) (fixed-order split-M reduction).
+    ``split=K0``: dW is delivered as two contiguous matrices (dW[:, :K0], dW[:, K0:]) -- returns ((dW0, dW1), db)."""
     lib = _lib.load()
     dy, x = _rowmajor(dy), _rowmajor(x)
     M, N = dy.shape
     K = x.size(1)
-    dW = torch.empty(N, K, dtype=torch.float32, device=x.device)
     db = torch.empty(N, dtype=torch.float32, device=x.device) if with_bias else None
-    fn = _gemm_entry(lib, "dgdm_gemm_tn", math)
     wsb = (lib.dgdm_gemm_tn_workspace_bytes if math == "fp32" else lib.dgdm_gemm_tn_bf16x3_workspace_bytes)(M, N, K, int(with_bias))
     ws = torch.empty(max(wsb, 4) // 4, dtype=torch.float32, device=x.device)
+    if split is None:
+        dW = torch.empty(N, K, dtype=torch.float32, device=x.device)
+        fn = _gemm_entry(lib, "dgdm_gemm_tn", math)
+        TIMERS.timed("gemm_tn", lambda: _lib.check(
+            fn(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), dW.data_ptr(), dW.stride(0), _lib.ptr(db), M, N, K,
+               ws.data_ptr(), wsb, _lib.stream_ptr(x.device)), "dgdm_gemm_tn"))
+        return dW, db
+    if not 0 < split < K:
+        raise ValueError(f"split must lie inside (0, {K}), got {split}")
+    dW0 = torch.empty(N, split, dtype=torch.float32, device=x.device)
+    dW1 = torch.empty(N, K - split, dtype=torch.float32, device=x.device)
+    fn = _gemm_entry(lib, "dgdm_gemm_tn_split", math)
     TIMERS.timed("gemm_tn", lambda: _lib.check(
-        fn(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), dW.data_ptr(), dW.stride(0), _lib.ptr(db), M, N, K,
-           ws.data_ptr(), wsb, _lib.stream_ptr(x.device)), "dgdm_gemm_tn"))
-    return dW, db
+        fn(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), dW0.data_ptr(), dW0.stride(0), split, dW1.data_ptr(), dW1.stride(0),
+           _lib.ptr(db), M, N, K, ws.data_ptr(), wsb, _lib.stream_ptr(x.device)), "dgdm_gemm_tn_split"))
+    return (dW0, dW1), db
 
 
 # Which implementation runs the dense contractions (env DGDM_GEMM):
@@ -714,6 +725,52 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
 def lin(module, x: torch.Tensor) -> torch.Tensor:
     """Apply an nn.Linear through `linear`."""
     return linear(x, module.weight, module.bias)
+
+
+class _GraphConvLinear(torch.autograd.Function):
+    """GraphConvolution in one autograd node:  out = [A_hat x | EA_hat] . [W | W_e]^T + b  (graph_layers.py:89-110).
+
+    forward : one SpMM that also lays EA_hat next to its result (dgdm_spmm_concat), one cat of the two weights, one GEMM;
+    backward: dW and dW_e leave the split-M GEMM as two contiguous matrices (no slicing copies), the input gradient is
+              contracted over W alone (EA_hat depends only on the inputs) and scattered back by the transposed SpMM."""
+
+    @staticmethod
+    def forward(ctx, x, ea_hat, gs: GraphStructure, w, we, b):
+        lib = _lib.load()
+        x = x if (x.dim() == 2 and x.stride(1) == 1 and x.stride(0) % 4 == 0) else _f32c(x)
+        ea_hat = _rowmajor(ea_hat)
+        n, cin, ed = gs.num_nodes, x.size(1), ea_hat.size(1)
+        buf = torch.empty(n, cin + ed, dtype=torch.float32, device=x.device)
+        TIMERS.timed(f"spmm_c{cin}", lambda: _lib.check(
+            lib.dgdm_spmm_concat(gs.rowptr.data_ptr(), gs.col.data_ptr(), gs.w.data_ptr(), x.data_ptr(), x.stride(0), x.size(0),
+                                 ea_hat.data_ptr(), ea_hat.stride(0), ed, buf.data_ptr(), buf.stride(0), n, cin,
+                                 _lib.stream_ptr(x.device)), "dgdm_spmm_concat"))
+        wcat = torch.cat([w, we], dim=1)
+        ctx.save_for_backward(buf, wcat)
+        ctx.gs, ctx.cin, ctx.has_bias = gs, cin, b is not None
+        if GEMM_FWD_BACKEND == "lib":
+            return torch.nn.functional.linear(buf, wcat, b)
+        return gemm_nt_raw(buf, wcat, b, math="bf16x3" if GEMM_FWD_BACKEND == "bf16x3" else "fp32")
+
+    @staticmethod
+    def backward(ctx, gy):
+        buf, wcat = ctx.saved_tensors
+        gs, cin = ctx.gs, ctx.cin
+        gy = _rowmajor(gy)
+        math = "bf16x3" if GEMM_FWD_BACKEND == "bf16x3" else "fp32"
+        dx = None
+        if ctx.needs_input_grad[0]:
+            w_only = wcat[:, :cin]                      # a view: row stride cin + edge_dim
+            dagg = gy @ w_only if GEMM_FWD_BACKEND == "lib" else gemm_nn_raw(gy, w_only, math=math)
+            dx = spmm_raw(gs.rowptr_t, gs.col_t, gs.w_t, dagg, gs.num_nodes)
+        dw = dwe = db = None
+        if ctx.needs_input_grad[3] or ctx.needs_input_grad[4] or (ctx.has_bias and ctx.needs_input_grad[5]):
+            (dw, dwe), db = gemm_tn_raw(gy, buf, ctx.has_bias, math=math, split=cin)
+        return dx, None, None, dw, dwe, db
+
+
+def graph_conv_linear(x, ea_hat, gs: GraphStructure, w, we, b):
+    return _GraphConvLinear.apply(x, ea_hat, gs, w, we, b)
 
 
 # ----------------------------------------------------------------------------- K9 top-k pooling / unpooling

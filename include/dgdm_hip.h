@@ -54,6 +54,12 @@ DGDM_API const char* dgdm_error_string(int code);
 DGDM_API int dgdm_seed_epoch_advance(void* stream);
 DGDM_API int dgdm_seed_epoch_set(uint32_t value, void* stream);
 
+/* Input checks of DGDMModel.forward (models/dgdm_model.py:646-690): one pass over the node features x (x_numel
+ * contiguous floats, 16-byte aligned) and one over edge_index (edge_numel int64 ids).  flags4[0]: NaN in x, [1]: inf
+ * in x, [2]: an edge id > num_nodes - 1, [3]: an edge id < 0 (each 0 or 1); the host reads the four words back once. */
+DGDM_API int dgdm_validate_inputs(const float* x, int64_t x_numel, const int64_t* edge_index, int64_t edge_numel,
+                                  int64_t num_nodes, uint32_t* flags4, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * K1  edge list -> CSR.   Replaces the index preparation of GraphConvolution.forward
  * (core/graph_layers.py:76-84: add_self_loops, degree) and fixes the scatter-add order of
@@ -82,6 +88,15 @@ DGDM_API int dgdm_gcn_dinv(const int32_t* rowptr_dst, int32_t N, float* dinv, vo
 DGDM_API int dgdm_csr_edge_weights(const int32_t* rowptr, const int32_t* col, const float* dinv, int32_t N,
                                    float* w, void* stream);
 
+/* Everything one edge list needs, in one pipeline of five launches: both CSR orientations (_dst = by_src 0, _src =
+ * by_src 1), dinv and the GCN weight w of every entry -- bit for bit what two dgdm_csr_build calls, dgdm_gcn_dinv and
+ * two dgdm_csr_edge_weights calls produce (seventeen launches; a training step builds seven such sets). */
+DGDM_API size_t dgdm_csr_build_pair_workspace_bytes(int64_t E, int32_t N, int32_t add_loops);
+DGDM_API int dgdm_csr_build_pair(const int64_t* edge_index, int64_t E, int32_t N, int32_t add_loops,
+                                 int32_t* rowptr_dst, int32_t* col_dst, int32_t* eid_dst, float* w_dst,
+                                 int32_t* rowptr_src, int32_t* col_src, int32_t* eid_src, float* w_src, float* dinv,
+                                 void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * K2  CSR segmented gather-reduce  Y[r,:] = sum_{p in row r} w[p] * X[col[p],:]  (+ bias).
  * Replaces MessagePassing.propagate's gather by edge_index[0] + `norm * msg` + scatter-add by
@@ -98,6 +113,12 @@ DGDM_API int dgdm_spmm(const int32_t* rowptr, const int32_t* col, const float* w
                        const float* X, int64_t ldx, int32_t table_rows,
                        float* Y, int64_t ldy, int32_t N, int32_t C,
                        const float* bias, int32_t accumulate, void* stream);
+/* Y[r, 0:C) as dgdm_spmm (no bias, no accumulate) and Y[r, C:C+Ct) = tail[r, :] in the same pass: the operand
+ * [A_hat x | EA_hat] of a graph convolution's single contraction (graph_layers.py:99-110) without a separate copy of the
+ * per-graph edge-attribute aggregate.  Ct % 4 == 0, ldt % 4 == 0, ldy >= C + Ct. */
+DGDM_API int dgdm_spmm_concat(const int32_t* rowptr, const int32_t* col, const float* w, const float* X, int64_t ldx,
+                              int32_t table_rows, const float* tail, int64_t ldt, int32_t Ct, float* Y, int64_t ldy,
+                              int32_t N, int32_t C, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K4  fused variable-length spatial attention (head dim 16), forward.
@@ -281,6 +302,12 @@ DGDM_API int dgdm_gemm_nn(const float* A, int64_t lda, const float* W, int64_t l
 DGDM_API size_t dgdm_gemm_tn_workspace_bytes(int32_t M, int32_t N, int32_t K, int32_t with_bias);
 DGDM_API int dgdm_gemm_tn(const float* dY, int64_t ldy, const float* X, int64_t ldx, float* dW, int64_t lddw, float* db, int32_t M,
                           int32_t N, int32_t K, void* workspace, size_t workspace_bytes, void* stream);
+/* dgdm_gemm_tn with the K columns of dW delivered to two matrices: [0, K0) -> dW0 (leading dimension ld0), [K0, K) -> dW1
+ * (ld1).  The graph convolution contracts [A_hat x | EA_hat] with [W | W_e] in one GEMM (graph_layers.py:99-110 has two
+ * Linear layers); this hands each of the two parameters a contiguous gradient without a copy.  Same workspace. */
+DGDM_API int dgdm_gemm_tn_split(const float* dY, int64_t ldy, const float* X, int64_t ldx, float* dW0, int64_t ld0, int32_t K0,
+                                float* dW1, int64_t ld1, float* db, int32_t M, int32_t N, int32_t K, void* workspace,
+                                size_t workspace_bytes, void* stream);
 
 /* The same three contractions on the 16-bit matrix pipe with fp32-level accuracy: every fp32 operand
  * is split exactly into three bf16 values (x = h + m + l) on its way into LDS and a product is the
@@ -294,6 +321,9 @@ DGDM_API int dgdm_gemm_nn_bf16x3(const float* A, int64_t lda, const float* W, in
 DGDM_API size_t dgdm_gemm_tn_bf16x3_workspace_bytes(int32_t M, int32_t N, int32_t K, int32_t with_bias);
 DGDM_API int dgdm_gemm_tn_bf16x3(const float* dY, int64_t ldy, const float* X, int64_t ldx, float* dW, int64_t lddw, float* db,
                                  int32_t M, int32_t N, int32_t K, void* workspace, size_t workspace_bytes, void* stream);
+DGDM_API int dgdm_gemm_tn_split_bf16x3(const float* dY, int64_t ldy, const float* X, int64_t ldx, float* dW0, int64_t ld0,
+                                       int32_t K0, float* dW1, int64_t ld1, float* db, int32_t M, int32_t N, int32_t K,
+                                       void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K9  top-k node pooling and unpooling of the graph U-Net

@@ -36,6 +36,23 @@ def test_gemm_nt_nn_tn(m, k, n, math):
     assert_close(dW3, gy.double().t() @ x.double(), 1e-5, "tn dW (no bias)")
 
 
+@pytest.mark.parametrize("math", MATHS)
+@pytest.mark.parametrize("m,k,k0,n", [(4001, 544, 512, 512), (40000, 160, 128, 128), (300, 36, 4, 64)])
+def test_gemm_tn_split_output_is_the_unsplit_result(m, k, k0, n, math):
+    """dgdm_gemm_tn_split: the same sums, delivered as two contiguous matrices (bit for bit)."""
+    from dgdm_histopath_lab_amd import ops
+    g = torch.Generator().manual_seed(m + k)
+    x, gy = torch.randn(m, k, generator=g).to(DEV), torch.randn(m, n, generator=g).to(DEV)
+    for with_bias in (True, False):
+        dW, db = ops.gemm_tn_raw(gy, x, with_bias, math=math)
+        (d0, d1), db2 = ops.gemm_tn_raw(gy, x, with_bias, math=math, split=k0)
+        assert d0.is_contiguous() and d1.is_contiguous() and d0.shape == (n, k0) and d1.shape == (n, k - k0)
+        assert torch.equal(d0, dW[:, :k0]) and torch.equal(d1, dW[:, k0:])
+        assert (db is None and db2 is None) or torch.equal(db, db2)
+    with pytest.raises(ValueError):
+        ops.gemm_tn_raw(gy, x, False, math=math, split=k)
+
+
 def test_bf16x3_matches_fp32_mfma_accuracy():
     """The split GEMM's error against fp64 is of the size of the fp32-MFMA kernel's own (accumulation
     rounding), also for operands spanning many binades and for gradient-sized (1e-6) values."""

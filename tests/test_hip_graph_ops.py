@@ -25,10 +25,11 @@ def _rand_edges(n, e, seed, hub=False):
 
 @pytest.mark.parametrize("n,e,hub", [(1, 0, False), (7, 0, False), (16, 40, False), (1000, 5000, False), (3000, 20000, True),
                                      (10000, 50000, False), (70001, 300007, False)])
-def test_csr_build_bit_exact(n, e, hub):
+@pytest.mark.parametrize("pipeline", ["pair", "single"])
+def test_csr_build_bit_exact(n, e, hub, pipeline):
     from dgdm_histopath_lab_amd import GraphStructure
     ei = _rand_edges(n, e, n + e, hub)
-    gs = GraphStructure(torch.from_numpy(ei).to(_dev()), n)
+    gs = GraphStructure(torch.from_numpy(ei).to(_dev()), n, pipeline=pipeline)
     o = csr_oracle.gcn_csr(ei, n)
     for k in ("rowptr", "col", "eid", "rowptr_t", "col_t", "eid_t"):
         got = getattr(gs, k).cpu().numpy()
@@ -47,6 +48,23 @@ def test_csr_build_no_loops_and_determinism():
     assert np.array_equal(a.col.cpu().numpy(), o["col"]) and np.array_equal(a.eid_t.cpu().numpy(), o["eid_t"])
     b = GraphStructure(t, 500, add_loops=False)
     assert torch.equal(a.col, b.col) and torch.equal(a.eid, b.eid)  # atomics only order-free counts
+
+
+def test_csr_pipelines_agree_with_dropped_edges():
+    """Edges with an endpoint outside [0, N) (how the sync-free pooling marks dropped edges) are skipped by both pipelines;
+    every defined array entry and all weights agree bit for bit."""
+    from dgdm_histopath_lab_amd import GraphStructure
+    ei = _rand_edges(4000, 30000, 7)
+    ei[0, ::7] = -1
+    ei[1, 3::11] = 4000 + 5
+    t = torch.from_numpy(ei).to(_dev())
+    for loops in (True, False):
+        a, b = GraphStructure(t, 4000, add_loops=loops), GraphStructure(t, 4000, add_loops=loops, pipeline="single")
+        m = int(a.rowptr[-1])
+        assert m == int(b.rowptr[-1]) == int(a.rowptr_t[-1]) and m < a.num_entries
+        assert torch.equal(a.rowptr, b.rowptr) and torch.equal(a.rowptr_t, b.rowptr_t) and torch.equal(a.dinv, b.dinv)
+        for k in ("col", "eid", "w", "col_t", "eid_t", "w_t"):
+            assert torch.equal(getattr(a, k)[:m], getattr(b, k)[:m]), k
 
 
 @pytest.mark.parametrize("c", [4, 32, 36, 128, 256, 512, 768, 1024])
@@ -99,3 +117,33 @@ def test_ops_fail_loudly_on_cpu_tensors():
     from dgdm_histopath_lab_amd import DGDMKernelError, GraphStructure
     with pytest.raises(DGDMKernelError):
         GraphStructure(torch.zeros(2, 3, dtype=torch.long), 4)
+
+
+@pytest.mark.parametrize("n,e,cin,cout", [(3000, 15000, 128, 128), (10000, 50000, 512, 256), (300, 900, 36, 64)])
+def test_graph_conv_linear_is_the_two_step_path(n, e, cin, cout):
+    """ops.graph_conv_linear (SpMM with the edge aggregate laid beside it, one GEMM, split weight gradients) against
+    aggregate_concat + linear on a concatenated weight: same values, same gradients."""
+    from dgdm_histopath_lab_amd import GraphStructure, ops
+    dev = _dev()
+    ei = _rand_edges(n, e, 11)
+    gs = GraphStructure(torch.from_numpy(ei).to(dev), n)
+    g = torch.Generator().manual_seed(5)
+    ea_hat = ops.aggregate_edge_attr(torch.randn(e, 32, generator=g).to(dev), gs)
+    gy = torch.randn(n, cout, generator=g).to(dev)
+
+    def leaves():
+        gg = torch.Generator().manual_seed(9)
+        return [t.to(dev).requires_grad_(True) for t in (torch.randn(n, cin, generator=gg), torch.randn(cout, cin, generator=gg) / cin ** 0.5,
+                                                         torch.randn(cout, 32, generator=gg) / 6, torch.randn(cout, generator=gg))]
+    x1, w1, we1, b1 = leaves()
+    y1 = ops.graph_conv_linear(x1, ea_hat, gs, w1, we1, b1)
+    y1.backward(gy)
+    x2, w2, we2, b2 = leaves()
+    y2 = ops.linear(ops.aggregate_concat(x2, ea_hat, gs), torch.cat([w2, we2], dim=1), b2)
+    y2.backward(gy)
+    assert torch.equal(y1, y2)
+    assert w1.grad.is_contiguous() and we1.grad.is_contiguous()
+    assert torch.equal(w1.grad, w2.grad) and torch.equal(we1.grad, we2.grad) and torch.equal(b1.grad, b2.grad)
+    # the input gradient is contracted over W alone instead of [W | W_e]: other K, other summation tree
+    scale = float(x2.grad.abs().max())
+    assert torch.allclose(x1.grad, x2.grad, rtol=1e-4, atol=1e-5 * scale)

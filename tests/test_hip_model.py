@@ -352,5 +352,15 @@ def test_model_error_contract():
         m(GraphData(x=torch.randn(10, 31, device=DEV), edge_index=ei))
     with pytest.raises(ModelInferenceError, match="invalid node indices"):
         m(GraphData(x=x, edge_index=ei + 5))
+    neg = ei.clone(); neg[1, 7] = -1
+    with pytest.raises(ModelInferenceError, match="negative"):
+        m(GraphData(x=x, edge_index=neg))
+    inf = x.clone(); inf[9, 31] = float("-inf")           # last element: the scalar tail of the vectorised pass
+    with pytest.raises(ModelInferenceError, match="infinity"):
+        m(GraphData(x=inf, edge_index=ei))
+    odd = torch.randn(11, 33, device=DEV)[:, :32]          # non-contiguous x takes the tensor-expression checks
+    odd[3, 3] = float("nan")
+    with pytest.raises(ModelInferenceError, match="NaN"):
+        m(GraphData(x=odd, edge_index=ei))
     with pytest.raises(ModelInferenceError):
         m(GraphData(x=x.cpu(), edge_index=ei.cpu()))  # no CPU fallback
