@@ -31,4 +31,80 @@ __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ in, in
   }
 }
 
+// Single-launch variant: each block owns 256/PARTS columns, its PARTS thread rows stride over the slots (two loads in
+// flight), LDS combines them in fixed order.  PARTS = 16 for hundreds of slots, 4 for a few.
+// split > 0: columns [0, split) go to out, [split, width) to out1; split <= 0: everything to out.
+template <int PARTS>
+__global__ __launch_bounds__(256) void k_colsum_final(const float* __restrict__ in, int slots, int width, float* __restrict__ out,
+                                                      int split, float* __restrict__ out1) {
+  constexpr int COLS = 256 / PARTS;
+  const int c = threadIdx.x % COLS, part = threadIdx.x / COLS;
+  const int col = blockIdx.x * COLS + c;
+  float a0 = 0.f, a1 = 0.f;
+  if (col < width) {
+    int s = part;
+    for (; s + PARTS < slots; s += 2 * PARTS) {
+      a0 += in[(int64_t)s * width + col];
+      a1 += in[(int64_t)(s + PARTS) * width + col];
+    }
+    if (s < slots) a0 += in[(int64_t)s * width + col];
+  }
+  __shared__ float sm[PARTS][COLS];
+  sm[part][c] = a0 + a1;
+  __syncthreads();
+  if (part == 0 && col < width) {
+    float t = sm[0][c];
+#pragma unroll
+    for (int p = 1; p < PARTS; ++p) t += sm[p][c];
+    if (split > 0 && col >= split) out1[col - split] = t; else out[col] = t;
+  }
+}
+
+// Two stages in ONE launch for thousands of slots: block (x, y) sums slot chunk y of 64 columns into stage[y][:]
+// (k_colsum's stage 1), then takes a ticket for its column block; the block that draws the last ticket adds the
+// gridDim.y stage rows in index order and writes the result -- fixed summation order whichever block that is.
+// tickets[gridDim.x] must be zero at launch (the producer kernel of `in` zeroes them: stream order).
+__global__ __launch_bounds__(256) void k_colsum_ticket(const float* __restrict__ in, int64_t slots, int width, int64_t chunk,
+                                                       float* __restrict__ stage, unsigned* __restrict__ tickets,
+                                                       float* __restrict__ out, int split, float* __restrict__ out1) {
+  const int c = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + c;
+  const int64_t s0 = (int64_t)blockIdx.y * chunk;
+  const int64_t s1 = s0 + chunk < slots ? s0 + chunk : slots;
+  float a0 = 0.f, a1 = 0.f;
+  if (col < width) {
+    int64_t s = s0 + part;
+    for (; s + 4 < s1; s += 8) {
+      a0 += in[s * width + col];
+      a1 += in[(s + 4) * width + col];
+    }
+    if (s < s1) a0 += in[s * width + col];
+  }
+  __shared__ float sm[4][64];
+  __shared__ bool last;
+  sm[part][c] = a0 + a1;
+  __syncthreads();
+  if (part == 0 && col < width) {
+    stage[(int64_t)blockIdx.y * width + col] = (sm[0][c] + sm[1][c]) + (sm[2][c] + sm[3][c]);
+    __threadfence();
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) last = atomicAdd(&tickets[blockIdx.x], 1u) == gridDim.y - 1;
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  if (part == 0 && col < width) {
+    float t = 0.f;
+    for (unsigned y = 0; y < gridDim.y; ++y) t += __builtin_nontemporal_load(&stage[(int64_t)y * width + col]);
+    if (split > 0 && col >= split) out1[col - split] = t; else out[col] = t;
+  }
+}
+
+inline void colsum_final_launch(const float* in, int slots, int width, float* out, int split, float* out1, hipStream_t s) {
+  if (slots > 32)
+    hipLaunchKernelGGL(k_colsum_final<16>, dim3((width + 15) / 16), dim3(256), 0, s, in, slots, width, out, split, out1);
+  else
+    hipLaunchKernelGGL(k_colsum_final<4>, dim3((width + 63) / 64), dim3(256), 0, s, in, slots, width, out, split, out1);
+}
+
 }  // namespace

@@ -401,13 +401,8 @@ extern "C" int dgdm_pool_score_bwd(const float* h, int64_t ldh, const float* w2,
   const int rpb = (N + SCORE_BWD_BLOCKS - 1) / SCORE_BWD_BLOCKS;
   const int nb = (N + rpb - 1) / rpb;
   float* partial = static_cast<float*>(workspace);
-  float* stage = partial + (size_t)SCORE_BWD_BLOCKS * (C + 1);
   hipLaunchKernelGGL(k_pool_score_bwd, dim3(nb), dim3(256), 0, st, h, ldh, w2, s, ds, N, C, rpb, dh, lddh, partial);
-  const int width = C + 1;
-  const int64_t per = (nb + 15) / 16;
-  const int slots = (int)((nb + per - 1) / per);
-  hipLaunchKernelGGL(k_colsum, dim3((width + 63) / 64, slots), dim3(256), 0, st, partial, (int64_t)nb, width, per, stage, 0, (float*)nullptr);
-  hipLaunchKernelGGL(k_colsum, dim3((width + 63) / 64, 1), dim3(256), 0, st, stage, (int64_t)slots, width, (int64_t)slots, dw2, C, db2);
+  colsum_final_launch(partial, nb, C + 1, dw2, C, db2, st);
   return dgdm_launch_status();
 }
 

@@ -102,8 +102,10 @@ __global__ __launch_bounds__(256) void k_rownorm_bwd(const float* __restrict__ x
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
                                                      const float* __restrict__ dy, int64_t rows, int L, int G, float drop_p,
-                                                     DgdmSeed seed_in, float* __restrict__ dx, float* __restrict__ partial, int C) {
+                                                     DgdmSeed seed_in, float* __restrict__ dx, float* __restrict__ partial, int C,
+                                                     unsigned* __restrict__ tickets, int ntickets) {
   const uint32_t seed = seed_in.value();
+  if (blockIdx.x == 0 && (int)threadIdx.x < ntickets) tickets[threadIdx.x] = 0u;   // for the column-sum kernel that follows
   constexpr int GPW = 64 / LPR;
   const int lane = threadIdx.x & 63, sub = lane / LPR, lir = lane % LPR;
   const int64_t ngroups = (int64_t)gridDim.x * (blockDim.x >> 6) * GPW;  // multiple of G (host guarantees)
@@ -300,15 +302,15 @@ extern "C" int dgdm_rownorm_bwd(const float* x, const float* res, const float* g
   float* partial = static_cast<float*>(workspace);
 #define BWD(LPR_, R_, ACT_, ...) \
   hipLaunchKernelGGL((k_rownorm_bwd<LPR_, R_, ACT_>), dim3((unsigned)blocks), dim3(256), 0, s, __VA_ARGS__)
-  ROWNORM_DISPATCH(BWD, x, res, gamma, beta, mean, rstd, dy, rows, L, G, drop_p, dgdm_seed_arg(seed), dx, partial, C);
-#undef BWD
-  // dgamma | dbeta = column sums of partial [slots][2C], two fixed-order stages
+  // dgamma | dbeta = column sums of partial [slots][2C]: two fixed-order stages in one launch (tickets zeroed above)
   float* stage1 = partial + slots * 2 * C;
+  unsigned* tickets = reinterpret_cast<unsigned*>(stage1 + (int64_t)REDUCE_CHUNKS * 2 * C);
+  const int ntickets = (2 * C + 63) / 64;
+  if (ntickets > 256) return DGDM_ERR_UNSUPPORTED;
+  ROWNORM_DISPATCH(BWD, x, res, gamma, beta, mean, rstd, dy, rows, L, G, drop_p, dgdm_seed_arg(seed), dx, partial, C, tickets, ntickets);
+#undef BWD
   const int64_t chunk = (slots + REDUCE_CHUNKS - 1) / REDUCE_CHUNKS;
   const int nch = (int)((slots + chunk - 1) / chunk);
-  hipLaunchKernelGGL(k_colsum, dim3((2 * C + 63) / 64, nch), dim3(256), 0, s, partial, slots, 2 * C, chunk, stage1, 0,
-                     (float*)nullptr);
-  hipLaunchKernelGGL(k_colsum, dim3((2 * C + 63) / 64, 1), dim3(256), 0, s, stage1, (int64_t)nch, 2 * C, (int64_t)nch, dgamma, C,
-                     dbeta);
+  hipLaunchKernelGGL(k_colsum_ticket, dim3(ntickets, nch), dim3(256), 0, s, partial, slots, 2 * C, chunk, stage1, tickets, dgamma, C, dbeta);
   return dgdm_launch_status();
 }
