@@ -278,6 +278,8 @@ def main():
                     "unit": "TFLOP/s", "frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(kernels[dom]),
                     "ms_per_launch": round(ms, 4), "launches_timed": timers[dom][0], "algorithmic_flop": flops[dom],
                     "other_kernels_ms": {k: round(v[1], 4) for k, v in timers.items() if k != dom}}
+        roofline["timed_with"] = ("HIP events around eager launches of the same step right after the timed region (a graph replay "
+                                  "cannot carry events)" if graphed else "HIP events inside the timed region")
         if args.mixed:   # launches differ in size from step to step: no single algorithmic FLOP count per launch
             roofline = {"note": "not computed for the mixed-size stream; see the fixed-size headline run"}
         elif split:
@@ -295,7 +297,8 @@ def main():
                                     f"DGDM-Base pretrain_step fwd+bwd+AdamW, batch={args.batch} x {args.nodes}-node/{args.edges}-edge "
                                     f"graphs per GPU, feat={FEATS}, edge_attr=32, T=10, heads=8, ") +
                                    f"{'eval (dropout off)' if args.eval_mode else 'training mode (dropout 0.1)'}",
-                       "global_batch": world * args.batch, "parallelism": f"dp{world}", "final_loss": round(loss_val, 5)},
+                       "global_batch": world * args.batch, "parallelism": f"dp{world}", "final_loss": round(loss_val, 5),
+                       "launch": "HIP graph replay (training.GraphedPretrainStep)" if graphed else "eager"},
             "roofline": roofline,
         }
     if world > 1 or force_dist:
