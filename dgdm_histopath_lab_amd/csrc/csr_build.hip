@@ -168,31 +168,38 @@ __global__ void k_count_pair(const int64_t* __restrict__ ei, int64_t E, int32_t 
   }
 }
 
-// block o scans the N row counts of orientation o (four per thread and iteration, running carry); block 0 also
-// writes dinv from the in-degrees it is looking at (k_dinv's formula)
+// Exclusive scan of the row counts (+1 per row with loops), orientation blockIdx.y, without a second launch or a
+// look-back chain: block b owns rows [b*4096, (b+1)*4096), first adds up every count in front of its chunk (the whole
+// array is a few hundred KB in L2), then scans its own chunk.  Block (b, 0) also writes dinv from the in-degrees it is
+// looking at (k_dinv's formula).
+constexpr int SCAN_CHUNK = 4 * SCAN_BLOCK;
 __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_pair(PairArrays a, int32_t N, int extra, float* __restrict__ dinv) {
-  const int o = blockIdx.x;
+  const int o = blockIdx.y;
   const int32_t* __restrict__ cnt = a.cnt[o];
   int32_t* __restrict__ rowptr = a.rowptr[o];
-  int carry = 0;
-  for (int base = 0; base < N; base += 4 * SCAN_BLOCK) {
-    const int i = base + 4 * threadIdx.x;
-    int v[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = i + j < N ? cnt[i + j] + extra : 0;
-    int tot;
-    int ex = carry + block_exclusive_scan(v[0] + v[1] + v[2] + v[3], &tot);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (i + j < N) {
-        rowptr[i + j] = ex;
-        if (o == 0) dinv[i + j] = v[j] > 0 ? 1.0f / sqrtf((float)v[j]) : 0.f;
-      }
-      ex += v[j];
-    }
-    carry += tot;
+  const int base = blockIdx.x * SCAN_CHUNK;
+  int before = 0;
+  for (int i = 4 * threadIdx.x; i < base; i += SCAN_CHUNK) {   // base is a multiple of 4: whole int4s (arrays are 256-B aligned)
+    const int4 c = *reinterpret_cast<const int4*>(cnt + i);
+    before += (c.x + c.y) + (c.z + c.w);
   }
-  if (threadIdx.x == 0) rowptr[N] = carry;
+  int tot;
+  block_exclusive_scan(before, &tot);
+  const int carry = tot + extra * base;
+  const int i = base + 4 * threadIdx.x;
+  int v[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] = i + j < N ? cnt[i + j] + extra : 0;
+  int ex = carry + block_exclusive_scan(v[0] + v[1] + v[2] + v[3], &tot);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (i + j < N) {
+      rowptr[i + j] = ex;
+      if (o == 0) dinv[i + j] = v[j] > 0 ? 1.0f / sqrtf((float)v[j]) : 0.f;
+    }
+    ex += v[j];
+  }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) rowptr[N] = carry + tot;
 }
 
 __global__ void k_fill_pair(const int64_t* __restrict__ ei, int64_t E, int32_t N, PairArrays a) {
@@ -244,7 +251,7 @@ __global__ void k_rank_pair(PairArrays a, int32_t N, int32_t E32, int add_loops,
 }
 
 struct PairWorkspace {
-  int32_t *cnt[2], *cursor[2], *tcol[2], *teid[2];
+  int32_t *cnt[2], *cursor[2], *tcol[2], *teid[2], *block_tot[2];
   size_t counters_bytes, bytes;
 };
 
@@ -261,6 +268,8 @@ PairWorkspace carve_pair(void* base, int64_t E, int32_t N, int32_t add_loops) {
   w.cnt[0] = take(N); w.cnt[1] = take(N); w.cursor[0] = take(N); w.cursor[1] = take(N);
   w.counters_bytes = off;  // the four counter arrays are adjacent: one fill
   w.tcol[0] = take(n_entries); w.tcol[1] = take(n_entries); w.teid[0] = take(n_entries); w.teid[1] = take(n_entries);
+  const size_t nblk = ((size_t)N + SCAN_BLOCK - 1) / SCAN_BLOCK + 1;
+  w.block_tot[0] = take(nblk); w.block_tot[1] = take(nblk);
   w.bytes = off;
   return w;
 }
@@ -381,7 +390,18 @@ extern "C" int dgdm_csr_build_pair(const int64_t* edge_index, int64_t E, int32_t
   dgdm_fill_async(ws.cnt[0], 0, ws.counters_bytes, stream);
   const int eb = (int)((E + 255) / 256 < 4096 ? (E + 255) / 256 : 4096);
   if (E > 0) hipLaunchKernelGGL(k_count_pair, dim3(eb), dim3(256), 0, stream, edge_index, E, N, ws.cnt[0], ws.cnt[1]);
-  hipLaunchKernelGGL(k_scan_pair, dim3(2), dim3(SCAN_BLOCK), 0, stream, a, N, extra, dinv);
+  if (N <= (1 << 20)) {
+    hipLaunchKernelGGL(k_scan_pair, dim3((N + SCAN_CHUNK - 1) / SCAN_CHUNK, 2), dim3(SCAN_BLOCK), 0, stream, a, N, extra, dinv);
+  } else {   // k_scan_pair reads O(N^2 / 4096) counts: beyond ~1M rows the three-pass scan is cheaper
+    const int nblk = (N + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    for (int o = 0; o < 2; ++o) {
+      int32_t* block_tot = ws.block_tot[o];
+      hipLaunchKernelGGL(k_scan_block_totals, dim3(nblk), dim3(SCAN_BLOCK), 0, stream, ws.cnt[o], N, extra, block_tot);
+      hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(SCAN_BLOCK), 0, stream, block_tot, nblk);
+      hipLaunchKernelGGL(k_scan_write, dim3(nblk), dim3(SCAN_BLOCK), 0, stream, ws.cnt[o], N, extra, block_tot, a.rowptr[o]);
+    }
+    hipLaunchKernelGGL(k_dinv, dim3((N + 255) / 256), dim3(256), 0, stream, a.rowptr[0], N, dinv);
+  }
   if (E > 0) hipLaunchKernelGGL(k_fill_pair, dim3(eb), dim3(256), 0, stream, edge_index, E, N, a);
   if (n_entries > 0) {
     const int rb = (N + 3) / 4 < 8192 ? (N + 3) / 4 : 8192;

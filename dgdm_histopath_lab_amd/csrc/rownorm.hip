@@ -199,7 +199,8 @@ int64_t bwd_lane_groups(int64_t rows, int G, const Geo& geo) {
   // lane groups in the backward grid: enough to fill the chip, a multiple of G and of the
   // groups-per-block, capped so the partial buffer stays small
   const int gpw = 64 / geo.lpr, gpb = gpw * 4;
-  int64_t want = rows < 4096 ? rows : 4096;
+  int64_t want = 4096 > 1024 * gpb ? 4096 : 1024 * gpb;   // >= 1024 workgroups also when a block packs 16 or 32 narrow rows
+  if (want > rows) want = rows;
   int64_t unit = (int64_t)gpb * G / std::gcd((int64_t)gpb, (int64_t)G);
   int64_t n = (want + unit - 1) / unit * unit;
   return n < unit ? unit : n;

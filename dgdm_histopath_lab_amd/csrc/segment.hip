@@ -106,52 +106,100 @@ __device__ __forceinline__ float drop_factor(uint32_t seed, uint64_t e, uint32_t
   return (a & 0xFFFFu) >= thresh ? keep_scale : 0.f;
 }
 
-// grid (H, B), 256 threads.  qs = q_proj(global_token) * 1/sqrt(d)  [H*D].
+// Forward in two launches over (head, graph, chunk of POOL_ROWS nodes) instead of one block per (head, graph) walking
+// 10k nodes three times: (1) per chunk: scores, chunk maximum m_c, e = exp(s - m_c) (left in P), l_c = sum e,
+// acc_c = sum e * dropout * V  -> part[g][h][c] = {m_c, l_c, acc_c[D]};  (2) every block combines the chunk records of
+// its (graph, head) in index order (m, l), rescales its chunk of P to exp(s - m) / l, and chunk 0 writes the pooled row.
+// qs = q_proj(global_token) * 1/sqrt(d)  [H*D].
+constexpr int POOL_ROWS = 512;   // 2 nodes per thread
+
 template <int D>
-__global__ __launch_bounds__(256) void k_attn_pool_fwd(const float* __restrict__ K, const float* __restrict__ V, int64_t ld,
-                                                       const float* __restrict__ qs, const int32_t* __restrict__ ptr, int H,
-                                                       float drop_p, DgdmSeed seed_in, float* __restrict__ P, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_attn_pool_part(const float* __restrict__ K, const float* __restrict__ V, int64_t ld,
+                                                        const float* __restrict__ qs, const int32_t* __restrict__ ptr, int H,
+                                                        float drop_p, DgdmSeed seed_in, float* __restrict__ P,
+                                                        float* __restrict__ part) {
   const uint32_t seed = seed_in.value();
-  const int h = blockIdx.x, g = blockIdx.y;
-  const int a = ptr[g], b = ptr[g + 1];
+  const int h = blockIdx.x, g = blockIdx.y, c = blockIdx.z;
+  const int a = ptr[g] + c * POOL_ROWS, b = min(ptr[g + 1], a + POOL_ROWS);
   __shared__ float red[4];
   __shared__ float accs[4][D];
+  float* rec = part + (((int64_t)g * H + h) * gridDim.z + c) * (D + 2);
+  if (a >= b) {   // chunk beyond this graph: neutral record
+    if (threadIdx.x == 0) { rec[0] = -INFINITY; rec[1] = 0.f; }
+    if (threadIdx.x < D) rec[2 + threadIdx.x] = 0.f;
+    return;
+  }
   float q[D];
 #pragma unroll
   for (int i = 0; i < D; ++i) q[i] = qs[h * D + i];
+  float sc[2];
   float m = -INFINITY;
-  for (int n = a + threadIdx.x; n < b; n += 256) m = fmaxf(m, dot_row<D>(K + (int64_t)n * ld + h * D, q));
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int n = a + threadIdx.x + 256 * r;
+    sc[r] = n < b ? dot_row<D>(K + (int64_t)n * ld + h * D, q) : -INFINITY;
+    m = fmaxf(m, sc[r]);
+  }
   m = block_max(m, red);
-  float l = 0.f;
-  for (int n = a + threadIdx.x; n < b; n += 256) l += __expf(dot_row<D>(K + (int64_t)n * ld + h * D, q) - m);
-  l = block_sum(l, red);
-  const float inv = 1.0f / l;
   const uint32_t thresh = (uint32_t)(drop_p * 65536.0f);
   const float keep_scale = drop_p > 0.f ? 1.0f / (1.0f - (float)thresh / 65536.0f) : 1.0f;
-  float acc[D];
+  float l = 0.f, acc[D];
 #pragma unroll
   for (int i = 0; i < D; ++i) acc[i] = 0.f;
-  for (int n = a + threadIdx.x; n < b; n += 256) {
-    const float p = __expf(dot_row<D>(K + (int64_t)n * ld + h * D, q) - m) * inv;
-    P[(int64_t)n * H + h] = p;
-    const float pm = drop_p > 0.f ? p * drop_factor(seed, (uint64_t)n * H + h, thresh, keep_scale) : p;
-    const float* vr = V + (int64_t)n * ld + h * D;
 #pragma unroll
-    for (int i = 0; i < D; i += 4) {
-      const float4 t = *reinterpret_cast<const float4*>(vr + i);
-      acc[i] = fmaf(pm, t.x, acc[i]); acc[i + 1] = fmaf(pm, t.y, acc[i + 1]);
-      acc[i + 2] = fmaf(pm, t.z, acc[i + 2]); acc[i + 3] = fmaf(pm, t.w, acc[i + 3]);
+  for (int r = 0; r < 2; ++r) {
+    const int n = a + threadIdx.x + 256 * r;
+    if (n < b) {
+      const float e = __expf(sc[r] - m);
+      l += e;
+      P[(int64_t)n * H + h] = e;
+      const float em = drop_p > 0.f ? e * drop_factor(seed, (uint64_t)n * H + h, thresh, keep_scale) : e;
+      const float* vr = V + (int64_t)n * ld + h * D;
+#pragma unroll
+      for (int i = 0; i < D; i += 4) {
+        const float4 t = *reinterpret_cast<const float4*>(vr + i);
+        acc[i] = fmaf(em, t.x, acc[i]); acc[i + 1] = fmaf(em, t.y, acc[i + 1]);
+        acc[i + 2] = fmaf(em, t.z, acc[i + 2]); acc[i + 3] = fmaf(em, t.w, acc[i + 3]);
+      }
     }
   }
+  l = block_sum(l, red);
 #pragma unroll
   for (int i = 0; i < D; ++i) {
     const float s = wave_sum(acc[i]);
     if ((threadIdx.x & 63) == 0) accs[threadIdx.x >> 6][i] = s;
   }
   __syncthreads();
-  if (threadIdx.x < D)
-    out[((int64_t)g * H + h) * D + threadIdx.x] =
-        (accs[0][threadIdx.x] + accs[1][threadIdx.x]) + (accs[2][threadIdx.x] + accs[3][threadIdx.x]);
+  if (threadIdx.x == 0) { rec[0] = m; rec[1] = l; }
+  if (threadIdx.x < D) rec[2 + threadIdx.x] = (accs[0][threadIdx.x] + accs[1][threadIdx.x]) + (accs[2][threadIdx.x] + accs[3][threadIdx.x]);
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void k_attn_pool_combine(const float* __restrict__ part, const int32_t* __restrict__ ptr, int H,
+                                                           float* __restrict__ P, float* __restrict__ out) {
+  const int h = blockIdx.x, g = blockIdx.y, c = blockIdx.z, nc = gridDim.z;
+  const float* recs = part + ((int64_t)g * H + h) * nc * (D + 2);
+  float m = -INFINITY;
+  for (int k = 0; k < nc; ++k) m = fmaxf(m, recs[k * (D + 2)]);
+  float l = 0.f;
+  for (int k = 0; k < nc; ++k) {   // every thread, same order: same value everywhere
+    const float mk = recs[k * (D + 2)];
+    l += mk > -INFINITY ? recs[k * (D + 2) + 1] * __expf(mk - m) : 0.f;
+  }
+  const float inv = l > 0.f ? 1.0f / l : 0.f;
+  const int a = ptr[g] + c * POOL_ROWS, b = min(ptr[g + 1], a + POOL_ROWS);
+  if (a < b) {
+    const float scale = __expf(recs[c * (D + 2)] - m) * inv;
+    for (int n = a + threadIdx.x; n < b; n += 256) P[(int64_t)n * H + h] *= scale;
+  }
+  if (c == 0 && threadIdx.x < D) {
+    float acc = 0.f;
+    for (int k = 0; k < nc; ++k) {
+      const float mk = recs[k * (D + 2)];
+      acc += mk > -INFINITY ? recs[k * (D + 2) + 2 + threadIdx.x] * __expf(mk - m) : 0.f;
+    }
+    out[((int64_t)g * H + h) * D + threadIdx.x] = acc * inv;
+  }
 }
 
 // grid (H, B).  dK = dS * qs, dV = Pm * dOut, dqs_part[g][h][:] = sum_n dS_n K_n.
@@ -254,14 +302,38 @@ extern "C" int dgdm_segment_sum(const float* x, const int32_t* ptr, int32_t B, i
     default: return DGDM_ERR_UNSUPPORTED;                                                                        \
   }
 
+static int pool_chunks(int32_t max_rows) { return max_rows <= 0 ? 1 : (max_rows + POOL_ROWS - 1) / POOL_ROWS; }
+
+extern "C" size_t dgdm_attn_pool_fwd_workspace_bytes(int32_t B, int32_t H, int32_t D, int32_t max_rows) {
+  if (B <= 0 || H <= 0 || D <= 0) return 0;
+  return (size_t)B * H * pool_chunks(max_rows) * (D + 2) * sizeof(float);
+}
+
+// max_rows: number of nodes of the largest graph of the batch (the caller knows the offsets on the host)
 extern "C" int dgdm_attn_pool_fwd(const float* K, const float* V, int64_t ld, const float* q_scaled, const int32_t* ptr, int32_t B,
-                                  int32_t H, int32_t D, float drop_p, uint32_t seed, float* P, float* out, void* stream_) {
-  DGDM_REQUIRE(B >= 0 && H > 0 && D > 0 && drop_p >= 0.f && drop_p < 1.f);
+                                  int32_t H, int32_t D, int32_t max_rows, float drop_p, uint32_t seed, float* P, float* out,
+                                  void* workspace, size_t workspace_bytes, void* stream_) {
+  DGDM_REQUIRE(B >= 0 && H > 0 && D > 0 && max_rows >= 0 && drop_p >= 0.f && drop_p < 1.f);
   if (B == 0) return DGDM_OK;
-  DGDM_REQUIRE(K && V && q_scaled && ptr && P && out);
+  DGDM_REQUIRE(K && V && q_scaled && ptr && P && out && workspace);
   if ((ld & 3) || ld < (int64_t)H * D || !dgdm_aligned16(K) || !dgdm_aligned16(V)) return DGDM_ERR_UNSUPPORTED;
+  if (workspace_bytes < dgdm_attn_pool_fwd_workspace_bytes(B, H, D, max_rows)) return DGDM_ERR_WORKSPACE;
+  const int nc = pool_chunks(max_rows);
+  if (nc > 65535) return DGDM_ERR_UNSUPPORTED;
   hipStream_t s = static_cast<hipStream_t>(stream_);
-  POOL_DISPATCH(D, k_attn_pool_fwd, K, V, ld, q_scaled, ptr, H, drop_p, dgdm_seed_arg(seed), P, out);
+  float* part = static_cast<float*>(workspace);
+  const dim3 grid(H, B, nc);
+#define POOL_FWD(D_)                                                                                                              \
+  hipLaunchKernelGGL((k_attn_pool_part<D_>), grid, dim3(256), 0, s, K, V, ld, q_scaled, ptr, H, drop_p, dgdm_seed_arg(seed), P, part); \
+  hipLaunchKernelGGL((k_attn_pool_combine<D_>), grid, dim3(256), 0, s, part, ptr, H, P, out)
+  switch (D) {
+    case 4: POOL_FWD(4); break;
+    case 8: POOL_FWD(8); break;
+    case 16: POOL_FWD(16); break;
+    case 32: POOL_FWD(32); break;
+    default: return DGDM_ERR_UNSUPPORTED;
+  }
+#undef POOL_FWD
   return dgdm_launch_status();
 }
 

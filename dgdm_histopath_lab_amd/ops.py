@@ -572,9 +572,12 @@ class _AttnPool(torch.autograd.Function):
         N, C = kv.size(0), H * D
         P = torch.empty(N, H, dtype=torch.float32, device=kv.device)
         out = torch.empty(plan.B, C, dtype=torch.float32, device=kv.device)
+        max_rows = max((plan.ptr_host[g + 1] - plan.ptr_host[g] for g in range(plan.B)), default=0)
+        wsb = lib.dgdm_attn_pool_fwd_workspace_bytes(plan.B, H, D, max_rows)
+        ws = torch.empty(max(wsb, 4) // 4, dtype=torch.float32, device=kv.device)
         _lib.check(lib.dgdm_attn_pool_fwd(kv.data_ptr(), kv[:, C:].data_ptr(), kv.stride(0), q_scaled.data_ptr(),
-                                          plan.ptr_dev.data_ptr(), plan.B, H, D, drop_p, seed, P.data_ptr(), out.data_ptr(),
-                                          _lib.stream_ptr(kv.device)), "dgdm_attn_pool_fwd")
+                                          plan.ptr_dev.data_ptr(), plan.B, H, D, max_rows, drop_p, seed, P.data_ptr(), out.data_ptr(),
+                                          ws.data_ptr(), wsb, _lib.stream_ptr(kv.device)), "dgdm_attn_pool_fwd")
         ctx.save_for_backward(kv, q_scaled, P, out)
         ctx.meta = (plan, H, D, drop_p, seed)
         return out

@@ -277,9 +277,14 @@ DGDM_API int dgdm_segment_sum(const float* x, const int32_t* ptr, int32_t B, int
  *   out[g,h,:] = sum_n dropout(softmax_n(q_h . K[n,h,:]))[n] * V[n,h,:]
  * K, V: [N, H*D] with row stride ld (two column blocks of one fused projection buffer);
  * P [N,H]: pre-dropout probabilities saved for the backward; out [B, H*D].  D in {4,8,16,32}.
+ * The forward runs over (head, graph, 512-node chunk) in two launches (chunk records, then their fixed-order
+ * combination); max_rows = node count of the largest graph of the batch (known to the caller on the host) sizes the
+ * grid and the workspace.
  * Backward: dK, dV [N, H*D] (row stride ldg), dq_partial [B, H*D] (sum over graphs = d q_scaled). */
+DGDM_API size_t dgdm_attn_pool_fwd_workspace_bytes(int32_t B, int32_t H, int32_t D, int32_t max_rows);
 DGDM_API int dgdm_attn_pool_fwd(const float* K, const float* V, int64_t ld, const float* q_scaled, const int32_t* ptr, int32_t B,
-                                int32_t H, int32_t D, float drop_p, uint32_t seed, float* P, float* out, void* stream);
+                                int32_t H, int32_t D, int32_t max_rows, float drop_p, uint32_t seed, float* P, float* out,
+                                void* workspace, size_t workspace_bytes, void* stream);
 DGDM_API int dgdm_attn_pool_bwd(const float* K, const float* V, int64_t ld, const float* q_scaled, const int32_t* ptr, int32_t B,
                                 int32_t H, int32_t D, float drop_p, uint32_t seed, const float* P, const float* out,
                                 const float* dout, float* dK, float* dV, int64_t ldg, float* dq_partial, void* stream);

@@ -24,7 +24,7 @@ def _rand_edges(n, e, seed, hub=False):
 
 
 @pytest.mark.parametrize("n,e,hub", [(1, 0, False), (7, 0, False), (16, 40, False), (1000, 5000, False), (3000, 20000, True),
-                                     (10000, 50000, False), (70001, 300007, False)])
+                                     (10000, 50000, False), (70001, 300007, False), (1100003, 2000001, False)])
 @pytest.mark.parametrize("pipeline", ["pair", "single"])
 def test_csr_build_bit_exact(n, e, hub, pipeline):
     from dgdm_histopath_lab_amd import GraphStructure

@@ -98,14 +98,15 @@ def test_segment_bcast_add_and_sum():
         assert_close(sd.grad, torch.zeros(4, c, dtype=torch.float64).index_add_(0, seg, gy.double()), 1e-5, "segment sum")
 
 
-@pytest.mark.parametrize("H,D", [(8, 16), (4, 8), (2, 32), (1, 4)])
-def test_attn_pool_matches_dense(H, D):
+@pytest.mark.parametrize("H,D,ptr", [(8, 16, [0, 9, 700, 1233]), (4, 8, [0, 9, 700, 1233]), (2, 32, [0, 9, 700, 1233]), (1, 4, [0, 9, 700, 1233]),
+                                     (8, 16, [0, 5000, 5003, 12345]), (4, 16, [0, 512, 1024, 1025])])
+def test_attn_pool_matches_dense(H, D, ptr):
+    """Graphs of a few nodes, of exactly one / two 512-node chunks and of many chunks (the forward combines chunk records)."""
     from dgdm_histopath_lab_amd import ops
-    ptr = [0, 9, 700, 1233]
     plan = ops.AttnPlan(ptr, DEV)
     C = H * D
     g = torch.Generator().manual_seed(H * D)
-    kv = torch.randn(1233, 2 * C, generator=g); q = torch.randn(C, generator=g) * 0.5; go = torch.randn(3, C, generator=g)
+    kv = torch.randn(ptr[-1], 2 * C, generator=g); q = torch.randn(C, generator=g) * 0.5; go = torch.randn(3, C, generator=g)
     kr, qr = kv.double().requires_grad_(True), q.double().requires_grad_(True)
     outs = []
     for i in range(3):
