@@ -63,7 +63,8 @@ __global__ __launch_bounds__(256) void k_colsum_final(const float* __restrict__ 
 // Two stages in ONE launch for thousands of slots: block (x, y) sums slot chunk y of 64 columns into stage[y][:]
 // (k_colsum's stage 1), then takes a ticket for its column block; the block that draws the last ticket adds the
 // gridDim.y stage rows in index order and writes the result -- fixed summation order whichever block that is.
-// tickets[gridDim.x] must be zero at launch (the producer kernel of `in` zeroes them: stream order).
+// tickets[gridDim.x] must be zero at launch (the producer kernel of `in` zeroes them: stream order).  gridDim.y <= MAXCH.
+template <int MAXCH>
 __global__ __launch_bounds__(256) void k_colsum_ticket(const float* __restrict__ in, int64_t slots, int width, int64_t chunk,
                                                        float* __restrict__ stage, unsigned* __restrict__ tickets,
                                                        float* __restrict__ out, int split, float* __restrict__ out1) {
@@ -71,18 +72,20 @@ __global__ __launch_bounds__(256) void k_colsum_ticket(const float* __restrict__
   const int col = blockIdx.x * 64 + c;
   const int64_t s0 = (int64_t)blockIdx.y * chunk;
   const int64_t s1 = s0 + chunk < slots ? s0 + chunk : slots;
-  float a0 = 0.f, a1 = 0.f;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   if (col < width) {
     int64_t s = s0 + part;
-    for (; s + 4 < s1; s += 8) {
+    for (; s + 12 < s1; s += 16) {   // four loads in flight
       a0 += in[s * width + col];
       a1 += in[(s + 4) * width + col];
+      a2 += in[(s + 8) * width + col];
+      a3 += in[(s + 12) * width + col];
     }
-    if (s < s1) a0 += in[s * width + col];
+    for (; s < s1; s += 4) a0 += in[s * width + col];
   }
   __shared__ float sm[4][64];
   __shared__ bool last;
-  sm[part][c] = a0 + a1;
+  sm[part][c] = (a0 + a1) + (a2 + a3);
   __syncthreads();
   if (part == 0 && col < width) {
     stage[(int64_t)blockIdx.y * width + col] = (sm[0][c] + sm[1][c]) + (sm[2][c] + sm[3][c]);
@@ -94,8 +97,12 @@ __global__ __launch_bounds__(256) void k_colsum_ticket(const float* __restrict__
   if (!last) return;
   __threadfence();
   if (part == 0 && col < width) {
+    float v[MAXCH];   // all loads in flight at once (a serial loop pays the memory latency gridDim.y times)
+#pragma unroll
+    for (int y = 0; y < MAXCH; ++y) v[y] = y < (int)gridDim.y ? stage[(int64_t)y * width + col] : 0.f;
     float t = 0.f;
-    for (unsigned y = 0; y < gridDim.y; ++y) t += __builtin_nontemporal_load(&stage[(int64_t)y * width + col]);
+#pragma unroll
+    for (int y = 0; y < MAXCH; ++y) t += v[y];
     if (split > 0 && col >= split) out1[col - split] = t; else out[col] = t;
   }
 }

@@ -312,6 +312,6 @@ extern "C" int dgdm_rownorm_bwd(const float* x, const float* res, const float* g
 #undef BWD
   const int64_t chunk = (slots + REDUCE_CHUNKS - 1) / REDUCE_CHUNKS;
   const int nch = (int)((slots + chunk - 1) / chunk);
-  hipLaunchKernelGGL(k_colsum_ticket, dim3(ntickets, nch), dim3(256), 0, s, partial, slots, 2 * C, chunk, stage1, tickets, dgamma, C, dbeta);
+  hipLaunchKernelGGL(k_colsum_ticket<REDUCE_CHUNKS>, dim3(ntickets, nch), dim3(256), 0, s, partial, slots, 2 * C, chunk, stage1, tickets, dgamma, C, dbeta);
   return dgdm_launch_status();
 }
