@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void k_rownorm_bwd(const float* __restrict__ x
                                                      const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
                                                      const float* __restrict__ dy, int64_t rows, int L, int G, float drop_p,
                                                      DgdmSeed seed_in, float* __restrict__ dx, float* __restrict__ partial, int C,
-                                                     unsigned* __restrict__ tickets, int ntickets) {
+                                                     unsigned* __restrict__ tickets, int ntickets, int block_slots) {
   const uint32_t seed = seed_in.value();
   if (blockIdx.x == 0 && (int)threadIdx.x < ntickets) tickets[threadIdx.x] = 0u;   // for the column-sum kernel that follows
   constexpr int GPW = 64 / LPR;
@@ -169,14 +169,29 @@ __global__ __launch_bounds__(256) void k_rownorm_bwd(const float* __restrict__ x
       }
     }
   }
-  // partial[slot][0..C) = dgamma slice, partial[slot][C..2C) = dbeta slice; slot = gid / G
-  float* pg = partial + (gid / G) * (int64_t)(2 * C) + coff;
+  // partial[slot][0..C) = dgamma slice, partial[slot][C..2C) = dbeta slice.
+  // block_slots > 0 (the block's lane groups cover block_slots whole rows of 2C, i.e. groups-per-block % G == 0): the rows
+  // are first added in LDS in index order and the block writes ONE row, slot = blockIdx.x -- 4x (LayerNorm) fewer partial
+  // rows for the column-sum kernel to read.  Otherwise every lane group writes its own slice, slot = gid / G.
+  extern __shared__ float red[];
+  const bool in_block = block_slots > 0;
+  const int gl = (int)(gid - (int64_t)blockIdx.x * (blockDim.x >> 6) * GPW);   // lane group inside the block
+  float* pg = in_block ? red + (gl / G) * (2 * C) + coff : partial + (gid / G) * (int64_t)(2 * C) + coff;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const int k = lir + r * LPR;
     if (k < l4) {
       reinterpret_cast<float4*>(pg)[k] = dg[r];
       reinterpret_cast<float4*>(pg + C)[k] = db[r];
+    }
+  }
+  if (in_block) {
+    __syncthreads();
+    float* prow = partial + (int64_t)blockIdx.x * (2 * C);
+    for (int c = threadIdx.x; c < 2 * C; c += blockDim.x) {
+      float t = red[c];
+      for (int sl = 1; sl < block_slots; ++sl) t += red[sl * 2 * C + c];
+      prow[c] = t;
     }
   }
 }
@@ -204,6 +219,16 @@ int64_t bwd_lane_groups(int64_t rows, int G, const Geo& geo) {
   int64_t unit = (int64_t)gpb * G / std::gcd((int64_t)gpb, (int64_t)G);
   int64_t n = (want + unit - 1) / unit * unit;
   return n < unit ? unit : n;
+}
+
+// rows of the partial buffer: one per workgroup when its lane groups cover whole rows of 2C (reduced in LDS), else one per G groups
+int bwd_block_slots(int G, const Geo& geo) {
+  const int gpb = (64 / geo.lpr) * 4;
+  return gpb % G == 0 ? gpb / G : 0;
+}
+int64_t bwd_slots(int64_t ng, int G, const Geo& geo) {
+  const int gpb = (64 / geo.lpr) * 4;
+  return bwd_block_slots(G, geo) > 0 ? ng / gpb : ng / G;
 }
 
 }  // namespace
@@ -272,7 +297,7 @@ extern "C" size_t dgdm_rownorm_bwd_workspace_bytes(int32_t N, int32_t C, int32_t
   Geo geo;
   if (N <= 0 || C <= 0 || G <= 0 || C % G || !geometry(C / G, &geo)) return 0;
   const int64_t ng = bwd_lane_groups((int64_t)N * G, G, geo);
-  return (size_t)(ng / G + REDUCE_CHUNKS + 1) * 2 * C * sizeof(float);  // partials + stage-1 sums + result row
+  return (size_t)(bwd_slots(ng, G, geo) + REDUCE_CHUNKS + 1) * 2 * C * sizeof(float);  // partials + stage-1 sums + ticket row
 }
 
 extern "C" int dgdm_rownorm_bwd(const float* x, const float* res, const float* gamma, const float* beta, const float* mean,
@@ -296,19 +321,22 @@ extern "C" int dgdm_rownorm_bwd(const float* x, const float* res, const float* g
   const int64_t rows = (int64_t)N * G;
   const int L = C / G;
   const int64_t ng = bwd_lane_groups(rows, G, geo);
-  const int64_t slots = ng / G;
+  const int64_t slots = bwd_slots(ng, G, geo);
+  const int block_slots = bwd_block_slots(G, geo);
+  const size_t lds = (size_t)block_slots * 2 * C * sizeof(float);
+  if (lds > 64 * 1024) return DGDM_ERR_UNSUPPORTED;
   if (workspace_bytes < (size_t)(slots + REDUCE_CHUNKS + 1) * 2 * C * sizeof(float)) return DGDM_ERR_WORKSPACE;
   const int gpb = (64 / geo.lpr) * 4;
   const int64_t blocks = ng / gpb;
   float* partial = static_cast<float*>(workspace);
 #define BWD(LPR_, R_, ACT_, ...) \
-  hipLaunchKernelGGL((k_rownorm_bwd<LPR_, R_, ACT_>), dim3((unsigned)blocks), dim3(256), 0, s, __VA_ARGS__)
+  hipLaunchKernelGGL((k_rownorm_bwd<LPR_, R_, ACT_>), dim3((unsigned)blocks), dim3(256), lds, s, __VA_ARGS__)
   // dgamma | dbeta = column sums of partial [slots][2C]: two fixed-order stages in one launch (tickets zeroed above)
   float* stage1 = partial + slots * 2 * C;
   unsigned* tickets = reinterpret_cast<unsigned*>(stage1 + (int64_t)REDUCE_CHUNKS * 2 * C);
   const int ntickets = (2 * C + 63) / 64;
   if (ntickets > 256) return DGDM_ERR_UNSUPPORTED;
-  ROWNORM_DISPATCH(BWD, x, res, gamma, beta, mean, rstd, dy, rows, L, G, drop_p, dgdm_seed_arg(seed), dx, partial, C, tickets, ntickets);
+  ROWNORM_DISPATCH(BWD, x, res, gamma, beta, mean, rstd, dy, rows, L, G, drop_p, dgdm_seed_arg(seed), dx, partial, C, tickets, ntickets, block_slots);
 #undef BWD
   const int64_t chunk = (slots + REDUCE_CHUNKS - 1) / REDUCE_CHUNKS;
   const int nch = (int)((slots + chunk - 1) / chunk);
