@@ -79,6 +79,7 @@ SIGNATURES = {
     "dgdm_edge_dedup_count": (C.c_int, [_p, _p, _i32, _p, _p, _i32, _i32, C.c_float, _p, _sz, _p, _p]),
     "dgdm_edge_emit": (C.c_int, [_p, _p, _i32, _p, _p, _i32, _i32, C.c_float, _p, _i64, _i32, _p, _p, _p, _p, _p]),
     "dgdm_gemm_nt_bf16x3": (C.c_int, [_p, _i64, _p, _i64, _p, _p, _i64, _i32, _i32, _i32, _i32, _p]),
+    "dgdm_gemm_nt_split_bf16x3": (C.c_int, [_p, _i64, _p, _i64, _i32, _p, _i64, _p, _p, _i64, _i32, _i32, _i32, _i32, _p]),
     "dgdm_gemm_nn_bf16x3": (C.c_int, [_p, _i64, _p, _i64, _p, _i64, _i32, _i32, _i32, _i32, _p]),
     "dgdm_gemm_tn_bf16x3_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
     "dgdm_gemm_tn_bf16x3": (C.c_int, [_p, _i64, _p, _i64, _p, _i64, _p, _i32, _i32, _i32, _p, _sz, _p]),

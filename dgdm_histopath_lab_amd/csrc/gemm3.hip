@@ -27,6 +27,7 @@
 // non-finite features before any GEMM, models/dgdm_model.py:278-283 in the reference).
 #include "common.hpp"
 #include "colsum.hpp"
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -135,6 +136,30 @@ struct RowLoader {
   }
 };
 
+// RowLoader over an operand whose reduction range is the concatenation of two matrices: k in [0, ksplit) comes from
+// the first (P, ld), k in [ksplit, kend) from the second (P2, ld2).  ksplit is a multiple of 4 (a float4 never straddles).
+struct RowLoaderSplit : RowLoader {
+  const float* q[2];   // row base in the second matrix, shifted by -ksplit so that the same k indexes it
+  int ksplit;
+  __device__ __forceinline__ void init2(const float* __restrict__ P2, int64_t ld2, int o0, int on, int ksplit_, int tid) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = o0 + (tid >> 2) + 64 * j;
+      q[j] = P2 + (int64_t)(row < on ? row : on - 1) * ld2 - ksplit_;
+    }
+    ksplit = ksplit_;
+  }
+  __device__ __forceinline__ void next(RowStage& R) {
+    const bool kin = k < kend;
+    const int kc = kin ? k : kend - 4;
+    const bool first = kc < ksplit;
+    R.v[0] = *reinterpret_cast<const float4*>((first ? p[0] : q[0]) + kc);
+    R.v[1] = *reinterpret_cast<const float4*>((first ? p[1] : q[1]) + kc);
+    R.ok = kin ? rowok : 0u;
+    k += KS;
+  }
+};
+
 struct ColLoader {
   const float* p[2];   // address of this thread's float4 in k rows k, k+1 of the next stage (clamped below klim)
   int k, kend, klim;   // klim: number of k rows that exist in memory (>= kend)
@@ -189,10 +214,12 @@ __device__ __forceinline__ f32x16 mma6(const Frag& a, const Frag& b, int mt, int
 //   acc[mt][nt] += sum over k in [kbeg, kend) of A(a0 + wave rows, k) * B(b0 + wave cols, k)
 // A_KC / B_KC: the operand's global layout has k contiguous (RowStage) or the output index (ColStage).
 // BIAS: also accumulate per-thread column sums of the A operand (ColStage only) into bs.
-template <bool A_KC, bool B_KC, bool BIAS>
+template <bool A_KC, bool B_KC, bool BIAS, bool B_SPLIT = false>
 __device__ __forceinline__ void mainloop3(const float* __restrict__ A, int64_t lda, int a0, int an, const float* __restrict__ B,
                                           int64_t ldb, int b0, int bn, int kbeg, int kend, int klim, char* __restrict__ smem,
-                                          f32x16 (&acc)[2][2], int live_m, int live_n, float (&bs)[4]) {
+                                          f32x16 (&acc)[2][2], int live_m, int live_n, float (&bs)[4],
+                                          const float* __restrict__ B2 = nullptr, int64_t ldb2 = 0, int bsplit = 0) {
+  static_assert(!B_SPLIT || B_KC, "the two-matrix operand is implemented for the k-contiguous layout");
   typedef typename StageOf<A_KC>::type SA;
   typedef typename StageOf<B_KC>::type SB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -202,9 +229,10 @@ __device__ __forceinline__ void mainloop3(const float* __restrict__ A, int64_t l
   SA ra0, ra1, ra2;
   SB rb0, rb1, rb2;
   typename StageOf<A_KC>::loader la;
-  typename StageOf<B_KC>::loader lb;
+  typename std::conditional<B_SPLIT, RowLoaderSplit, typename StageOf<B_KC>::loader>::type lb;
   la.init(A, lda, a0, an, kbeg, kend, klim, tid);
   lb.init(B, ldb, b0, bn, kbeg, kend, klim, tid);
+  if constexpr (B_SPLIT) lb.init2(B2, ldb2, b0, bn, bsplit, tid);
   la.next(ra0); lb.next(rb0);
   la.next(ra1); lb.next(rb1);
   la.next(ra2); lb.next(rb2);
@@ -273,10 +301,11 @@ __device__ __forceinline__ void mainloop3(const float* __restrict__ A, int64_t l
 #undef DGDM_STAGE_SCHEDULE
 }
 
-template <bool B_KCONTIG, bool ACCUM>
+template <bool B_KCONTIG, bool ACCUM, bool B_SPLIT = false>
 __global__ __launch_bounds__(256, 2) void k_gemm3_rows(const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
                                                        int64_t ldb, float* __restrict__ C, int64_t ldc, int M, int N, int K,
-                                                       const float* __restrict__ bias) {
+                                                       const float* __restrict__ bias, const float* __restrict__ B2, int64_t ldb2,
+                                                       int bsplit) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
@@ -290,7 +319,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm3_rows(const float* __restrict__
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
   float nobs[4] = {0.f, 0.f, 0.f, 0.f};
-  mainloop3<true, B_KCONTIG, false>(A, lda, m0, M, B, ldb, n0, N, 0, K, K, smem, acc, live_m, live_n, nobs);
+  mainloop3<true, B_KCONTIG, false, B_SPLIT>(A, lda, m0, M, B, ldb, n0, N, 0, K, K, smem, acc, live_m, live_n, nobs, B2, ldb2, bsplit);
 
   const int j = lane & 31, hi = lane >> 5;
 #pragma unroll
@@ -430,9 +459,9 @@ int allow_big_lds(Kern kern) {
 
 template <typename Kern>
 static int launch_rows(Kern kern, dim3 grid, hipStream_t s, const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
-                       int M, int N, int K, const float* bias) {
+                       int M, int N, int K, const float* bias, const float* B2 = nullptr, int64_t ldb2 = 0, int bsplit = 0) {
   if (allow_big_lds(kern) != DGDM_OK) return DGDM_ERR_LAUNCH;
-  hipLaunchKernelGGL(kern, grid, dim3(256), LDS_BYTES, s, A, lda, B, ldb, C, ldc, M, N, K, bias);
+  hipLaunchKernelGGL(kern, grid, dim3(256), LDS_BYTES, s, A, lda, B, ldb, C, ldc, M, N, K, bias, B2, ldb2, bsplit);
   return dgdm_launch_status();
 }
 
@@ -448,6 +477,22 @@ extern "C" int dgdm_gemm_nt_bf16x3(const float* A, int64_t lda, const float* W, 
   hipStream_t s = static_cast<hipStream_t>(stream);
   return accumulate ? launch_rows(k_gemm3_rows<true, true>, grid, s, A, lda, W, ldw, C, ldc, M, N, K, bias)
                     : launch_rows(k_gemm3_rows<true, false>, grid, s, A, lda, W, ldw, C, ldc, M, N, K, bias);
+}
+
+// C = A . [W0 | W1]^T (+ bias): the weight's K columns come from two matrices, [0, K0) from W0 and [K0, K) from W1
+extern "C" int dgdm_gemm_nt_split_bf16x3(const float* A, int64_t lda, const float* W0, int64_t ldw0, int32_t K0, const float* W1,
+                                         int64_t ldw1, const float* bias, float* C, int64_t ldc, int32_t M, int32_t N, int32_t K,
+                                         int32_t accumulate, void* stream) {
+  if (M < 0 || N < 0 || K < 0 || K0 <= 0 || K0 >= K) return DGDM_ERR_INVALID_ARG;
+  if (M == 0 || N == 0) return DGDM_OK;
+  if (!A || !W0 || !W1 || !C) return DGDM_ERR_INVALID_ARG;
+  if ((K & 3) || (K0 & 3) || (lda & 3) || (ldw0 & 3) || (ldw1 & 3) || !dgdm_aligned16(A) || !dgdm_aligned16(W0) || !dgdm_aligned16(W1))
+    return DGDM_ERR_UNSUPPORTED;
+  if (lda < K || ldw0 < K0 || ldw1 < K - K0 || ldc < N) return DGDM_ERR_INVALID_ARG;
+  const dim3 grid((M + BM - 1) / BM, (N + BN - 1) / BN);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return accumulate ? launch_rows(k_gemm3_rows<true, true, true>, grid, s, A, lda, W0, ldw0, C, ldc, M, N, K, bias, W1, ldw1, K0)
+                    : launch_rows(k_gemm3_rows<true, false, true>, grid, s, A, lda, W0, ldw0, C, ldc, M, N, K, bias, W1, ldw1, K0);
 }
 
 extern "C" int dgdm_gemm_nn_bf16x3(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc, int32_t M, int32_t N,

@@ -18,6 +18,8 @@ and the random-draw injection hooks ``timesteps`` / ``noise`` / ``noise_target``
 """
 from __future__ import annotations
 
+import copy
+
 import math
 import warnings
 from typing import Any, Dict, List, Optional
@@ -333,7 +335,9 @@ class DGDMModel(nn.Module):
         recorded in a HIP graph either).  Injected ``mask_indices`` take the indexed path."""
         n = data.x.size(0)
         num_masked = int(n * mask_ratio)
-        masked = data.clone()
+        # the reference deep-copies the batch (data.clone()) and overwrites rows of the copy; nothing on this path writes
+        # into a tensor of the batch, so the copy shares every tensor with `data` and only `x` is replaced
+        masked = copy.copy(data)
         if num_masked > 0:
             dev = data.x.device
             if mask_token is None:
@@ -347,6 +351,7 @@ class DGDMModel(nn.Module):
                     mask_indices = torch.randperm(n, device=dev)[:num_masked]
                 node_mask = torch.zeros(n, dtype=torch.bool, device=dev)
                 node_mask[mask_indices] = True
+                masked.x = data.x.clone()
                 masked.x[mask_indices] = mask_token.to(data.x.dtype)
             masked.node_mask = node_mask
         return masked

@@ -637,6 +637,21 @@ def gemm_nt_raw(a, w, bias=None, out=None, accumulate=False, math="fp32"):
     return out
 
 
+def gemm_nt_split_raw(a, w0, w1, bias=None):
+    """a [M, K0 + K1] . [w0 | w1]^T (+ bias) without materialising the concatenated weight (bf16x3 kernel only)."""
+    lib = _lib.load()
+    a, w0, w1 = _rowmajor(a), _rowmajor(w0), _rowmajor(w1)
+    M, K = a.shape
+    N, K0 = w0.shape
+    if w1.size(0) != N or K0 + w1.size(1) != K:
+        raise ValueError(f"weights {tuple(w0.shape)} | {tuple(w1.shape)} do not match the operand {tuple(a.shape)}")
+    out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    TIMERS.timed("gemm_nt", lambda: _lib.check(
+        lib.dgdm_gemm_nt_split_bf16x3(a.data_ptr(), a.stride(0), w0.data_ptr(), w0.stride(0), K0, w1.data_ptr(), w1.stride(0), _lib.ptr(bias),
+                                      out.data_ptr(), out.stride(0), M, N, K, 0, _lib.stream_ptr(a.device)), "dgdm_gemm_nt_split_bf16x3"))
+    return out
+
+
 def gemm_nn_raw(a, w, out=None, accumulate=False, math="fp32"):
     """a [M,N] . w [N,K] -> [M,K]"""
     lib = _lib.load()
@@ -748,22 +763,25 @@ class _GraphConvLinear(torch.autograd.Function):
             lib.dgdm_spmm_concat(gs.rowptr.data_ptr(), gs.col.data_ptr(), gs.w.data_ptr(), x.data_ptr(), x.stride(0), x.size(0),
                                  ea_hat.data_ptr(), ea_hat.stride(0), ed, buf.data_ptr(), buf.stride(0), n, cin,
                                  _lib.stream_ptr(x.device)), "dgdm_spmm_concat"))
+        ctx.gs, ctx.cin, ctx.has_bias = gs, cin, b is not None
+        if GEMM_FWD_BACKEND == "bf16x3" and cin % 4 == 0:
+            ctx.save_for_backward(buf, w)          # the kernel reads the two weights side by side: no concatenated copy
+            return gemm_nt_split_raw(buf, w, we, b)
         wcat = torch.cat([w, we], dim=1)
         ctx.save_for_backward(buf, wcat)
-        ctx.gs, ctx.cin, ctx.has_bias = gs, cin, b is not None
         if GEMM_FWD_BACKEND == "lib":
             return torch.nn.functional.linear(buf, wcat, b)
-        return gemm_nt_raw(buf, wcat, b, math="bf16x3" if GEMM_FWD_BACKEND == "bf16x3" else "fp32")
+        return gemm_nt_raw(buf, wcat, b, math="fp32")
 
     @staticmethod
     def backward(ctx, gy):
-        buf, wcat = ctx.saved_tensors
+        buf, wsaved = ctx.saved_tensors
         gs, cin = ctx.gs, ctx.cin
         gy = _rowmajor(gy)
         math = "bf16x3" if GEMM_FWD_BACKEND == "bf16x3" else "fp32"
         dx = None
         if ctx.needs_input_grad[0]:
-            w_only = wcat[:, :cin]                      # a view: row stride cin + edge_dim
+            w_only = wsaved[:, :cin]                    # node_lin.weight itself, or a view into the concatenated copy
             dagg = gy @ w_only if GEMM_FWD_BACKEND == "lib" else gemm_nn_raw(gy, w_only, math=math)
             dx = spmm_raw(gs.rowptr_t, gs.col_t, gs.w_t, dagg, gs.num_nodes)
         dw = dwe = db = None

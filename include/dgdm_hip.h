@@ -323,6 +323,12 @@ DGDM_API int dgdm_gemm_nt_bf16x3(const float* A, int64_t lda, const float* W, in
                                  int32_t M, int32_t N, int32_t K, int32_t accumulate, void* stream);
 DGDM_API int dgdm_gemm_nn_bf16x3(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc, int32_t M, int32_t N,
                                  int32_t K, int32_t accumulate, void* stream);
+/* dgdm_gemm_nt_bf16x3 with the weight given as two matrices side by side in K: C = A . [W0 | W1]^T (+ bias), W0 [N, K0]
+ * (leading dimension ldw0), W1 [N, K - K0] (ldw1); K0 % 4 == 0, 0 < K0 < K.  The graph convolution contracts
+ * [A_hat x | EA_hat] with node_lin.weight and edge_lin.weight (graph_layers.py:44,48,99-105) without concatenating them. */
+DGDM_API int dgdm_gemm_nt_split_bf16x3(const float* A, int64_t lda, const float* W0, int64_t ldw0, int32_t K0, const float* W1,
+                                       int64_t ldw1, const float* bias, float* C, int64_t ldc, int32_t M, int32_t N, int32_t K,
+                                       int32_t accumulate, void* stream);
 DGDM_API size_t dgdm_gemm_tn_bf16x3_workspace_bytes(int32_t M, int32_t N, int32_t K, int32_t with_bias);
 DGDM_API int dgdm_gemm_tn_bf16x3(const float* dY, int64_t ldy, const float* X, int64_t ldx, float* dW, int64_t lddw, float* db,
                                  int32_t M, int32_t N, int32_t K, void* workspace, size_t workspace_bytes, void* stream);

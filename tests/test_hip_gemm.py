@@ -53,6 +53,22 @@ def test_gemm_tn_split_output_is_the_unsplit_result(m, k, k0, n, math):
         ops.gemm_tn_raw(gy, x, False, math=math, split=k)
 
 
+@pytest.mark.parametrize("m,k0,k1,n", [(4001, 512, 32, 512), (40000, 128, 32, 128), (300, 36, 32, 64), (1000, 4, 8, 12)])
+def test_gemm_nt_split_weight_is_the_concatenated_product(m, k0, k1, n):
+    """dgdm_gemm_nt_split_bf16x3 reads [W0 | W1] in place: bit for bit the GEMM on the concatenated weight."""
+    from dgdm_histopath_lab_amd import ops
+    g = torch.Generator().manual_seed(m + k0)
+    a = torch.randn(m, k0 + k1, generator=g).to(DEV)
+    w0, w1, b = torch.randn(n, k0, generator=g).to(DEV), torch.randn(n, k1, generator=g).to(DEV), torch.randn(n, generator=g).to(DEV)
+    want = ops.gemm_nt_raw(a, torch.cat([w0, w1], dim=1), b, math="bf16x3")
+    assert torch.equal(ops.gemm_nt_split_raw(a, w0, w1, b), want)
+    wide = torch.randn(n, k0 + 8, generator=g).to(DEV)              # W0 as a column slice of a wider matrix
+    want2 = ops.gemm_nt_raw(a, torch.cat([wide[:, :k0], w1], dim=1), None, math="bf16x3")
+    assert torch.equal(ops.gemm_nt_split_raw(a, wide[:, :k0], w1), want2)
+    with pytest.raises(ValueError):
+        ops.gemm_nt_split_raw(a, w0, w1[:, :4])
+
+
 def test_bf16x3_matches_fp32_mfma_accuracy():
     """The split GEMM's error against fp64 is of the size of the fp32-MFMA kernel's own (accumulation
     rounding), also for operands spanning many binades and for gradient-sized (1e-6) values."""
