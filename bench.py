@@ -149,6 +149,9 @@ def main():
                     help="BASELINE configs[4] shape instead of the headline: a stream of batches whose graphs have 1k..10k nodes "
                          "(E = 5 N), 8 different batches resident in HBM and cycled; reported under config.workload, not comparable "
                          "with the fixed-size number")
+    ap.add_argument("--large", action="store_true",
+                    help="BASELINE configs[3] instead of the headline: the Large model (hidden 1024/512/256, 16 heads, T=20) on 50k-node / "
+                         "300k-edge graphs, 1 graph per GPU unless --batch is given; reported under config.workload")
     ap.add_argument("--eager", action="store_true",
                     help="launch every kernel of the step from the host instead of replaying the step from HIP graphs "
                          "(training.GraphedPretrainStep, the default for the fixed-shape headline workload)")
@@ -187,8 +190,15 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    cfg = dict(MODEL_CFG)
+    if args.large:
+        cfg.update(hidden_dims=[1024, 512, 256], attention_heads=16, num_diffusion_steps=20)
+        if args.nodes == NODES and args.edges == EDGES:
+            args.nodes, args.edges = 50000, 300000
+        if args.batch == PER_GPU_BATCH:
+            args.batch = 1
     torch.manual_seed(0)
-    model = DGDMModel(**MODEL_CFG).to(dev)
+    model = DGDMModel(**cfg).to(dev)
     model.train(not args.eval_mode)
     # training/trainer.py:221-226 defaults; fused=True: one multi-tensor kernel instead of ~10 foreach launches
     opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-5, fused=True)
@@ -260,7 +270,7 @@ def main():
     result = None
     if rank == 0:
         timers = ops.TIMERS.summary()
-        heads, hd = MODEL_CFG["attention_heads"], 16
+        heads, hd = cfg["attention_heads"], 16
         flops = {"attn_fwd": attention_flops(sizes, heads, hd, 2), "attn_bwd_dq": attention_flops(sizes, heads, hd, 3),
                  "attn_bwd_dkv": attention_flops(sizes, heads, hd, 4)}
         split = ops.ATTN_PRECISION == "fp16x2"
@@ -275,7 +285,8 @@ def main():
         # `issued_*` prices THAT against the fp16 peak.  Neither pipe is the limiter: the kernel is bound by the
         # softmax/dropout VALU work per score (attention section).
         roofline = {"kernel": kernels[dom], "bound": "mfma", "achieved": round(tf, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(kernels[dom]),
+                    "unit": "TFLOP/s", "frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4),
+                    "traffic": None if args.large else pmc_traffic(kernels[dom]),   # the PMC passes were taken on the headline workload
                     "ms_per_launch": round(ms, 4), "launches_timed": timers[dom][0], "algorithmic_flop": flops[dom],
                     "other_kernels_ms": {k: round(v[1], 4) for k, v in timers.items() if k != dom}}
         roofline["timed_with"] = ("HIP events around eager launches of the same step right after the timed region (a graph replay "
@@ -294,8 +305,8 @@ def main():
             "config": {"workload": (f"MIXED-SIZE STREAM (configs[4]): DGDM-Base pretrain_step fwd+bwd+AdamW, batch={args.batch} graphs of "
                                     f"1k..10k nodes (E = 5 N) per GPU, 8 batches cycled, feat={FEATS}, edge_attr=32, T=10, heads=8, "
                                     if args.mixed else
-                                    f"DGDM-Base pretrain_step fwd+bwd+AdamW, batch={args.batch} x {args.nodes}-node/{args.edges}-edge "
-                                    f"graphs per GPU, feat={FEATS}, edge_attr=32, T=10, heads=8, ") +
+                                    f"DGDM-{'Large (configs[3])' if args.large else 'Base'} pretrain_step fwd+bwd+AdamW, batch={args.batch} x {args.nodes}-node/{args.edges}-edge "
+                                    f"graphs per GPU, feat={FEATS}, edge_attr=32, T={cfg['num_diffusion_steps']}, heads={cfg['attention_heads']}, ") +
                                    f"{'eval (dropout off)' if args.eval_mode else 'training mode (dropout 0.1)'}",
                        "global_batch": world * args.batch, "parallelism": f"dp{world}", "final_loss": round(loss_val, 5),
                        "launch": "HIP graph replay (training.GraphedPretrainStep)" if graphed else "eager"},
