@@ -134,7 +134,10 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq(const float* __restrict_
         f32x4 s = mfma16_k16(kf, qf[h], f32x4{0.f, 0.f, 0.f, 0.f});    // S'^T[key][q]
         f32x4 dp = mfma16_k16(vf, dof[h], f32x4{0.f, 0.f, 0.f, 0.f});  // dP^T[key][q]
         f32x4 ds;
-        if (DROP) dp *= drop_factors_qmajor(attn_hq(attn_head_seed(seed, n0, head0 + h), q_local), q_local, kb0 + 16 * t + 4 * G, dc);
+        if (DROP) {
+          const DropHead dhh(seed, n0, head0 + h);
+          dp *= drop_factors_qmajor(attn_hq(dhh, q_local), dhh, q_local, kb0 + 16 * t + 4 * G, dc);
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float p = __builtin_amdgcn_exp2f(s[r] - bias[t][r] - l2[h]);
@@ -284,7 +287,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv(const float* __restrict
         f32x4 s = mfma16_k16(qa, kf[h], f32x4{0.f, 0.f, 0.f, 0.f});   // S'[q][key]
         f32x4 dp = mfma16_k16(ga, vf[h], f32x4{0.f, 0.f, 0.f, 0.f});  // dP[q][key]
         f32x4 p, ds, f = f32x4{1.f, 1.f, 1.f, 1.f};
-        if (DROP) f = drop_factors_kmajor(attn_head_seed(seed, n0, head0 + h), k_local, qb0 + 16 * t + 4 * G, dc);
+        if (DROP) f = drop_factors_kmajor(DropHead(seed, n0, head0 + h), k_local, qb0 + 16 * t + 4 * G, dc);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           p[r] = __builtin_amdgcn_exp2f(s[r] - bias[t][r] - lq[r]);

@@ -57,10 +57,12 @@ __global__ __launch_bounds__(256, 2) void k_attn_fwd(const float* __restrict__ Q
   f32x4 oacc[HG], oacc2[HG];
   float m[HG], l[HG];
   uint32_t hq[HG];  // per-(lane, head) part of the dropout hash, hoisted out of the key loop
+  DropHead dh[HG];
 #pragma unroll
   for (int h = 0; h < HG; ++h) {
     oacc[h] = f32x4{0.f, 0.f, 0.f, 0.f}; oacc2[h] = f32x4{0.f, 0.f, 0.f, 0.f}; m[h] = NEG_BIG; l[h] = 0.f;
-    hq[h] = attn_hq(attn_head_seed(seed, n0, head0 + h), q_local);
+    dh[h] = DropHead(seed, n0, head0 + h);
+    hq[h] = attn_hq(dh[h], q_local);
   }
 
   // staging map: idx -> (key, h, part), part fastest => HG*64 contiguous bytes per key row
@@ -172,7 +174,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_fwd(const float* __restrict__ Q
       oacc2[h] *= alpha;
       if (DROP) {  // the row sum above uses the un-dropped weights; only the P.V product sees the mask
 #pragma unroll
-        for (int t = 0; t < NT; ++t) s[t] *= drop_factors_qmajor(hq[h], q_local, kb0 + 16 * t + 4 * G, dc);
+        for (int t = 0; t < NT; ++t) s[t] *= drop_factors_qmajor(hq[h], dh[h], q_local, kb0 + 16 * t + 4 * G, dc);
       }
       f32x4 vf[NT];
 #pragma unroll

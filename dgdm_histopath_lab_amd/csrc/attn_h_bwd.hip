@@ -54,6 +54,7 @@ __global__ __launch_bounds__(256) void k_attn_h_bwd_dq(const _Float16* __restric
   f32x4 dq[HG], dq2[HG];
   float nl2[HG], ndl[HG];
   uint32_t hq[HG];
+  DropHead dh[HG];
 #pragma unroll
   for (int h = 0; h < HG; ++h) {
     const int64_t rowoff = (((int64_t)blockIdx.x * H + head0 + h) * HB + q_in_blk);
@@ -62,7 +63,8 @@ __global__ __launch_bounds__(256) void k_attn_h_bwd_dq(const _Float16* __restric
     nl2[h] = -lse2_b[rowoff];
     ndl[h] = -delta_b[rowoff];
     dq[h] = f32x4{0.f, 0.f, 0.f, 0.f}; dq2[h] = f32x4{0.f, 0.f, 0.f, 0.f};
-    hq[h] = attn_hq(attn_head_seed(seed, n0, head0 + h), q_local);
+    dh[h] = DropHead(seed, n0, head0 + h);
+    hq[h] = attn_hq(dh[h], q_local);
   }
   const float2 pq = *reinterpret_cast<const float2*>(pos_b + ((int64_t)blockIdx.x * HB + q_in_blk) * 2);
   __syncthreads();
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(256) void k_attn_h_bwd_dq(const _Float16* __restric
         s = mfma_h(kf, qb2[h], s);
         f32x4 dp = mfma_h(vf, gb1[h], cdl);              // dP^T - delta
         dp = mfma_h(vf, gb2[h], dp);
-        if (DROP) dp = dp * drop_factors_qmajor(hq[h], q_local, kb0 + 16 * t + 4 * G, dc) + ndl[h];
+        if (DROP) dp = dp * drop_factors_qmajor(hq[h], dh[h], q_local, kb0 + 16 * t + 4 * G, dc) + ndl[h];
 #pragma unroll
         for (int r = 0; r < 4; ++r) ds[t][r] = __builtin_amdgcn_exp2f(s[r]) * dp[r];
       }
@@ -173,7 +175,7 @@ __global__ __launch_bounds__(256) void k_attn_h_bwd_dkv(const _Float16* __restri
 
   f16x8 kb1[HG], kb2[HG], vb1[HG], vb2[HG];
   f32x4 dk[HG], dk2[HG], dv[HG], dv2[HG];
-  uint32_t hs[HG];
+  DropHead hs[HG];
 #pragma unroll
   for (int h = 0; h < HG; ++h) {
     const int64_t rowoff = (((int64_t)blockIdx.x * H + head0 + h) * HB + k_in_blk);
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(256) void k_attn_h_bwd_dkv(const _Float16* __restri
     load_b_pair(Rv + rowoff * 32, G, &vb1[h], &vb2[h]);
     dk[h] = f32x4{0.f, 0.f, 0.f, 0.f}; dk2[h] = f32x4{0.f, 0.f, 0.f, 0.f};
     dv[h] = f32x4{0.f, 0.f, 0.f, 0.f}; dv2[h] = f32x4{0.f, 0.f, 0.f, 0.f};
-    hs[h] = attn_head_seed(seed, n0, head0 + h);
+    hs[h] = DropHead(seed, n0, head0 + h);
   }
   const float2 pk = *reinterpret_cast<const float2*>(pos_b + ((int64_t)blockIdx.x * HB + k_in_blk) * 2);
   __syncthreads();

@@ -130,13 +130,15 @@ __global__ __launch_bounds__(256, 2) void k_attn_h_fwd(const _Float16* __restric
   f32x4 oacc[HG], oacc2[HG], lacc[HG];  // lacc: every register = sum over keys of the ROUNDED weights (ones . P)
   float m[HG];
   uint32_t hq[HG];
+  DropHead dh[HG];
   const _Float16 one = (_Float16)1.0f;
   const f16x8 ones = {one, one, one, one, one, one, one, one};
 #pragma unroll
   for (int h = 0; h < HG; ++h) {
     load_b_pair(Rq + (((int64_t)blockIdx.x * H + head0 + h) * HB + q_in_blk) * 32, G, &qb1[h], &qb2[h]);
     oacc[h] = f32x4{0.f, 0.f, 0.f, 0.f}; oacc2[h] = f32x4{0.f, 0.f, 0.f, 0.f}; lacc[h] = f32x4{0.f, 0.f, 0.f, 0.f}; m[h] = NEG_BIG;
-    hq[h] = attn_hq(attn_head_seed(seed, n0, head0 + h), q_local);
+    dh[h] = DropHead(seed, n0, head0 + h);
+    hq[h] = attn_hq(dh[h], q_local);
   }
   const float2 pq = *reinterpret_cast<const float2*>(pos_b + ((int64_t)blockIdx.x * HB + q_in_blk) * 2);
   __syncthreads();  // block 0 landed (vmcnt(0) + barrier)
@@ -196,10 +198,16 @@ __global__ __launch_bounds__(256, 2) void k_attn_h_fwd(const _Float16* __restric
         // result already covers all four lane groups of a query
         f16x8 pb = pack8(s[2 * tp], s[2 * tp + 1]);
         lacc[h] = mfma_h(ones, pb, lacc[h]);
-        if (DROP) {  // dropout applies to the normalised weights: mask only what multiplies V
-          s[2 * tp] *= drop_factors_qmajor(hq[h], q_local, kb0 + 32 * tp + 4 * G, dc);
-          s[2 * tp + 1] *= drop_factors_qmajor(hq[h], q_local, kb0 + 32 * tp + 16 + 4 * G, dc);
-          pb = pack8(s[2 * tp], s[2 * tp + 1]);
+        if (DROP) {  // dropout applies to the normalised weights: mask only what multiplies V.  The packed halfs are masked
+                     // in place (0xFFFF / 0 per half-word); the constant 1/(1-p) multiplies the finished row below.
+          typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+          u32x4 mk;
+          uint32_t a, b;
+          drop_masks_qmajor(hq[h], dh[h], q_local, kb0 + 32 * tp + 4 * G, dc, &a, &b);
+          mk[0] = a; mk[1] = b;
+          drop_masks_qmajor(hq[h], dh[h], q_local, kb0 + 32 * tp + 16 + 4 * G, dc, &a, &b);
+          mk[2] = a; mk[3] = b;
+          pb = __builtin_bit_cast(f16x8, __builtin_bit_cast(u32x4, pb) & mk);
         }
         oacc[h] = mfma_h(load_t_pair(vh, j, 2 * tp, G), pb, oacc[h]);
         oacc2[h] = mfma_h(load_t_pair(vh + T_PART, j, 2 * tp, G), pb, oacc2[h]);
@@ -211,7 +219,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_h_fwd(const _Float16* __restric
 #pragma unroll
   for (int h = 0; h < HG; ++h) {
     const float lt = lacc[h][0];
-    const float inv = 1.0f / lt;
+    const float inv = (DROP ? dc.keep : 1.0f) / lt;
     if (q_ok) {
       const f32x4 os = oacc[h] + oacc2[h];
       *reinterpret_cast<float4*>(O + (int64_t)(n0 + q_local) * ldo + (head0 + h) * 16 + 4 * G) =
