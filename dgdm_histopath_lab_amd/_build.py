@@ -32,7 +32,10 @@ def _hipcc() -> str:
 # the accumulators in AGPRs (the compiler's choice under their register pressure) each value costs a v_accvgpr_read and
 # each C operand a v_accvgpr_write -- 272 of the 1330 VALU instructions of the dQ loop.  Keeping the MFMA operands in
 # architected VGPRs removes them (235 / 210 VGPRs, no spills).
-EXTRA_FLAGS = {"attn_h_bwd.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+# -fno-honor-nans: fmaxf on MFMA results otherwise gets a canonicalising v_max_f32 x, x per operand (masked scores are -1e30, never
+# NaN or inf).
+EXTRA_FLAGS = {"attn_h_bwd.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-fno-honor-nans"],
+               "attn_h_fwd.hip": ["-fno-honor-nans"]}
 
 
 def _sources():

@@ -174,9 +174,13 @@ __global__ __launch_bounds__(256, 2) void k_attn_h_fwd(const _Float16* __restric
         s[t] = mfma_h(kf, qb1[h], nbias[t]);
         s[t] = mfma_h(kf, qb2[h], s[t]);
       }
-      float mloc = fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3]));
+      float mloc = fmaxf(s[0][0], s[0][1]);   // a chain the compiler folds into v_max3_f32: two values per instruction
+      mloc = fmaxf(fmaxf(mloc, s[0][2]), s[0][3]);
 #pragma unroll
-      for (int t = 1; t < NT; ++t) mloc = fmaxf(mloc, fmaxf(fmaxf(s[t][0], s[t][1]), fmaxf(s[t][2], s[t][3])));
+      for (int t = 1; t < NT; ++t) {
+        mloc = fmaxf(fmaxf(mloc, s[t][0]), s[t][1]);
+        mloc = fmaxf(fmaxf(mloc, s[t][2]), s[t][3]);
+      }
       if (__any(mloc > m[h] + LAZY_THR)) {  // wave-uniform: rare after the first blocks
         const float m_new = fmaxf(m[h], group_max4(mloc));
         const float alpha = __builtin_amdgcn_exp2f(m[h] - m_new);
@@ -185,11 +189,14 @@ __global__ __launch_bounds__(256, 2) void k_attn_h_fwd(const _Float16* __restric
         oacc[h] *= alpha;
         oacc2[h] *= alpha;
       }
-      const float mh = m[h];
+      const float nm = -m[h];
+      const f32x4 mh = {nm, nm, nm, nm};
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
+      for (int t = 0; t < NT; ++t) {
+        s[t] = s[t] + mh;   // vector form: two v_pk_add_f32 instead of four v_sub_f32
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s[t][r] = __builtin_amdgcn_exp2f(s[t][r] - mh);
+        for (int r = 0; r < 4; ++r) s[t][r] = __builtin_amdgcn_exp2f(s[t][r]);
+      }
       const _Float16* vh = Vimg + h * T_HEAD;
 #pragma unroll
       for (int tp = 0; tp < NT / 2; ++tp) {
