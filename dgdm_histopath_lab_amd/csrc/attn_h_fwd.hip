@@ -160,9 +160,15 @@ __global__ __launch_bounds__(256, 2) void k_attn_h_fwd(const _Float16* __restric
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float dx = pq.x - kx[r], dy = pq.y - ky[r];
-        const float d = __builtin_amdgcn_sqrtf(fmaf(dx, dx, dy * dy)) * bscale;
-        nbias[t][r] = (kb0 + 16 * t + 4 * G + r < ng) ? -d : NEG_BIG;
+        nbias[t][r] = -(__builtin_amdgcn_sqrtf(fmaf(dx, dx, dy * dy)) * bscale);
       }
+    }
+    if (kb0 + HB > ng) {   // only the last key block of a graph has keys to mask (wave-uniform branch)
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (kb0 + 16 * t + 4 * G + r >= ng) nbias[t][r] = NEG_BIG;
     }
 
 #pragma unroll
