@@ -69,16 +69,22 @@ class GraphConvolution(nn.Module):
         if self.bias is not None:
             nn.init.zeros_(self.bias)
 
-    def forward(self, x: Tensor, edge_index: Union[Tensor, GraphContext], edge_attr: Optional[Tensor] = None, size=None) -> Tensor:
+    def forward(self, x: Tensor, edge_index: Union[Tensor, GraphContext], edge_attr: Optional[Tensor] = None, size=None,
+                return_skip: bool = False):
+        """``return_skip=True`` returns ``(out, x_skip)``: ``x_skip`` is ``x`` for a residual connection of the caller; on the
+        fused path it is an alias routed through this convolution's autograd node, so the residual's gradient is added inside
+        the convolution's backward kernel instead of by a separate element-wise pass."""
         ctx = _context(edge_index, x, edge_attr, self.add_self_loops)
         if self.edge_lin is not None and ctx.ea_hat is not None:
             # one contraction over K = C_in + edge_dim:  [A_hat x | EA_hat] . [W | W_e]^T + b
             if (x.size(0) >= ops.GEMM_MIN_ROWS and x.size(1) % 4 == 0 and self.out_channels % 4 == 0 and ctx.ea_hat.size(1) % 4 == 0
                     and x.dtype == torch.float32):
-                return ops.graph_conv_linear(x, ctx.ea_hat, ctx.gs, self.node_lin.weight, self.edge_lin.weight, self.bias)
+                return ops.graph_conv_linear(x, ctx.ea_hat, ctx.gs, self.node_lin.weight, self.edge_lin.weight, self.bias, skip=return_skip)
             buf = ops.aggregate_concat(x, ctx.ea_hat, ctx.gs)
-            return ops.linear(buf, torch.cat([self.node_lin.weight, self.edge_lin.weight], dim=1), self.bias)
-        return ops.linear(ops.aggregate(x, ctx.gs), self.node_lin.weight, self.bias)
+            out = ops.linear(buf, torch.cat([self.node_lin.weight, self.edge_lin.weight], dim=1), self.bias)
+        else:
+            out = ops.linear(ops.aggregate(x, ctx.gs), self.node_lin.weight, self.bias)
+        return (out, x) if return_skip else out
 
 
 class DynamicGraphLayer(nn.Module):
@@ -108,12 +114,13 @@ class DynamicGraphLayer(nn.Module):
     def forward(self, x: Tensor, edge_index: Union[Tensor, GraphContext], edge_attr: Optional[Tensor] = None) -> Tensor:
         ctx = _context(edge_index, x, edge_attr)
         p, tr = self.dropout.p, self.training
-        h = ops.act_dropout(self.graph_conv1(x, ctx), ops.ACT_GELU, p, tr)
+        h, xs = self.graph_conv1(x, ctx, return_skip=True)      # xs: x for the residual below (see GraphConvolution.forward)
+        h = ops.act_dropout(h, ops.ACT_GELU, p, tr)
         h = ops.act_dropout(self.graph_conv2(h, ctx), ops.ACT_GELU, p, tr)
         out = ops.lin(self.output_proj, h)
         if isinstance(self.norm1, nn.LayerNorm) and ops.row_norm_supported(self.node_dim, 1):
-            return ops.row_norm(out, self.norm1.weight, self.norm1.bias, res=x, eps=self.norm1.eps)
-        return self.norm1(out + x)
+            return ops.row_norm(out, self.norm1.weight, self.norm1.bias, res=xs, eps=self.norm1.eps)
+        return self.norm1(out + xs)
 
 
 class AdaptiveGraphPooling(nn.Module):

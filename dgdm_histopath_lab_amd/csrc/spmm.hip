@@ -16,7 +16,8 @@ __global__ __launch_bounds__(256) void k_spmm(const int32_t* __restrict__ rowptr
                                               const float* __restrict__ w, const float* __restrict__ X, int64_t ldx,
                                               int32_t table_rows, float* __restrict__ Y, int64_t ldy, int32_t N, int32_t C,
                                               const float* __restrict__ bias, int accumulate,
-                                              const float* __restrict__ tail, int64_t ldt, int tail_c4) {
+                                              const float* __restrict__ tail, int64_t ldt, int tail_c4,
+                                              const float* __restrict__ addend, int64_t lda) {
   constexpr int RPW = 64 / LPR;                 // rows per wave
   const int lane = threadIdx.x & 63;
   const int sub = lane / LPR, lir = lane % LPR;  // which row of the wave, lane inside the row
@@ -73,6 +74,10 @@ __global__ __launch_bounds__(256) void k_spmm(const int32_t* __restrict__ rowptr
           const float4 y0 = dst[k];
           o.x += y0.x; o.y += y0.y; o.z += y0.z; o.w += y0.w;
         }
+        if (addend) {  // Y = result + addend: a second gradient arriving at the same tensor (residual connection), no extra pass
+          const float4 a0 = reinterpret_cast<const float4*>(addend + (int64_t)row * lda)[k];
+          o.x += a0.x; o.y += a0.y; o.z += a0.z; o.w += a0.w;
+        }
         dst[k] = o;
       }
     }
@@ -86,13 +91,13 @@ __global__ __launch_bounds__(256) void k_spmm(const int32_t* __restrict__ rowptr
 template <int LPR, int R, int UNROLL>
 int launch(const int32_t* rowptr, const int32_t* col, const float* w, const float* X, int64_t ldx, int32_t table_rows,
            float* Y, int64_t ldy, int32_t N, int32_t C, const float* bias, int accumulate, const float* tail, int64_t ldt,
-           int tail_c4, hipStream_t stream) {
+           int tail_c4, const float* addend, int64_t lda, hipStream_t stream) {
   constexpr int RPW = 64 / LPR;
   const int64_t waves = ((int64_t)N + RPW - 1) / RPW;
   int64_t blocks = (waves + 3) / 4;
   if (blocks > 256 * 64) blocks = 256 * 64;  // grid-stride beyond that
   hipLaunchKernelGGL((k_spmm<LPR, R, UNROLL>), dim3((unsigned)blocks), dim3(256), 0, stream, rowptr, col, w, X, ldx,
-                     table_rows, Y, ldy, N, C, bias, accumulate, tail, ldt, tail_c4);
+                     table_rows, Y, ldy, N, C, bias, accumulate, tail, ldt, tail_c4, addend, lda);
   return dgdm_launch_status();
 }
 
@@ -100,7 +105,8 @@ int launch(const int32_t* rowptr, const int32_t* col, const float* w, const floa
 
 static int spmm_dispatch(const int32_t* rowptr, const int32_t* col, const float* w, const float* X, int64_t ldx,
                          int32_t table_rows, float* Y, int64_t ldy, int32_t N, int32_t C, const float* bias,
-                         int32_t accumulate, const float* tail, int64_t ldt, int32_t Ct, void* stream_) {
+                         int32_t accumulate, const float* tail, int64_t ldt, int32_t Ct, const float* addend, int64_t lda,
+                         void* stream_) {
   DGDM_REQUIRE(N >= 0 && C > 0 && table_rows >= 0 && Ct >= 0);
   if (N == 0) return DGDM_OK;
   DGDM_REQUIRE(rowptr && col && w && Y);
@@ -109,15 +115,16 @@ static int spmm_dispatch(const int32_t* rowptr, const int32_t* col, const float*
   if ((C & 3) || C > 1024 || (ldx & 3) || (ldy & 3) || ldx < C || ldy < C + Ct) return DGDM_ERR_UNSUPPORTED;
   if (!dgdm_aligned16(X) || !dgdm_aligned16(Y) || (bias && !dgdm_aligned16(bias))) return DGDM_ERR_UNSUPPORTED;
   if (Ct && ((Ct & 3) || (ldt & 3) || ldt < Ct || !dgdm_aligned16(tail) || accumulate)) return DGDM_ERR_UNSUPPORTED;
+  if (addend && ((lda & 3) || lda < C || !dgdm_aligned16(addend))) return DGDM_ERR_UNSUPPORTED;
   hipStream_t s = static_cast<hipStream_t>(stream_);
   if (table_rows == 0) {  // nothing to gather: Y = 0 (or unchanged when accumulating)
-    if (bias || Ct) return DGDM_ERR_UNSUPPORTED;
+    if (bias || Ct || addend) return DGDM_ERR_UNSUPPORTED;
     if (!accumulate) dgdm_fill2d_async(Y, ldy, C, N, s);
     return dgdm_launch_status();
   }
   const int c4 = C >> 2;
   if (!Ct) tail = nullptr;
-#define GO(LPR, R, U) return launch<LPR, R, U>(rowptr, col, w, X, ldx, table_rows, Y, ldy, N, C, bias, accumulate, tail, ldt, Ct >> 2, s)
+#define GO(LPR, R, U) return launch<LPR, R, U>(rowptr, col, w, X, ldx, table_rows, Y, ldy, N, C, bias, accumulate, tail, ldt, Ct >> 2, addend, lda, s)
   if (c4 <= 8) GO(8, 1, 4);
   if (c4 <= 16) GO(16, 1, 4);
   if (c4 <= 32) GO(32, 1, 4);
@@ -131,11 +138,18 @@ static int spmm_dispatch(const int32_t* rowptr, const int32_t* col, const float*
 extern "C" int dgdm_spmm(const int32_t* rowptr, const int32_t* col, const float* w, const float* X, int64_t ldx,
                          int32_t table_rows, float* Y, int64_t ldy, int32_t N, int32_t C, const float* bias,
                          int32_t accumulate, void* stream) {
-  return spmm_dispatch(rowptr, col, w, X, ldx, table_rows, Y, ldy, N, C, bias, accumulate, nullptr, 0, 0, stream);
+  return spmm_dispatch(rowptr, col, w, X, ldx, table_rows, Y, ldy, N, C, bias, accumulate, nullptr, 0, 0, nullptr, 0, stream);
 }
 
 extern "C" int dgdm_spmm_concat(const int32_t* rowptr, const int32_t* col, const float* w, const float* X, int64_t ldx,
                                 int32_t table_rows, const float* tail, int64_t ldt, int32_t Ct, float* Y, int64_t ldy,
                                 int32_t N, int32_t C, void* stream) {
-  return spmm_dispatch(rowptr, col, w, X, ldx, table_rows, Y, ldy, N, C, nullptr, 0, tail, ldt, Ct, stream);
+  return spmm_dispatch(rowptr, col, w, X, ldx, table_rows, Y, ldy, N, C, nullptr, 0, tail, ldt, Ct, nullptr, 0, stream);
+}
+
+extern "C" int dgdm_spmm_add(const int32_t* rowptr, const int32_t* col, const float* w, const float* X, int64_t ldx,
+                             int32_t table_rows, const float* addend, int64_t lda, float* Y, int64_t ldy, int32_t N, int32_t C,
+                             void* stream) {
+  DGDM_REQUIRE(addend);
+  return spmm_dispatch(rowptr, col, w, X, ldx, table_rows, Y, ldy, N, C, nullptr, 0, nullptr, 0, 0, addend, lda, stream);
 }

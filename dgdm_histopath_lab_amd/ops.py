@@ -54,7 +54,7 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
 
 # ----------------------------------------------------------------------------- K2 SpMM
 def spmm_raw(rowptr, col, w, X, num_rows: int, *, table_rows: Optional[int] = None, out: Optional[torch.Tensor] = None,
-             bias: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+             bias: Optional[torch.Tensor] = None, accumulate: bool = False, addend: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Y[r] = sum_p w[p] X[col[p]] (+bias): dgdm_spmm.  X may be a column-strided view
     (row stride multiple of 4 floats); ``out`` likewise."""
     _lib.require_cuda(X, rowptr, col, w)
@@ -68,6 +68,15 @@ def spmm_raw(rowptr, col, w, X, num_rows: int, *, table_rows: Optional[int] = No
     tr = X.size(0) if table_rows is None else table_rows
     ldx = X.stride(0) if X.size(0) > 1 else max(C, X.stride(0))
     ldy = out.stride(0) if out.size(0) > 1 else max(C, out.stride(0))
+    if addend is not None:   # Y = result + addend (dgdm_spmm_add)
+        if bias is not None or accumulate:
+            raise ValueError("addend excludes bias / accumulate")
+        addend = _rowmajor(addend)
+        TIMERS.timed(f"spmm_c{C}", lambda: _lib.check(
+            lib.dgdm_spmm_add(rowptr.data_ptr(), col.data_ptr(), w.data_ptr(), X.data_ptr() if X.numel() else None, ldx, tr, addend.data_ptr(),
+                              addend.stride(0) if addend.size(0) > 1 else max(C, addend.stride(0)), out.data_ptr(), ldy, num_rows, C,
+                              _lib.stream_ptr(X.device)), "dgdm_spmm_add"))
+        return out
     TIMERS.timed(f"spmm_c{C}", lambda: _lib.check(
         lib.dgdm_spmm(rowptr.data_ptr(), col.data_ptr(), w.data_ptr(), X.data_ptr() if X.numel() else None, ldx, tr,
                       out.data_ptr(), ldy, num_rows, C, _lib.ptr(bias), int(accumulate), _lib.stream_ptr(X.device)), "dgdm_spmm"))
@@ -753,8 +762,11 @@ class _GraphConvLinear(torch.autograd.Function):
               contracted over W alone (EA_hat depends only on the inputs) and scattered back by the transposed SpMM."""
 
     @staticmethod
-    def forward(ctx, x, ea_hat, gs: GraphStructure, w, we, b):
+    def forward(ctx, x, ea_hat, gs: GraphStructure, w, we, b, skip: bool = False):
+        """``skip=True`` also returns ``x`` itself as a second output: a caller that feeds x to a residual connection as well
+        uses that alias, so both gradients of x arrive here and are added while the scattered one is written (dgdm_spmm_add)."""
         lib = _lib.load()
+        x_in = x
         x = x if (x.dim() == 2 and x.stride(1) == 1 and x.stride(0) % 4 == 0) else _f32c(x)
         ea_hat = _rowmajor(ea_hat)
         n, cin, ed = gs.num_nodes, x.size(1), ea_hat.size(1)
@@ -763,18 +775,20 @@ class _GraphConvLinear(torch.autograd.Function):
             lib.dgdm_spmm_concat(gs.rowptr.data_ptr(), gs.col.data_ptr(), gs.w.data_ptr(), x.data_ptr(), x.stride(0), x.size(0),
                                  ea_hat.data_ptr(), ea_hat.stride(0), ed, buf.data_ptr(), buf.stride(0), n, cin,
                                  _lib.stream_ptr(x.device)), "dgdm_spmm_concat"))
-        ctx.gs, ctx.cin, ctx.has_bias = gs, cin, b is not None
+        ctx.gs, ctx.cin, ctx.has_bias, ctx.skip = gs, cin, b is not None, skip
         if GEMM_FWD_BACKEND == "bf16x3" and cin % 4 == 0:
             ctx.save_for_backward(buf, w)          # the kernel reads the two weights side by side: no concatenated copy
-            return gemm_nt_split_raw(buf, w, we, b)
-        wcat = torch.cat([w, we], dim=1)
-        ctx.save_for_backward(buf, wcat)
-        if GEMM_FWD_BACKEND == "lib":
-            return torch.nn.functional.linear(buf, wcat, b)
-        return gemm_nt_raw(buf, wcat, b, math="fp32")
+            y = gemm_nt_split_raw(buf, w, we, b)
+        else:
+            wcat = torch.cat([w, we], dim=1)
+            ctx.save_for_backward(buf, wcat)
+            y = torch.nn.functional.linear(buf, wcat, b) if GEMM_FWD_BACKEND == "lib" else gemm_nt_raw(buf, wcat, b, math="fp32")
+        return (y, x_in.view_as(x_in)) if skip else y
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, gskip=None):
+        if gy is None:      # only the alias of x was used downstream
+            return gskip, None, None, None, None, None, None
         buf, wsaved = ctx.saved_tensors
         gs, cin = ctx.gs, ctx.cin
         gy = _rowmajor(gy)
@@ -783,15 +797,15 @@ class _GraphConvLinear(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             w_only = wsaved[:, :cin]                    # node_lin.weight itself, or a view into the concatenated copy
             dagg = gy @ w_only if GEMM_FWD_BACKEND == "lib" else gemm_nn_raw(gy, w_only, math=math)
-            dx = spmm_raw(gs.rowptr_t, gs.col_t, gs.w_t, dagg, gs.num_nodes)
+            dx = spmm_raw(gs.rowptr_t, gs.col_t, gs.w_t, dagg, gs.num_nodes, addend=gskip)
         dw = dwe = db = None
         if ctx.needs_input_grad[3] or ctx.needs_input_grad[4] or (ctx.has_bias and ctx.needs_input_grad[5]):
             (dw, dwe), db = gemm_tn_raw(gy, buf, ctx.has_bias, math=math, split=cin)
-        return dx, None, None, dw, dwe, db
+        return dx, None, None, dw, dwe, db, None
 
 
-def graph_conv_linear(x, ea_hat, gs: GraphStructure, w, we, b):
-    return _GraphConvLinear.apply(x, ea_hat, gs, w, we, b)
+def graph_conv_linear(x, ea_hat, gs: GraphStructure, w, we, b, skip: bool = False):
+    return _GraphConvLinear.apply(x, ea_hat, gs, w, we, b, skip)
 
 
 # ----------------------------------------------------------------------------- K9 top-k pooling / unpooling

@@ -116,6 +116,12 @@ DGDM_API int dgdm_spmm(const int32_t* rowptr, const int32_t* col, const float* w
 /* Y[r, 0:C) as dgdm_spmm (no bias, no accumulate) and Y[r, C:C+Ct) = tail[r, :] in the same pass: the operand
  * [A_hat x | EA_hat] of a graph convolution's single contraction (graph_layers.py:99-110) without a separate copy of the
  * per-graph edge-attribute aggregate.  Ct % 4 == 0, ldt % 4 == 0, ldy >= C + Ct. */
+/* Y = dgdm_spmm(...) + addend (addend [N, C], leading dimension lda; may not alias Y): the backward of a graph convolution
+ * whose input also feeds a residual connection (DynamicGraphLayer, graph_layers.py:233-245) adds the residual's gradient
+ * while it writes the scattered one, instead of leaving the sum to a separate element-wise pass. */
+DGDM_API int dgdm_spmm_add(const int32_t* rowptr, const int32_t* col, const float* w, const float* X, int64_t ldx,
+                           int32_t table_rows, const float* addend, int64_t lda, float* Y, int64_t ldy, int32_t N, int32_t C,
+                           void* stream);
 DGDM_API int dgdm_spmm_concat(const int32_t* rowptr, const int32_t* col, const float* w, const float* X, int64_t ldx,
                               int32_t table_rows, const float* tail, int64_t ldt, int32_t Ct, float* Y, int64_t ldy,
                               int32_t N, int32_t C, void* stream);

@@ -147,3 +147,34 @@ def test_graph_conv_linear_is_the_two_step_path(n, e, cin, cout):
     # the input gradient is contracted over W alone instead of [W | W_e]: other K, other summation tree
     scale = float(x2.grad.abs().max())
     assert torch.allclose(x1.grad, x2.grad, rtol=1e-4, atol=1e-5 * scale)
+
+
+def test_graph_conv_skip_alias_adds_the_residual_gradient_in_the_backward_kernel():
+    """graph_conv_linear(skip=True): the alias of x carries the residual's gradient into the convolution's backward, where
+    dgdm_spmm_add sums it with the scattered gradient -- same numbers as letting autograd add the two."""
+    from dgdm_histopath_lab_amd import GraphStructure, ops
+    dev = _dev()
+    n, e, cin, cout = 3000, 15000, 128, 128
+    ei = _rand_edges(n, e, 21)
+    gs = GraphStructure(torch.from_numpy(ei).to(dev), n)
+    g = torch.Generator().manual_seed(3)
+    ea_hat = ops.aggregate_edge_attr(torch.randn(e, 32, generator=g).to(dev), gs)
+    gy, gres = torch.randn(n, cout, generator=g).to(dev), torch.randn(n, cin, generator=g).to(dev)
+
+    def leaves():
+        gg = torch.Generator().manual_seed(9)
+        return [t.to(dev).requires_grad_(True) for t in (torch.randn(n, cin, generator=gg), torch.randn(cout, cin, generator=gg) / cin ** 0.5,
+                                                         torch.randn(cout, 32, generator=gg) / 6, torch.randn(cout, generator=gg))]
+    x1, w1, we1, b1 = leaves()
+    y1, xs = ops.graph_conv_linear(x1, ea_hat, gs, w1, we1, b1, skip=True)
+    assert xs.data_ptr() == x1.data_ptr()
+    ((y1 * gy).sum() + (xs * gres).sum()).backward()
+    x2, w2, we2, b2 = leaves()
+    y2 = ops.graph_conv_linear(x2, ea_hat, gs, w2, we2, b2)
+    ((y2 * gy).sum() + (x2 * gres).sum()).backward()
+    assert torch.equal(y1, y2) and torch.equal(w1.grad, w2.grad) and torch.equal(b1.grad, b2.grad)
+    assert torch.allclose(x1.grad, x2.grad, rtol=1e-6, atol=1e-6)      # (a + b) vs a then + b: one rounding apart
+    x3 = leaves()[0]
+    _, xs3 = ops.graph_conv_linear(x3, ea_hat, gs, w2.detach(), we2.detach(), b2.detach(), skip=True)
+    (xs3 * gres).sum().backward()                                      # only the alias used
+    assert torch.equal(x3.grad, gres)
