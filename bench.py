@@ -230,12 +230,29 @@ def main():
         opt.step()
         return out["total_pretrain_loss"]
 
+    graph_note = None
     if not args.eager and stream is None:
         from dgdm_histopath_lab_amd.training import GraphedPretrainStep
         gstep = GraphedPretrainStep(model, opt, mask_ratio=0.15, grad_reducer=reducer)
-        eager_step, step = step, (lambda: gstep(batch))
-        for _ in range(gstep.warmup + 1):     # eager priming + recording: setup, not part of the W warmup steps
-            step()
+        eager_step, graph_step = step, (lambda: gstep(batch))
+        done = 0
+        try:
+            for _ in range(gstep.warmup + 1):     # eager priming + recording: setup, not part of the W warmup steps
+                graph_step()
+                done += 1
+        except Exception as e:                    # recording refused on this box: finish the priming steps eagerly (every rank
+            graph_note = f"eager (recording failed: {type(e).__name__}: {e})"[:300]   # issues the same collectives) and stay eager
+            print(f"bench.py: rank {rank}: {graph_note}", file=sys.stderr)
+            for _ in range(gstep.warmup + 1 - done):
+                eager_step()
+        ok = torch.tensor([0.0 if graph_note else 1.0], device=dev)
+        if world > 1 or force_dist:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if float(ok.item()) > 0:
+            step = graph_step
+        else:
+            graph_note = graph_note or "eager (another rank could not record the step)"
+            args.eager = True
 
     for _ in range(args.warmup):
         step()
@@ -309,7 +326,7 @@ def main():
                                     f"graphs per GPU, feat={FEATS}, edge_attr=32, T={cfg['num_diffusion_steps']}, heads={cfg['attention_heads']}, ") +
                                    f"{'eval (dropout off)' if args.eval_mode else 'training mode (dropout 0.1)'}",
                        "global_batch": world * args.batch, "parallelism": f"dp{world}", "final_loss": round(loss_val, 5),
-                       "launch": "HIP graph replay (training.GraphedPretrainStep)" if graphed else "eager"},
+                       "launch": "HIP graph replay (training.GraphedPretrainStep)" if graphed else (graph_note or "eager")},
             "roofline": roofline,
         }
     if world > 1 or force_dist:
