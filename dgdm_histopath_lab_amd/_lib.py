@@ -139,7 +139,20 @@ def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_ptr(device=None) -> int:
+    """Handle of torch's current stream on ``device`` (called once per kernel launch: the raw accessor is ~10x cheaper
+    than building a torch.cuda.Stream object)."""
+    if _raw_stream is not None:
+        if device is None:
+            idx = torch.cuda.current_device()
+        elif isinstance(device, int):
+            idx = device
+        else:
+            idx = device.index if device.index is not None else torch.cuda.current_device()
+        return _raw_stream(idx)
     return torch.cuda.current_stream(device).cuda_stream
 
 

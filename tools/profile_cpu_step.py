@@ -7,7 +7,7 @@ dev = torch.device("cuda:0")
 torch.manual_seed(0)
 model = DGDMModel(node_features=768, hidden_dims=[512, 256, 128], num_diffusion_steps=10, attention_heads=8).to(dev).train()
 opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-5, fused=True)
-batch = synthetic_batch(0, 4, 10000, 50000, 768).to(dev)
+nodes = int(os.environ.get("NODES", "10000")); batch = synthetic_batch(0, 4, nodes, 5 * nodes, 768).to(dev)
 def step():
     opt.zero_grad(set_to_none=True)
     out = model.pretrain_step(batch, mask_ratio=0.15)
