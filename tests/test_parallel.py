@@ -58,6 +58,65 @@ def test_flat_grad_all_reduce_two_ranks_gloo():
             torch.testing.assert_close(g, dict(m.named_parameters())[k].grad, rtol=1e-6, atol=1e-7)
 
 
+def _phase_worker(rank, world, port, q):
+    """A phase switch changes which parameters carry gradients: the reducer raises unless it is reset on every rank."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    m = Tiny()
+    red = FlatGradAllReducer(m, world)
+    x = torch.full((2, 6), float(rank + 1))
+    m(x).sum().backward()
+    red.all_reduce()
+    first = red.nbytes
+    m.zero_grad(set_to_none=True)
+    (m(x).sum() + m.dead(torch.ones(1, 3)).sum()).backward()      # `dead` is live now
+    try:
+        red.all_reduce()
+        raised = False
+    except RuntimeError:
+        raised = True
+    red.reset()
+    red.all_reduce()
+    q.put((rank, raised, first, red.nbytes, m.dead.bias.grad.clone()))
+    dist.destroy_process_group()
+
+
+def test_reducer_reset_on_phase_switch_two_ranks_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_phase_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, raised, first, second, dead_bias_grad in res:
+        assert raised and first == 4 * (24 + 4 + 4) and second == first + 4 * (9 + 3)
+        torch.testing.assert_close(dead_bias_grad, torch.ones(3))       # identical on both ranks: mean == value
+
+
+def test_single_rank_always_flag_runs_the_collective():
+    """`always=True` (bench rehearsal knob) must not return early with one rank."""
+    port = 33500 + os.getpid() % 2000
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        m = Tiny()
+        m(torch.ones(2, 6)).sum().backward()
+        g = m.a.weight.grad.clone()
+        red = FlatGradAllReducer(m, 1, always=True)
+        red.all_reduce()
+        assert red.nbytes == 4 * (24 + 4 + 4) and torch.equal(m.a.weight.grad, g)
+        lazy = FlatGradAllReducer(m, 1)
+        lazy.all_reduce()
+        assert lazy.nbytes == 0
+    finally:
+        dist.destroy_process_group()
+
+
 def test_sharding_helpers():
     assert [list(shard_slides(32, r, 8)) for r in range(8)][3] == [12, 13, 14, 15]
     assert sum(len(shard_slides(10, r, 4)) for r in range(4)) == 10 and list(shard_slides(10, 3, 4)) == [8, 9]
