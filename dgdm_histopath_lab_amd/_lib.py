@@ -139,6 +139,19 @@ def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
+_WS_BYTES: dict = {}
+
+
+def workspace_bytes(name: str, *args) -> int:
+    """``lib.<name>(*args)`` for the ``*_workspace_bytes`` entry points, memoised: they are pure functions of the shape, and a
+    training step asks the same ~100 questions every time."""
+    key = (name, args)
+    v = _WS_BYTES.get(key)
+    if v is None:
+        v = _WS_BYTES[key] = getattr(load(), name)(*args)
+    return v
+
+
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 

@@ -132,7 +132,7 @@ class GraphStructure:
         self.w = torch.empty(n_ent, dtype=torch.float32, device=dev)
         self.w_t = torch.empty(n_ent, dtype=torch.float32, device=dev)
         if pipeline == "pair":       # both orientations, dinv and the weights in five launches
-            ws_bytes = lib.dgdm_csr_build_pair_workspace_bytes(E, N, int(add_loops))
+            ws_bytes = _lib.workspace_bytes("dgdm_csr_build_pair_workspace_bytes", E, N, int(add_loops))
             ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
             _lib.check(lib.dgdm_csr_build_pair(ei.data_ptr(), E, N, int(add_loops), self.rowptr.data_ptr(), self.col.data_ptr(),
                                                self.eid.data_ptr(), self.w.data_ptr(), self.rowptr_t.data_ptr(), self.col_t.data_ptr(),

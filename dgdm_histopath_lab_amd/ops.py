@@ -481,7 +481,7 @@ class _RowNorm(torch.autograd.Function):
         N, C = x.shape
         dx = torch.empty_like(x)
         dg, db = torch.empty_like(gamma), torch.empty_like(beta)
-        wsb = lib.dgdm_rownorm_bwd_workspace_bytes(N, C, groups)
+        wsb = _lib.workspace_bytes("dgdm_rownorm_bwd_workspace_bytes", N, C, groups)
         ws = torch.empty(max(wsb, 4) // 4, dtype=torch.float32, device=x.device)
         _lib.check(lib.dgdm_rownorm_bwd(x.data_ptr(), _lib.ptr(res), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(),
                                         rstd.data_ptr(), gy.data_ptr(), N, C, groups, act, drop_p, seed, dx.data_ptr(),
@@ -538,7 +538,7 @@ def segment_sum_raw(x, plan: AttnPlan) -> torch.Tensor:
     _lib.require_cuda(x)
     C = x.size(1)
     out = torch.empty(plan.B, C, dtype=torch.float32, device=x.device)
-    wsb = lib.dgdm_segment_sum_workspace_bytes(plan.B, C)
+    wsb = _lib.workspace_bytes("dgdm_segment_sum_workspace_bytes", plan.B, C)
     ws = torch.empty(max(wsb, 4) // 4, dtype=torch.float32, device=x.device)
     _lib.check(lib.dgdm_segment_sum(x.data_ptr(), plan.ptr_dev.data_ptr(), plan.B, C, out.data_ptr(), ws.data_ptr(), wsb,
                                     _lib.stream_ptr(x.device)), "dgdm_segment_sum")
@@ -582,7 +582,7 @@ class _AttnPool(torch.autograd.Function):
         P = torch.empty(N, H, dtype=torch.float32, device=kv.device)
         out = torch.empty(plan.B, C, dtype=torch.float32, device=kv.device)
         max_rows = max((plan.ptr_host[g + 1] - plan.ptr_host[g] for g in range(plan.B)), default=0)
-        wsb = lib.dgdm_attn_pool_fwd_workspace_bytes(plan.B, H, D, max_rows)
+        wsb = _lib.workspace_bytes("dgdm_attn_pool_fwd_workspace_bytes", plan.B, H, D, max_rows)
         ws = torch.empty(max(wsb, 4) // 4, dtype=torch.float32, device=kv.device)
         _lib.check(lib.dgdm_attn_pool_fwd(kv.data_ptr(), kv[:, C:].data_ptr(), kv.stride(0), q_scaled.data_ptr(),
                                           plan.ptr_dev.data_ptr(), plan.B, H, D, max_rows, drop_p, seed, P.data_ptr(), out.data_ptr(),
@@ -684,7 +684,7 @@ def gemm_tn_raw(dy, x, with_bias: bool, math="fp32", split: Optional[int] = None
     M, N = dy.shape
     K = x.size(1)
     db = torch.empty(N, dtype=torch.float32, device=x.device) if with_bias else None
-    wsb = (lib.dgdm_gemm_tn_workspace_bytes if math == "fp32" else lib.dgdm_gemm_tn_bf16x3_workspace_bytes)(M, N, K, int(with_bias))
+    wsb = _lib.workspace_bytes("dgdm_gemm_tn_workspace_bytes" if math == "fp32" else "dgdm_gemm_tn_bf16x3_workspace_bytes", M, N, K, int(with_bias))
     ws = torch.empty(max(wsb, 4) // 4, dtype=torch.float32, device=x.device)
     if split is None:
         dW = torch.empty(N, K, dtype=torch.float32, device=x.device)
@@ -839,7 +839,7 @@ class _PoolScore(torch.autograd.Function):
         dh = torch.empty_like(h)
         dw2 = torch.empty(C2, dtype=torch.float32, device=h.device)
         db2 = torch.empty(1, dtype=torch.float32, device=h.device)
-        wsb = lib.dgdm_pool_score_bwd_workspace_bytes(N, C2)
+        wsb = _lib.workspace_bytes("dgdm_pool_score_bwd_workspace_bytes", N, C2)
         ws = torch.empty(max(wsb, 4) // 4, dtype=torch.float32, device=h.device)
         _lib.check(lib.dgdm_pool_score_bwd(h.data_ptr(), h.stride(0), w2c.data_ptr(), s.data_ptr(), ds.data_ptr(), N, C2, dh.data_ptr(),
                                            dh.stride(0), dw2.data_ptr(), db2.data_ptr(), ws.data_ptr(), wsb, _lib.stream_ptr(h.device)),
@@ -859,7 +859,7 @@ def topk_perm(s: torch.Tensor, k: int):
     N = s.numel()
     perm = torch.empty(k, dtype=torch.int64, device=s.device)
     node_map = torch.empty(N, dtype=torch.int32, device=s.device)
-    wsb = lib.dgdm_topk_perm_workspace_bytes(N)
+    wsb = _lib.workspace_bytes("dgdm_topk_perm_workspace_bytes", N)
     ws = torch.empty(max(wsb, 4), dtype=torch.uint8, device=s.device)
     _lib.check(lib.dgdm_topk_perm(s.data_ptr(), N, k, perm.data_ptr(), node_map.data_ptr(), ws.data_ptr(), wsb, _lib.stream_ptr(s.device)),
                "dgdm_topk_perm")
