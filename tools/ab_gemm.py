@@ -33,3 +33,10 @@ for (m, k, n) in [(40000, 768, 512), (40000, 544, 512), (40000, 288, 256), (4000
             ta += timeit(fa); tb += timeit(fb)
         res[kind] = (ta / 5, tb / 5)
     print(f"{m}x{k}->{n}: " + "  ".join(f"{kd} A {a:7.1f} us  B {b_:7.1f} us ({(b_ / a - 1) * 100:+.1f}%)" for kd, (a, b_) in res.items()), flush=True)
+# accuracy of both builds against float64 on one shape
+m, k, n = 4000, 544, 512
+x = torch.randn(m, k, device="cuda"); w = torch.randn(n, k, device="cuda") / k ** 0.5; y = torch.empty(m, n, device="cuda")
+ref = x.double() @ w.double().t()
+for name, l in zip("AB", libs):
+    l.dgdm_gemm_nt_bf16x3(x.data_ptr(), k, w.data_ptr(), k, None, y.data_ptr(), n, m, n, k, 0, st); torch.cuda.synchronize()
+    print(name, "NT max abs err vs fp64: %.3e  (max |ref| %.2f)" % (float((y.double() - ref).abs().max()), float(ref.abs().max())))
