@@ -6,6 +6,7 @@ There is no CPU fallback: every op in this package goes through this library and
 from __future__ import annotations
 
 import ctypes as C
+import functools
 import os
 from typing import Optional
 
@@ -42,8 +43,8 @@ SIGNATURES = {
     "dgdm_rownorm_fwd": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, C.c_float, _i32, C.c_float, C.c_uint32, _p, _p, _p, _p]),
     "dgdm_rownorm_bwd_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "dgdm_rownorm_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, C.c_float, C.c_uint32, _p, _p, _p, _p, _sz, _p]),
-    "dgdm_act_dropout_fwd": (C.c_int, [_p, _i64, _i32, C.c_float, C.c_uint32, _p, _p]),
-    "dgdm_act_dropout_bwd": (C.c_int, [_p, _p, _i64, _i32, C.c_float, C.c_uint32, _p, _p]),
+    "dgdm_act_dropout_fwd": (C.c_int, [_p, _i64, _i32, C.c_float, C.c_uint32, _p, _p, _p]),
+    "dgdm_act_dropout_bwd": (C.c_int, [_p, _p, _i64, _i32, C.c_float, C.c_uint32, _p, _p, _p]),
     "dgdm_spatial_attn_bwd_dq": (C.c_int, [_p, _p, _p, _i64, _p, _p, _i64, _p, _p, _i32, _i32, _i32, _i32, C.c_float, C.c_float,
                                            _p, C.c_float, C.c_uint32, _p, _i64, _p, _p]),
     "dgdm_spatial_attn_bwd_dkv": (C.c_int, [_p, _p, _p, _i64, _p, _i64, _p, _p, _i32, _i32, _i32, _i32, C.c_float, C.c_float,
@@ -60,16 +61,16 @@ SIGNATURES = {
     "dgdm_gemm_tn": (C.c_int, [_p, _i64, _p, _i64, _p, _i64, _p, _i32, _i32, _i32, _p, _sz, _p]),
     "dgdm_seed_epoch_advance": (C.c_int, [_p]),
     "dgdm_seed_epoch_set": (C.c_int, [C.c_uint32, _p]),
-    "dgdm_pool_score_fwd": (C.c_int, [_p, _i64, _p, _p, _i32, _i32, _p, _p]),
+    "dgdm_pool_score_fwd": (C.c_int, [_p, _i64, _p, _p, _i32, _i32, _p, _p, _p]),
     "dgdm_pool_score_bwd_workspace_bytes": (_sz, [_i32, _i32]),
-    "dgdm_pool_score_bwd": (C.c_int, [_p, _i64, _p, _p, _p, _i32, _i32, _p, _i64, _p, _p, _p, _sz, _p]),
+    "dgdm_pool_score_bwd": (C.c_int, [_p, _i64, _p, _p, _p, _i32, _i32, _p, _i64, _p, _p, _p, _p, _sz, _p]),
     "dgdm_topk_perm_workspace_bytes": (_sz, [_i32]),
     "dgdm_topk_perm": (C.c_int, [_p, _i32, _i32, _p, _p, _p, _sz, _p]),
     "dgdm_pool_gather_fwd": (C.c_int, [_p, _i64, _p, _p, _i32, _i32, C.c_float, _p, _i64, _p]),
     "dgdm_pool_gather_bwd": (C.c_int, [_p, _i64, _p, _i64, _p, _p, _i32, _i32, C.c_float, _p, _i64, _p, _p]),
     "dgdm_edge_relabel": (C.c_int, [_p, _i64, _p, _i32, _p, _p]),
-    "dgdm_unpool_add_relu_fwd": (C.c_int, [_p, _i64, _p, _i64, _p, _i32, _i32, _p, _i64, _p]),
-    "dgdm_unpool_add_relu_bwd": (C.c_int, [_p, _i64, _p, _i64, _p, _i32, _i32, _p, _i64, _p, _i64, _p]),
+    "dgdm_unpool_add_relu_fwd": (C.c_int, [_p, _i64, _p, _i64, _p, _i32, _i32, _p, _i64, _p, _p]),
+    "dgdm_unpool_add_relu_bwd": (C.c_int, [_p, _i64, _p, _i64, _p, _i32, _i32, _p, _i64, _p, _i64, _p, _p]),
     "dgdm_knn2d": (C.c_int, [_p, _i32, _i32, _p, _p, _p]),
     "dgdm_row_sqnorm": (C.c_int, [_p, _i64, _i32, _i32, _p, _p]),
     "dgdm_knn_gram_workspace_bytes": (_sz, [_i32, _i32]),
@@ -139,17 +140,15 @@ def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
-_WS_BYTES: dict = {}
+@functools.lru_cache(maxsize=4096)
+def _workspace_bytes(name: str, args: tuple) -> int:
+    return getattr(load(), name)(*args)
 
 
 def workspace_bytes(name: str, *args) -> int:
-    """``lib.<name>(*args)`` for the ``*_workspace_bytes`` entry points, memoised: they are pure functions of the shape, and a
-    training step asks the same ~100 questions every time."""
-    key = (name, args)
-    v = _WS_BYTES.get(key)
-    if v is None:
-        v = _WS_BYTES[key] = getattr(load(), name)(*args)
-    return v
+    """``lib.<name>(*args)`` for the ``*_workspace_bytes`` entry points, memoised (bounded LRU: a mixed-size stream asks about new
+    shapes at every step): they are pure functions of the shape, and a training step asks the same ~100 questions every time."""
+    return _workspace_bytes(name, args)
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)

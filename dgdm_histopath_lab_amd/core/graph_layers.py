@@ -143,16 +143,33 @@ class AdaptiveGraphPooling(nn.Module):
         self._nl = nonlinearity
 
     def forward(self, x: Tensor, edge_index: Tensor, edge_attr: Optional[Tensor] = None, batch: Optional[Tensor] = None,
-                compact: bool = False, return_node_map: bool = False):
+                compact: bool = False, return_node_map: bool = False, *, relu_decisions: Optional[Tensor] = None,
+                perm_decision: Optional[Tensor] = None, trace: Optional[dict] = None, trace_tag: str = ""):
+        """``relu_decisions`` / ``perm_decision`` (parity tests only): the side of the score MLP's ReLU kink per element and the
+        kept node ids, taken from the reference run instead of being decided here (see ``GraphUNet.forward``).  ``trace``
+        receives this level's own pre-activation and scores so that the test can hold every decision that differs to the
+        rounding margin."""
         n = x.size(0)
         k = max(1, int(self.ratio * n))
         h = ops.lin(self.score_net[0], x)
         w2, b2 = self.score_net[2].weight, self.score_net[2].bias
         fused = (x.is_cuda and self._nl == "tanh" and x.dtype == torch.float32 and ops.pool_supported(x.size(1), h.size(1))
                  and n < 2 ** 31)
+        if (relu_decisions is not None or perm_decision is not None) and not fused:
+            raise NotImplementedError("decision injection is wired into the K9 kernels only")
         if fused:   # K9 kernels: no host sync, no data-dependent shapes
-            s = ops.pool_score(h, w2, b2)
+            s = ops.pool_score(h, w2, b2, decide=relu_decisions)
+            if trace is not None:
+                trace[f"pre.pool{trace_tag}"], trace[f"score{trace_tag}"] = h.detach(), s.detach()
             perm, node_map = ops.topk_perm(s, k)
+            if trace is not None:
+                trace[f"own_perm{trace_tag}"] = perm
+            if perm_decision is not None:
+                perm = perm_decision.to(device=x.device, dtype=torch.int64)
+                if perm.numel() != k:
+                    raise ValueError(f"injected perm has {perm.numel()} entries, this level keeps {k}")
+                node_map = torch.full((n,), -1, dtype=torch.int32, device=x.device)
+                node_map[perm] = torch.arange(k, dtype=torch.int32, device=x.device)
             pooled_x = ops.pool_gather(x, s, perm, node_map, self.multiplier)
             mapped_keep = ops.edge_relabel(edge_index, node_map)     # dropped edges (now or earlier) are (-1, -1)
             if compact:  # reference layout (graph_layers.py:322-327); boolean indexing syncs
@@ -199,8 +216,23 @@ class GraphUNet(nn.Module):
         self.up_convs = nn.ModuleList([mk(hidden_channels) for _ in range(depth)])
         self.final_conv = nn.Linear(hidden_channels, out_channels)
 
+    def _relu(self, x: Tensor, decide: Optional[Tensor] = None) -> Tensor:
+        if self.act is F.relu and x.is_cuda and x.dtype == torch.float32 and x.numel() % 4 == 0:
+            return ops.act_dropout(x, ops.ACT_RELU, decide=decide)
+        if decide is not None:
+            raise NotImplementedError("decision injection is wired into the ReLU kernels only")
+        return self.act(x)
+
     def forward(self, x: Tensor, edge_index: Union[Tensor, GraphContext], edge_attr: Optional[Tensor] = None,
-                batch: Optional[Tensor] = None, trace: Optional[dict] = None) -> Tensor:
+                batch: Optional[Tensor] = None, trace: Optional[dict] = None, decisions: Optional[dict] = None) -> Tensor:
+        """``decisions`` (parity tests only; ``None`` on every product call): the discrete choices of a reference run of the same
+        input -- ``relu.down{i}`` / ``relu.pool{i}`` / ``relu.bottom`` / ``relu.up{i}`` (bool, shape of the activation: which
+        elements pass the ReLU) and ``perm{i}`` (kept node ids of pooling level i).  The kernels then take the side of every kink
+        from them, forward and backward, so that this network and the reference differentiate the same piecewise-linear function;
+        a pre-activation within rounding of zero (2 of 512 000 at 2 x 2 000 nodes) would otherwise make the gradients
+        incomparable.  ``trace`` additionally receives the pre-activations (``pre.*``), this run's own scores and top-k choice, so
+        that the caller can check that every decision that differs from the injected one lies within the rounding margin."""
+        dec = decisions or {}
         ctx0 = _context(edge_index, x, edge_attr)
         eis, eas = [ctx0.edge_index], [ctx0.edge_attr]
         ctxs = {(0, x.size(0)): ctx0}
@@ -213,17 +245,23 @@ class GraphUNet(nn.Module):
         x = self.down_convs[0](x, ctx0)
         xs, perms, nmaps = [x], [], []
         for i in range(self.depth):
-            xr = self.act(x)
+            if trace is not None:
+                trace[f"pre.down{i}"] = x.detach()
+            xr = self._relu(x, dec.get(f"relu.down{i}"))
             x = self.down_convs[i + 1](xr, level(i, x.size(0)))
             xs.append(x)
             if trace is not None:
                 trace[f"relu.down{i}"] = xr
-                trace[f"relu.pool{i}"] = F.relu(self.pools[i].score_net[0](x))
-            x, ei, ea, perm, nmap = self.pools[i](x, eis[-1], eas[-1], batch, return_node_map=True)
+            x, ei, ea, perm, nmap = self.pools[i](x, eis[-1], eas[-1], batch, return_node_map=True,
+                                                  relu_decisions=dec.get(f"relu.pool{i}"), perm_decision=dec.get(f"perm{i}"),
+                                                  trace=trace, trace_tag=str(i))
             eis.append(ei); eas.append(ea); perms.append(perm); nmaps.append(nmap)
             if trace is not None:
+                trace[f"relu.pool{i}"] = F.relu(trace[f"pre.pool{i}"])
                 trace[f"perm{i}"] = perm
-        xr = self.act(x)
+        if trace is not None:
+            trace["pre.bottom"] = x.detach()
+        xr = self._relu(x, dec.get("relu.bottom"))
         if trace is not None:
             trace["relu.bottom"] = xr
         x = self.bottom_conv(xr, level(self.depth, x.size(0)))
@@ -233,8 +271,12 @@ class GraphUNet(nn.Module):
                 trace[f"unet.xs{k}"] = t
         for i in range(self.depth):
             j = self.depth - 1 - i
+            if trace is not None:   # the fused kernel below never materialises its pre-activation: rebuilt here for the margin check
+                trace[f"pre.up{i}"] = (torch.zeros_like(xs[j + 1]).index_copy(0, perms[j], x.detach()) + xs[j + 1].detach())
             if self.act is F.relu and x.is_cuda and x.dtype == torch.float32 and x.size(1) % 4 == 0:
-                x = ops.unpool_add_relu(x, xs[j + 1], nmaps[j])       # K9: gather by node_map, no zero fill
+                x = ops.unpool_add_relu(x, xs[j + 1], nmaps[j], decide=dec.get(f"relu.up{i}"))  # K9: gather by node_map, no zero fill
+            elif dec.get(f"relu.up{i}") is not None:
+                raise NotImplementedError("decision injection is wired into the K9 kernels only")
             else:
                 up = torch.zeros(xs[j + 1].size(0), x.size(1), device=x.device, dtype=x.dtype).index_copy(0, perms[j], x)
                 x = self.act(up + xs[j + 1])

@@ -1,6 +1,9 @@
 // Fused activation + dropout for the convolution outputs of DynamicGraphLayer
 // (core/graph_layers.py:233-239: h = dropout(GELU(conv(x)))) and the U-Net's ReLU sites.
 //   fwd: y  = dropout(act(x))            bwd: dx = dy * mask * act'(x)
+// `decide` (ReLU only, nullable, one byte per element): the side of the kink every element takes is read from it instead
+// of from the sign of x -- the parity tests hand the reference's decisions to the kernels so that both sides differentiate the
+// same piecewise-linear function (an element within rounding of zero may otherwise fall on either side).
 // Pure HBM streaming: 16 B per lane, grid-stride; the dropout mask is recomputed from
 // (seed, element index) in the backward instead of being stored.
 #include "common.hpp"
@@ -10,7 +13,8 @@ namespace {
 
 template <int ACT, bool BWD>
 __global__ __launch_bounds__(256) void k_act_dropout(const float* __restrict__ x, const float* __restrict__ dy, int64_t n4,
-                                                     float drop_p, DgdmSeed seed_in, float* __restrict__ out) {
+                                                     float drop_p, DgdmSeed seed_in, float* __restrict__ out,
+                                                     const uint8_t* __restrict__ decide) {
   const uint32_t seed = seed_in.value();
   const uint32_t thresh = (uint32_t)(drop_p * 65536.0f);
   const float keep_scale = drop_p > 0.f ? 1.0f / (1.0f - (float)thresh / 65536.0f) : 1.0f;
@@ -24,6 +28,11 @@ __global__ __launch_bounds__(256) void k_act_dropout(const float* __restrict__ x
     } else {
       o = make_float4(act_f<ACT>(v.x), act_f<ACT>(v.y), act_f<ACT>(v.z), act_f<ACT>(v.w));
     }
+    if (ACT == DGDM_ACT_RELU && decide) {
+      const uchar4 d = reinterpret_cast<const uchar4*>(decide)[i];
+      const float4 s = BWD ? reinterpret_cast<const float4*>(dy)[i] : v;
+      o = make_float4(d.x ? s.x : 0.f, d.y ? s.y : 0.f, d.z ? s.z : 0.f, d.w ? s.w : 0.f);
+    }
     if (drop_p > 0.f) {
       const float4 m = dropout_scale4(seed, (uint64_t)i * 4, thresh, keep_scale);
       o.x *= m.x; o.y *= m.y; o.z *= m.z; o.w *= m.w;
@@ -33,15 +42,17 @@ __global__ __launch_bounds__(256) void k_act_dropout(const float* __restrict__ x
 }
 
 template <bool BWD>
-int launch(const float* x, const float* dy, int64_t n, int32_t act, float drop_p, uint32_t seed, float* out, hipStream_t s) {
+int launch(const float* x, const float* dy, int64_t n, int32_t act, float drop_p, uint32_t seed, float* out, const uint8_t* decide,
+           hipStream_t s) {
   if (n < 0 || act < 0 || act > 3 || !(drop_p >= 0.f && drop_p < 1.f)) return DGDM_ERR_INVALID_ARG;
+  if (decide && act != DGDM_ACT_RELU) return DGDM_ERR_INVALID_ARG;
   if (n == 0) return DGDM_OK;
   if (!x || !out || (BWD && !dy)) return DGDM_ERR_INVALID_ARG;
   if ((n & 3) || !dgdm_aligned16(x) || !dgdm_aligned16(out) || (BWD && !dgdm_aligned16(dy))) return DGDM_ERR_UNSUPPORTED;
   const int64_t n4 = n >> 2;
   int64_t blocks = (n4 + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-#define GO(A) hipLaunchKernelGGL((k_act_dropout<A, BWD>), dim3((unsigned)blocks), dim3(256), 0, s, x, dy, n4, drop_p, dgdm_seed_arg(seed), out)
+#define GO(A) hipLaunchKernelGGL((k_act_dropout<A, BWD>), dim3((unsigned)blocks), dim3(256), 0, s, x, dy, n4, drop_p, dgdm_seed_arg(seed), out, decide)
   switch (act) {
     case DGDM_ACT_GELU: GO(DGDM_ACT_GELU); break;
     case DGDM_ACT_RELU: GO(DGDM_ACT_RELU); break;
@@ -54,11 +65,12 @@ int launch(const float* x, const float* dy, int64_t n, int32_t act, float drop_p
 
 }  // namespace
 
-extern "C" int dgdm_act_dropout_fwd(const float* x, int64_t n, int32_t act, float drop_p, uint32_t seed, float* y, void* stream) {
-  return launch<false>(x, nullptr, n, act, drop_p, seed, y, static_cast<hipStream_t>(stream));
+extern "C" int dgdm_act_dropout_fwd(const float* x, int64_t n, int32_t act, float drop_p, uint32_t seed, float* y, const uint8_t* decide,
+                                    void* stream) {
+  return launch<false>(x, nullptr, n, act, drop_p, seed, y, decide, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int dgdm_act_dropout_bwd(const float* x, const float* dy, int64_t n, int32_t act, float drop_p, uint32_t seed,
-                                    float* dx, void* stream) {
-  return launch<true>(x, dy, n, act, drop_p, seed, dx, static_cast<hipStream_t>(stream));
+                                    float* dx, const uint8_t* decide, void* stream) {
+  return launch<true>(x, dy, n, act, drop_p, seed, dx, decide, static_cast<hipStream_t>(stream));
 }

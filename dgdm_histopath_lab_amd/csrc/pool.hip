@@ -23,14 +23,20 @@ namespace {
 // ------------------------------------------------------------------ score
 // 16 lanes per row, float4 per lane per 64-column chunk; 16 rows per 256-thread block.
 __global__ __launch_bounds__(256) void k_pool_score_fwd(const float* __restrict__ h, int64_t ldh, const float* __restrict__ w2,
-                                                        const float* __restrict__ b2, int N, int C, float* __restrict__ s) {
+                                                        const float* __restrict__ b2, int N, int C, float* __restrict__ s,
+                                                        const uint8_t* __restrict__ decide) {
   const int sub = threadIdx.x & 15, row = blockIdx.x * 16 + (threadIdx.x >> 4);
   float acc = 0.f;
   if (row < N)
     for (int c = 4 * sub; c < C; c += 64) {
       const float4 v = *reinterpret_cast<const float4*>(h + (int64_t)row * ldh + c);
       const float4 w = *reinterpret_cast<const float4*>(w2 + c);
-      acc += fmaxf(v.x, 0.f) * w.x + fmaxf(v.y, 0.f) * w.y + fmaxf(v.z, 0.f) * w.z + fmaxf(v.w, 0.f) * w.w;
+      if (decide) {   // kink decisions supplied by the caller (parity tests), see dgdm_hip.h
+        const uchar4 d = *reinterpret_cast<const uchar4*>(decide + (int64_t)row * C + c);
+        acc += (d.x ? v.x : 0.f) * w.x + (d.y ? v.y : 0.f) * w.y + (d.z ? v.z : 0.f) * w.z + (d.w ? v.w : 0.f) * w.w;
+      } else {
+        acc += fmaxf(v.x, 0.f) * w.x + fmaxf(v.y, 0.f) * w.y + fmaxf(v.z, 0.f) * w.z + fmaxf(v.w, 0.f) * w.w;
+      }
     }
 #pragma unroll
   for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
@@ -41,7 +47,7 @@ __global__ __launch_bounds__(256) void k_pool_score_fwd(const float* __restrict_
 __global__ __launch_bounds__(256) void k_pool_score_bwd(const float* __restrict__ h, int64_t ldh, const float* __restrict__ w2,
                                                         const float* __restrict__ s, const float* __restrict__ ds, int N, int C,
                                                         int rows_per_block, float* __restrict__ dh, int64_t lddh,
-                                                        float* __restrict__ partial) {
+                                                        float* __restrict__ partial, const uint8_t* __restrict__ decide) {
   // thread = (float4 column c4, row lane): C/4 <= 64 columns x (256 / cols) row lanes
   const int cols = C / 4;
   const int c4 = threadIdx.x % cols, rl = threadIdx.x / cols, nrl = 256 / cols;
@@ -54,11 +60,16 @@ __global__ __launch_bounds__(256) void k_pool_score_bwd(const float* __restrict_
       const float sv = s[r];
       const float t = ds[r] * (1.f - sv * sv);
       const float4 v = *reinterpret_cast<const float4*>(h + (int64_t)r * ldh + 4 * c4);
+      bool px = v.x > 0.f, py = v.y > 0.f, pz = v.z > 0.f, pw = v.w > 0.f;
+      if (decide) {
+        const uchar4 d = *reinterpret_cast<const uchar4*>(decide + (int64_t)r * C + 4 * c4);
+        px = d.x; py = d.y; pz = d.z; pw = d.w;
+      }
       float4 g;
-      g.x = v.x > 0.f ? t * w.x : 0.f; g.y = v.y > 0.f ? t * w.y : 0.f;
-      g.z = v.z > 0.f ? t * w.z : 0.f; g.w = v.w > 0.f ? t * w.w : 0.f;
+      g.x = px ? t * w.x : 0.f; g.y = py ? t * w.y : 0.f;
+      g.z = pz ? t * w.z : 0.f; g.w = pw ? t * w.w : 0.f;
       *reinterpret_cast<float4*>(dh + (int64_t)r * lddh + 4 * c4) = g;
-      acc.x += t * fmaxf(v.x, 0.f); acc.y += t * fmaxf(v.y, 0.f); acc.z += t * fmaxf(v.z, 0.f); acc.w += t * fmaxf(v.w, 0.f);
+      acc.x += px ? t * v.x : 0.f; acc.y += py ? t * v.y : 0.f; acc.z += pz ? t * v.z : 0.f; acc.w += pw ? t * v.w : 0.f;
       if (c4 == 0) tsum += t;
     }
   }
@@ -332,7 +343,7 @@ __global__ __launch_bounds__(256) void k_edge_relabel(const int64_t* __restrict_
 // ------------------------------------------------------------------ unpool + skip + relu
 __global__ __launch_bounds__(256) void k_unpool_add_relu_fwd(const float* __restrict__ xc, int64_t ldxc, const float* __restrict__ skip,
                                                              int64_t lds, const int32_t* __restrict__ node_map, int N, int C,
-                                                             float* __restrict__ out, int64_t ldo) {
+                                                             float* __restrict__ out, int64_t ldo, const uint8_t* __restrict__ decide) {
   const int sub = threadIdx.x & 15, i = blockIdx.x * 16 + (threadIdx.x >> 4);
   if (i >= N) return;
   const int nm = node_map[i];
@@ -342,7 +353,12 @@ __global__ __launch_bounds__(256) void k_unpool_add_relu_fwd(const float* __rest
       const float4 u = *reinterpret_cast<const float4*>(xc + (int64_t)nm * ldxc + c);
       v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
     }
-    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    if (decide) {
+      const uchar4 d = *reinterpret_cast<const uchar4*>(decide + (int64_t)i * C + c);
+      v.x = d.x ? v.x : 0.f; v.y = d.y ? v.y : 0.f; v.z = d.z ? v.z : 0.f; v.w = d.w ? v.w : 0.f;
+    } else {
+      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    }
     *reinterpret_cast<float4*>(out + (int64_t)i * ldo + c) = v;
   }
 }
@@ -351,15 +367,20 @@ __global__ __launch_bounds__(256) void k_unpool_add_relu_fwd(const float* __rest
 __global__ __launch_bounds__(256) void k_unpool_add_relu_bwd(const float* __restrict__ g, int64_t ldg, const float* __restrict__ out,
                                                              int64_t ldo, const int32_t* __restrict__ node_map, int N, int C,
                                                              float* __restrict__ dskip, int64_t ldds, float* __restrict__ dxc,
-                                                             int64_t lddxc) {
+                                                             int64_t lddxc, const uint8_t* __restrict__ decide) {
   const int sub = threadIdx.x & 15, i = blockIdx.x * 16 + (threadIdx.x >> 4);
   if (i >= N) return;
   const int nm = node_map[i];
   for (int c = 4 * sub; c < C; c += 64) {
     const float4 gv = *reinterpret_cast<const float4*>(g + (int64_t)i * ldg + c);
     const float4 ov = *reinterpret_cast<const float4*>(out + (int64_t)i * ldo + c);
+    bool px = ov.x > 0.f, py = ov.y > 0.f, pz = ov.z > 0.f, pw = ov.w > 0.f;
+    if (decide) {
+      const uchar4 m = *reinterpret_cast<const uchar4*>(decide + (int64_t)i * C + c);
+      px = m.x; py = m.y; pz = m.z; pw = m.w;
+    }
     float4 d;
-    d.x = ov.x > 0.f ? gv.x : 0.f; d.y = ov.y > 0.f ? gv.y : 0.f; d.z = ov.z > 0.f ? gv.z : 0.f; d.w = ov.w > 0.f ? gv.w : 0.f;
+    d.x = px ? gv.x : 0.f; d.y = py ? gv.y : 0.f; d.z = pz ? gv.z : 0.f; d.w = pw ? gv.w : 0.f;
     *reinterpret_cast<float4*>(dskip + (int64_t)i * ldds + c) = d;
     if (nm >= 0) *reinterpret_cast<float4*>(dxc + (int64_t)nm * lddxc + c) = d;
   }
@@ -370,12 +391,13 @@ inline bool rows_ok(const float* p, int64_t ld, int C) { return p && (ld & 3) ==
 }  // namespace
 
 extern "C" int dgdm_pool_score_fwd(const float* h, int64_t ldh, const float* w2, const float* b2, int32_t N, int32_t C, float* s,
-                                   void* stream) {
+                                   const uint8_t* decide, void* stream) {
   if (N < 0 || C <= 0) return DGDM_ERR_INVALID_ARG;
   if (N == 0) return DGDM_OK;
   if (!h || !w2 || !b2 || !s) return DGDM_ERR_INVALID_ARG;
   if ((C & 3) || !rows_ok(h, ldh, C) || !dgdm_aligned16(w2)) return DGDM_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(k_pool_score_fwd, dim3((N + 15) / 16), dim3(256), 0, static_cast<hipStream_t>(stream), h, ldh, w2, b2, N, C, s);
+  hipLaunchKernelGGL(k_pool_score_fwd, dim3((N + 15) / 16), dim3(256), 0, static_cast<hipStream_t>(stream), h, ldh, w2, b2, N, C, s,
+                     decide);
   return dgdm_launch_status();
 }
 
@@ -385,8 +407,8 @@ extern "C" size_t dgdm_pool_score_bwd_workspace_bytes(int32_t N, int32_t C) {
 }
 
 extern "C" int dgdm_pool_score_bwd(const float* h, int64_t ldh, const float* w2, const float* s, const float* ds, int32_t N, int32_t C,
-                                   float* dh, int64_t lddh, float* dw2, float* db2, void* workspace, size_t workspace_bytes,
-                                   void* stream_) {
+                                   float* dh, int64_t lddh, float* dw2, float* db2, const uint8_t* decide, void* workspace,
+                                   size_t workspace_bytes, void* stream_) {
   if (N < 0 || C <= 0) return DGDM_ERR_INVALID_ARG;
   if (!dw2 || !db2) return DGDM_ERR_INVALID_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream_);
@@ -401,7 +423,7 @@ extern "C" int dgdm_pool_score_bwd(const float* h, int64_t ldh, const float* w2,
   const int rpb = (N + SCORE_BWD_BLOCKS - 1) / SCORE_BWD_BLOCKS;
   const int nb = (N + rpb - 1) / rpb;
   float* partial = static_cast<float*>(workspace);
-  hipLaunchKernelGGL(k_pool_score_bwd, dim3(nb), dim3(256), 0, st, h, ldh, w2, s, ds, N, C, rpb, dh, lddh, partial);
+  hipLaunchKernelGGL(k_pool_score_bwd, dim3(nb), dim3(256), 0, st, h, ldh, w2, s, ds, N, C, rpb, dh, lddh, partial, decide);
   colsum_final_launch(partial, nb, C + 1, dw2, C, db2, st);
   return dgdm_launch_status();
 }
@@ -470,23 +492,24 @@ extern "C" int dgdm_edge_relabel(const int64_t* edge_index, int64_t E, const int
 }
 
 extern "C" int dgdm_unpool_add_relu_fwd(const float* xc, int64_t ldxc, const float* skip, int64_t lds, const int32_t* node_map, int32_t N,
-                                        int32_t C, float* out, int64_t ldo, void* stream) {
+                                        int32_t C, float* out, int64_t ldo, const uint8_t* decide, void* stream) {
   if (N < 0 || C <= 0) return DGDM_ERR_INVALID_ARG;
   if (N == 0) return DGDM_OK;
   if (!xc || !skip || !node_map || !out) return DGDM_ERR_INVALID_ARG;
   if ((C & 3) || !rows_ok(xc, ldxc, C) || !rows_ok(skip, lds, C) || !rows_ok(out, ldo, C)) return DGDM_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(k_unpool_add_relu_fwd, dim3((N + 15) / 16), dim3(256), 0, static_cast<hipStream_t>(stream), xc, ldxc, skip, lds,
-                     node_map, N, C, out, ldo);
+                     node_map, N, C, out, ldo, decide);
   return dgdm_launch_status();
 }
 
 extern "C" int dgdm_unpool_add_relu_bwd(const float* g, int64_t ldg, const float* out, int64_t ldo, const int32_t* node_map, int32_t N,
-                                        int32_t C, float* dskip, int64_t ldds, float* dxc, int64_t lddxc, void* stream) {
+                                        int32_t C, float* dskip, int64_t ldds, float* dxc, int64_t lddxc, const uint8_t* decide,
+                                        void* stream) {
   if (N < 0 || C <= 0) return DGDM_ERR_INVALID_ARG;
   if (N == 0) return DGDM_OK;
   if (!g || !out || !node_map || !dskip || !dxc) return DGDM_ERR_INVALID_ARG;
   if ((C & 3) || !rows_ok(g, ldg, C) || !rows_ok(out, ldo, C) || !rows_ok(dskip, ldds, C) || !rows_ok(dxc, lddxc, C)) return DGDM_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(k_unpool_add_relu_bwd, dim3((N + 15) / 16), dim3(256), 0, static_cast<hipStream_t>(stream), g, ldg, out, ldo, node_map,
-                     N, C, dskip, ldds, dxc, lddxc);
+                     N, C, dskip, ldds, dxc, lddxc, decide);
   return dgdm_launch_status();
 }

@@ -13,8 +13,9 @@ loops over graphs of the reference (spatial attention dgdm_model.py:346-357, dif
 forward (input validation) instead of >= 3*B.
 
 Build-only keyword arguments (absent => reference behaviour): ``strict_reference`` (D8/D10),
-and the random-draw injection hooks ``timesteps`` / ``noise`` / ``noise_target`` /
-``mask_indices`` / ``mask_token`` used by the parity tests.
+the random-draw injection hooks ``timesteps`` / ``noise`` / ``noise_target`` /
+``mask_indices`` / ``mask_token`` used by the parity tests, and ``decisions`` (the reference run's
+ReLU-kink / top-k choices for the graph U-Net, see ``GraphUNet.forward``).
 """
 from __future__ import annotations
 
@@ -233,7 +234,7 @@ class DGDMModel(nn.Module):
     # ------------------------------------------------------------------ forward
     def forward(self, data, mode: str = "inference", return_attention: bool = False, return_embeddings: bool = False, *,
                 timesteps: Optional[Tensor] = None, noise: Optional[Tensor] = None, noise_target: Optional[Tensor] = None,
-                trace: Optional[dict] = None) -> Dict[str, Any]:
+                trace: Optional[dict] = None, decisions: Optional[dict] = None) -> Dict[str, Any]:
         if self.validate_inputs:   # callers that validated the batch themselves (e.g. before replaying a recorded step) may switch it off
             try:
                 self._validate_forward_inputs(data, mode, return_attention, return_embeddings)
@@ -254,12 +255,12 @@ class DGDMModel(nn.Module):
             raise ModelInferenceError(f"Graph encoding failed: {e}")
         try:
             return self._forward_continue(h, data, plan, mode, return_attention, return_embeddings, timesteps, noise,
-                                          noise_target, trace)
+                                          noise_target, trace, decisions)
         except Exception as e:
             raise ModelInferenceError(f"Forward pass failed: {e}")
 
     def _forward_continue(self, h, data, plan: BatchPlan, mode, return_attention, return_embeddings, timesteps, noise,
-                          noise_target, trace):
+                          noise_target, trace, decisions=None):
         outputs: Dict[str, Any] = {}
         attention_weights = None
         pos = getattr(data, "pos", None)
@@ -270,7 +271,7 @@ class DGDMModel(nn.Module):
             if trace is not None:
                 trace["spatial_attention"] = h
         if self.hierarchical_processor is not None:
-            h = self.hierarchical_processor(h, plan.ctx, None, plan.seg, trace=trace)
+            h = self.hierarchical_processor(h, plan.ctx, None, plan.seg, trace=trace, decisions=decisions)
             if trace is not None:
                 trace["graph_unet"] = h
         if mode == "pretrain":

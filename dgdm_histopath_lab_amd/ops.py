@@ -5,6 +5,7 @@ ctypes; tensors only provide device memory.  No CPU path exists.
 """
 from __future__ import annotations
 
+import collections
 import os as _os
 from typing import Optional
 
@@ -139,20 +140,47 @@ def aggregate_edge_attr(edge_attr: Optional[torch.Tensor], gs: GraphStructure) -
 
 
 # ----------------------------------------------------------------------------- K4 attention
-_DEVICE_CONSTANTS: dict = {}
+_DEVICE_CONSTANTS: "collections.OrderedDict" = collections.OrderedDict()
+_DEVICE_CONSTANTS_MAX = 4096
+_CONSTANT_SINKS: list = []      # lists that collect every constant handed out while a step is being recorded
 
 
 def device_constant(values, dtype: torch.dtype, device) -> torch.Tensor:
     """Small host-known constant (graph offsets, per-graph sizes) as a device tensor, cached by value: the same
     batch layout comes back every step, and a cached tensor means no host-to-device copy inside the step -- which a
-    HIP graph capture of the step could not record."""
+    HIP graph capture of the step could not record.
+
+    The cache is an LRU (a mixed-size stream brings a new layout with every batch).  Eviction only drops the cache's own
+    reference: whoever bakes a constant's ADDRESS into something that outlives the call -- a recorded HIP graph -- holds its
+    own reference through ``collect_device_constants`` (training.GraphedPretrainStep does), so an evicted entry that a graph
+    still reads stays allocated."""
     key = (tuple(values), dtype, str(device))
     t = _DEVICE_CONSTANTS.get(key)
     if t is None:
-        if len(_DEVICE_CONSTANTS) > 4096:
-            _DEVICE_CONSTANTS.clear()
         t = _DEVICE_CONSTANTS[key] = torch.tensor(list(values), dtype=dtype).to(device)
+        while len(_DEVICE_CONSTANTS) > _DEVICE_CONSTANTS_MAX:
+            _DEVICE_CONSTANTS.popitem(last=False)
+    else:
+        _DEVICE_CONSTANTS.move_to_end(key)
+    for sink in _CONSTANT_SINKS:
+        sink.append(t)
     return t
+
+
+class collect_device_constants:
+    """Context manager: ``with collect_device_constants() as held:`` appends every constant ``device_constant`` returns inside
+    the block to ``held`` (a list the caller keeps for as long as it needs the addresses to stay valid)."""
+
+    def __init__(self):
+        self.held: list = []
+
+    def __enter__(self):
+        _CONSTANT_SINKS.append(self.held)
+        return self.held
+
+    def __exit__(self, *exc):
+        _CONSTANT_SINKS.remove(self.held)
+        return False
 
 
 class AttnPlan:
@@ -497,38 +525,49 @@ def row_norm(x, weight, bias, *, res=None, groups: int = 1, eps: float = 1e-5, a
     return _RowNorm.apply(x, res, weight, bias, groups, eps, act, p, next_dropout_seed() if p > 0 else 0)
 
 
+def _decide_arg(decide, like: torch.Tensor):
+    """Kink decisions for the ReLU kernels (include/dgdm_hip.h, `decide`): uint8 [N, C] contiguous on the device, or None."""
+    if decide is None:
+        return None
+    d = decide.to(device=like.device, dtype=torch.uint8).contiguous()
+    if d.numel() != like.numel():
+        raise ValueError(f"decisions have {d.numel()} elements, the activation {like.numel()}")
+    return d
+
+
 class _ActDropout(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, act: int, drop_p: float, seed: int):
+    def forward(ctx, x, act: int, drop_p: float, seed: int, decide=None):
         lib = _lib.load()
         x = _f32c(x)
         _lib.require_cuda(x)
         y = torch.empty_like(x)
-        _lib.check(lib.dgdm_act_dropout_fwd(x.data_ptr(), x.numel(), act, drop_p, seed, y.data_ptr(), _lib.stream_ptr(x.device)),
-                   "dgdm_act_dropout_fwd")
+        _lib.check(lib.dgdm_act_dropout_fwd(x.data_ptr(), x.numel(), act, drop_p, seed, y.data_ptr(), _lib.ptr(decide),
+                                            _lib.stream_ptr(x.device)), "dgdm_act_dropout_fwd")
         ctx.save_for_backward(x)
-        ctx.meta = (act, drop_p, seed)
+        ctx.meta = (act, drop_p, seed, decide)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         lib = _lib.load()
         (x,) = ctx.saved_tensors
-        act, drop_p, seed = ctx.meta
+        act, drop_p, seed, decide = ctx.meta
         gy = _f32c(gy)
         dx = torch.empty_like(x)
-        _lib.check(lib.dgdm_act_dropout_bwd(x.data_ptr(), gy.data_ptr(), x.numel(), act, drop_p, seed, dx.data_ptr(),
+        _lib.check(lib.dgdm_act_dropout_bwd(x.data_ptr(), gy.data_ptr(), x.numel(), act, drop_p, seed, dx.data_ptr(), _lib.ptr(decide),
                                             _lib.stream_ptr(x.device)), "dgdm_act_dropout_bwd")
-        return dx, None, None, None
+        return dx, None, None, None, None
 
 
-def act_dropout(x, act: int = ACT_NONE, drop_p: float = 0.0, training: bool = False):
+def act_dropout(x, act: int = ACT_NONE, drop_p: float = 0.0, training: bool = False, decide=None):
+    """dropout(act(x)).  ``decide`` (ReLU only): kink decisions handed in by a parity test instead of the sign of x."""
     p = float(drop_p) if training else 0.0
     if act == ACT_NONE and p == 0.0:
         return x
     if x.numel() % 4:
         raise _lib.DGDMKernelError("act_dropout needs numel % 4 == 0")
-    return _ActDropout.apply(x, act, p, next_dropout_seed() if p > 0 else 0)
+    return _ActDropout.apply(x, act, p, next_dropout_seed() if p > 0 else 0, _decide_arg(decide, x))
 
 
 # ----------------------------------------------------------------------------- segment ops / K10 pooling
@@ -818,16 +857,16 @@ class _PoolScore(torch.autograd.Function):
     """s = tanh(w2 . relu(h) + b2); h [N, C2] is the first score layer's output (a GEMM through `lin`)."""
 
     @staticmethod
-    def forward(ctx, h, w2, b2):
+    def forward(ctx, h, w2, b2, decide=None):
         lib = _lib.load()
         h = _rowmajor(h)
         w2c, b2c = _f32c(w2.reshape(-1)), _f32c(b2.reshape(-1))
         N, C2 = h.shape
         s = torch.empty(N, dtype=torch.float32, device=h.device)
         _lib.check(lib.dgdm_pool_score_fwd(h.data_ptr(), h.stride(0), w2c.data_ptr(), b2c.data_ptr(), N, C2, s.data_ptr(),
-                                           _lib.stream_ptr(h.device)), "dgdm_pool_score_fwd")
+                                           _lib.ptr(decide), _lib.stream_ptr(h.device)), "dgdm_pool_score_fwd")
         ctx.save_for_backward(h, w2c, s)
-        ctx.w2_shape, ctx.b2_shape = w2.shape, b2.shape
+        ctx.w2_shape, ctx.b2_shape, ctx.decide = w2.shape, b2.shape, decide
         return s
 
     @staticmethod
@@ -842,13 +881,13 @@ class _PoolScore(torch.autograd.Function):
         wsb = _lib.workspace_bytes("dgdm_pool_score_bwd_workspace_bytes", N, C2)
         ws = torch.empty(max(wsb, 4) // 4, dtype=torch.float32, device=h.device)
         _lib.check(lib.dgdm_pool_score_bwd(h.data_ptr(), h.stride(0), w2c.data_ptr(), s.data_ptr(), ds.data_ptr(), N, C2, dh.data_ptr(),
-                                           dh.stride(0), dw2.data_ptr(), db2.data_ptr(), ws.data_ptr(), wsb, _lib.stream_ptr(h.device)),
-                   "dgdm_pool_score_bwd")
-        return dh, dw2.view(ctx.w2_shape), db2.view(ctx.b2_shape)
+                                           dh.stride(0), dw2.data_ptr(), db2.data_ptr(), _lib.ptr(ctx.decide), ws.data_ptr(), wsb,
+                                           _lib.stream_ptr(h.device)), "dgdm_pool_score_bwd")
+        return dh, dw2.view(ctx.w2_shape), db2.view(ctx.b2_shape), None
 
 
-def pool_score(h, w2, b2):
-    return _PoolScore.apply(h, w2, b2)
+def pool_score(h, w2, b2, decide=None):
+    return _PoolScore.apply(h, w2, b2, _decide_arg(decide, h))
 
 
 def topk_perm(s: torch.Tensor, k: int):
@@ -913,15 +952,16 @@ class _UnpoolAddRelu(torch.autograd.Function):
     """relu(skip + unpool(xc)): unpool = zero-fill + index write of the reference (graph_layers.py:441-444)."""
 
     @staticmethod
-    def forward(ctx, xc, skip, node_map):
+    def forward(ctx, xc, skip, node_map, decide=None):
         lib = _lib.load()
         xc, skip = _rowmajor(xc), _rowmajor(skip)
         N, C = skip.shape
         out = torch.empty(N, C, dtype=torch.float32, device=skip.device)
         _lib.check(lib.dgdm_unpool_add_relu_fwd(xc.data_ptr(), xc.stride(0), skip.data_ptr(), skip.stride(0), node_map.data_ptr(), N, C,
-                                                out.data_ptr(), out.stride(0), _lib.stream_ptr(skip.device)), "dgdm_unpool_add_relu_fwd")
+                                                out.data_ptr(), out.stride(0), _lib.ptr(decide), _lib.stream_ptr(skip.device)),
+                   "dgdm_unpool_add_relu_fwd")
         ctx.save_for_backward(out, node_map)
-        ctx.k = xc.size(0)
+        ctx.k, ctx.decide = xc.size(0), decide
         return out
 
     @staticmethod
@@ -933,10 +973,10 @@ class _UnpoolAddRelu(torch.autograd.Function):
         dskip = torch.empty(N, C, dtype=torch.float32, device=out.device)
         dxc = torch.empty(ctx.k, C, dtype=torch.float32, device=out.device)
         _lib.check(lib.dgdm_unpool_add_relu_bwd(g.data_ptr(), g.stride(0), out.data_ptr(), out.stride(0), node_map.data_ptr(), N, C,
-                                                dskip.data_ptr(), dskip.stride(0), dxc.data_ptr(), dxc.stride(0),
+                                                dskip.data_ptr(), dskip.stride(0), dxc.data_ptr(), dxc.stride(0), _lib.ptr(ctx.decide),
                                                 _lib.stream_ptr(out.device)), "dgdm_unpool_add_relu_bwd")
-        return dxc, dskip, None
+        return dxc, dskip, None, None
 
 
-def unpool_add_relu(xc, skip, node_map):
-    return _UnpoolAddRelu.apply(xc, skip, node_map)
+def unpool_add_relu(xc, skip, node_map, decide=None):
+    return _UnpoolAddRelu.apply(xc, skip, node_map, _decide_arg(decide, skip))

@@ -389,25 +389,40 @@ class GraphedPretrainStep:
         self._side = torch.cuda.Stream(self.dev)
 
     # ------------------------------------------------------------------ static inputs
-    @staticmethod
-    def _sig(batch):
+    # tensors of a batch the step reads (PyG-style objects keep them outside __dict__, so they are named here)
+    FIELDS = ("x", "edge_index", "edge_attr", "pos", "batch", "y", "regression_targets")
+
+    @classmethod
+    def _sig(cls, batch):
+        """Layout of a batch: shapes/dtypes of its tensors AND the per-graph node offsets as host integers -- two batches with the
+        same total node count but another split must not share a recording (the graph bakes the offsets in).  A batch that carries
+        its offsets on the host (GraphBatch.ptr) costs no device sync here; one that only has a device ``batch`` / ``ptr`` tensor
+        costs one readback per step."""
+        from .graph import graph_ptr
         sig = []
-        for k, v in sorted(batch.__dict__.items()):
+        for k in cls.FIELDS:
+            v = getattr(batch, k, None)
             if isinstance(v, torch.Tensor):
                 sig.append((k, tuple(v.shape), v.dtype))
-            elif k == "ptr" and v is not None:
-                sig.append((k, tuple(int(i) for i in v)))
+        sig.append(("ptr", tuple(graph_ptr(batch, batch.x.size(0)))))
         return tuple(sig)
 
     def _load(self, batch):
         sig = self._sig(batch)
         if self.static is None:
-            self.static, self._signature = batch.clone(), sig
+            from .graph import GraphBatch
+            st = GraphBatch()
+            for k in self.FIELDS:
+                v = getattr(batch, k, None)
+                setattr(st, k, v.clone() if isinstance(v, torch.Tensor) else v)
+            st.ptr = list(sig[-1][1])            # host offsets: no device sync in the step
+            self.static, self._signature = st, sig
             return
         if sig != self._signature:
             raise BatchLayoutError("GraphedPretrainStep: batch layout differs from the recorded one (tensor shapes or per-graph node "
                              "offsets); run this batch through the eager step")
-        for k, v in batch.__dict__.items():
+        for k in self.FIELDS:
+            v = getattr(batch, k, None)
             if isinstance(v, torch.Tensor):
                 getattr(self.static, k).copy_(v, non_blocking=True)
 
@@ -440,7 +455,10 @@ class GraphedPretrainStep:
         torch.cuda.synchronize(self.dev)
         mode = dict(capture_error_mode="thread_local")
         g1 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g1, **mode):
+        from . import ops
+        # the recording bakes the ADDRESSES of the batch-layout constants (graph offsets, per-graph sizes) into its kernel
+        # arguments: hold them here, whatever the value cache of ops.device_constant evicts later
+        with ops.collect_device_constants() as self._held_constants, torch.cuda.graph(g1, **mode):
             self._loss = self._forward_backward()
             if self.reducer is None:
                 self.opt.step()

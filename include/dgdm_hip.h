@@ -260,10 +260,18 @@ DGDM_API int dgdm_rownorm_bwd(const float* x, const float* res, const float* gam
                               void* stream);
 
 /* y = dropout(act(x)) and dx = dy * mask * act'(x) over n contiguous floats (n % 4 == 0):
- * the GELU+dropout after each graph convolution (core/graph_layers.py:233-239). */
-DGDM_API int dgdm_act_dropout_fwd(const float* x, int64_t n, int32_t act, float drop_p, uint32_t seed, float* y, void* stream);
+ * the GELU+dropout after each graph convolution (core/graph_layers.py:233-239) and the ReLU between
+ * the levels of the graph U-Net (core/graph_layers.py:418,434).
+ * `decide` (nullable; ReLU sites only -- here, dgdm_pool_score_* and dgdm_unpool_add_relu_*): one byte
+ * per element, contiguous [N, C]; non-zero = the element passes.  When given, the kernels take the side
+ * of the ReLU kink from it instead of from the sign of the pre-activation, forward and backward.  It
+ * exists for the parity tests: an element within rounding of zero may fall on either side, which makes
+ * gradients incomparable; handing the reference's decisions to the kernels makes both sides
+ * differentiate the same piecewise-linear function.  NULL (every product call) = sign of the value. */
+DGDM_API int dgdm_act_dropout_fwd(const float* x, int64_t n, int32_t act, float drop_p, uint32_t seed, float* y,
+                                  const uint8_t* decide, void* stream);
 DGDM_API int dgdm_act_dropout_bwd(const float* x, const float* dy, int64_t n, int32_t act, float drop_p, uint32_t seed,
-                                  float* dx, void* stream);
+                                  float* dx, const uint8_t* decide, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Per-graph (segment) primitives; graph g owns the contiguous rows [ptr[g], ptr[g+1]) (ptr: int32
@@ -360,11 +368,11 @@ DGDM_API int dgdm_gemm_tn_split_bf16x3(const float* dY, int64_t ldy, const float
  *   dgdm_unpool_add_relu_bwd : dskip[i] = g[i] * [out[i] > 0];  dxc[node_map[i]] = dskip[i]
  * All row pointers: C % 4 == 0, row strides % 4 == 0, 16-byte aligned. */
 DGDM_API int dgdm_pool_score_fwd(const float* h, int64_t ldh, const float* w2, const float* b2, int32_t N, int32_t C, float* s,
-                                 void* stream);
+                                 const uint8_t* decide, void* stream);
 DGDM_API size_t dgdm_pool_score_bwd_workspace_bytes(int32_t N, int32_t C);
 DGDM_API int dgdm_pool_score_bwd(const float* h, int64_t ldh, const float* w2, const float* s, const float* ds, int32_t N, int32_t C,
-                                 float* dh, int64_t lddh, float* dw2, float* db2, void* workspace, size_t workspace_bytes,
-                                 void* stream);
+                                 float* dh, int64_t lddh, float* dw2, float* db2, const uint8_t* decide, void* workspace,
+                                 size_t workspace_bytes, void* stream);
 DGDM_API size_t dgdm_topk_perm_workspace_bytes(int32_t N);
 DGDM_API int dgdm_topk_perm(const float* s, int32_t N, int32_t k, int64_t* perm, int32_t* node_map, void* workspace,
                             size_t workspace_bytes, void* stream);
@@ -374,9 +382,10 @@ DGDM_API int dgdm_pool_gather_bwd(const float* g, int64_t ldg, const float* x, i
                                   int32_t N, int32_t C, float mult, float* dx, int64_t lddx, float* ds, void* stream);
 DGDM_API int dgdm_edge_relabel(const int64_t* edge_index, int64_t E, const int32_t* node_map, int32_t N, int64_t* out, void* stream);
 DGDM_API int dgdm_unpool_add_relu_fwd(const float* xc, int64_t ldxc, const float* skip, int64_t lds, const int32_t* node_map, int32_t N,
-                                      int32_t C, float* out, int64_t ldo, void* stream);
+                                      int32_t C, float* out, int64_t ldo, const uint8_t* decide, void* stream);
 DGDM_API int dgdm_unpool_add_relu_bwd(const float* g, int64_t ldg, const float* out, int64_t ldo, const int32_t* node_map, int32_t N,
-                                      int32_t C, float* dskip, int64_t ldds, float* dxc, int64_t lddxc, void* stream);
+                                      int32_t C, float* dskip, int64_t ldds, float* dxc, int64_t lddxc, const uint8_t* decide,
+                                      void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K11  tissue-graph edge construction (the step upstream of the model)

@@ -2,6 +2,7 @@
 classes in the dev container (the only place /root/reference exists).
 
     python -m oracle.capture_golden            # rewrites every fixture
+    python -m oracle.capture_golden g7_repaired   # only the named capture functions
 
 Nothing of the reference is copied: its files are imported from /root/reference at run
 time, and only numbers (inputs, weights, outputs, gradients) are stored.  ``torch_geometric``
@@ -296,6 +297,41 @@ def repaired_state_to_oracle_keys(sd):
     return out
 
 
+class DecisionRecorder:
+    """Records the discrete choices of one run of the reference's GraphUNet.forward (core/graph_layers.py:400-458): which
+    elements pass each ReLU (``self.act`` is called for down 0..depth-1, bottom, up 0..depth-1 in that order, :418,434,452; the
+    score MLP's nn.ReLU once per pooling level, :263) and the kept node ids of each pooling level (:308-316).  The HIP parity
+    tests hand these to the kernels so that both sides differentiate the same piecewise-linear function."""
+
+    def __init__(self, unet):
+        self.unet, self.out, self._acts, self._hooks = unet, {}, 0, []
+        depth = unet.depth
+        self.act_names = [f"relu.down{i}" for i in range(depth)] + ["relu.bottom"] + [f"relu.up{i}" for i in range(depth)]
+
+    def __enter__(self):
+        inner = self.unet.act
+
+        def act(x):
+            self.out[self.act_names[self._acts]] = (x > 0).detach().clone()
+            self.out["margin." + self.act_names[self._acts]] = x.detach().abs().min()
+            self._acts += 1
+            return inner(x)
+        self._inner, self.unet.act = inner, act
+        for i, pool in enumerate(self.unet.pools):
+            self._hooks.append(pool.score_net[1].register_forward_hook(
+                lambda mod, inp, out, i=i: self.out.__setitem__(f"relu.pool{i}", (inp[0] > 0).detach().clone())))
+            self._hooks.append(pool.register_forward_hook(
+                lambda mod, inp, out, i=i: self.out.__setitem__(f"perm{i}", out[3].detach().clone())))
+        return self
+
+    def __exit__(self, *exc):
+        self.unet.act = self._inner
+        for h in self._hooks:
+            h.remove()
+        assert exc[0] is not None or self._acts == len(self.act_names), (self._acts, self.act_names)
+        return False
+
+
 def small_batch(ref, sizes, feat, seed, edge_mult=3):
     from torch_geometric.data import Data, Batch
     gs = []
@@ -355,7 +391,8 @@ def g7_repaired(ref):
         # (1) inference forward with embeddings + attention
         out_inf = m(data, mode="inference", return_attention=True, return_embeddings=True)
         # (2) pretrain_step with every draw injected
-        with injected_rng(randperm=[mask_idx], randn=[mask_tok], randint=[timesteps], randn_like=rl):
+        with injected_rng(randperm=[mask_idx], randn=[mask_tok], randint=[timesteps], randn_like=rl), \
+                DecisionRecorder(m.hierarchical_processor) as rec:
             out_pre = m.pretrain_step(data, mask_ratio=0.15)
         named = dict(m.named_parameters())
         watch = ["feature_encoder.encoder.0.weight", "graph_encoder.graph_layers.0.graph_conv1.node_lin.weight",
@@ -371,6 +408,7 @@ def g7_repaired(ref):
                       inf_attn0=out_inf["attention_weights"][0], inf_attn1=out_inf["attention_weights"][1],
                       pre_diffusion_loss=out_pre["diffusion_loss"], pre_graph_embedding=out_pre["graph_embedding"],
                       pre_noisy_embeddings=out_pre["noisy_embeddings"], cfg_json=np.array(__import__("json").dumps(cfg)))
+        arrays.update({"dec." + k: v for k, v in rec.out.items()})   # the reference run's ReLU / top-k decisions (pretrain_step)
         for k, gk in zip(watch, gl):
             ok = repaired_state_to_oracle_keys({k: 0}).popitem()[0]
             if tag == "base":  # keep the fixture small: a checksum-like slice + norm
@@ -390,8 +428,10 @@ def main():
     torch.set_num_threads(4)
     ref = load_reference()
     print("reference modules loaded from", REF_ROOT)
-    g1_scheduler(ref); g2_graph_conv(ref); g2b_plain_encoder(ref); g4_attention(ref)
-    g5_diffusion(ref); g6_small_modules(ref); g7_repaired(ref)
+    only = set(sys.argv[1:])
+    for fn in (g1_scheduler, g2_graph_conv, g2b_plain_encoder, g4_attention, g5_diffusion, g6_small_modules, g7_repaired):
+        if not only or fn.__name__ in only:
+            fn(ref)
 
 
 if __name__ == "__main__":
