@@ -85,27 +85,48 @@ class DiffusionLayer(nn.Module):
         a, b = tab["sqrt_ac"][timesteps][seg].unsqueeze(-1), tab["sqrt_1mac"][timesteps][seg].unsqueeze(-1)
         return a * x0 + b * noise
 
+    def time_bias(self, timesteps: Tensor) -> Tensor:
+        """Per-timestep bias of the first denoiser layer, [len(timesteps), 2*hidden]: ``time_embed`` of the sinusoid
+        (diffusion.py:147-163) pushed through the time half of ``denoise_net[0]`` plus its bias -- the ``[x_t | t_emb]`` concat of
+        diffusion.py:165-170 without the concat.  A few rows: the exact-fp32 small-M kernels (csrc/smallm.hip)."""
+        C = self.node_dim
+        emb = self._embedding_table(timesteps.device).index_select(0, timesteps.reshape(-1))
+        te = ops.linear_small(emb, self.time_embed[0].weight, self.time_embed[0].bias, ops.ACT_SILU)
+        te = ops.linear_small(te, self.time_embed[2].weight, self.time_embed[2].bias)
+        lin0 = self.denoise_net[0]
+        return ops.linear_small(te, lin0.weight[:, C:], lin0.bias)
+
+    def _embedding_table(self, device) -> Tensor:
+        """Sinusoidal embeddings of the T possible timesteps (diffusion.py:112-121), built once per device."""
+        tabs = self.__dict__.setdefault("_emb_tables", {})
+        key = str(device)
+        if key not in tabs:
+            tabs[key] = self.get_timestep_embedding(torch.arange(self.num_timesteps, device=device)).contiguous()
+        return tabs[key]
+
+    def _denoise_tail(self, h: Tensor) -> Tensor:
+        for i in (1, 5):
+            gn, drop, lin = self.denoise_net[i], self.denoise_net[i + 2], self.denoise_net[i + 3]
+            if not ops.row_norm_supported(h.size(1), gn.num_groups):
+                raise ops._lib.DGDMKernelError(f"GroupNorm({gn.num_groups}, {h.size(1)}): the fused row kernels need group widths that are "
+                                               "multiples of 4 channels")
+            h = ops.row_norm(h, gn.weight, gn.bias, groups=gn.num_groups, eps=gn.eps, act=ops.ACT_SILU, drop_p=drop.p,
+                             training=self.training)
+            h = ops.lin(lin, h)
+        return h
+
     def predict_noise_segments(self, x_noisy: Tensor, timesteps: Tensor, seg: Tensor, plan=None) -> Tensor:
         """x_noisy [N_tot, C]; timesteps [B]; seg [N_tot] graph id per row; ``plan`` (ops.AttnPlan)
         carries the per-graph row offsets for the segment kernels."""
         C = self.node_dim
-        te = self.time_embed(self.get_timestep_embedding(timesteps))                  # [B, hidden]
-        lin0 = self.denoise_net[0]
-        per_graph = F.linear(te, lin0.weight[:, C:], lin0.bias)                      # time half of the concat + bias
-        h = ops.linear(x_noisy, lin0.weight[:, :C])
-        if plan is not None and h.size(1) % 4 == 0:
-            h = ops.segment_bcast_add(h, per_graph, plan)
-        else:
-            h = h + per_graph[seg]
-        for i in (1, 5):
-            gn, drop, lin = self.denoise_net[i], self.denoise_net[i + 2], self.denoise_net[i + 3]
-            if ops.row_norm_supported(h.size(1), gn.num_groups):
-                h = ops.row_norm(h, gn.weight, gn.bias, groups=gn.num_groups, eps=gn.eps, act=ops.ACT_SILU, drop_p=drop.p,
-                                 training=self.training)
-            else:  # group width not a multiple of 4 channels: separate GPU ops
-                h = drop(F.silu(F.group_norm(h, gn.num_groups, gn.weight, gn.bias, gn.eps)))
-            h = ops.lin(lin, h)
-        return h
+        per_graph = self.time_bias(timesteps)                                         # [B, 2*hidden]
+        h = ops.linear(x_noisy, self.denoise_net[0].weight[:, :C])
+        if plan is None:
+            if timesteps.numel() != 1:
+                raise ValueError("predict_noise_segments needs the batch plan when graphs carry different timesteps")
+            plan = ops.AttnPlan([0, x_noisy.size(0)], x_noisy.device)
+        h = ops.segment_bcast_add(h, per_graph, plan)
+        return self._denoise_tail(h)
 
     # -- reference-shaped API (same graph for every row) --------------------------------------
     def add_noise(self, x_start: Tensor, noise: Tensor, timesteps: Tensor) -> Tensor:
@@ -134,23 +155,66 @@ class DiffusionLayer(nn.Module):
 
     @torch.no_grad()
     def sample(self, shape, device, condition: Optional[Tensor] = None, num_inference_steps: int = 50,
-               x_init: Optional[Tensor] = None, step_noise: Optional[List[Tensor]] = None) -> Tensor:
-        """DDPM ancestral sampling (reference: diffusion.py:214-275): timesteps =
-        linspace(T-1, 0, steps).long(), final step returns x0_hat without noise.  ``x_init`` /
-        ``step_noise`` inject the random draws (tests); the timestep table is read on the host
-        once, the loop itself issues no device->host sync."""
-        x = torch.randn(shape, device=device) if x_init is None else x_init.to(device)
-        tab = self.scheduler.on(device)
-        ts = torch.linspace(self.num_timesteps - 1, 0, num_inference_steps, dtype=torch.long).tolist()
-        seg = torch.zeros(x.size(0), dtype=torch.long, device=device)
+               x_init: Optional[Tensor] = None, step_noise: Optional[List[Tensor]] = None, graphed: bool = False) -> Tensor:
+        """DDPM ancestral sampling (reference: diffusion.py:214-275): timesteps = linspace(T-1, 0, steps).long(), final step
+        returns x0_hat without noise.  ``x_init`` / ``step_noise`` inject the random draws (tests).
+
+        Per step: 3 tile GEMMs (the time half of the first layer enters as that GEMM's bias), 2 fused GroupNorm+SiLU rows, one
+        update kernel (dgdm_ddpm_step) and one normal draw -- 7 launches, no host synchronisation.  The time-embedding MLP runs
+        ONCE for the <= T distinct timesteps before the loop (3 small-M launches).  ``graphed=True`` records the whole loop as one
+        HIP graph per (rows, steps) and replays it (fresh draws on every replay through torch's graph-aware generator)."""
+        if condition is not None:
+            raise NotImplementedError("conditioning is not used by DGDMModel")
+        if len(shape) != 2 or shape[1] != self.node_dim:
+            raise ValueError(f"sample expects shape [N, {self.node_dim}] (the 3-D form cannot run in the reference: GroupNorm, D5)")
+        device = torch.device(device)
+        steps = int(num_inference_steps)
+        ts = torch.linspace(self.num_timesteps - 1, 0, steps).long().tolist()
+        x = torch.randn(shape, device=device) if x_init is None else x_init.to(device=device, dtype=torch.float32).contiguous()
+        if step_noise is not None:
+            step_noise = [z.to(device=device, dtype=torch.float32).contiguous() for z in step_noise]
+        if not graphed:
+            return self._sample_loop(x, ts, step_noise)
+        key = (tuple(shape), steps, str(device), self.training, step_noise is not None)
+        cache = self.__dict__.setdefault("_sample_graphs", {})
+        if key not in cache:
+            sx = torch.empty(shape, device=device)
+            sz = [torch.empty(shape, device=device) for _ in range(steps - 1)] if step_noise is not None else None
+            side = torch.cuda.Stream(device)
+            side.wait_stream(torch.cuda.current_stream(device))
+            with torch.cuda.stream(side):          # warm-up outside the capture (allocator, lazy module state)
+                sx.copy_(x)
+                self._sample_loop(sx, ts[:2] + ts[-1:], sz[:2] if sz else None)
+            torch.cuda.current_stream(device).wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with ops.collect_device_constants() as held, torch.cuda.graph(g):
+                out = self._sample_loop(sx, ts, sz)
+            cache[key] = (g, sx, sz, out, held)
+        g, sx, sz, out, _ = cache[key]
+        sx.copy_(x)
+        if sz is not None:
+            for dst, src in zip(sz, step_noise):
+                dst.copy_(src)
+        g.replay()
+        return out.clone()
+
+    def _sample_loop(self, x: Tensor, ts: List[int], step_noise: Optional[List[Tensor]]) -> Tensor:
+        device, C = x.device, self.node_dim
+        sch = self.scheduler
+        # fp32 table arithmetic as the reference does it on its tensors (diffusion.py:245-270), then host scalars
+        s1mac, sac = torch.sqrt(1 - sch.alphas_cumprod).tolist(), torch.sqrt(sch.alphas_cumprod).tolist()
+        salpha, svar = torch.sqrt(sch.alphas).tolist(), torch.sqrt(sch.posterior_variance).tolist()
+        # first-layer bias of every timestep 0..T-1 in one go (3 small-M launches; no host-to-device copy inside the loop)
+        bias = self.time_bias(ops.device_constant(range(self.num_timesteps), torch.long, device))       # [T, 2*hidden]
+        row = list(range(self.num_timesteps))
+        w0x = self.denoise_net[0].weight[:, :C]
         for i, t in enumerate(ts):
-            tt = torch.full((1,), t, dtype=torch.long, device=device)
-            eps = self.predict_noise_segments(x, tt, seg)
-            ac, alpha = tab["alphas_cumprod"][t], tab["alphas"][t]
-            x0 = (x - torch.sqrt(1 - ac) * eps) / torch.sqrt(ac)
-            if i < len(ts) - 1:
-                z = torch.randn_like(x) if step_noise is None else step_noise[i].to(device)
-                x = torch.sqrt(alpha) * x0 + torch.sqrt(tab["posterior_variance"][t]) * z
+            last = i == len(ts) - 1
+            if x.size(0) >= ops.GEMM_MIN_ROWS:
+                h = ops.gemm_nt_raw(x, w0x, bias[row[t]], math=ops.GEMM_MATH)
             else:
-                x = x0
+                h = ops.linear_small_fwd_raw(x, w0x, bias[row[t]])[0]
+            eps = self._denoise_tail(h)
+            z = None if last else (torch.randn_like(x) if step_noise is None else step_noise[i])
+            x = ops.ddpm_step(x, eps, z, s1mac[t], sac[t], salpha[t], svar[t], last)
         return x

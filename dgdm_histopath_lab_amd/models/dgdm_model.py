@@ -378,14 +378,21 @@ def _seg(x: Tensor, batch: Optional[Tensor]) -> Tensor:
     return batch if batch is not None else torch.zeros(x.size(0), dtype=torch.long, device=x.device)
 
 
+def _plan_for(x: Tensor, batch: Optional[Tensor], plan):
+    """The attention/segment plan of a pooling call: the forward's own, or one derived from ``batch`` (one readback)."""
+    if plan is not None:
+        return plan.attn if isinstance(plan, BatchPlan) else plan
+    holder = type("_B", (), {"batch": batch, "ptr": None})()
+    return ops.AttnPlan(graph_ptr(holder, x.size(0)), x.device)
+
+
 class GlobalMeanPool(nn.Module):
-    """dgdm_model.py:552-567 as one segmented reduction."""
+    """dgdm_model.py:552-567 as one fixed-order segmented reduction (csrc/segment.hip)."""
 
     def forward(self, x: Tensor, batch: Optional[Tensor] = None, plan=None) -> Tensor:
-        B, seg = _num_graphs(batch, plan), _seg(x, batch)
-        s = torch.zeros(B, x.size(1), device=x.device, dtype=x.dtype).index_add_(0, seg, x)
-        cnt = torch.zeros(B, device=x.device, dtype=x.dtype).index_add_(0, seg, torch.ones_like(seg, dtype=x.dtype))
-        return s / cnt.clamp_min(1).unsqueeze(-1)
+        if x.size(1) % 4 or x.size(1) > 1024:
+            raise _lib.DGDMKernelError("segment kernels need a channel count that is a multiple of 4 and <= 1024")
+        return ops.segment_mean(x, _plan_for(x, batch, plan))
 
 
 class GlobalMaxPool(nn.Module):
@@ -422,22 +429,25 @@ class GlobalAttentionPool(nn.Module):
 
     def forward(self, x: Tensor, batch: Optional[Tensor] = None, plan=None) -> Tensor:
         att = self.attention
-        B, seg = _num_graphs(batch, plan), _seg(x, batch)
+        ap = _plan_for(x, batch, plan)
         H, d, C = att.num_heads, att.head_dim, att.embed_dim
-        if plan is not None and d in ops.POOL_HEAD_DIMS:   # fused segment-softmax kernel (K10)
-            q = att.q_proj(self.global_token.view(1, C)).view(C) * (1.0 / math.sqrt(d))
-            kv = ops.linear(x, torch.cat([att.k_proj.weight, att.v_proj.weight]), torch.cat([att.k_proj.bias, att.v_proj.bias]))
-            o = ops.attn_pool(kv, q, plan.attn, H, d, att.attn_dropout.p, att.training)
-            return ops.act_dropout(att.out_proj(o), ops.ACT_NONE, att.resid_dropout.p, att.training) if (B * C) % 4 == 0 \
-                else att.resid_dropout(att.out_proj(o))
-        q = att.q_proj(self.global_token.view(1, C)).view(1, H, d)
-        k = att.k_proj(x).view(-1, H, d)
-        v = att.v_proj(x).view(-1, H, d)
-        s = (k * q).sum(-1) / math.sqrt(d)                                         # [N, H]
-        idx = seg.unsqueeze(-1).expand_as(s)
-        m = torch.full((B, H), float("-inf"), device=x.device, dtype=x.dtype).scatter_reduce(0, idx, s.detach(), "amax")
-        e = torch.exp(s - m[seg])
-        den = torch.zeros(B, H, device=x.device, dtype=x.dtype).index_add_(0, seg, e)
-        p = att.attn_dropout(e / den[seg])
-        o = torch.zeros(B, H, d, device=x.device, dtype=x.dtype).index_add_(0, seg, p.unsqueeze(-1) * v)
-        return att.resid_dropout(att.out_proj(o.reshape(B, C)))
+        D = next((v for v in ops.POOL_HEAD_DIMS if v >= d), None)
+        if D is None:
+            raise _lib.DGDMKernelError(f"attention pooling kernels support head_dim <= {ops.POOL_HEAD_DIMS[-1]}, got {d}")
+        q = ops.linear_small(self.global_token.view(1, C), att.q_proj.weight, att.q_proj.bias).view(C) * (1.0 / math.sqrt(d))
+        wkv = torch.cat([att.k_proj.weight, att.v_proj.weight])
+        bkv = torch.cat([att.k_proj.bias, att.v_proj.bias])
+        if D != d:   # heads zero-padded to the kernels' width (scores and outputs are unchanged by zero columns)
+            wkv = F.pad(wkv.view(2 * H, d, C), (0, 0, 0, D - d)).reshape(2 * H * D, C)
+            bkv = F.pad(bkv.view(2 * H, d), (0, D - d)).reshape(-1)
+            q = F.pad(q.view(H, d), (0, D - d)).reshape(-1)
+        kv = ops.linear(x, wkv, bkv)
+        o = ops.attn_pool(kv, q, ap, H, D, att.attn_dropout.p, att.training)
+        if D != d:
+            o = o.view(-1, H, D)[:, :, :d].reshape(-1, C)
+        o = ops.linear(o, att.out_proj.weight, att.out_proj.bias)
+        if att.training and att.resid_dropout.p > 0:
+            if o.numel() % 4:
+                raise _lib.DGDMKernelError("dropout kernel needs numel % 4 == 0")
+            o = ops.act_dropout(o, ops.ACT_NONE, att.resid_dropout.p, True)
+        return o

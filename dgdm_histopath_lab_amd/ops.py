@@ -6,7 +6,6 @@ ctypes; tensors only provide device memory.  No CPU path exists.
 from __future__ import annotations
 
 import collections
-import os as _os
 from typing import Optional
 
 import torch
@@ -379,8 +378,10 @@ class _SpatialAttention(torch.autograd.Function):
         return dqkv, None, None, None, None, None, None, None
 
 
-# "fp16x2": split-fp16 (hi+lo) attention kernels (default); "fp32": exact fp32-MFMA kernels.
-ATTN_PRECISION = _os.environ.get("DGDM_ATTN", "fp16x2")
+# "fp16x2": split-fp16 (hi+lo operands, fp32 accumulate) attention kernels -- the shipped path; "fp32": the same tiling on the
+# fp32 matrix instructions (the reference's own arithmetic; parity tests run both, bench.py reports both).  Set with
+# ``configure(attention=...)``; no environment variable selects kernels.
+ATTN_PRECISION = "fp16x2"
 
 
 def spatial_attention(qkv, pos, plan: AttnPlan, H: int, scale: float, inv_tau: float = 1.0, drop_p: float = 0.0,
@@ -570,6 +571,18 @@ def act_dropout(x, act: int = ACT_NONE, drop_p: float = 0.0, training: bool = Fa
     return _ActDropout.apply(x, act, p, next_dropout_seed() if p > 0 else 0, _decide_arg(decide, x))
 
 
+def ddpm_step(x, eps, z, sqrt_one_minus_ac: float, sqrt_ac: float, sqrt_alpha: float, sqrt_var: float, last: bool, out=None):
+    """One update of DiffusionLayer.sample (core/diffusion.py:255-273): x0 = (x - s*eps)/a; out = x0 or sqrt(alpha) x0 + sqrt(var) z."""
+    lib = _lib.load()
+    x, eps = _f32c(x), _f32c(eps)
+    z = _f32c(z) if z is not None else None
+    _lib.require_cuda(x, eps, z)
+    out = torch.empty_like(x) if out is None else out
+    _lib.check(lib.dgdm_ddpm_step(x.data_ptr(), eps.data_ptr(), _lib.ptr(z), x.numel(), sqrt_one_minus_ac, sqrt_ac, sqrt_alpha, sqrt_var,
+                                  int(last), out.data_ptr(), _lib.stream_ptr(x.device)), "dgdm_ddpm_step")
+    return out
+
+
 # ----------------------------------------------------------------------------- segment ops / K10 pooling
 def segment_sum_raw(x, plan: AttnPlan) -> torch.Tensor:
     lib = _lib.load()
@@ -601,6 +614,33 @@ class _SegmentBcastAdd(torch.autograd.Function):
     def backward(ctx, g):
         g = _f32c(g)
         return g, segment_sum_raw(g, ctx.plan), None
+
+
+class _SegmentMean(torch.autograd.Function):
+    """out[g] = mean of the rows of graph g (GlobalMeanPool, models/dgdm_model.py:552-567): the fixed-order segment sum times
+    1/n_g; backward broadcasts g/n_g back over the graph's rows."""
+
+    @staticmethod
+    def forward(ctx, x, plan: AttnPlan):
+        inv = device_constant([1.0 / max(plan.ptr_host[g + 1] - plan.ptr_host[g], 1) for g in range(plan.B)], torch.float32, x.device)
+        ctx.plan, ctx.n = plan, x.size(0)
+        ctx.save_for_backward(inv)
+        return segment_sum_raw(x, plan) * inv.unsqueeze(1)
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        (inv,) = ctx.saved_tensors
+        src = _f32c(g * inv.unsqueeze(1))
+        plan, C = ctx.plan, g.size(1)
+        out = torch.empty(ctx.n, C, dtype=torch.float32, device=g.device)
+        _lib.check(lib.dgdm_segment_bcast_add(None, src.data_ptr(), plan.ptr_dev.data_ptr(), plan.B, ctx.n, C, out.data_ptr(),
+                                              _lib.stream_ptr(g.device)), "dgdm_segment_bcast_add")
+        return out, None
+
+
+def segment_mean(x, plan: AttnPlan):
+    return _SegmentMean.apply(x, plan)
 
 
 def segment_bcast_add(x, src, plan: AttnPlan):
@@ -653,7 +693,7 @@ def attn_pool(kv, q_scaled, plan: AttnPlan, H: int, D: int, drop_p: float = 0.0,
 
 
 # ----------------------------------------------------------------------------- K3 dense contractions
-GEMM_MIN_ROWS = 256   # below this the launch is latency-bound either way: tiny per-graph GEMMs stay in torch
+GEMM_MIN_ROWS = 256   # fewer rows (one per graph / timestep): the exact-fp32 small-M kernels (csrc/smallm.hip), not a tile GEMM
 
 
 def _rowmajor(t: torch.Tensor) -> torch.Tensor:
@@ -743,49 +783,122 @@ def gemm_tn_raw(dy, x, with_bias: bool, math="fp32", split: Optional[int] = None
     return (dW0, dW1), db
 
 
-# Which implementation runs the dense contractions (env DGDM_GEMM):
-#   "bf16x3" (default) csrc/gemm3.hip: exact three-way bf16 split of every fp32 operand, six bf16
-#            MFMAs per product, fp32 accumulate -- fp32-level accuracy at 2-2.5x the fp32 matrix rate;
-#   "own"    csrc/gemm.hip: fp32 MFMA for all three contractions;
-#   "lib"    hipBLASLt (through torch) for y and dx, csrc/gemm.hip's split-M kernel for dW/db.
-# The weight/bias gradient never goes to the library: its split-M kernel is 1.3-2.8x faster than a
-# library GEMM plus a separate column sum, and bitwise reproducible.
-import os as _os
-GEMM_FWD_BACKEND = _os.environ.get("DGDM_GEMM", "bf16x3")
-if GEMM_FWD_BACKEND not in ("bf16x3", "own", "lib"):
-    raise ValueError(f"DGDM_GEMM must be bf16x3, own or lib, got {GEMM_FWD_BACKEND!r}")
+# Arithmetic of the dense contractions (``configure(gemm=...)``; both are this library's kernels):
+#   "bf16x3" (shipped) csrc/gemm3.hip: exact three-way bf16 split of every fp32 operand, six bf16 MFMAs per product,
+#            fp32 accumulate -- fp32-level accuracy at 2-2.5x the fp32 matrix rate;
+#   "fp32"   csrc/gemm.hip: fp32 MFMA for all three contractions.
+GEMM_MATH = "bf16x3"
+
+
+def configure(attention: Optional[str] = None, gemm: Optional[str] = None) -> dict:
+    """Select the arithmetic of the attention kernels ("fp16x2" | "fp32") and of the tile GEMMs ("bf16x3" | "fp32") for the
+    calls that follow; returns the previous setting (pass it back as ``configure(**prev)`` to restore)."""
+    global ATTN_PRECISION, GEMM_MATH
+    prev = dict(attention=ATTN_PRECISION, gemm=GEMM_MATH)
+    if attention is not None:
+        if attention not in ("fp16x2", "fp32"):
+            raise ValueError(f"attention precision must be 'fp16x2' or 'fp32', got {attention!r}")
+        ATTN_PRECISION = attention
+    if gemm is not None:
+        if gemm not in ("bf16x3", "fp32"):
+            raise ValueError(f"GEMM math must be 'bf16x3' or 'fp32', got {gemm!r}")
+        GEMM_MATH = gemm
+    return prev
 
 
 class _Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b):
         ctx.save_for_backward(x, w)
-        ctx.has_bias = b is not None
-        if GEMM_FWD_BACKEND == "lib":
-            return torch.nn.functional.linear(x, w, b)
-        return gemm_nt_raw(x, w, b, math="bf16x3" if GEMM_FWD_BACKEND == "bf16x3" else "fp32")
+        ctx.has_bias, ctx.math = b is not None, GEMM_MATH
+        return gemm_nt_raw(x, w, b, math=GEMM_MATH)
 
     @staticmethod
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
         gy = _rowmajor(gy)
-        math = "bf16x3" if GEMM_FWD_BACKEND == "bf16x3" else "fp32"
-        dx = None
-        if ctx.needs_input_grad[0]:
-            dx = gy @ w if GEMM_FWD_BACKEND == "lib" else gemm_nn_raw(gy, w, math=math)
+        dx = gemm_nn_raw(gy, w, math=ctx.math) if ctx.needs_input_grad[0] else None
         dW = db = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            dW, db = gemm_tn_raw(gy, x, ctx.has_bias, math=math)
+            dW, db = gemm_tn_raw(gy, x, ctx.has_bias, math=ctx.math)
         return dx, dW, db
 
 
+def _ld(t: torch.Tensor) -> int:
+    return t.stride(0) if t.size(0) > 1 else max(t.size(1), t.stride(0))
+
+
+def _rows(t: torch.Tensor) -> torch.Tensor:
+    """2-D fp32 view with unit column stride (any row stride): what the small-M kernels address."""
+    if t.dtype != torch.float32:
+        raise _lib.DGDMKernelError(f"HIP kernels compute in fp32, got {t.dtype}")
+    return t if (t.dim() == 2 and t.stride(1) == 1 and (t.size(0) <= 1 or t.stride(0) >= t.size(1))) else t.contiguous()
+
+
+def linear_small_fwd_raw(x, w, b, act: int = ACT_NONE, want_pre: bool = False):
+    lib = _lib.load()
+    x, w = _rows(x), _rows(w)
+    _lib.require_cuda(x, w, b)
+    M, K = x.shape
+    N = w.size(0)
+    if w.size(1) != K:
+        raise ValueError(f"weight {tuple(w.shape)} does not match the input {tuple(x.shape)}")
+    y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    pre = torch.empty(M, N, dtype=torch.float32, device=x.device) if want_pre else None
+    b = _f32c(b) if b is not None else None
+    _lib.check(lib.dgdm_linear_small_fwd(x.data_ptr(), _ld(x), w.data_ptr(), _ld(w), _lib.ptr(b), M, N, K, act, y.data_ptr(), N,
+                                         _lib.ptr(pre), N, _lib.stream_ptr(x.device)), "dgdm_linear_small_fwd")
+    return y, pre
+
+
+class _LinearSmall(torch.autograd.Function):
+    """act(x w^T + b) for few rows (csrc/smallm.hip): exact fp32, fixed-order reductions.  ``w`` may be a column block of a larger
+    weight (row stride > K); its gradient is then returned as a dense [N, K] block and autograd assembles the full matrix."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, act: int):
+        x, w = _rows(x), _rows(w)
+        y, pre = linear_small_fwd_raw(x, w, b, act, want_pre=act != ACT_NONE)
+        ctx.save_for_backward(x, w, pre)
+        ctx.act, ctx.has_bias = act, b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.load()
+        x, w, pre = ctx.saved_tensors
+        gy = _rows(gy)
+        M, K = x.shape
+        N = w.size(0)
+        dev = x.device
+        dx = torch.empty(M, K, dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        dw = torch.empty(N, K, dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
+        db = torch.empty(N, dtype=torch.float32, device=dev) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        _lib.check(lib.dgdm_linear_small_bwd(gy.data_ptr(), _ld(gy), _lib.ptr(pre), N, ctx.act, x.data_ptr(), _ld(x), w.data_ptr(), _ld(w),
+                                             M, N, K, _lib.ptr(dx), K, _lib.ptr(dw), K, _lib.ptr(db), _lib.stream_ptr(dev)),
+                   "dgdm_linear_small_bwd")
+        return dx, dw, db, None
+
+
+SMALL_MAX_K = 2048
+
+
+def linear_small(x, weight, bias=None, act: int = ACT_NONE):
+    return _LinearSmall.apply(x, weight, bias, act)
+
+
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """y = x @ weight^T + bias on the kernels DGDM_GEMM selects.  Shapes the kernels are not built for (fewer than GEMM_MIN_ROWS rows,
-    K or N not a multiple of 4) go to the library GEMM -- still on the GPU."""
-    if (x.dim() == 2 and x.is_cuda and x.size(0) >= GEMM_MIN_ROWS and x.size(1) % 4 == 0 and weight.size(0) % 4 == 0
-            and x.dtype == torch.float32):
+    """y = x @ weight^T + bias on this library's kernels: the tile GEMMs (``GEMM_MATH``) for >= GEMM_MIN_ROWS rows with K and N
+    multiples of 4, the exact-fp32 small-M kernels otherwise.  There is no library / CPU fallback."""
+    if x.dim() != 2 or x.dtype != torch.float32:
+        raise _lib.DGDMKernelError(f"linear expects a 2-D fp32 matrix, got {x.dtype} {tuple(x.shape)}")
+    _lib.require_cuda(x, weight, bias)
+    if x.size(0) >= GEMM_MIN_ROWS and x.size(1) % 4 == 0 and weight.size(0) % 4 == 0:
         return _Linear.apply(x, weight, bias)
-    return torch.nn.functional.linear(x, weight, bias)
+    if x.size(1) > SMALL_MAX_K:
+        raise _lib.DGDMKernelError(f"no kernel for a [{x.size(0)}, {x.size(1)}] x [{weight.size(0)}, {weight.size(1)}]^T contraction "
+                                   "(tile GEMMs need K, N % 4 == 0 and >= 256 rows; the small-M kernels K <= 2048)")
+    return _LinearSmall.apply(x, weight, bias, ACT_NONE)
 
 
 def lin(module, x: torch.Tensor) -> torch.Tensor:
@@ -814,14 +927,14 @@ class _GraphConvLinear(torch.autograd.Function):
             lib.dgdm_spmm_concat(gs.rowptr.data_ptr(), gs.col.data_ptr(), gs.w.data_ptr(), x.data_ptr(), x.stride(0), x.size(0),
                                  ea_hat.data_ptr(), ea_hat.stride(0), ed, buf.data_ptr(), buf.stride(0), n, cin,
                                  _lib.stream_ptr(x.device)), "dgdm_spmm_concat"))
-        ctx.gs, ctx.cin, ctx.has_bias, ctx.skip = gs, cin, b is not None, skip
-        if GEMM_FWD_BACKEND == "bf16x3" and cin % 4 == 0:
+        ctx.gs, ctx.cin, ctx.has_bias, ctx.skip, ctx.math = gs, cin, b is not None, skip, GEMM_MATH
+        if GEMM_MATH == "bf16x3" and cin % 4 == 0:
             ctx.save_for_backward(buf, w)          # the kernel reads the two weights side by side: no concatenated copy
             y = gemm_nt_split_raw(buf, w, we, b)
         else:
             wcat = torch.cat([w, we], dim=1)
             ctx.save_for_backward(buf, wcat)
-            y = torch.nn.functional.linear(buf, wcat, b) if GEMM_FWD_BACKEND == "lib" else gemm_nt_raw(buf, wcat, b, math="fp32")
+            y = gemm_nt_raw(buf, wcat, b, math="fp32")
         return (y, x_in.view_as(x_in)) if skip else y
 
     @staticmethod
@@ -831,11 +944,11 @@ class _GraphConvLinear(torch.autograd.Function):
         buf, wsaved = ctx.saved_tensors
         gs, cin = ctx.gs, ctx.cin
         gy = _rowmajor(gy)
-        math = "bf16x3" if GEMM_FWD_BACKEND == "bf16x3" else "fp32"
+        math = ctx.math
         dx = None
         if ctx.needs_input_grad[0]:
             w_only = wsaved[:, :cin]                    # node_lin.weight itself, or a view into the concatenated copy
-            dagg = gy @ w_only if GEMM_FWD_BACKEND == "lib" else gemm_nn_raw(gy, w_only, math=math)
+            dagg = gemm_nn_raw(gy, w_only, math=math)
             dx = spmm_raw(gs.rowptr_t, gs.col_t, gs.w_t, dagg, gs.num_nodes, addend=gskip)
         dw = dwe = db = None
         if ctx.needs_input_grad[3] or ctx.needs_input_grad[4] or (ctx.has_bias and ctx.needs_input_grad[5]):

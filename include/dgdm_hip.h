@@ -10,9 +10,11 @@
  * Conventions (all entry points):
  *   - plain pointers to DEVICE memory (hipMalloc'ed or torch CUDA tensors), sizes as integers,
  *     trailing `void* stream` = hipStream_t (NULL = default stream);
- *   - returns DGDM_OK (0) or a negative DGDM_ERR_* code; never allocates, never synchronises,
- *     no global state: re-entrant per stream; scratch memory is passed in by the caller and its
- *     size is given by the matching *_workspace_bytes() query;
+ *   - returns DGDM_OK (0) or a negative DGDM_ERR_* code; never allocates, never synchronises;
+ *     scratch memory is passed in by the caller and its size is given by the matching
+ *     *_workspace_bytes() query.  The library keeps ONE piece of state: the dropout seed epoch, a
+ *     uint32 counter in device memory, one per device (see dgdm_seed_epoch_advance).  Everything
+ *     else is re-entrant per stream;
  *   - float data is fp32 row-major; node/edge ids inside CSR structures are int32; the edge list
  *     at the boundary is int64 [2,E] exactly as the reference holds it (graph_layers.py:77-81);
  *   - arguments are checked on the host (null pointers, negative sizes, unsupported widths) before
@@ -50,7 +52,10 @@ DGDM_API const char* dgdm_error_string(int code);
  *   effective seed = seed ^ (epoch * 0x9E3779B9).
  * dgdm_seed_epoch_advance enqueues epoch += 1 (record it once per training step, before the forward, in
  * the captured graph); dgdm_seed_epoch_set enqueues epoch = value.  The counter starts at 0, where the
- * effective seed equals the seed: callers that never touch it see no change. */
+ * effective seed equals the seed: callers that never touch it see no change.
+ * This counter is the library's only state: one uint32 per device, shared by every stream and every caller of
+ * that device (two models trained in one process advance the same epoch: their dropout streams stay distinct
+ * through their seeds, but neither replays bit-identically if the other runs in between). */
 DGDM_API int dgdm_seed_epoch_advance(void* stream);
 DGDM_API int dgdm_seed_epoch_set(uint32_t value, void* stream);
 
@@ -272,6 +277,27 @@ DGDM_API int dgdm_act_dropout_fwd(const float* x, int64_t n, int32_t act, float 
                                   const uint8_t* decide, void* stream);
 DGDM_API int dgdm_act_dropout_bwd(const float* x, const float* dy, int64_t n, int32_t act, float drop_p, uint32_t seed,
                                   float* dx, const uint8_t* decide, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Dense layers with few rows (one row per graph or per timestep): the denoiser's time-embedding MLP
+ * (core/diffusion.py:87-91,147-163: Linear -> SiLU -> Linear), the time half of its first Linear folded
+ * into a per-graph bias (:165-170), GlobalAttentionPool's query / output projections
+ * (models/dgdm_model.py:596-615).  Exact fp32 on the VALU, fixed-order reductions, any M, N; K <= 2048.
+ *   dgdm_linear_small_fwd: y[m,n] = act(pre), pre = sum_k x[m,k] w[n,k] + b[n] (b nullable); `pre`
+ *                          (nullable, [M, N] row stride ldp) receives the pre-activation for the backward.
+ *   dgdm_linear_small_bwd: g = gy * act'(pre) (act = NONE: g = gy, pre may be NULL);
+ *                          dx[m,k] = sum_n g[m,n] w[n,k]; dw[n,k] = sum_m g[m,n] x[m,k]; db[n] = sum_m g[m,n];
+ *                          each of dx / dw / db is skipped when NULL; lddw lets dw be a column block of a
+ *                          larger gradient matrix.
+ * K8  dgdm_ddpm_step: one update of DiffusionLayer.sample (core/diffusion.py:255-273) over n floats
+ *   (n % 4 == 0):  x0 = (x - sqrt_one_minus_ac * eps) / sqrt_ac;  out = last ? x0 : sqrt_alpha * x0 + sqrt_var * z. */
+DGDM_API int dgdm_linear_small_fwd(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* b, int32_t M, int32_t N,
+                                   int32_t K, int32_t act, float* y, int64_t ldy, float* pre, int64_t ldp, void* stream);
+DGDM_API int dgdm_linear_small_bwd(const float* gy, int64_t ldg, const float* pre, int64_t ldp, int32_t act, const float* x,
+                                   int64_t ldx, const float* w, int64_t ldw, int32_t M, int32_t N, int32_t K, float* dx,
+                                   int64_t lddx, float* dw, int64_t lddw, float* db, void* stream);
+DGDM_API int dgdm_ddpm_step(const float* x, const float* eps, const float* z, int64_t n, float sqrt_one_minus_ac, float sqrt_ac,
+                            float sqrt_alpha, float sqrt_var, int32_t last, float* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Per-graph (segment) primitives; graph g owns the contiguous rows [ptr[g], ptr[g+1]) (ptr: int32

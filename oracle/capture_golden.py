@@ -14,6 +14,7 @@ Fixture inventory:
   G2b GraphEncoder(use_edge_features=False)              models/encoders.py as-is
   G4  MultiHeadAttention w/ float mask, SpatialAttention core/attention.py as-is
   G5  DiffusionLayer add_noise/predict_noise/forward/sample (2-D input)  as-is
+  G5b DiffusionLayer.sample at Base widths, 10 and 50 inference steps     as-is
   G6  FeatureEncoder, AdaptiveGraphPooling, GlobalAttentionPool          as-is
   G7  DynamicGraphLayer (R1), GraphEncoder (R1+R2), GraphUNet (R1+R5), full model
       forward/pretrain_step (R1-R5): reference leaf classes, repaired wiring
@@ -206,6 +207,31 @@ def g5_diffusion(ref):
         samp = dl.sample((n, C), torch.device("cpu"), num_inference_steps=steps)
     save("g5_diffusion", x0=x0, noise=noise, t=t, x_noisy=xn, pred=pred, gp=gp, gx0=gx0, gw0=gw0, gte=gte, temb=temb,
          x_init=x_init, step_noise=torch.stack(step_noise), sample=samp, steps=steps, T=T, **sd_np(dl))
+
+
+def sample_draws(n, C, steps, seed):
+    """The random draws of one DiffusionLayer.sample call, reproducible from a seed (the fixtures store the seed, not 49 noise
+    tensors): x_init, then one [n, C] normal tensor per non-final step."""
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(n, C, generator=g), [torch.randn(n, C, generator=g) for _ in range(steps - 1)]
+
+
+def g5b_sample_base(ref):
+    """DiffusionLayer.sample at DGDM-Base widths (node_dim 128, hidden 256, T = 10) on 300 rows, 10 and 50 inference steps
+    (50 > T: linspace(T-1, 0, 50).long() repeats timesteps, diffusion.py:238-240).  Weights = the oracle's seeded initialiser
+    (stored as a seed), draws = sample_draws(seed)."""
+    from . import dgdm_oracle as O
+    C, Hd, T, n = 128, 256, 10, 300
+    cfg = O.OracleConfig()
+    P = O.init_params(cfg, seed=5, perturb=0.05)
+    dl = ref.diffusion.DiffusionLayer(C, Hd, num_timesteps=T).eval()
+    missing = dl.load_state_dict({k[len("diffusion_layer."):]: v for k, v in P.items() if k.startswith("diffusion_layer.")}, strict=True)
+    out = {}
+    for steps in (10, 50):
+        x_init, noises = sample_draws(n, C, steps, 2520 + steps)
+        with injected_rng(randn=[x_init], randn_like=noises):
+            out[f"sample{steps}"] = dl.sample((n, C), torch.device("cpu"), num_inference_steps=steps)
+    save("g5b_sample_base", init_seed=5, init_perturb=0.05, n=n, C=C, T=T, draw_seed_base=2520, **out)
 
 
 def g6_small_modules(ref):
@@ -429,7 +455,7 @@ def main():
     ref = load_reference()
     print("reference modules loaded from", REF_ROOT)
     only = set(sys.argv[1:])
-    for fn in (g1_scheduler, g2_graph_conv, g2b_plain_encoder, g4_attention, g5_diffusion, g6_small_modules, g7_repaired):
+    for fn in (g1_scheduler, g2_graph_conv, g2b_plain_encoder, g4_attention, g5_diffusion, g5b_sample_base, g6_small_modules, g7_repaired):
         if not only or fn.__name__ in only:
             fn(ref)
 

@@ -152,8 +152,11 @@ def test_recorded_step_survives_eviction_of_the_device_constant_cache(monkeypatc
     assert step._graphs and len(step._held_constants) >= 2
     held = {t.data_ptr() for t in step._held_constants}
 
+    from dgdm_histopath_lab_amd import _lib
+
     def run():
-        torch.manual_seed(9)           # same masking / noise draws
+        torch.manual_seed(9)           # same masking / noise draws ...
+        _lib.check(_lib.load().dgdm_seed_epoch_set(41, _lib.stream_ptr(torch.device(DEV))), "dgdm_seed_epoch_set")   # ... and dropout masks
         loss = step(batch)
         return float(loss), [p.grad.clone() for p in m.parameters() if p.grad is not None]
     l0, g0 = run()

@@ -115,6 +115,23 @@ def test_g5_diffusion_layer_as_is():
     assert_close(s, g["sample"], 1e-4, "sample")
 
 
+def sample_draws(n, C, steps, seed):
+    """Same draws as oracle/capture_golden.py::sample_draws (the fixture stores the seed)."""
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(n, C, generator=g), [torch.randn(n, C, generator=g) for _ in range(steps - 1)]
+
+
+@pytest.mark.parametrize("steps", [10, 50])
+def test_g5b_sample_at_base_widths(steps):
+    """DiffusionLayer.sample of the reference (as-is) at node_dim 128 / hidden 256 / T 10, 10 and 50 inference steps."""
+    g = load_golden("g5b_sample_base")
+    P = O.init_params(O.OracleConfig(), seed=int(g["init_seed"]), perturb=float(g["init_perturb"]))
+    x_init, noises = sample_draws(int(g["n"]), int(g["C"]), steps, int(g["draw_seed_base"]) + steps)
+    with torch.no_grad():
+        s = O.ddpm_sample(P, O.diffusion_schedule(int(g["T"]), "cosine"), int(g["T"]), x_init, noises, steps)
+    assert_close(s, g[f"sample{steps}"], 1e-4, f"sample{steps}")
+
+
 def test_g6_feature_encoder_pool_attention_pool_as_is():
     g = load_golden("g6_feature_encoder")
     P = {"feature_encoder." + k: v.requires_grad_(True) for k, v in weights(g).items()}
