@@ -88,7 +88,7 @@ def projection_microbench(dev, iters=50):
     from dgdm_histopath_lab_amd import ops
     m, k, n = NODES * PER_GPU_BATCH, FEATS, 512
     x = torch.randn(m, k, device=dev); w = torch.randn(n, k, device=dev) / k ** 0.5; b = torch.randn(n, device=dev)
-    math = "bf16x3" if ops.GEMM_FWD_BACKEND == "bf16x3" else "fp32"
+    math = ops.GEMM_MATH
     y = torch.empty(m, n, device=dev)
     for _ in range(5):
         ops.gemm_nt_raw(x, w, b, out=y, math=math)

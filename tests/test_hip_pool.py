@@ -109,3 +109,39 @@ def test_pooling_module_matches_torch_path():
     ac, bc = pool(x, ei, ea, None, compact=True), None
     keep = a[1][0] >= 0
     assert torch.equal(ac[1], a[1][:, keep]) and torch.equal(ac[2], ea[keep])
+
+
+def test_relu_kernels_take_injected_decisions():
+    """`decide` (include/dgdm_hip.h): the ReLU kernels of the U-Net take the side of every kink from the caller's mask, forward and
+    backward -- checked against a float64 restatement that multiplies by the same mask, with ~1 % of the decisions deliberately
+    opposite to the sign of the pre-activation."""
+    from dgdm_histopath_lab_amd import ops
+    g = torch.Generator().manual_seed(5)
+    n, c, c2 = 777, 128, 64
+    x = torch.randn(n, c, generator=g); h = torch.randn(n, c2, generator=g); skip = torch.randn(n, c, generator=g)
+    w2 = torch.randn(1, c2, generator=g) / c2 ** 0.5; b2 = torch.randn(1, generator=g)
+    k = n // 2
+    flip = lambda t: (t > 0) ^ (torch.rand(t.shape, generator=g) < 0.01)
+    m_act, m_pool = flip(x), flip(h)
+    xd, hd, skd = (t.to(DEV).requires_grad_(True) for t in (x, h, skip))
+    w2d, b2d = w2.to(DEV).requires_grad_(True), b2.to(DEV).requires_grad_(True)
+    y = ops.act_dropout(xd, ops.ACT_RELU, decide=m_act)
+    s = ops.pool_score(hd, w2d, b2d, decide=m_pool)
+    perm, nmap = ops.topk_perm(s, k)
+    pooled = ops.pool_gather(y, s, perm, nmap, 1.0)
+    pre_up = torch.zeros(n, c).index_copy(0, perm.cpu(), pooled.detach().cpu()) + skip
+    m_up = flip(pre_up)
+    up = ops.unpool_add_relu(pooled, skd, nmap, decide=m_up)
+    gy = torch.randn(n, c, generator=g)
+    (up * gy.to(DEV)).sum().backward()
+    X, H, W2, B2, SK = (t.double().requires_grad_(True) for t in (x, h, w2, b2, skip))
+    yr = X * m_act
+    sr = torch.tanh(torch.nn.functional.linear(H * m_pool, W2, B2).squeeze(-1))
+    p = perm.cpu()
+    pooled_r = yr[p] * sr[p].unsqueeze(-1)
+    up_r = (torch.zeros(n, c, dtype=torch.float64).index_copy(0, p, pooled_r) + SK) * m_up
+    (up_r * gy.double()).sum().backward()
+    assert_close(y, yr, 1e-6, "relu"); assert_close(s, sr, 1e-5, "score"); assert_close(up, up_r, 1e-5, "unpool")
+    for name, a, b in (("dx", xd.grad, X.grad), ("dh", hd.grad, H.grad), ("dw2", w2d.grad, W2.grad), ("db2", b2d.grad, B2.grad),
+                       ("dskip", skd.grad, SK.grad)):
+        assert_close(a, b, 2e-5, name)
