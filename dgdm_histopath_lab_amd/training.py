@@ -113,6 +113,9 @@ class DGDMTrainer(nn.Module):
         self._graphed: Optional["GraphedPretrainStep"] = None
         self._optimizer: Optional[torch.optim.Optimizer] = None
         self._scheduler = None
+        # build-only: ``step_kwargs(global_step) -> dict`` of extra keyword arguments for ``model.pretrain_step`` (the random-draw /
+        # decision injection hooks of DGDMModel), so that a parity test can drive the trainer and a CPU checker with the same draws
+        self.step_kwargs = None
 
     # ------------------------------------------------------------------ logging sink
     def log(self, name: str, value, **_):
@@ -139,7 +142,8 @@ class DGDMTrainer(nn.Module):
         return self._finetune_step(batch, batch_idx)
 
     def _pretrain_step(self, batch, batch_idx: int = 0) -> torch.Tensor:
-        outputs = self.model.pretrain_step(batch, mask_ratio=self.masking_ratio)
+        extra = self.step_kwargs(self.global_step) if self.step_kwargs is not None else {}
+        outputs = self.model.pretrain_step(batch, mask_ratio=self.masking_ratio, **extra)
         total = outputs["total_pretrain_loss"]
         if self.contrastive_loss is not None and "node_embeddings" in outputs:
             c = self.contrastive_loss(outputs["node_embeddings"], batch.batch)

@@ -16,6 +16,7 @@ Fixture inventory:
   G5  DiffusionLayer add_noise/predict_noise/forward/sample (2-D input)  as-is
   G5b DiffusionLayer.sample at Base widths, 10 and 50 inference steps     as-is
   G6  FeatureEncoder, AdaptiveGraphPooling, GlobalAttentionPool          as-is
+  G9  ClassificationHead / RegressionHead forward + every compute_loss branch   models/decoders.py as-is
   G7  DynamicGraphLayer (R1), GraphEncoder (R1+R2), GraphUNet (R1+R5), full model
       forward/pretrain_step (R1-R5): reference leaf classes, repaired wiring
 All modules run in eval() (dropout off); random draws are injected by temporarily
@@ -260,6 +261,59 @@ def g6_small_modules(ref):
     save("g6_attention_pool", x=xg, batch=batch, out=out, go=go, gx=gxg, gtok=gtok, **sd_np(gp))
 
 
+def g9_heads(ref):
+    """Task heads: models/decoders.py imports and runs as-is.  ClassificationHead / RegressionHead exactly as
+    DGDMModel constructs them (dgdm_model.py:168-184), eval mode with non-trivial BatchNorm statistics, every compute_loss branch;
+    plus one training-mode forward (batch statistics, dropout 0) with gradients."""
+    dec = importlib.import_module("dgdm_histopath.models.decoders")
+    torch.manual_seed(29)
+    C, ncls, ntgt, B = 128, 5, 3, 6
+    g = torch.Generator().manual_seed(291)
+    x = torch.randn(B, C, generator=g)
+    y = torch.randint(0, ncls, (B,), generator=g)
+    tgt = torch.randn(B, ntgt, generator=g)
+    cw = torch.rand(ncls, generator=g) + 0.5
+    out = dict(x=x, y=y, targets=tgt, class_weights=cw)
+
+    def trained_stats(bn, seed):
+        gg = torch.Generator().manual_seed(seed)
+        bn.running_mean.copy_(0.3 * torch.randn(bn.num_features, generator=gg)); bn.running_var.copy_(0.5 + torch.rand(bn.num_features, generator=gg))
+
+    cls = dec.ClassificationHead(C, ncls, hidden_dims=[C // 2], dropout=0.1, activation="gelu").eval(); randomize_(cls, 292)
+    with torch.no_grad():
+        trained_stats(cls.classifier[1], 293)
+    xg = x.clone().requires_grad_(True)
+    logits = cls(xg)
+    out.update(cls_logits=logits, cls_loss=cls.compute_loss(logits, y), cls_pred=cls.predict(x), cls_probs=cls.predict(x, return_probs=True))
+    gx, gw = grads_of(cls.compute_loss(logits, y), [xg, cls.classifier[0].weight])
+    out.update(cls_gx=gx, cls_gw0=gw, **sd_np(cls, "cls."))
+    cls_w = dec.ClassificationHead(C, ncls, hidden_dims=[C // 2], class_weights=cw).eval(); cls_w.load_state_dict(cls.state_dict(), strict=False)
+    out["cls_loss_weighted"] = cls_w.compute_loss(cls_w(x), y)
+    cls_s = dec.ClassificationHead(C, ncls, hidden_dims=[C // 2], label_smoothing=0.1).eval(); cls_s.load_state_dict(cls.state_dict())
+    out["cls_loss_smooth"] = cls_s.compute_loss(cls_s(x), y)
+    # training mode: BatchNorm batch statistics (dropout 0 so that no draw is involved)
+    cls_t = dec.ClassificationHead(C, ncls, hidden_dims=[C // 2], dropout=0.0).train(); cls_t.load_state_dict(cls.state_dict())
+    xt = x.clone().requires_grad_(True)
+    lt = cls_t(xt)
+    gxt, gwt = grads_of(cls_t.compute_loss(lt, y), [xt, cls_t.classifier[4].weight])
+    out.update(cls_train_logits=lt, cls_train_gx=gxt, cls_train_gw4=gwt, cls_train_running_mean=cls_t.classifier[1].running_mean,
+               cls_train_running_var=cls_t.classifier[1].running_var)
+
+    reg = dec.RegressionHead(C, ntgt, hidden_dims=[C // 2], dropout=0.1, activation="gelu").eval(); randomize_(reg, 294)
+    with torch.no_grad():
+        trained_stats(reg.feature_layers[1], 295)
+    xr = x.clone().requires_grad_(True)
+    pr = reg(xr)
+    out.update(reg_out=pr, **{f"reg_loss_{k}": reg.compute_loss(pr, tgt, k) for k in ("mse", "mae", "huber")}, **sd_np(reg, "reg."))
+    gxr, gwr = grads_of(reg.compute_loss(pr, tgt), [xr, reg.mean_head.weight])
+    out.update(reg_gx=gxr, reg_gwm=gwr)
+    regu = dec.RegressionHead(C, ntgt, hidden_dims=[C // 2], output_activation="softplus", predict_uncertainty=True).eval(); randomize_(regu, 296)
+    pu = regu(x)
+    out.update(regu_mean=pu["mean"], regu_var=pu["var"], regu_log_var=pu["log_var"], regu_nll=regu.compute_loss(pu, tgt, "gaussian_nll"),
+               regu_mse=regu.compute_loss(pu, tgt, "mse"), **sd_np(regu, "regu."))
+    save("g9_heads", **out)
+
+
 # -- repaired wiring around reference leaf classes (R2, R5) -------------------------------------
 def build_repaired_model(ref, cfg):
     """Reference DGDMModel with (R2) dim_proj wrappers in the graph encoder, (R5a/b) a
@@ -455,7 +509,7 @@ def main():
     ref = load_reference()
     print("reference modules loaded from", REF_ROOT)
     only = set(sys.argv[1:])
-    for fn in (g1_scheduler, g2_graph_conv, g2b_plain_encoder, g4_attention, g5_diffusion, g5b_sample_base, g6_small_modules, g7_repaired):
+    for fn in (g1_scheduler, g2_graph_conv, g2b_plain_encoder, g4_attention, g5_diffusion, g5b_sample_base, g6_small_modules, g7_repaired, g9_heads):
         if not only or fn.__name__ in only:
             fn(ref)
 

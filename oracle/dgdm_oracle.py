@@ -60,6 +60,9 @@ class OracleConfig:
     pooling: str = "attention"
     strict_reference: bool = True
     unet_depth: int = 3  # models/dgdm_model.py:154
+    activation: str = "gelu"
+    num_classes: Optional[int] = None     # models/dgdm_model.py:168-175 (heads)
+    regression_targets: int = 0           # models/dgdm_model.py:177-184
 
     def encoder_dims(self):
         dims = [self.hidden_dims[0]] + list(self.hidden_dims)  # encoders.py:173
@@ -139,7 +142,34 @@ def param_shapes(cfg: OracleConfig) -> Dict[str, tuple]:
         s["global_pool.global_token"] = (1, 1, C)
         for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
             s[f"global_pool.attention.{n}.weight"] = (C, C); s[f"global_pool.attention.{n}.bias"] = (C,)
+    # task heads (models/decoders.py:54-75,213-231 as DGDMModel builds them, dgdm_model.py:168-184: hidden_dims=[C // 2],
+    # BatchNorm1d after the hidden Linear).  Sequential indices: 0 Linear, 1 BatchNorm1d, 2 act, 3 Dropout, 4 Linear.
+    if cfg.num_classes is not None:
+        p = "classification_head.classifier"
+        s[f"{p}.0.weight"] = (C // 2, C); s[f"{p}.0.bias"] = (C // 2,)
+        s[f"{p}.1.weight"] = (C // 2,); s[f"{p}.1.bias"] = (C // 2,)
+        s[f"{p}.4.weight"] = (cfg.num_classes, C // 2); s[f"{p}.4.bias"] = (cfg.num_classes,)
+    if cfg.regression_targets > 0:
+        p = "regression_head"
+        s[f"{p}.feature_layers.0.weight"] = (C // 2, C); s[f"{p}.feature_layers.0.bias"] = (C // 2,)
+        s[f"{p}.feature_layers.1.weight"] = (C // 2,); s[f"{p}.feature_layers.1.bias"] = (C // 2,)
+        s[f"{p}.mean_head.weight"] = (cfg.regression_targets, C // 2); s[f"{p}.mean_head.bias"] = (cfg.regression_targets,)
     return s
+
+
+def batchnorm_buffers(cfg: OracleConfig, seed: int = 0, trained: bool = False) -> Dict[str, Tensor]:
+    """running_mean / running_var / num_batches_tracked of the heads' BatchNorm1d layers (state_dict buffers).  Fresh modules
+    hold (0, 1, 0); ``trained=True`` draws non-trivial statistics so that eval-mode parity exercises them."""
+    C2 = cfg.hidden_dims[-1] // 2
+    out: Dict[str, Tensor] = {}
+    pres = (["classification_head.classifier.1"] if cfg.num_classes is not None else []) + \
+           (["regression_head.feature_layers.1"] if cfg.regression_targets > 0 else [])
+    for i, pre in enumerate(pres):
+        g = torch.Generator().manual_seed(seed * 7919 + 31 + i)
+        out[f"{pre}.running_mean"] = 0.3 * torch.randn(C2, generator=g) if trained else torch.zeros(C2)
+        out[f"{pre}.running_var"] = 0.5 + torch.rand(C2, generator=g) if trained else torch.ones(C2)
+        out[f"{pre}.num_batches_tracked"] = torch.tensor(7 if trained else 0)
+    return out
 
 
 def init_params(cfg: OracleConfig, seed: int = 0, dtype=torch.float32, perturb: float = 0.0) -> Dict[str, Tensor]:
@@ -462,6 +492,47 @@ def attention_pool(P, x, ptr, H, p_drop=0.1, training=False, pre="global_pool"):
     return torch.cat(out, dim=0)
 
 
+def _head_act(name: str):
+    return {"relu": F.relu, "gelu": F.gelu, "elu": F.elu}.get(name, F.relu)   # decoders.py:57-64: unknown names fall back to ReLU
+
+
+def _head_features(P, lin: str, bn: str, x, act: str, p_drop: float, training: bool):
+    """Linear -> BatchNorm1d -> act -> Dropout (decoders.py:69-78 / 228-237).  eval: running statistics; training: batch
+    statistics (biased variance), as nn.BatchNorm1d."""
+    h = _lin(P, lin, x)
+    rm, rv = P.get(f"{bn}.running_mean"), P.get(f"{bn}.running_var")
+    if rm is None:
+        rm, rv = torch.zeros(h.shape[1], dtype=h.dtype), torch.ones(h.shape[1], dtype=h.dtype)
+    h = F.batch_norm(h, rm.detach().to(h.dtype).clone(), rv.detach().to(h.dtype).clone(), P[f"{bn}.weight"], P[f"{bn}.bias"], training, 0.1, 1e-5)
+    return _drop(_head_act(act)(h), p_drop, training)
+
+
+def classification_head(P, x, act="gelu", p_drop=0.1, training=False, pre="classification_head") -> Tensor:
+    """ClassificationHead.forward (models/decoders.py:89-99)."""
+    h = _head_features(P, f"{pre}.classifier.0", f"{pre}.classifier.1", x, act, p_drop, training)
+    return _lin(P, f"{pre}.classifier.4", h)
+
+
+def classification_loss(logits, targets, class_weights=None, label_smoothing: float = 0.0) -> Tensor:
+    """ClassificationHead.compute_loss (models/decoders.py:101-128)."""
+    if label_smoothing > 0:
+        logp = F.log_softmax(logits, dim=-1)
+        soft = torch.zeros_like(logp).scatter_(1, targets.unsqueeze(1), 1 - label_smoothing) + label_smoothing / logits.shape[1]
+        return -(soft * logp).sum(dim=-1).mean()
+    return F.cross_entropy(logits, targets, weight=class_weights)
+
+
+def regression_head(P, x, act="gelu", p_drop=0.1, training=False, pre="regression_head") -> Tensor:
+    """RegressionHead.forward (models/decoders.py:246-273), default construction (identity output activation, no variance head)."""
+    h = _head_features(P, f"{pre}.feature_layers.0", f"{pre}.feature_layers.1", x, act, p_drop, training)
+    return _lin(P, f"{pre}.mean_head", h)
+
+
+def regression_loss(pred, targets, loss_type="mse") -> Tensor:
+    """RegressionHead.compute_loss (models/decoders.py:275-315)."""
+    return {"mse": F.mse_loss, "mae": F.l1_loss, "huber": F.huber_loss}[loss_type](pred, targets)
+
+
 # --------------------------------------------------------------------------------------
 # whole model
 # --------------------------------------------------------------------------------------
@@ -539,6 +610,12 @@ def forward(P, cfg: OracleConfig, data, mode: str = "inference", *, training: bo
         out["graph_embedding"] = torch.stack([h[ptr[g]:ptr[g + 1]].max(0)[0] for g in range(B)])
     else:
         raise ValueError(cfg.pooling)
+    g = out["graph_embedding"]
+    if cfg.num_classes is not None and mode in ("inference", "finetune"):      # dgdm_model.py:383-391
+        out["classification_logits"] = classification_head(P, g, cfg.activation, cfg.dropout, training)
+        out["classification_probs"] = F.softmax(out["classification_logits"], dim=-1)
+    if cfg.regression_targets > 0 and mode in ("inference", "finetune"):
+        out["regression_outputs"] = regression_head(P, g, cfg.activation, cfg.dropout, training)
     if return_embeddings:
         out["node_embeddings"] = h
     if return_attention and attn_w is not None:

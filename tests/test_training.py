@@ -179,3 +179,147 @@ def test_trainer_runs_real_model_and_predicts(tmp_path):
     assert pa["num_nodes"] == 200 and pa["num_edges"] == 400
     assert (pa["graph_embedding"] == pb["graph_embedding"]).all()       # same weights, eval mode: bitwise reproducible
 
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hierarchical", [False, True])
+def test_loss_trajectory_matches_oracle_with_plain_adamw(hierarchical):
+    """SURVEY.md 8(f) N1, second pin: the first k pretraining steps of DGDMTrainer on the HIP path against the CPU oracle driven by
+    plain torch AdamW + CosineAnnealingLR with the reference's recipe (training/trainer.py:217-254: lr 1e-4 -> here 1e-3 to make
+    the weights move, weight_decay 1e-5, T_max = total steps, eta_min = 0.01 lr), the same injected draws on both sides (entity
+    mask, mask token, timesteps, noise, target; every dropout probability 0).  With the graph U-Net on, the oracle's ReLU / top-k
+    decisions of each step are handed to the kernels (conftest.check_decision_margins holds the differing ones to the margin)."""
+    import types
+    from conftest import assert_close, check_decision_margins, decisions_from_trace
+    from oracle import dgdm_oracle as O
+    from dgdm_histopath_lab_amd import DGDMModel
+    from dgdm_histopath_lab_amd.synthetic import synthetic_batch
+    from dgdm_histopath_lab_amd.training import DGDMTrainer, closed_form_lr
+    DEV, K, LR = "cuda:0", 6, 1e-3
+    cfgd = dict(node_features=64, hidden_dims=[64, 32, 32], num_diffusion_steps=10, attention_heads=2, dropout=0.0,
+                use_hierarchical=hierarchical)
+    cfg = O.OracleConfig(**cfgd)
+    P0 = O.init_params(cfg, seed=21, perturb=0.05)
+    batches = [synthetic_batch(50 + 7 * i, 2, 260 + 40 * i, 1000 + 160 * i, 64) for i in range(2)]     # two layouts, cycled
+    gen = torch.Generator().manual_seed(5)
+    draws = []
+    for i in range(K):
+        n = batches[i % 2].x.size(0)
+        draws.append(dict(timesteps=torch.randint(0, 10, (2,), generator=gen), noise=torch.randn(n, 32, generator=gen),
+                          noise_target=torch.randn(n, 32, generator=gen), mask_indices=torch.randperm(n, generator=gen)[: int(0.15 * n)],
+                          mask_token=torch.randn(64, generator=gen)))
+    # --- checker: float64 oracle + plain AdamW / cosine schedule on the CPU
+    P = {k: v.double().requires_grad_(True) for k, v in P0.items()}
+    opt = torch.optim.AdamW(list(P.values()), lr=LR, weight_decay=1e-5)
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=K, eta_min=LR * 0.01)
+    ref_losses, ref_traces = [], []
+
+    def oracle_step(i):
+        b = batches[i % 2]
+        b64 = types.SimpleNamespace(x=b.x.double(), edge_index=b.edge_index, edge_attr=b.edge_attr.double(), pos=b.pos.double(), batch=b.batch)
+        d = draws[i]
+        tro = {}
+        opt.zero_grad(set_to_none=True)
+        out = O.pretrain_step(P, cfg, b64, mask_indices=d["mask_indices"], mask_token=d["mask_token"].double(), timesteps=d["timesteps"],
+                              noise=d["noise"].double(), noise_target=d["noise_target"].double(), trace=tro)
+        out["total_pretrain_loss"].backward()
+        for p in P.values():            # dead parameters (D9) carry no gradient: AdamW skips them, as on the HIP side
+            pass
+        opt.step(); sched.step()
+        ref_losses.append(float(out["total_pretrain_loss"]))
+        return tro
+
+    # --- HIP trainer, fed the same draws (and, with the U-Net, the checker's decisions of the same step)
+    m = DGDMModel(**cfgd)
+    m.load_state_dict(P0, strict=True)
+    m = m.to(DEV)
+    tr = DGDMTrainer(m, learning_rate=LR, weight_decay=1e-5, pretrain_epochs=K, finetune_epochs=0, masking_ratio=0.15)
+    own_traces = []
+
+    def step_kwargs(i):
+        tro = oracle_step(i)
+        kw = {k: v.to(DEV) for k, v in draws[i].items()}
+        if hierarchical:
+            own_traces.append(({}, decisions_from_trace(tro)))
+            kw["trace"], kw["decisions"] = own_traces[-1]
+        return kw
+    tr.step_kwargs = step_kwargs
+    zero_p = [mod for mod in m.modules() if isinstance(mod, torch.nn.Dropout)]
+
+    def on_step(trainer, loss):
+        pass
+    # fit() switches the model to train(): dropout sites are disabled by probability, not by mode
+    for mod in zero_p:
+        mod.p = 0.0
+    losses = tr.fit([batches[0], batches[1]] * (K // 2), max_epochs=1, steps_per_epoch=K, on_step=on_step)
+    assert len(losses) == K == len(ref_losses)
+    for i, (a, b) in enumerate(zip(losses, ref_losses)):
+        assert abs(a - b) <= 1e-3 * max(1.0, abs(b)), (i, a, b)
+    for own, dec in own_traces:
+        check_decision_margins(own, dec)
+    # the parameters themselves after K optimizer steps, and the learning rate the schedule arrived at
+    named = dict(m.named_parameters())
+    moved = 0
+    gmax = max(float(v.grad.abs().max()) for v in P.values() if v.grad is not None)
+    for k, v in P.items():
+        if v.grad is None:
+            assert torch.equal(named[k].detach().cpu(), P0[k]), k      # dead parameters never move (no weight decay without a gradient)
+            continue
+        if float(v.grad.abs().max()) < 1e-9 * gmax:
+            # zero by construction (attention k_proj.bias: softmax is shift invariant): Adam divides rounding noise by its own
+            # magnitude, so the fp32 path random-walks by ~lr per step where exact arithmetic stays put; the loss cannot see it
+            continue
+        assert_close(named[k], v.detach(), 1e-3, "param " + k)
+        moved += 1
+    assert moved > 60
+    lr = float(tr.optimizers().param_groups[0]["lr"])
+    assert lr == pytest.approx(closed_form_lr(K, LR, K), rel=1e-5) and lr == pytest.approx(opt.param_groups[0]["lr"], rel=1e-6)
+
+
+@pytest.mark.gpu
+def test_predict_graph_values_and_reference_keyed_checkpoint(tmp_path):
+    """SURVEY.md 8(f) N2 at value level: every entry of predict_graph's dictionary (evaluation/predictor.py:188-257) equals what
+    `forward(mode="inference")` returned for the same graph; a checkpoint that holds exactly the REFERENCE's keys (its
+    save_model layout, trainer.py:348-358, no `graph_encoder.dim_proj.*`) loads with only the repair-R2 keys reported missing and
+    reproduces the oracle's outputs."""
+    import types
+    import numpy as np
+    from conftest import assert_close
+    from oracle import dgdm_oracle as O
+    from dgdm_histopath_lab_amd import DGDMModel
+    from dgdm_histopath_lab_amd.synthetic import synthetic_batch
+    from dgdm_histopath_lab_amd.training import DGDMTrainer, predict_graph
+    DEV = "cuda:0"
+    cfgd = dict(node_features=64, hidden_dims=[64, 32, 32], num_diffusion_steps=10, attention_heads=2, num_classes=4, regression_targets=2,
+                use_hierarchical=False)
+    cfg = O.OracleConfig(**cfgd)
+    P = {**O.init_params(cfg, seed=8, perturb=0.05), **O.batchnorm_buffers(cfg, seed=8, trained=True)}
+    ref_keys = {k: v for k, v in P.items() if ".dim_proj." not in k}                  # what a reference checkpoint can contain
+    f = tmp_path / "reference_layout.pt"
+    torch.save({"model_state_dict": ref_keys, "hyperparameters": {"learning_rate": 1e-4}, "epoch": 4, "global_step": 123}, str(f))
+    m = DGDMModel(**cfgd).to(DEV)
+    tr = DGDMTrainer(m)
+    info = tr.load_checkpoint(str(f))
+    assert sorted(info["missing_keys"]) == sorted(k for k in P if ".dim_proj." in k) and not info["unexpected_keys"]
+    assert tr.current_epoch == 4 and tr.global_step == 123
+    with torch.no_grad():                                                              # the R2 projections are the build's own: give the oracle the same
+        Pm = {**P, **{k: v.detach().cpu() for k, v in m.state_dict().items() if ".dim_proj." in k}}
+    one = synthetic_batch(5, 1, 333, 1300, 64)
+    pred = predict_graph(m, one, return_attention=True, return_embeddings=True)
+    m.eval()
+    with torch.no_grad():
+        out = m(one.to(DEV), mode="inference", return_attention=True, return_embeddings=True)
+    probs = out["classification_probs"].cpu().numpy()
+    assert np.array_equal(pred["classification_probs"], probs) and pred["predicted_class"] == int(probs.argmax())
+    assert pred["confidence"] == float(probs.max()) and all(pred[f"class_{i}_prob"] == float(probs[0, i]) for i in range(4))
+    reg = out["regression_outputs"].cpu().numpy()
+    assert np.array_equal(pred["regression_outputs"], reg) and all(pred[f"regression_target_{i}"] == float(reg[0, i]) for i in range(2))
+    assert np.array_equal(pred["graph_embedding"], out["graph_embedding"].cpu().numpy())
+    assert np.array_equal(pred["node_embeddings"], out["node_embeddings"].cpu().numpy())
+    assert np.array_equal(pred["attention_weights"][0], out["attention_weights"][0].cpu().numpy())
+    assert pred["num_nodes"] == 333 and pred["num_edges"] == 650
+    b64 = types.SimpleNamespace(x=one.x.double(), edge_index=one.edge_index, edge_attr=one.edge_attr.double(), pos=one.pos.double(), batch=one.batch)
+    with torch.no_grad():
+        ref = O.forward({k: (v.double() if v.is_floating_point() else v) for k, v in Pm.items()}, cfg, b64, "inference", return_embeddings=True)
+    for k in ("classification_probs", "regression_outputs", "graph_embedding", "node_embeddings"):
+        assert_close(out[k], ref[k], 1e-3, k)
