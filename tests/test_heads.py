@@ -102,7 +102,8 @@ def test_product_heads_match_reference_golden_gpu():
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode,training", [("finetune", True), ("inference", False)])
 def test_model_finetune_and_inference_outputs_match_oracle(mode, training):
-    """DGDMModel(num_classes=5, regression_targets=3) on 2 x 700-node graphs, Base widths, U-Net on: classification_logits /
+    """DGDMModel(num_classes=5, regression_targets=3) on 6 x 300-node graphs (training-mode BatchNorm over 2 rows would be
+    degenerate: both normalise to +-1 and the gradient through it is rounding noise), Base widths, U-Net on: classification_logits /
     probs, regression_outputs, graph_embedding against the float64 oracle; in finetune mode (training-mode BatchNorm = batch
     statistics, every dropout probability set to 0) also the supervised loss of trainer.py:130-175 and EVERY live gradient."""
     from dgdm_histopath_lab_amd import DGDMModel
@@ -113,8 +114,8 @@ def test_model_finetune_and_inference_outputs_match_oracle(mode, training):
     cfg = O.OracleConfig(**cfgd)
     P = O.init_params(cfg, seed=13, perturb=0.05)
     bufs = O.batchnorm_buffers(cfg, seed=13, trained=True)
-    batch = synthetic_batch(40, 2, 700, 2800)
-    y, rt = torch.tensor([1, 4]), torch.randn(2, 3, generator=torch.Generator().manual_seed(3))
+    batch = synthetic_batch(40, 6, 300, 1200)
+    y, rt = torch.tensor([1, 4, 0, 2, 2, 3]), torch.randn(6, 3, generator=torch.Generator().manual_seed(3))
     b64 = types.SimpleNamespace(x=batch.x.double(), edge_index=batch.edge_index, edge_attr=batch.edge_attr.double(), pos=batch.pos.double(),
                                 batch=batch.batch)
     P64 = {k: v.double().requires_grad_(True) for k, v in P.items()}
@@ -149,6 +150,14 @@ def test_model_finetune_and_inference_outputs_match_oracle(mode, training):
         if not v.requires_grad or v.grad is None or v.grad.abs().max() < 1e-12:
             continue
         assert named[k].grad is not None, k
+        if v.numel() <= 4 and k.endswith(".bias"):
+            # a scalar bias gradient (score MLP of a pooling level) is ONE signed sum over the nodes: when it nearly cancels its own
+            # magnitude is no yardstick; the weight of the same layer sums the same per-node terms and provides the scale
+            scale = float(P64[k[:-4] + "weight"].grad.abs().max())
+            err = float((named[k].grad.double().cpu() - v.grad).abs().max())
+            assert err <= 1e-3 * max(scale, float(v.grad.abs().max())), (k, err, scale)
+            live += 1
+            continue
         assert_close(named[k].grad, v.grad, 1e-3, "grad " + k); live += 1
     assert live > 100
 
