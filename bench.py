@@ -36,8 +36,19 @@ NODES, EDGES, FEATS, PER_GPU_BATCH = 10000, 50000, 768, 4
 MODEL_CFG = dict(node_features=FEATS, hidden_dims=[512, 256, 128], num_diffusion_steps=10, attention_heads=8)
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md, dense fp32 matrix peak
 FP16_MFMA_PEAK_TFLOPS = 2516.6  # MI355X_MICROARCH.md, dense fp16 matrix peak
-PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")  # tools/pmc_traffic.py, separate --pmc passes
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md, HBM3E spec
+
+
+def _latest_profile(stem):
+    """profiles/rNN_<stem>.json of the highest round that has one (the PMC passes are taken with rocprofv3 on the same bench command
+    and committed; bench.py only reads them)."""
+    import glob
+    c = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_{stem}.json")))
+    return c[-1] if c else None
+
+
+PMC_TRAFFIC = _latest_profile("pmc_traffic")   # tools/pmc_traffic.py, separate --pmc passes
+PMC_VALU = _latest_profile("pmc_valu")         # tools/pmc_valu.py, one --pmc pass
 
 
 def attention_flops(num_graph_nodes, heads, head_dim, products):
@@ -45,13 +56,34 @@ def attention_flops(num_graph_nodes, heads, head_dim, products):
     return sum(2.0 * n * n * heads * head_dim * products for n in num_graph_nodes)
 
 
+def _pmc_kernel(path, kernel):
+    """Entry of `kernel` in a committed PMC summary; template arguments may be spelled with or without blanks."""
+    try:
+        with open(path) as f:
+            ks = json.load(f)["kernels"]
+    except (OSError, KeyError, ValueError, TypeError):
+        return None
+    want = kernel.replace(" ", "")
+    for name, v in ks.items():
+        if name.replace(" ", "") == want:
+            return v
+    return None
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed PMC passes (same command, same sizes), or None."""
-    try:
-        with open(PMC_TRAFFIC) as f:
-            return json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
+    v = _pmc_kernel(PMC_TRAFFIC, kernel)
+    return None if v is None else v["hbm_bytes_per_launch"]
+
+
+def pmc_valu(kernel):
+    """VALU / matrix-pipe occupancy and the wave-cycle split of `kernel` from the committed PMC pass, or None."""
+    v = _pmc_kernel(PMC_VALU, kernel)
+    if v is None:
         return None
+    keep = ("valu_busy", "mfma_busy", "wave_cycles_active", "wave_cycles_issue_stalled", "wave_cycles_parked", "valu_share_of_active",
+            "valu_insts_per_launch", "mfma_insts_per_launch", "occupancy_waves_per_simd")
+    return dict({k: v[k] for k in keep if k in v}, source=os.path.relpath(PMC_VALU, ROOT))
 
 
 def gather_bytes(n, e, c):
@@ -59,7 +91,17 @@ def gather_bytes(n, e, c):
     return ent * c * 4 + n * c * 4 + ent * 8 + (n + 1) * 4
 
 
-def gather_microbench(dev, iters=200):
+def gather_unique_bytes(n, e, c):
+    """Cold-cache lower bound of the same launch: every table row read once, every output row written once, the index arrays."""
+    return n * c * 4 + n * c * 4 + (e + n) * 8 + (n + 1) * 4
+
+
+def gather_microbench(dev, iters=200, cold_iters=12):
+    """The north star's message-passing gather (one graph convolution's aggregation at 10k nodes x 768 features).
+    `achieved` / `frac`: SURVEY.md 8(d) algorithmic bytes over the mean of back-to-back launches -- the 30.7 MB table then lives
+    in L2 / Infinity Cache, so this is a cache-resident figure (it can exceed what HBM alone delivers).  `cold`: single launches,
+    each after a 1 GiB buffer was rewritten (L2 and the 256 MiB Infinity Cache evicted), priced both on the algorithmic bytes and
+    on the unique bytes (what HBM has to move at least)."""
     from dgdm_histopath_lab_amd import GraphStructure, ops
     from dgdm_histopath_lab_amd.synthetic import synthetic_graph
     g = synthetic_graph(0, NODES, EDGES, 8)
@@ -74,11 +116,27 @@ def gather_microbench(dev, iters=200):
         ops.spmm_raw(gs.rowptr, gs.col, gs.w, x, NODES, out=y)
     b.record(); torch.cuda.synchronize()
     us = a.elapsed_time(b) * 1e3 / iters
-    by = gather_bytes(NODES, EDGES, FEATS)
+    by, ub = gather_bytes(NODES, EDGES, FEATS), gather_unique_bytes(NODES, EDGES, FEATS)
+    evict = torch.zeros(256 * 1024 * 1024, dtype=torch.float32, device=dev)       # 1 GiB
+    cold = []
+    for _ in range(cold_iters):
+        evict.add_(1.0)
+        a.record()
+        ops.spmm_raw(gs.rowptr, gs.col, gs.w, x, NODES, out=y)
+        b.record(); torch.cuda.synchronize()
+        cold.append(a.elapsed_time(b) * 1e3)
+    del evict
+    cold.sort()
+    cus = cold[len(cold) // 2]
     return {"kernel": "dgdm_spmm (k_spmm<64,3,4>)", "workload": f"{NODES} nodes x {FEATS} feat, {EDGES}+{NODES} entries",
             "bound": "hbm", "achieved": round(by / us / 1e3, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": round(by / us / 1e3 / HBM_PEAK_GBPS, 4), "traffic": pmc_traffic("k_spmm<64, 3, 4>"), "us_per_launch": round(us, 2),
-            "algorithmic_bytes": by}
+            "frac": round(min(by / us / 1e3 / HBM_PEAK_GBPS, 1.0), 4), "traffic": pmc_traffic("k_spmm<64, 3, 4>"), "us_per_launch": round(us, 2),
+            "algorithmic_bytes": by, "unique_bytes": ub,
+            "note": "back-to-back launches: the table is re-read from L2 / Infinity Cache (cache-resident figure)",
+            "unique_bytes_GBps": round(ub / us / 1e3, 1), "unique_frac": round(ub / us / 1e3 / HBM_PEAK_GBPS, 4),
+            "cold": {"us_per_launch": round(cus, 2), "launches": cold_iters, "evicted_with": "1 GiB buffer rewritten before every launch",
+                     "algorithmic_GBps": round(by / cus / 1e3, 1), "algorithmic_frac": round(by / cus / 1e3 / HBM_PEAK_GBPS, 4),
+                     "unique_GBps": round(ub / cus / 1e3, 1), "unique_frac": round(ub / cus / 1e3 / HBM_PEAK_GBPS, 4)}}
 
 
 def projection_microbench(dev, iters=50):
@@ -100,23 +158,49 @@ def projection_microbench(dev, iters=50):
     us = a.elapsed_time(e) * 1e3 / iters
     fl = 2.0 * m * k * n
     tf = fl / us / 1e6
-    out = {"kernel": "dgdm_gemm_nt_bf16x3 (k_gemm3_rows<true,false>)" if math == "bf16x3" else "dgdm_gemm_nt (k_gemm_rows)",
-           "workload": f"[{m}, {k}] x [{n}, {k}]^T + bias", "bound": "mfma", "achieved": round(tf, 1), "peak": FP32_MFMA_PEAK_TFLOPS,
-           "unit": "TFLOP/s", "frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4), "us_per_launch": round(us, 1), "algorithmic_flop": fl,
+    bf = math == "bf16x3"
+    peak = FP16_MFMA_PEAK_TFLOPS if bf else FP32_MFMA_PEAK_TFLOPS      # the pipe the kernel runs on (bf16 dense peak = f16 dense peak)
+    out = {"kernel": "dgdm_gemm_nt_bf16x3 (k_gemm3_rows<true,false>)" if bf else "dgdm_gemm_nt (k_gemm_rows)",
+           "workload": f"[{m}, {k}] x [{n}, {k}]^T + bias", "bound": "mfma", "achieved": round(tf, 1), "peak": peak,
+           "unit": "TFLOP/s", "frac": round(tf / peak, 4), "us_per_launch": round(us, 1), "algorithmic_flop": fl,
+           "pipe": "bf16 dense matrix pipe (v_mfma_f32_32x32x16_bf16)" if bf else "fp32 matrix pipe",
            "traffic": None}   # the committed PMC pass averages this kernel over all shapes of a step: not comparable per launch
-    if math == "bf16x3":
+    if bf:
         out.update({"mfma_dtype": "bf16 x3 exact split, fp32 accumulate", "issued_tflops": round(6 * tf, 1),
-                    "issued_frac_of_bf16_peak": round(6 * tf / FP16_MFMA_PEAK_TFLOPS, 4)})
+                    "issued_frac": round(6 * tf / FP16_MFMA_PEAK_TFLOPS, 4), "fp32_equivalent_frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4)})
     return out
 
 
+def host_cpu():
+    """(model name, physical cores, logical cpus) of the host, from /proc/cpuinfo."""
+    model, cores = "unknown", set()
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name":
+                model = v
+            elif k == "physical id":
+                phys = v
+            elif k == "core id":
+                core = v
+            elif not k and phys is not None:
+                cores.add((phys, core)); phys = core = None
+    except OSError:
+        pass
+    logical = os.cpu_count() or 1
+    return model, (len(cores) or logical), logical
+
+
 def cpu_baseline(nodes, edges):
-    """CPU oracle (port of the reference path incl. its dense attention + dropout) on ONE slide,
-    one fwd+bwd step after one warm-up step at a reduced size."""
+    """CPU oracle (restatement of the reference path incl. its dense attention and dropout, training mode), SURVEY.md 8(d)
+    protocol: BASELINE configs[0] (ONE 2k-node / 8k-edge graph), 3 warm-up + 5 timed fwd+bwd steps, median -> `value`;
+    plus ONE step on one graph of the headline size.  Threads = physical cores of this host."""
     from oracle import dgdm_oracle as O
     from dgdm_histopath_lab_amd.synthetic import synthetic_batch
-    cores = os.cpu_count() or 1
-    threads = max(1, cores // 2) if cores > 16 else cores  # physical cores on SMT hosts
+    model, physical, logical = host_cpu()
+    threads = max(1, min(physical, logical))
     torch.set_num_threads(threads)
     cfg = O.OracleConfig(**MODEL_CFG)
     P = O.init_params(cfg, seed=0)
@@ -127,11 +211,17 @@ def cpu_baseline(nodes, edges):
         t0 = time.perf_counter()
         O.loss_and_grads(P, cfg, b, mask_indices=idx, mask_token=torch.randn(FEATS), training=True)
         return time.perf_counter() - t0
-    step(1000, 4000)  # warm-up (thread pool, allocator)
-    dt = step(nodes, edges)
-    return {"value": round(1.0 / dt, 5), "unit": "slides/s", "cores": threads, "kind": "port",
-            "sample": f"1 slide of {nodes} nodes / {edges} edges, 1 fwd+bwd step (training mode, dropout 0.1), "
-                      f"CPU oracle = restatement of the reference path, {dt:.1f} s"}
+    for _ in range(3):
+        step(2000, 8000)
+    ts = sorted(step(2000, 8000) for _ in range(5))
+    med = ts[2]
+    big = step(nodes, edges)
+    return {"value": round(1.0 / med, 4), "unit": "slides/s", "cores": threads, "kind": "port",
+            "sample": f"BASELINE configs[0]: 1 graph of 2000 nodes / 8000 edges, fwd+bwd (training mode, dropout 0.1), 3 warm-up + 5 timed "
+                      f"steps, median {med:.3f} s (min {ts[0]:.3f}, max {ts[-1]:.3f}); CPU oracle = restatement of the reference path",
+            "headline_size": {"value": round(1.0 / big, 5), "unit": "slides/s",
+                              "sample": f"1 graph of {nodes} nodes / {edges} edges, 1 fwd+bwd step, {big:.1f} s"},
+            "cpu": model, "physical_cores": physical, "logical_cpus": logical}
 
 
 def main():
@@ -144,6 +234,7 @@ def main():
     ap.add_argument("--edges", type=int, default=EDGES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--no-strict", action="store_true", help="skip the strict-fp32-attention leg")
     ap.add_argument("--eval-mode", action="store_true", help="dropout off (diagnostics only; not the headline)")
     ap.add_argument("--mixed", action="store_true",
                     help="BASELINE configs[4] shape instead of the headline: a stream of batches whose graphs have 1k..10k nodes "
@@ -210,15 +301,25 @@ def main():
     # rank r owns slides [r*B, (r+1)*B): independent units, no data-path collective
     batch = synthetic_batch(rank * args.batch, args.batch, args.nodes, args.edges, FEATS).to(dev)
     sizes = [args.nodes] * args.batch
-    stream = None
+    stream, balance_note = None, None
     if args.mixed:
+        # BASELINE configs[4]: per step a global pool of world x batch graphs with N ~ U{1k..10k}, E = 5 N, assigned to ranks by
+        # the cost-aware LPT sharding (parallel.balance_slides over parallel.slide_cost): attention cost grows with N^2, so equal
+        # COUNTS per rank would leave the ranks unbalanced.  Every rank draws the same pool (same seed) and keeps its own bin.
         from dgdm_histopath_lab_amd import GraphBatch
+        from dgdm_histopath_lab_amd.parallel import balance_slides, slide_cost
         from dgdm_histopath_lab_amd.synthetic import synthetic_graph
-        g = torch.Generator().manual_seed(77 + rank)
-        stream = []
+        g = torch.Generator().manual_seed(77)
+        stream, worst = [], 0.0
         for b in range(8):
-            ns = torch.randint(1000, 10001, (args.batch,), generator=g).tolist()
-            stream.append(GraphBatch.from_data_list([synthetic_graph(1000 * rank + 10 * b + i, n, 5 * n, FEATS) for i, n in enumerate(ns)]).to(dev))
+            ns = torch.randint(1000, 10001, (world * args.batch,), generator=g).tolist()
+            costs = [slide_cost(n, 5 * n) for n in ns]
+            bins = balance_slides(costs, world)
+            loads = [sum(costs[i] for i in bn) for bn in bins]
+            worst = max(worst, max(loads) / (sum(loads) / world))
+            mine = sorted(bins[rank])
+            stream.append(GraphBatch.from_data_list([synthetic_graph(100 * b + i, ns[i], 5 * ns[i], FEATS) for i in mine]).to(dev))
+        balance_note = {"sharding": "parallel.balance_slides (LPT on alpha N^2 + beta N + gamma E)", "max_over_mean_rank_load": round(worst, 4)}
         step_no = [0]
 
     def step():
@@ -235,10 +336,23 @@ def main():
         return out["total_pretrain_loss"]
 
     graph_note = None
-    if not args.eager and stream is None:
+    eager_step = step
+    if not args.eager and stream is not None and reducer is None:
+        # the 8 layouts of the stream recur: one recording per layout (training.GraphedStepCache)
+        from dgdm_histopath_lab_amd.training import GraphedStepCache
+        cache = GraphedStepCache(model, opt, mask_ratio=0.15, max_layouts=len(stream))
+
+        def step():
+            cur = stream[step_no[0] % len(stream)]
+            step_no[0] += 1
+            return cache(cur)
+        for _ in range(len(stream) * (cache.warmup + 2)):     # every layout primed and recorded: setup, not part of the W warmup steps
+            step()
+        graph_note = f"HIP graph replay, one recording per layout ({len(cache.steps)} layouts, training.GraphedStepCache)"
+    elif not args.eager and stream is None:
         from dgdm_histopath_lab_amd.training import GraphedPretrainStep
         gstep = GraphedPretrainStep(model, opt, mask_ratio=0.15, grad_reducer=reducer)
-        eager_step, graph_step = step, (lambda: gstep(batch))
+        graph_step = (lambda: gstep(batch))
         done = 0
         try:
             for _ in range(gstep.warmup + 1):     # eager priming + recording: setup, not part of the W warmup steps
@@ -264,7 +378,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     timed = ["attn_fwd", "attn_bwd_dq", "attn_bwd_dkv", "spmm_c512"]
-    graphed = not args.eager and stream is None
+    graphed = step is not eager_step
     if not graphed:
         ops.TIMERS.start(timed)
     t0 = time.perf_counter()
@@ -274,7 +388,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if graphed:
+    if graphed and stream is None:
         # kernels launched by a graph replay cannot be bracketed by events: the per-kernel durations of the roofline come
         # from eager launches of the same step right after the timed region (same kernels, same shapes, same clocks)
         ops.TIMERS.start(timed)
@@ -282,6 +396,26 @@ def main():
             eager_step()
         torch.cuda.synchronize()
     ops.TIMERS.stop()
+    # the same step at the reference's own arithmetic in the attention (fp32 MFMA kernels instead of split-fp16 operands):
+    # measured here, in the same process on the same box, so the two numbers are comparable
+    strict = None
+    if world == 1 and stream is None and not args.large and not args.eager and not args.no_strict and ops.ATTN_PRECISION == "fp16x2":
+        from dgdm_histopath_lab_amd.training import GraphedPretrainStep
+        prev = ops.configure(attention="fp32")
+        try:
+            g32 = GraphedPretrainStep(model, opt, mask_ratio=0.15)
+            for _ in range(g32.warmup + 1 + 2):
+                g32(batch)
+            n32 = max(5, min(args.steps, 20))
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            for _ in range(n32):
+                g32(batch)
+            torch.cuda.synchronize()
+            d32 = (time.perf_counter() - t1) / n32
+            strict = {"value": round(args.batch / d32, 3), "unit": "slides/s", "ms_per_step": round(d32 * 1e3, 3), "steps": n32,
+                      "attention": "fp32 operands on v_mfma_f32_16x16x4_f32 (csrc/attn_fwd.hip, attn_bwd.hip); everything else as in `value`"}
+        finally:
+            ops.configure(**prev)
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -297,32 +431,37 @@ def main():
         split = ops.ATTN_PRECISION == "fp16x2"
         kernels = ({"attn_fwd": "k_attn_h_fwd<4,1>", "attn_bwd_dq": "k_attn_h_bwd_dq<4,1,1>", "attn_bwd_dkv": "k_attn_h_bwd_dkv<2,2,1>"}
                    if split else {"attn_fwd": "k_attn_fwd<4,64>", "attn_bwd_dq": "k_attn_bwd_dq<4,64>", "attn_bwd_dkv": "k_attn_bwd_dkv<4,32>"})
-        dom = max((k for k in flops if k in timers), key=lambda k: timers[k][1])
-        ms = timers[dom][1]
-        tf = flops[dom] / (ms * 1e-3) / 1e12
-        # `achieved`: algorithmic fp32 FLOP of the reference's products (2*N^2*H*d each) per second, priced against
-        # the dense fp32 matrix peak (the arithmetic type of the path).  The split-fp16 kernels issue every product
-        # as two v_mfma_f32_16x16x32_f16 on [hi|lo] operand pairs = 4x the algorithmic FLOP on the fp16 pipe;
-        # `issued_*` prices THAT against the fp16 peak.  Neither pipe is the limiter: the kernel is bound by the
-        # softmax/dropout VALU work per score (attention section).
-        roofline = {"kernel": kernels[dom], "bound": "mfma", "achieved": round(tf, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4),
-                    "traffic": None if args.large else pmc_traffic(kernels[dom]),   # the PMC passes were taken on the headline workload
-                    "ms_per_launch": round(ms, 4), "launches_timed": timers[dom][0], "algorithmic_flop": flops[dom],
-                    "other_kernels_ms": {k: round(v[1], 4) for k, v in timers.items() if k != dom}}
-        roofline["timed_with"] = ("HIP events around eager launches of the same step right after the timed region (a graph replay "
-                                  "cannot carry events)" if graphed else "HIP events inside the timed region")
-        if args.mixed:   # launches differ in size from step to step: no single algorithmic FLOP count per launch
-            roofline = {"note": "not computed for the mixed-size stream; see the fixed-size headline run"}
-        elif split:
-            roofline.update({"mfma_dtype": "f16 hi+lo split, fp32 accumulate", "issued_flop": 4 * flops[dom],
-                             "issued_tflops": round(4 * tf, 1), "issued_frac_of_f16_peak": round(4 * tf / FP16_MFMA_PEAK_TFLOPS, 4),
-                             "limiter": "VALU (exp2, dropout hash, fp16 packing) -- see DESIGN.md"})
+        dom = max((k for k in flops if k in timers), key=lambda k: timers[k][1]) if any(k in timers for k in flops) else None
+        roofline = {"note": "not computed for this run; see the fixed-size headline run"}
+        if dom is not None and not args.mixed:
+            ms = timers[dom][1]
+            tf = flops[dom] / (ms * 1e-3) / 1e12
+            # `achieved`: ALGORITHMIC FLOP of the reference's products (2 N^2 H d each) per second of the dominant
+            # kernel, priced against the dense peak of the matrix pipe the kernel RUNS ON.  The split-fp16 kernels issue every
+            # product as two v_mfma_f32_16x16x32_f16 on [hi|lo] operand pairs (4x the algorithmic FLOP): `issued_*` is the pipe's
+            # real load; `fp32_equivalent_frac` relates the algorithmic rate to the fp32 matrix peak the reference's arithmetic
+            # would be bound by (it can exceed 1: these kernels do not use that pipe).  The limiter is the VALU (`valu`, PMC).
+            peak = FP16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
+            roofline = {"kernel": kernels[dom], "bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
+                        "frac": round(tf / peak, 4), "pipe": "f16 dense matrix pipe (v_mfma_f32_16x16x32_f16)" if split else "fp32 matrix pipe",
+                        "traffic": None if args.large else pmc_traffic(kernels[dom]),   # the PMC passes were taken on the headline workload
+                        "ms_per_launch": round(ms, 4), "launches_timed": timers[dom][0], "algorithmic_flop": flops[dom],
+                        "other_kernels_ms": {k: round(v[1], 4) for k, v in timers.items() if k != dom}}
+            roofline["timed_with"] = ("HIP events around eager launches of the same step right after the timed region (a graph replay "
+                                      "cannot carry events)" if graphed else "HIP events inside the timed region")
+            if split:
+                roofline.update({"mfma_dtype": "f16 hi+lo split operands, single-f16 P / dS, fp32 accumulate", "issued_flop": 4 * flops[dom],
+                                 "issued_tflops": round(4 * tf, 1), "issued_frac": round(4 * tf / FP16_MFMA_PEAK_TFLOPS, 4),
+                                 "fp32_equivalent_frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4)})
+            if not args.large:
+                roofline["valu"] = pmc_valu(kernels[dom])
         result = {
             "metric": "slides/sec (DGDM fwd+bwd, 10k-node/768-feat graphs)", "value": round(world * args.batch * args.steps / dt, 3),
             "unit": "slides/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": ("f32 (attention products: split-fp16 hi+lo operands, single-fp16 P / dS, fp32 accumulate; dense layers: exact 3-way bf16 "
+                      "split, fp32 accumulate)" if split else "f32 (dense layers: exact 3-way bf16 split, fp32 accumulate)"),
+            "data": "synthetic",
             "config": {"workload": (f"MIXED-SIZE STREAM (configs[4]): DGDM-Base pretrain_step fwd+bwd+AdamW, batch={args.batch} graphs of "
                                     f"1k..10k nodes (E = 5 N) per GPU, 8 batches cycled, feat={FEATS}, edge_attr=32, T=10, heads=8, "
                                     if args.mixed else
@@ -330,9 +469,13 @@ def main():
                                     f"graphs per GPU, feat={FEATS}, edge_attr=32, T={cfg['num_diffusion_steps']}, heads={cfg['attention_heads']}, ") +
                                    f"{'eval (dropout off)' if args.eval_mode else 'training mode (dropout 0.1)'}",
                        "global_batch": world * args.batch, "parallelism": f"dp{world}", "final_loss": round(loss_val, 5),
-                       "launch": "HIP graph replay (training.GraphedPretrainStep)" if graphed else (graph_note or "eager")},
+                       "launch": (graph_note or "HIP graph replay (training.GraphedPretrainStep)") if graphed else (graph_note or "eager")},
             "roofline": roofline,
         }
+        if balance_note is not None:
+            result["config"].update(balance_note)
+        if strict is not None:
+            result["strict_fp32"] = strict
     if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -245,8 +245,9 @@ class DGDMTrainer(nn.Module):
         """Runs ``max_epochs`` (default pretrain + finetune epochs) over ``train_loader`` (re-iterable;
         batches already on the model's device or exposing ``.to``).  ``grad_reducer``: an object
         with ``all_reduce()`` called between backward and the optimizer step (data parallel).
-        ``graphed``: replay the pretrain step from HIP graphs (GraphedPretrainStep) for batches that share the
-        layout of the first one; other batches and the finetune phase run eagerly.
+        ``graphed``: replay the pretrain step from HIP graphs -- one recording per recurring batch layout (GraphedStepCache);
+        with a ``grad_reducer`` one recording (GraphedPretrainStep) for the layout of the first batch, other layouts eagerly.
+        The finetune phase runs eagerly.
         Returns the per-step training losses."""
         max_epochs = self.pretrain_epochs + self.finetune_epochs if max_epochs is None else max_epochs
         if steps_per_epoch is None:
@@ -274,8 +275,11 @@ class DGDMTrainer(nn.Module):
                 loss = None
                 if graphed and self.current_phase == "pretrain":
                     if self._graphed is None:
-                        self._graphed = GraphedPretrainStep(self.model, self._optimizer, grad_reducer=grad_reducer,
-                                                            step_fn=lambda b: self._pretrain_step(b))
+                        # one rank: a recording per recurring layout; data parallel: one recording split around the collective
+                        self._graphed = (GraphedStepCache(self.model, self._optimizer, self.masking_ratio, step_fn=lambda b: self._pretrain_step(b))
+                                         if grad_reducer is None else
+                                         GraphedPretrainStep(self.model, self._optimizer, grad_reducer=grad_reducer,
+                                                             step_fn=lambda b: self._pretrain_step(b)))
                     try:
                         loss = self._graphed(batch)
                     except BatchLayoutError:    # another batch layout: eager step below
@@ -508,6 +512,45 @@ class GraphedPretrainStep:
             self.reducer.all_reduce()
             self._graphs[1].replay()
         return self._loss.clone()     # the recorded loss tensor is overwritten by the next replay
+
+
+class GraphedStepCache:
+    """Recorded steps for a stream of batches whose layouts RECUR (the same batch compositions epoch after epoch, a cycled
+    validation-style set, fixed-size batches): one ``GraphedPretrainStep`` per layout signature, least-recently-used eviction.
+    All recordings share the model, the optimizer and its state; each owns the activations and gradient buffers of its layout
+    (``param.grad`` points at the buffers of the layout recorded last -- with a gradient reducer use one recording, or eager steps).
+
+    A layout seen for the first time runs ``warmup`` eager steps (they are real training steps; the first one also creates the
+    layout's device constants, which a capture cannot), is recorded on the next, and replays from then on.  Graph padding to
+    bucket sizes is NOT done: top-k pooling and attention are defined over the true node sets (graph_layers.py:306-310)."""
+
+    def __init__(self, model: nn.Module, optimizer: torch.optim.Optimizer, mask_ratio: float = 0.15, step_fn=None, max_layouts: int = 16,
+                 warmup: int = 1, validate: bool = True):
+        import collections
+        self.model, self.opt, self.mask_ratio, self.step_fn = model, optimizer, mask_ratio, step_fn
+        self.max_layouts, self.warmup, self.validate = max_layouts, warmup, validate
+        self.steps: "collections.OrderedDict" = collections.OrderedDict()
+        self.replays = self.eager = 0
+
+    def __call__(self, batch) -> torch.Tensor:
+        sig = GraphedPretrainStep._sig(batch)
+        st = self.steps.get(sig)
+        if st is None:
+            st = GraphedPretrainStep(self.model, self.opt, self.mask_ratio, warmup=self.warmup if self.steps else max(self.warmup, 2),
+                                     step_fn=self.step_fn, validate=self.validate)
+            self.steps[sig] = st
+            while len(self.steps) > self.max_layouts:
+                self.steps.popitem(last=False)
+        else:
+            self.steps.move_to_end(sig)
+        if st._graphs:
+            self.replays += 1
+        else:
+            self.eager += 1
+        return st(batch)
+
+    def set_lr(self, lr: float, group: int = 0) -> None:
+        self.opt.param_groups[group]["lr"].fill_(float(lr))
 
 
 def closed_form_lr(step: int, base_lr: float, total_steps: int, finetune_start_step: Optional[int] = None) -> float:
