@@ -1,16 +1,24 @@
 """Per-kernel summary of a rocprofv3 --kernel-trace run stored in rocpd (sqlite) format.
-usage: python tools/kernel_stats_from_db.py <results.db> <steps_kernel_substring> > profiles/<name>.txt
+usage: python tools/kernel_stats_from_db.py <results.db> <steps_kernel_substring> [max_rows] > profiles/<name>.txt
 The number of steps in the trace is taken as the launch count of the kernel whose name contains the given substring
-(one launch per step, e.g. k_attn_h_bwd_dkv)."""
+(one launch per step, e.g. k_attn_h_bwd_dkv).  The header also gives launches per step, the share of launches shorter than
+10 us, and the subtotal of kernels that are not this library's (torch element-wise / copy / fill / RNG / optimizer)."""
 import sqlite3
 import sys
 
 db, marker = sys.argv[1], sys.argv[2]
+max_rows = int(sys.argv[3]) if len(sys.argv) > 3 else 400
 c = sqlite3.connect(db)
 rows = c.execute("select name, count(*), avg(end-start)/1e3, sum(end-start)/1e6 from kernels group by name order by 4 desc").fetchall()
 steps = next(r[1] for r in rows if marker in r[0])
 total = sum(r[3] for r in rows)
+launches = sum(r[1] for r in rows)
+short = c.execute("select count(*), sum(end-start)/1e6 from kernels where end-start < 10000").fetchone()
+foreign = [r for r in rows if r[0].startswith(("void at::", "at::", "__amd_rocclr", "void rocprim", "rocprim", "Cijk_", "void hipcub"))
+           or "at::native" in r[0] or "Cijk_" in r[0]]
 print(f"# total kernel time {total:.2f} ms over {steps} steps = {total / steps:.2f} ms/step ({db})")
+print(f"# launches/step {launches / steps:.1f}; shorter than 10 us: {short[0] / steps:.1f} launches = {(short[1] or 0) / steps:.3f} ms/step; "
+      f"not this library's (torch/rocclr/library): {sum(r[1] for r in foreign) / steps:.1f} launches = {sum(r[3] for r in foreign) / steps:.3f} ms/step")
 print(f"{'kernel':92s} {'calls':>6s} {'avg_us':>9s} {'ms/step':>8s} {'%':>6s}")
-for name, calls, avg_us, ms in rows[:45]:
+for name, calls, avg_us, ms in rows[:max_rows]:
     print(f"{name[:92]:92s} {calls:6d} {avg_us:9.1f} {ms / steps:8.3f} {100 * ms / total:6.2f}")
