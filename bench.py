@@ -67,6 +67,10 @@ def _pmc_kernel(path, kernel):
     for name, v in ks.items():
         if name.replace(" ", "") == want:
             return v
+    base = want.split("<")[0] + "<"          # same kernel, another instantiation (the summary names what was profiled)
+    for name, v in ks.items():
+        if name.replace(" ", "").startswith(base):
+            return dict(v, profiled_instantiation=name)
     return None
 
 
@@ -82,7 +86,7 @@ def pmc_valu(kernel):
     if v is None:
         return None
     keep = ("valu_busy", "mfma_busy", "wave_cycles_active", "wave_cycles_issue_stalled", "wave_cycles_parked", "valu_share_of_active",
-            "valu_insts_per_launch", "mfma_insts_per_launch", "occupancy_waves_per_simd")
+            "valu_insts_per_launch", "mfma_insts_per_launch", "occupancy_waves_per_simd", "profiled_instantiation")
     return dict({k: v[k] for k in keep if k in v}, source=os.path.relpath(PMC_VALU, ROOT))
 
 
@@ -429,7 +433,7 @@ def main():
         flops = {"attn_fwd": attention_flops(sizes, heads, hd, 2), "attn_bwd_dq": attention_flops(sizes, heads, hd, 3),
                  "attn_bwd_dkv": attention_flops(sizes, heads, hd, 4)}
         split = ops.ATTN_PRECISION == "fp16x2"
-        kernels = ({"attn_fwd": "k_attn_h_fwd<4,1>", "attn_bwd_dq": "k_attn_h_bwd_dq<4,1,1>", "attn_bwd_dkv": "k_attn_h_bwd_dkv<2,2,1>"}
+        kernels = ({"attn_fwd": "k_attn_h_fwd<4,1,1,3>", "attn_bwd_dq": "k_attn_h_bwd_dq<4,1,1,1>", "attn_bwd_dkv": "k_attn_h_bwd_dkv<2,1,1,3>"}
                    if split else {"attn_fwd": "k_attn_fwd<4,64>", "attn_bwd_dq": "k_attn_bwd_dq<4,64>", "attn_bwd_dkv": "k_attn_bwd_dkv<4,32>"})
         dom = max((k for k in flops if k in timers), key=lambda k: timers[k][1]) if any(k in timers for k in flops) else None
         roofline = {"note": "not computed for this run; see the fixed-size headline run"}

@@ -93,7 +93,7 @@ SIGNATURES = {
     "dgdm_amax_scale_workspace_bytes": (_sz, []),
     "dgdm_amax_pow2_scale": (C.c_int, [_p, _i64, C.c_float, _p, _p, _sz, _p]),
     "dgdm_attn_pack": (C.c_int, [_p, _i64, _i32, _i32, _i32, C.c_float, _p, _p, _i32, _i32, _i32, _p, _p, _p, _p, _p, _i64, _p, _p]),
-    "dgdm_spatial_attn_h_fwd": (C.c_int, [_p, _p, _p, _p, _p, _i32, _i32, _i32, C.c_float, C.c_float, C.c_uint32, _p, _i64, _p, _p]),
+    "dgdm_spatial_attn_h_fwd": (C.c_int, [_p, _p, _p, _p, _p, _i32, _i32, _i32, C.c_float, C.c_float, C.c_uint32, _p, _i64, _p, _i32, _p]),
     "dgdm_spatial_attn_h_bwd_dq": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, C.c_float, C.c_float, C.c_float,
                                              C.c_uint32, _p, _p, _i64, _i32, _p]),
     "dgdm_spatial_attn_h_bwd_dkv": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, C.c_float, C.c_float,

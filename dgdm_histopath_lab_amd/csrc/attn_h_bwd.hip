@@ -15,8 +15,8 @@ constexpr float NEG_BIG = -1.0e30f;
 
 // ---------------------------------------------------------------------------------------- dQ
 // LDS per buffer: Rk | Rv | Tk | pos
-template <int HG, int NBUF, bool DROP>
-__global__ __launch_bounds__(256) void k_attn_h_bwd_dq(const _Float16* __restrict__ Rq, const _Float16* __restrict__ Rk,
+template <int HG, int NBUF, bool DROP, int WPE = 1>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) void k_attn_h_bwd_dq(const _Float16* __restrict__ Rq, const _Float16* __restrict__ Rk,
                                                        const _Float16* __restrict__ Rv, const _Float16* __restrict__ Tk,
                                                        const _Float16* __restrict__ Rg, const float* __restrict__ pos_b,
                                                        const float* __restrict__ lse2_b, const float* __restrict__ delta_b, int H,
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void k_attn_h_bwd_dq(const _Float16* __restric
   stage(0, 0);
 
   f16x8 qb1[HG], qb2[HG], gb1[HG], gb2[HG];
-  f32x4 dq[HG], dq2[HG];
+  f32x4 dq[HG];
   float nl2[HG], ndl[HG];
   uint32_t hq[HG];
   DropHead dh[HG];
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void k_attn_h_bwd_dq(const _Float16* __restric
     load_b_pair(Rg + rowoff * 32, G, &gb1[h], &gb2[h]);
     nl2[h] = -lse2_b[rowoff];
     ndl[h] = -delta_b[rowoff];
-    dq[h] = f32x4{0.f, 0.f, 0.f, 0.f}; dq2[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+    dq[h] = f32x4{0.f, 0.f, 0.f, 0.f};
     dh[h] = DropHead(seed, n0, head0 + h);
     hq[h] = attn_hq(dh[h], q_local);
   }
@@ -119,7 +119,8 @@ __global__ __launch_bounds__(256) void k_attn_h_bwd_dq(const _Float16* __restric
       for (int tp = 0; tp < NT / 2; ++tp) {
         const f16x8 dsb = pack8(ds[2 * tp], ds[2 * tp + 1]);
         dq[h] = mfma_h(load_t_pair(kt, j, 2 * tp, G), dsb, dq[h]);            // dQ^T[d=j][q] += K^T[d][key] dS^T[key][q]
-        dq2[h] = mfma_h(load_t_pair(kt + T_PART, j, 2 * tp, G), dsb, dq2[h]);
+        dq[h] = mfma_h(load_t_pair(kt + T_PART, j, 2 * tp, G), dsb, dq[h]);   // lo part of K: same accumulator (back-to-back
+                                                                               // MFMAs on one accumulator issue at full rate)
       }
     }
     __syncthreads();
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(256) void k_attn_h_bwd_dq(const _Float16* __restric
   if (q_ok) {
 #pragma unroll
     for (int h = 0; h < HG; ++h) {
-      const f32x4 o = (dq[h] + dq2[h]) * (scale * unscale_dev[1]);
+      const f32x4 o = dq[h] * (scale * unscale_dev[1]);
       *reinterpret_cast<float4*>(dQ + (int64_t)(n0 + q_local) * ldg + (head0 + h) * 16 + 4 * G) = make_float4(o[0], o[1], o[2], o[3]);
     }
   }
@@ -140,8 +141,8 @@ __global__ __launch_bounds__(256) void k_attn_h_bwd_dq(const _Float16* __restric
 
 // ------------------------------------------------------------------------------------- dK, dV
 // LDS per buffer: Rq | Rg | Tg | Tq | lse2 [HG][64] | delta [HG][64] | pos
-template <int HG, int NBUF, bool DROP>
-__global__ __launch_bounds__(256) void k_attn_h_bwd_dkv(const _Float16* __restrict__ Rq, const _Float16* __restrict__ Tq,
+template <int HG, int NBUF, bool DROP, int WPE = 1>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) void k_attn_h_bwd_dkv(const _Float16* __restrict__ Rq, const _Float16* __restrict__ Tq,
                                                         const _Float16* __restrict__ Rk, const _Float16* __restrict__ Rv,
                                                         const _Float16* __restrict__ Rg, const _Float16* __restrict__ Tg,
                                                         const float* __restrict__ pos_b, const float* __restrict__ lse2_b,
@@ -180,15 +181,15 @@ __global__ __launch_bounds__(256) void k_attn_h_bwd_dkv(const _Float16* __restri
   stage(0, 0);
 
   f16x8 kb1[HG], kb2[HG], vb1[HG], vb2[HG];
-  f32x4 dk[HG], dk2[HG], dv[HG], dv2[HG];
+  f32x4 dk[HG], dv[HG];
   DropHead hs[HG];
 #pragma unroll
   for (int h = 0; h < HG; ++h) {
     const int64_t rowoff = (((int64_t)blockIdx.x * H + head0 + h) * HB + k_in_blk);
     load_b_pair(Rk + rowoff * 32, G, &kb1[h], &kb2[h]);
     load_b_pair(Rv + rowoff * 32, G, &vb1[h], &vb2[h]);
-    dk[h] = f32x4{0.f, 0.f, 0.f, 0.f}; dk2[h] = f32x4{0.f, 0.f, 0.f, 0.f};
-    dv[h] = f32x4{0.f, 0.f, 0.f, 0.f}; dv2[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+    dk[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+    dv[h] = f32x4{0.f, 0.f, 0.f, 0.f};
     hs[h] = DropHead(seed, n0, head0 + h);
   }
   const float2 pk = *reinterpret_cast<const float2*>(pos_b + ((int64_t)blockIdx.x * HB + k_in_blk) * 2);
@@ -260,9 +261,9 @@ __global__ __launch_bounds__(256) void k_attn_h_bwd_dkv(const _Float16* __restri
         const f16x8 pb = pack8(p[2 * tp], p[2 * tp + 1]);
         const f16x8 dsb = pack8(ds[2 * tp], ds[2 * tp + 1]);
         dv[h] = mfma_h(load_t_pair(gt, j, 2 * tp, G), pb, dv[h]);              // dV^T[d=j][key] += dO^T[d][q] P[q][key]
-        dv2[h] = mfma_h(load_t_pair(gt + T_PART, j, 2 * tp, G), pb, dv2[h]);
+        dv[h] = mfma_h(load_t_pair(gt + T_PART, j, 2 * tp, G), pb, dv[h]);
         dk[h] = mfma_h(load_t_pair(qt, j, 2 * tp, G), dsb, dk[h]);             // dK^T[d=j][key] += Q'^T[d][q] dS[q][key]
-        dk2[h] = mfma_h(load_t_pair(qt + T_PART, j, 2 * tp, G), dsb, dk2[h]);
+        dk[h] = mfma_h(load_t_pair(qt + T_PART, j, 2 * tp, G), dsb, dk[h]);
       }
     }
     __syncthreads();
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(256) void k_attn_h_bwd_dkv(const _Float16* __restri
     for (int h = 0; h < HG; ++h) {
       const int64_t off = (int64_t)(n0 + k_local) * ldg + (head0 + h) * 16 + 4 * G;
       const float un = unscale_dev[1];
-      const f32x4 a = (dk[h] + dk2[h]) * (kscale * un), b = (dv[h] + dv2[h]) * un;
+      const f32x4 a = dk[h] * (kscale * un), b = dv[h] * un;
       *reinterpret_cast<float4*>(dK + off) = make_float4(a[0], a[1], a[2], a[3]);
       *reinterpret_cast<float4*>(dV + off) = make_float4(b[0], b[1], b[2], b[3]);
     }
@@ -306,13 +307,25 @@ extern "C" int dgdm_spatial_attn_h_bwd_dq(const void* Rq, const void* Rk, const 
       hipLaunchKernelGGL((k_attn_h_bwd_dq<HG, NBUF, false>), dim3(num_blocks, H / HG), dim3(256), 0, s, h16(Rq), h16(Rk),        \
                          h16(Rv), h16(Tk), h16(Rg), pos_b, lse2_b, delta_b, H, ptr, B, bscale, scale, grad_scale2, dQ, ldg, 0.f, dgdm_seed_arg(0u));         \
   } while (0)
+#define GOW(HG, NBUF, WPE)                                                                                                        \
+  do {                                                                                                                           \
+    if (drop_p > 0.f)                                                                                                            \
+      hipLaunchKernelGGL((k_attn_h_bwd_dq<HG, NBUF, true, WPE>), dim3(num_blocks, H / HG), dim3(256), 0, s, h16(Rq), h16(Rk), h16(Rv), \
+                         h16(Tk), h16(Rg), pos_b, lse2_b, delta_b, H, ptr, B, bscale, scale, grad_scale2, dQ, ldg, drop_p, dgdm_seed_arg(seed));             \
+    else                                                                                                                         \
+      hipLaunchKernelGGL((k_attn_h_bwd_dq<HG, NBUF, false, WPE>), dim3(num_blocks, H / HG), dim3(256), 0, s, h16(Rq), h16(Rk),        \
+                         h16(Rv), h16(Tk), h16(Rg), pos_b, lse2_b, delta_b, H, ptr, B, bscale, scale, grad_scale2, dQ, ldg, 0.f, dgdm_seed_arg(0u));         \
+  } while (0)
   if (H % 2 == 0 && variant == 1) GO(2, 2);
   else if (H % 4 == 0 && variant == 2) GO(4, 2);
   else if (H % 2 == 0 && variant == 3) GO(2, 1);
+  else if (H % 2 == 0 && variant == 4) GOW(2, 1, 4);
+  else if (H % 4 == 0 && variant == 5) GOW(4, 1, 3);
   else if (H % 4 == 0) GO(4, 1);
-  else if (H % 2 == 0) GO(2, 2);
+  else if (H % 2 == 0) GO(2, 1);
   else GO(1, 2);
 #undef GO
+#undef GOW
   return dgdm_launch_status();
 }
 
@@ -338,11 +351,23 @@ extern "C" int dgdm_spatial_attn_h_bwd_dkv(const void* Rq, const void* Tq, const
       hipLaunchKernelGGL((k_attn_h_bwd_dkv<HG, NBUF, false>), dim3(num_blocks, H / HG), dim3(256), 0, s, h16(Rq), h16(Tq), h16(Rk), \
                          h16(Rv), h16(Rg), h16(Tg), pos_b, lse2_b, delta_b, H, ptr, B, bscale, kscale, grad_scale2, dK, dV, ldg, 0.f, dgdm_seed_arg(0u));      \
   } while (0)
+#define GO3(HG, NBUF)                                                                                                              \
+  do {                                                                                                                             \
+    if (drop_p > 0.f)                                                                                                              \
+      hipLaunchKernelGGL((k_attn_h_bwd_dkv<HG, NBUF, true, 3>), dim3(num_blocks, H / HG), dim3(256), 0, s, h16(Rq), h16(Tq), h16(Rk),  \
+                         h16(Rv), h16(Rg), h16(Tg), pos_b, lse2_b, delta_b, H, ptr, B, bscale, kscale, grad_scale2, dK, dV, ldg, drop_p, dgdm_seed_arg(seed)); \
+    else                                                                                                                           \
+      hipLaunchKernelGGL((k_attn_h_bwd_dkv<HG, NBUF, false, 3>), dim3(num_blocks, H / HG), dim3(256), 0, s, h16(Rq), h16(Tq), h16(Rk), \
+                         h16(Rv), h16(Rg), h16(Tg), pos_b, lse2_b, delta_b, H, ptr, B, bscale, kscale, grad_scale2, dK, dV, ldg, 0.f, dgdm_seed_arg(0u));      \
+  } while (0)
   if (H % 4 == 0 && variant == 1) GO(4, 1);
   else if (H % 4 == 0 && variant == 2) GO(4, 2);
   else if (H % 2 == 0 && variant == 3) GO(2, 1);
-  else if (H % 2 == 0) GO(2, 2);   // default: 2 heads per group, double-buffered (lowest register pressure)
-  else GO(1, 2);
+  else if (H % 2 == 0 && variant == 4) GO3(2, 1);   // 3 workgroups per CU (registers capped at 168)
+  else if (H % 2 == 0 && variant == 5) GO3(2, 2);
+  else if (H % 2 == 0) GO3(2, 1);  // default: 2 heads per group, one staging buffer, registers capped at 168 => three workgroups
+  else GO(1, 2);                   // per CU (2.11 vs 2.22 ms for the double-buffered two-per-CU form at 4 x 10k nodes)
 #undef GO
+#undef GO3
   return dgdm_launch_status();
 }

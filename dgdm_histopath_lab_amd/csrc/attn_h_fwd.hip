@@ -95,8 +95,8 @@ __global__ __launch_bounds__(256) void k_attn_pack(const float* __restrict__ X, 
   *reinterpret_cast<f16x4*>(tb + T_PART + d * T_STRIDE + 4 * rc) = *reinterpret_cast<const f16x4*>(&sm[1][d][4 * rc]);
 }
 
-template <int HG, bool DROP>
-__global__ __launch_bounds__(256, 2) void k_attn_h_fwd(const _Float16* __restrict__ Rq, const _Float16* __restrict__ Rk,
+template <int HG, bool DROP, int NBUF = 2, int WPE = 2>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) void k_attn_h_fwd(const _Float16* __restrict__ Rq, const _Float16* __restrict__ Rk,
                                                     const _Float16* __restrict__ Tv, const float* __restrict__ pos_b, int H,
                                                     const int32_t* __restrict__ ptr, int B, float bscale, float* __restrict__ O,
                                                     int64_t ldo, float* __restrict__ lse2_b, float drop_p, DgdmSeed seed_in) {
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_h_fwd(const _Float16* __restric
   constexpr int NT = HB / 16;
   constexpr int RK_BYTES = HG * R_HEAD * 2, TV_BYTES = HG * T_HEAD * 2, POS_BYTES = HB * 8;
   constexpr int BUF_BYTES = RK_BYTES + TV_BYTES + POS_BYTES;
-  __shared__ __attribute__((aligned(16))) char smem[2 * BUF_BYTES];
+  __shared__ __attribute__((aligned(16))) char smem[NBUF * BUF_BYTES];
   const DropCfg dc(drop_p);
 
   int n0, ng, lblk, blk0;
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_h_fwd(const _Float16* __restric
   stage(0, 0);
 
   f16x8 qb1[HG], qb2[HG];
-  f32x4 oacc[HG], oacc2[HG], lacc[HG];  // lacc: every register = sum over keys of the ROUNDED weights (ones . P)
+  f32x4 oacc[HG], lacc[HG];  // lacc: every register = sum over keys of the ROUNDED weights (ones . P)
   float m[HG];
   uint32_t hq[HG];
   DropHead dh[HG];
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_h_fwd(const _Float16* __restric
 #pragma unroll
   for (int h = 0; h < HG; ++h) {
     load_b_pair(Rq + (((int64_t)blockIdx.x * H + head0 + h) * HB + q_in_blk) * 32, G, &qb1[h], &qb2[h]);
-    oacc[h] = f32x4{0.f, 0.f, 0.f, 0.f}; oacc2[h] = f32x4{0.f, 0.f, 0.f, 0.f}; lacc[h] = f32x4{0.f, 0.f, 0.f, 0.f}; m[h] = NEG_BIG;
+    oacc[h] = f32x4{0.f, 0.f, 0.f, 0.f}; lacc[h] = f32x4{0.f, 0.f, 0.f, 0.f}; m[h] = NEG_BIG;
     dh[h] = DropHead(seed, n0, head0 + h);
     hq[h] = attn_hq(dh[h], q_local);
   }
@@ -144,8 +144,8 @@ __global__ __launch_bounds__(256, 2) void k_attn_h_fwd(const _Float16* __restric
   __syncthreads();  // block 0 landed (vmcnt(0) + barrier)
 
   for (int kb = 0; kb < nbg; ++kb) {
-    const int buf = kb & 1;
-    if (kb + 1 < nbg) stage(kb + 1, buf ^ 1);  // lands under this block's math; its buffer was released by the last barrier
+    const int buf = NBUF == 2 ? (kb & 1) : 0;
+    if (NBUF == 2 && kb + 1 < nbg) stage(kb + 1, buf ^ 1);  // lands under this block's math; its buffer was released by the last barrier
     const _Float16* Kimg = reinterpret_cast<const _Float16*>(smem + buf * BUF_BYTES);
     const _Float16* Vimg = reinterpret_cast<const _Float16*>(smem + buf * BUF_BYTES + RK_BYTES);
     const float* Ps = reinterpret_cast<const float*>(smem + buf * BUF_BYTES + RK_BYTES + TV_BYTES);
@@ -193,7 +193,6 @@ __global__ __launch_bounds__(256, 2) void k_attn_h_fwd(const _Float16* __restric
         m[h] = m_new;
         lacc[h] *= alpha;
         oacc[h] *= alpha;
-        oacc2[h] *= alpha;
       }
       const float nm = -m[h];
       const f32x4 mh = {nm, nm, nm, nm};
@@ -223,10 +222,14 @@ __global__ __launch_bounds__(256, 2) void k_attn_h_fwd(const _Float16* __restric
           pb = __builtin_bit_cast(f16x8, __builtin_bit_cast(u32x4, pb) & mk);
         }
         oacc[h] = mfma_h(load_t_pair(vh, j, 2 * tp, G), pb, oacc[h]);
-        oacc2[h] = mfma_h(load_t_pair(vh + T_PART, j, 2 * tp, G), pb, oacc2[h]);
+        oacc[h] = mfma_h(load_t_pair(vh + T_PART, j, 2 * tp, G), pb, oacc[h]);   // lo part of V: same accumulator
       }
     }
     __syncthreads();  // everyone is done with `buf`; the DMA of the next block has landed
+    if (NBUF == 1 && kb + 1 < nbg) {   // single buffer: other workgroups of the CU (3 per CU) cover this load
+      stage(kb + 1, 0);
+      __syncthreads();
+    }
   }
 
 #pragma unroll
@@ -234,7 +237,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_h_fwd(const _Float16* __restric
     const float lt = lacc[h][0];
     const float inv = (DROP ? dc.keep : 1.0f) / lt;
     if (q_ok) {
-      const f32x4 os = oacc[h] + oacc2[h];
+      const f32x4 os = oacc[h];
       *reinterpret_cast<float4*>(O + (int64_t)(n0 + q_local) * ldo + (head0 + h) * 16 + 4 * G) =
           make_float4(os[0] * inv, os[1] * inv, os[2] * inv, os[3] * inv);
     }
@@ -295,7 +298,7 @@ extern "C" int dgdm_attn_pack(const float* X, int64_t ld, int32_t col0, int32_t 
 
 extern "C" int dgdm_spatial_attn_h_fwd(const void* Rq, const void* Rk, const void* Tv, const float* pos_b, const int32_t* ptr,
                                        int32_t B, int32_t num_blocks, int32_t H, float inv_tau, float drop_p, uint32_t seed, float* O,
-                                       int64_t ldo, float* lse2_b, void* stream_) {
+                                       int64_t ldo, float* lse2_b, int32_t variant, void* stream_) {
   DGDM_REQUIRE(B >= 0 && H > 0 && num_blocks >= 0 && drop_p >= 0.f && drop_p < 1.f);
   if (num_blocks == 0 || B == 0) return DGDM_OK;
   DGDM_REQUIRE(Rq && Rk && Tv && pos_b && ptr && O && lse2_b);
@@ -305,18 +308,24 @@ extern "C" int dgdm_spatial_attn_h_fwd(const void* Rq, const void* Rk, const voi
   hipStream_t s = static_cast<hipStream_t>(stream_);
   const float bscale = inv_tau * DGDM_LOG2E;
   const _Float16 *q = static_cast<const _Float16*>(Rq), *k = static_cast<const _Float16*>(Rk), *v = static_cast<const _Float16*>(Tv);
-#define GO(HG)                                                                                                              \
+#define GO(HG, NBUF, WPE)                                                                                                   \
   do {                                                                                                                      \
     if (drop_p > 0.f)                                                                                                       \
-      hipLaunchKernelGGL((k_attn_h_fwd<HG, true>), dim3(num_blocks, H / HG), dim3(256), 0, s, q, k, v, pos_b, H, ptr, B,    \
+      hipLaunchKernelGGL((k_attn_h_fwd<HG, true, NBUF, WPE>), dim3(num_blocks, H / HG), dim3(256), 0, s, q, k, v, pos_b, H, ptr, B,    \
                          bscale, O, ldo, lse2_b, drop_p, dgdm_seed_arg(seed));                                                             \
     else                                                                                                                    \
-      hipLaunchKernelGGL((k_attn_h_fwd<HG, false>), dim3(num_blocks, H / HG), dim3(256), 0, s, q, k, v, pos_b, H, ptr, B,   \
+      hipLaunchKernelGGL((k_attn_h_fwd<HG, false, NBUF, WPE>), dim3(num_blocks, H / HG), dim3(256), 0, s, q, k, v, pos_b, H, ptr, B,   \
                          bscale, O, ldo, lse2_b, 0.f, dgdm_seed_arg(0u));                                                                  \
   } while (0)
-  if (H % 4 == 0) GO(4);
-  else if (H % 2 == 0) GO(2);
-  else GO(1);
+  // variant 0 = default; 1..3 select a tiling explicitly (tools/microbench_attn.py)
+  if (H % 4 == 0 && variant == 1) GO(4, 2, 2);        // 4 heads, double-buffered, 2 workgroups per CU
+  else if (H % 4 == 0 && variant == 2) GO(4, 1, 3);   // 4 heads, single buffer, 3 workgroups per CU
+  else if (H % 2 == 0 && variant == 3) GO(2, 2, 4);   // 2 heads, double-buffered, 4 workgroups per CU
+  // default: 4 heads share one distance bias, ONE staging buffer, three workgroups per CU -- the other workgroups' math covers
+  // a workgroup's DMA wait better than its own second buffer did at two per CU (1.29 vs 1.46 ms at 4 x 10k nodes, dropout on)
+  else if (H % 4 == 0) GO(4, 1, 3);
+  else if (H % 2 == 0) GO(2, 2, 4);
+  else GO(1, 2, 2);
 #undef GO
   return dgdm_launch_status();
 }

@@ -48,20 +48,35 @@ __global__ __launch_bounds__(256) void k_linear_small_fwd(const float* __restric
   }
 }
 
-// dx[m, k] = sum_n g[m, n] w[n, k]; g = gy * act'(pre) when pre is given.  thread = column k, block row = m.
+// dx[m, k] = sum_n g[m, n] w[n, k]; g = gy * act'(pre) when pre is given.  Block = (64 columns k) x (4 slices of n): lane = column
+// (w rows are read 256 B at a time), wave = n slice with four independent accumulators; the slices meet in LDS in a fixed order.
 template <int ACT>
 __global__ __launch_bounds__(256) void k_linear_small_dx(const float* __restrict__ gy, int64_t ldg, const float* __restrict__ pre,
                                                          int64_t ldp, const float* __restrict__ w, int64_t ldw, int N, int K,
                                                          float* __restrict__ dx, int64_t lddx) {
-  const int k = blockIdx.x * 256 + threadIdx.x, m = blockIdx.y;
-  if (k >= K) return;
-  float acc = 0.f;
-  for (int n = 0; n < N; ++n) {
+  const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int k = blockIdx.x * 64 + lane, m = blockIdx.y;
+  const int per = (N + 3) / 4, n0 = part * per, n1 = min(N, n0 + per);
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  auto gval = [&](int n) {
     float g = gy[(int64_t)m * ldg + n];
     if (ACT != DGDM_ACT_NONE) g *= act_df<ACT>(pre[(int64_t)m * ldp + n]);
-    acc = fmaf(g, w[(int64_t)n * ldw + k], acc);
+    return g;
+  };
+  if (k < K) {
+    int n = n0;
+    for (; n + 3 < n1; n += 4) {
+      a0 = fmaf(gval(n), w[(int64_t)n * ldw + k], a0);
+      a1 = fmaf(gval(n + 1), w[(int64_t)(n + 1) * ldw + k], a1);
+      a2 = fmaf(gval(n + 2), w[(int64_t)(n + 2) * ldw + k], a2);
+      a3 = fmaf(gval(n + 3), w[(int64_t)(n + 3) * ldw + k], a3);
+    }
+    for (; n < n1; ++n) a0 = fmaf(gval(n), w[(int64_t)n * ldw + k], a0);
   }
-  dx[(int64_t)m * lddx + k] = acc;
+  __shared__ float sm[4][64];
+  sm[part][lane] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (part == 0 && k < K) dx[(int64_t)m * lddx + k] = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
 }
 
 // dw[n, k] = sum_m g[m, n] x[m, k] (thread = column k, block row = n; rows in index order); db[n] by the blocks with blockIdx.x == 0
@@ -135,7 +150,7 @@ extern "C" int dgdm_linear_small_bwd(const float* gy, int64_t ldg, const float* 
 #define GO(A)                                                                                                                    \
   do {                                                                                                                           \
     if (dx && M > 0)                                                                                                             \
-      hipLaunchKernelGGL((k_linear_small_dx<A>), dim3((K + 255) / 256, M), block, 0, st, gy, ldg, pre, ldp, w, ldw, N, K, dx, lddx); \
+      hipLaunchKernelGGL((k_linear_small_dx<A>), dim3((K + 63) / 64, M), block, 0, st, gy, ldg, pre, ldp, w, ldw, N, K, dx, lddx); \
     if (dw || db)                                                                                                                \
       hipLaunchKernelGGL((k_linear_small_dw<A>), dim3((K + 255) / 256, N), block, 0, st, gy, ldg, pre, ldp, x, ldx, M, K, dw, lddw, db); \
   } while (0)

@@ -254,7 +254,7 @@ def attn_pack(x, col0: int, cstride: int, ntensors: int, scale0: float, plan: At
 
 
 def spatial_attn_h_fwd_raw(qkv, pos, plan: AttnPlan, H: int, scale: float, inv_tau: float, drop_p: float = 0.0, seed: int = 0,
-                           packed: Optional[PackedOperands] = None):
+                           packed: Optional[PackedOperands] = None, variant: int = 0):
     """Split-fp16 forward over a fused [N, 3*H*16] QKV buffer; returns (out, lse2_b, packed)."""
     lib = _lib.load()
     N, C = qkv.size(0), H * 16
@@ -264,7 +264,7 @@ def spatial_attn_h_fwd_raw(qkv, pos, plan: AttnPlan, H: int, scale: float, inv_t
     TIMERS.timed("attn_fwd", lambda: _lib.check(
         lib.dgdm_spatial_attn_h_fwd(pk.r(0).data_ptr(), pk.r(1).data_ptr(), pk.t(2).data_ptr(), pk.pos_b.data_ptr(),
                                     plan.ptr_dev.data_ptr(), plan.B, plan.num_q_tiles, H, inv_tau, drop_p, seed, out.data_ptr(),
-                                    out.stride(0), lse2_b.data_ptr(), _lib.stream_ptr(qkv.device)), "dgdm_spatial_attn_h_fwd"))
+                                    out.stride(0), lse2_b.data_ptr(), variant, _lib.stream_ptr(qkv.device)), "dgdm_spatial_attn_h_fwd"))
     return out, lse2_b, pk
 
 

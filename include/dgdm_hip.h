@@ -219,7 +219,7 @@ DGDM_API int dgdm_attn_pack(const float* X, int64_t ld, int32_t col0, int32_t cs
  * fp32 (row stride ldo); lse2_b [blk][H][64] (log2-domain log-sum-exp, block layout). */
 DGDM_API int dgdm_spatial_attn_h_fwd(const void* Rq, const void* Rk, const void* Tv, const float* pos_b, const int32_t* ptr,
                                      int32_t B, int32_t num_blocks, int32_t H, float inv_tau, float drop_p, uint32_t seed, float* O,
-                                     int64_t ldo, float* lse2_b, void* stream);
+                                     int64_t ldo, float* lse2_b, int32_t variant, void* stream);
 /* backward: Rg/Tg = images of dO and delta_b = rowsum(dO*O) from a second dgdm_attn_pack call
  * (ntensors = 1, scale0 = 1, O given); lse2_b from the forward.  dQ/dK/dV fp32 [N_tot, H*16], row
  * stride ldg.  Same drop_p/seed as the forward.  grad_scale2 = the {alpha, 1/alpha} pair dO was packed

@@ -22,18 +22,19 @@ def t(fn, iters=10):
     return a.elapsed_time(b) / iters
 variants = [int(v) for v in os.environ.get("VARIANTS", "0").split(",")]
 for p in (0.0, 0.1):
-    for var in variants:
+    for var in ([] if os.environ.get("SPLIT_ONLY") else variants):
         ms = t(lambda: ops.spatial_attn_fwd_raw(qkv[:, :C], qkv[:, C:2*C], qkv[:, 2*C:], pos, plan, H, 0.25, 1.0, var, p, 123))
         print(json.dumps(dict(kernel="fwd", variant=var, drop=p, ms=round(ms, 3), TF=round(2 * fl / ms / 1e9, 1))))
     ms = t(lambda: ops.attn_pack(qkv, 0, C, 3, 0.25 * ops.LOG2E, plan, H, pos=pos))
     print(json.dumps(dict(kernel="attn_pack qkv", ms=round(ms, 3))))
     packed = ops.attn_pack(qkv, 0, C, 3, 0.25 * ops.LOG2E, plan, H, pos=pos)
-    ms = t(lambda: ops.spatial_attn_h_fwd_raw(qkv, pos, plan, H, 0.25, 1.0, p, 123, packed))
-    print(json.dumps(dict(kernel="fwd split-fp16", drop=p, ms=round(ms, 3), TF=round(2 * fl / ms / 1e9, 1))))
+    for var in (1, 2, 3):
+        ms = t(lambda: ops.spatial_attn_h_fwd_raw(qkv, pos, plan, H, 0.25, 1.0, p, 123, packed, var))
+        print(json.dumps(dict(kernel="fwd split-fp16", variant=var, drop=p, ms=round(ms, 3), TF=round(2 * fl / ms / 1e9, 1))))
     if os.environ.get("FWD_ONLY"): continue
     outh, lse2_b, pk = ops.spatial_attn_h_fwd_raw(qkv, pos, plan, H, 0.25, 1.0, p, 123, packed)
     dq2 = torch.empty_like(qkv)
-    for var in (0, 1, 2, 3):
+    for var in (0, 3, 4, 5):
         ops.TIMERS.start()
         for _ in range(6):
             ops.spatial_attn_h_bwd_raw(pk, outh, gout, plan, H, 0.25, 1.0, lse2_b, dq2, p, 123, var, var)
