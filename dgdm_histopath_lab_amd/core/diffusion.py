@@ -80,21 +80,26 @@ class DiffusionLayer(nn.Module):
         return F.pad(e, (0, 1)) if dim % 2 == 1 else e
 
     # -- batched (segment) forms: one timestep per graph, rows gathered with `seg` -----------
-    def add_noise_segments(self, x0: Tensor, noise: Tensor, timesteps: Tensor, seg: Tensor) -> Tensor:
+    def add_noise_segments(self, x0: Tensor, noise: Tensor, timesteps: Tensor, seg: Tensor, plan=None) -> Tensor:
         tab = self.scheduler.on(x0.device)
+        if plan is not None and x0.dim() == 2 and x0.size(1) % 4 == 0:          # one launch for the whole batch (csrc/diffusion_ops.hip)
+            return ops.qsample(x0, noise, timesteps, tab["sqrt_ac"], tab["sqrt_1mac"], plan)
         a, b = tab["sqrt_ac"][timesteps][seg].unsqueeze(-1), tab["sqrt_1mac"][timesteps][seg].unsqueeze(-1)
         return a * x0 + b * noise
+
+    def time_features(self, timesteps: Tensor) -> Tensor:
+        """time_embed(sinusoid(t)) (diffusion.py:147-163), [len(timesteps), hidden]."""
+        emb = self._embedding_table(timesteps.device).index_select(0, timesteps.reshape(-1))
+        te = ops.linear_small(emb, self.time_embed[0].weight, self.time_embed[0].bias, ops.ACT_SILU)
+        return ops.linear_small(te, self.time_embed[2].weight, self.time_embed[2].bias)
 
     def time_bias(self, timesteps: Tensor) -> Tensor:
         """Per-timestep bias of the first denoiser layer, [len(timesteps), 2*hidden]: ``time_embed`` of the sinusoid
         (diffusion.py:147-163) pushed through the time half of ``denoise_net[0]`` plus its bias -- the ``[x_t | t_emb]`` concat of
         diffusion.py:165-170 without the concat.  A few rows: the exact-fp32 small-M kernels (csrc/smallm.hip)."""
         C = self.node_dim
-        emb = self._embedding_table(timesteps.device).index_select(0, timesteps.reshape(-1))
-        te = ops.linear_small(emb, self.time_embed[0].weight, self.time_embed[0].bias, ops.ACT_SILU)
-        te = ops.linear_small(te, self.time_embed[2].weight, self.time_embed[2].bias)
         lin0 = self.denoise_net[0]
-        return ops.linear_small(te, lin0.weight[:, C:], lin0.bias)
+        return ops.linear_small(self.time_features(timesteps), lin0.weight[:, C:], lin0.bias)
 
     def _embedding_table(self, device) -> Tensor:
         """Sinusoidal embeddings of the T possible timesteps (diffusion.py:112-121), built once per device."""
@@ -118,14 +123,12 @@ class DiffusionLayer(nn.Module):
     def predict_noise_segments(self, x_noisy: Tensor, timesteps: Tensor, seg: Tensor, plan=None) -> Tensor:
         """x_noisy [N_tot, C]; timesteps [B]; seg [N_tot] graph id per row; ``plan`` (ops.AttnPlan)
         carries the per-graph row offsets for the segment kernels."""
-        C = self.node_dim
-        per_graph = self.time_bias(timesteps)                                         # [B, 2*hidden]
-        h = ops.linear(x_noisy, self.denoise_net[0].weight[:, :C])
         if plan is None:
             if timesteps.numel() != 1:
                 raise ValueError("predict_noise_segments needs the batch plan when graphs carry different timesteps")
             plan = ops.AttnPlan([0, x_noisy.size(0)], x_noisy.device)
-        h = ops.segment_bcast_add(h, per_graph, plan)
+        lin0 = self.denoise_net[0]
+        h = ops.denoise_first_layer(x_noisy, self.time_features(timesteps), lin0.weight, lin0.bias, plan)
         return self._denoise_tail(h)
 
     # -- reference-shaped API (same graph for every row) --------------------------------------

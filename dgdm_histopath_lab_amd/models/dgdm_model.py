@@ -304,16 +304,19 @@ class DGDMModel(nn.Module):
         if noise is None:
             noise = torch.randn_like(node_embeddings)
         dl = self.diffusion_layer
-        noisy = dl.add_noise_segments(node_embeddings, noise, timesteps, plan.seg)
+        noisy = dl.add_noise_segments(node_embeddings, noise, timesteps, plan.seg, plan.attn)
         pred = dl.predict_noise_segments(noisy, timesteps, plan.seg, plan.attn)
         if self.strict_reference:
             target = torch.randn_like(node_embeddings) if noise_target is None else noise_target
         else:
             target = noise
-        # mean over graphs of the per-graph MSE (dgdm_model.py:430-433)
-        sizes = ops.device_constant([plan.ptr[g + 1] - plan.ptr[g] for g in range(B)], torch.float32, dev)
-        w = (1.0 / (sizes * node_embeddings.size(1) * B))[plan.seg]
-        loss = (((pred - target) ** 2).sum(dim=1) * w).sum()
+        # mean over graphs of the per-graph MSE (dgdm_model.py:430-433): one fixed-order reduction over the batch
+        if pred.size(1) % 4 == 0:
+            loss = ops.segment_mse(pred, target, plan.attn)
+        else:
+            sizes = ops.device_constant([plan.ptr[g + 1] - plan.ptr[g] for g in range(B)], torch.float32, dev)
+            w = (1.0 / (sizes * node_embeddings.size(1) * B))[plan.seg]
+            loss = (((pred - target) ** 2).sum(dim=1) * w).sum()
         last = slice(plan.ptr[B - 1], plan.ptr[B])
         return {"diffusion_loss": loss, "noisy_embeddings": noisy[last].unsqueeze(0)}
 
@@ -346,7 +349,10 @@ class DGDMModel(nn.Module):
             if mask_indices is None and data.x.is_cuda and n < 2 ** 31:
                 _, node_map = ops.topk_perm(torch.rand(n, device=dev), num_masked)
                 node_mask = node_map >= 0
-                masked.x = torch.where(node_mask.unsqueeze(1), mask_token.to(data.x.dtype), data.x)
+                if data.x.dtype == torch.float32 and data.x.size(1) % 4 == 0:
+                    masked.x = ops.mask_rows(data.x, node_map, mask_token)
+                else:
+                    masked.x = torch.where(node_mask.unsqueeze(1), mask_token.to(data.x.dtype), data.x)
             else:
                 if mask_indices is None:
                     mask_indices = torch.randperm(n, device=dev)[:num_masked]

@@ -66,7 +66,9 @@ class FeatureEncoder(nn.Module):
             h = ops.lin(lin, h)
             h = _norm_act_dropout(h, norm, act, drop, self.training)
         if self.use_residual:
-            h = h + (ops.lin(self.residual_proj, x) if self.residual_proj is not None else x)
+            if self.residual_proj is not None:   # the projection's GEMM accumulates into h: no separate add
+                return ops.linear_add_into(h, x, self.residual_proj.weight, self.residual_proj.bias)
+            h = h + x
         return h
 
 

@@ -571,6 +571,82 @@ def act_dropout(x, act: int = ACT_NONE, drop_p: float = 0.0, training: bool = Fa
     return _ActDropout.apply(x, act, p, next_dropout_seed() if p > 0 else 0, _decide_arg(decide, x))
 
 
+class _QSample(torch.autograd.Function):
+    """x_t = sqrt(ac[t_g]) x0 + sqrt(1 - ac[t_g]) eps, t_g = the timestep of the row's graph (DiffusionLayer.add_noise,
+    core/diffusion.py:123-145, for a whole batch in one launch); d/dx0 = sqrt(ac[t_g])."""
+
+    @staticmethod
+    def forward(ctx, x0, eps, timesteps, tab_a, tab_b, plan: AttnPlan):
+        x0, eps = _f32c(x0), _f32c(eps)
+        ctx.save_for_backward(timesteps, tab_a)
+        ctx.plan = plan
+        return _qsample_raw(x0, eps, timesteps, tab_a, tab_b, plan)
+
+    @staticmethod
+    def backward(ctx, g):
+        timesteps, tab_a = ctx.saved_tensors
+        return _qsample_raw(_f32c(g), None, timesteps, tab_a, None, ctx.plan), None, None, None, None, None
+
+
+def _qsample_raw(x, eps, timesteps, tab_a, tab_b, plan: AttnPlan):
+    lib = _lib.load()
+    _lib.require_cuda(x, eps, timesteps, tab_a, tab_b)
+    if timesteps.dtype != torch.int64 or timesteps.numel() != plan.B:
+        raise ValueError(f"timesteps must be int64 [{plan.B}], got {timesteps.dtype} {tuple(timesteps.shape)}")
+    out = torch.empty_like(x)
+    _lib.check(lib.dgdm_qsample(x.data_ptr(), _lib.ptr(eps), tab_a.data_ptr(), _lib.ptr(tab_b), timesteps.contiguous().data_ptr(),
+                                plan.ptr_dev.data_ptr(), plan.B, x.size(0), x.size(1), out.data_ptr(), _lib.stream_ptr(x.device)), "dgdm_qsample")
+    return out
+
+
+def qsample(x0, eps, timesteps, tab_a, tab_b, plan: AttnPlan):
+    return _QSample.apply(x0, eps.detach(), timesteps, tab_a, tab_b, plan)
+
+
+class _SegmentMSE(torch.autograd.Function):
+    """mean over graphs of mse(pred_g, target_g) (models/dgdm_model.py:430-433) as one fixed-order reduction."""
+
+    @staticmethod
+    def forward(ctx, pred, target, plan: AttnPlan):
+        lib = _lib.load()
+        pred, target = _f32c(pred), _f32c(target)
+        _lib.require_cuda(pred, target)
+        loss = torch.empty((), dtype=torch.float32, device=pred.device)
+        wsb = _lib.workspace_bytes("dgdm_segment_mse_workspace_bytes", plan.B)
+        ws = torch.empty(max(wsb, 4) // 4, dtype=torch.float32, device=pred.device)
+        _lib.check(lib.dgdm_segment_mse_fwd(pred.data_ptr(), target.data_ptr(), plan.ptr_dev.data_ptr(), plan.B, pred.size(0), pred.size(1),
+                                            loss.data_ptr(), ws.data_ptr(), wsb, _lib.stream_ptr(pred.device)), "dgdm_segment_mse_fwd")
+        ctx.save_for_backward(pred, target)
+        ctx.plan = plan
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss):
+        lib = _lib.load()
+        pred, target = ctx.saved_tensors
+        plan = ctx.plan
+        gloss = _f32c(gloss.reshape(1))
+        dpred = torch.empty_like(pred)
+        _lib.check(lib.dgdm_segment_mse_bwd(pred.data_ptr(), target.data_ptr(), gloss.data_ptr(), plan.ptr_dev.data_ptr(), plan.B, pred.size(0),
+                                            pred.size(1), dpred.data_ptr(), _lib.stream_ptr(pred.device)), "dgdm_segment_mse_bwd")
+        return dpred, None, None
+
+
+def segment_mse(pred, target, plan: AttnPlan):
+    return _SegmentMSE.apply(pred, target.detach(), plan)
+
+
+def mask_rows(x, node_map, token):
+    """out[n] = token where node_map[n] >= 0 else x[n] (entity masking, models/dgdm_model.py:494-503); no gradient (inputs are data)."""
+    lib = _lib.load()
+    x, token = _f32c(x), _f32c(token)
+    _lib.require_cuda(x, node_map, token)
+    out = torch.empty_like(x)
+    _lib.check(lib.dgdm_mask_rows(x.data_ptr(), node_map.data_ptr(), token.data_ptr(), x.size(0), x.size(1), out.data_ptr(),
+                                  _lib.stream_ptr(x.device)), "dgdm_mask_rows")
+    return out
+
+
 def ddpm_step(x, eps, z, sqrt_one_minus_ac: float, sqrt_ac: float, sqrt_alpha: float, sqrt_var: float, last: bool, out=None):
     """One update of DiffusionLayer.sample (core/diffusion.py:255-273): x0 = (x - s*eps)/a; out = x0 or sqrt(alpha) x0 + sqrt(var) z."""
     lib = _lib.load()
@@ -755,9 +831,10 @@ def gemm_nn_raw(a, w, out=None, accumulate=False, math="fp32"):
     return out
 
 
-def gemm_tn_raw(dy, x, with_bias: bool, math="fp32", split: Optional[int] = None):
+def gemm_tn_raw(dy, x, with_bias: bool, math="fp32", split: Optional[int] = None, out: Optional[torch.Tensor] = None):
     """dW [N,K] = dy[M,N]^T x[M,K]; db [N] = colsum(dy) (fixed-order split-M reduction).
-    ``split=K0``: dW is delivered as two contiguous matrices (dW[:, :K0], dW[:, K0:]) -- returns ((dW0, dW1), db)."""
+    ``split=K0``: dW is delivered as two contiguous matrices (dW[:, :K0], dW[:, K0:]) -- returns ((dW0, dW1), db).
+    ``out``: write dW there (a [N, K] view with unit column stride, e.g. a column block of a wider gradient matrix)."""
     lib = _lib.load()
     dy, x = _rowmajor(dy), _rowmajor(x)
     M, N = dy.shape
@@ -766,7 +843,8 @@ def gemm_tn_raw(dy, x, with_bias: bool, math="fp32", split: Optional[int] = None
     wsb = _lib.workspace_bytes("dgdm_gemm_tn_workspace_bytes" if math == "fp32" else "dgdm_gemm_tn_bf16x3_workspace_bytes", M, N, K, int(with_bias))
     ws = torch.empty(max(wsb, 4) // 4, dtype=torch.float32, device=x.device)
     if split is None:
-        dW = torch.empty(N, K, dtype=torch.float32, device=x.device)
+        dW = torch.empty(N, K, dtype=torch.float32, device=x.device) if out is None else out
+        assert dW.shape == (N, K) and dW.stride(1) == 1
         fn = _gemm_entry(lib, "dgdm_gemm_tn", math)
         TIMERS.timed("gemm_tn", lambda: _lib.check(
             fn(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), dW.data_ptr(), dW.stride(0), _lib.ptr(db), M, N, K,
@@ -899,6 +977,101 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
         raise _lib.DGDMKernelError(f"no kernel for a [{x.size(0)}, {x.size(1)}] x [{weight.size(0)}, {weight.size(1)}]^T contraction "
                                    "(tile GEMMs need K, N % 4 == 0 and >= 256 rows; the small-M kernels K <= 2048)")
     return _LinearSmall.apply(x, weight, bias, ACT_NONE)
+
+
+class _LinearAddInto(torch.autograd.Function):
+    """acc + x w^T + b, accumulated by the GEMM's epilogue INTO ``acc`` (FeatureEncoder: encoder output + residual projection,
+    models/encoders.py:119-122) -- no separate element-wise add, no third [N, C] buffer."""
+
+    @staticmethod
+    def forward(ctx, acc, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias, ctx.math = b is not None, GEMM_MATH
+        gemm_nt_raw(x, w, b, out=acc, accumulate=True, math=GEMM_MATH)
+        ctx.mark_dirty(acc)
+        return acc
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gy = _rowmajor(gy)
+        dx = gemm_nn_raw(gy, w, math=ctx.math) if ctx.needs_input_grad[1] else None
+        dW = db = None
+        if ctx.needs_input_grad[2] or (ctx.has_bias and ctx.needs_input_grad[3]):
+            dW, db = gemm_tn_raw(gy, x, ctx.has_bias, math=ctx.math)
+        return gy, dx, dW, db
+
+
+def linear_add_into(acc: torch.Tensor, x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``acc += x @ weight^T + bias`` in place (returns ``acc``); falls back to a separate add for shapes outside the tile GEMMs."""
+    if (x.dim() == 2 and x.size(0) >= GEMM_MIN_ROWS and x.size(1) % 4 == 0 and weight.size(0) % 4 == 0 and acc.is_contiguous()
+            and acc.dtype == torch.float32 and not acc.is_leaf):
+        return _LinearAddInto.apply(acc, x, weight, bias)
+    return acc + linear(x, weight, bias)
+
+
+class _DenoiseFirstLayer(torch.autograd.Function):
+    """First Linear of the denoiser on [x_t | t_emb] (core/diffusion.py:165-170) without the concat:
+        h[n] = x_t[n] W[:, :C]^T + (te[g(n)] W[:, C:]^T + b)
+    as ONE autograd node, so that the gradient of W is written once, in place, as a whole matrix (the column block of the node half
+    by the split-M GEMM, the block of the time half by the small-M kernel) instead of two slice gradients that autograd pads and adds."""
+
+    @staticmethod
+    def forward(ctx, x, te, w, b, plan: AttnPlan):
+        lib = _lib.load()
+        x, te = _rowmajor(x), _rows(te)
+        C = x.size(1)
+        wx, wt = w[:, :C], w[:, C:]
+        pg, _ = linear_small_fwd_raw(te, wt, b)                                # [B, N_out]
+        h = gemm_nt_raw(x, wx, None, math=GEMM_MATH) if x.size(0) >= GEMM_MIN_ROWS else linear_small_fwd_raw(x, wx, None)[0]
+        out = torch.empty_like(h)
+        _lib.check(lib.dgdm_segment_bcast_add(h.data_ptr(), pg.data_ptr(), plan.ptr_dev.data_ptr(), plan.B, h.size(0), h.size(1), out.data_ptr(),
+                                              _lib.stream_ptr(x.device)), "dgdm_segment_bcast_add")
+        ctx.save_for_backward(x, te, w)
+        ctx.plan, ctx.math, ctx.has_bias = plan, GEMM_MATH, b is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        x, te, w = ctx.saved_tensors
+        plan, C = ctx.plan, x.size(1)
+        g = _rowmajor(g)
+        N_out, K = w.shape
+        dev = x.device
+        big = x.size(0) >= GEMM_MIN_ROWS
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = gemm_nn_raw(g, w[:, :C], math=ctx.math) if big else _small_dx(g, w[:, :C])
+        gpg = segment_sum_raw(g, plan)                                         # [B, N_out]: gradient of the per-graph bias
+        dw = torch.empty(N_out, K, dtype=torch.float32, device=dev)
+        if big:
+            gemm_tn_raw(g, x, False, math=ctx.math, out=dw[:, :C])
+        else:
+            _lib.check(lib.dgdm_linear_small_bwd(g.data_ptr(), _ld(g), None, 0, ACT_NONE, x.data_ptr(), _ld(x), None, 0, x.size(0), N_out, C,
+                                                 None, 0, dw.data_ptr(), K, None, _lib.stream_ptr(dev)), "dgdm_linear_small_bwd")
+        dte = torch.empty_like(te) if ctx.needs_input_grad[1] else None
+        db = torch.empty(N_out, dtype=torch.float32, device=dev) if ctx.has_bias else None
+        wt = w[:, C:]
+        _lib.check(lib.dgdm_linear_small_bwd(gpg.data_ptr(), _ld(gpg), None, 0, ACT_NONE, te.data_ptr(), _ld(te), wt.data_ptr(), _ld(wt), te.size(0),
+                                             N_out, K - C, _lib.ptr(dte), K - C, dw[:, C:].data_ptr(), K, _lib.ptr(db), _lib.stream_ptr(dev)),
+                   "dgdm_linear_small_bwd")
+        return dx, dte, dw, db, None
+
+
+def _small_dx(g, w):
+    lib = _lib.load()
+    g, w = _rows(g), _rows(w)
+    dx = torch.empty(g.size(0), w.size(1), dtype=torch.float32, device=g.device)
+    _lib.check(lib.dgdm_linear_small_bwd(g.data_ptr(), _ld(g), None, 0, ACT_NONE, None, 0, w.data_ptr(), _ld(w), g.size(0), w.size(0), w.size(1),
+                                         dx.data_ptr(), w.size(1), None, 0, None, _lib.stream_ptr(g.device)), "dgdm_linear_small_bwd")
+    return dx
+
+
+def denoise_first_layer(x, te, weight, bias, plan: AttnPlan):
+    if weight.size(0) % 4 or x.size(1) % 4 or (weight.size(1) - x.size(1)) > SMALL_MAX_K or not weight.is_contiguous():
+        raise _lib.DGDMKernelError("denoiser widths must be multiples of 4 (and the time embedding at most 2048 wide)")
+    return _DenoiseFirstLayer.apply(x, te, weight, bias, plan)
 
 
 def lin(module, x: torch.Tensor) -> torch.Tensor:

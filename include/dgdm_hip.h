@@ -312,6 +312,27 @@ DGDM_API size_t dgdm_segment_sum_workspace_bytes(int32_t B, int32_t C);
 DGDM_API int dgdm_segment_sum(const float* x, const int32_t* ptr, int32_t B, int32_t C, float* out, void* workspace,
                               size_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * K7 / K11  element-wise pieces of the diffusion objective and of entity masking, one launch for the whole batch
+ * (the reference: framework-op chains inside Python loops over graphs, models/dgdm_model.py:405-445,482-506;
+ * core/diffusion.py:123-145).  ptr: int32 DEVICE [B+1] graph offsets; timesteps: int64 DEVICE [B].
+ *   dgdm_qsample : out[n,:] = tab_a[t_g] * x[n,:] + tab_b[t_g] * eps[n,:]  (tab_a = sqrt(alphas_cumprod),
+ *                  tab_b = sqrt(1 - alphas_cumprod), DEVICE tables [T]); eps = NULL: out = tab_a[t_g] * x (the backward).
+ *   dgdm_segment_mse_fwd : loss[0] = (1/B) sum_g mse(pred_g, target_g) (dgdm_model.py:430-433), two fixed-order stages.
+ *   dgdm_segment_mse_bwd : dpred[n,:] = gloss[0] * 2 / (B n_g C) * (pred[n,:] - target[n,:])   (gloss: DEVICE scalar).
+ *   dgdm_mask_rows : out[n,:] = node_map[n] >= 0 ? token[:] : x[n,:]  (entity masking, dgdm_model.py:494-503, with the
+ *                  node_map of dgdm_topk_perm over N uniform variates = a uniformly random subset of the masked size).
+ * C, F % 4 == 0; float pointers 16-byte aligned. */
+DGDM_API int dgdm_qsample(const float* x, const float* eps, const float* tab_a, const float* tab_b, const int64_t* timesteps,
+                          const int32_t* ptr, int32_t B, int32_t N, int32_t C, float* out, void* stream);
+DGDM_API size_t dgdm_segment_mse_workspace_bytes(int32_t B);
+DGDM_API int dgdm_segment_mse_fwd(const float* pred, const float* target, const int32_t* ptr, int32_t B, int32_t N, int32_t C,
+                                  float* loss, void* workspace, size_t workspace_bytes, void* stream);
+DGDM_API int dgdm_segment_mse_bwd(const float* pred, const float* target, const float* gloss, const int32_t* ptr, int32_t B,
+                                  int32_t N, int32_t C, float* dpred, void* stream);
+DGDM_API int dgdm_mask_rows(const float* x, const int32_t* node_map, const float* token, int32_t N, int32_t F, float* out,
+                            void* stream);
+
 /* K10  GlobalAttentionPool (models/dgdm_model.py:588-615): per graph, ONE query (the projected,
  * 1/sqrt(D)-scaled global token, q_scaled [H*D]) attends over the graph's nodes:
  *   out[g,h,:] = sum_n dropout(softmax_n(q_h . K[n,h,:]))[n] * V[n,h,:]
