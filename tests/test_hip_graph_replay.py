@@ -149,7 +149,7 @@ def test_recorded_step_survives_eviction_of_the_device_constant_cache(monkeypatc
     torch.manual_seed(5)
     for _ in range(4):
         step(batch)
-    assert step._graphs and len(step._held_constants) >= 2
+    assert step._graphs and len(step._held_constants) >= 1
     held = {t.data_ptr() for t in step._held_constants}
 
     from dgdm_histopath_lab_amd import _lib
