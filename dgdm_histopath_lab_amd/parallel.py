@@ -1,5 +1,5 @@
 """Data-parallel harness for the DGDM hot path: one process per GPU, slides sharded across
-ranks, ONE all-reduce of a flat fp32 gradient buffer per step over RCCL/xGMI
+ranks, the live gradients exchanged through one flat fp32 buffer (two buckets) per step over RCCL/xGMI
 (`torch.distributed` backend "nccl" == RCCL on ROCm).
 
 The reference gets data parallelism implicitly from Lightning's DDP (cli/train.py:346-359) and
@@ -19,51 +19,166 @@ import torch.distributed as dist
 
 
 class FlatGradAllReducer:
-    """Average gradients across ranks with a single all-reduce.
+    """Average gradients across ranks through ONE persistent flat fp32 buffer, exchanged in two buckets.
 
-    The set of live parameters is fixed at the first call (same on every rank: same model, same
-    mode) and checked afterwards.  xGMI is point-to-point (7 links per GPU): one large message per
-    step keeps every link busy once instead of paying the per-collective latency ~100 times."""
+    * The set of live parameters is fixed at the first call (same on every rank: same model, same mode) and checked
+      afterwards; dead parameters (D9) never enter the buffer.  They are laid out in the ORDER THEIR GRADIENTS COMPLETED in that
+      first backward (post-accumulate hooks), i.e. last layers first: bucket 0 = the first ``bucket_split`` of the bytes is
+      complete while the backward still runs through the encoder.
+    * From the second step on (eager mode) a hook on the last parameter of bucket 0 packs that bucket and starts its all-reduce
+      ASYNCHRONOUSLY, under the tail of the backward; ``all_reduce()`` (called after backward) packs and reduces bucket 1 and waits
+      for both.  xGMI is point-to-point (7 links per GPU): two large messages keep the links busy while paying the collective
+      latency twice, not ~140 times.
+    * After the exchange ``p.grad`` of every live parameter IS its slice of the flat buffer (a view): the optimizer reads the
+      averaged gradients in place -- nothing is copied back.  ``ReduceOp.AVG`` does the division inside the collective (NCCL/RCCL);
+      gloo (CPU tests) sums and scales.
+    * Recorded steps (training.GraphedPretrainStep) call ``pack()`` inside the recording (one multi-tensor copy, no host cost),
+      ``reduce_packed()`` eagerly between the two graphs, and record the optimizer step on the views.
+    """
 
-    def __init__(self, module: torch.nn.Module, world_size: Optional[int] = None, group=None, always: bool = False):
+    def __init__(self, module: torch.nn.Module, world_size: Optional[int] = None, group=None, always: bool = False,
+                 bucket_split: float = 0.5, overlap: bool = True):
         self.always = always          # issue the collective even with one rank (rehearsals of the N > 1 path)
         self.params = [p for p in module.parameters() if p.requires_grad]
         self.world = world_size if world_size is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
-        self.group = group
+        self.group, self.bucket_split, self.overlap = group, bucket_split, overlap
         self.live: Optional[List[torch.nn.Parameter]] = None
         self.flat: Optional[torch.Tensor] = None
+        self._order: List[torch.nn.Parameter] = []
+        self._probe = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+        self._fired = 0
+        self._early = None            # in-flight work handle of bucket 0
+        self.capturing = False        # set by a recording: hooks stay passive, the recording calls pack() itself
+        self.stats = {"early_launches": 0, "steps": 0}
 
+    # ------------------------------------------------------------------ hooks
+    def _on_grad(self, p: torch.nn.Parameter) -> None:
+        if self.live is None:
+            self._order.append(p)                 # first backward: learn the completion order
+            return
+        if self.capturing or not self.overlap or not self._active():
+            return
+        if id(p) in self._bucket0_ids:
+            self._fired += 1
+            if self._fired == len(self._bucket0_ids) and self._early is None:
+                self._pack(0)
+                self._early = self._launch(0, async_op=True)
+                self.stats["early_launches"] += 1
+
+    def _active(self) -> bool:
+        return self.world > 1 or self.always
+
+    # ------------------------------------------------------------------ layout
     def _setup(self):
-        self.live = [p for p in self.params if p.grad is not None]
-        self._live_ids = {id(p) for p in self.live}
+        have = [p for p in self.params if p.grad is not None]
+        seen = {id(p) for p in self._order}
+        order = [p for p in self._order if p.grad is not None] + [p for p in have if id(p) not in seen]
+        uniq, ids = [], set()
+        for p in order:                            # a parameter used twice fires once per backward; keep the first position
+            if id(p) not in ids:
+                uniq.append(p); ids.add(id(p))
+        self.live, self._live_ids = uniq, ids
         n = sum(p.numel() for p in self.live)
         ref = self.live[0]
         self.flat = torch.empty(n, dtype=ref.grad.dtype, device=ref.grad.device)
-        self.views, off = [], 0
-        for p in self.live:
+        self.views, off, cut = [], 0, None
+        for i, p in enumerate(self.live):
             self.views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
+            if cut is None and off >= self.bucket_split * n:
+                cut = (i + 1, off)
+        k, split = cut if cut is not None else (len(self.live), n)
+        if k == len(self.live) and len(self.live) > 1:      # keep two non-empty buckets
+            k, split = len(self.live) - 1, n - self.live[-1].numel()
+        self._bucket_params = [self.live[:k], self.live[k:]]
+        self._bucket_views = [self.views[:k], self.views[k:]]
+        self._bucket_flat = [self.flat[:split], self.flat[split:]]
+        self._bucket0_ids = {id(p) for p in self.live[:k]}
 
     def reset(self) -> None:
         """Forget the live set (call on every rank at the same step, e.g. when the training phase changes)."""
-        self.live, self.flat = None, None
+        self.live, self.flat, self._order, self._fired, self._early = None, None, [], 0, None
 
     @property
     def nbytes(self) -> int:
         return 0 if self.flat is None else self.flat.numel() * self.flat.element_size()
 
-    def all_reduce(self) -> None:
-        if self.world <= 1 and not self.always:
-            return
+    @property
+    def bucket_nbytes(self) -> List[int]:
+        return [] if self.flat is None else [b.numel() * b.element_size() for b in self._bucket_flat]
+
+    # ------------------------------------------------------------------ exchange
+    def _pack(self, b: int) -> None:
+        src, dst = [], []
+        for p, v in zip(self._bucket_params[b], self._bucket_views[b]):
+            if p.grad.data_ptr() != v.data_ptr():        # already a view of the buffer: nothing to move
+                src.append(p.grad); dst.append(v)
+        if dst:
+            torch._foreach_copy_(dst, src)
+
+    def _launch(self, b: int, async_op: bool = False):
+        buf = self._bucket_flat[b]
+        if buf.numel() == 0:
+            return None
+        if dist.get_backend(self.group) == "nccl":
+            return dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=self.group, async_op=async_op)
+        w = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+        if async_op:
+            return _ScaledWork(w, buf, self.world)
+        buf.div_(self.world)
+        return None
+
+    def _check_live(self) -> None:
+        if any(p.grad is None for p in self.live) or any(p.grad is not None and id(p) not in self._live_ids for p in self.params):
+            raise RuntimeError("the set of parameters receiving gradients changed between steps")
+
+    def pack(self) -> None:
+        """Copy every live gradient into the flat buffer (first call: fixes the live set and the layout)."""
         if self.live is None:
             self._setup()
-        grads = [p.grad for p in self.live]
-        if any(g is None for g in grads) or any(p.grad is not None and id(p) not in self._live_ids for p in self.params):
-            raise RuntimeError("the set of parameters receiving gradients changed between steps")
-        torch._foreach_copy_(self.views, grads)
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
-        self.flat.div_(self.world)
-        torch._foreach_copy_(grads, self.views)
+        self._check_live()
+        self._pack(0); self._pack(1)
+
+    def reduce_packed(self) -> None:
+        """All-reduce the (already packed) buffer, bucket by bucket, and wait."""
+        works = [self._launch(0, async_op=True), self._launch(1, async_op=True)]
+        for w in works:
+            if w is not None:
+                w.wait()
+
+    def adopt_views(self) -> None:
+        """Make ``p.grad`` of every live parameter its slice of the flat buffer."""
+        for p, v in zip(self.live, self.views):
+            p.grad = v
+
+    def all_reduce(self) -> None:
+        if not self._active():
+            return
+        self.stats["steps"] += 1
+        if self.live is None:
+            self._setup()
+        self._check_live()
+        early, self._early, self._fired = self._early, None, 0
+        if early is None:
+            self._pack(0)
+            early = self._launch(0, async_op=True)
+        self._pack(1)
+        late = self._launch(1, async_op=True)
+        for w in (early, late):
+            if w is not None:
+                w.wait()
+        self.adopt_views()
+
+
+class _ScaledWork:
+    """Async SUM all-reduce followed by the 1/world scale (back-ends without ReduceOp.AVG)."""
+
+    def __init__(self, work, buf, world):
+        self.work, self.buf, self.world = work, buf, world
+
+    def wait(self):
+        self.work.wait()
+        self.buf.div_(self.world)
 
 
 def shard_slides(num_slides: int, rank: int, world: int) -> range:

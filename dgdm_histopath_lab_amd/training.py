@@ -450,7 +450,7 @@ class GraphedPretrainStep:
     def _eager(self):
         loss = self._forward_backward()
         if self.reducer is not None:
-            self.reducer.all_reduce()
+            self.reducer.all_reduce()       # leaves p.grad as views of the reducer's flat buffer
         self.opt.step()
         return loss
 
@@ -466,16 +466,25 @@ class GraphedPretrainStep:
         from . import ops
         # the recording bakes the ADDRESSES of the batch-layout constants (graph offsets, per-graph sizes) into its kernel
         # arguments: hold them here, whatever the value cache of ops.device_constant evicts later
-        with ops.collect_device_constants() as self._held_constants, torch.cuda.graph(g1, **mode):
-            self._loss = self._forward_backward()
-            if self.reducer is None:
-                self.opt.step()
-        self._graphs = [g1]
         if self.reducer is not None:
-            g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g2, pool=g1.pool(), **mode):
-                self.opt.step()
-            self._graphs.append(g2)
+            self.reducer.capturing = True       # its hooks stay passive: the recording packs the buffer itself
+        try:
+            with ops.collect_device_constants() as self._held_constants, torch.cuda.graph(g1, **mode):
+                self._loss = self._forward_backward()
+                if self.reducer is None:
+                    self.opt.step()
+                else:
+                    self.reducer.pack()          # graph 1 ends by laying the live gradients into the flat buffer (one multi-tensor copy)
+            self._graphs = [g1]
+            if self.reducer is not None:
+                self.reducer.adopt_views()       # the optimizer step is recorded on the buffer's slices: nothing is copied back
+                g2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g2, pool=g1.pool(), **mode):
+                    self.opt.step()
+                self._graphs.append(g2)
+        finally:
+            if self.reducer is not None:
+                self.reducer.capturing = False
 
     def __call__(self, batch) -> torch.Tensor:
         """One training step on ``batch``; returns the (detached, device) loss of this step."""
@@ -509,7 +518,7 @@ class GraphedPretrainStep:
             self._record()          # recording launches nothing: the step itself is the replay below
         self._graphs[0].replay()
         if self.reducer is not None:
-            self.reducer.all_reduce()
+            self.reducer.reduce_packed()    # the one eager piece: two bucket all-reduces of the buffer graph 0 just packed
             self._graphs[1].replay()
         return self._loss.clone()     # the recorded loss tensor is overwritten by the next replay
 

@@ -192,3 +192,53 @@ def test_recorded_step_rejects_equal_shapes_with_another_split():
     a2 = GraphBatch.from_data_list([synthetic_graph(5, 400, 1600, 64), synthetic_graph(6, 400, 1600, 64)]).to(DEV)
     a2.ptr = torch.tensor(a2.ptr, device=DEV)
     assert torch.isfinite(step(a2))                   # same layout, offsets as a tensor: accepted and replayed
+
+
+def test_split_recording_around_the_collective_is_bitwise_the_plain_step():
+    """N > 1 path on one GPU: a single-rank RCCL group (backend "nccl"), the step recorded as [forward + backward + pack] ->
+    eager bucket all-reduces -> [optimizer on the flat buffer's slices], against the plain recorded step and the plain eager step:
+    identical losses, gradients and parameters, bit for bit (an average over one rank is the identity).  Also the eager reducer
+    path, where a gradient hook starts bucket 0 under the backward."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from dgdm_histopath_lab_amd.parallel import FlatGradAllReducer
+    from dgdm_histopath_lab_amd.synthetic import synthetic_batch
+    from dgdm_histopath_lab_amd.training import GraphedPretrainStep
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        batches = [synthetic_batch(3 + 5 * i, 2, 400, 1600, 64).to(DEV) for i in range(2)]
+        objective = lambda model: (lambda b: model(b, mode="inference")["graph_embedding"].pow(2).mean())
+        plain, split, eager = _small_model(0.0).eval(), _small_model(0.0).eval(), _small_model(0.0).eval()
+        mk = lambda m: torch.optim.AdamW(m.parameters(), lr=1e-3, weight_decay=1e-5, fused=True)
+        s_plain = GraphedPretrainStep(plain, mk(plain), step_fn=objective(plain))
+        red = FlatGradAllReducer(split, 1, always=True)
+        s_split = GraphedPretrainStep(split, mk(split), step_fn=objective(split), grad_reducer=red)
+        red_e = FlatGradAllReducer(eager, 1, always=True)
+        opt_e = torch.optim.AdamW(eager.parameters(), lr=torch.tensor(1e-3, device=DEV), weight_decay=1e-5, fused=True, capturable=True)
+        la, lb, lc = [], [], []
+        for i in range(7):
+            la.append(float(s_plain(batches[i % 2])))
+            lb.append(float(s_split(batches[i % 2])))
+            opt_e.zero_grad(set_to_none=True)
+            loss = objective(eager)(batches[i % 2])
+            loss.backward()
+            red_e.all_reduce()
+            opt_e.step()
+            lc.append(float(loss.detach()))
+        assert len(s_split._graphs) == 2 and len(s_plain._graphs) == 1
+        assert la == lb == lc
+        for pa, pb, pc in zip(plain.parameters(), split.parameters(), eager.parameters()):
+            assert torch.equal(pa, pb) and torch.equal(pa, pc)
+            if pb.grad is not None:
+                assert torch.equal(pa.grad, pb.grad) and torch.equal(pa.grad, pc.grad)
+        live = [p for p in split.parameters() if p.grad is not None]
+        assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(red.live, red.views)) and len(live) == len(red.live) > 20
+        assert red.nbytes == sum(p.numel() for p in live) * 4 and min(red.bucket_nbytes) > 0
+        assert red_e.stats["early_launches"] == red_e.stats["steps"] - 1 == 6      # bucket 0 left from the hook on every step but the first
+    finally:
+        dist.destroy_process_group()

@@ -1,12 +1,36 @@
 """N>1 path on CPU: world_size-2 gloo processes run the flat-buffer gradient all-reduce and the
 slide sharding helpers (the GPU path uses the same code with backend nccl == RCCL)."""
 import os
+import socket
 
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from dgdm_histopath_lab_amd.parallel import FlatGradAllReducer, balance_slides, shard_slides, slide_cost
+
+
+def free_port() -> int:
+    """A port the OS hands out (bind to 0) -- no arithmetic on the pid that two concurrent runs could share."""
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def run_ranks(target, world, *extra):
+    """Spawn `world` ranks, collect ONE plain-python result per rank (no tensors on the queue: a tensor travels as a shared-memory
+    handle that needs its producer alive), then join."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=target, args=(r, world, port, q, *extra)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    return sorted(res, key=lambda t: t[0])
 
 
 class Tiny(torch.nn.Module):
@@ -28,34 +52,30 @@ def _worker(rank, world, port, q):
     red = FlatGradAllReducer(m, world)
     data = torch.arange(24, dtype=torch.float32).view(4, 6) / 10.0
     mine = data[list(shard_slides(4, rank, world))]
-    for _ in range(2):  # second step reuses the buffer
+    for _ in range(3):  # later steps reuse the buffer and start bucket 0 under the backward
         m.zero_grad(set_to_none=True)
         m(mine).sum().backward()
         red.all_reduce()
-    q.put((rank, {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}, red.nbytes))
+    views = all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(red.live, red.views))     # .grad IS the buffer: nothing copied back
+    order = [k for p in red.live for k, q_ in m.named_parameters() if q_ is p]
+    q.put((rank, {k: p.grad.tolist() for k, p in m.named_parameters() if p.grad is not None}, red.nbytes, red.bucket_nbytes,
+           dict(red.stats), views, order))
     dist.destroy_process_group()
 
 
 def test_flat_grad_all_reduce_two_ranks_gloo():
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = 29500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = sorted((q.get(timeout=120) for _ in procs), key=lambda t: t[0])
-    for p in procs:
-        p.join(60)
-        assert p.exitcode == 0
+    res = run_ranks(_worker, 2)
     torch.manual_seed(0)
     m = Tiny()
     data = torch.arange(24, dtype=torch.float32).view(4, 6) / 10.0
     (m(data[:2]).sum() / 2 + m(data[2:]).sum() / 2).backward()  # mean over ranks of per-rank sums
-    for rank, grads, nbytes in res:
+    for rank, grads, nbytes, buckets, stats, views, order in res:
         assert set(grads) == {"a.weight", "a.bias", "b.weight"}          # dead params stay out
-        assert nbytes == 4 * (24 + 4 + 4)
+        assert nbytes == 4 * (24 + 4 + 4) and sum(buckets) == nbytes and len(buckets) == 2 and min(buckets) > 0
+        assert order[0] == "b.weight"                                     # laid out in completion order of the backward: last layer first
+        assert stats == {"early_launches": 2, "steps": 3} and views      # steps 2 and 3 started bucket 0 from the gradient hook
         for k, g in grads.items():
-            torch.testing.assert_close(g, dict(m.named_parameters())[k].grad, rtol=1e-6, atol=1e-7)
+            torch.testing.assert_close(torch.tensor(g), dict(m.named_parameters())[k].grad, rtol=1e-6, atol=1e-7)
 
 
 def _phase_worker(rank, world, port, q):
@@ -78,30 +98,20 @@ def _phase_worker(rank, world, port, q):
         raised = True
     red.reset()
     red.all_reduce()
-    q.put((rank, raised, first, red.nbytes, m.dead.bias.grad.clone()))
+    q.put((rank, raised, first, red.nbytes, m.dead.bias.grad.tolist()))
     dist.destroy_process_group()
 
 
 def test_reducer_reset_on_phase_switch_two_ranks_gloo():
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = 31500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_phase_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=120) for _ in procs]
-    for p in procs:
-        p.join(60)
-        assert p.exitcode == 0
+    res = run_ranks(_phase_worker, 2)
     for rank, raised, first, second, dead_bias_grad in res:
         assert raised and first == 4 * (24 + 4 + 4) and second == first + 4 * (9 + 3)
-        torch.testing.assert_close(dead_bias_grad, torch.ones(3))       # identical on both ranks: mean == value
+        assert dead_bias_grad == [1.0, 1.0, 1.0]       # identical on both ranks: mean == value
 
 
 def test_single_rank_always_flag_runs_the_collective():
     """`always=True` (bench rehearsal knob) must not return early with one rank."""
-    port = 33500 + os.getpid() % 2000
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
     dist.init_process_group("gloo", rank=0, world_size=1)
     try:
         m = Tiny()
