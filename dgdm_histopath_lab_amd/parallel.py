@@ -205,3 +205,56 @@ def balance_slides(costs: Sequence[float], world: int) -> List[List[int]]:
         bins[r].append(i)
         loads[r] += costs[i]
     return bins
+
+
+class BalancedSlideLoader:
+    """Per-rank batches of a data-parallel step for slides of MIXED size (BASELINE config 5): every step takes the next
+    ``global_batch`` slides of the (rank-identical) slide list and hands each rank the bin the cost-aware LPT sharding gives it
+    (``balance_slides`` over ``slide_cost``: attention makes a slide's cost grow with N^2, so equal COUNTS per rank would leave the
+    ranks waiting for whoever drew the large slides).  Re-iterable (one pass = one epoch, same batches every epoch -- which is
+    what lets ``DGDMTrainer.fit(graphed=True)`` replay recorded steps for recurring layouts); feeds ``DGDMTrainer.fit`` directly.
+
+    ``slides``: sequence of ``GraphData`` (or a callable ``i -> GraphData`` with ``num_slides``); every rank must pass the same
+    list.  ``max_over_mean_load()`` reports the worst step's rank imbalance under the cost model."""
+
+    def __init__(self, slides, global_batch: int, world: int, rank: int, num_slides: Optional[int] = None, device=None,
+                 cost=slide_cost, drop_last: bool = True):
+        self.get = slides if callable(slides) else slides.__getitem__
+        self.n = num_slides if num_slides is not None else len(slides)
+        if global_batch < world:
+            raise ValueError(f"global_batch {global_batch} < world size {world}: some rank would get no slide")
+        self.global_batch, self.world, self.rank, self.device, self.cost, self.drop_last = global_batch, world, rank, device, cost, drop_last
+        self._sizes = None
+
+    def __len__(self) -> int:
+        return self.n // self.global_batch if self.drop_last else (self.n + self.global_batch - 1) // self.global_batch
+
+    def plan(self):
+        """[(slide indices of every rank) per step] -- identical on all ranks (pure function of the slide sizes)."""
+        if self._sizes is None:
+            self._sizes = []
+            for i in range(self.n):
+                g = self.get(i)
+                self._sizes.append((int(g.x.size(0)), int(g.edge_index.size(1))))
+        steps = []
+        for s in range(len(self)):
+            idx = list(range(s * self.global_batch, min(self.n, (s + 1) * self.global_batch)))
+            bins = balance_slides([self.cost(*self._sizes[i]) for i in idx], self.world)
+            steps.append([sorted(idx[j] for j in b) for b in bins])
+        return steps
+
+    def max_over_mean_load(self) -> float:
+        worst = 1.0
+        for bins in self.plan():
+            loads = [sum(self.cost(*self._sizes[i]) for i in b) for b in bins]
+            worst = max(worst, max(loads) / (sum(loads) / len(loads)))
+        return worst
+
+    def __iter__(self):
+        from .graph import GraphBatch
+        for bins in self.plan():
+            mine = bins[self.rank]
+            if not mine:
+                raise RuntimeError("a rank received no slide for a step (global_batch too small for this world size)")
+            b = GraphBatch.from_data_list([self.get(i) for i in mine])
+            yield b.to(self.device) if self.device is not None else b
