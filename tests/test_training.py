@@ -361,7 +361,7 @@ def test_config4_mixed_size_pretrain_stream_through_the_trainer():
     losses = tr.fit(loader, max_epochs=3, graphed=True)
     assert len(losses) == 12 and all(math.isfinite(l) for l in losses)
     assert sum(losses[8:]) < sum(losses[:4])                            # the objective moves (target is fresh noise: it falls towards 1)
-    assert isinstance(tr._graphed, GraphedStepCache) and len(tr._graphed.steps) == 4 and tr._graphed.replays >= 4
+    assert isinstance(tr._graphed, GraphedStepCache) and len(tr._graphed.steps) == 4 and tr._graphed.replays >= 3   # epochs 2-3 record, then replay
     assert float(tr.optimizers().param_groups[0]["lr"]) == pytest.approx(closed_form_lr(12, 1e-3, 12), rel=1e-4)
     # --- parity of one step on the smallest per-rank batch, with the weights the run arrived at
     batches = list(BalancedSlideLoader(slides, 4, 2, 0))
