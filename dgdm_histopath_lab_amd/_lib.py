@@ -30,6 +30,7 @@ SIGNATURES = {
     "dgdm_csr_build_workspace_bytes": (_sz, [_i64, _i32, _i32]),
     "dgdm_csr_build": (C.c_int, [_p, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _sz, _p]),
     "dgdm_csr_build_pair_workspace_bytes": (_sz, [_i64, _i32, _i32]),
+    "dgdm_csr_build_pair_status_offset": (_sz, [_i64, _i32, _i32]),
     "dgdm_csr_build_pair": (C.c_int, [_p, _i64, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "dgdm_gcn_dinv": (C.c_int, [_p, _i32, _p, _p]),
     "dgdm_csr_edge_weights": (C.c_int, [_p, _p, _p, _i32, _p, _p]),

@@ -153,6 +153,10 @@ struct PairArrays {
   int32_t *cnt[2], *cursor[2], *tcol[2], *teid[2];
   int32_t *rowptr[2], *col[2], *eid[2];
   float* w[2];
+  int32_t* status;      // one word in the workspace (zeroed with the counters): bit 0 = a scatter slot fell outside its row,
+                        // bit 1 = a row's extent fell outside the arrays.  The offending write is SKIPPED: stale or corrupted
+                        // counters (the hipMemsetAsync-in-graph bug of round 1) become a readable flag, not a memory fault.
+  int32_t n_entries;
 };
 
 __global__ void k_count_pair(const int64_t* __restrict__ ei, int64_t E, int32_t N, int32_t* __restrict__ cnt_dst,
@@ -209,12 +213,14 @@ __global__ void k_fill_pair(const int64_t* __restrict__ ei, int64_t E, int32_t N
     const int64_t s64 = ei[e], d64 = ei[E + e];
     if (!edge_ok(s64, d64, N)) continue;
     const int32_t s = (int32_t)s64, d = (int32_t)d64;
-    const int32_t slot_d = a.rowptr[0][d] + atomicAdd(&a.cursor[0][d], 1);
-    a.tcol[0][slot_d] = s;
-    a.teid[0][slot_d] = (int32_t)e;
-    const int32_t slot_s = a.rowptr[1][s] + atomicAdd(&a.cursor[1][s], 1);
-    a.tcol[1][slot_s] = d;
-    a.teid[1][slot_s] = (int32_t)e;
+    const int32_t cd = atomicAdd(&a.cursor[0][d], 1), cs = atomicAdd(&a.cursor[1][s], 1);
+    const int32_t slot_d = a.rowptr[0][d] + cd, slot_s = a.rowptr[1][s] + cs;
+    // a slot is valid while the cursor stays below the row's count AND inside the scratch arrays
+    const bool ok_d = cd >= 0 && cd < a.cnt[0][d] && slot_d >= 0 && slot_d < a.n_entries;
+    const bool ok_s = cs >= 0 && cs < a.cnt[1][s] && slot_s >= 0 && slot_s < a.n_entries;
+    if (ok_d) { a.tcol[0][slot_d] = s; a.teid[0][slot_d] = (int32_t)e; }
+    if (ok_s) { a.tcol[1][slot_s] = d; a.teid[1][slot_s] = (int32_t)e; }
+    if (!(ok_d && ok_s)) atomicOr(a.status, 1);
   }
 }
 
@@ -232,6 +238,10 @@ __global__ void k_rank_pair(PairArrays a, int32_t N, int32_t E32, int add_loops,
   for (int r = wave; r < N; r += nwaves) {
     const int s = rowptr[r];
     const int n = rowptr[r + 1] - s - (add_loops ? 1 : 0);
+    if (s < 0 || n < 0 || (int64_t)s + n + (add_loops ? 1 : 0) > a.n_entries) {   // corrupted offsets: flag, leave the row alone
+      if (lane == 0) atomicOr(a.status, 2);
+      continue;
+    }
     const float dr = dinv[r];
     for (int i = lane; i < n; i += 64) {
       const int my = teid[s + i];
@@ -240,7 +250,7 @@ __global__ void k_rank_pair(PairArrays a, int32_t N, int32_t E32, int add_loops,
       const int c = tcol[s + i];
       col[s + rank] = c;
       eid[s + rank] = my;
-      w[s + rank] = dinv[c] * dr;
+      w[s + rank] = ((unsigned)c < (unsigned)N ? dinv[c] : 0.f) * dr;
     }
     if (add_loops && lane == 0) {
       col[s + n] = r;
@@ -251,8 +261,8 @@ __global__ void k_rank_pair(PairArrays a, int32_t N, int32_t E32, int add_loops,
 }
 
 struct PairWorkspace {
-  int32_t *cnt[2], *cursor[2], *tcol[2], *teid[2], *block_tot[2];
-  size_t counters_bytes, bytes;
+  int32_t *cnt[2], *cursor[2], *tcol[2], *teid[2], *block_tot[2], *status;
+  size_t counters_bytes, status_offset, bytes;
 };
 
 PairWorkspace carve_pair(void* base, int64_t E, int32_t N, int32_t add_loops) {
@@ -266,7 +276,9 @@ PairWorkspace carve_pair(void* base, int64_t E, int32_t N, int32_t add_loops) {
     return r;
   };
   w.cnt[0] = take(N); w.cnt[1] = take(N); w.cursor[0] = take(N); w.cursor[1] = take(N);
-  w.counters_bytes = off;  // the four counter arrays are adjacent: one fill
+  w.status_offset = off;
+  w.status = take(1);
+  w.counters_bytes = off;  // the four counter arrays and the status word are adjacent: one fill
   w.tcol[0] = take(n_entries); w.tcol[1] = take(n_entries); w.teid[0] = take(n_entries); w.teid[1] = take(n_entries);
   const size_t nblk = ((size_t)N + SCAN_BLOCK - 1) / SCAN_BLOCK + 1;
   w.block_tot[0] = take(nblk); w.block_tot[1] = take(nblk);
@@ -364,6 +376,11 @@ extern "C" size_t dgdm_csr_build_pair_workspace_bytes(int64_t E, int32_t N, int3
   return carve_pair(nullptr, E, N, add_loops).bytes;
 }
 
+extern "C" size_t dgdm_csr_build_pair_status_offset(int64_t E, int32_t N, int32_t add_loops) {
+  if (E < 0 || N < 0) return 0;
+  return carve_pair(nullptr, E, N, add_loops).status_offset;
+}
+
 extern "C" int dgdm_csr_build_pair(const int64_t* edge_index, int64_t E, int32_t N, int32_t add_loops,
                                    int32_t* rowptr_dst, int32_t* col_dst, int32_t* eid_dst, float* w_dst,
                                    int32_t* rowptr_src, int32_t* col_src, int32_t* eid_src, float* w_src, float* dinv,
@@ -386,6 +403,8 @@ extern "C" int dgdm_csr_build_pair(const int64_t* edge_index, int64_t E, int32_t
   for (int o = 0; o < 2; ++o) { a.cnt[o] = ws.cnt[o]; a.cursor[o] = ws.cursor[o]; a.tcol[o] = ws.tcol[o]; a.teid[o] = ws.teid[o]; }
   a.rowptr[0] = rowptr_dst; a.col[0] = col_dst; a.eid[0] = eid_dst; a.w[0] = w_dst;
   a.rowptr[1] = rowptr_src; a.col[1] = col_src; a.eid[1] = eid_src; a.w[1] = w_src;
+  a.status = ws.status;
+  a.n_entries = (int32_t)n_entries;
   const int extra = add_loops ? 1 : 0;
   dgdm_fill_async(ws.cnt[0], 0, ws.counters_bytes, stream);
   const int eb = (int)((E + 255) / 256 < 4096 ? (E + 255) / 256 : 4096);

@@ -109,8 +109,15 @@ def graph_ptr(data, num_nodes: int) -> List[int]:
 class GraphStructure:
     """Device CSR/CSC + GCN weights of one edge list over ``num_nodes`` nodes (self loops added)."""
 
+    def assert_ok(self) -> None:
+        """Reads the builder's status word (ONE host sync -- not on the training path): raises if a scatter slot or a row
+        extent fell outside its bounds, i.e. the counters the scatter trusts were inconsistent."""
+        if self.status is not None and int(self.status.item()) != 0:
+            raise _lib.DGDMKernelError(f"CSR build reported inconsistent counters (status {int(self.status.item())}): the affected entries "
+                                       "were skipped")
+
     __slots__ = ("num_nodes", "num_edges", "num_entries", "rowptr", "col", "eid", "w",
-                 "rowptr_t", "col_t", "eid_t", "w_t", "dinv")
+                 "rowptr_t", "col_t", "eid_t", "w_t", "dinv", "status")
 
     def __init__(self, edge_index: torch.Tensor, num_nodes: int, add_loops: bool = True, pipeline: str = "pair"):
         """``pipeline``: "pair" (dgdm_csr_build_pair) or "single" (one entry point per array set; same results)."""
@@ -131,9 +138,13 @@ class GraphStructure:
         self.dinv = torch.empty(N, dtype=torch.float32, device=dev)
         self.w = torch.empty(n_ent, dtype=torch.float32, device=dev)
         self.w_t = torch.empty(n_ent, dtype=torch.float32, device=dev)
+        self.status = None
         if pipeline == "pair":       # both orientations, dinv and the weights in five launches
             ws_bytes = _lib.workspace_bytes("dgdm_csr_build_pair_workspace_bytes", E, N, int(add_loops))
-            ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+            ws = torch.empty(max(ws_bytes, 4), dtype=torch.uint8, device=dev)
+            if N > 0:    # the builder's overflow flag (include/dgdm_hip.h): kept as a 4-byte view, read only by assert_ok()
+                off = _lib.workspace_bytes("dgdm_csr_build_pair_status_offset", E, N, int(add_loops))
+                self.status = ws[off:off + 4].view(torch.int32)
             _lib.check(lib.dgdm_csr_build_pair(ei.data_ptr(), E, N, int(add_loops), self.rowptr.data_ptr(), self.col.data_ptr(),
                                                self.eid.data_ptr(), self.w.data_ptr(), self.rowptr_t.data_ptr(), self.col_t.data_ptr(),
                                                self.eid_t.data_ptr(), self.w_t.data_ptr(), self.dinv.data_ptr(), ws.data_ptr(),

@@ -97,6 +97,11 @@ DGDM_API int dgdm_csr_edge_weights(const int32_t* rowptr, const int32_t* col, co
  * by_src 1), dinv and the GCN weight w of every entry -- bit for bit what two dgdm_csr_build calls, dgdm_gcn_dinv and
  * two dgdm_csr_edge_weights calls produce (seventeen launches; a training step builds seven such sets). */
 DGDM_API size_t dgdm_csr_build_pair_workspace_bytes(int64_t E, int32_t N, int32_t add_loops);
+/* Byte offset, inside the workspace of dgdm_csr_build_pair, of one int32 status word the call zeroes and its scatter kernels
+ * OR into: bit 0 = an edge's slot fell outside its row (cursor >= count), bit 1 = a row's extent fell outside the arrays.  The
+ * offending writes are skipped, so inconsistent counters (e.g. a fill that did not re-execute in a graph replay) surface as
+ * this flag instead of an out-of-bounds write.  0 after a healthy build; read it whenever a host sync is acceptable. */
+DGDM_API size_t dgdm_csr_build_pair_status_offset(int64_t E, int32_t N, int32_t add_loops);
 DGDM_API int dgdm_csr_build_pair(const int64_t* edge_index, int64_t E, int32_t N, int32_t add_loops,
                                  int32_t* rowptr_dst, int32_t* col_dst, int32_t* eid_dst, float* w_dst,
                                  int32_t* rowptr_src, int32_t* col_src, int32_t* eid_src, float* w_src, float* dinv,

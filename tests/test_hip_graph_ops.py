@@ -31,6 +31,7 @@ def test_csr_build_bit_exact(n, e, hub, pipeline):
     ei = _rand_edges(n, e, n + e, hub)
     gs = GraphStructure(torch.from_numpy(ei).to(_dev()), n, pipeline=pipeline)
     o = csr_oracle.gcn_csr(ei, n)
+    gs.assert_ok()          # bounds guard of the scatter kernels: status word 0 (pair pipeline; the other has none)
     for k in ("rowptr", "col", "eid", "rowptr_t", "col_t", "eid_t"):
         got = getattr(gs, k).cpu().numpy()
         assert got.dtype == np.int32 and np.array_equal(got, o[k]), k
