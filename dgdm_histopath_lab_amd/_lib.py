@@ -95,6 +95,15 @@ SIGNATURES = {
     "dgdm_gemm_tn_bf16x3": (C.c_int, [_p, _i64, _p, _i64, _p, _i64, _p, _i32, _i32, _i32, _p, _sz, _p]),
     "dgdm_gemm_tn_split": (C.c_int, [_p, _i64, _p, _i64, _p, _i64, _i32, _p, _i64, _p, _i32, _i32, _i32, _p, _sz, _p]),
     "dgdm_gemm_tn_split_bf16x3": (C.c_int, [_p, _i64, _p, _i64, _p, _i64, _i32, _p, _i64, _p, _i32, _i32, _i32, _p, _sz, _p]),
+    "dgdm_fill_u32": (C.c_int, [_p, _i64, C.c_uint32, _p]),
+    "dgdm_amax_bits": (C.c_int, [_p, _i64, _i64, _i32, _p, _p]),
+    "dgdm_amax_table": (C.c_int, [_p, _i32, _p, _p]),
+    "dgdm_gemm_nt_f16x2": (C.c_int, [_p, _i64, _p, _i64, _p, _p, _i64, _i32, _i32, _i32, _i32, _p, _p, _p]),
+    "dgdm_gemm_nt_split_f16x2": (C.c_int, [_p, _i64, _p, _i64, _i32, _p, _i64, _p, _p, _i64, _i32, _i32, _i32, _i32, _p, _p, _p, _p]),
+    "dgdm_gemm_nn_f16x2": (C.c_int, [_p, _i64, _p, _i64, _p, _i64, _i32, _i32, _i32, _i32, _p, _p, _p]),
+    "dgdm_gemm_tn_f16x2_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
+    "dgdm_gemm_tn_f16x2": (C.c_int, [_p, _i64, _p, _i64, _p, _i64, _p, _i32, _i32, _i32, _p, _sz, _p, _p, _p]),
+    "dgdm_gemm_tn_split_f16x2": (C.c_int, [_p, _i64, _p, _i64, _p, _i64, _i32, _p, _i64, _p, _i32, _i32, _i32, _p, _sz, _p, _p, _p]),
     "dgdm_attn_pack_bytes": (_sz, [_i32, _i32, _i32]),
     "dgdm_amax_scale_workspace_bytes": (_sz, []),
     "dgdm_amax_pow2_scale": (C.c_int, [_p, _i64, C.c_float, _p, _p, _sz, _p]),

@@ -43,3 +43,13 @@ extern "C" int dgdm_seed_epoch_set(uint32_t value, void* stream) {
   hipLaunchKernelGGL(k_seed_epoch, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), const_cast<uint32_t*>(dgdm_seed_epoch_ptr()), value, 1);
   return dgdm_launch_status();
 }
+
+// p[0 .. n) <- value (uint32 words); a kernel node, so it re-executes in a graph replay (see common.hpp, dgdm_fill_async)
+extern "C" int dgdm_fill_u32(uint32_t* p, int64_t n, uint32_t value, void* stream) {
+  if (n < 0 || (n > 0 && !p)) return DGDM_ERR_INVALID_ARG;
+  if (n == 0) return DGDM_OK;
+  const int64_t blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(k_dgdm_fill32, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, static_cast<hipStream_t>(stream), p,
+                     (size_t)n, value);
+  return dgdm_launch_status();
+}

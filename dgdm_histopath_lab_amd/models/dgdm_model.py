@@ -241,6 +241,7 @@ class DGDMModel(nn.Module):
             except Exception as e:
                 raise ModelInferenceError(f"Input validation failed: {e}")
         try:
+            ops.refresh_weight_amax(self)       # max|w| of every weight, one launch (fp16 hi+lo GEMMs scale their operands by it)
             plan = BatchPlan(data, data.x.device)
             h = self.feature_encoder(data.x)
             if trace is not None:

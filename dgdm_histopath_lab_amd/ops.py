@@ -768,6 +768,110 @@ def attn_pool(kv, q_scaled, plan: AttnPlan, H: int, D: int, drop_p: float = 0.0,
     return _AttnPool.apply(kv, q_scaled, plan, H, D, p, next_dropout_seed() if p > 0 else 0)
 
 
+# ----------------------------------------------------------------------------- operand maxima for the fp16 hi+lo GEMMs
+class AmaxArena:
+    """Device slots holding the float bits of max|x| of GEMM operands (csrc/gemm_h.hip).  A ring of uint32 slots, zeroed chunk by
+    chunk as the bump pointer enters a chunk (one fill launch per CHUNK slots, also recorded by a graph capture at the same
+    position, so a replay re-zeroes exactly the slots it refills).  A slot's content is valid from the kernel that fills it to the
+    end of the training step that allocated it; the ring is far longer (SLOTS) than the ~300 slots a step takes, so a pending
+    backward never meets a recycled slot."""
+
+    SLOTS, CHUNK = 1 << 12, 1 << 6          # slot groups in the ring / groups zeroed per fill launch
+    GROUP_WORDS = 32 * 64                   # DGDM_AMAX_WAYS * DGDM_AMAX_STRIDE (include/dgdm_hip.h): 8 KiB per slot group
+
+    def __init__(self, device):
+        self.buf = torch.zeros(self.SLOTS * self.GROUP_WORDS, dtype=torch.int32, device=device)     # 32 MiB
+        self.next = 0
+        self.base = self.buf.data_ptr()
+
+    def take(self) -> int:
+        """Address of a zeroed slot group."""
+        i = self.next
+        if i % self.CHUNK == 0:
+            _lib.check(_lib.load().dgdm_fill_u32(self.base + 4 * i * self.GROUP_WORDS, self.CHUNK * self.GROUP_WORDS, 0,
+                                                 _lib.stream_ptr(self.buf.device)), "dgdm_fill_u32")
+        self.next = (i + 1) % self.SLOTS
+        return self.base + 4 * i * self.GROUP_WORDS
+
+
+_ARENAS: dict = {}
+
+
+def _arena(device) -> AmaxArena:
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    a = _ARENAS.get(key)
+    if a is None:
+        a = _ARENAS[key] = AmaxArena(torch.device("cuda", key))
+    return a
+
+
+def amax_of(t: torch.Tensor) -> Optional[int]:
+    """Slot address of an upper bound of max|t| if a producer (or an earlier GEMM) left one, else None."""
+    return getattr(t, "_dgdm_amax", None)
+
+
+def tag_amax(t: torch.Tensor, slot: Optional[int]) -> torch.Tensor:
+    if slot is not None:
+        t._dgdm_amax = slot
+    return t
+
+
+def ensure_amax(t: torch.Tensor) -> int:
+    """The tensor's amax slot; computes it with one reduction launch (dgdm_amax_bits) when no producer supplied it.  ``t``: 2-D fp32,
+    unit column stride, cols % 4 == 0, 16-byte aligned (what the tile GEMMs accept anyway)."""
+    slot = amax_of(t)
+    if slot is None:
+        slot = _arena(t.device).take()
+        _lib.check(_lib.load().dgdm_amax_bits(t.data_ptr(), _ld(t), t.size(0), t.size(1), slot, _lib.stream_ptr(t.device)), "dgdm_amax_bits")
+        t._dgdm_amax = slot
+    return slot
+
+
+class WeightAmax:
+    """max|w| of every parameter of a module, refreshed by ONE launch (dgdm_amax_table) at the start of a forward: weights only
+    change in the optimizer step, so the values hold for the whole forward + backward.  Parameters are tagged with their slot;
+    a column slice of a weight inherits the whole matrix's maximum (an upper bound is all the GEMM needs)."""
+
+    def __init__(self, module: torch.nn.Module):
+        self.params = [p for p in module.parameters() if p.dim() >= 2 and p.dtype == torch.float32 and p.is_cuda and p.is_contiguous()]
+        self.ptrs = [p.data_ptr() for p in self.params]
+        dev = self.params[0].device if self.params else None
+        self.device = dev
+        if not self.params:
+            return
+        import struct
+        recs, CH = [], 1 << 16
+        for g, p in enumerate(self.params):       # large tensors are cut into 64K-float records that share the tensor's group
+            for off in range(0, p.numel(), CH):
+                recs.append(struct.pack("<Qqq", p.data_ptr() + 4 * off, min(CH, p.numel() - off), g))
+        self.count = len(recs)
+        self.table = torch.frombuffer(bytearray(b"".join(recs)), dtype=torch.uint8).to(dev)
+        self.slots = torch.zeros(len(self.params) * AmaxArena.GROUP_WORDS, dtype=torch.int32, device=dev)
+        for i, p in enumerate(self.params):
+            p._dgdm_amax = self.slots.data_ptr() + 4 * i * AmaxArena.GROUP_WORDS
+
+    def stale(self) -> bool:
+        return any(p.data_ptr() != q for p, q in zip(self.params, self.ptrs))
+
+    def refresh(self) -> None:
+        if not self.params:
+            return
+        lib, st = _lib.load(), _lib.stream_ptr(self.device)
+        _lib.check(lib.dgdm_fill_u32(self.slots.data_ptr(), self.slots.numel(), 0, st), "dgdm_fill_u32")
+        _lib.check(lib.dgdm_amax_table(self.table.data_ptr(), self.count, self.slots.data_ptr(), st), "dgdm_amax_table")
+
+
+def refresh_weight_amax(module: torch.nn.Module) -> None:
+    """Call at the start of a forward (DGDMModel.forward does): (re)builds the module's weight-maximum table when its parameters
+    moved, then refreshes the maxima.  No-op unless the fp16 hi+lo GEMMs are selected."""
+    if GEMM_MATH != "f16x2":
+        return
+    wa = module.__dict__.get("_dgdm_weight_amax")
+    if wa is None or wa.stale():
+        wa = module.__dict__["_dgdm_weight_amax"] = WeightAmax(module)
+    wa.refresh()
+
+
 # ----------------------------------------------------------------------------- K3 dense contractions
 GEMM_MIN_ROWS = 256   # fewer rows (one per graph / timestep): the exact-fp32 small-M kernels (csrc/smallm.hip), not a tile GEMM
 
@@ -782,51 +886,65 @@ def _rowmajor(t: torch.Tensor) -> torch.Tensor:
 
 
 def _gemm_entry(lib, name: str, math: str):
-    if math not in ("fp32", "bf16x3"):
-        raise ValueError(f"GEMM math must be 'fp32' or 'bf16x3', got {math!r}")
-    return getattr(lib, name if math == "fp32" else name + "_bf16x3")
+    if math not in ("fp32", "bf16x3", "f16x2"):
+        raise ValueError(f"GEMM math must be 'fp32', 'bf16x3' or 'f16x2', got {math!r}")
+    return getattr(lib, name if math == "fp32" else name + "_" + math)
+
+
+def _rm_tagged(t: torch.Tensor) -> torch.Tensor:
+    """_rowmajor that keeps the operand's amax tag when it has to copy."""
+    r = _rowmajor(t)
+    return r if r is t else tag_amax(r, amax_of(t))
 
 
 def gemm_nt_raw(a, w, bias=None, out=None, accumulate=False, math="fp32"):
     lib = _lib.load()
-    a, w = _rowmajor(a), _rowmajor(w)
+    a, w = _rm_tagged(a), _rm_tagged(w)
     M, K = a.shape
     N = w.size(0)
     if out is None:
         out = torch.empty(M, N, dtype=torch.float32, device=a.device)
     fn = _gemm_entry(lib, "dgdm_gemm_nt", math)
+    extra = (ensure_amax(a), ensure_amax(w)) if math == "f16x2" else ()
     TIMERS.timed("gemm_nt", lambda: _lib.check(
         fn(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), _lib.ptr(bias), out.data_ptr(), out.stride(0), M, N, K,
-           int(accumulate), _lib.stream_ptr(a.device)), "dgdm_gemm_nt"))
+           int(accumulate), *extra, _lib.stream_ptr(a.device)), "dgdm_gemm_nt"))
     return out
 
 
-def gemm_nt_split_raw(a, w0, w1, bias=None):
-    """a [M, K0 + K1] . [w0 | w1]^T (+ bias) without materialising the concatenated weight (bf16x3 kernel only)."""
+def gemm_nt_split_raw(a, w0, w1, bias=None, math="bf16x3"):
+    """a [M, K0 + K1] . [w0 | w1]^T (+ bias) without materialising the concatenated weight (16-bit-pipe kernels only)."""
     lib = _lib.load()
+    a0, w00, w10 = a, w0, w1
     a, w0, w1 = _rowmajor(a), _rowmajor(w0), _rowmajor(w1)
+    for new, old in ((a, a0), (w0, w00), (w1, w10)):
+        if new is not old:
+            tag_amax(new, amax_of(old))
     M, K = a.shape
     N, K0 = w0.shape
     if w1.size(0) != N or K0 + w1.size(1) != K:
         raise ValueError(f"weights {tuple(w0.shape)} | {tuple(w1.shape)} do not match the operand {tuple(a.shape)}")
     out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    fn = lib.dgdm_gemm_nt_split_f16x2 if math == "f16x2" else lib.dgdm_gemm_nt_split_bf16x3
+    extra = (ensure_amax(a), ensure_amax(w0), ensure_amax(w1)) if math == "f16x2" else ()
     TIMERS.timed("gemm_nt", lambda: _lib.check(
-        lib.dgdm_gemm_nt_split_bf16x3(a.data_ptr(), a.stride(0), w0.data_ptr(), w0.stride(0), K0, w1.data_ptr(), w1.stride(0), _lib.ptr(bias),
-                                      out.data_ptr(), out.stride(0), M, N, K, 0, _lib.stream_ptr(a.device)), "dgdm_gemm_nt_split_bf16x3"))
+        fn(a.data_ptr(), a.stride(0), w0.data_ptr(), w0.stride(0), K0, w1.data_ptr(), w1.stride(0), _lib.ptr(bias),
+           out.data_ptr(), out.stride(0), M, N, K, 0, *extra, _lib.stream_ptr(a.device)), "dgdm_gemm_nt_split"))
     return out
 
 
 def gemm_nn_raw(a, w, out=None, accumulate=False, math="fp32"):
     """a [M,N] . w [N,K] -> [M,K]"""
     lib = _lib.load()
-    a, w = _rowmajor(a), _rowmajor(w)
+    a, w = _rm_tagged(a), _rm_tagged(w)
     M, N = a.shape
     K = w.size(1)
     if out is None:
         out = torch.empty(M, K, dtype=torch.float32, device=a.device)
     fn = _gemm_entry(lib, "dgdm_gemm_nn", math)
+    extra = (ensure_amax(a), ensure_amax(w)) if math == "f16x2" else ()
     TIMERS.timed("gemm_nn", lambda: _lib.check(
-        fn(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(), out.stride(0), M, N, K, int(accumulate),
+        fn(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(), out.stride(0), M, N, K, int(accumulate), *extra,
            _lib.stream_ptr(a.device)), "dgdm_gemm_nn"))
     return out
 
@@ -836,19 +954,20 @@ def gemm_tn_raw(dy, x, with_bias: bool, math="fp32", split: Optional[int] = None
     ``split=K0``: dW is delivered as two contiguous matrices (dW[:, :K0], dW[:, K0:]) -- returns ((dW0, dW1), db).
     ``out``: write dW there (a [N, K] view with unit column stride, e.g. a column block of a wider gradient matrix)."""
     lib = _lib.load()
-    dy, x = _rowmajor(dy), _rowmajor(x)
+    dy, x = _rm_tagged(dy), _rm_tagged(x)
     M, N = dy.shape
     K = x.size(1)
     db = torch.empty(N, dtype=torch.float32, device=x.device) if with_bias else None
-    wsb = _lib.workspace_bytes("dgdm_gemm_tn_workspace_bytes" if math == "fp32" else "dgdm_gemm_tn_bf16x3_workspace_bytes", M, N, K, int(with_bias))
+    wsb = _lib.workspace_bytes("dgdm_gemm_tn_workspace_bytes" if math == "fp32" else f"dgdm_gemm_tn_{math}_workspace_bytes", M, N, K, int(with_bias))
     ws = torch.empty(max(wsb, 4) // 4, dtype=torch.float32, device=x.device)
+    extra = (ensure_amax(dy), ensure_amax(x)) if math == "f16x2" else ()
     if split is None:
         dW = torch.empty(N, K, dtype=torch.float32, device=x.device) if out is None else out
         assert dW.shape == (N, K) and dW.stride(1) == 1
         fn = _gemm_entry(lib, "dgdm_gemm_tn", math)
         TIMERS.timed("gemm_tn", lambda: _lib.check(
             fn(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), dW.data_ptr(), dW.stride(0), _lib.ptr(db), M, N, K,
-               ws.data_ptr(), wsb, _lib.stream_ptr(x.device)), "dgdm_gemm_tn"))
+               ws.data_ptr(), wsb, *extra, _lib.stream_ptr(x.device)), "dgdm_gemm_tn"))
         return dW, db
     if not 0 < split < K:
         raise ValueError(f"split must lie inside (0, {K}), got {split}")
@@ -857,15 +976,17 @@ def gemm_tn_raw(dy, x, with_bias: bool, math="fp32", split: Optional[int] = None
     fn = _gemm_entry(lib, "dgdm_gemm_tn_split", math)
     TIMERS.timed("gemm_tn", lambda: _lib.check(
         fn(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), dW0.data_ptr(), dW0.stride(0), split, dW1.data_ptr(), dW1.stride(0),
-           _lib.ptr(db), M, N, K, ws.data_ptr(), wsb, _lib.stream_ptr(x.device)), "dgdm_gemm_tn_split"))
+           _lib.ptr(db), M, N, K, ws.data_ptr(), wsb, *extra, _lib.stream_ptr(x.device)), "dgdm_gemm_tn_split"))
     return (dW0, dW1), db
 
 
 # Arithmetic of the dense contractions (``configure(gemm=...)``; both are this library's kernels):
 #   "bf16x3" (shipped) csrc/gemm3.hip: exact three-way bf16 split of every fp32 operand, six bf16 MFMAs per product,
 #            fp32 accumulate -- fp32-level accuracy at 2-2.5x the fp32 matrix rate;
+#   "f16x2"  csrc/gemm_h.hip: fp16 hi + lo operands (22 significand bits), three fp16 MFMAs per product, each operand scaled by a
+#            power of two derived from its absolute maximum (kept by the producing kernels / one reduction launch otherwise);
 #   "fp32"   csrc/gemm.hip: fp32 MFMA for all three contractions.
-GEMM_MATH = "bf16x3"
+GEMM_MATH = "f16x2"
 
 
 def configure(attention: Optional[str] = None, gemm: Optional[str] = None) -> dict:
@@ -878,8 +999,8 @@ def configure(attention: Optional[str] = None, gemm: Optional[str] = None) -> di
             raise ValueError(f"attention precision must be 'fp16x2' or 'fp32', got {attention!r}")
         ATTN_PRECISION = attention
     if gemm is not None:
-        if gemm not in ("bf16x3", "fp32"):
-            raise ValueError(f"GEMM math must be 'bf16x3' or 'fp32', got {gemm!r}")
+        if gemm not in ("bf16x3", "f16x2", "fp32"):
+            raise ValueError(f"GEMM math must be 'bf16x3', 'f16x2' or 'fp32', got {gemm!r}")
         GEMM_MATH = gemm
     return prev
 
@@ -887,14 +1008,18 @@ def configure(attention: Optional[str] = None, gemm: Optional[str] = None) -> di
 class _Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b):
+        x, w = _rm_tagged(x), _rm_tagged(w)
         ctx.save_for_backward(x, w)
         ctx.has_bias, ctx.math = b is not None, GEMM_MATH
-        return gemm_nt_raw(x, w, b, math=GEMM_MATH)
+        y = gemm_nt_raw(x, w, b, math=GEMM_MATH)
+        ctx.amax = (amax_of(x), amax_of(w))      # slots the forward GEMM used (or filled): the backward GEMMs reuse them
+        return y
 
     @staticmethod
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
-        gy = _rowmajor(gy)
+        tag_amax(x, ctx.amax[0]); tag_amax(w, ctx.amax[1])
+        gy = _rm_tagged(gy)
         dx = gemm_nn_raw(gy, w, math=ctx.math) if ctx.needs_input_grad[0] else None
         dW = db = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
@@ -985,16 +1110,21 @@ class _LinearAddInto(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, acc, x, w, b):
+        x, w = _rm_tagged(x), _rm_tagged(w)
         ctx.save_for_backward(x, w)
         ctx.has_bias, ctx.math = b is not None, GEMM_MATH
         gemm_nt_raw(x, w, b, out=acc, accumulate=True, math=GEMM_MATH)
+        ctx.amax = (amax_of(x), amax_of(w))
         ctx.mark_dirty(acc)
+        if hasattr(acc, "_dgdm_amax"):
+            del acc._dgdm_amax                  # its content changed: a maximum taken before no longer bounds it
         return acc
 
     @staticmethod
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
-        gy = _rowmajor(gy)
+        tag_amax(x, ctx.amax[0]); tag_amax(w, ctx.amax[1])
+        gy = _rm_tagged(gy)
         dx = gemm_nn_raw(gy, w, math=ctx.math) if ctx.needs_input_grad[1] else None
         dW = db = None
         if ctx.needs_input_grad[2] or (ctx.has_bias and ctx.needs_input_grad[3]):
@@ -1019,11 +1149,12 @@ class _DenoiseFirstLayer(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, te, w, b, plan: AttnPlan):
         lib = _lib.load()
-        x, te = _rowmajor(x), _rows(te)
+        x, te = _rm_tagged(x), _rows(te)
         C = x.size(1)
-        wx, wt = w[:, :C], w[:, C:]
+        wx, wt = tag_amax(w[:, :C], amax_of(w)), w[:, C:]                       # a column block is bounded by the whole matrix's maximum
         pg, _ = linear_small_fwd_raw(te, wt, b)                                # [B, N_out]
         h = gemm_nt_raw(x, wx, None, math=GEMM_MATH) if x.size(0) >= GEMM_MIN_ROWS else linear_small_fwd_raw(x, wx, None)[0]
+        ctx.amax = (amax_of(x), amax_of(wx))
         out = torch.empty_like(h)
         _lib.check(lib.dgdm_segment_bcast_add(h.data_ptr(), pg.data_ptr(), plan.ptr_dev.data_ptr(), plan.B, h.size(0), h.size(1), out.data_ptr(),
                                               _lib.stream_ptr(x.device)), "dgdm_segment_bcast_add")
@@ -1036,13 +1167,14 @@ class _DenoiseFirstLayer(torch.autograd.Function):
         lib = _lib.load()
         x, te, w = ctx.saved_tensors
         plan, C = ctx.plan, x.size(1)
-        g = _rowmajor(g)
+        g = _rm_tagged(g)
+        tag_amax(x, ctx.amax[0])
         N_out, K = w.shape
         dev = x.device
         big = x.size(0) >= GEMM_MIN_ROWS
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = gemm_nn_raw(g, w[:, :C], math=ctx.math) if big else _small_dx(g, w[:, :C])
+            dx = gemm_nn_raw(g, tag_amax(w[:, :C], ctx.amax[1]), math=ctx.math) if big else _small_dx(g, w[:, :C])
         gpg = segment_sum_raw(g, plan)                                         # [B, N_out]: gradient of the per-graph bias
         dw = torch.empty(N_out, K, dtype=torch.float32, device=dev)
         if big:
@@ -1101,9 +1233,12 @@ class _GraphConvLinear(torch.autograd.Function):
                                  ea_hat.data_ptr(), ea_hat.stride(0), ed, buf.data_ptr(), buf.stride(0), n, cin,
                                  _lib.stream_ptr(x.device)), "dgdm_spmm_concat"))
         ctx.gs, ctx.cin, ctx.has_bias, ctx.skip, ctx.math = gs, cin, b is not None, skip, GEMM_MATH
-        if GEMM_MATH == "bf16x3" and cin % 4 == 0:
+        ctx.amax = (None, None)
+        if GEMM_MATH in ("bf16x3", "f16x2") and cin % 4 == 0:
+            w = _rm_tagged(w)
             ctx.save_for_backward(buf, w)          # the kernel reads the two weights side by side: no concatenated copy
-            y = gemm_nt_split_raw(buf, w, we, b)
+            y = gemm_nt_split_raw(buf, w, we, b, math=GEMM_MATH)
+            ctx.amax = (amax_of(buf), amax_of(w))
         else:
             wcat = torch.cat([w, we], dim=1)
             ctx.save_for_backward(buf, wcat)
@@ -1116,11 +1251,13 @@ class _GraphConvLinear(torch.autograd.Function):
             return gskip, None, None, None, None, None, None
         buf, wsaved = ctx.saved_tensors
         gs, cin = ctx.gs, ctx.cin
-        gy = _rowmajor(gy)
+        gy = _rm_tagged(gy)
+        tag_amax(buf, ctx.amax[0]); tag_amax(wsaved, ctx.amax[1])
         math = ctx.math
         dx = None
         if ctx.needs_input_grad[0]:
-            w_only = wsaved[:, :cin]                    # node_lin.weight itself, or a view into the concatenated copy
+            # node_lin.weight itself, or a view into the concatenated copy (bounded by the copy's maximum)
+            w_only = wsaved if wsaved.size(1) == cin else tag_amax(wsaved[:, :cin], amax_of(wsaved))
             dagg = gemm_nn_raw(gy, w_only, math=math)
             dx = spmm_raw(gs.rowptr_t, gs.col_t, gs.w_t, dagg, gs.num_nodes, addend=gskip)
         dw = dwe = db = None

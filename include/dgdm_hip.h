@@ -40,6 +40,12 @@ enum {
   DGDM_ERR_LAUNCH = -4         /* hipGetLastError() != hipSuccess after a launch */
 };
 
+/* An "amax slot" (operand maxima of the fp16 hi+lo GEMMs, K3'') is a group of DGDM_AMAX_WAYS uint32 words spaced
+ * DGDM_AMAX_STRIDE words apart: producers spread their atomic maxima over the ways, consumers take the maximum of the ways.
+ * A group therefore spans DGDM_AMAX_WAYS * DGDM_AMAX_STRIDE words; all of them zero before the first producer runs. */
+#define DGDM_AMAX_WAYS 32
+#define DGDM_AMAX_STRIDE 64
+
 /* activation ids shared by the fused row kernels */
 enum { DGDM_ACT_NONE = 0, DGDM_ACT_GELU = 1, DGDM_ACT_RELU = 2, DGDM_ACT_SILU = 3 };
 
@@ -401,6 +407,42 @@ DGDM_API int dgdm_gemm_tn_bf16x3(const float* dY, int64_t ldy, const float* X, i
 DGDM_API int dgdm_gemm_tn_split_bf16x3(const float* dY, int64_t ldy, const float* X, int64_t ldx, float* dW0, int64_t ld0,
                                        int32_t K0, float* dW1, int64_t ld1, float* db, int32_t M, int32_t N, int32_t K,
                                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K3''  the same three contractions with every fp32 operand carried as fp16 hi + lo (22 significand bits) and three
+ * v_mfma_f32_32x32x16_f16 per product term (csrc/gemm_h.hip): half the matrix work of the bf16x3 kernels at the same
+ * fp32-level accuracy.  fp16 has no range to spare, so every operand comes with `amax_*`: a DEVICE amax slot (a group of
+ * DGDM_AMAX_WAYS words, see above) whose maximum is the float bits of an UPPER BOUND of max|x| over the operand (the exact
+ * maximum, or that of a tensor the operand is a slice of); the kernel scales the operand by the power of two that puts that
+ * bound in [2^14, 2^15) and undoes it in the epilogue (exact).
+ * A bound that is too SMALL overflows fp16: callers without a bound use the bf16x3 entry points.
+ *   dgdm_amax_bits : atomic max of the float bits of |x| over a [rows, cols] matrix (row stride ld) into the slot group
+ *                    (zero it first; non-negative floats order like integers, so the result does not depend on the order).
+ *   dgdm_amax_table: the same for many contiguous tensors in one launch; table = DEVICE array of `count` records
+ *                    {const float* p; int64 n; int64 group;} (a large tensor is cut into several records with the same
+ *                    group index), groups = base of the zeroed slot groups (all weights of a model, once per step).
+ * Shapes / alignment / workspace as the bf16x3 entry points (dgdm_gemm_tn_f16x2_workspace_bytes == the bf16x3 size). */
+DGDM_API int dgdm_fill_u32(uint32_t* p, int64_t n, uint32_t value, void* stream);   /* p[0..n) <- value, as a kernel (graph-replay safe) */
+DGDM_API int dgdm_amax_bits(const float* x, int64_t ld, int64_t rows, int32_t cols, uint32_t* group, void* stream);
+DGDM_API int dgdm_amax_table(const void* table, int32_t count, uint32_t* groups, void* stream);
+DGDM_API int dgdm_gemm_nt_f16x2(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* C, int64_t ldc,
+                                int32_t M, int32_t N, int32_t K, int32_t accumulate, const uint32_t* amax_a, const uint32_t* amax_w,
+                                void* stream);
+DGDM_API int dgdm_gemm_nt_split_f16x2(const float* A, int64_t lda, const float* W0, int64_t ldw0, int32_t K0, const float* W1,
+                                      int64_t ldw1, const float* bias, float* C, int64_t ldc, int32_t M, int32_t N, int32_t K,
+                                      int32_t accumulate, const uint32_t* amax_a, const uint32_t* amax_w0, const uint32_t* amax_w1,
+                                      void* stream);
+DGDM_API int dgdm_gemm_nn_f16x2(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc, int32_t M, int32_t N,
+                                int32_t K, int32_t accumulate, const uint32_t* amax_a, const uint32_t* amax_w, void* stream);
+DGDM_API size_t dgdm_gemm_tn_f16x2_workspace_bytes(int32_t M, int32_t N, int32_t K, int32_t with_bias);
+DGDM_API int dgdm_gemm_tn_f16x2(const float* dY, int64_t ldy, const float* X, int64_t ldx, float* dW, int64_t lddw, float* db,
+                                int32_t M, int32_t N, int32_t K, void* workspace, size_t workspace_bytes, const uint32_t* amax_dy,
+                                const uint32_t* amax_x, void* stream);
+DGDM_API int dgdm_gemm_tn_split_f16x2(const float* dY, int64_t ldy, const float* X, int64_t ldx, float* dW0, int64_t ld0,
+                                      int32_t K0, float* dW1, int64_t ld1, float* db, int32_t M, int32_t N, int32_t K,
+                                      void* workspace, size_t workspace_bytes, const uint32_t* amax_dy, const uint32_t* amax_x,
+                                      void* stream);
+
 
 /* ---------------------------------------------------------------------------------------------
  * K9  top-k node pooling and unpooling of the graph U-Net

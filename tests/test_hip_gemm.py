@@ -8,7 +8,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-MATHS = ["fp32", "bf16x3"]
+MATHS = ["fp32", "bf16x3", "f16x2"]
 
 
 @pytest.mark.parametrize("math", MATHS)
@@ -65,12 +65,14 @@ def test_gemm_nt_split_weight_is_the_concatenated_product(m, k0, k1, n):
     wide = torch.randn(n, k0 + 8, generator=g).to(DEV)              # W0 as a column slice of a wider matrix
     want2 = ops.gemm_nt_raw(a, torch.cat([wide[:, :k0], w1], dim=1), None, math="bf16x3")
     assert torch.equal(ops.gemm_nt_split_raw(a, wide[:, :k0], w1), want2)
+    # fp16 hi+lo kernel: the two weights share the scale of the larger maximum = the scale of the concatenated matrix
+    assert torch.equal(ops.gemm_nt_split_raw(a, w0, w1, b, math="f16x2"), ops.gemm_nt_raw(a, torch.cat([w0, w1], dim=1), b, math="f16x2"))
     with pytest.raises(ValueError):
         ops.gemm_nt_split_raw(a, w0, w1[:, :4])
 
 
 def test_bf16x3_matches_fp32_mfma_accuracy():
-    """The split GEMM's error against fp64 is of the size of the fp32-MFMA kernel's own (accumulation
+    """The split GEMMs' (bf16 x3 and fp16 hi+lo) error against fp64 is of the size of the fp32-MFMA kernel's own (accumulation
     rounding), also for operands spanning many binades and for gradient-sized (1e-6) values."""
     from dgdm_histopath_lab_amd import ops
     g = torch.Generator().manual_seed(5)
@@ -86,8 +88,9 @@ def test_bf16x3_matches_fp32_mfma_accuracy():
         for math in MATHS:
             y = ops.gemm_nt_raw(x, w, None, math=math); dx = ops.gemm_nn_raw(gy, w, math=math); dw, _ = ops.gemm_tn_raw(gy, x, False, math=math)
             err[math] = [float((a.double() - r).abs().max() / r.abs().max()) for a, r in ((y, ref_y), (dx, ref_dx), (dw, ref_dw))]
-        for e3, e32 in zip(err["bf16x3"], err["fp32"]):
-            assert e3 < 2e-6 and e3 < 4 * e32 + 2e-7, (scale_x, scale_g, err)
+        for math in ("bf16x3", "f16x2"):
+            for e3, e32 in zip(err[math], err["fp32"]):
+                assert e3 < 2e-6 and e3 < 4 * e32 + 2e-7, (math, scale_x, scale_g, err)
 
 
 def test_gemm_strided_operands_and_autograd():
@@ -110,3 +113,32 @@ def test_gemm_strided_operands_and_autograd():
     # shapes outside the kernel's domain fall back to the library GEMM but stay correct
     small = torch.randn(7, 10, device=DEV); ws = torch.randn(3, 10, device=DEV)
     assert_close(ops.linear(small, ws), small.double().cpu() @ ws.double().cpu().t(), 1e-5, "fallback")
+
+
+def test_f16x2_range_handling():
+    """What fp16 cannot hold without the per-operand power-of-two scale: gradients of 1e-30, inputs of 1e30, an all-zero operand,
+    an operand whose maximum is a single huge outlier, and an amax tag that is only an UPPER BOUND (a slice of a tagged matrix)."""
+    from dgdm_histopath_lab_amd import ops
+    g = torch.Generator().manual_seed(9)
+    m, k, n = 1024, 256, 128
+    w = (torch.randn(n, k, generator=g) / 16).to(DEV)
+    for sx in (1e-30, 1.0, 1e30):
+        x = (torch.randn(m, k, generator=g) * sx).to(DEV)
+        y = ops.gemm_nt_raw(x, w, None, math="f16x2")
+        ref = x.double() @ w.double().t()
+        assert torch.isfinite(y).all() and float((y.double() - ref).abs().max() / ref.abs().max()) < 2e-6, sx
+    z = ops.gemm_nt_raw(torch.zeros(m, k, device=DEV), w, None, math="f16x2")
+    assert torch.equal(z, torch.zeros_like(z))
+    x = torch.randn(m, k, generator=g).to(DEV)
+    x[5, 7] = 3e4                                  # one outlier sets the scale: everything else sits 15 binades lower
+    y = ops.gemm_nt_raw(x, w, None, math="f16x2")
+    ref = x.double() @ w.double().t()
+    assert float((y.double() - ref).abs().max() / ref.abs().max()) < 2e-6
+    small = x[:, :128]
+    big = torch.randn(m, 512, generator=g).to(DEV) * 100
+    big[:, :128] = small
+    ops.ensure_amax(big)                           # tag = max over the WIDE matrix (100x larger than the slice's own)
+    sl = ops.tag_amax(big[:, :128], ops.amax_of(big))
+    y2 = ops.gemm_nt_raw(sl, w[:, :128].contiguous(), None, math="f16x2")
+    ref2 = small.double() @ w[:, :128].double().t()
+    assert float((y2.double() - ref2).abs().max() / ref2.abs().max()) < 2e-6

@@ -1,10 +1,12 @@
-"""fp32 GEMM microbenchmark: own MFMA kernels vs the library path (torch -> hipBLASLt) at the model's shapes."""
+"""GEMM microbenchmark at the model's shapes: bf16x3 (exact 3-way bf16 split, 6 MFMAs / product) vs f16x2 (fp16 hi+lo, 3 MFMAs /
+product, amax slots already filled -- as in a step, where producers / the first GEMM on a tensor fill them) vs the fp32-MFMA
+kernels.  Alternating launches on the same box (box-to-box spread of these kernels is up to 7 %)."""
 import json, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dgdm_histopath_lab_amd import ops
 
-def t(fn, iters=50):
+def t(fn, iters=40):
     for _ in range(5): fn()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(); a.record()
@@ -14,15 +16,22 @@ def t(fn, iters=50):
 
 dev = "cuda:0"
 shapes = [(40000, 768, 512), (40000, 512, 512), (40000, 544, 512), (40000, 544, 256), (40000, 288, 256), (40000, 160, 128), (40000, 128, 128),
-          (40000, 128, 384), (40000, 128, 512), (40000, 512, 256), (40000, 256, 128), (20000, 160, 128), (10000, 160, 128), (5000, 160, 128)]
+          (40000, 128, 384), (40000, 512, 256), (40000, 256, 128), (20000, 160, 128), (10000, 160, 128), (5000, 160, 128)]
+maths = os.environ.get("MATHS", "bf16x3,f16x2").split(",")
+tot = {m: 0.0 for m in maths}
 for (m, k, n) in shapes:
     x = torch.randn(m, k, device=dev); w = torch.randn(n, k, device=dev); b = torch.randn(n, device=dev); gy = torch.randn(m, n, device=dev)
+    for ten in (x, w, gy):
+        ops.ensure_amax(ten)
     fl = 2.0 * m * k * n
     r = dict(M=m, K=k, N=n)
-    for name, ours, x3, lib in (
-            ("nt", lambda: ops.gemm_nt_raw(x, w, b), lambda: ops.gemm_nt_raw(x, w, b, math="bf16x3"), lambda: torch.nn.functional.linear(x, w, b)),
-            ("nn", lambda: ops.gemm_nn_raw(gy, w), lambda: ops.gemm_nn_raw(gy, w, math="bf16x3"), lambda: gy @ w),
-            ("tn", lambda: ops.gemm_tn_raw(gy, x, True), lambda: ops.gemm_tn_raw(gy, x, True, math="bf16x3"), lambda: (gy.t() @ x, gy.sum(0)))):
-        a, c, l = t(ours), t(x3), t(lib)
-        r[name] = f"fp32 {a:6.1f}us {fl/a/1e6:5.1f}TF | bf16x3 {c:6.1f}us {fl/c/1e6:5.1f}TF | lib {l:6.1f}us {fl/l/1e6:5.1f}TF"
+    for name, fn in (("nt", lambda mt: ops.gemm_nt_raw(x, w, b, math=mt)), ("nn", lambda mt: ops.gemm_nn_raw(gy, w, math=mt)),
+                     ("tn", lambda mt: ops.gemm_tn_raw(gy, x, True, math=mt))):
+        cells = []
+        for mt in maths:
+            us = t(lambda: fn(mt))
+            tot[mt] += us
+            cells.append(f"{mt} {us:6.1f}us {fl/us/1e6:5.1f}TF")
+        r[name] = " | ".join(cells)
     print(json.dumps(r))
+print(json.dumps({"sum_us": {k: round(v, 1) for k, v in tot.items()}}))
