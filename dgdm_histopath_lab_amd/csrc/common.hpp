@@ -64,6 +64,27 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// ---- operand maxima for the fp16 hi+lo GEMMs (include/dgdm_hip.h: "amax slot", csrc/gemm_h.hip).  A kernel that produces a
+// GEMM operand keeps max|x| as the float bits of its outputs (non-negative floats order like unsigned integers): per-thread
+// running maximum, then ONE atomic max per workgroup into way (blockIdx.x % WAYS) of the caller's slot group.  Integer max is
+// order-free: the result is bitwise reproducible.  Every thread of the workgroup must reach dgdm_amax_commit.
+__device__ __forceinline__ unsigned dgdm_absbits(float v) { return __float_as_uint(v) & 0x7fffffffu; }
+__device__ __forceinline__ unsigned dgdm_amax4(unsigned m, const float4 v) {
+  return max(max(m, dgdm_absbits(v.x)), max(max(dgdm_absbits(v.y), dgdm_absbits(v.z)), dgdm_absbits(v.w)));
+}
+__device__ __forceinline__ void dgdm_amax_commit(unsigned m, unsigned* __restrict__ group) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+  __shared__ unsigned dgdm_amax_sm[16];
+  if ((threadIdx.x & 63) == 0) dgdm_amax_sm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned t = 0;
+    for (unsigned w = 0; w < (blockDim.x + 63) / 64; ++w) t = max(t, dgdm_amax_sm[w]);
+    if (t) atomicMax(group + (blockIdx.x % DGDM_AMAX_WAYS) * DGDM_AMAX_STRIDE, t);
+  }
+}
+
 // Dropout seeds.  Every dropout site passes its seed by value (so a forward kernel and the backward
 // kernels that recompute its mask agree by construction).  A kernel launch recorded in a HIP graph
 // replays with the recorded value; to give each replay fresh masks the kernels fold in a per-device

@@ -14,7 +14,8 @@ namespace {
 template <int ACT, bool BWD>
 __global__ __launch_bounds__(256) void k_act_dropout(const float* __restrict__ x, const float* __restrict__ dy, int64_t n4,
                                                      float drop_p, DgdmSeed seed_in, float* __restrict__ out,
-                                                     const uint8_t* __restrict__ decide) {
+                                                     const uint8_t* __restrict__ decide, unsigned* __restrict__ amax) {
+  unsigned am = 0;
   const uint32_t seed = seed_in.value();
   const uint32_t thresh = (uint32_t)(drop_p * 65536.0f);
   const float keep_scale = drop_p > 0.f ? 1.0f / (1.0f - (float)thresh / 65536.0f) : 1.0f;
@@ -38,12 +39,14 @@ __global__ __launch_bounds__(256) void k_act_dropout(const float* __restrict__ x
       o.x *= m.x; o.y *= m.y; o.z *= m.z; o.w *= m.w;
     }
     reinterpret_cast<float4*>(out)[i] = o;
+    if (amax) am = dgdm_amax4(am, o);
   }
+  if (amax) dgdm_amax_commit(am, amax);     // wave-uniform: every thread of the block gets here
 }
 
 template <bool BWD>
 int launch(const float* x, const float* dy, int64_t n, int32_t act, float drop_p, uint32_t seed, float* out, const uint8_t* decide,
-           hipStream_t s) {
+           uint32_t* amax, hipStream_t s) {
   if (n < 0 || act < 0 || act > 3 || !(drop_p >= 0.f && drop_p < 1.f)) return DGDM_ERR_INVALID_ARG;
   if (decide && act != DGDM_ACT_RELU) return DGDM_ERR_INVALID_ARG;
   if (n == 0) return DGDM_OK;
@@ -52,7 +55,7 @@ int launch(const float* x, const float* dy, int64_t n, int32_t act, float drop_p
   const int64_t n4 = n >> 2;
   int64_t blocks = (n4 + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-#define GO(A) hipLaunchKernelGGL((k_act_dropout<A, BWD>), dim3((unsigned)blocks), dim3(256), 0, s, x, dy, n4, drop_p, dgdm_seed_arg(seed), out, decide)
+#define GO(A) hipLaunchKernelGGL((k_act_dropout<A, BWD>), dim3((unsigned)blocks), dim3(256), 0, s, x, dy, n4, drop_p, dgdm_seed_arg(seed), out, decide, amax)
   switch (act) {
     case DGDM_ACT_GELU: GO(DGDM_ACT_GELU); break;
     case DGDM_ACT_RELU: GO(DGDM_ACT_RELU); break;
@@ -66,11 +69,11 @@ int launch(const float* x, const float* dy, int64_t n, int32_t act, float drop_p
 }  // namespace
 
 extern "C" int dgdm_act_dropout_fwd(const float* x, int64_t n, int32_t act, float drop_p, uint32_t seed, float* y, const uint8_t* decide,
-                                    void* stream) {
-  return launch<false>(x, nullptr, n, act, drop_p, seed, y, decide, static_cast<hipStream_t>(stream));
+                                    uint32_t* amax, void* stream) {
+  return launch<false>(x, nullptr, n, act, drop_p, seed, y, decide, amax, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int dgdm_act_dropout_bwd(const float* x, const float* dy, int64_t n, int32_t act, float drop_p, uint32_t seed,
-                                    float* dx, const uint8_t* decide, void* stream) {
-  return launch<true>(x, dy, n, act, drop_p, seed, dx, decide, static_cast<hipStream_t>(stream));
+                                    float* dx, const uint8_t* decide, uint32_t* amax, void* stream) {
+  return launch<true>(x, dy, n, act, drop_p, seed, dx, decide, amax, static_cast<hipStream_t>(stream));
 }

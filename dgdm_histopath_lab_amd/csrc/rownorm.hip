@@ -32,8 +32,10 @@ template <int LPR, int R, int ACT>
 __global__ __launch_bounds__(256) void k_rownorm_fwd(const float* __restrict__ x, const float* __restrict__ res,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      int64_t rows, int L, int G, float eps, float drop_p, DgdmSeed seed_in,
-                                                     float* __restrict__ y, float* __restrict__ mean_o, float* __restrict__ rstd_o) {
+                                                     float* __restrict__ y, float* __restrict__ mean_o, float* __restrict__ rstd_o,
+                                                     unsigned* __restrict__ amax) {
   const uint32_t seed = seed_in.value();
+  unsigned am = 0;
   constexpr int GPW = 64 / LPR;  // pseudo-rows per wave
   const int lane = threadIdx.x & 63, sub = lane / LPR, lir = lane % LPR;
   const int64_t ngroups = (int64_t)gridDim.x * (blockDim.x >> 6) * GPW;
@@ -91,10 +93,12 @@ __global__ __launch_bounds__(256) void k_rownorm_fwd(const float* __restrict__ x
           o.x *= m.x; o.y *= m.y; o.z *= m.z; o.w *= m.w;
         }
         yr[k] = o;
+        if (amax) am = dgdm_amax4(am, o);
       }
     }
     if (lir == 0) { mean_o[row] = mu; rstd_o[row] = rs; }
   }
+  if (amax) dgdm_amax_commit(am, amax);
 }
 
 template <int LPR, int R, int ACT>
@@ -103,8 +107,10 @@ __global__ __launch_bounds__(256) void k_rownorm_bwd(const float* __restrict__ x
                                                      const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
                                                      const float* __restrict__ dy, int64_t rows, int L, int G, float drop_p,
                                                      DgdmSeed seed_in, float* __restrict__ dx, float* __restrict__ partial, int C,
-                                                     unsigned* __restrict__ tickets, int ntickets, int block_slots) {
+                                                     unsigned* __restrict__ tickets, int ntickets, int block_slots,
+                                                     unsigned* __restrict__ amax) {
   const uint32_t seed = seed_in.value();
+  unsigned am = 0;
   if (blockIdx.x == 0 && (int)threadIdx.x < ntickets) tickets[threadIdx.x] = 0u;   // for the column-sum kernel that follows
   constexpr int GPW = 64 / LPR;
   const int lane = threadIdx.x & 63, sub = lane / LPR, lir = lane % LPR;
@@ -166,9 +172,11 @@ __global__ __launch_bounds__(256) void k_rownorm_bwd(const float* __restrict__ x
         o.z = rs * (gz[r].z - m1 - xh[r].z * m2);
         o.w = rs * (gz[r].w - m1 - xh[r].w * m2);
         reinterpret_cast<float4*>(dx + row * L)[k] = o;
+        if (amax) am = dgdm_amax4(am, o);
       }
     }
   }
+  if (amax) dgdm_amax_commit(am, amax);
   // partial[slot][0..C) = dgamma slice, partial[slot][C..2C) = dbeta slice.
   // block_slots > 0 (the block's lane groups cover block_slots whole rows of 2C, i.e. groups-per-block % G == 0): the rows
   // are first added in LDS in index order and the block writes ONE row, slot = blockIdx.x -- 4x (LayerNorm) fewer partial
@@ -271,7 +279,7 @@ static int check_common(const float* x, const float* gamma, const float* beta, i
 
 extern "C" int dgdm_rownorm_fwd(const float* x, const float* res, const float* gamma, const float* beta, int32_t N, int32_t C,
                                 int32_t G, float eps, int32_t act, float drop_p, uint32_t seed, float* y, float* mean,
-                                float* rstd, void* stream_) {
+                                float* rstd, uint32_t* amax, void* stream_) {
   int rc = check_common(x, gamma, beta, N, C, G, act, drop_p);
   if (rc != DGDM_OK) return rc;
   if (N == 0) return DGDM_OK;
@@ -288,7 +296,7 @@ extern "C" int dgdm_rownorm_fwd(const float* x, const float* res, const float* g
   if (blocks > 16384) blocks = 16384;
 #define FWD(LPR_, R_, ACT_, ...) \
   hipLaunchKernelGGL((k_rownorm_fwd<LPR_, R_, ACT_>), dim3((unsigned)blocks), dim3(256), 0, s, __VA_ARGS__)
-  ROWNORM_DISPATCH(FWD, x, res, gamma, beta, rows, L, G, eps, drop_p, dgdm_seed_arg(seed), y, mean, rstd);
+  ROWNORM_DISPATCH(FWD, x, res, gamma, beta, rows, L, G, eps, drop_p, dgdm_seed_arg(seed), y, mean, rstd, amax);
 #undef FWD
   return dgdm_launch_status();
 }
@@ -303,7 +311,7 @@ extern "C" size_t dgdm_rownorm_bwd_workspace_bytes(int32_t N, int32_t C, int32_t
 extern "C" int dgdm_rownorm_bwd(const float* x, const float* res, const float* gamma, const float* beta, const float* mean,
                                 const float* rstd, const float* dy, int32_t N, int32_t C, int32_t G, int32_t act, float drop_p,
                                 uint32_t seed, float* dx, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
-                                void* stream_) {
+                                uint32_t* amax, void* stream_) {
   int rc = check_common(x, gamma, beta, N, C, G, act, drop_p);
   if (rc != DGDM_OK) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream_);
@@ -336,7 +344,7 @@ extern "C" int dgdm_rownorm_bwd(const float* x, const float* res, const float* g
   unsigned* tickets = reinterpret_cast<unsigned*>(stage1 + (int64_t)REDUCE_CHUNKS * 2 * C);
   const int ntickets = (2 * C + 63) / 64;
   if (ntickets > 256) return DGDM_ERR_UNSUPPORTED;
-  ROWNORM_DISPATCH(BWD, x, res, gamma, beta, mean, rstd, dy, rows, L, G, drop_p, dgdm_seed_arg(seed), dx, partial, C, tickets, ntickets, block_slots);
+  ROWNORM_DISPATCH(BWD, x, res, gamma, beta, mean, rstd, dy, rows, L, G, drop_p, dgdm_seed_arg(seed), dx, partial, C, tickets, ntickets, block_slots, amax);
 #undef BWD
   const int64_t chunk = (slots + REDUCE_CHUNKS - 1) / REDUCE_CHUNKS;
   const int nch = (int)((slots + chunk - 1) / chunk);

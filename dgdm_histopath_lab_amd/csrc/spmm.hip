@@ -17,8 +17,9 @@ __global__ __launch_bounds__(256) void k_spmm(const int32_t* __restrict__ rowptr
                                               int32_t table_rows, float* __restrict__ Y, int64_t ldy, int32_t N, int32_t C,
                                               const float* __restrict__ bias, int accumulate,
                                               const float* __restrict__ tail, int64_t ldt, int tail_c4,
-                                              const float* __restrict__ addend, int64_t lda) {
+                                              const float* __restrict__ addend, int64_t lda, unsigned* __restrict__ amax) {
   constexpr int RPW = 64 / LPR;                 // rows per wave
+  unsigned am = 0;                              // max |Y| over what this thread writes (GEMM operand scale, see common.hpp)
   const int lane = threadIdx.x & 63;
   const int sub = lane / LPR, lir = lane % LPR;  // which row of the wave, lane inside the row
   const int wave_global = (blockIdx.x * (blockDim.x >> 6)) + (threadIdx.x >> 6);
@@ -79,25 +80,31 @@ __global__ __launch_bounds__(256) void k_spmm(const int32_t* __restrict__ rowptr
           o.x += a0.x; o.y += a0.y; o.z += a0.z; o.w += a0.w;
         }
         dst[k] = o;
+        if (amax) am = dgdm_amax4(am, o);
       }
     }
     if (tail) {  // Y[row, C : C + 4*tail_c4) = tail[row, :]  (the [A_hat x | EA_hat] operand of a graph convolution)
       const float4* t = reinterpret_cast<const float4*>(tail + (int64_t)row * ldt);
-      for (int k = lir; k < tail_c4; k += LPR) dst[c4 + k] = t[k];
+      for (int k = lir; k < tail_c4; k += LPR) {
+        const float4 tv = t[k];
+        dst[c4 + k] = tv;
+        if (amax) am = dgdm_amax4(am, tv);
+      }
     }
   }
+  if (amax) dgdm_amax_commit(am, amax);
 }
 
 template <int LPR, int R, int UNROLL>
 int launch(const int32_t* rowptr, const int32_t* col, const float* w, const float* X, int64_t ldx, int32_t table_rows,
            float* Y, int64_t ldy, int32_t N, int32_t C, const float* bias, int accumulate, const float* tail, int64_t ldt,
-           int tail_c4, const float* addend, int64_t lda, hipStream_t stream) {
+           int tail_c4, const float* addend, int64_t lda, uint32_t* amax, hipStream_t stream) {
   constexpr int RPW = 64 / LPR;
   const int64_t waves = ((int64_t)N + RPW - 1) / RPW;
   int64_t blocks = (waves + 3) / 4;
   if (blocks > 256 * 64) blocks = 256 * 64;  // grid-stride beyond that
   hipLaunchKernelGGL((k_spmm<LPR, R, UNROLL>), dim3((unsigned)blocks), dim3(256), 0, stream, rowptr, col, w, X, ldx,
-                     table_rows, Y, ldy, N, C, bias, accumulate, tail, ldt, tail_c4, addend, lda);
+                     table_rows, Y, ldy, N, C, bias, accumulate, tail, ldt, tail_c4, addend, lda, amax);
   return dgdm_launch_status();
 }
 
@@ -106,7 +113,7 @@ int launch(const int32_t* rowptr, const int32_t* col, const float* w, const floa
 static int spmm_dispatch(const int32_t* rowptr, const int32_t* col, const float* w, const float* X, int64_t ldx,
                          int32_t table_rows, float* Y, int64_t ldy, int32_t N, int32_t C, const float* bias,
                          int32_t accumulate, const float* tail, int64_t ldt, int32_t Ct, const float* addend, int64_t lda,
-                         void* stream_) {
+                         uint32_t* amax, void* stream_) {
   DGDM_REQUIRE(N >= 0 && C > 0 && table_rows >= 0 && Ct >= 0);
   if (N == 0) return DGDM_OK;
   DGDM_REQUIRE(rowptr && col && w && Y);
@@ -124,7 +131,7 @@ static int spmm_dispatch(const int32_t* rowptr, const int32_t* col, const float*
   }
   const int c4 = C >> 2;
   if (!Ct) tail = nullptr;
-#define GO(LPR, R, U) return launch<LPR, R, U>(rowptr, col, w, X, ldx, table_rows, Y, ldy, N, C, bias, accumulate, tail, ldt, Ct >> 2, addend, lda, s)
+#define GO(LPR, R, U) return launch<LPR, R, U>(rowptr, col, w, X, ldx, table_rows, Y, ldy, N, C, bias, accumulate, tail, ldt, Ct >> 2, addend, lda, amax, s)
   if (c4 <= 8) GO(8, 1, 4);
   if (c4 <= 16) GO(16, 1, 4);
   if (c4 <= 32) GO(32, 1, 4);
@@ -138,18 +145,18 @@ static int spmm_dispatch(const int32_t* rowptr, const int32_t* col, const float*
 extern "C" int dgdm_spmm(const int32_t* rowptr, const int32_t* col, const float* w, const float* X, int64_t ldx,
                          int32_t table_rows, float* Y, int64_t ldy, int32_t N, int32_t C, const float* bias,
                          int32_t accumulate, void* stream) {
-  return spmm_dispatch(rowptr, col, w, X, ldx, table_rows, Y, ldy, N, C, bias, accumulate, nullptr, 0, 0, nullptr, 0, stream);
+  return spmm_dispatch(rowptr, col, w, X, ldx, table_rows, Y, ldy, N, C, bias, accumulate, nullptr, 0, 0, nullptr, 0, nullptr, stream);
 }
 
 extern "C" int dgdm_spmm_concat(const int32_t* rowptr, const int32_t* col, const float* w, const float* X, int64_t ldx,
                                 int32_t table_rows, const float* tail, int64_t ldt, int32_t Ct, float* Y, int64_t ldy,
-                                int32_t N, int32_t C, void* stream) {
-  return spmm_dispatch(rowptr, col, w, X, ldx, table_rows, Y, ldy, N, C, nullptr, 0, tail, ldt, Ct, nullptr, 0, stream);
+                                int32_t N, int32_t C, uint32_t* amax, void* stream) {
+  return spmm_dispatch(rowptr, col, w, X, ldx, table_rows, Y, ldy, N, C, nullptr, 0, tail, ldt, Ct, nullptr, 0, amax, stream);
 }
 
 extern "C" int dgdm_spmm_add(const int32_t* rowptr, const int32_t* col, const float* w, const float* X, int64_t ldx,
                              int32_t table_rows, const float* addend, int64_t lda, float* Y, int64_t ldy, int32_t N, int32_t C,
                              void* stream) {
   DGDM_REQUIRE(addend);
-  return spmm_dispatch(rowptr, col, w, X, ldx, table_rows, Y, ldy, N, C, nullptr, 0, nullptr, 0, 0, addend, lda, stream);
+  return spmm_dispatch(rowptr, col, w, X, ldx, table_rows, Y, ldy, N, C, nullptr, 0, nullptr, 0, 0, addend, lda, nullptr, stream);
 }

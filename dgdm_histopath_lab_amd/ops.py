@@ -494,12 +494,13 @@ class _RowNorm(torch.autograd.Function):
         y = torch.empty_like(x)
         mean = torch.empty(N * groups, dtype=torch.float32, device=x.device)
         rstd = torch.empty_like(mean)
+        slot = new_amax_slot(x.device)
         _lib.check(lib.dgdm_rownorm_fwd(x.data_ptr(), _lib.ptr(res), gamma.data_ptr(), beta.data_ptr(), N, C, groups, eps, act,
-                                        drop_p, seed, y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _lib.stream_ptr(x.device)),
+                                        drop_p, seed, y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), slot, _lib.stream_ptr(x.device)),
                    "dgdm_rownorm_fwd")
         ctx.save_for_backward(x, res, gamma, beta, mean, rstd)
         ctx.meta = (groups, act, drop_p, seed)
-        return y
+        return tag_amax(y, slot)
 
     @staticmethod
     def backward(ctx, gy):
@@ -512,10 +513,12 @@ class _RowNorm(torch.autograd.Function):
         dg, db = torch.empty_like(gamma), torch.empty_like(beta)
         wsb = _lib.workspace_bytes("dgdm_rownorm_bwd_workspace_bytes", N, C, groups)
         ws = torch.empty(max(wsb, 4) // 4, dtype=torch.float32, device=x.device)
+        slot = new_amax_slot(x.device)
         _lib.check(lib.dgdm_rownorm_bwd(x.data_ptr(), _lib.ptr(res), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(),
                                         rstd.data_ptr(), gy.data_ptr(), N, C, groups, act, drop_p, seed, dx.data_ptr(),
-                                        dg.data_ptr(), db.data_ptr(), ws.data_ptr(), wsb, _lib.stream_ptr(x.device)),
+                                        dg.data_ptr(), db.data_ptr(), ws.data_ptr(), wsb, slot, _lib.stream_ptr(x.device)),
                    "dgdm_rownorm_bwd")
+        tag_amax(dx, slot)
         return dx, (dx if res is not None else None), dg, db, None, None, None, None, None
 
 
@@ -543,11 +546,12 @@ class _ActDropout(torch.autograd.Function):
         x = _f32c(x)
         _lib.require_cuda(x)
         y = torch.empty_like(x)
-        _lib.check(lib.dgdm_act_dropout_fwd(x.data_ptr(), x.numel(), act, drop_p, seed, y.data_ptr(), _lib.ptr(decide),
+        slot = new_amax_slot(x.device)
+        _lib.check(lib.dgdm_act_dropout_fwd(x.data_ptr(), x.numel(), act, drop_p, seed, y.data_ptr(), _lib.ptr(decide), slot,
                                             _lib.stream_ptr(x.device)), "dgdm_act_dropout_fwd")
         ctx.save_for_backward(x)
         ctx.meta = (act, drop_p, seed, decide)
-        return y
+        return tag_amax(y, slot)
 
     @staticmethod
     def backward(ctx, gy):
@@ -556,9 +560,10 @@ class _ActDropout(torch.autograd.Function):
         act, drop_p, seed, decide = ctx.meta
         gy = _f32c(gy)
         dx = torch.empty_like(x)
-        _lib.check(lib.dgdm_act_dropout_bwd(x.data_ptr(), gy.data_ptr(), x.numel(), act, drop_p, seed, dx.data_ptr(), _lib.ptr(decide),
+        slot = new_amax_slot(x.device)
+        _lib.check(lib.dgdm_act_dropout_bwd(x.data_ptr(), gy.data_ptr(), x.numel(), act, drop_p, seed, dx.data_ptr(), _lib.ptr(decide), slot,
                                             _lib.stream_ptr(x.device)), "dgdm_act_dropout_bwd")
-        return dx, None, None, None, None
+        return tag_amax(dx, slot), None, None, None, None
 
 
 def act_dropout(x, act: int = ACT_NONE, drop_p: float = 0.0, training: bool = False, decide=None):
@@ -795,6 +800,7 @@ class AmaxArena:
 
 
 _ARENAS: dict = {}
+AMAX_FALLBACK_LOG: Optional[list] = None
 
 
 def _arena(device) -> AmaxArena:
@@ -803,6 +809,11 @@ def _arena(device) -> AmaxArena:
     if a is None:
         a = _ARENAS[key] = AmaxArena(torch.device("cuda", key))
     return a
+
+
+def new_amax_slot(device) -> Optional[int]:
+    """A zeroed slot group for a producer kernel to fill -- or None when the fp16 hi+lo GEMMs are not selected."""
+    return _arena(device).take() if GEMM_MATH == "f16x2" else None
 
 
 def amax_of(t: torch.Tensor) -> Optional[int]:
@@ -821,6 +832,10 @@ def ensure_amax(t: torch.Tensor) -> int:
     unit column stride, cols % 4 == 0, 16-byte aligned (what the tile GEMMs accept anyway)."""
     slot = amax_of(t)
     if slot is None:
+        if AMAX_FALLBACK_LOG is not None:       # diagnostics (tools/amax_fallbacks.py): who still needs a reduction launch?
+            import traceback
+            fr = [f for f in traceback.extract_stack(limit=12) if "dgdm_histopath_lab_amd" in f.filename][-5:-1]
+            AMAX_FALLBACK_LOG.append((tuple(t.shape), " < ".join(f"{f.name}:{f.lineno}" for f in reversed(fr))))
         slot = _arena(t.device).take()
         _lib.check(_lib.load().dgdm_amax_bits(t.data_ptr(), _ld(t), t.size(0), t.size(1), slot, _lib.stream_ptr(t.device)), "dgdm_amax_bits")
         t._dgdm_amax = slot
@@ -1228,10 +1243,12 @@ class _GraphConvLinear(torch.autograd.Function):
         ea_hat = _rowmajor(ea_hat)
         n, cin, ed = gs.num_nodes, x.size(1), ea_hat.size(1)
         buf = torch.empty(n, cin + ed, dtype=torch.float32, device=x.device)
+        slot = new_amax_slot(x.device)
         TIMERS.timed(f"spmm_c{cin}", lambda: _lib.check(
             lib.dgdm_spmm_concat(gs.rowptr.data_ptr(), gs.col.data_ptr(), gs.w.data_ptr(), x.data_ptr(), x.stride(0), x.size(0),
-                                 ea_hat.data_ptr(), ea_hat.stride(0), ed, buf.data_ptr(), buf.stride(0), n, cin,
+                                 ea_hat.data_ptr(), ea_hat.stride(0), ed, buf.data_ptr(), buf.stride(0), n, cin, slot,
                                  _lib.stream_ptr(x.device)), "dgdm_spmm_concat"))
+        tag_amax(buf, slot)
         ctx.gs, ctx.cin, ctx.has_bias, ctx.skip, ctx.math = gs, cin, b is not None, skip, GEMM_MATH
         ctx.amax = (None, None)
         if GEMM_MATH in ("bf16x3", "f16x2") and cin % 4 == 0:

@@ -140,7 +140,7 @@ DGDM_API int dgdm_spmm_add(const int32_t* rowptr, const int32_t* col, const floa
                            void* stream);
 DGDM_API int dgdm_spmm_concat(const int32_t* rowptr, const int32_t* col, const float* w, const float* X, int64_t ldx,
                               int32_t table_rows, const float* tail, int64_t ldt, int32_t Ct, float* Y, int64_t ldy,
-                              int32_t N, int32_t C, void* stream);
+                              int32_t N, int32_t C, uint32_t* amax, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K4  fused variable-length spatial attention (head dim 16), forward.
@@ -265,15 +265,18 @@ DGDM_API int dgdm_add_posenc(const float* x, int64_t ldx, const float* pos, cons
  * Dropout: element e is dropped iff hash(seed, e) < drop_p (16-bit threshold), kept values are
  * scaled by 1/(1-p); the backward recomputes the mask from the same seed.
  * Backward: dx (gradient wrt x and, identically, wrt res), dgamma, dbeta via a fixed-order
- * two-stage reduction through `workspace` (no atomics). */
+ * two-stage reduction through `workspace` (no atomics).
+ * `amax` (nullable; also on dgdm_act_dropout_*, dgdm_spmm_concat, dgdm_qsample ...): an amax slot group (see
+ * DGDM_AMAX_WAYS) that receives max|out| -- the kernel that produces a GEMM operand keeps its maximum, so the fp16 hi+lo
+ * GEMMs (K3'') need no separate reduction launch.  The group must be zero at launch. */
 DGDM_API int dgdm_rownorm_fwd(const float* x, const float* res, const float* gamma, const float* beta, int32_t N, int32_t C,
                               int32_t G, float eps, int32_t act, float drop_p, uint32_t seed, float* y, float* mean,
-                              float* rstd, void* stream);
+                              float* rstd, uint32_t* amax, void* stream);
 DGDM_API size_t dgdm_rownorm_bwd_workspace_bytes(int32_t N, int32_t C, int32_t G);
 DGDM_API int dgdm_rownorm_bwd(const float* x, const float* res, const float* gamma, const float* beta, const float* mean,
                               const float* rstd, const float* dy, int32_t N, int32_t C, int32_t G, int32_t act, float drop_p,
                               uint32_t seed, float* dx, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
-                              void* stream);
+                              uint32_t* amax, void* stream);
 
 /* y = dropout(act(x)) and dx = dy * mask * act'(x) over n contiguous floats (n % 4 == 0):
  * the GELU+dropout after each graph convolution (core/graph_layers.py:233-239) and the ReLU between
@@ -285,9 +288,9 @@ DGDM_API int dgdm_rownorm_bwd(const float* x, const float* res, const float* gam
  * gradients incomparable; handing the reference's decisions to the kernels makes both sides
  * differentiate the same piecewise-linear function.  NULL (every product call) = sign of the value. */
 DGDM_API int dgdm_act_dropout_fwd(const float* x, int64_t n, int32_t act, float drop_p, uint32_t seed, float* y,
-                                  const uint8_t* decide, void* stream);
+                                  const uint8_t* decide, uint32_t* amax, void* stream);
 DGDM_API int dgdm_act_dropout_bwd(const float* x, const float* dy, int64_t n, int32_t act, float drop_p, uint32_t seed,
-                                  float* dx, const uint8_t* decide, void* stream);
+                                  float* dx, const uint8_t* decide, uint32_t* amax, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Dense layers with few rows (one row per graph or per timestep): the denoiser's time-embedding MLP

@@ -142,3 +142,47 @@ def test_f16x2_range_handling():
     y2 = ops.gemm_nt_raw(sl, w[:, :128].contiguous(), None, math="f16x2")
     ref2 = small.double() @ w[:, :128].double().t()
     assert float((y2.double() - ref2).abs().max() / ref2.abs().max()) < 2e-6
+
+
+def test_producer_kernels_keep_the_operand_maximum():
+    """The kernels that produce GEMM operands (row norm fwd/bwd, activation+dropout fwd/bwd, the graph convolution's
+    aggregate-and-concat) leave max|out| in the tensor's amax slot group: bit-identical to a reduction over the finished tensor."""
+    from dgdm_histopath_lab_amd import GraphStructure, ops
+    prev = ops.configure(gemm="f16x2")
+    try:
+        g = torch.Generator().manual_seed(3)
+
+        def slot_max(t):
+            s = ops.amax_of(t)
+            assert s is not None
+            a = ops._arena(t.device)
+            off = (s - a.base) // 4
+            return a.buf[off: off + a.GROUP_WORDS].max().view(torch.float32)
+
+        x = torch.randn(5000, 512, generator=g).to(DEV).requires_grad_(True)
+        w, b = torch.randn(512, generator=g).to(DEV).requires_grad_(True), torch.randn(512, generator=g).to(DEV).requires_grad_(True)
+        y = ops.row_norm(x, w, b, act=ops.ACT_GELU, drop_p=0.1, training=True)
+        assert torch.equal(slot_max(y), y.detach().abs().max())
+        a = ops.act_dropout(y, ops.ACT_GELU, 0.1, True)
+        assert torch.equal(slot_max(a), a.detach().abs().max())
+        grads = {}
+        y.register_hook(lambda t: grads.setdefault("dy", t))
+        x.register_hook(lambda t: grads.setdefault("dx", t))
+        (a * torch.randn(5000, 512, generator=g).to(DEV)).sum().backward()
+        assert torch.equal(slot_max(grads["dy"]), grads["dy"].abs().max())      # act_dropout_bwd
+        assert torch.equal(slot_max(grads["dx"]), grads["dx"].abs().max())      # rownorm_bwd
+        n = 3000
+        gs = GraphStructure(torch.randint(0, n, (2, 12000), generator=g).to(DEV), n)
+        ea = torch.randn(n, 32, generator=g).to(DEV) * 3
+        conv_w, conv_we = torch.randn(256, 128, generator=g).to(DEV) / 12, torch.randn(256, 32, generator=g).to(DEV) / 6
+        xin = torch.randn(n, 128, generator=g).to(DEV)
+        seen = {}
+        orig = ops.gemm_nt_split_raw
+        ops.gemm_nt_split_raw = lambda buf, *a_, **k_: (seen.setdefault("buf", buf), orig(buf, *a_, **k_))[1]
+        try:
+            ops.graph_conv_linear(xin, ea, gs, conv_w, conv_we, None)
+        finally:
+            ops.gemm_nt_split_raw = orig
+        assert torch.equal(slot_max(seen["buf"]), seen["buf"].abs().max())      # spmm_concat: aggregate AND the copied edge block
+    finally:
+        ops.configure(**prev)

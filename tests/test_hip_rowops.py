@@ -134,12 +134,12 @@ def test_seed_epoch_changes_dropout_masks_and_zero_is_identity():
 
     def fwd():
         y = torch.empty_like(x)
-        _lib.check(lib.dgdm_act_dropout_fwd(x.data_ptr(), x.numel(), ops.ACT_NONE, 0.25, seed, y.data_ptr(), None, st), "fwd")
+        _lib.check(lib.dgdm_act_dropout_fwd(x.data_ptr(), x.numel(), ops.ACT_NONE, 0.25, seed, y.data_ptr(), None, None, st), "fwd")
         return y
 
     def bwd():
         g = torch.ones_like(x); dx = torch.empty_like(x)
-        _lib.check(lib.dgdm_act_dropout_bwd(x.data_ptr(), g.data_ptr(), x.numel(), ops.ACT_NONE, 0.25, seed, dx.data_ptr(), None, st), "bwd")
+        _lib.check(lib.dgdm_act_dropout_bwd(x.data_ptr(), g.data_ptr(), x.numel(), ops.ACT_NONE, 0.25, seed, dx.data_ptr(), None, None, st), "bwd")
         return dx
     try:
         _lib.check(lib.dgdm_seed_epoch_set(0, st), "set")
