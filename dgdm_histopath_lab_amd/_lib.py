@@ -39,7 +39,7 @@ SIGNATURES = {
     "dgdm_spatial_attn_fwd_variant": (C.c_int, [_p, _p, _p, _i64, _p, _p, _i32, _i32, _i32, _i32, C.c_float, C.c_float, C.c_float, C.c_uint32, _p, _i64, _p, _i32, _p]),
     "dgdm_spatial_attn_bwd": (C.c_int, [_p, _p, _p, _i64, _p, _p, _i64, _p, _p, _i32, _i32, _i32, _i32, C.c_float, C.c_float,
                                         _p, C.c_float, C.c_uint32, _p, _p, _p, _i64, _p, _p]),
-    "dgdm_add_posenc": (C.c_int, [_p, _i64, _p, _p, _i32, _i32, _i32, _p, _p, _i64, _p]),
+    "dgdm_add_posenc": (C.c_int, [_p, _i64, _p, _p, _i32, _i32, _i32, _p, _p, _i64, _p, _p]),
     "dgdm_spatial_attn_mean_weights": (C.c_int, [_p, _p, _i64, _p, _p, _i32, _i32, _i32, _i32, C.c_float, C.c_float, _p, _p, _p, _p]),
     "dgdm_rownorm_fwd": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, C.c_float, _i32, C.c_float, C.c_uint32, _p, _p, _p, _p, _p]),
     "dgdm_rownorm_bwd_workspace_bytes": (_sz, [_i32, _i32, _i32]),
@@ -64,11 +64,11 @@ SIGNATURES = {
     "dgdm_seed_epoch_set": (C.c_int, [C.c_uint32, _p]),
     "dgdm_linear_small_fwd": (C.c_int, [_p, _i64, _p, _i64, _p, _i32, _i32, _i32, _i32, _p, _i64, _p, _i64, _p]),
     "dgdm_linear_small_bwd": (C.c_int, [_p, _i64, _p, _i64, _i32, _p, _i64, _p, _i64, _i32, _i32, _i32, _p, _i64, _p, _i64, _p, _p]),
-    "dgdm_qsample": (C.c_int, [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _p, _p]),
+    "dgdm_qsample": (C.c_int, [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _p]),
     "dgdm_segment_mse_workspace_bytes": (_sz, [_i32]),
     "dgdm_segment_mse_fwd": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _p, _p, _sz, _p]),
     "dgdm_segment_mse_bwd": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _p, _p]),
-    "dgdm_mask_rows": (C.c_int, [_p, _p, _p, _i32, _i32, _p, _p]),
+    "dgdm_mask_rows": (C.c_int, [_p, _p, _p, _i32, _i32, _p, _p, _p]),
     "dgdm_ddpm_step": (C.c_int, [_p, _p, _p, _i64, C.c_float, C.c_float, C.c_float, C.c_float, _i32, _p, _p]),
     "dgdm_pool_score_fwd": (C.c_int, [_p, _i64, _p, _p, _i32, _i32, _p, _p, _p]),
     "dgdm_pool_score_bwd_workspace_bytes": (_sz, [_i32, _i32]),

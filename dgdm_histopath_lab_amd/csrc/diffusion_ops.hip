@@ -19,8 +19,9 @@ __device__ __forceinline__ int graph_of(const int32_t* __restrict__ ptr, int B, 
 
 __global__ __launch_bounds__(256) void k_qsample(const float* __restrict__ x, const float* __restrict__ eps, const float* __restrict__ tab_a,
                                                  const float* __restrict__ tab_b, const int64_t* __restrict__ t, const int32_t* __restrict__ ptr,
-                                                 int B, int64_t n4total, int c4, float* __restrict__ out) {
+                                                 int B, int64_t n4total, int c4, float* __restrict__ out, unsigned* __restrict__ amax) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  unsigned am = 0;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4total; i += stride) {
     const int g = graph_of(ptr, B, (int)(i / c4));
     const int64_t tg = t[g];
@@ -33,7 +34,9 @@ __global__ __launch_bounds__(256) void k_qsample(const float* __restrict__ x, co
       v.x = fmaf(b, e.x, v.x); v.y = fmaf(b, e.y, v.y); v.z = fmaf(b, e.z, v.z); v.w = fmaf(b, e.w, v.w);
     }
     reinterpret_cast<float4*>(out)[i] = v;
+    if (amax) am = dgdm_amax4(am, v);
   }
+  if (amax) dgdm_amax_commit(am, amax);
 }
 
 constexpr int MSE_CHUNKS = 64;
@@ -87,13 +90,17 @@ __global__ __launch_bounds__(256) void k_mse_bwd(const float* __restrict__ pred,
 }
 
 __global__ __launch_bounds__(256) void k_mask_rows(const float* __restrict__ x, const int32_t* __restrict__ node_map, const float* __restrict__ token,
-                                                   int64_t n4total, int f4, float* __restrict__ out) {
+                                                   int64_t n4total, int f4, float* __restrict__ out, unsigned* __restrict__ amax) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  unsigned am = 0;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4total; i += stride) {
     const int64_t n = i / f4;
     const int k = (int)(i % f4);
-    reinterpret_cast<float4*>(out)[i] = node_map[n] >= 0 ? reinterpret_cast<const float4*>(token)[k] : reinterpret_cast<const float4*>(x)[i];
+    const float4 v = node_map[n] >= 0 ? reinterpret_cast<const float4*>(token)[k] : reinterpret_cast<const float4*>(x)[i];
+    reinterpret_cast<float4*>(out)[i] = v;
+    if (amax) am = dgdm_amax4(am, v);
   }
+  if (amax) dgdm_amax_commit(am, amax);
 }
 
 inline unsigned stream_blocks(int64_t n4) {
@@ -104,14 +111,14 @@ inline unsigned stream_blocks(int64_t n4) {
 }  // namespace
 
 extern "C" int dgdm_qsample(const float* x, const float* eps, const float* tab_a, const float* tab_b, const int64_t* timesteps,
-                            const int32_t* ptr, int32_t B, int32_t N, int32_t C, float* out, void* stream) {
+                            const int32_t* ptr, int32_t B, int32_t N, int32_t C, float* out, uint32_t* amax, void* stream) {
   DGDM_REQUIRE(B >= 0 && N >= 0 && C > 0);
   if (N == 0 || B == 0) return DGDM_OK;
   DGDM_REQUIRE(x && tab_a && timesteps && ptr && out && (!eps || tab_b));
   if ((C & 3) || !dgdm_aligned16(x) || !dgdm_aligned16(out) || (eps && !dgdm_aligned16(eps))) return DGDM_ERR_UNSUPPORTED;
   const int64_t n4 = (int64_t)N * (C >> 2);
   hipLaunchKernelGGL(k_qsample, dim3(stream_blocks(n4)), dim3(256), 0, static_cast<hipStream_t>(stream), x, eps, tab_a, tab_b, timesteps, ptr,
-                     B, n4, C >> 2, out);
+                     B, n4, C >> 2, out, amax);
   return dgdm_launch_status();
 }
 
@@ -142,12 +149,13 @@ extern "C" int dgdm_segment_mse_bwd(const float* pred, const float* target, cons
   return dgdm_launch_status();
 }
 
-extern "C" int dgdm_mask_rows(const float* x, const int32_t* node_map, const float* token, int32_t N, int32_t F, float* out, void* stream) {
+extern "C" int dgdm_mask_rows(const float* x, const int32_t* node_map, const float* token, int32_t N, int32_t F, float* out, uint32_t* amax,
+                              void* stream) {
   DGDM_REQUIRE(N >= 0 && F > 0);
   if (N == 0) return DGDM_OK;
   DGDM_REQUIRE(x && node_map && token && out);
   if ((F & 3) || !dgdm_aligned16(x) || !dgdm_aligned16(token) || !dgdm_aligned16(out)) return DGDM_ERR_UNSUPPORTED;
   const int64_t n4 = (int64_t)N * (F >> 2);
-  hipLaunchKernelGGL(k_mask_rows, dim3(stream_blocks(n4)), dim3(256), 0, static_cast<hipStream_t>(stream), x, node_map, token, n4, F >> 2, out);
+  hipLaunchKernelGGL(k_mask_rows, dim3(stream_blocks(n4)), dim3(256), 0, static_cast<hipStream_t>(stream), x, node_map, token, n4, F >> 2, out, amax);
   return dgdm_launch_status();
 }

@@ -33,10 +33,13 @@ __global__ __launch_bounds__(256) void k_pos_minmax(const float* __restrict__ po
 // one thread per (node, frequency k): writes 4 consecutive channels (16 B)
 __global__ __launch_bounds__(256) void k_add_posenc(const float* __restrict__ x, int64_t ldx, const float* __restrict__ pos,
                                                     const int32_t* __restrict__ ptr, int B, const float* __restrict__ minmax,
-                                                    int N, int C, float* __restrict__ out, int64_t ldo) {
+                                                    int N, int C, float* __restrict__ out, int64_t ldo, unsigned* __restrict__ amax) {
   const int nk = C >> 2;
   const int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (idx >= (int64_t)N * nk) return;
+  if (idx >= (int64_t)N * nk) {          // keep the whole block alive for the amax commit's barrier
+    if (amax) dgdm_amax_commit(0u, amax);
+    return;
+  }
   const int n = (int)(idx / nk), k = (int)(idx % nk);
   int g = 0;
   while (g + 1 < B && ptr[g + 1] <= n) ++g;  // B is small
@@ -48,12 +51,13 @@ __global__ __launch_bounds__(256) void k_add_posenc(const float* __restrict__ x,
   if (x) v = *reinterpret_cast<const float4*>(x + (int64_t)n * ldx + 4 * k);
   v.x += sinf(px * f); v.y += cosf(px * f); v.z += sinf(py * f); v.w += cosf(py * f);
   *reinterpret_cast<float4*>(out + (int64_t)n * ldo + 4 * k) = v;
+  if (amax) dgdm_amax_commit(dgdm_amax4(0u, v), amax);
 }
 
 }  // namespace
 
 extern "C" int dgdm_add_posenc(const float* x, int64_t ldx, const float* pos, const int32_t* ptr, int32_t B, int32_t N,
-                               int32_t C, float* minmax_ws, float* out, int64_t ldo, void* stream_) {
+                               int32_t C, float* minmax_ws, float* out, int64_t ldo, uint32_t* amax, void* stream_) {
   DGDM_REQUIRE(B >= 0 && N >= 0 && C > 0);
   if (N == 0 || B == 0) return DGDM_OK;
   DGDM_REQUIRE(pos && ptr && minmax_ws && out);
@@ -62,6 +66,6 @@ extern "C" int dgdm_add_posenc(const float* x, int64_t ldx, const float* pos, co
   hipLaunchKernelGGL(k_pos_minmax, dim3(B), dim3(256), 0, s, pos, ptr, minmax_ws);
   const int64_t total = (int64_t)N * (C >> 2);
   hipLaunchKernelGGL(k_add_posenc, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, ldx, pos, ptr, B, minmax_ws, N, C, out,
-                     ldo);
+                     ldo, amax);
   return dgdm_launch_status();
 }

@@ -417,10 +417,11 @@ def add_posenc_raw(x: Optional[torch.Tensor], pos, plan: AttnPlan, C: int) -> to
     N = pos.size(0)
     out = torch.empty(N, C, dtype=torch.float32, device=pos.device)
     ws = torch.empty(2 * max(plan.B, 1), dtype=torch.float32, device=pos.device)
+    slot = new_amax_slot(pos.device)
     _lib.check(lib.dgdm_add_posenc(_lib.ptr(x), x.stride(0) if x is not None else 0, pos.data_ptr(), plan.ptr_dev.data_ptr(),
-                                   plan.B, N, C, ws.data_ptr(), out.data_ptr(), out.stride(0), _lib.stream_ptr(pos.device)),
+                                   plan.B, N, C, ws.data_ptr(), out.data_ptr(), out.stride(0), slot, _lib.stream_ptr(pos.device)),
                "dgdm_add_posenc")
-    return out
+    return tag_amax(out, slot)
 
 
 def add_posenc(x, pos, plan: AttnPlan):
@@ -599,9 +600,11 @@ def _qsample_raw(x, eps, timesteps, tab_a, tab_b, plan: AttnPlan):
     if timesteps.dtype != torch.int64 or timesteps.numel() != plan.B:
         raise ValueError(f"timesteps must be int64 [{plan.B}], got {timesteps.dtype} {tuple(timesteps.shape)}")
     out = torch.empty_like(x)
+    slot = new_amax_slot(x.device)
     _lib.check(lib.dgdm_qsample(x.data_ptr(), _lib.ptr(eps), tab_a.data_ptr(), _lib.ptr(tab_b), timesteps.contiguous().data_ptr(),
-                                plan.ptr_dev.data_ptr(), plan.B, x.size(0), x.size(1), out.data_ptr(), _lib.stream_ptr(x.device)), "dgdm_qsample")
-    return out
+                                plan.ptr_dev.data_ptr(), plan.B, x.size(0), x.size(1), out.data_ptr(), slot, _lib.stream_ptr(x.device)),
+               "dgdm_qsample")
+    return tag_amax(out, slot)
 
 
 def qsample(x0, eps, timesteps, tab_a, tab_b, plan: AttnPlan):
@@ -647,9 +650,10 @@ def mask_rows(x, node_map, token):
     x, token = _f32c(x), _f32c(token)
     _lib.require_cuda(x, node_map, token)
     out = torch.empty_like(x)
-    _lib.check(lib.dgdm_mask_rows(x.data_ptr(), node_map.data_ptr(), token.data_ptr(), x.size(0), x.size(1), out.data_ptr(),
+    slot = new_amax_slot(x.device)
+    _lib.check(lib.dgdm_mask_rows(x.data_ptr(), node_map.data_ptr(), token.data_ptr(), x.size(0), x.size(1), out.data_ptr(), slot,
                                   _lib.stream_ptr(x.device)), "dgdm_mask_rows")
-    return out
+    return tag_amax(out, slot)
 
 
 def ddpm_step(x, eps, z, sqrt_one_minus_ac: float, sqrt_ac: float, sqrt_alpha: float, sqrt_var: float, last: bool, out=None):
@@ -817,13 +821,20 @@ def new_amax_slot(device) -> Optional[int]:
 
 
 def amax_of(t: torch.Tensor) -> Optional[int]:
-    """Slot address of an upper bound of max|t| if a producer (or an earlier GEMM) left one, else None."""
-    return getattr(t, "_dgdm_amax", None)
+    """Slot address of an upper bound of max|t| if a producer (or an earlier GEMM) left one, else None.  A tag is bound to the
+    tensor's version counter: an in-place write after tagging (the autograd engine sums a second gradient INTO the first one's
+    buffer; an accumulating GEMM epilogue) invalidates it, and the consumer falls back to a reduction launch."""
+    tag = getattr(t, "_dgdm_amax", None)
+    if tag is None:
+        return None
+    if isinstance(tag, tuple):
+        return tag[0] if tag[1] == t._version else None
+    return tag                      # parameters: refreshed at every forward (WeightAmax), never version-bound
 
 
 def tag_amax(t: torch.Tensor, slot: Optional[int]) -> torch.Tensor:
     if slot is not None:
-        t._dgdm_amax = slot
+        t._dgdm_amax = (slot, t._version)
     return t
 
 
@@ -838,7 +849,7 @@ def ensure_amax(t: torch.Tensor) -> int:
             AMAX_FALLBACK_LOG.append((tuple(t.shape), " < ".join(f"{f.name}:{f.lineno}" for f in reversed(fr))))
         slot = _arena(t.device).take()
         _lib.check(_lib.load().dgdm_amax_bits(t.data_ptr(), _ld(t), t.size(0), t.size(1), slot, _lib.stream_ptr(t.device)), "dgdm_amax_bits")
-        t._dgdm_amax = slot
+        tag_amax(t, slot)
     return slot
 
 
@@ -1130,9 +1141,7 @@ class _LinearAddInto(torch.autograd.Function):
         ctx.has_bias, ctx.math = b is not None, GEMM_MATH
         gemm_nt_raw(x, w, b, out=acc, accumulate=True, math=GEMM_MATH)
         ctx.amax = (amax_of(x), amax_of(w))
-        ctx.mark_dirty(acc)
-        if hasattr(acc, "_dgdm_amax"):
-            del acc._dgdm_amax                  # its content changed: a maximum taken before no longer bounds it
+        ctx.mark_dirty(acc)                     # bumps acc's version: a maximum tagged before no longer applies (amax_of checks)
         return acc
 
     @staticmethod

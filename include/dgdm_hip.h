@@ -254,7 +254,7 @@ DGDM_API int dgdm_spatial_attn_h_bwd_dkv(const void* Rq, const void* Tq, const v
  *   minmax_ws: float [2*B] scratch; out [N, C] (row stride ldo).  C % 4 == 0.
  */
 DGDM_API int dgdm_add_posenc(const float* x, int64_t ldx, const float* pos, const int32_t* ptr, int32_t B, int32_t N,
-                             int32_t C, float* minmax_ws, float* out, int64_t ldo, void* stream);
+                             int32_t C, float* minmax_ws, float* out, int64_t ldo, uint32_t* amax, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K6/K7  fused row normalisation  y = dropout(act(norm_G(x [+ res]) * gamma + beta)).
@@ -338,14 +338,14 @@ DGDM_API int dgdm_segment_sum(const float* x, const int32_t* ptr, int32_t B, int
  *                  node_map of dgdm_topk_perm over N uniform variates = a uniformly random subset of the masked size).
  * C, F % 4 == 0; float pointers 16-byte aligned. */
 DGDM_API int dgdm_qsample(const float* x, const float* eps, const float* tab_a, const float* tab_b, const int64_t* timesteps,
-                          const int32_t* ptr, int32_t B, int32_t N, int32_t C, float* out, void* stream);
+                          const int32_t* ptr, int32_t B, int32_t N, int32_t C, float* out, uint32_t* amax, void* stream);
 DGDM_API size_t dgdm_segment_mse_workspace_bytes(int32_t B);
 DGDM_API int dgdm_segment_mse_fwd(const float* pred, const float* target, const int32_t* ptr, int32_t B, int32_t N, int32_t C,
                                   float* loss, void* workspace, size_t workspace_bytes, void* stream);
 DGDM_API int dgdm_segment_mse_bwd(const float* pred, const float* target, const float* gloss, const int32_t* ptr, int32_t B,
                                   int32_t N, int32_t C, float* dpred, void* stream);
 DGDM_API int dgdm_mask_rows(const float* x, const int32_t* node_map, const float* token, int32_t N, int32_t F, float* out,
-                            void* stream);
+                            uint32_t* amax, void* stream);
 
 /* K10  GlobalAttentionPool (models/dgdm_model.py:588-615): per graph, ONE query (the projected,
  * 1/sqrt(D)-scaled global token, q_scaled [H*D]) attends over the graph's nodes:
