@@ -328,7 +328,8 @@ def main():
             cur = stream[step_no[0] % len(stream)]
             step_no[0] += 1
         out = model.pretrain_step(cur, mask_ratio=0.15)
-        out["total_pretrain_loss"].backward()
+        with ops.deferred_weight_grads():      # zero_grad(set_to_none=True) above: the dW reductions of the pass run in one launch
+            out["total_pretrain_loss"].backward()
         if reducer is not None:
             reducer.all_reduce()
         opt.step()

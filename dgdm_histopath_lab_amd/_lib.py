@@ -104,6 +104,10 @@ SIGNATURES = {
     "dgdm_gemm_tn_f16x2_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
     "dgdm_gemm_tn_f16x2": (C.c_int, [_p, _i64, _p, _i64, _p, _i64, _p, _i32, _i32, _i32, _p, _sz, _p, _p, _p]),
     "dgdm_gemm_tn_split_f16x2": (C.c_int, [_p, _i64, _p, _i64, _p, _i64, _i32, _p, _i64, _p, _i32, _i32, _i32, _p, _sz, _p, _p, _p]),
+    "dgdm_gemm_tn_chunks": (_i32, [_i32, _i32, _i32]),
+    "dgdm_gemm_tn_partial_bf16x3": (C.c_int, [_p, _i64, _p, _i64, _i32, _i32, _i32, _i32, _p, _sz, _p]),
+    "dgdm_gemm_tn_partial_f16x2": (C.c_int, [_p, _i64, _p, _i64, _i32, _i32, _i32, _i32, _p, _sz, _p, _p, _p]),
+    "dgdm_gemm_tn_reduce_many": (C.c_int, [_p, _i32, _p]),
     "dgdm_attn_pack_bytes": (_sz, [_i32, _i32, _i32]),
     "dgdm_amax_scale_workspace_bytes": (_sz, []),
     "dgdm_amax_pow2_scale": (C.c_int, [_p, _i64, C.c_float, _p, _p, _sz, _p]),
@@ -117,6 +121,14 @@ SIGNATURES = {
     "dgdm_spmm_add": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _p, _i64, _p, _i64, _i32, _i32, _p]),
     "dgdm_spmm_concat": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _p, _i64, _i32, _p, _i64, _i32, _i32, _p, _p]),
 }
+
+class TnReduce(C.Structure):
+    """struct DgdmTnReduce of include/dgdm_hip.h"""
+    _fields_ = [("partial", _p), ("dW0", _p), ("dW1", _p), ("db", _p), ("ld0", _i64), ("ld1", _i64), ("slots", _i32), ("N", _i32), ("K", _i32),
+                ("K0", _i32)]
+
+
+TN_REDUCE_MAX = 24
 
 _lib: Optional[C.CDLL] = None
 

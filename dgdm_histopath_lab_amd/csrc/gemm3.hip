@@ -519,7 +519,8 @@ extern "C" size_t dgdm_gemm_tn_bf16x3_workspace_bytes(int32_t M, int32_t N, int3
 }
 
 static int tn_impl(const float* dY, int64_t ldy, const float* X, int64_t ldx, float* dW, int64_t lddw, int32_t K0, float* dW1, int64_t ld1,
-                   float* db, int32_t M, int32_t N, int32_t K, void* workspace, size_t workspace_bytes, void* stream_) {
+                   float* db, int32_t M, int32_t N, int32_t K, void* workspace, size_t workspace_bytes, void* stream_,
+                   bool partial_only = false) {
   if (M < 0 || N < 0 || K < 0) return DGDM_ERR_INVALID_ARG;
   if (N == 0 || K == 0) return DGDM_OK;
   if (K0 < 0 || K0 > K || (K0 > 0 && (!dW || lddw < K0)) || (K0 < K && (!dW1 || ld1 < K - K0))) return DGDM_ERR_INVALID_ARG;
@@ -547,6 +548,7 @@ static int tn_impl(const float* dY, int64_t ldy, const float* X, int64_t ldx, fl
     if (allow_big_lds(k_gemm3_tn_partial<false>) != DGDM_OK) return DGDM_ERR_LAUNCH;
     hipLaunchKernelGGL(k_gemm3_tn_partial<false>, grid, dim3(256), LDS_BYTES, s, dY, ldy, X, ldx, M, N, K, chunk, 0, partial);
   }
+  if (partial_only) return dgdm_launch_status();   // the caller reduces the chunk partials later (dgdm_gemm_tn_reduce_many)
   if (nchunks > 32)
     hipLaunchKernelGGL(k_gemm3_tn_final<16>, dim3((unsigned)((width + 15) / 16)), dim3(256), 0, s, partial, nchunks, width, N, K, dW, lddw, db, K0, dW1, ld1);
   else
@@ -557,6 +559,19 @@ static int tn_impl(const float* dY, int64_t ldy, const float* X, int64_t ldx, fl
 extern "C" int dgdm_gemm_tn_bf16x3(const float* dY, int64_t ldy, const float* X, int64_t ldx, float* dW, int64_t lddw, float* db, int32_t M,
                                    int32_t N, int32_t K, void* workspace, size_t workspace_bytes, void* stream) {
   return tn_impl(dY, ldy, X, ldx, dW, lddw, K, nullptr, 0, db, M, N, K, workspace, workspace_bytes, stream);
+}
+
+extern "C" int dgdm_gemm_tn_partial_bf16x3(const float* dY, int64_t ldy, const float* X, int64_t ldx, int32_t with_bias, int32_t M, int32_t N,
+                                           int32_t K, void* workspace, size_t workspace_bytes, void* stream) {
+  float dummy;   // tn_impl only checks the destination pointers for presence when it skips the final reduction
+  return tn_impl(dY, ldy, X, ldx, &dummy, K, K, nullptr, 0, with_bias ? &dummy : nullptr, M, N, K, workspace, workspace_bytes, stream, true);
+}
+
+// number of row chunks (= partial slots) dgdm_gemm_tn_*_bf16x3 / _f16x2 cut M into (same rule for both)
+extern "C" int32_t dgdm_gemm_tn_chunks(int32_t M, int32_t N, int32_t K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  const int chunk = tn3_chunk_rows(M, N, K);
+  return (M + chunk - 1) / chunk;
 }
 
 extern "C" int dgdm_gemm_tn_split_bf16x3(const float* dY, int64_t ldy, const float* X, int64_t ldx, float* dW0, int64_t ld0, int32_t K0, float* dW1,

@@ -529,7 +529,7 @@ extern "C" size_t dgdm_gemm_tn_f16x2_workspace_bytes(int32_t M, int32_t N, int32
 
 static int tn_impl(const float* dY, int64_t ldy, const float* X, int64_t ldx, float* dW, int64_t lddw, int32_t K0, float* dW1, int64_t ld1,
                    float* db, int32_t M, int32_t N, int32_t K, void* workspace, size_t workspace_bytes, const uint32_t* amax_dy,
-                   const uint32_t* amax_x, void* stream_) {
+                   const uint32_t* amax_x, void* stream_, bool partial_only = false) {
   if (M < 0 || N < 0 || K < 0) return DGDM_ERR_INVALID_ARG;
   if (N == 0 || K == 0) return DGDM_OK;
   if (K0 < 0 || K0 > K || (K0 > 0 && (!dW || lddw < K0)) || (K0 < K && (!dW1 || ld1 < K - K0))) return DGDM_ERR_INVALID_ARG;
@@ -557,6 +557,7 @@ static int tn_impl(const float* dY, int64_t ldy, const float* X, int64_t ldx, fl
     if (allow_big_lds(k_gemmh_tn_partial<false>) != DGDM_OK) return DGDM_ERR_LAUNCH;
     hipLaunchKernelGGL(k_gemmh_tn_partial<false>, grid, dim3(256), LDS_BYTES, s, dY, ldy, X, ldx, M, N, K, chunk, 0, partial, amax_dy, amax_x);
   }
+  if (partial_only) return dgdm_launch_status();   // the caller reduces the chunk partials later (dgdm_gemm_tn_reduce_many)
   if (nchunks > 32)
     hipLaunchKernelGGL(k_gemmh_tn_final<16>, dim3((unsigned)((width + 15) / 16)), dim3(256), 0, s, partial, nchunks, width, N, K, dW, lddw, db, K0, dW1, ld1);
   else
@@ -568,6 +569,14 @@ extern "C" int dgdm_gemm_tn_f16x2(const float* dY, int64_t ldy, const float* X, 
                                   int32_t N, int32_t K, void* workspace, size_t workspace_bytes, const uint32_t* amax_dy,
                                   const uint32_t* amax_x, void* stream) {
   return tn_impl(dY, ldy, X, ldx, dW, lddw, K, nullptr, 0, db, M, N, K, workspace, workspace_bytes, amax_dy, amax_x, stream);
+}
+
+extern "C" int dgdm_gemm_tn_partial_f16x2(const float* dY, int64_t ldy, const float* X, int64_t ldx, int32_t with_bias, int32_t M, int32_t N,
+                                          int32_t K, void* workspace, size_t workspace_bytes, const uint32_t* amax_dy, const uint32_t* amax_x,
+                                          void* stream) {
+  float dummy;   // tn_impl only checks the destination pointers for presence when it skips the final reduction
+  return tn_impl(dY, ldy, X, ldx, &dummy, K, K, nullptr, 0, with_bias ? &dummy : nullptr, M, N, K, workspace, workspace_bytes, amax_dy, amax_x,
+                 stream, true);
 }
 
 extern "C" int dgdm_gemm_tn_split_f16x2(const float* dY, int64_t ldy, const float* X, int64_t ldx, float* dW0, int64_t ld0, int32_t K0,

@@ -975,6 +975,56 @@ def gemm_nn_raw(a, w, out=None, accumulate=False, math="fp32"):
     return out
 
 
+# ---- deferred reduction of the split-M weight-gradient GEMMs ---------------------------------------------------------------
+# Inside ``with deferred_weight_grads():`` the dW GEMMs of a backward pass only write their chunk partials; ONE launch per 24 GEMMs
+# reduces them when the autograd engine finishes the pass (queue_callback) -- ~50 tiny reduction launches per step otherwise.  The
+# returned dW / db tensors are filled by that launch: only valid for loops that start the backward with ``.grad is None`` (the
+# engine then just stores the tensor) -- GraphedPretrainStep, DGDMTrainer.fit and bench.py do; anything that reads a weight
+# gradient before the pass ends must call ``flush_deferred_tn()`` first (parallel.FlatGradAllReducer's early bucket does).
+_DEFER_TN = False
+_PENDING_TN: list = []
+
+
+class deferred_weight_grads:
+    def __enter__(self):
+        global _DEFER_TN
+        self.prev, _DEFER_TN = _DEFER_TN, True
+        return self
+
+    def __exit__(self, *exc):
+        global _DEFER_TN
+        _DEFER_TN = self.prev
+        flush_deferred_tn()
+        return False
+
+
+def flush_deferred_tn() -> None:
+    """Reduce every pending dW GEMM's partials (fixed order, bitwise the immediate reduction)."""
+    if not _PENDING_TN:
+        return
+    lib = _lib.load()
+    pend = list(_PENDING_TN)
+    _PENDING_TN.clear()
+    for i in range(0, len(pend), _lib.TN_REDUCE_MAX):
+        part = pend[i:i + _lib.TN_REDUCE_MAX]
+        arr = (_lib.TnReduce * len(part))()
+        for j, (desc, _keep) in enumerate(part):
+            arr[j] = _lib.TnReduce(*desc)
+        dev = part[0][1][0].device
+        _lib.check(lib.dgdm_gemm_tn_reduce_many(arr, len(part), _lib.stream_ptr(dev)), "dgdm_gemm_tn_reduce_many")
+
+
+def _defer_tn(desc, keep) -> bool:
+    """Queue a reduction for the end of the running backward pass; False when no pass is running."""
+    if not _PENDING_TN:
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(flush_deferred_tn)
+        except RuntimeError:
+            return False
+    _PENDING_TN.append((desc, keep))
+    return True
+
+
 def gemm_tn_raw(dy, x, with_bias: bool, math="fp32", split: Optional[int] = None, out: Optional[torch.Tensor] = None):
     """dW [N,K] = dy[M,N]^T x[M,K]; db [N] = colsum(dy) (fixed-order split-M reduction).
     ``split=K0``: dW is delivered as two contiguous matrices (dW[:, :K0], dW[:, K0:]) -- returns ((dW0, dW1), db).
@@ -987,6 +1037,29 @@ def gemm_tn_raw(dy, x, with_bias: bool, math="fp32", split: Optional[int] = None
     wsb = _lib.workspace_bytes("dgdm_gemm_tn_workspace_bytes" if math == "fp32" else f"dgdm_gemm_tn_{math}_workspace_bytes", M, N, K, int(with_bias))
     ws = torch.empty(max(wsb, 4) // 4, dtype=torch.float32, device=x.device)
     extra = (ensure_amax(dy), ensure_amax(x)) if math == "f16x2" else ()
+    if _DEFER_TN and math in ("bf16x3", "f16x2") and M > 0:
+        if split is None:
+            dW = torch.empty(N, K, dtype=torch.float32, device=x.device) if out is None else out
+            d0, d1, k0 = dW, None, K
+        else:
+            if not 0 < split < K:
+                raise ValueError(f"split must lie inside (0, {K}), got {split}")
+            d0 = torch.empty(N, split, dtype=torch.float32, device=x.device)
+            d1 = torch.empty(N, K - split, dtype=torch.float32, device=x.device)
+            k0 = split
+        slots = lib.dgdm_gemm_tn_chunks(M, N, K)
+        desc = (ws.data_ptr(), d0.data_ptr(), _lib.ptr(d1), _lib.ptr(db), d0.stride(0), d1.stride(0) if d1 is not None else 0, slots, N, K, k0)
+        if _defer_tn(desc, (ws, d0, d1, db, dy, x)):
+            fn = getattr(lib, "dgdm_gemm_tn_partial_" + math)
+            TIMERS.timed("gemm_tn", lambda: _lib.check(
+                fn(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), int(with_bias), M, N, K, ws.data_ptr(), wsb, *extra,
+                   _lib.stream_ptr(x.device)), "dgdm_gemm_tn_partial"))
+            return (d0 if split is None else (d0, d1)), db
+        if split is not None:      # no backward pass is running: reduce right away into the tensors just made
+            fn = _gemm_entry(lib, "dgdm_gemm_tn_split", math)
+            _lib.check(fn(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), d0.data_ptr(), d0.stride(0), split, d1.data_ptr(), d1.stride(0),
+                          _lib.ptr(db), M, N, K, ws.data_ptr(), wsb, *extra, _lib.stream_ptr(x.device)), "dgdm_gemm_tn_split")
+            return (d0, d1), db
     if split is None:
         dW = torch.empty(N, K, dtype=torch.float32, device=x.device) if out is None else out
         assert dW.shape == (N, K) and dW.stride(1) == 1

@@ -61,6 +61,8 @@ class FlatGradAllReducer:
         if id(p) in self._bucket0_ids:
             self._fired += 1
             if self._fired == len(self._bucket0_ids) and self._early is None:
+                from . import ops
+                ops.flush_deferred_tn()           # weight gradients whose reduction was queued for the end of the pass (ops.py)
                 self._pack(0)
                 self._early = self._launch(0, async_op=True)
                 self.stats["early_launches"] += 1

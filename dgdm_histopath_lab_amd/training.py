@@ -286,9 +286,15 @@ class DGDMTrainer(nn.Module):
                         loss = None
                 if loss is None:
                     # gradients recorded by a graphed step must keep their addresses: zero them in place
-                    self._optimizer.zero_grad(set_to_none=self._graphed is None)
+                    fresh = self._graphed is None
+                    self._optimizer.zero_grad(set_to_none=fresh)
                     loss = self.training_step(batch, i)
-                    loss.backward()
+                    if fresh:       # .grad is None everywhere: the weight-gradient reductions may be deferred to the end of the pass
+                        from . import ops
+                        with ops.deferred_weight_grads():
+                            loss.backward()
+                    else:
+                        loss.backward()
                     if grad_reducer is not None:
                         grad_reducer.all_reduce()
                     self._optimizer.step()
@@ -442,9 +448,11 @@ class GraphedPretrainStep:
         self._lib.check(self._lib.load().dgdm_seed_epoch_advance(self._lib.stream_ptr(self.dev)), "dgdm_seed_epoch_advance")
 
     def _forward_backward(self):
+        from . import ops
         self._advance_seed()
         loss = self.step_fn(self.static)
-        loss.backward()
+        with ops.deferred_weight_grads():        # gradients start as None here: the dW reductions of the pass run in one launch at its end
+            loss.backward()
         return loss.detach()
 
     def _eager(self):

@@ -446,6 +446,28 @@ DGDM_API int dgdm_gemm_tn_split_f16x2(const float* dY, int64_t ldy, const float*
                                       void* workspace, size_t workspace_bytes, const uint32_t* amax_dy, const uint32_t* amax_x,
                                       void* stream);
 
+/* Deferred reduction of the split-M weight-gradient GEMMs.  dgdm_gemm_tn_partial_* run only the first half of dgdm_gemm_tn_*
+ * (chunk partials into `workspace`, [dgdm_gemm_tn_chunks(M,N,K)][N*K (+N when with_bias)] floats); dgdm_gemm_tn_reduce_many then
+ * reduces up to DGDM_TN_REDUCE_MAX such workspaces in ONE launch, with the arithmetic (fixed order) of the immediate reduction.
+ * `descs` is a HOST array (copied into the kernel arguments): partial/slots/N/K as above; dW0 (ld0) receives columns [0, K0) of
+ * dW, dW1 (ld1) columns [K0, K) (K0 == K: one matrix); db nullable. */
+#define DGDM_TN_REDUCE_MAX 24
+typedef struct DgdmTnReduce {
+  const float* partial;
+  float* dW0;
+  float* dW1;
+  float* db;
+  int64_t ld0, ld1;
+  int32_t slots, N, K, K0;
+} DgdmTnReduce;
+DGDM_API int32_t dgdm_gemm_tn_chunks(int32_t M, int32_t N, int32_t K);
+DGDM_API int dgdm_gemm_tn_partial_bf16x3(const float* dY, int64_t ldy, const float* X, int64_t ldx, int32_t with_bias, int32_t M,
+                                         int32_t N, int32_t K, void* workspace, size_t workspace_bytes, void* stream);
+DGDM_API int dgdm_gemm_tn_partial_f16x2(const float* dY, int64_t ldy, const float* X, int64_t ldx, int32_t with_bias, int32_t M,
+                                        int32_t N, int32_t K, void* workspace, size_t workspace_bytes, const uint32_t* amax_dy,
+                                        const uint32_t* amax_x, void* stream);
+DGDM_API int dgdm_gemm_tn_reduce_many(const DgdmTnReduce* descs, int32_t count, void* stream);
+
 
 /* ---------------------------------------------------------------------------------------------
  * K9  top-k node pooling and unpooling of the graph U-Net

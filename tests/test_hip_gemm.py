@@ -186,3 +186,41 @@ def test_producer_kernels_keep_the_operand_maximum():
         assert torch.equal(slot_max(seen["buf"]), seen["buf"].abs().max())      # spmm_concat: aggregate AND the copied edge block
     finally:
         ops.configure(**prev)
+
+
+@pytest.mark.parametrize("math", ["bf16x3", "f16x2"])
+def test_deferred_weight_gradient_reduction_is_bitwise_the_immediate_one(math):
+    """Inside ops.deferred_weight_grads() the dW GEMMs of a backward pass leave their chunk partials and ONE launch reduces them
+    when the pass ends (csrc/dw_reduce.hip): same sums in the same order -- weight and bias gradients are bit-identical, for few
+    and for many chunks, for the split form (two parameters behind one contraction) and for an output that is a column block."""
+    from dgdm_histopath_lab_amd import GraphStructure, ops
+    prev = ops.configure(gemm=math)
+    try:
+        g = torch.Generator().manual_seed(8)
+        x = torch.randn(40000, 128, generator=g).to(DEV)
+        ws = [(torch.randn(o, i, generator=g) / i ** 0.5).to(DEV) for o, i in ((512, 128), (128, 512), (256, 128), (128, 256))]
+        bs = [torch.randn(w.size(0), generator=g).to(DEV) for w in ws]
+        n = x.size(0)
+        gs = GraphStructure(torch.randint(0, n, (2, 100000), generator=g).to(DEV), n)
+        ea = torch.randn(n, 32, generator=g).to(DEV)
+        cw, cwe = (torch.randn(128, 128, generator=g) / 11).to(DEV), (torch.randn(128, 32, generator=g) / 6).to(DEV)
+
+        def run(deferred):
+            params = [t.clone().requires_grad_(True) for t in ws + bs + [cw, cwe]]
+            W, Bv, (pw, pwe) = params[:4], params[4:8], params[8:]
+            h = ops.linear(ops.linear(x, W[0], Bv[0]), W[1], Bv[1])
+            h = ops.graph_conv_linear(h, ea, gs, pw, pwe, None)
+            h = ops.linear(ops.linear(h, W[2], Bv[2]), W[3], Bv[3])
+            loss = h.square().mean()
+            if deferred:
+                with ops.deferred_weight_grads():
+                    loss.backward()
+                assert not ops._PENDING_TN
+            else:
+                loss.backward()
+            return [p.grad for p in params]
+        a, b = run(False), run(True)
+        assert all(torch.equal(u, v) for u, v in zip(a, b))
+        assert all(torch.isfinite(v).all() and v.abs().max() > 0 for v in b)
+    finally:
+        ops.configure(**prev)
