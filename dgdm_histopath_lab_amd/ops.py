@@ -1049,7 +1049,10 @@ def gemm_tn_raw(dy, x, with_bias: bool, math="fp32", split: Optional[int] = None
             k0 = split
         slots = lib.dgdm_gemm_tn_chunks(M, N, K)
         desc = (ws.data_ptr(), d0.data_ptr(), _lib.ptr(d1), _lib.ptr(db), d0.stride(0), d1.stride(0) if d1 is not None else 0, slots, N, K, k0)
-        if _defer_tn(desc, (ws, d0, d1, db, dy, x)):
+        # keep-alive ALIASES of the outputs (same storage, other tensor objects): holding d0 itself would raise its reference count and
+        # make the engine's AccumulateGrad CLONE it -- a copy of memory this launch has not filled yet -- instead of adopting it
+        alias = lambda t: None if t is None else t.detach()
+        if _defer_tn(desc, (ws, alias(d0), alias(d1), alias(db), dy, x)):
             fn = getattr(lib, "dgdm_gemm_tn_partial_" + math)
             TIMERS.timed("gemm_tn", lambda: _lib.check(
                 fn(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), int(with_bias), M, N, K, ws.data_ptr(), wsb, *extra,
