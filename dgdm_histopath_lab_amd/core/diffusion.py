@@ -190,8 +190,15 @@ class DiffusionLayer(nn.Module):
                 self._sample_loop(sx, ts[:2] + ts[-1:], sz[:2] if sz else None)
             torch.cuda.current_stream(device).wait_stream(side)
             g = torch.cuda.CUDAGraph()
-            with ops.collect_device_constants() as held, torch.cuda.graph(g):
-                out = self._sample_loop(sx, ts, sz)
+            import gc
+            gc_was = gc.isenabled()
+            gc.disable()      # no cyclic collection inside the capture (it could destroy another recording: illegal during capture)
+            try:
+                with ops.collect_device_constants() as held, torch.cuda.graph(g):
+                    out = self._sample_loop(sx, ts, sz)
+            finally:
+                if gc_was:
+                    gc.enable()
             cache[key] = (g, sx, sz, out, held)
         g, sx, sz, out, _ = cache[key]
         sx.copy_(x)

@@ -1005,30 +1005,39 @@ def flush_deferred_tn() -> None:
     lib = _lib.load()
     pend = list(_PENDING_TN)
     _PENDING_TN.clear()
-    for i in range(0, len(pend), _lib.TN_REDUCE_MAX):
-        part = pend[i:i + _lib.TN_REDUCE_MAX]
-        arr = (_lib.TnReduce * len(part))()
-        for j, (desc, _keep) in enumerate(part):
-            arr[j] = _lib.TnReduce(*desc)
-        dev = part[0][1][0].device
-        _lib.check(lib.dgdm_gemm_tn_reduce_many(arr, len(part), _lib.stream_ptr(dev)), "dgdm_gemm_tn_reduce_many")
+    # on the stream each GEMM's partials were launched on (the engine's end-of-pass callback may run under another current stream
+    # than the backward nodes did, e.g. when the step runs on a side stream)
+    by_stream: dict = {}
+    for desc, keep, stream in pend:
+        by_stream.setdefault(stream, []).append(desc)
+    for stream, descs in by_stream.items():
+        for i in range(0, len(descs), _lib.TN_REDUCE_MAX):
+            part = descs[i:i + _lib.TN_REDUCE_MAX]
+            arr = (_lib.TnReduce * len(part))()
+            for j, desc in enumerate(part):
+                arr[j] = _lib.TnReduce(*desc)
+            _lib.check(lib.dgdm_gemm_tn_reduce_many(arr, len(part), stream), "dgdm_gemm_tn_reduce_many")
 
 
-def _defer_tn(desc, keep) -> bool:
+def _defer_tn(desc, keep, stream) -> bool:
     """Queue a reduction for the end of the running backward pass; False when no pass is running."""
     if not _PENDING_TN:
         try:
             torch.autograd.Variable._execution_engine.queue_callback(flush_deferred_tn)
         except RuntimeError:
             return False
-    _PENDING_TN.append((desc, keep))
+    _PENDING_TN.append((desc, keep, stream))
     return True
 
 
-def gemm_tn_raw(dy, x, with_bias: bool, math="fp32", split: Optional[int] = None, out: Optional[torch.Tensor] = None):
+def gemm_tn_raw(dy, x, with_bias: bool, math="fp32", split: Optional[int] = None, out: Optional[torch.Tensor] = None,
+                may_defer: bool = False):
     """dW [N,K] = dy[M,N]^T x[M,K]; db [N] = colsum(dy) (fixed-order split-M reduction).
     ``split=K0``: dW is delivered as two contiguous matrices (dW[:, :K0], dW[:, K0:]) -- returns ((dW0, dW1), db).
-    ``out``: write dW there (a [N, K] view with unit column stride, e.g. a column block of a wider gradient matrix)."""
+    ``out``: write dW there (a [N, K] view with unit column stride, e.g. a column block of a wider gradient matrix).
+    ``may_defer``: the caller guarantees that dW / db go STRAIGHT to leaf parameters (the engine only stores them), so inside
+    ``deferred_weight_grads()`` their reduction may wait for the end of the pass; a gradient that another backward node reads
+    (padding / slicing of a concatenated weight) must not be deferred."""
     lib = _lib.load()
     dy, x = _rm_tagged(dy), _rm_tagged(x)
     M, N = dy.shape
@@ -1037,7 +1046,7 @@ def gemm_tn_raw(dy, x, with_bias: bool, math="fp32", split: Optional[int] = None
     wsb = _lib.workspace_bytes("dgdm_gemm_tn_workspace_bytes" if math == "fp32" else f"dgdm_gemm_tn_{math}_workspace_bytes", M, N, K, int(with_bias))
     ws = torch.empty(max(wsb, 4) // 4, dtype=torch.float32, device=x.device)
     extra = (ensure_amax(dy), ensure_amax(x)) if math == "f16x2" else ()
-    if _DEFER_TN and math in ("bf16x3", "f16x2") and M > 0:
+    if _DEFER_TN and may_defer and math in ("bf16x3", "f16x2") and M > 0:
         if split is None:
             dW = torch.empty(N, K, dtype=torch.float32, device=x.device) if out is None else out
             d0, d1, k0 = dW, None, K
@@ -1052,7 +1061,7 @@ def gemm_tn_raw(dy, x, with_bias: bool, math="fp32", split: Optional[int] = None
         # keep-alive ALIASES of the outputs (same storage, other tensor objects): holding d0 itself would raise its reference count and
         # make the engine's AccumulateGrad CLONE it -- a copy of memory this launch has not filled yet -- instead of adopting it
         alias = lambda t: None if t is None else t.detach()
-        if _defer_tn(desc, (ws, alias(d0), alias(d1), alias(db), dy, x)):
+        if _defer_tn(desc, (ws, alias(d0), alias(d1), alias(db), dy, x), _lib.stream_ptr(x.device)):
             fn = getattr(lib, "dgdm_gemm_tn_partial_" + math)
             TIMERS.timed("gemm_tn", lambda: _lib.check(
                 fn(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), int(with_bias), M, N, K, ws.data_ptr(), wsb, *extra,
@@ -1113,6 +1122,7 @@ class _Linear(torch.autograd.Function):
         x, w = _rm_tagged(x), _rm_tagged(w)
         ctx.save_for_backward(x, w)
         ctx.has_bias, ctx.math = b is not None, GEMM_MATH
+        ctx.leaf = w.is_leaf and (b is None or b.is_leaf)     # gradients go straight to parameters: their reduction may be deferred
         y = gemm_nt_raw(x, w, b, math=GEMM_MATH)
         ctx.amax = (amax_of(x), amax_of(w))      # slots the forward GEMM used (or filled): the backward GEMMs reuse them
         return y
@@ -1125,7 +1135,7 @@ class _Linear(torch.autograd.Function):
         dx = gemm_nn_raw(gy, w, math=ctx.math) if ctx.needs_input_grad[0] else None
         dW = db = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            dW, db = gemm_tn_raw(gy, x, ctx.has_bias, math=ctx.math)
+            dW, db = gemm_tn_raw(gy, x, ctx.has_bias, math=ctx.math, may_defer=ctx.leaf)
         return dx, dW, db
 
 
@@ -1215,6 +1225,7 @@ class _LinearAddInto(torch.autograd.Function):
         x, w = _rm_tagged(x), _rm_tagged(w)
         ctx.save_for_backward(x, w)
         ctx.has_bias, ctx.math = b is not None, GEMM_MATH
+        ctx.leaf = w.is_leaf and (b is None or b.is_leaf)
         gemm_nt_raw(x, w, b, out=acc, accumulate=True, math=GEMM_MATH)
         ctx.amax = (amax_of(x), amax_of(w))
         ctx.mark_dirty(acc)                     # bumps acc's version: a maximum tagged before no longer applies (amax_of checks)
@@ -1228,7 +1239,7 @@ class _LinearAddInto(torch.autograd.Function):
         dx = gemm_nn_raw(gy, w, math=ctx.math) if ctx.needs_input_grad[1] else None
         dW = db = None
         if ctx.needs_input_grad[2] or (ctx.has_bias and ctx.needs_input_grad[3]):
-            dW, db = gemm_tn_raw(gy, x, ctx.has_bias, math=ctx.math)
+            dW, db = gemm_tn_raw(gy, x, ctx.has_bias, math=ctx.math, may_defer=ctx.leaf)
         return gy, dx, dW, db
 
 
@@ -1260,6 +1271,7 @@ class _DenoiseFirstLayer(torch.autograd.Function):
                                               _lib.stream_ptr(x.device)), "dgdm_segment_bcast_add")
         ctx.save_for_backward(x, te, w)
         ctx.plan, ctx.math, ctx.has_bias = plan, GEMM_MATH, b is not None
+        ctx.leaf = w.is_leaf
         return out
 
     @staticmethod
@@ -1278,7 +1290,7 @@ class _DenoiseFirstLayer(torch.autograd.Function):
         gpg = segment_sum_raw(g, plan)                                         # [B, N_out]: gradient of the per-graph bias
         dw = torch.empty(N_out, K, dtype=torch.float32, device=dev)
         if big:
-            gemm_tn_raw(g, x, False, math=ctx.math, out=dw[:, :C])
+            gemm_tn_raw(g, x, False, math=ctx.math, out=dw[:, :C], may_defer=ctx.leaf)
         else:
             _lib.check(lib.dgdm_linear_small_bwd(g.data_ptr(), _ld(g), None, 0, ACT_NONE, x.data_ptr(), _ld(x), None, 0, x.size(0), N_out, C,
                                                  None, 0, dw.data_ptr(), K, None, _lib.stream_ptr(dev)), "dgdm_linear_small_bwd")
@@ -1336,6 +1348,7 @@ class _GraphConvLinear(torch.autograd.Function):
         tag_amax(buf, slot)
         ctx.gs, ctx.cin, ctx.has_bias, ctx.skip, ctx.math = gs, cin, b is not None, skip, GEMM_MATH
         ctx.amax = (None, None)
+        ctx.leaf = w.is_leaf and we.is_leaf and (b is None or b.is_leaf)
         if GEMM_MATH in ("bf16x3", "f16x2") and cin % 4 == 0:
             w = _rm_tagged(w)
             ctx.save_for_backward(buf, w)          # the kernel reads the two weights side by side: no concatenated copy
@@ -1364,7 +1377,7 @@ class _GraphConvLinear(torch.autograd.Function):
             dx = spmm_raw(gs.rowptr_t, gs.col_t, gs.w_t, dagg, gs.num_nodes, addend=gskip)
         dw = dwe = db = None
         if ctx.needs_input_grad[3] or ctx.needs_input_grad[4] or (ctx.has_bias and ctx.needs_input_grad[5]):
-            (dw, dwe), db = gemm_tn_raw(gy, buf, ctx.has_bias, math=math, split=cin)
+            (dw, dwe), db = gemm_tn_raw(gy, buf, ctx.has_bias, math=math, split=cin, may_defer=ctx.leaf)
         return dx, None, None, dw, dwe, db, None
 
 

@@ -476,6 +476,9 @@ class GraphedPretrainStep:
         # arguments: hold them here, whatever the value cache of ops.device_constant evicts later
         if self.reducer is not None:
             self.reducer.capturing = True       # its hooks stay passive: the recording packs the buffer itself
+        import gc
+        gc_was = gc.isenabled()
+        gc.disable()     # a cyclic collection DURING the capture could destroy an older recording (hipGraphDestroy inside a capture aborts)
         try:
             with ops.collect_device_constants() as self._held_constants, torch.cuda.graph(g1, **mode):
                 self._loss = self._forward_backward()
@@ -491,6 +494,8 @@ class GraphedPretrainStep:
                     self.opt.step()
                 self._graphs.append(g2)
         finally:
+            if gc_was:
+                gc.enable()
             if self.reducer is not None:
                 self.reducer.capturing = False
 
