@@ -144,9 +144,9 @@ def gather_microbench(dev, iters=200, cold_iters=12):
 
 
 def projection_microbench(dev, iters=50):
-    """The largest dense contraction of the step (FeatureEncoder first layer: [4 x 10k, 768] x [512, 768]^T) on the
-    shipped GEMM kernel: algorithmic fp32 FLOP against the fp32 matrix peak, issued bf16 FLOP (6 MFMAs per product
-    term, csrc/gemm3.hip) against the bf16 peak."""
+    """The largest dense contraction of the step (FeatureEncoder first layer: [4 x 10k, 768] x [512, 768]^T) on the shipped GEMM
+    kernel, priced on the matrix pipe it runs on: algorithmic FLOP (2 M N K), the FLOP the kernel issues (3 fp16 MFMAs per product
+    term for the fp16 hi+lo kernel, 6 bf16 MFMAs for the exact bf16 split), and the fp32-equivalent fraction."""
     from dgdm_histopath_lab_amd import ops
     m, k, n = NODES * PER_GPU_BATCH, FEATS, 512
     x = torch.randn(m, k, device=dev); w = torch.randn(n, k, device=dev) / k ** 0.5; b = torch.randn(n, device=dev)
@@ -162,16 +162,18 @@ def projection_microbench(dev, iters=50):
     us = a.elapsed_time(e) * 1e3 / iters
     fl = 2.0 * m * k * n
     tf = fl / us / 1e6
-    bf = math == "bf16x3"
-    peak = FP16_MFMA_PEAK_TFLOPS if bf else FP32_MFMA_PEAK_TFLOPS      # the pipe the kernel runs on (bf16 dense peak = f16 dense peak)
-    out = {"kernel": "dgdm_gemm_nt_bf16x3 (k_gemm3_rows<true,false>)" if bf else "dgdm_gemm_nt (k_gemm_rows)",
-           "workload": f"[{m}, {k}] x [{n}, {k}]^T + bias", "bound": "mfma", "achieved": round(tf, 1), "peak": peak,
-           "unit": "TFLOP/s", "frac": round(tf / peak, 4), "us_per_launch": round(us, 1), "algorithmic_flop": fl,
-           "pipe": "bf16 dense matrix pipe (v_mfma_f32_32x32x16_bf16)" if bf else "fp32 matrix pipe",
+    info = {"f16x2": ("dgdm_gemm_nt_f16x2 (k_gemmh_rows<true,false,false>)", "f16 dense matrix pipe (v_mfma_f32_32x32x16_f16)",
+                      "fp16 hi+lo operands (power-of-two scaled by the operand maximum), 3 MFMAs per product, fp32 accumulate", 3),
+            "bf16x3": ("dgdm_gemm_nt_bf16x3 (k_gemm3_rows<true,false,false>)", "bf16 dense matrix pipe (v_mfma_f32_32x32x16_bf16)",
+                       "bf16 x3 exact split, 6 MFMAs per product, fp32 accumulate", 6),
+            "fp32": ("dgdm_gemm_nt (k_gemm_rows)", "fp32 matrix pipe", "fp32", 1)}[math]
+    peak = FP32_MFMA_PEAK_TFLOPS if math == "fp32" else FP16_MFMA_PEAK_TFLOPS      # bf16 and f16 dense peaks are equal
+    out = {"kernel": info[0], "workload": f"[{m}, {k}] x [{n}, {k}]^T + bias", "bound": "mfma", "achieved": round(tf, 1), "peak": peak,
+           "unit": "TFLOP/s", "frac": round(tf / peak, 4), "us_per_launch": round(us, 1), "algorithmic_flop": fl, "pipe": info[1],
            "traffic": None}   # the committed PMC pass averages this kernel over all shapes of a step: not comparable per launch
-    if bf:
-        out.update({"mfma_dtype": "bf16 x3 exact split, fp32 accumulate", "issued_tflops": round(6 * tf, 1),
-                    "issued_frac": round(6 * tf / FP16_MFMA_PEAK_TFLOPS, 4), "fp32_equivalent_frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4)})
+    if math != "fp32":
+        out.update({"mfma_dtype": info[2], "issued_tflops": round(info[3] * tf, 1), "issued_frac": round(info[3] * tf / peak, 4),
+                    "fp32_equivalent_frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4)})
     return out
 
 
@@ -396,12 +398,12 @@ def main():
             eager_step()
         torch.cuda.synchronize()
     ops.TIMERS.stop()
-    # the same step at the reference's own arithmetic in the attention (fp32 MFMA kernels instead of split-fp16 operands):
-    # measured here, in the same process on the same box, so the two numbers are comparable
+    # the same step at the reference's own arithmetic (fp32 operands on the fp32 matrix instructions, in the attention and in every
+    # dense layer): measured here, in the same process on the same box, so the two numbers are comparable
     strict = None
     if world == 1 and stream is None and not args.large and not args.eager and not args.no_strict and ops.ATTN_PRECISION == "fp16x2":
         from dgdm_histopath_lab_amd.training import GraphedPretrainStep
-        prev = ops.configure(attention="fp32")
+        prev = ops.configure(attention="fp32", gemm="fp32")
         try:
             g32 = GraphedPretrainStep(model, opt, mask_ratio=0.15)
             for _ in range(g32.warmup + 1 + 2):
@@ -413,7 +415,8 @@ def main():
             torch.cuda.synchronize()
             d32 = (time.perf_counter() - t1) / n32
             strict = {"value": round(args.batch / d32, 3), "unit": "slides/s", "ms_per_step": round(d32 * 1e3, 3), "steps": n32,
-                      "attention": "fp32 operands on v_mfma_f32_16x16x4_f32 (csrc/attn_fwd.hip, attn_bwd.hip); everything else as in `value`"}
+                      "attention": "fp32 operands on v_mfma_f32_16x16x4_f32 (csrc/attn_fwd.hip, attn_bwd.hip)",
+                      "dense_layers": "fp32 operands on v_mfma_f32_32x32x2_f32 (csrc/gemm.hip)"}
         finally:
             ops.configure(**prev)
     if world > 1:
@@ -459,8 +462,10 @@ def main():
             "metric": "slides/sec (DGDM fwd+bwd, 10k-node/768-feat graphs)", "value": round(world * args.batch * args.steps / dt, 3),
             "unit": "slides/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("f32 (attention products: split-fp16 hi+lo operands, single-fp16 P / dS, fp32 accumulate; dense layers: exact 3-way bf16 "
-                      "split, fp32 accumulate)" if split else "f32 (dense layers: exact 3-way bf16 split, fp32 accumulate)"),
+            "dtype": "f32 (" + ("attention products: split-fp16 hi+lo operands, single-fp16 P / dS, fp32 accumulate; " if split else "") +
+                     {"f16x2": "dense layers: fp16 hi+lo operands with per-operand power-of-two scale, 3 MFMAs per product, fp32 accumulate",
+                      "bf16x3": "dense layers: exact 3-way bf16 split, 6 MFMAs per product, fp32 accumulate",
+                      "fp32": "dense layers: fp32 MFMA"}[ops.GEMM_MATH] + ")",
             "data": "synthetic",
             "config": {"workload": (f"MIXED-SIZE STREAM (configs[4]): DGDM-Base pretrain_step fwd+bwd+AdamW, batch={args.batch} graphs of "
                                     f"1k..10k nodes (E = 5 N) per GPU, 8 batches cycled, feat={FEATS}, edge_attr=32, T=10, heads=8, "

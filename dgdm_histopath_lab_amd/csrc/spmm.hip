@@ -11,7 +11,7 @@
 
 namespace {
 
-template <int LPR, int R, int UNROLL>
+template <int LPR, int R, int UNROLL, bool AMAX>
 __global__ __launch_bounds__(256) void k_spmm(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                               const float* __restrict__ w, const float* __restrict__ X, int64_t ldx,
                                               int32_t table_rows, float* __restrict__ Y, int64_t ldy, int32_t N, int32_t C,
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void k_spmm(const int32_t* __restrict__ rowptr
           o.x += a0.x; o.y += a0.y; o.z += a0.z; o.w += a0.w;
         }
         dst[k] = o;
-        if (amax) am = dgdm_amax4(am, o);
+        if (AMAX) am = dgdm_amax4(am, o);
       }
     }
     if (tail) {  // Y[row, C : C + 4*tail_c4) = tail[row, :]  (the [A_hat x | EA_hat] operand of a graph convolution)
@@ -88,11 +88,11 @@ __global__ __launch_bounds__(256) void k_spmm(const int32_t* __restrict__ rowptr
       for (int k = lir; k < tail_c4; k += LPR) {
         const float4 tv = t[k];
         dst[c4 + k] = tv;
-        if (amax) am = dgdm_amax4(am, tv);
+        if (AMAX) am = dgdm_amax4(am, tv);
       }
     }
   }
-  if (amax) dgdm_amax_commit(am, amax);
+  if (AMAX) dgdm_amax_commit(am, amax);
 }
 
 template <int LPR, int R, int UNROLL>
@@ -103,8 +103,12 @@ int launch(const int32_t* rowptr, const int32_t* col, const float* w, const floa
   const int64_t waves = ((int64_t)N + RPW - 1) / RPW;
   int64_t blocks = (waves + 3) / 4;
   if (blocks > 256 * 64) blocks = 256 * 64;  // grid-stride beyond that
-  hipLaunchKernelGGL((k_spmm<LPR, R, UNROLL>), dim3((unsigned)blocks), dim3(256), 0, stream, rowptr, col, w, X, ldx,
-                     table_rows, Y, ldy, N, C, bias, accumulate, tail, ldt, tail_c4, addend, lda, amax);
+  if (amax)   // the variant that also keeps max|Y| (GEMM operand scale); the plain kernel carries none of that code
+    hipLaunchKernelGGL((k_spmm<LPR, R, UNROLL, true>), dim3((unsigned)blocks), dim3(256), 0, stream, rowptr, col, w, X, ldx,
+                       table_rows, Y, ldy, N, C, bias, accumulate, tail, ldt, tail_c4, addend, lda, amax);
+  else
+    hipLaunchKernelGGL((k_spmm<LPR, R, UNROLL, false>), dim3((unsigned)blocks), dim3(256), 0, stream, rowptr, col, w, X, ldx,
+                       table_rows, Y, ldy, N, C, bias, accumulate, tail, ldt, tail_c4, addend, lda, amax);
   return dgdm_launch_status();
 }
 
