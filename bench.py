@@ -132,9 +132,9 @@ def gather_microbench(dev, iters=200, cold_iters=12):
     del evict
     cold.sort()
     cus = cold[len(cold) // 2]
-    return {"kernel": "dgdm_spmm (k_spmm<64,3,4>)", "workload": f"{NODES} nodes x {FEATS} feat, {EDGES}+{NODES} entries",
+    return {"kernel": "dgdm_spmm (k_spmm<64,3,4,false>)", "workload": f"{NODES} nodes x {FEATS} feat, {EDGES}+{NODES} entries",
             "bound": "hbm", "achieved": round(by / us / 1e3, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": round(min(by / us / 1e3 / HBM_PEAK_GBPS, 1.0), 4), "traffic": pmc_traffic("k_spmm<64, 3, 4>"), "us_per_launch": round(us, 2),
+            "frac": round(min(by / us / 1e3 / HBM_PEAK_GBPS, 1.0), 4), "traffic": pmc_traffic("k_spmm<64, 3, 4, false>"), "us_per_launch": round(us, 2),
             "algorithmic_bytes": by, "unique_bytes": ub,
             "note": "back-to-back launches: the table is re-read from L2 / Infinity Cache (cache-resident figure)",
             "unique_bytes_GBps": round(ub / us / 1e3, 1), "unique_frac": round(ub / us / 1e3 / HBM_PEAK_GBPS, 4),

@@ -20,6 +20,7 @@ PMCB="$REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-gather --no-str
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE \
    --kernel-trace --output-format csv -d /tmp/prof_$TAG/valu -- python3 $PMCB > /dev/null 2> /tmp/prof_$TAG/valu.err || { tail -5 /tmp/prof_$TAG/valu.err; exit 1; }
 python3 $REPO/tools/pmc_valu.py /tmp/prof_$TAG/valu > $OUT/${TAG}_pmc_valu.json && echo "valu pass done"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/prof_$TAG/fetch -- python3 $PMCB > /dev/null 2> /tmp/prof_$TAG/fetch.err || { tail -5 /tmp/prof_$TAG/fetch.err; exit 1; }
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/prof_$TAG/write -- python3 $PMCB > /dev/null 2> /tmp/prof_$TAG/write.err || { tail -5 /tmp/prof_$TAG/write.err; exit 1; }
+PMCT="$REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-strict"     # with the gather microbenchmark: its traffic is the calibration row
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/prof_$TAG/fetch -- python3 $PMCT > /dev/null 2> /tmp/prof_$TAG/fetch.err || { tail -5 /tmp/prof_$TAG/fetch.err; exit 1; }
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/prof_$TAG/write -- python3 $PMCT > /dev/null 2> /tmp/prof_$TAG/write.err || { tail -5 /tmp/prof_$TAG/write.err; exit 1; }
 python3 $REPO/tools/pmc_traffic.py /tmp/prof_$TAG/fetch /tmp/prof_$TAG/write > $OUT/${TAG}_pmc_traffic.json && echo "traffic passes done"
