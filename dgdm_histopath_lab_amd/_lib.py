@@ -117,6 +117,11 @@ SIGNATURES = {
                                              C.c_uint32, _p, _p, _i64, _i32, _p]),
     "dgdm_spatial_attn_h_bwd_dkv": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, C.c_float, C.c_float,
                                               C.c_uint32, _p, _p, _p, _i64, _i32, _p]),
+    "dgdm_gemm_image_bytes": (_sz, [_i32, _i32]),
+    "dgdm_gemm_image_blocks": (_i32, [_i32, _i32]),
+    "dgdm_gemm_image_build_many": (C.c_int, [_p, _i32, _i32, _p]),
+    "dgdm_gemm_image_build": (C.c_int, [_p, _i64, _p, _i64, _p, _p, _p, _i32, _i32, _i32, _i32, _p]),
+    "dgdm_gemm_rows_img": (C.c_int, [_p, _i64, _i32, _i32, _p, _i32, _i32, _i32, _p, _p, _i64, _i32, _p, _p]),
     "dgdm_spmm": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _p, _i64, _i32, _i32, _p, _i32, _p]),
     "dgdm_spmm_add": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _p, _i64, _p, _i64, _i32, _i32, _p]),
     "dgdm_spmm_concat": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _p, _i64, _i32, _p, _i64, _i32, _i32, _p, _p]),

@@ -185,9 +185,26 @@ __global__ __launch_bounds__(256, 2) void k_gemm_rows(const float* __restrict__ 
         }
       }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wr * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        if (row < M && col < N) C[(int64_t)row * ldc + col] = acc[mt][nt][r] + bv + (ACCUM ? old[r] : 0.f);
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = acc[mt][nt][r] + bv + (ACCUM ? old[r] : 0.f);
+    }
+  // the stores follow once every output is finished in place: a store whose data register is recycled for the next value makes
+  // hipcc wait vmcnt(0) in front of every store (~7 us per launch, tools/ubench/gemm_img_stamps.hip)
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int col = n0 + wc * 64 + nt * 32 + j;
+      const int rbase = m0 + wr * 64 + mt * 32 + 4 * hi;
+      if (col >= N) continue;
+      float* p = C + (int64_t)rbase * ldc + col;
+      if (m0 + wr * 64 + mt * 32 + 32 <= M) {       // wave-uniform: all 32 rows exist
+#pragma unroll
+        for (int r = 0; r < 16; ++r) p[(int64_t)((r & 3) + 8 * (r >> 2)) * ldc] = acc[mt][nt][r];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (rbase + (r & 3) + 8 * (r >> 2) < M) p[(int64_t)((r & 3) + 8 * (r >> 2)) * ldc] = acc[mt][nt][r];
       }
     }
 }

@@ -322,6 +322,8 @@ __global__ __launch_bounds__(256, 2) void k_gemmh_rows(const float* __restrict__
   float nobs[4] = {0.f, 0.f, 0.f, 0.f};
   mainloop_h<true, B_KCONTIG, false, B_SPLIT>(A, lda, m0, M, B, ldb, n0, N, 0, K, K, smem, acc, live_m, live_n, nobs, sca, scb, B2, ldb2, bsplit);
 
+  // Epilogue: every output is finished IN PLACE first, the stores follow.  A store whose data register is recycled for the next
+  // value makes hipcc wait vmcnt(0) in front of every store: 64 round trips = ~7 us per launch (tools/ubench/gemm_img_stamps.hip).
   const int j = lane & 31, hi = lane >> 5;
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
@@ -339,9 +341,24 @@ __global__ __launch_bounds__(256, 2) void k_gemmh_rows(const float* __restrict__
         }
       }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wr * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        if (row < M && col < N) C[(int64_t)row * ldc + col] = (acc[mt][nt][r] * ia) * ib + bv + (ACCUM ? old[r] : 0.f);
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = (acc[mt][nt][r] * ia) * ib + bv + (ACCUM ? old[r] : 0.f);
+    }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int col = n0 + wc * 64 + nt * 32 + j;
+      const int rbase = m0 + wr * 64 + mt * 32 + 4 * hi;
+      if (col >= N) continue;
+      float* p = C + (int64_t)rbase * ldc + col;
+      if (m0 + wr * 64 + mt * 32 + 32 <= M) {       // wave-uniform: all 32 rows exist
+#pragma unroll
+        for (int r = 0; r < 16; ++r) p[(int64_t)((r & 3) + 8 * (r >> 2)) * ldc] = acc[mt][nt][r];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (rbase + (r & 3) + 8 * (r >> 2) < M) p[(int64_t)((r & 3) + 8 * (r >> 2)) * ldc] = acc[mt][nt][r];
       }
     }
 }
@@ -377,13 +394,25 @@ __global__ __launch_bounds__(256, 2) void k_gemmh_tn_partial(const float* __rest
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = (acc[mt][nt][r] * ia) * ib;     // in place first: see k_gemmh_rows
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
       const int col = kk0 + wc * 64 + nt * 32 + j;
       if (col >= K) continue;
+      const int rbase = n0 + wr * 64 + mt * 32 + 4 * hi;
+      float* p = P + (int64_t)rbase * K + col;
+      if (n0 + wr * 64 + mt * 32 + 32 <= N) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = n0 + wr * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        if (row < N) P[(int64_t)row * K + col] = (acc[mt][nt][r] * ia) * ib;
+        for (int r = 0; r < 16; ++r) p[(int64_t)((r & 3) + 8 * (r >> 2)) * K] = acc[mt][nt][r];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (rbase + (r & 3) + 8 * (r >> 2) < N) p[(int64_t)((r & 3) + 8 * (r >> 2)) * K] = acc[mt][nt][r];
       }
     }
   if (BIAS && blockIdx.y == 0) {  // the 8 threads (tid & 7) of one column group hold the k pairs of the same 4 columns

@@ -1,0 +1,389 @@
+// K3-img: the two "row" contractions of every nn.Linear of the hot path -- forward y = x W^T + b and dx = dy W -- with the WEIGHT
+// operand pre-split once per step into an fp16 hi+lo "image" in MFMA fragment order, and the activation operand loaded straight
+// from global memory into MFMA fragment registers.
+//
+// Why (profiles/r02f_pmc_valu.json): the register-staged kernels of gemm_h.hip convert BOTH operands fp32 -> fp16 hi+lo inside
+// the main loop, once per 128 x 128 tile -- ~15 vector instructions per MFMA, the matrix pipe busy 11-15 % of the time, half of
+// all wave cycles parked at the per-16-k barrier.  Here
+//   * the weight side costs the main loop NOTHING: `dgdm_gemm_image_build` splits a weight (scaled by the power of two its amax
+//     slot gives, exactly as gemm_h.hip does) into halfs laid out so that one 1 KiB block = one wave's B fragment of one MFMA;
+//     a workgroup copies the blocks of its column range global -> LDS by LDS-DMA (no VGPRs, no VALU), 64 k per stage, double
+//     buffered, ONE barrier per 64 k;
+//   * the activation side is converted once per WAVE (32 rows x 32 k = 16 floats per lane, ~2.7 vector instructions per MFMA) and
+//     never touches LDS: lane (row, kg) loads the 16 consecutive floats k = 32c + 16kg .. +15 of its row; MFMA j of the chunk
+//     contracts floats 8j .. 8j+7.  The weight image uses the same (kg, j, i) -> k map, so the products pair up.
+// Arithmetic is gemm_h.hip's: a.b = a_lo.b_hi + a_hi.b_lo + a_hi.b_hi, three v_mfma_f32_32x32x16_f16 per term, fp32 accumulate,
+// operands scaled by 2^e with amax.2^e in [2^14, 2^15), accumulators unscaled in the epilogue.
+//
+// Image layout (bytes): [256-byte header: float scale_b] then blocks (c, t) of 4 KiB, c = 32-k chunk, t = 32-column tile, block
+// index c * T + t (T = tiles of the whole image); inside a block four 1 KiB fragments (j, p), j = MFMA of the chunk, p = 0 hi /
+// 1 lo, at (2j + p) KiB; lane l's 8 halfs at 16 l: B(col = 32t + (l & 31), k = 32c + 16 (l >> 5) + 8j + i), i = 0..7.
+// The column count is zero-padded to a multiple of 32, K to a multiple of 64 (whole LDS stages).
+#include "common.hpp"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+constexpr int IMG_HDR = 256;
+constexpr int BLK = 4096;
+
+__device__ __forceinline__ unsigned amax_group(const unsigned* __restrict__ g) {
+  const int lane = threadIdx.x & 63;
+  unsigned m = lane < DGDM_AMAX_WAYS ? g[lane * DGDM_AMAX_STRIDE] : 0u;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+  return m;
+}
+
+// 2^e with amax * 2^e in [2^14, 2^15) from the float bits of amax; 1 for a zero / denormal maximum (gemm_h.hip's rule)
+__device__ __forceinline__ float scale_of(unsigned amax_bits) {
+  const int E = (int)((amax_bits >> 23) & 0xffu) - 127;
+  int e = (amax_bits & 0x7f800000u) ? 14 - E : 0;
+  e = e < -100 ? -100 : (e > 100 ? 100 : e);
+  return __uint_as_float((unsigned)(127 + e) << 23);
+}
+
+__device__ __forceinline__ void split_pair(float a, float b, unsigned* h, unsigned* l) {
+  const f16x2 hh = __builtin_convertvector(f32x2{a, b}, f16x2);
+  const f16x2 ll = __builtin_convertvector(f32x2{a - (float)hh[0], b - (float)hh[1]}, f16x2);
+  *h = __builtin_bit_cast(unsigned, hh);
+  *l = __builtin_bit_cast(unsigned, ll);
+}
+
+struct ImgDesc {
+  const float* w0; const float* w1;     // sources (w1: second matrix of a column-concatenated weight, or null)
+  long long ld0, ld1;
+  const unsigned* amax0; const unsigned* amax1;
+  char* img;
+  int rows, cols0, cols1;               // source matrix [rows, cols0 (+ cols1)]
+  int transposed;                       // 0: B(col, k) = W[col][k] (forward); 1: B(col, k) = W[k][col] (dx = dy . W)
+  int block0;                           // first block of this image in the launch's block numbering
+};
+
+// one workgroup per image block (c, t): 32 columns x 32 k = 1024 elements, 4 per thread
+__device__ __forceinline__ void image_block(const ImgDesc& d) {
+  const int ncol = d.transposed ? d.cols0 : d.rows, nk = d.transposed ? d.rows : d.cols0 + d.cols1;
+  const int T = (ncol + 31) >> 5;
+  const int b = blockIdx.x - d.block0, c = b / T, t = b % T;
+  unsigned u = amax_group(d.amax0);
+  if (d.w1) { const unsigned u1 = amax_group(d.amax1); u = u > u1 ? u : u1; }
+  const float sc = scale_of(u);
+  if (b == 0 && threadIdx.x == 0) *reinterpret_cast<float*>(d.img) = sc;
+  const int tid = threadIdx.x, j = tid >> 7, l = (tid >> 1) & 63, h = tid & 1;
+  const int col = 32 * t + (l & 31), k0 = 32 * c + 16 * (l >> 5) + 8 * j + 4 * h;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  if (col < ncol) {
+    if (!d.transposed) {
+      if (k0 < d.cols0) {
+        const float4 x = *reinterpret_cast<const float4*>(d.w0 + (long long)col * d.ld0 + k0);
+        v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+      } else if (k0 < nk) {
+        const float4 x = *reinterpret_cast<const float4*>(d.w1 + (long long)col * d.ld1 + (k0 - d.cols0));
+        v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (k0 + i < nk) v[i] = d.w0[(long long)(k0 + i) * d.ld0 + col];
+    }
+  }
+  uint2 hi, lo;
+  split_pair(v[0] * sc, v[1] * sc, &hi.x, &lo.x);
+  split_pair(v[2] * sc, v[3] * sc, &hi.y, &lo.y);
+  char* dst = d.img + IMG_HDR + (size_t)b * BLK + (2 * j) * 1024 + 16 * l + 8 * h;
+  *reinterpret_cast<uint2*>(dst) = hi;
+  *reinterpret_cast<uint2*>(dst + 1024) = lo;
+}
+
+__global__ __launch_bounds__(256) void k_image_build_many(const ImgDesc* __restrict__ table, int count) {
+  int lo = 0, hi = count - 1;                    // last record with block0 <= blockIdx.x
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (table[mid].block0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const ImgDesc d = table[lo];
+  image_block(d);
+}
+
+__global__ __launch_bounds__(256) void k_image_build_one(const ImgDesc d) { image_block(d); }
+
+__device__ __forceinline__ f32x16 mfma_hf(f16x8 a, f16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+// In-kernel time stamps for tools/ubench/gemm_img_stamps.hip (a diagnostic build of this file; in the library no stamp executes):
+// workgroup 0, wave 0 writes (s_memtime, s_memrealtime) pairs to dgdm_stamp_buf.
+#ifdef DGDM_GEMM_IMG_STAMPS
+__device__ unsigned long long* dgdm_stamp_buf;
+#define DGDM_STAMP(i_)                                                                                    \
+  if (blockIdx.x == 0 && threadIdx.x == 0) {                                                              \
+    dgdm_stamp_buf[2 * (i_)] = __builtin_amdgcn_s_memtime();                                              \
+    dgdm_stamp_buf[2 * (i_) + 1] = __builtin_amdgcn_s_memrealtime();                                      \
+  }
+#else
+#define DGDM_STAMP(i_)
+#endif
+
+constexpr int NTW = 4;    // 32-column tiles per wave (128 columns)
+constexpr int CPS = 2;    // 32-k chunks per LDS stage (64 k); images are padded to whole stages
+
+// C[M, Ncols] (+)= A[M, K] . B + bias, B = image tiles [t_begin, t_begin + ceil(Ncols / 32)) of an image with T_img tiles per chunk.
+// Workgroup = WM x WN waves; wave (wm, wn) owns rows 32 (WM rowtile + wm) .. +31 and columns 128 (WN colgroup + wn) .. +127.
+// The main loop has no data-dependent branch: a wave always runs its four column tiles (tiles past the end of the matrix
+// multiply whatever the LDS holds and are never stored), A loads past K re-read the row's last float4 (the image is zero there).
+template <int WM, int WN, bool ACCUM>
+__global__ __launch_bounds__(64 * WM * WN, 2) void k_gemm_img(const float* __restrict__ A, int64_t lda, int M, int K,
+                                                            const char* __restrict__ img, int T_img, int t_begin, int Ncols,
+                                                            const float* __restrict__ bias, float* __restrict__ C, int64_t ldc,
+                                                            const unsigned* __restrict__ amax_a) {
+  constexpr int WAVES = WM * WN, NT_WG = NTW * WN, STAGE = CPS * NT_WG * BLK;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 * STAGE
+  const int tid = threadIdx.x, lane = tid & 63;
+  DGDM_STAMP(0)
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int gcol = (Ncols + 128 * WN - 1) / (128 * WN);          // column groups
+  const int rowtile = blockIdx.x / gcol, colgroup = blockIdx.x % gcol;   // column groups of one row tile run side by side
+  const int r0 = (rowtile * WM + wm) * 32;
+  const int tiles = (Ncols + 31) >> 5;
+  const int tg0 = colgroup * NT_WG;                               // first tile (relative to t_begin) of this workgroup
+  const int live_wg = min(NT_WG, tiles - tg0);                    // tiles this workgroup stages
+  const int nst = (K + 32 * CPS - 1) / (32 * CPS);
+  const char* blocks = img + IMG_HDR + (size_t)(t_begin + tg0) * BLK;
+  DGDM_STAMP(1)
+
+  // LDS-DMA of stage s: chunk cc -> blocks [c * T_img + t_begin + tg0, + live_wg) -> smem[buf][cc][0 .. live_wg); 1 KiB per wave instruction
+  auto stage_dma = [&](int s, int buf) {
+#pragma unroll
+    for (int cc = 0; cc < CPS; ++cc) {
+      const char* src = blocks + (size_t)(s * CPS + cc) * T_img * BLK + lane * 16;
+      char* dst = smem + buf * STAGE + cc * NT_WG * BLK;
+#pragma unroll
+      for (int p0 = 0; p0 < NT_WG * 4; p0 += WAVES) {
+        const int p = p0 + wave;
+        if (p < live_wg * 4)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + p * 1024),
+                                           (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, 0, 0);
+      }
+    }
+  };
+
+  // this lane's A row (clamped); its 16 floats of chunk c start at k = 32c + 16 (lane >> 5), clamped into the row (K % 16 == 0)
+  const int row = min(r0 + (lane & 31), M - 1);
+  const float* arow = A + (int64_t)row * lda;
+  const int klane = 16 * (lane >> 5);
+  // The A loads are inline asm: hipcc otherwise sinks them to the end of the loop body (right in front of the wait that
+  // retires them) and, next to an LDS-DMA in flight, waits vmcnt(0) at every use.  Completion is by hand: the ONE
+  // `s_waitcnt vmcnt(0)` at the top of a stage retires the DMA of that stage and both register sets (issued at least 24
+  // MFMAs = 768 matrix-pipe cycles earlier); a set is only read after that wait and only overwritten after its conversion.
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  f32x4 a00, a01, a02, a03, a10, a11, a12, a13;          // two chunks in flight
+#define DGDM_LOAD_CHUNK(c_, r0_, r1_, r2_, r3_)                                                                     \
+  {                                                                                                                 \
+    const float* p__ = arow + min(32 * (c_) + klane, K - 16);                                                       \
+    asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:16\n\t"                \
+                 "global_load_dwordx4 %2, %4, off offset:32\n\tglobal_load_dwordx4 %3, %4, off offset:48"            \
+                 : "=&v"(r0_), "=&v"(r1_), "=&v"(r2_), "=&v"(r3_) : "v"(p__) : "memory");                              \
+  }
+#define DGDM_CONVERT(cc_, r0_, r1_, r2_, r3_)                                                                       \
+  {                                                                                                                 \
+    uint4 h__, l__;                                                                                                 \
+    split_pair(r0_[0] * sca, r0_[1] * sca, &h__.x, &l__.x);                                                         \
+    split_pair(r0_[2] * sca, r0_[3] * sca, &h__.y, &l__.y);                                                         \
+    split_pair(r1_[0] * sca, r1_[1] * sca, &h__.z, &l__.z);                                                         \
+    split_pair(r1_[2] * sca, r1_[3] * sca, &h__.w, &l__.w);                                                         \
+    ah[cc_][0] = __builtin_bit_cast(f16x8, h__);                                                                    \
+    al[cc_][0] = __builtin_bit_cast(f16x8, l__);                                                                    \
+    split_pair(r2_[0] * sca, r2_[1] * sca, &h__.x, &l__.x);                                                         \
+    split_pair(r2_[2] * sca, r2_[3] * sca, &h__.y, &l__.y);                                                         \
+    split_pair(r3_[0] * sca, r3_[1] * sca, &h__.z, &l__.z);                                                         \
+    split_pair(r3_[2] * sca, r3_[3] * sca, &h__.w, &l__.w);                                                         \
+    ah[cc_][1] = __builtin_bit_cast(f16x8, h__);                                                                    \
+    al[cc_][1] = __builtin_bit_cast(f16x8, l__);                                                                    \
+  }
+
+  f32x16 acc[NTW];
+#pragma unroll
+  for (int t = 0; t < NTW; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  stage_dma(0, 0);
+  DGDM_LOAD_CHUNK(0, a00, a01, a02, a03)
+  DGDM_LOAD_CHUNK(1, a10, a11, a12, a13)
+  // the operand scales are read AFTER the first stage and the first two chunks are on their way: one memory latency, not two
+  const float sca = scale_of(amax_group(amax_a));
+  const float scb = *reinterpret_cast<const float*>(img);
+
+  for (int s = 0; s < nst; ++s) {
+    // stage s has landed (this wave's pieces: vmcnt; everybody's: the barrier), and every wave is done reading the other buffer
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a00), "+v"(a01), "+v"(a02), "+v"(a03), "+v"(a10), "+v"(a11), "+v"(a12), "+v"(a13) :: "memory");
+    __builtin_amdgcn_s_barrier();
+    DGDM_STAMP(2 + (s < 5 ? s : 5))
+    if (s + 1 < nst) stage_dma(s + 1, (s + 1) & 1);
+    const char* buf = smem + (s & 1) * STAGE + (wn * NTW) * BLK + lane * 16;
+    f16x8 ah[CPS][2], al[CPS][2];
+    // Four batches b = (cc, j) of 8 fragment reads (4 column tiles x hi / lo) + 12 MFMAs.  The reads of batch b + 1 are issued
+    // BEFORE the MFMAs of batch b and pinned there (sched_barrier): left alone, hipcc sinks every read to just in front of its
+    // MFMA and the wave eats the LDS latency 16 times per stage.
+    f16x8 bh[2][NTW], bl[2][NTW];
+#define DGDM_READ_BATCH(b_, slot_)                                                                                  \
+  {                                                                                                                 \
+    const char* q__ = buf + ((b_) >> 1) * NT_WG * BLK + (2 * ((b_) & 1)) * 1024;                                    \
+    _Pragma("unroll") for (int t = 0; t < NTW; ++t) {                                                               \
+      bh[slot_][t] = *reinterpret_cast<const f16x8*>(q__ + t * BLK);                                                \
+      bl[slot_][t] = *reinterpret_cast<const f16x8*>(q__ + t * BLK + 1024);                                         \
+    }                                                                                                               \
+  }
+#define DGDM_MFMA_BATCH(b_, slot_)                                                                                  \
+  _Pragma("unroll") for (int t = 0; t < NTW; ++t) {                                                                 \
+    acc[t] = mfma_hf(al[(b_) >> 1][(b_) & 1], bh[slot_][t], acc[t]);      /* smaller terms first */                 \
+    acc[t] = mfma_hf(ah[(b_) >> 1][(b_) & 1], bl[slot_][t], acc[t]);                                                \
+    acc[t] = mfma_hf(ah[(b_) >> 1][(b_) & 1], bh[slot_][t], acc[t]);                                                \
+  }
+    DGDM_READ_BATCH(0, 0)
+    DGDM_CONVERT(0, a00, a01, a02, a03)
+    DGDM_LOAD_CHUNK(s * CPS + CPS, a00, a01, a02, a03)       // past the end: clamped re-reads, retired after the loop
+    __builtin_amdgcn_sched_barrier(0);
+    DGDM_READ_BATCH(1, 1)
+    __builtin_amdgcn_sched_barrier(0);
+    DGDM_MFMA_BATCH(0, 0)
+    DGDM_CONVERT(1, a10, a11, a12, a13)                      // scheduled among the MFMAs of batch 0
+    DGDM_LOAD_CHUNK(s * CPS + CPS + 1, a10, a11, a12, a13)
+    __builtin_amdgcn_sched_barrier(0);
+    DGDM_READ_BATCH(2, 0)
+    __builtin_amdgcn_sched_barrier(0);
+    DGDM_MFMA_BATCH(1, 1)
+    __builtin_amdgcn_sched_barrier(0);
+    DGDM_READ_BATCH(3, 1)
+    __builtin_amdgcn_sched_barrier(0);
+    DGDM_MFMA_BATCH(2, 0)
+    __builtin_amdgcn_sched_barrier(0);
+    DGDM_MFMA_BATCH(3, 1)
+  }
+#undef DGDM_READ_BATCH
+#undef DGDM_MFMA_BATCH
+  // nothing may still be in flight into the a-registers when the epilogue reuses them (an asm load completes behind the
+  // compiler's back: a late one would land in whatever the register holds by then -- a store address, for instance)
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(a00), "+v"(a01), "+v"(a02), "+v"(a03), "+v"(a10), "+v"(a11), "+v"(a12), "+v"(a13) :: "memory");
+#undef DGDM_LOAD_CHUNK
+#undef DGDM_CONVERT
+
+  DGDM_STAMP(8)
+  // Epilogue.  All 64 outputs of the wave are finished IN PLACE first and stored afterwards: a store whose data register is
+  // recycled for the next value makes hipcc wait vmcnt(0) in front of every store (64 round trips = 7 us per launch, measured
+  // with tools/ubench/gemm_img_stamps.hip -- more than the main loop of the U-Net's GEMMs).
+  const float inv = (1.0f / sca) * (1.0f / scb);     // exact: powers of two
+  const int jc = lane & 31, hi = lane >> 5;
+  const int rbase = r0 + 4 * hi;
+#pragma unroll
+  for (int t = 0; t < NTW; ++t) {
+    const int col = 32 * (tg0 + wn * NTW + t) + jc;
+    const float bv = (bias && col < Ncols) ? bias[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = acc[t][r] * inv + bv;
+  }
+  if (ACCUM) {
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+      const int col = 32 * (tg0 + wn * NTW + t) + jc;
+      const float* p = C + (int64_t)min(rbase, M - 1) * ldc + min(col, Ncols - 1);
+      float old[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) old[r] = (rbase + (r & 3) + 8 * (r >> 2) < M) ? p[(int64_t)((r & 3) + 8 * (r >> 2)) * ldc] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] += old[r];
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int t = 0; t < NTW; ++t) {
+    const int col = 32 * (tg0 + wn * NTW + t) + jc;
+    float* p = C + (int64_t)rbase * ldc + col;
+    if (col < Ncols) {
+      if (r0 + 32 <= M) {          // wave-uniform: all 32 rows exist
+#pragma unroll
+        for (int r = 0; r < 16; ++r) p[(int64_t)((r & 3) + 8 * (r >> 2)) * ldc] = acc[t][r];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (rbase + (r & 3) + 8 * (r >> 2) < M) p[(int64_t)((r & 3) + 8 * (r >> 2)) * ldc] = acc[t][r];
+      }
+    }
+  }
+  DGDM_STAMP(9)
+}
+
+template <int WM, int WN>
+int launch_img(hipStream_t s, const float* A, int64_t lda, int M, int K, const char* img, int T_img, int t_begin, int Ncols,
+               const float* bias, float* C, int64_t ldc, int accumulate, const unsigned* amax_a) {
+  constexpr int LDS = 2 * CPS * NTW * WN * BLK;
+  static int status[2] = {1, 1};
+  auto kern = accumulate ? k_gemm_img<WM, WN, true> : k_gemm_img<WM, WN, false>;
+  int& st = status[accumulate ? 1 : 0];
+  if (st == 1)
+    st = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess
+             ? DGDM_OK : DGDM_ERR_LAUNCH;
+  if (st != DGDM_OK) return st;
+  const int gcol = (Ncols + 128 * WN - 1) / (128 * WN), grow = (M + 32 * WM - 1) / (32 * WM);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(gcol * grow)), dim3(64 * WM * WN), LDS, s, A, lda, M, K, img, T_img, t_begin, Ncols, bias, C,
+                     ldc, amax_a);
+  return dgdm_launch_status();
+}
+
+}  // namespace
+
+extern "C" size_t dgdm_gemm_image_bytes(int32_t cols, int32_t k) {
+  if (cols <= 0 || k <= 0) return 0;
+  return (size_t)IMG_HDR + (size_t)((cols + 31) / 32) * (2 * ((k + 63) / 64)) * BLK;
+}
+
+extern "C" int32_t dgdm_gemm_image_blocks(int32_t cols, int32_t k) {
+  if (cols <= 0 || k <= 0) return 0;
+  return ((cols + 31) / 32) * (2 * ((k + 63) / 64));
+}
+
+extern "C" int dgdm_gemm_image_build_many(const void* table, int32_t count, int32_t total_blocks, void* stream) {
+  if (count < 0 || total_blocks < 0 || (count > 0 && !table)) return DGDM_ERR_INVALID_ARG;
+  if (count == 0 || total_blocks == 0) return DGDM_OK;
+  hipLaunchKernelGGL(k_image_build_many, dim3((unsigned)total_blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const ImgDesc*>(table), count);
+  return dgdm_launch_status();
+}
+
+extern "C" int dgdm_gemm_image_build(const float* w0, int64_t ld0, const float* w1, int64_t ld1, const uint32_t* amax0,
+                                     const uint32_t* amax1, void* image, int32_t rows, int32_t cols0, int32_t cols1, int32_t transposed,
+                                     void* stream) {
+  if (rows < 0 || cols0 < 0 || cols1 < 0) return DGDM_ERR_INVALID_ARG;
+  if (rows == 0 || cols0 == 0) return DGDM_OK;
+  if (!w0 || !amax0 || !image || (cols1 > 0 && (!w1 || !amax1 || transposed))) return DGDM_ERR_INVALID_ARG;
+  if ((cols0 & 3) || (cols1 & 3) || (ld0 & 3) || (ld1 & 3) || ld0 < cols0 || (cols1 > 0 && ld1 < cols1) || !dgdm_aligned16(w0) ||
+      (cols1 > 0 && !dgdm_aligned16(w1)) || !dgdm_aligned16(image))
+    return DGDM_ERR_UNSUPPORTED;
+  ImgDesc d;
+  d.w0 = w0; d.w1 = cols1 > 0 ? w1 : nullptr; d.ld0 = ld0; d.ld1 = ld1; d.amax0 = amax0; d.amax1 = amax1;
+  d.img = static_cast<char*>(image); d.rows = rows; d.cols0 = cols0; d.cols1 = cols1; d.transposed = transposed; d.block0 = 0;
+  const int blocks = transposed ? dgdm_gemm_image_blocks(cols0, rows) : dgdm_gemm_image_blocks(rows, cols0 + cols1);
+  hipLaunchKernelGGL(k_image_build_one, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), d);
+  return dgdm_launch_status();
+}
+
+extern "C" int dgdm_gemm_rows_img(const float* A, int64_t lda, int32_t M, int32_t K, const void* image, int32_t image_tiles,
+                                  int32_t tile_begin, int32_t ncols, const float* bias, float* C, int64_t ldc, int32_t accumulate,
+                                  const uint32_t* amax_a, void* stream) {
+  if (M < 0 || K < 0 || ncols < 0 || image_tiles <= 0 || tile_begin < 0) return DGDM_ERR_INVALID_ARG;
+  if (M == 0 || ncols == 0) return DGDM_OK;
+  if (!A || !image || !C || !amax_a) return DGDM_ERR_INVALID_ARG;
+  if (K == 0) return DGDM_ERR_UNSUPPORTED;
+  if ((K & 15) || (lda & 3) || !dgdm_aligned16(A) || !dgdm_aligned16(image)) return DGDM_ERR_UNSUPPORTED;
+  if (lda < K || ldc < ncols || tile_begin + (ncols + 31) / 32 > image_tiles) return DGDM_ERR_INVALID_ARG;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const char* img = static_cast<const char*>(image);
+  if (ncols <= 128)
+    return launch_img<4, 1>(s, A, lda, M, K, img, image_tiles, tile_begin, ncols, bias, C, ldc, accumulate, amax_a);
+  return launch_img<4, 2>(s, A, lda, M, K, img, image_tiles, tile_begin, ncols, bias, C, ldc, accumulate, amax_a);
+}

@@ -895,7 +895,175 @@ def refresh_weight_amax(module: torch.nn.Module) -> None:
     wa = module.__dict__.get("_dgdm_weight_amax")
     if wa is None or wa.stale():
         wa = module.__dict__["_dgdm_weight_amax"] = WeightAmax(module)
+        WEIGHT_IMAGES.dirty = True          # the parameters' amax slots moved: the image table points at the old ones
     wa.refresh()
+    if USE_WEIGHT_IMAGES and wa.device is not None:
+        WEIGHT_IMAGES.refresh(wa.device)
+
+
+# ----------------------------------------------------------------------------- weight images (csrc/gemm_img.hip)
+class _WImage:
+    __slots__ = ("kind", "srcs", "img", "tiles", "cols", "k", "versions", "epoch", "used", "blocks")
+
+
+class WeightImages:
+    """Pre-split fp16 hi+lo images of the WEIGHT operands of y = x W^T (kind 0) and dx = dy W (kind 1).
+
+    Weights only change in the optimizer step, so an image built at the start of a forward holds for the whole forward +
+    backward.  Images whose sources are parameters (or views of parameters) are registered here and ALL rebuilt by ONE launch
+    per step (``refresh``, called from ``refresh_weight_amax`` right after the weight maxima); an image of a temporary (the
+    concatenated QKV weight) lives on the tensor object and costs one small launch.  A registered image is valid while the
+    registry epoch and the sources' version counters are those of its last build; anything else rebuilds it on the spot, so a
+    weight written in place between two calls is never served from a stale image."""
+
+    MAX_IDLE_EPOCHS = 4      # registered images not looked up for this many refreshes are dropped (models that went away)
+
+    def __init__(self):
+        self.entries: dict = {}
+        self.epoch = 0
+        self.table = None          # device table of the registered images (rebuilt when the set changes)
+        self.table_n = 0
+        self.table_blocks = 0
+        self.dirty = True
+
+    @staticmethod
+    def _key(kind, w0, w1):
+        k = (kind, w0.data_ptr(), tuple(w0.shape), w0.stride(0))
+        return k if w1 is None else k + (w1.data_ptr(), tuple(w1.shape), w1.stride(0))
+
+    @staticmethod
+    def _persistent(w) -> bool:
+        b = w._base if w._base is not None else w
+        return isinstance(b, torch.nn.Parameter)
+
+    @staticmethod
+    def _dims(kind, w0, w1):
+        rows, c0 = w0.shape
+        c1 = 0 if w1 is None else w1.size(1)
+        return (rows, c0 + c1) if kind == 0 else (c0, rows)        # (image columns, reduction length)
+
+    def _new(self, kind, w0, w1) -> _WImage:
+        e = _WImage()
+        e.kind, e.srcs = kind, (w0, w1)
+        e.cols, e.k = self._dims(kind, w0, w1)
+        lib = _lib.load()
+        e.img = torch.empty(lib.dgdm_gemm_image_bytes(e.cols, e.k), dtype=torch.uint8, device=w0.device)
+        e.blocks = lib.dgdm_gemm_image_blocks(e.cols, e.k)
+        e.tiles = (e.cols + 31) // 32
+        e.versions, e.epoch, e.used = None, -1, self.epoch
+        return e
+
+    @staticmethod
+    def _param_amax(w) -> Optional[int]:
+        """The persistent amax slot of the parameter ``w`` is (a view of): refreshed by WeightAmax at every forward.  A slice
+        inherits the whole matrix's maximum (an upper bound is all the scale needs)."""
+        if w is None:
+            return None
+        b = w._base if w._base is not None else w
+        tag = getattr(b, "_dgdm_amax", None)
+        return tag if isinstance(tag, int) else None
+
+    def _build_one(self, e: _WImage) -> None:
+        w0, w1 = e.srcs
+        a0 = self._param_amax(w0) or ensure_amax(w0)
+        a1 = (self._param_amax(w1) or ensure_amax(w1)) if w1 is not None else None
+        _lib.check(_lib.load().dgdm_gemm_image_build(
+            w0.data_ptr(), w0.stride(0), _lib.ptr(w1), w1.stride(0) if w1 is not None else 0, a0, a1, e.img.data_ptr(), w0.size(0),
+            w0.size(1), 0 if w1 is None else w1.size(1), e.kind, _lib.stream_ptr(w0.device)), "dgdm_gemm_image_build")
+        e.versions = (w0._version, None if w1 is None else w1._version)
+        e.epoch = self.epoch
+
+    def get(self, kind: int, w0: torch.Tensor, w1: Optional[torch.Tensor] = None) -> _WImage:
+        """Image of B for ``x . [w0 | w1]^T`` (kind 0) or ``dy . w0`` (kind 1); w0 / w1: 2-D fp32, unit column stride."""
+        if not (self._persistent(w0) and (w1 is None or self._persistent(w1))):
+            holder = w0.__dict__.setdefault("_dgdm_images", {}) if hasattr(w0, "__dict__") else {}
+            key = (kind, None if w1 is None else id(w1))
+            e = holder.get(key)
+            if e is None or e.versions != (w0._version, None if w1 is None else w1._version) or e.epoch != self.epoch:
+                e = holder[key] = self._new(kind, w0, w1)
+                self._build_one(e)
+            for sink in _CONSTANT_SINKS:
+                sink.append(e.img)
+            return e
+        key = self._key(kind, w0, w1)
+        e = self.entries.get(key)
+        if e is None:
+            e = self.entries[key] = self._new(kind, w0, w1)
+            self.dirty = True
+        e.used = self.epoch
+        if e.epoch != self.epoch or e.versions != (w0._version, None if w1 is None else w1._version):
+            e.srcs = (w0, w1)
+            self._build_one(e)
+        for sink in _CONSTANT_SINKS:      # a step being recorded bakes the image's address into its launches: it keeps the image alive
+            sink.append(e.img)
+        return e
+
+    def _upload_table(self, device) -> None:
+        import struct
+        recs, block0 = [], 0
+        live = {}
+        for key, e in self.entries.items():
+            if self.epoch - e.used > self.MAX_IDLE_EPOCHS:
+                continue
+            live[key] = e
+        self.entries = live
+        self.table_entries = []
+        for e in self.entries.values():
+            w0, w1 = e.srcs
+            a0, a1 = self._param_amax(w0), self._param_amax(w1)
+            if w0.device != device or a0 is None or (w1 is not None and a1 is None):
+                continue           # no persistent maximum (a bare parameter outside a model): rebuilt on first use instead
+            recs.append(struct.pack("<QQqqQQQiiiii4x", w0.data_ptr(), _lib.ptr(w1) or 0, w0.stride(0), w1.stride(0) if w1 is not None else 0,
+                                    a0, a1 or 0, e.img.data_ptr(), w0.size(0), w0.size(1), 0 if w1 is None else w1.size(1), e.kind, block0))
+            block0 += e.blocks
+            self.table_entries.append(e)
+        self.table_n, self.table_blocks = len(recs), block0
+        self.table = torch.frombuffer(bytearray(b"".join(recs)), dtype=torch.uint8).to(device) if recs else None
+        self.dirty = False
+
+    def refresh(self, device) -> None:
+        """New epoch: every registered image is rebuilt from the current weights by one launch (the weights' maxima must have
+        been refreshed on the same stream just before)."""
+        self.epoch += 1
+        capturing = torch.cuda.is_current_stream_capturing()
+        stale = self.dirty or any(self.epoch - e.used > self.MAX_IDLE_EPOCHS for e in self.entries.values())
+        if stale and not capturing:
+            self._upload_table(device)
+        if self.table is None:
+            return                      # first step: images are built one by one on first use
+        _lib.check(_lib.load().dgdm_gemm_image_build_many(self.table.data_ptr(), self.table_n, self.table_blocks, _lib.stream_ptr(device)),
+                   "dgdm_gemm_image_build_many")
+        for sink in _CONSTANT_SINKS:      # a recorded step replays this launch: the table and every image it writes stay allocated
+            sink.append(self.table)
+            sink.extend(e.img for e in self.table_entries)
+        for e in self.table_entries:
+            w0, w1 = e.srcs
+            e.versions = (w0._version, None if w1 is None else w1._version)
+            e.epoch = self.epoch
+
+
+WEIGHT_IMAGES = WeightImages()
+USE_WEIGHT_IMAGES = True      # tools/ A/B switch: False sends the f16x2 row contractions to the register-staged kernels (gemm_h.hip)
+
+
+def weights_changed() -> None:
+    """Tell the image cache that weights were written behind autograd's back (a HIP-graph replay of an optimizer step bumps no
+    version counter): images built before are not used again."""
+    WEIGHT_IMAGES.epoch += 1
+
+
+def _img_ok(a: torch.Tensor, K: int) -> bool:
+    return USE_WEIGHT_IMAGES and K % 16 == 0 and K >= 16 and a.size(0) > 0
+
+
+def _gemm_rows_img(a, e: _WImage, tile_begin: int, ncols: int, bias, out, accumulate: bool):
+    M, K = a.shape
+    if out is None:
+        out = torch.empty(M, ncols, dtype=torch.float32, device=a.device)
+    TIMERS.timed("gemm_img", lambda: _lib.check(_lib.load().dgdm_gemm_rows_img(
+        a.data_ptr(), a.stride(0), M, K, e.img.data_ptr(), e.tiles, tile_begin, ncols, _lib.ptr(bias), out.data_ptr(), out.stride(0),
+        int(accumulate), ensure_amax(a), _lib.stream_ptr(a.device)), "dgdm_gemm_rows_img"))
+    return out
 
 
 # ----------------------------------------------------------------------------- K3 dense contractions
@@ -928,6 +1096,8 @@ def gemm_nt_raw(a, w, bias=None, out=None, accumulate=False, math="fp32"):
     a, w = _rm_tagged(a), _rm_tagged(w)
     M, K = a.shape
     N = w.size(0)
+    if math == "f16x2" and _img_ok(a, K):
+        return _gemm_rows_img(a, WEIGHT_IMAGES.get(0, w), 0, N, bias, out, accumulate)
     if out is None:
         out = torch.empty(M, N, dtype=torch.float32, device=a.device)
     fn = _gemm_entry(lib, "dgdm_gemm_nt", math)
@@ -950,6 +1120,8 @@ def gemm_nt_split_raw(a, w0, w1, bias=None, math="bf16x3"):
     N, K0 = w0.shape
     if w1.size(0) != N or K0 + w1.size(1) != K:
         raise ValueError(f"weights {tuple(w0.shape)} | {tuple(w1.shape)} do not match the operand {tuple(a.shape)}")
+    if math == "f16x2" and _img_ok(a, K):
+        return _gemm_rows_img(a, WEIGHT_IMAGES.get(0, w0, w1), 0, N, bias, None, False)
     out = torch.empty(M, N, dtype=torch.float32, device=a.device)
     fn = lib.dgdm_gemm_nt_split_f16x2 if math == "f16x2" else lib.dgdm_gemm_nt_split_bf16x3
     extra = (ensure_amax(a), ensure_amax(w0), ensure_amax(w1)) if math == "f16x2" else ()
@@ -965,6 +1137,8 @@ def gemm_nn_raw(a, w, out=None, accumulate=False, math="fp32"):
     a, w = _rm_tagged(a), _rm_tagged(w)
     M, N = a.shape
     K = w.size(1)
+    if math == "f16x2" and _img_ok(a, N):
+        return _gemm_rows_img(a, WEIGHT_IMAGES.get(1, w), 0, K, None, out, accumulate)
     if out is None:
         out = torch.empty(M, K, dtype=torch.float32, device=a.device)
     fn = _gemm_entry(lib, "dgdm_gemm_nn", math)

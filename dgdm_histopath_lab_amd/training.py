@@ -533,6 +533,8 @@ class GraphedPretrainStep:
         if self.reducer is not None:
             self.reducer.reduce_packed()    # the one eager piece: two bucket all-reduces of the buffer graph 0 just packed
             self._graphs[1].replay()
+        from . import ops
+        ops.weights_changed()         # the replayed optimizer step wrote the weights without bumping their version counters
         return self._loss.clone()     # the recorded loss tensor is overwritten by the next replay
 
 

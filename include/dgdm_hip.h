@@ -446,6 +446,34 @@ DGDM_API int dgdm_gemm_tn_split_f16x2(const float* dY, int64_t ldy, const float*
                                       void* workspace, size_t workspace_bytes, const uint32_t* amax_dy, const uint32_t* amax_x,
                                       void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * K3-img  weight images (csrc/gemm_img.hip).  The two contractions whose second operand is a WEIGHT -- y = x W^T + b
+ * (core/graph_layers.py:45-49,141-150, models/encoders.py:73-91, core/attention.py:60-63, core/diffusion.py:87-104 of the
+ * reference: every nn.Linear forward) and dx = dy W (its input gradient) -- take the weight pre-split: an "image" holds the
+ * fp16 hi+lo halves of B(col, k), scaled by the power of two of the weight's amax slot, in MFMA fragment order, so the GEMM
+ * copies it global -> LDS without touching a register and converts only the activation operand (once per wave).
+ *   image of B [cols, k]: dgdm_gemm_image_bytes(cols, k) bytes, 16-byte aligned; dgdm_gemm_image_blocks(cols, k) build blocks.
+ *   dgdm_gemm_image_build_many: ONE launch builds `count` images.  table = DEVICE array of records
+ *       { const float* w0; const float* w1; int64 ld0, ld1; const uint32* amax0; const uint32* amax1; void* image;
+ *         int32 rows, cols0, cols1, transposed, block0; }           (80 bytes, 8-byte aligned)
+ *     transposed = 0: B(col, k) = [W0 | W1][col][k], W0 [rows, cols0], W1 [rows, cols1] or NULL (forward; a weight given as two
+ *                     matrices side by side in k);   transposed = 1: B(col, k) = W0[k][col] (dx = dy . W0; W1 unused).
+ *     block0 = running sum of dgdm_gemm_image_blocks over the preceding records; total_blocks = the sum over all records.
+ *     cols0, cols1, ld0, ld1 multiples of 4, pointers 16-byte aligned.
+ *   dgdm_gemm_rows_img: C[M, ncols] (+)= A[M, K] . B[tile_begin*32 .. +ncols, 0..K)^T + bias[ncols]; `image_tiles` = number
+ *     of 32-column tiles of the WHOLE image (its column count / 32 rounded up): a column range of an image is an operand too
+ *     (the slice of a weight).  K % 16 == 0, lda % 4 == 0; amax_a as for dgdm_gemm_nt_f16x2.  Arithmetic: that of K3''. */
+DGDM_API size_t dgdm_gemm_image_bytes(int32_t cols, int32_t k);
+DGDM_API int32_t dgdm_gemm_image_blocks(int32_t cols, int32_t k);
+DGDM_API int dgdm_gemm_image_build_many(const void* table, int32_t count, int32_t total_blocks, void* stream);
+/* one image, the record passed by value (no device table: usable inside a stream capture) */
+DGDM_API int dgdm_gemm_image_build(const float* w0, int64_t ld0, const float* w1, int64_t ld1, const uint32_t* amax0,
+                                   const uint32_t* amax1, void* image, int32_t rows, int32_t cols0, int32_t cols1, int32_t transposed,
+                                   void* stream);
+DGDM_API int dgdm_gemm_rows_img(const float* A, int64_t lda, int32_t M, int32_t K, const void* image, int32_t image_tiles,
+                                int32_t tile_begin, int32_t ncols, const float* bias, float* C, int64_t ldc, int32_t accumulate,
+                                const uint32_t* amax_a, void* stream);
+
 /* Deferred reduction of the split-M weight-gradient GEMMs.  dgdm_gemm_tn_partial_* run only the first half of dgdm_gemm_tn_*
  * (chunk partials into `workspace`, [dgdm_gemm_tn_chunks(M,N,K)][N*K (+N when with_bias)] floats); dgdm_gemm_tn_reduce_many then
  * reduces up to DGDM_TN_REDUCE_MAX such workspaces in ONE launch, with the arithmetic (fixed order) of the immediate reduction.
