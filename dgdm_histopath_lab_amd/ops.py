@@ -874,7 +874,7 @@ class WeightAmax:
         self.table = torch.frombuffer(bytearray(b"".join(recs)), dtype=torch.uint8).to(dev)
         self.slots = torch.zeros(len(self.params) * AmaxArena.GROUP_WORDS, dtype=torch.int32, device=dev)
         for i, p in enumerate(self.params):
-            p._dgdm_amax = self.slots.data_ptr() + 4 * i * AmaxArena.GROUP_WORDS
+            p._dgdm_amax = p._dgdm_wamax = self.slots.data_ptr() + 4 * i * AmaxArena.GROUP_WORDS    # _dgdm_wamax: never re-tagged
 
     def stale(self) -> bool:
         return any(p.data_ptr() != q for p, q in zip(self.params, self.ptrs))
@@ -960,8 +960,7 @@ class WeightImages:
         if w is None:
             return None
         b = w._base if w._base is not None else w
-        tag = getattr(b, "_dgdm_amax", None)
-        return tag if isinstance(tag, int) else None
+        return getattr(b, "_dgdm_wamax", None)
 
     def _build_one(self, e: _WImage) -> None:
         w0, w1 = e.srcs
@@ -1020,6 +1019,13 @@ class WeightImages:
         self.table_n, self.table_blocks = len(recs), block0
         self.table = torch.frombuffer(bytearray(b"".join(recs)), dtype=torch.uint8).to(device) if recs else None
         self.dirty = False
+
+    def prepare(self, device) -> None:
+        """Bring the device table up to date with the registered images (a host-to-device copy: call it OUTSIDE a stream
+        capture -- training.GraphedPretrainStep does, right before it records, so that the recorded step rebuilds every image
+        with the one table launch instead of one launch per weight)."""
+        if self.dirty and not torch.cuda.is_current_stream_capturing():
+            self._upload_table(device)
 
     def refresh(self, device) -> None:
         """New epoch: every registered image is rebuilt from the current weights by one launch (the weights' maxima must have

@@ -472,6 +472,7 @@ class GraphedPretrainStep:
         mode = dict(capture_error_mode="thread_local")
         g1 = torch.cuda.CUDAGraph()
         from . import ops
+        ops.WEIGHT_IMAGES.prepare(self.dev)      # the table of weight images the warm-up steps registered (a copy a capture cannot record)
         # the recording bakes the ADDRESSES of the batch-layout constants (graph offsets, per-graph sizes) into its kernel
         # arguments: hold them here, whatever the value cache of ops.device_constant evicts later
         if self.reducer is not None:
