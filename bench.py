@@ -162,7 +162,9 @@ def projection_microbench(dev, iters=50):
     us = a.elapsed_time(e) * 1e3 / iters
     fl = 2.0 * m * k * n
     tf = fl / us / 1e6
-    info = {"f16x2": ("dgdm_gemm_nt_f16x2 (k_gemmh_rows<true,false,false>)", "f16 dense matrix pipe (v_mfma_f32_32x32x16_f16)",
+    info = {"f16x2": ("dgdm_gemm_rows_img (k_gemm_img8<false>: weight pre-split into an fp16 hi+lo image, activation rows straight into MFMA fragments)"
+                      if ops.USE_WEIGHT_IMAGES else "dgdm_gemm_nt_f16x2 (k_gemmh_rows<true,false,false>)",
+                      "f16 dense matrix pipe (v_mfma_f32_32x32x16_f16)",
                       "fp16 hi+lo operands (power-of-two scaled by the operand maximum), 3 MFMAs per product, fp32 accumulate", 3),
             "bf16x3": ("dgdm_gemm_nt_bf16x3 (k_gemm3_rows<true,false,false>)", "bf16 dense matrix pipe (v_mfma_f32_32x32x16_bf16)",
                        "bf16 x3 exact split, 6 MFMAs per product, fp32 accumulate", 6),

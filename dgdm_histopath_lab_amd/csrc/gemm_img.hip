@@ -318,6 +318,181 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_gemm_img(const float* __res
   DGDM_STAMP(9)
 }
 
+// ---- the wide variant: a wave owns 32 rows x 256 columns (8 accumulator tiles), a workgroup of four waves 128 x 256, ONE 32-k
+// chunk per LDS stage (32 KiB, two slots) so that TWO workgroups share a CU.  Why two independent workgroups instead of one of
+// eight waves: the two waves of a SIMD that belong to one workgroup run in lockstep behind the stage barrier -- both stage and
+// convert, then both want the matrix pipe (stamps: 5,900 cycles per 64 k against 3,072 of MFMA) -- while waves of different
+// workgroups drift apart and one's staging / conversion / LDS latency hides under the other's MFMAs.  Against the 4 x 2-wave form
+// the conversion work per MFMA halves as well (16 floats per lane feed 48 MFMAs instead of 24).
+constexpr int NT8 = 8;
+template <bool ACCUM>
+__global__ __launch_bounds__(256, 2) void k_gemm_img8(const float* __restrict__ A, int64_t lda, int M, int K, const char* __restrict__ img,
+                                                      int T_img, int t_begin, int Ncols, const float* __restrict__ bias,
+                                                      float* __restrict__ C, int64_t ldc, const unsigned* __restrict__ amax_a) {
+  constexpr int SLOT = NT8 * BLK;                                  // 32 KiB: one chunk of 8 column tiles
+  extern __shared__ __attribute__((aligned(16))) char smem[];      // 2 * SLOT
+  const int tid = threadIdx.x, lane = tid & 63;
+  DGDM_STAMP(0)
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int gcol = (Ncols + 255) / 256;
+  const int rowtile = blockIdx.x / gcol, colgroup = blockIdx.x % gcol;
+  const int r0 = (rowtile * 4 + wave) * 32;
+  const int tiles = (Ncols + 31) >> 5;
+  const int tg0 = colgroup * NT8;
+  const int live_wg = min(NT8, tiles - tg0);
+  const int nchunks = 2 * ((K + 63) / 64);                         // images are padded to whole 64-k stages: always even
+  const char* blocks = img + IMG_HDR + (size_t)(t_begin + tg0) * BLK + lane * 16;
+
+  auto chunk_dma = [&](int c, int slot) {
+    const char* src = blocks + (size_t)c * T_img * BLK;
+    char* dst = smem + slot * SLOT;
+#pragma unroll
+    for (int p0 = 0; p0 < NT8 * 4; p0 += 4) {
+      const int p = p0 + wave;
+      if (p < live_wg * 4)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + p * 1024),
+                                         (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, 0, 0);
+    }
+  };
+
+  const int row = min(r0 + (lane & 31), M - 1);
+  const float* arow = A + (int64_t)row * lda;
+  const int klane = 16 * (lane >> 5);
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  f32x4 a00, a01, a02, a03, a10, a11, a12, a13;
+#define DGDM_LOAD_CHUNK(c_, r0_, r1_, r2_, r3_)                                                                     \
+  {                                                                                                                 \
+    const float* p__ = arow + min(32 * (c_) + klane, K - 16);                                                       \
+    asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:16\n\t"                \
+                 "global_load_dwordx4 %2, %4, off offset:32\n\tglobal_load_dwordx4 %3, %4, off offset:48"            \
+                 : "=&v"(r0_), "=&v"(r1_), "=&v"(r2_), "=&v"(r3_) : "v"(p__) : "memory");                              \
+  }
+  f32x16 acc[NT8];
+#pragma unroll
+  for (int t = 0; t < NT8; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  chunk_dma(0, 0);
+  DGDM_LOAD_CHUNK(0, a00, a01, a02, a03)
+  DGDM_LOAD_CHUNK(1, a10, a11, a12, a13)
+  const float sca = scale_of(amax_group(amax_a));
+  const float scb = *reinterpret_cast<const float*>(img);
+
+  // one chunk: wait for its B slot (and the A set), restage the other slot, convert the A set and refill it two chunks ahead,
+  // then 8 batches (j, tile pair) of four fragment reads + six MFMAs, the reads one batch ahead
+#define DGDM_CHUNK(c_, r0_, r1_, r2_, r3_)                                                                          \
+  {                                                                                                                 \
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a00), "+v"(a01), "+v"(a02), "+v"(a03), "+v"(a10), "+v"(a11), "+v"(a12), "+v"(a13) :: "memory"); \
+    __builtin_amdgcn_s_barrier();                                                                                   \
+    DGDM_STAMP(2 + ((c_) < 5 ? (c_) : 5))                                                                           \
+    if ((c_) + 1 < nchunks) chunk_dma((c_) + 1, ((c_) + 1) & 1);                                                    \
+    const char* buf = smem + ((c_) & 1) * SLOT + lane * 16;                                                         \
+    f16x8 ah[2], al[2];                                                                                             \
+    {                                                                                                               \
+      uint4 h__, l__;                                                                                               \
+      split_pair(r0_[0] * sca, r0_[1] * sca, &h__.x, &l__.x);                                                       \
+      split_pair(r0_[2] * sca, r0_[3] * sca, &h__.y, &l__.y);                                                       \
+      split_pair(r1_[0] * sca, r1_[1] * sca, &h__.z, &l__.z);                                                       \
+      split_pair(r1_[2] * sca, r1_[3] * sca, &h__.w, &l__.w);                                                       \
+      ah[0] = __builtin_bit_cast(f16x8, h__);                                                                       \
+      al[0] = __builtin_bit_cast(f16x8, l__);                                                                       \
+      split_pair(r2_[0] * sca, r2_[1] * sca, &h__.x, &l__.x);                                                       \
+      split_pair(r2_[2] * sca, r2_[3] * sca, &h__.y, &l__.y);                                                       \
+      split_pair(r3_[0] * sca, r3_[1] * sca, &h__.z, &l__.z);                                                       \
+      split_pair(r3_[2] * sca, r3_[3] * sca, &h__.w, &l__.w);                                                       \
+      ah[1] = __builtin_bit_cast(f16x8, h__);                                                                       \
+      al[1] = __builtin_bit_cast(f16x8, l__);                                                                       \
+    }                                                                                                               \
+    DGDM_LOAD_CHUNK((c_) + 2, r0_, r1_, r2_, r3_)      /* past the end: clamped re-reads, retired after the loop */  \
+    f16x8 bh[2][2], bl[2][2];                                                                                       \
+    _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                                 \
+      bh[0][u] = *reinterpret_cast<const f16x8*>(buf + u * BLK);                                                    \
+      bl[0][u] = *reinterpret_cast<const f16x8*>(buf + u * BLK + 1024);                                             \
+    }                                                                                                               \
+    _Pragma("unroll") for (int b = 0; b < 8; ++b) {          /* b = 4 j + tile pair */                               \
+      __builtin_amdgcn_sched_barrier(0);                                                                            \
+      if (b + 1 < 8) {                                                                                              \
+        const char* q__ = buf + (2 * ((b + 1) & 3)) * BLK + (2 * ((b + 1) >> 2)) * 1024;                            \
+        _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                             \
+          bh[(b + 1) & 1][u] = *reinterpret_cast<const f16x8*>(q__ + u * BLK);                                      \
+          bl[(b + 1) & 1][u] = *reinterpret_cast<const f16x8*>(q__ + u * BLK + 1024);                               \
+        }                                                                                                           \
+      }                                                                                                             \
+      __builtin_amdgcn_sched_barrier(0);                                                                            \
+      _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                               \
+        const int t = 2 * (b & 3) + u;                                                                              \
+        acc[t] = mfma_hf(al[b >> 2], bh[b & 1][u], acc[t]);      /* smaller terms first */                          \
+        acc[t] = mfma_hf(ah[b >> 2], bl[b & 1][u], acc[t]);                                                         \
+        acc[t] = mfma_hf(ah[b >> 2], bh[b & 1][u], acc[t]);                                                         \
+      }                                                                                                             \
+    }                                                                                                               \
+  }
+  for (int c = 0; c < nchunks; c += 2) {
+    DGDM_CHUNK(c, a00, a01, a02, a03)
+    DGDM_CHUNK(c + 1, a10, a11, a12, a13)
+  }
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(a00), "+v"(a01), "+v"(a02), "+v"(a03), "+v"(a10), "+v"(a11), "+v"(a12), "+v"(a13) :: "memory");
+#undef DGDM_CHUNK
+#undef DGDM_LOAD_CHUNK
+  DGDM_STAMP(8)
+
+  const float inv = (1.0f / sca) * (1.0f / scb);
+  const int jc = lane & 31, hi = lane >> 5;
+  const int rbase = r0 + 4 * hi;
+#pragma unroll
+  for (int t = 0; t < NT8; ++t) {
+    const int col = 32 * (tg0 + t) + jc;
+    const float bv = (bias && col < Ncols) ? bias[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = acc[t][r] * inv + bv;
+  }
+  if (ACCUM) {
+#pragma unroll
+    for (int t = 0; t < NT8; ++t) {
+      const int col = 32 * (tg0 + t) + jc;
+      const float* p = C + (int64_t)min(rbase, M - 1) * ldc + min(col, Ncols - 1);
+      float old[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) old[r] = (rbase + (r & 3) + 8 * (r >> 2) < M) ? p[(int64_t)((r & 3) + 8 * (r >> 2)) * ldc] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] += old[r];
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int t = 0; t < NT8; ++t) {
+    const int col = 32 * (tg0 + t) + jc;
+    float* p = C + (int64_t)rbase * ldc + col;
+    if (col < Ncols) {
+      if (r0 + 32 <= M) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) p[(int64_t)((r & 3) + 8 * (r >> 2)) * ldc] = acc[t][r];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (rbase + (r & 3) + 8 * (r >> 2) < M) p[(int64_t)((r & 3) + 8 * (r >> 2)) * ldc] = acc[t][r];
+      }
+    }
+  }
+  DGDM_STAMP(9)
+}
+
+int launch_img8(hipStream_t s, const float* A, int64_t lda, int M, int K, const char* img, int T_img, int t_begin, int Ncols,
+                const float* bias, float* C, int64_t ldc, int accumulate, const unsigned* amax_a) {
+  constexpr int LDS = 2 * NT8 * BLK;
+  static int status[2] = {1, 1};
+  auto kern = accumulate ? k_gemm_img8<true> : k_gemm_img8<false>;
+  int& st = status[accumulate ? 1 : 0];
+  if (st == 1)
+    st = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess
+             ? DGDM_OK : DGDM_ERR_LAUNCH;
+  if (st != DGDM_OK) return st;
+  const int gcol = (Ncols + 255) / 256, grow = (M + 127) / 128;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(gcol * grow)), dim3(256), LDS, s, A, lda, M, K, img, T_img, t_begin, Ncols, bias, C, ldc, amax_a);
+  return dgdm_launch_status();
+}
+
 template <int WM, int WN>
 int launch_img(hipStream_t s, const float* A, int64_t lda, int M, int K, const char* img, int T_img, int t_begin, int Ncols,
                const float* bias, float* C, int64_t ldc, int accumulate, const unsigned* amax_a) {
@@ -385,5 +560,5 @@ extern "C" int dgdm_gemm_rows_img(const float* A, int64_t lda, int32_t M, int32_
   const char* img = static_cast<const char*>(image);
   if (ncols <= 128)
     return launch_img<4, 1>(s, A, lda, M, K, img, image_tiles, tile_begin, ncols, bias, C, ldc, accumulate, amax_a);
-  return launch_img<4, 2>(s, A, lda, M, K, img, image_tiles, tile_begin, ncols, bias, C, ldc, accumulate, amax_a);
+  return launch_img8(s, A, lda, M, K, img, image_tiles, tile_begin, ncols, bias, C, ldc, accumulate, amax_a);
 }

@@ -30,3 +30,24 @@ for it in range(4):
     if it >= 2:
         for k, v in list(why.items())[:12]:
             print("   ", v, k)
+
+# ---- shapes of the weight-image GEMMs and the dW GEMMs of one step (M, K, ncols) x count
+shapes = collections.Counter()
+orig_img = ops._gemm_rows_img
+def spy_img(a, e, tile_begin, ncols, bias, out, accumulate):
+    shapes[("img", a.size(0), a.size(1), ncols, bool(accumulate))] += 1
+    return orig_img(a, e, tile_begin, ncols, bias, out, accumulate)
+ops._gemm_rows_img = spy_img
+orig_tn = ops.gemm_tn_raw
+def spy_tn(dy, x, with_bias, **kw):
+    shapes[("tn", dy.size(0), dy.size(1), x.size(1), with_bias)] += 1
+    return orig_tn(dy, x, with_bias, **kw)
+ops.gemm_tn_raw = spy_tn
+batch = synthetic_batch(0, 4, 10000, 50000, 768).to(dev)
+opt.zero_grad(set_to_none=True)
+out = model.pretrain_step(batch, mask_ratio=0.15)
+with ops.deferred_weight_grads():
+    out["total_pretrain_loss"].backward()
+torch.cuda.synchronize()
+for k, v in sorted(shapes.items()):
+    print(v, k)
