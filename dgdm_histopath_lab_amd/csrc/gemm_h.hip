@@ -365,17 +365,115 @@ __global__ __launch_bounds__(256, 2) void k_gemmh_rows(const float* __restrict__
 
 // dW partial: tile (n0, kk0) of [N x K], rows [mc*chunk, (mc+1)*chunk); partial row of chunk mc =
 // [N*K dW elements | N bias sums (if with_bias)], as k_gemm_tn_partial of gemm.hip.
+// ---- dW partial, 32 m rows per stage, transposed LDS reads.
+// Both operands of dW = dY^T X have the REDUCTION index (the node m) as their slow index, so an MFMA fragment (8 consecutive m of
+// one column per lane) is a transpose of what a coalesced load delivers.  The bf16x3 kernel transposes on the way INTO LDS
+// (gemm3.hip's ColStage: 16-m stages, ds_write_b32 per column pair, 8 vector instructions per MFMA); here the stage is stored as it arrives --
+// row-major [m][column] halves, one ds_write_b64 per float4 -- and gfx950's ds_read_b64_tr_b16 delivers the column-major
+// fragments (per 16 lanes a block of 4 m x 16 columns; lane 4q + p supplies the address of row q, columns 4p..4p+3, lane i
+// receives column i of the 4 rows).  Twice the reduction depth per barrier, half the LDS store instructions, ~4.5 vector
+// instructions per MFMA.  LDS rows are 320 B (256 B of halves + 64 B pad): the 4 rows x 64 B a 32-lane half reads sit on
+// disjoint bank quarters.
+namespace tn32 {
+constexpr int KS2 = 32;                  // m rows per stage
+constexpr int RS = 320;                  // bytes per LDS row
+constexpr int PLANE2 = KS2 * RS;         // 10240
+constexpr int OPER2 = 2 * PLANE2;        // hi plane, lo plane
+constexpr int STAGE2 = 2 * OPER2;        // dY image, X image: 40960
+constexpr int LDS2 = 2 * STAGE2;         // 81920: two workgroups per CU
+
+typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
+
+// one operand's 32 x 128 stage in registers: thread (cg = tid & 31, mq = tid >> 5) holds rows 4 mq + e (e = 0..3), columns 4 cg .. +3
+typedef float f32x4r __attribute__((ext_vector_type(4)));
+struct Regs {
+  f32x4r v[4];
+  unsigned ok;        // bit e: row e exists and belongs to this chunk (and the columns exist)
+};
+
+struct Loader {
+  const float* p[4];
+  int64_t step;
+  int m, mend, mlim;
+  bool colok;
+  __device__ __forceinline__ void init(const float* __restrict__ P, int64_t ld, int c0, int cn, int mbeg, int mend_, int mlim_, int tid) {
+    const int col = c0 + 4 * (tid & 31);
+    colok = col < cn;                                  // cn % 4 == 0: a float4 is inside or outside as a whole
+    m = mbeg + 4 * (tid >> 5);
+    mend = mend_; mlim = mlim_;
+    step = (int64_t)KS2 * ld;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) p[e] = P + (int64_t)min(m + e, mlim - 1) * ld + (colok ? col : 0);
+  }
+  // The loads are inline asm: hipcc sinks a plain load to just in front of its first use -- here the conversion at the END of the
+  // stage, with the whole memory latency exposed.  Completion is by hand (k_gemmh_tn32: one `s_waitcnt vmcnt(0)` tied to the eight
+  // registers before the conversion); the register set is written by no one else in between (checked in the ISA: no spill, no
+  // copy of these registers between the loads and the wait -- keep it so when this kernel's register budget changes).
+  __device__ __forceinline__ void next(Regs& R) {
+    unsigned ok = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ok |= (colok && m + e < mend) ? (1u << e) : 0u;
+    asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %5, off\n\t"
+                 "global_load_dwordx4 %2, %6, off\n\tglobal_load_dwordx4 %3, %7, off"
+                 : "=&v"(R.v[0]), "=&v"(R.v[1]), "=&v"(R.v[2]), "=&v"(R.v[3]) : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]) : "memory");
+#pragma unroll
+    for (int e = 0; e < 4; ++e) p[e] += (m + e + KS2 < mlim) ? step : 0;         // stop at the end of memory; those rows are masked anyway
+    R.ok = ok;
+    m += KS2;
+  }
+};
+
+// split the stage and store it row-major: rows 4 mq + e, 8 bytes (4 halves) per plane at column 4 cg
 template <bool BIAS>
-__global__ __launch_bounds__(256, 2) void k_gemmh_tn_partial(const float* __restrict__ dY, int64_t ldy, const float* __restrict__ X,
-                                                             int64_t ldx, int M, int N, int K, int chunk, int with_bias,
-                                                             float* __restrict__ partial, const unsigned* __restrict__ amax_dy,
-                                                             const unsigned* __restrict__ amax_x) {
+__device__ __forceinline__ void store_stage(const Regs& R, char* __restrict__ img, int tid, float sc, float (&bs)[4]) {
+  char* dst = img + (4 * (tid >> 5)) * RS + 8 * (tid & 31);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const bool g = (R.ok >> e) & 1u;
+    const float x0 = g ? R.v[e][0] : 0.f, x1 = g ? R.v[e][1] : 0.f, x2 = g ? R.v[e][2] : 0.f, x3 = g ? R.v[e][3] : 0.f;
+    if (BIAS) { bs[0] += x0; bs[1] += x1; bs[2] += x2; bs[3] += x3; }
+    uint2 h, l;
+    split_pair(x0 * sc, x1 * sc, &h.x, &l.x);
+    split_pair(x2 * sc, x3 * sc, &h.y, &l.y);
+    *reinterpret_cast<uint2*>(dst + e * RS) = h;
+    *reinterpret_cast<uint2*>(dst + e * RS + PLANE2) = l;
+  }
+}
+
+// MFMA fragment (8 consecutive m of one column per lane) of the 32-column tile at byte column offset `cb`, MFMA step j, from a plane
+__device__ __forceinline__ f16x8 tr_frag(const char* __restrict__ plane_lane, int j, int cb) {
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(plane_lane + (16 * j) * RS + cb));
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(plane_lane + (16 * j + 4) * RS + cb));
+  typedef short s16x8 __attribute__((__vector_size__(8 * sizeof(short))));
+  const s16x8 r = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  return __builtin_bit_cast(f16x8, r);
+}
+}  // namespace tn32
+
+template <bool BIAS>
+__global__ __launch_bounds__(256, 2) void k_gemmh_tn32(const float* __restrict__ dY, int64_t ldy, const float* __restrict__ X, int64_t ldx,
+                                                       int M, int N, int K, int chunk, int with_bias, float* __restrict__ partial,
+                                                       const unsigned* __restrict__ amax_dy, const unsigned* __restrict__ amax_x) {
+  using namespace tn32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n0 = blockIdx.x * BM, kk0 = blockIdx.y * BN, mc = blockIdx.z;
   const int mbeg = mc * chunk, mend = min(M, mbeg + chunk);
   const int wr = wave >> 1, wc = wave & 1;
-  const int live_m = min(2, max(0, (N - (n0 + wr * 64) + 31) / 32)), live_n = min(2, max(0, (K - (kk0 + wc * 64) + 31) / 32));
+  const int nst = (mend - mbeg + KS2 - 1) / KS2;
+
+  Loader la, lb;
+  la.init(dY, ldy, n0, N, mbeg, mend, M, tid);
+  lb.init(X, ldx, kk0, K, mbeg, mend, M, tid);
+  Regs ra, rb;
+  la.next(ra); lb.next(rb);
+  const float sca = scale_of(amax_group(amax_dy)), scb = scale_of(amax_group(amax_x));
+  const float ia = 1.0f / sca, ib = 1.0f / scb;
+#define DGDM_TN32_RETIRE()                                                                                       \
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra.v[0]), "+v"(ra.v[1]), "+v"(ra.v[2]), "+v"(ra.v[3]), "+v"(rb.v[0]), "+v"(rb.v[1]),       \
+               "+v"(rb.v[2]), "+v"(rb.v[3]) :: "memory");
+
   f32x16 acc[2][2];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -383,10 +481,48 @@ __global__ __launch_bounds__(256, 2) void k_gemmh_tn_partial(const float* __rest
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-  float bs[4] = {0.f, 0.f, 0.f, 0.f};
-  const float sca = scale_of(amax_group(amax_dy)), scb = scale_of(amax_group(amax_x));
-  const float ia = 1.0f / sca, ib = 1.0f / scb;
-  mainloop_h<false, false, BIAS>(dY, ldy, n0, N, X, ldx, kk0, K, mbeg, mend, M, smem, acc, live_m, live_n, bs, sca, scb);
+  float bs[4] = {0.f, 0.f, 0.f, 0.f}, nobs[4];
+
+  // this lane's block address inside a 32-column tile: lane = 16 g + 4 q + p -> row 8 (g >> 1) + q, byte column 32 (g & 1) + 8 p
+  const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+  const int lane_off = (8 * (g >> 1) + q) * RS + 32 * (g & 1) + 8 * pp;
+
+  DGDM_TN32_RETIRE()
+  store_stage<BIAS>(ra, smem, tid, sca, bs);
+  store_stage<false>(rb, smem + OPER2, tid, scb, nobs);
+
+  // stage s: the loads of stage s + 1 go out first; MFMAs from LDS[s & 1]; then the loaded stage is split into LDS[(s + 1) & 1].
+  // The conversion runs behind this wave's MFMAs, under those of the CU's other workgroup (two per CU, never in lockstep).
+  for (int s = 0; s < nst; ++s) {
+    __syncthreads();
+    const char* cur = smem + (s & 1) * STAGE2 + lane_off;
+    char* nxt = smem + ((s & 1) ^ 1) * STAGE2;
+    la.next(ra);
+    lb.next(rb);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      f16x8 fa[2][2], fb[2][2];
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          fa[p][t] = tr_frag(cur + p * PLANE2, j, 2 * (wr * 64 + t * 32));
+          fb[p][t] = tr_frag(cur + OPER2 + p * PLANE2, j, 2 * (wc * 64 + t * 32));
+        }
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          acc[mt][nt] = mfma_hf(fa[1][mt], fb[0][nt], acc[mt][nt]);   // smaller terms first
+          acc[mt][nt] = mfma_hf(fa[0][mt], fb[1][nt], acc[mt][nt]);
+          acc[mt][nt] = mfma_hf(fa[0][mt], fb[0][nt], acc[mt][nt]);
+        }
+    }
+    DGDM_TN32_RETIRE()
+    store_stage<BIAS>(ra, nxt, tid, sca, bs);
+    store_stage<false>(rb, nxt + OPER2, tid, scb, nobs);
+  }
+#undef DGDM_TN32_RETIRE
 
   const int j = lane & 31, hi = lane >> 5;
   const int64_t width = (int64_t)N * K + (with_bias ? N : 0);
@@ -415,15 +551,17 @@ __global__ __launch_bounds__(256, 2) void k_gemmh_tn_partial(const float* __rest
           if (rbase + (r & 3) + 8 * (r >> 2) < N) p[(int64_t)((r & 3) + 8 * (r >> 2)) * K] = acc[mt][nt][r];
       }
     }
-  if (BIAS && blockIdx.y == 0) {  // the 8 threads (tid & 7) of one column group hold the k pairs of the same 4 columns
+  if (BIAS && blockIdx.y == 0) {   // threads tid, tid + 32, ... (the 8 row groups) hold sums of the same 4 columns: add them through LDS
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+    *reinterpret_cast<float4*>(&red[(tid >> 5) * 128 + 4 * (tid & 31)]) = make_float4(bs[0], bs[1], bs[2], bs[3]);
+    __syncthreads();
+    if (tid < 128) {
+      float t = 0.f;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      bs[q] += __shfl_xor(bs[q], 1, 64);
-      bs[q] += __shfl_xor(bs[q], 2, 64);
-      bs[q] += __shfl_xor(bs[q], 4, 64);
+      for (int gq = 0; gq < 8; ++gq) t += red[gq * 128 + tid];
+      if (n0 + tid < N) P[(int64_t)N * K + n0 + tid] = t;
     }
-    const int n = n0 + 4 * (tid >> 3);
-    if ((tid & 7) == 0 && n < N) *reinterpret_cast<float4*>(&P[(int64_t)N * K + n]) = make_float4(bs[0], bs[1], bs[2], bs[3]);
   }
 }
 
@@ -480,10 +618,10 @@ int tnh_chunk_rows(int M, int N, int K) {
 
 // dynamic LDS opt-in once per kernel (per process; one device per process)
 template <typename Kern>
-int allow_big_lds(Kern kern) {
+int allow_big_lds(Kern kern, int bytes = LDS_BYTES) {
   static int status = 1;   // 1 = not asked yet
   if (status == 1)
-    status = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess
+    status = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess
                  ? DGDM_OK : DGDM_ERR_LAUNCH;
   return status;
 }
@@ -580,11 +718,11 @@ static int tn_impl(const float* dY, int64_t ldy, const float* X, int64_t ldx, fl
   float* partial = static_cast<float*>(workspace);
   const dim3 grid((N + BM - 1) / BM, (K + BN - 1) / BN, nchunks);
   if (db) {
-    if (allow_big_lds(k_gemmh_tn_partial<true>) != DGDM_OK) return DGDM_ERR_LAUNCH;
-    hipLaunchKernelGGL(k_gemmh_tn_partial<true>, grid, dim3(256), LDS_BYTES, s, dY, ldy, X, ldx, M, N, K, chunk, 1, partial, amax_dy, amax_x);
+    if (allow_big_lds(k_gemmh_tn32<true>, tn32::LDS2) != DGDM_OK) return DGDM_ERR_LAUNCH;
+    hipLaunchKernelGGL(k_gemmh_tn32<true>, grid, dim3(256), tn32::LDS2, s, dY, ldy, X, ldx, M, N, K, chunk, 1, partial, amax_dy, amax_x);
   } else {
-    if (allow_big_lds(k_gemmh_tn_partial<false>) != DGDM_OK) return DGDM_ERR_LAUNCH;
-    hipLaunchKernelGGL(k_gemmh_tn_partial<false>, grid, dim3(256), LDS_BYTES, s, dY, ldy, X, ldx, M, N, K, chunk, 0, partial, amax_dy, amax_x);
+    if (allow_big_lds(k_gemmh_tn32<false>, tn32::LDS2) != DGDM_OK) return DGDM_ERR_LAUNCH;
+    hipLaunchKernelGGL(k_gemmh_tn32<false>, grid, dim3(256), tn32::LDS2, s, dY, ldy, X, ldx, M, N, K, chunk, 0, partial, amax_dy, amax_x);
   }
   if (partial_only) return dgdm_launch_status();   // the caller reduces the chunk partials later (dgdm_gemm_tn_reduce_many)
   if (nchunks > 32)
