@@ -334,6 +334,40 @@ def test_gradients_match_oracle_at_the_headline_graph_size():
     assert _assert_all_grads(m, gref, 5e-4) > 60
 
 
+@pytest.mark.parametrize("pooling", ["mean", "max", "set2set"])
+def test_non_default_pools_match_oracle(pooling):
+    """dgdm_model.py:552-585, 618-642: graph embeddings of the mean / max / "set2set" (= mean) pools on a ragged three-graph batch
+    (one graph of two nodes), forward against the float64 oracle and the gradient that reaches the node embeddings."""
+    from dgdm_histopath_lab_amd.graph import GraphBatch
+    from dgdm_histopath_lab_amd.synthetic import synthetic_graph
+    cfgd = dict(node_features=768, hidden_dims=[512, 256, 128], num_diffusion_steps=10, attention_heads=8, use_hierarchical=False,
+                pooling=pooling)
+    cfg = O.OracleConfig(**cfgd)
+    P = O.init_params(cfg, seed=5, perturb=0.05)
+    batch = GraphBatch.from_data_list([synthetic_graph(0, 700, 2800), synthetic_graph(1, 2, 2), synthetic_graph(2, 333, 1500)])
+    b64 = types.SimpleNamespace(x=batch.x.double(), edge_index=batch.edge_index, edge_attr=batch.edge_attr.double(),
+                                pos=batch.pos.double(), batch=batch.batch)
+    P64 = {k: v.double().requires_grad_(k.startswith("graph_encoder.output_proj")) for k, v in P.items()}
+    ref = O.forward(P64, cfg, b64, mode="inference", return_embeddings=True)
+    w = torch.randn(ref["graph_embedding"].shape, generator=torch.Generator().manual_seed(1), dtype=torch.float64)
+    (ref["graph_embedding"] * w).sum().backward()
+    if pooling == "set2set":     # the reference's unused LSTM (dgdm_model.py:623) has no counterpart in the oracle's parameters
+        from dgdm_histopath_lab_amd import DGDMModel
+        m = DGDMModel(**cfgd)
+        res = m.load_state_dict(dict(P), strict=False)
+        assert not res.unexpected_keys and all(k.startswith("global_pool.lstm.") for k in res.missing_keys)
+        m = m.to(DEV).eval()
+    else:
+        m = _model(cfgd, P)
+    out = m(batch.to(DEV), mode="inference", return_embeddings=True)
+    assert out["graph_embedding"].shape == (3, 128)
+    assert_close(out["graph_embedding"], ref["graph_embedding"], 2e-4, "graph_embedding")
+    assert_close(out["node_embeddings"], ref["node_embeddings"], 2e-4, "node_embeddings")
+    (out["graph_embedding"] * w.to(DEV).float()).sum().backward()
+    for k in ("graph_encoder.output_proj.weight", "graph_encoder.output_proj.bias"):
+        assert_close(dict(m.named_parameters())[k].grad, P64[k].grad, 1e-3, k)
+
+
 def test_model_error_contract():
     from dgdm_histopath_lab_amd import DGDMModel, GraphData, ModelConfigurationError, ModelInferenceError
     with pytest.raises(ModelConfigurationError):

@@ -19,6 +19,22 @@ foreign = [r for r in rows if r[0].startswith(("void at::", "at::", "__amd_roccl
 print(f"# total kernel time {total:.2f} ms over {steps} steps = {total / steps:.2f} ms/step ({db})")
 print(f"# launches/step {launches / steps:.1f}; shorter than 10 us: {short[0] / steps:.1f} launches = {(short[1] or 0) / steps:.3f} ms/step; "
       f"not this library's (torch/rocclr/library): {sum(r[1] for r in foreign) / steps:.1f} launches = {sum(r[3] for r in foreign) / steps:.3f} ms/step")
+# idle time between consecutive kernels over the LAST six steps (steady state: a replayed HIP graph in the default bench), the window
+# running from the marker kernel's 7th-last launch to its last one
+marks = [r[0] for r in c.execute("select start from kernels where name like ? order by start", (f"%{marker}%",)).fetchall()]
+if len(marks) >= 7:
+    t0, t1 = marks[-7], marks[-1]
+    ks = c.execute("select start, end from kernels where start >= ? and start < ? order by start", (t0, t1)).fetchall()
+    busy, idle, nidle, cur_end = 0, 0, 0, ks[0][0]
+    for st, en in ks:
+        if st > cur_end:
+            idle += st - cur_end; nidle += 1
+            busy += en - st
+        else:
+            busy += max(0, en - cur_end)
+        cur_end = max(cur_end, en)
+    print(f"# last 6 steps: wall {(t1 - t0) / 6e6:.3f} ms/step = GPU busy {busy / 6e6:.3f} + idle {idle / 6e6:.3f} ms/step over {nidle / 6:.0f} "
+          f"gaps ({idle / max(1, nidle) / 1e3:.2f} us each); {len(ks) / 6:.0f} launches/step")
 print(f"{'kernel':92s} {'calls':>6s} {'avg_us':>9s} {'ms/step':>8s} {'%':>6s}")
 for name, calls, avg_us, ms in rows[:max_rows]:
     print(f"{name[:92]:92s} {calls:6d} {avg_us:9.1f} {ms / steps:8.3f} {100 * ms / total:6.2f}")
