@@ -212,12 +212,28 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_gemm_img(const float* __res
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
+  float sca, scb;
+  if (ACCUM) {   // C += ...: the accumulators START from C (times the operand scales: powers of two, exact), no epilogue pass.
+    // Done BEFORE any asm load is in flight: whatever the register allocator spills or copies here is complete data.
+    sca = scale_of(amax_group(amax_a));
+    scb = *reinterpret_cast<const float*>(img);
+    const float sc2 = sca * scb;
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+      const float* p = C + min(32 * (tg0 + wn * NTW + t) + (lane & 31), Ncols - 1);
+#pragma unroll
+      for (int r = 0; r < 16; ++r)      // unconditional loads from clamped rows (rows past M are never stored): no branch per element
+        acc[t][r] = p[(int64_t)min(r0 + 4 * (lane >> 5) + (r & 3) + 8 * (r >> 2), M - 1) * ldc] * sc2;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
   stage_dma(0, 0);
   DGDM_LOAD_CHUNK(0, a00, a01, a02, a03)
   DGDM_LOAD_CHUNK(1, a10, a11, a12, a13)
-  // the operand scales are read AFTER the first stage and the first two chunks are on their way: one memory latency, not two
-  const float sca = scale_of(amax_group(amax_a));
-  const float scb = *reinterpret_cast<const float*>(img);
+  if (!ACCUM) {  // the operand scales are read AFTER the first stage and the first two chunks are on their way: one memory latency, not two
+    sca = scale_of(amax_group(amax_a));
+    scb = *reinterpret_cast<const float*>(img);
+  }
 
   for (int s = 0; s < nst; ++s) {
     // stage s has landed (this wave's pieces: vmcnt; everybody's: the barrier), and every wave is done reading the other buffer
@@ -286,18 +302,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_gemm_img(const float* __res
     const float bv = (bias && col < Ncols) ? bias[col] : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = acc[t][r] * inv + bv;
-  }
-  if (ACCUM) {
-#pragma unroll
-    for (int t = 0; t < NTW; ++t) {
-      const int col = 32 * (tg0 + wn * NTW + t) + jc;
-      const float* p = C + (int64_t)min(rbase, M - 1) * ldc + min(col, Ncols - 1);
-      float old[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) old[r] = (rbase + (r & 3) + 8 * (r >> 2) < M) ? p[(int64_t)((r & 3) + 8 * (r >> 2)) * ldc] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[t][r] += old[r];
-    }
   }
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -373,11 +377,28 @@ __global__ __launch_bounds__(256, 2) void k_gemm_img8(const float* __restrict__ 
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
+  float sca, scb;
+  if (ACCUM) {   // C += ...: the accumulators START from C (times the operand scales: powers of two, exact), no epilogue pass.
+    // Done BEFORE any asm load is in flight: whatever the register allocator spills or copies here is complete data.
+    sca = scale_of(amax_group(amax_a));
+    scb = *reinterpret_cast<const float*>(img);
+    const float sc2 = sca * scb;
+#pragma unroll
+    for (int t = 0; t < NT8; ++t) {
+      const float* p = C + min(32 * (tg0 + t) + (lane & 31), Ncols - 1);
+#pragma unroll
+      for (int r = 0; r < 16; ++r)      // unconditional loads from clamped rows (rows past M are never stored): no branch per element
+        acc[t][r] = p[(int64_t)min(r0 + 4 * (lane >> 5) + (r & 3) + 8 * (r >> 2), M - 1) * ldc] * sc2;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
   chunk_dma(0, 0);
   DGDM_LOAD_CHUNK(0, a00, a01, a02, a03)
   DGDM_LOAD_CHUNK(1, a10, a11, a12, a13)
-  const float sca = scale_of(amax_group(amax_a));
-  const float scb = *reinterpret_cast<const float*>(img);
+  if (!ACCUM) {  // the operand scales are read AFTER the first stage and the first two chunks are on their way: one memory latency, not two
+    sca = scale_of(amax_group(amax_a));
+    scb = *reinterpret_cast<const float*>(img);
+  }
 
   // one chunk: wait for its B slot (and the A set), restage the other slot, convert the A set and refill it two chunks ahead,
   // then 8 batches (j, tile pair) of four fragment reads + six MFMAs, the reads one batch ahead
@@ -446,18 +467,6 @@ __global__ __launch_bounds__(256, 2) void k_gemm_img8(const float* __restrict__ 
     const float bv = (bias && col < Ncols) ? bias[col] : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = acc[t][r] * inv + bv;
-  }
-  if (ACCUM) {
-#pragma unroll
-    for (int t = 0; t < NT8; ++t) {
-      const int col = 32 * (tg0 + t) + jc;
-      const float* p = C + (int64_t)min(rbase, M - 1) * ldc + min(col, Ncols - 1);
-      float old[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) old[r] = (rbase + (r & 3) + 8 * (r >> 2) < M) ? p[(int64_t)((r & 3) + 8 * (r >> 2)) * ldc] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[t][r] += old[r];
-    }
   }
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

@@ -51,3 +51,26 @@ def test_host_side_argument_checks(lib_path):
     assert lib.dgdm_csr_build_pair(None, 10, 4, 1, None, None, None, None, None, None, None, None, None, None, 0, None) == -1
     assert lib.dgdm_spmm(None, None, None, None, 8, 4, None, 8, 4, 8, None, 0, None) == -1
     assert lib.dgdm_spmm(1, 1, 1, 16, 6, 4, 16, 8, 4, 6, None, 0, None) == -2                 # C % 4 != 0
+
+
+def test_kernels_with_asm_issued_loads_do_not_spill():
+    """csrc/gemm_img.hip and k_gemmh_tn32 issue their activation loads as inline asm and retire them by hand (one s_waitcnt per
+    stage): between the load and that wait the compiler believes the registers hold data, so a spill or a copy placed there would
+    move bytes that have not arrived.  With no scratch use at all there is nothing the allocator could have moved: hold the
+    kernels to zero spills (compile-time check, no GPU)."""
+    import subprocess
+    from dgdm_histopath_lab_amd import _build
+    for src, names in (("gemm_img.hip", ("k_gemm_img",)), ("gemm_h.hip", ("k_gemmh_tn32",))):
+        r = subprocess.run([_build._hipcc(), *_build.FLAGS, *_build.EXTRA_FLAGS.get(src, []), "--cuda-device-only", "-S", "-o", "/dev/null",
+                            "-Rpass-analysis=kernel-resource-usage", os.path.join(_build.CSRC, src)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        cur, seen = None, 0
+        for line in r.stderr.splitlines():
+            m = re.search(r"Function Name: (\S+)", line)
+            if m:
+                cur = m.group(1)
+            m = re.search(r"VGPRs Spill: (\d+)", line)
+            if m and cur and any(n in cur for n in names):
+                seen += 1
+                assert int(m.group(1)) == 0, f"{cur} spills {m.group(1)} VGPRs"
+        assert seen >= 2, (src, seen)
