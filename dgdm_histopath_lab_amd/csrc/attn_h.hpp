@@ -61,6 +61,24 @@ __device__ __forceinline__ f16x8 load_t_pair(const _Float16* __restrict__ timg_p
   return f16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
 }
 
+// The same A operand (tile pair t0, t0+1 of a [d][row] matrix, lane (d = j, G) holding rows 16*t0 + 4G .. +3 and 16*(t0+1) + 4G .. +3)
+// read TRANSPOSED out of the ROW image in LDS (64 B per row: 16 hi halfs | 16 lo halfs; `part` 0 = hi, 1 = lo) with gfx950's
+// ds_read_b64_tr_b16: per group of 16 lanes a block of 4 rows x 16 halfs, lane 4q + p of the group supplies the address of row q,
+// halfs 4p .. 4p+3, lane i receives column i of the 4 rows.  A kernel that reads its transposed operands this way needs no
+// transposed image staged at all: half the LDS-DMA pieces per block and half the LDS footprint.  (Two-way bank conflict: the rows
+// r and r + 4 of a 32-lane half share banks at the 64-byte row pitch.)  EXEC must be all ones (no divergence around the call).
+__device__ __forceinline__ f16x8 load_tr_pair(const _Float16* __restrict__ rimg_head, int part, int t0, int lane) {
+  typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  typedef short s16x8 __attribute__((__vector_size__(8 * sizeof(short))));
+  const int j = lane & 15, G = lane >> 4;
+  const _Float16* p = rimg_head + (16 * t0 + 4 * G + (j >> 2)) * 32 + 16 * part + 4 * (j & 3);
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p);
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 16 * 32));
+  const s16x8 r = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  return __builtin_bit_cast(f16x8, r);
+}
+
 // Asynchronous copy of BYTES contiguous bytes global -> LDS by a 256-thread workgroup: each wave
 // instruction moves 1 KiB (lane l: 16 B at offset piece*1024 + l*16; LDS destination = wave-uniform
 // base + l*16).  Completion: the issuing wave's vmcnt, then a workgroup barrier (hipcc emits

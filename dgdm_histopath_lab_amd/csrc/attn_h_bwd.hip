@@ -9,12 +9,29 @@
 // staged by direct-to-LDS DMA.
 #include "attn_h.hpp"
 
+// In-kernel time stamps for tools/attn_stamps.py (a diagnostic build with -DDGDM_ATTN_STAMPS; in the library no stamp executes):
+// one workgroup (blockIdx.x == 40, blockIdx.y == 0), thread 0, iteration 40 of the block loop writes (s_memtime, s_memrealtime) pairs.
+#ifdef DGDM_ATTN_STAMPS
+__device__ unsigned long long* dgdm_attn_stamps;
+extern "C" __attribute__((visibility("default"))) int dgdm_debug_set_attn_stamps(void* p) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(dgdm_attn_stamps), &p, sizeof(p)) == hipSuccess ? 0 : -1;
+}
+#define DGDM_ASTAMP(it_, i_)                                                                              \
+  if (blockIdx.x == 40 && blockIdx.y == 0 && threadIdx.x == 0 && (it_) == 40) {                           \
+    dgdm_attn_stamps[2 * (i_)] = __builtin_amdgcn_s_memtime();                                            \
+    dgdm_attn_stamps[2 * (i_) + 1] = __builtin_amdgcn_s_memrealtime();                                    \
+  }
+#else
+#define DGDM_ASTAMP(it_, i_)
+#endif
+
 namespace {
 
 constexpr float NEG_BIG = -1.0e30f;
 
 // ---------------------------------------------------------------------------------------- dQ
-// LDS per buffer: Rk | Rv | Tk | pos
+// LDS per buffer: Rk | Rv | pos  (K^T of the dQ product is read transposed out of the row image Rk: load_tr_pair; Tk stays in the
+// signature, unused)
 template <int HG, int NBUF, bool DROP, int WPE = 1>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) void k_attn_h_bwd_dq(const _Float16* __restrict__ Rq, const _Float16* __restrict__ Rk,
                                                        const _Float16* __restrict__ Rv, const _Float16* __restrict__ Tk,
@@ -25,8 +42,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
                                                        float drop_p, DgdmSeed seed_in) {
   const uint32_t seed = seed_in.value();
   constexpr int NT = HB / 16;
-  constexpr int R_BYTES = HG * R_HEAD * 2, T_BYTES = HG * T_HEAD * 2, POS_BYTES = HB * 8;
-  constexpr int BUF_BYTES = 2 * R_BYTES + T_BYTES + POS_BYTES;
+  constexpr int R_BYTES = HG * R_HEAD * 2, POS_BYTES = HB * 8;
+  constexpr int BUF_BYTES = 2 * R_BYTES + POS_BYTES;
   __shared__ __attribute__((aligned(16))) char smem[NBUF * BUF_BYTES];
   const DropCfg dc(drop_p);
 
@@ -45,8 +62,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
     char* base = smem + buf * BUF_BYTES;
     dma_to_lds<R_BYTES>(Rk + gb * R_HEAD, base, tid);
     dma_to_lds<R_BYTES>(Rv + gb * R_HEAD, base + R_BYTES, tid);
-    dma_to_lds<T_BYTES>(Tk + gb * T_HEAD, base + 2 * R_BYTES, tid);
-    dma_to_lds<POS_BYTES>(pos_b + (int64_t)(blk0 + kb) * HB * 2, base + 2 * R_BYTES + T_BYTES, tid);
+    dma_to_lds<POS_BYTES>(pos_b + (int64_t)(blk0 + kb) * HB * 2, base + 2 * R_BYTES, tid);
   };
   stage(0, 0);
 
@@ -74,8 +90,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
     if (NBUF == 2 && kb + 1 < nbg) stage(kb + 1, buf ^ 1);
     const _Float16* Kimg = reinterpret_cast<const _Float16*>(smem + buf * BUF_BYTES);
     const _Float16* Vimg = reinterpret_cast<const _Float16*>(smem + buf * BUF_BYTES + R_BYTES);
-    const _Float16* Ktim = reinterpret_cast<const _Float16*>(smem + buf * BUF_BYTES + 2 * R_BYTES);
-    const float* Ps = reinterpret_cast<const float*>(smem + buf * BUF_BYTES + 2 * R_BYTES + T_BYTES);
+    const float* Ps = reinterpret_cast<const float*>(smem + buf * BUF_BYTES + 2 * R_BYTES);
     const int kb0 = kb * HB;
 
     f32x4 nbias[NT];
@@ -114,12 +129,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
 #pragma unroll
         for (int r = 0; r < 4; ++r) ds[t][r] = __builtin_amdgcn_exp2f(s[r]) * dp[r];
       }
-      const _Float16* kt = Ktim + h * T_HEAD;
+      const _Float16* kr = Kimg + h * R_HEAD;
 #pragma unroll
       for (int tp = 0; tp < NT / 2; ++tp) {
         const f16x8 dsb = pack8(ds[2 * tp], ds[2 * tp + 1]);
-        dq[h] = mfma_h(load_t_pair(kt, j, 2 * tp, G), dsb, dq[h]);            // dQ^T[d=j][q] += K^T[d][key] dS^T[key][q]
-        dq[h] = mfma_h(load_t_pair(kt + T_PART, j, 2 * tp, G), dsb, dq[h]);   // lo part of K: same accumulator (back-to-back
+        dq[h] = mfma_h(load_tr_pair(kr, 0, 2 * tp, lane), dsb, dq[h]);        // dQ^T[d=j][q] += K^T[d][key] dS^T[key][q]
+        dq[h] = mfma_h(load_tr_pair(kr, 1, 2 * tp, lane), dsb, dq[h]);        // lo part of K: same accumulator (back-to-back
                                                                                // MFMAs on one accumulator issue at full rate)
       }
     }
@@ -152,8 +167,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
                                                         DgdmSeed seed_in) {
   const uint32_t seed = seed_in.value();
   constexpr int NT = HB / 16;
-  constexpr int R_BYTES = HG * R_HEAD * 2, T_BYTES = HG * T_HEAD * 2, SC_BYTES = HG * HB * 4, POS_BYTES = HB * 8;
-  constexpr int BUF_BYTES = 2 * R_BYTES + 2 * T_BYTES + 2 * SC_BYTES + POS_BYTES;
+  // LDS per buffer: Rq | Rg | lse2 | delta | pos.  The transposed operands of the dV / dK products (dO^T, Q'^T) are read out of the
+  // ROW images with transposed LDS reads (load_tr_pair): no transposed image is staged (Tq / Tg stay in the signature, unused) --
+  // half the LDS-DMA pieces per block (their issue was 18 % of an iteration: tools/attn_stamps.py) and half the LDS footprint.
+  constexpr int R_BYTES = HG * R_HEAD * 2, SC_BYTES = HG * HB * 4, POS_BYTES = HB * 8;
+  constexpr int BUF_BYTES = 2 * R_BYTES + 2 * SC_BYTES + POS_BYTES;
   __shared__ __attribute__((aligned(16))) char smem[NBUF * BUF_BYTES];
   const DropCfg dc(drop_p);
 
@@ -172,11 +190,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
     char* base = smem + buf * BUF_BYTES;
     dma_to_lds<R_BYTES>(Rq + gb * R_HEAD, base, tid);
     dma_to_lds<R_BYTES>(Rg + gb * R_HEAD, base + R_BYTES, tid);
-    dma_to_lds<T_BYTES>(Tg + gb * T_HEAD, base + 2 * R_BYTES, tid);
-    dma_to_lds<T_BYTES>(Tq + gb * T_HEAD, base + 2 * R_BYTES + T_BYTES, tid);
-    dma_to_lds<SC_BYTES>(lse2_b + gb * HB, base + 2 * R_BYTES + 2 * T_BYTES, tid);
-    dma_to_lds<SC_BYTES>(delta_b + gb * HB, base + 2 * R_BYTES + 2 * T_BYTES + SC_BYTES, tid);
-    dma_to_lds<POS_BYTES>(pos_b + (int64_t)(blk0 + qb) * HB * 2, base + 2 * R_BYTES + 2 * T_BYTES + 2 * SC_BYTES, tid);
+    dma_to_lds<SC_BYTES>(lse2_b + gb * HB, base + 2 * R_BYTES, tid);
+    dma_to_lds<SC_BYTES>(delta_b + gb * HB, base + 2 * R_BYTES + SC_BYTES, tid);
+    dma_to_lds<POS_BYTES>(pos_b + (int64_t)(blk0 + qb) * HB * 2, base + 2 * R_BYTES + 2 * SC_BYTES, tid);
   };
   stage(0, 0);
 
@@ -201,12 +217,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
     const char* base = smem + buf * BUF_BYTES;
     const _Float16* Qimg = reinterpret_cast<const _Float16*>(base);
     const _Float16* Gimg = reinterpret_cast<const _Float16*>(base + R_BYTES);
-    const _Float16* Gtim = reinterpret_cast<const _Float16*>(base + 2 * R_BYTES);
-    const _Float16* Qtim = reinterpret_cast<const _Float16*>(base + 2 * R_BYTES + T_BYTES);
-    const float* Ls = reinterpret_cast<const float*>(base + 2 * R_BYTES + 2 * T_BYTES);
+    const float* Ls = reinterpret_cast<const float*>(base + 2 * R_BYTES);
     const float* Ds = Ls + HG * HB;
     const float* Ps = Ds + HG * HB;
     const int qb0 = qb * HB;
+    DGDM_ASTAMP(qb, 0)
 
     // lane (key=j, G), reg r <-> query 16t + 4G + r
     f32x4 nbias[NT];
@@ -228,6 +243,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
         for (int r = 0; r < 4; ++r)
           if (qb0 + 16 * t + 4 * G + r >= ng) nbias[t][r] = NEG_BIG;
     }
+    DGDM_ASTAMP(qb, 1)
 
 #pragma unroll
     for (int h = 0; h < HG; ++h) {
@@ -254,22 +270,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
           p[t][r] = DROP ? pr * f[r] : pr;   // dV sees the dropped weights
         }
       }
-      const _Float16* gt = Gtim + h * T_HEAD;
-      const _Float16* qt = Qtim + h * T_HEAD;
+      DGDM_ASTAMP(qb, 2 + 2 * h)
+      const _Float16* gr = Gimg + h * R_HEAD;
+      const _Float16* qr = Qimg + h * R_HEAD;
 #pragma unroll
       for (int tp = 0; tp < NT / 2; ++tp) {
         const f16x8 pb = pack8(p[2 * tp], p[2 * tp + 1]);
         const f16x8 dsb = pack8(ds[2 * tp], ds[2 * tp + 1]);
-        dv[h] = mfma_h(load_t_pair(gt, j, 2 * tp, G), pb, dv[h]);              // dV^T[d=j][key] += dO^T[d][q] P[q][key]
-        dv[h] = mfma_h(load_t_pair(gt + T_PART, j, 2 * tp, G), pb, dv[h]);
-        dk[h] = mfma_h(load_t_pair(qt, j, 2 * tp, G), dsb, dk[h]);             // dK^T[d=j][key] += Q'^T[d][q] dS[q][key]
-        dk[h] = mfma_h(load_t_pair(qt + T_PART, j, 2 * tp, G), dsb, dk[h]);
+        dv[h] = mfma_h(load_tr_pair(gr, 0, 2 * tp, lane), pb, dv[h]);          // dV^T[d=j][key] += dO^T[d][q] P[q][key]
+        dv[h] = mfma_h(load_tr_pair(gr, 1, 2 * tp, lane), pb, dv[h]);
+        dk[h] = mfma_h(load_tr_pair(qr, 0, 2 * tp, lane), dsb, dk[h]);         // dK^T[d=j][key] += Q'^T[d][q] dS[q][key]
+        dk[h] = mfma_h(load_tr_pair(qr, 1, 2 * tp, lane), dsb, dk[h]);
       }
+      DGDM_ASTAMP(qb, 3 + 2 * h)
     }
+    DGDM_ASTAMP(qb, 10)
     __syncthreads();
+    DGDM_ASTAMP(qb, 11)
     if (NBUF == 1 && qb + 1 < nbg) {
       stage(qb + 1, 0);
+      DGDM_ASTAMP(qb, 12)
       __syncthreads();
+      DGDM_ASTAMP(qb, 13)
     }
   }
 

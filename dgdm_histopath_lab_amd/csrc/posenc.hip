@@ -36,22 +36,25 @@ __global__ __launch_bounds__(256) void k_add_posenc(const float* __restrict__ x,
                                                     int N, int C, float* __restrict__ out, int64_t ldo, unsigned* __restrict__ amax) {
   const int nk = C >> 2;
   const int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (idx >= (int64_t)N * nk) {          // keep the whole block alive for the amax commit's barrier
-    if (amax) dgdm_amax_commit(0u, amax);
-    return;
+  // ONE call of dgdm_amax_commit, reached by every thread without divergence: it contains a workgroup barrier, and a wave whose
+  // lanes sit on both sides of `idx < N * nk` (N * C / 4 not a multiple of 64: any odd N at C = 128) would otherwise run it once per
+  // side -- the barrier count goes wrong and thread 0 reads maxima the other waves have not stored yet (whatever the LDS held).
+  unsigned am = 0u;
+  if (idx < (int64_t)N * nk) {
+    const int n = (int)(idx / nk), k = (int)(idx % nk);
+    int g = 0;
+    while (g + 1 < B && ptr[g + 1] <= n) ++g;  // B is small
+    const float lo = minmax[2 * g], hi = minmax[2 * g + 1];
+    const float inv = 1.0f / (hi - lo + 1e-8f);
+    const float px = (pos[2 * (int64_t)n] - lo) * inv, py = (pos[2 * (int64_t)n + 1] - lo) * inv;
+    const float f = expf((float)(2 * k) * (-9.210340371976184f / (float)(C / 2)));  // ln(1e4)
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (x) v = *reinterpret_cast<const float4*>(x + (int64_t)n * ldx + 4 * k);
+    v.x += sinf(px * f); v.y += cosf(px * f); v.z += sinf(py * f); v.w += cosf(py * f);
+    *reinterpret_cast<float4*>(out + (int64_t)n * ldo + 4 * k) = v;
+    am = dgdm_amax4(0u, v);
   }
-  const int n = (int)(idx / nk), k = (int)(idx % nk);
-  int g = 0;
-  while (g + 1 < B && ptr[g + 1] <= n) ++g;  // B is small
-  const float lo = minmax[2 * g], hi = minmax[2 * g + 1];
-  const float inv = 1.0f / (hi - lo + 1e-8f);
-  const float px = (pos[2 * (int64_t)n] - lo) * inv, py = (pos[2 * (int64_t)n + 1] - lo) * inv;
-  const float f = expf((float)(2 * k) * (-9.210340371976184f / (float)(C / 2)));  // ln(1e4)
-  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (x) v = *reinterpret_cast<const float4*>(x + (int64_t)n * ldx + 4 * k);
-  v.x += sinf(px * f); v.y += cosf(px * f); v.z += sinf(py * f); v.w += cosf(py * f);
-  *reinterpret_cast<float4*>(out + (int64_t)n * ldo + 4 * k) = v;
-  if (amax) dgdm_amax_commit(dgdm_amax4(0u, v), amax);
+  if (amax) dgdm_amax_commit(am, amax);
 }
 
 }  // namespace

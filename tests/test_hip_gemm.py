@@ -188,6 +188,33 @@ def test_producer_kernels_keep_the_operand_maximum():
         ops.configure(**prev)
 
 
+def test_posenc_maximum_with_a_partial_last_wave():
+    """dgdm_add_posenc with N * C / 4 not a multiple of 64 (an odd node count at C = 128): the last wave is half in range.  The maximum
+    in the slot must still be exactly max|out| -- the kernel once ran its amax commit (which holds a workgroup barrier) on both sides
+    of the range check, the barrier count went wrong and thread 0 committed whatever the LDS held (after a weight-image GEMM: fp16
+    halfs with the sign bit set, which an unsigned maximum prefers to every legitimate value; the next GEMM then scaled its operand
+    into fp16 infinity).  Run behind a GEMM that leaves such halfs in the LDS, many times."""
+    from dgdm_histopath_lab_amd import ops
+    prev = ops.configure(gemm="f16x2")
+    try:
+        g = torch.Generator().manual_seed(8)
+        xg, wg = torch.randn(4096, 128, generator=g).to(DEV), -torch.rand(128, 128, generator=g).to(DEV)
+        for n in (8495, 10603, 1001, 63):
+            plan = ops.AttnPlan([0, n], DEV)
+            x, pos = torch.randn(n, 128, generator=g).to(DEV), torch.rand(n, 2, generator=g).to(DEV)
+            for _ in range(12):
+                ops.gemm_nt_raw(xg, wg, None, math="f16x2")
+                y = ops.add_posenc_raw(x, pos, plan, 128)
+                s = ops.amax_of(y)
+                a = ops._arena(y.device)
+                off = (s - a.base) // 4
+                ways = a.buf[off: off + a.GROUP_WORDS]
+                assert int(ways.min()) >= 0, "a way holds the bit pattern of a negative float"
+                assert torch.equal(ways.max().view(torch.float32), y.abs().max())
+    finally:
+        ops.configure(**prev)
+
+
 @pytest.mark.parametrize("math", ["bf16x3", "f16x2"])
 def test_deferred_weight_gradient_reduction_is_bitwise_the_immediate_one(math):
     """Inside ops.deferred_weight_grads() the dW GEMMs of a backward pass leave their chunk partials and ONE launch reduces them

@@ -1,0 +1,61 @@
+"""Who writes a sign-bit-set word into the amax arena?  (every legitimate word there is the bit pattern of a non-negative float)"""
+import inspect, os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dgdm_histopath_lab_amd import DGDMModel, ops
+from dgdm_histopath_lab_amd.parallel import BalancedSlideLoader
+from dgdm_histopath_lab_amd.synthetic import synthetic_graph
+DEV = "cuda:0"
+cfgd = dict(node_features=768, hidden_dims=[512, 256, 128], num_diffusion_steps=10, attention_heads=8, diffusion_schedule="cosine")
+gen = torch.Generator().manual_seed(4)
+ns = torch.randint(1000, 10001, (16,), generator=gen).tolist(); ns[5] = 1000; ns[6] = 1200
+slides = [synthetic_graph(200 + i, n, 5 * n, 768) for i, n in enumerate(ns)]
+batches = list(BalancedSlideLoader(slides, 4, 2, 0, device=DEV))
+torch.manual_seed(0)
+model = DGDMModel(**cfgd).to(DEV).train()
+opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-5, fused=True)
+state = {"step": -1, "found": False}
+def check(where):
+    if state["found"]:
+        return
+    ar = ops._ARENAS.get(0)
+    if ar is None:
+        return
+    neg = (ar.buf < 0)
+    if bool(neg.any()):
+        idx = neg.nonzero().flatten()
+        w = idx[0].item()
+        print(f"   CORRUPT after {where} (step {state['step']}): {int(neg.sum())} words; first at word {w} = slot {w // 2048} way {(w % 2048) // 64} offset-in-way {w % 64}; value {hex(int(ar.buf[w]) & 0xffffffff)}; arena.next {ar.next}")
+        state["found"] = True
+def wrap(cls):
+    of, ob = cls.forward, cls.backward
+    def nf(ctx, *a):
+        r = of(ctx, *a); check(cls.__name__ + ".forward " + str([tuple(t.shape) for t in a if isinstance(t, torch.Tensor)][:3])); return r
+    def nb(ctx, *g):
+        r = ob(ctx, *g); check(cls.__name__ + ".backward " + str([tuple(t.shape) for t in g if isinstance(t, torch.Tensor)][:2])); return r
+    cls.forward, cls.backward = staticmethod(nf), staticmethod(nb)
+for nm, obj in inspect.getmembers(ops):
+    if inspect.isclass(obj) and issubclass(obj, torch.autograd.Function) and obj is not torch.autograd.Function:
+        wrap(obj)
+for fn in ("refresh_weight_amax", "flush_deferred_tn"):
+    o = getattr(ops, fn)
+    def mk(o, fn):
+        def f(*a, **k):
+            r = o(*a, **k); check(fn); return r
+        return f
+    setattr(ops, fn, mk(o, fn))
+import dgdm_histopath_lab_amd.models.dgdm_model as M
+M.ops = ops
+for step in range(8):
+    state["step"] = step
+    b = batches[step % 4]
+    opt.zero_grad(set_to_none=True)
+    out = model.pretrain_step(b, mask_ratio=0.15)
+    check("forward end")
+    with ops.deferred_weight_grads():
+        out["total_pretrain_loss"].backward()
+    check("backward end")
+    opt.step()
+    check("optimizer")
+    print(f"step {step} loss {float(out['total_pretrain_loss']):.4f} corrupt {state['found']}")
+    if state["found"]:
+        break
