@@ -108,6 +108,7 @@ SIGNATURES = {
     "dgdm_gemm_tn_partial_bf16x3": (C.c_int, [_p, _i64, _p, _i64, _i32, _i32, _i32, _i32, _p, _sz, _p]),
     "dgdm_gemm_tn_partial_f16x2": (C.c_int, [_p, _i64, _p, _i64, _i32, _i32, _i32, _i32, _p, _sz, _p, _p, _p]),
     "dgdm_gemm_tn_reduce_many": (C.c_int, [_p, _i32, _p]),
+    "dgdm_gemm_tn_partial_many_f16x2": (C.c_int, [_p, _i32, _p]),
     "dgdm_attn_pack_bytes": (_sz, [_i32, _i32, _i32]),
     "dgdm_amax_scale_workspace_bytes": (_sz, []),
     "dgdm_amax_pow2_scale": (C.c_int, [_p, _i64, C.c_float, _p, _p, _sz, _p]),
@@ -134,6 +135,15 @@ class TnReduce(C.Structure):
 
 
 TN_REDUCE_MAX = 24
+
+
+class TnPartial(C.Structure):
+    """struct DgdmTnPartial of include/dgdm_hip.h"""
+    _fields_ = [("dY", _p), ("X", _p), ("workspace", _p), ("amax_dy", _p), ("amax_x", _p), ("ldy", _i64), ("ldx", _i64),
+                ("workspace_bytes", C.c_size_t), ("M", _i32), ("N", _i32), ("K", _i32), ("with_bias", _i32)]
+
+
+TN_PARTIAL_MAX = 24
 
 _lib: Optional[C.CDLL] = None
 

@@ -451,14 +451,15 @@ __device__ __forceinline__ f16x8 tr_frag(const char* __restrict__ plane_lane, in
 }
 }  // namespace tn32
 
+// one workgroup's tile: (bx, by) of the [N x K] output, row chunk mc.  Shared by the one-problem launch and by the many-problem one.
 template <bool BIAS>
-__global__ __launch_bounds__(256, 2) void k_gemmh_tn32(const float* __restrict__ dY, int64_t ldy, const float* __restrict__ X, int64_t ldx,
-                                                       int M, int N, int K, int chunk, int with_bias, float* __restrict__ partial,
-                                                       const unsigned* __restrict__ amax_dy, const unsigned* __restrict__ amax_x) {
+__device__ __forceinline__ void tn32_tile(const float* __restrict__ dY, int64_t ldy, const float* __restrict__ X, int64_t ldx, int M, int N,
+                                          int K, int chunk, int with_bias, float* __restrict__ partial,
+                                          const unsigned* __restrict__ amax_dy, const unsigned* __restrict__ amax_x, int bx, int by, int mc,
+                                          char* __restrict__ smem) {
   using namespace tn32;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n0 = blockIdx.x * BM, kk0 = blockIdx.y * BN, mc = blockIdx.z;
+  const int n0 = bx * BM, kk0 = by * BN;
   const int mbeg = mc * chunk, mend = min(M, mbeg + chunk);
   const int wr = wave >> 1, wc = wave & 1;
   const int nst = (mend - mbeg + KS2 - 1) / KS2;
@@ -551,7 +552,7 @@ __global__ __launch_bounds__(256, 2) void k_gemmh_tn32(const float* __restrict__
           if (rbase + (r & 3) + 8 * (r >> 2) < N) p[(int64_t)((r & 3) + 8 * (r >> 2)) * K] = acc[mt][nt][r];
       }
     }
-  if (BIAS && blockIdx.y == 0) {   // threads tid, tid + 32, ... (the 8 row groups) hold sums of the same 4 columns: add them through LDS
+  if (BIAS && with_bias && by == 0) {   // threads tid, tid + 32, ... (the 8 row groups) hold sums of the same 4 columns: add them through LDS
     __syncthreads();
     float* red = reinterpret_cast<float*>(smem);
     *reinterpret_cast<float4*>(&red[(tid >> 5) * 128 + 4 * (tid & 31)]) = make_float4(bs[0], bs[1], bs[2], bs[3]);
@@ -563,6 +564,34 @@ __global__ __launch_bounds__(256, 2) void k_gemmh_tn32(const float* __restrict__
       if (n0 + tid < N) P[(int64_t)N * K + n0 + tid] = t;
     }
   }
+}
+
+template <bool BIAS>
+__global__ __launch_bounds__(256, 2) void k_gemmh_tn32(const float* __restrict__ dY, int64_t ldy, const float* __restrict__ X, int64_t ldx,
+                                                       int M, int N, int K, int chunk, int with_bias, float* __restrict__ partial,
+                                                       const unsigned* __restrict__ amax_dy, const unsigned* __restrict__ amax_x) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  tn32_tile<BIAS>(dY, ldy, X, ldx, M, N, K, chunk, with_bias, partial, amax_dy, amax_x, blockIdx.x, blockIdx.y, blockIdx.z, smem);
+}
+
+// MANY dW problems in one launch (the weight gradients of the pooled U-Net levels and of the 128-wide layers: 12-25 us each as
+// launches of their own, a few dozen workgroups of four stages -- start-up, not work).  Workgroup b belongs to the last problem
+// whose block0 <= b; inside it the tile order of the one-problem grid.  The descriptors travel in the kernel arguments.
+struct TnProb {
+  const float* dY; const float* X; float* partial; const unsigned* amax_dy; const unsigned* amax_x;
+  int64_t ldy, ldx;
+  int M, N, K, chunk, with_bias, gx, gy, block0;
+};
+struct TnMany { TnProb p[DGDM_TN_PARTIAL_MAX]; int n; };
+
+__global__ __launch_bounds__(256, 2) void k_gemmh_tn32_many(const TnMany b) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int i = 0;
+  for (int j = 1; j < b.n; ++j) i = ((int)blockIdx.x >= b.p[j].block0) ? j : i;        // wave-uniform: scalar loads of the arguments
+  const TnProb& q = b.p[i];
+  const int local = (int)blockIdx.x - q.block0;
+  const int bx = local % q.gx, rest = local / q.gx;
+  tn32_tile<true>(q.dY, q.ldy, q.X, q.ldx, q.M, q.N, q.K, q.chunk, q.with_bias, q.partial, q.amax_dy, q.amax_x, bx, rest % q.gy, rest / q.gy, smem);
 }
 
 // dW[n][k] / db[n] = sum over slots of in[slot][n*K + k] / in[slot][N*K + n]; fixed order: thread (column, part)
@@ -744,6 +773,35 @@ extern "C" int dgdm_gemm_tn_partial_f16x2(const float* dY, int64_t ldy, const fl
   float dummy;   // tn_impl only checks the destination pointers for presence when it skips the final reduction
   return tn_impl(dY, ldy, X, ldx, &dummy, K, K, nullptr, 0, with_bias ? &dummy : nullptr, M, N, K, workspace, workspace_bytes, amax_dy, amax_x,
                  stream, true);
+}
+
+extern "C" int dgdm_gemm_tn_partial_many_f16x2(const DgdmTnPartial* descs, int32_t count, void* stream) {
+  if (count < 0 || count > DGDM_TN_PARTIAL_MAX || (count && !descs)) return DGDM_ERR_INVALID_ARG;
+  if (count == 0) return DGDM_OK;
+  TnMany b;
+  int blocks = 0;
+  for (int i = 0; i < count; ++i) {
+    const DgdmTnPartial& d = descs[i];
+    if (d.M <= 0 || d.N <= 0 || d.K <= 0 || !d.dY || !d.X || !d.workspace || bad_amax(d.amax_dy, d.amax_x)) return DGDM_ERR_INVALID_ARG;
+    if ((d.ldy & 3) || (d.ldx & 3) || (d.N & 3) || (d.K & 3) || d.ldy < d.N || d.ldx < d.K || !dgdm_aligned16(d.dY) || !dgdm_aligned16(d.X))
+      return DGDM_ERR_UNSUPPORTED;
+    const int chunk = tnh_chunk_rows(d.M, d.N, d.K);
+    const int nchunks = (d.M + chunk - 1) / chunk;
+    const int64_t width = (int64_t)d.N * d.K + (d.with_bias ? d.N : 0);
+    if (width > 0x7fffffffLL) return DGDM_ERR_UNSUPPORTED;
+    if (d.workspace_bytes < (size_t)nchunks * width * sizeof(float)) return DGDM_ERR_WORKSPACE;
+    TnProb& q = b.p[i];
+    q.dY = d.dY; q.X = d.X; q.partial = static_cast<float*>(d.workspace); q.amax_dy = d.amax_dy; q.amax_x = d.amax_x;
+    q.ldy = d.ldy; q.ldx = d.ldx; q.M = d.M; q.N = d.N; q.K = d.K; q.chunk = chunk; q.with_bias = d.with_bias ? 1 : 0;
+    q.gx = (d.N + BM - 1) / BM; q.gy = (d.K + BN - 1) / BN; q.block0 = blocks;
+    const int64_t nb = (int64_t)q.gx * q.gy * nchunks;
+    if (nb + blocks > 0x3fffffff) return DGDM_ERR_UNSUPPORTED;
+    blocks += (int)nb;
+  }
+  b.n = count;
+  if (allow_big_lds(k_gemmh_tn32_many, tn32::LDS2) != DGDM_OK) return DGDM_ERR_LAUNCH;
+  hipLaunchKernelGGL(k_gemmh_tn32_many, dim3((unsigned)blocks), dim3(256), tn32::LDS2, static_cast<hipStream_t>(stream), b);
+  return dgdm_launch_status();
 }
 
 extern "C" int dgdm_gemm_tn_split_f16x2(const float* dY, int64_t ldy, const float* X, int64_t ldx, float* dW0, int64_t ld0, int32_t K0,

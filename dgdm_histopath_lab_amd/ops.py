@@ -6,6 +6,7 @@ ctypes; tensors only provide device memory.  No CPU path exists.
 from __future__ import annotations
 
 import collections
+import os
 from typing import Optional
 
 import torch
@@ -1188,8 +1189,18 @@ def flush_deferred_tn() -> None:
     # on the stream each GEMM's partials were launched on (the engine's end-of-pass callback may run under another current stream
     # than the backward nodes did, e.g. when the step runs on a side stream)
     by_stream: dict = {}
-    for desc, keep, stream in pend:
+    small: dict = {}
+    for desc, keep, stream, partial in pend:
         by_stream.setdefault(stream, []).append(desc)
+        if partial is not None:
+            small.setdefault(stream, []).append(partial)
+    for stream, parts in small.items():       # the partial GEMMs that were held back: up to TN_PARTIAL_MAX problems per launch
+        for i in range(0, len(parts), _lib.TN_PARTIAL_MAX):
+            part = parts[i:i + _lib.TN_PARTIAL_MAX]
+            arr = (_lib.TnPartial * len(part))()
+            for j, d in enumerate(part):
+                arr[j] = _lib.TnPartial(*d)
+            _lib.check(lib.dgdm_gemm_tn_partial_many_f16x2(arr, len(part), stream), "dgdm_gemm_tn_partial_many_f16x2")
     for stream, descs in by_stream.items():
         for i in range(0, len(descs), _lib.TN_REDUCE_MAX):
             part = descs[i:i + _lib.TN_REDUCE_MAX]
@@ -1199,15 +1210,21 @@ def flush_deferred_tn() -> None:
             _lib.check(lib.dgdm_gemm_tn_reduce_many(arr, len(part), stream), "dgdm_gemm_tn_reduce_many")
 
 
-def _defer_tn(desc, keep, stream) -> bool:
-    """Queue a reduction for the end of the running backward pass; False when no pass is running."""
+def _defer_tn(desc, keep, stream, partial=None) -> bool:
+    """Queue a reduction for the end of the running backward pass; False when no pass is running.  ``partial``: the arguments of the
+    partial GEMM itself (a _lib.TnPartial tuple) when that launch is held back too and joins the pass's many-problem launch."""
     if not _PENDING_TN:
         try:
             torch.autograd.Variable._execution_engine.queue_callback(flush_deferred_tn)
         except RuntimeError:
             return False
-    _PENDING_TN.append((desc, keep, stream))
+    _PENDING_TN.append((desc, keep, stream, partial))
     return True
+
+
+# A dW GEMM whose own grid has at most this many workgroups (row chunks x 128 x 128 tiles) is start-up bound as a launch of its
+# own: inside ``deferred_weight_grads()`` it is held back and runs in the many-problem launch at the end of the pass.
+TN_GROUP_MAX_BLOCKS = int(os.environ.get("DGDM_TN_GROUP_MAX_BLOCKS", "1000"))
 
 
 def gemm_tn_raw(dy, x, with_bias: bool, math="fp32", split: Optional[int] = None, out: Optional[torch.Tensor] = None,
@@ -1241,7 +1258,12 @@ def gemm_tn_raw(dy, x, with_bias: bool, math="fp32", split: Optional[int] = None
         # keep-alive ALIASES of the outputs (same storage, other tensor objects): holding d0 itself would raise its reference count and
         # make the engine's AccumulateGrad CLONE it -- a copy of memory this launch has not filled yet -- instead of adopting it
         alias = lambda t: None if t is None else t.detach()
-        if _defer_tn(desc, (ws, alias(d0), alias(d1), alias(db), dy, x), _lib.stream_ptr(x.device)):
+        keep = (ws, alias(d0), alias(d1), alias(db), dy, x)
+        if math == "f16x2" and slots * ((N + 127) // 128) * ((K + 127) // 128) <= TN_GROUP_MAX_BLOCKS:
+            partial = (dy.data_ptr(), x.data_ptr(), ws.data_ptr(), extra[0], extra[1], dy.stride(0), x.stride(0), wsb, M, N, K, int(with_bias))
+            if _defer_tn(desc, keep, _lib.stream_ptr(x.device), partial):
+                return (d0 if split is None else (d0, d1)), db
+        elif _defer_tn(desc, keep, _lib.stream_ptr(x.device)):
             fn = getattr(lib, "dgdm_gemm_tn_partial_" + math)
             TIMERS.timed("gemm_tn", lambda: _lib.check(
                 fn(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), int(with_bias), M, N, K, ws.data_ptr(), wsb, *extra,

@@ -495,6 +495,21 @@ DGDM_API int dgdm_gemm_tn_partial_f16x2(const float* dY, int64_t ldy, const floa
                                         int32_t N, int32_t K, void* workspace, size_t workspace_bytes, const uint32_t* amax_dy,
                                         const uint32_t* amax_x, void* stream);
 DGDM_API int dgdm_gemm_tn_reduce_many(const DgdmTnReduce* descs, int32_t count, void* stream);
+/* Up to DGDM_TN_PARTIAL_MAX dgdm_gemm_tn_partial_f16x2 calls as ONE launch (the dW GEMMs of small layers are start-up bound as
+ * launches of their own).  `descs` is a HOST array; each entry has the arguments of the single call (M, N, K > 0) and fills its
+ * workspace bit-identically to it. */
+#define DGDM_TN_PARTIAL_MAX 24
+typedef struct DgdmTnPartial {
+  const float* dY;
+  const float* X;
+  void* workspace;
+  const uint32_t* amax_dy;
+  const uint32_t* amax_x;
+  int64_t ldy, ldx;
+  size_t workspace_bytes;
+  int32_t M, N, K, with_bias;
+} DgdmTnPartial;
+DGDM_API int dgdm_gemm_tn_partial_many_f16x2(const DgdmTnPartial* descs, int32_t count, void* stream);
 
 
 /* ---------------------------------------------------------------------------------------------

@@ -188,6 +188,42 @@ def test_producer_kernels_keep_the_operand_maximum():
         ops.configure(**prev)
 
 
+def test_many_problem_dw_launch_is_bitwise_the_single_launches():
+    """Inside ops.deferred_weight_grads() the dW GEMMs with small grids are held back and run as ONE launch per 24 problems at the
+    end of the pass (k_gemmh_tn32_many): each problem's partials -- and so the reduced gradients -- are bit-identical to its own
+    launch.  30 layers (two launches), ragged widths, row counts from one stage to many chunks, with and without bias."""
+    from dgdm_histopath_lab_amd import ops
+    prev = ops.configure(gemm="f16x2")
+    try:
+        g = torch.Generator().manual_seed(21)
+        widths = [128, 12, 20, 132, 64, 256, 36, 128, 100, 8, 128, 160, 32, 128, 516, 128, 4, 44, 128, 128, 96, 192, 128, 64, 320, 128, 24,
+                  128, 72, 128, 128]
+        for m in (257, 5000):
+            x = torch.randn(m, widths[0], generator=g).to(DEV)
+            ws = [(torch.randn(o, i, generator=g) / i ** 0.5).to(DEV) for i, o in zip(widths[:-1], widths[1:])]
+            bs = [torch.randn(w.size(0), generator=g).to(DEV) if k % 3 else None for k, w in enumerate(ws)]
+
+            def run(deferred):
+                W = [w.clone().requires_grad_(True) for w in ws]
+                Bv = [None if b is None else b.clone().requires_grad_(True) for b in bs]
+                h = x
+                for w, b in zip(W, Bv):
+                    h = ops.linear(h, w, b)
+                loss = h.square().mean()
+                if deferred:
+                    with ops.deferred_weight_grads():
+                        loss.backward()
+                    assert not ops._PENDING_TN
+                else:
+                    loss.backward()
+                return [p.grad for p in W + [b for b in Bv if b is not None]]
+            a, b = run(False), run(True)
+            assert all(torch.equal(u, v) for u, v in zip(a, b))
+            assert all(torch.isfinite(v).all() for v in b) and sum(float(v.abs().max()) > 0 for v in b) > len(b) // 2
+    finally:
+        ops.configure(**prev)
+
+
 def test_posenc_maximum_with_a_partial_last_wave():
     """dgdm_add_posenc with N * C / 4 not a multiple of 64 (an odd node count at C = 128): the last wave is half in range.  The maximum
     in the slot must still be exactly max|out| -- the kernel once ran its amax commit (which holds a workgroup barrier) on both sides

@@ -38,3 +38,16 @@ if len(marks) >= 7:
 print(f"{'kernel':92s} {'calls':>6s} {'avg_us':>9s} {'ms/step':>8s} {'%':>6s}")
 for name, calls, avg_us, ms in rows[:max_rows]:
     print(f"{name[:92]:92s} {calls:6d} {avg_us:9.1f} {ms / steps:8.3f} {100 * ms / total:6.2f}")
+
+# optional 4th argument: a file that receives the launch sequence of the last step (start offset, duration, gap to the previous
+# kernel's end, short name) -- what to read when hunting for chains of short launches worth fusing
+if len(sys.argv) > 4 and len(marks) >= 2:
+    import re
+    t0, t1 = marks[-2], marks[-1]
+    seq = c.execute("select start, end, name from kernels where start >= ? and start < ? order by start", (t0, t1)).fetchall()
+    with open(sys.argv[4], "w") as f:
+        prev_end = seq[0][0]
+        for st, en, name in seq:
+            short = re.sub(r"\(anonymous namespace\)::|void |_ZN12_GLOBAL__N_1\d+", "", name)[:70]
+            f.write(f"{(st - t0) / 1e3:10.1f} {(en - st) / 1e3:8.1f} {(st - prev_end) / 1e3:7.1f}  {short}\n")
+            prev_end = max(prev_end, en)

@@ -8,14 +8,15 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out
 mkdir -p $OUT
 BENCH_PROF="$REPO/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-gather --no-strict"
-python3 bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err || { tail -5 $OUT/${TAG}_bench.err; exit 1; }
-echo "bench done"; cut -c1-400 $OUT/${TAG}_bench.json
+[ -n "$ONLY_TRACE" ] || python3 bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err || { tail -5 $OUT/${TAG}_bench.err; exit 1; }
+[ -n "$ONLY_TRACE" ] || { echo "bench done"; cut -c1-400 $OUT/${TAG}_bench.json; }
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_$TAG && mkdir -p /tmp/prof_$TAG
 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG/trace -o bench -- python3 $BENCH_PROF > $OUT/${TAG}_trace_bench_line.json 2> /tmp/prof_$TAG/trace.err || { tail -5 /tmp/prof_$TAG/trace.err; exit 1; }
 DB=$(find /tmp/prof_$TAG/trace -name "*.db" | head -1)
-python3 $REPO/tools/kernel_stats_from_db.py $DB k_attn_h_bwd_dkv > $OUT/${TAG}_kernel_stats.txt && head -30 $OUT/${TAG}_kernel_stats.txt
+python3 $REPO/tools/kernel_stats_from_db.py $DB k_attn_h_bwd_dkv 400 $OUT/${TAG}_sequence.txt > $OUT/${TAG}_kernel_stats.txt && head -30 $OUT/${TAG}_kernel_stats.txt
 echo "trace done"
+[ -n "$ONLY_TRACE" ] && exit 0      # ONLY_TRACE=1: no PMC passes
 PMCB="$REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-gather --no-strict"
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE \
    --kernel-trace --output-format csv -d /tmp/prof_$TAG/valu -- python3 $PMCB > /dev/null 2> /tmp/prof_$TAG/valu.err || { tail -5 /tmp/prof_$TAG/valu.err; exit 1; }
