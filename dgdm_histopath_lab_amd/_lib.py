@@ -43,6 +43,7 @@ SIGNATURES = {
     "dgdm_spatial_attn_mean_weights": (C.c_int, [_p, _p, _i64, _p, _p, _i32, _i32, _i32, _i32, C.c_float, C.c_float, _p, _p, _p, _p]),
     "dgdm_rownorm_fwd": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, C.c_float, _i32, C.c_float, C.c_uint32, _p, _p, _p, _p, _p]),
     "dgdm_rownorm_bwd_workspace_bytes": (_sz, [_i32, _i32, _i32]),
+    "dgdm_rownorm_bwd_slots": (_i64, [_i32, _i32, _i32]),
     "dgdm_rownorm_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, C.c_float, C.c_uint32, _p, _p, _p, _p, _sz, _p, _p]),
     "dgdm_act_dropout_fwd": (C.c_int, [_p, _i64, _i32, C.c_float, C.c_uint32, _p, _p, _p, _p]),
     "dgdm_act_dropout_bwd": (C.c_int, [_p, _p, _i64, _i32, C.c_float, C.c_uint32, _p, _p, _p, _p]),

@@ -77,7 +77,8 @@ extern "C" int dgdm_gemm_tn_reduce_many(const DgdmTnReduce* descs, int32_t count
     const DgdmTnReduce& d = descs[i];
     if (!d.partial || d.slots <= 0 || d.N <= 0 || d.K <= 0 || d.K0 < 0 || d.K0 > d.K || (d.K0 > 0 && !d.dW0) || (d.K0 < d.K && !d.dW1))
       return DGDM_ERR_INVALID_ARG;
-    if ((d.N & 3) || (d.K & 3) || (d.K0 & 3) || !dgdm_aligned16(d.partial)) return DGDM_ERR_UNSUPPORTED;   // what the dW GEMMs require anyway
+    // what the dW GEMMs require anyway; N only counts through the bias columns behind the N*K block
+    if ((d.K & 3) || (d.K0 & 3) || (d.db && (d.N & 3)) || !dgdm_aligned16(d.partial)) return DGDM_ERR_UNSUPPORTED;
     b.d[i] = d;
     b.first_block[i] = blocks;
     const int64_t width = (int64_t)d.N * d.K + (d.db ? d.N : 0);

@@ -308,6 +308,12 @@ extern "C" size_t dgdm_rownorm_bwd_workspace_bytes(int32_t N, int32_t C, int32_t
   return (size_t)(bwd_slots(ng, G, geo) + REDUCE_CHUNKS + 1) * 2 * C * sizeof(float);  // partials + stage-1 sums + ticket row
 }
 
+extern "C" int64_t dgdm_rownorm_bwd_slots(int32_t N, int32_t C, int32_t G) {
+  Geo geo;
+  if (N <= 0 || C <= 0 || G <= 0 || C % G || !geometry(C / G, &geo)) return 0;
+  return bwd_slots(bwd_lane_groups((int64_t)N * G, G, geo), G, geo);
+}
+
 extern "C" int dgdm_rownorm_bwd(const float* x, const float* res, const float* gamma, const float* beta, const float* mean,
                                 const float* rstd, const float* dy, int32_t N, int32_t C, int32_t G, int32_t act, float drop_p,
                                 uint32_t seed, float* dx, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
@@ -320,7 +326,8 @@ extern "C" int dgdm_rownorm_bwd(const float* x, const float* res, const float* g
     if (dbeta) dgdm_fill_async(dbeta, 0, sizeof(float) * C, s);
     return dgdm_launch_status();
   }
-  DGDM_REQUIRE(mean && rstd && dy && dx && dgamma && dbeta && workspace);
+  DGDM_REQUIRE(mean && rstd && dy && dx && workspace);
+  if (!dgamma != !dbeta) return DGDM_ERR_INVALID_ARG;      // both, or neither (the caller reduces the partials: dgdm_rownorm_bwd_slots)
   Geo geo;
   if (!geometry(C / G, &geo)) return DGDM_ERR_UNSUPPORTED;
   if (!dgdm_aligned16(x) || !dgdm_aligned16(dy) || !dgdm_aligned16(dx) || (res && !dgdm_aligned16(res)) ||
@@ -346,6 +353,7 @@ extern "C" int dgdm_rownorm_bwd(const float* x, const float* res, const float* g
   if (ntickets > 256) return DGDM_ERR_UNSUPPORTED;
   ROWNORM_DISPATCH(BWD, x, res, gamma, beta, mean, rstd, dy, rows, L, G, drop_p, dgdm_seed_arg(seed), dx, partial, C, tickets, ntickets, block_slots, amax);
 #undef BWD
+  if (!dgamma) return dgdm_launch_status();
   const int64_t chunk = (slots + REDUCE_CHUNKS - 1) / REDUCE_CHUNKS;
   const int nch = (int)((slots + chunk - 1) / chunk);
   hipLaunchKernelGGL(k_colsum_ticket<REDUCE_CHUNKS>, dim3(ntickets, nch), dim3(256), 0, s, partial, slots, 2 * C, chunk, stage1, tickets, dgamma, C, dbeta);

@@ -502,6 +502,7 @@ class _RowNorm(torch.autograd.Function):
                    "dgdm_rownorm_fwd")
         ctx.save_for_backward(x, res, gamma, beta, mean, rstd)
         ctx.meta = (groups, act, drop_p, seed)
+        ctx.leaf = gamma.is_leaf and beta.is_leaf
         return tag_amax(y, slot)
 
     @staticmethod
@@ -516,9 +517,18 @@ class _RowNorm(torch.autograd.Function):
         wsb = _lib.workspace_bytes("dgdm_rownorm_bwd_workspace_bytes", N, C, groups)
         ws = torch.empty(max(wsb, 4) // 4, dtype=torch.float32, device=x.device)
         slot = new_amax_slot(x.device)
+        # inside deferred_weight_grads(): the column sums of the row partials (dgamma | dbeta) join the pass's one reduction launch
+        # (as a [1, 2C] "weight gradient" split at C) instead of a launch of their own behind every norm
+        later = False
+        if _DEFER_TN and ctx.leaf and N > 0 and C % 4 == 0:
+            slots = int(_lib.workspace_bytes("dgdm_rownorm_bwd_slots", N, C, groups))       # (memoised call, not a byte count)
+            alias = lambda t: t.detach()
+            later = slots > 0 and _defer_tn((ws.data_ptr(), dg.data_ptr(), db.data_ptr(), None, C, C, slots, 1, 2 * C, C),
+                                            (ws, alias(dg), alias(db)), _lib.stream_ptr(x.device))
         _lib.check(lib.dgdm_rownorm_bwd(x.data_ptr(), _lib.ptr(res), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(),
                                         rstd.data_ptr(), gy.data_ptr(), N, C, groups, act, drop_p, seed, dx.data_ptr(),
-                                        dg.data_ptr(), db.data_ptr(), ws.data_ptr(), wsb, slot, _lib.stream_ptr(x.device)),
+                                        None if later else dg.data_ptr(), None if later else db.data_ptr(), ws.data_ptr(), wsb, slot,
+                                        _lib.stream_ptr(x.device)),
                    "dgdm_rownorm_bwd")
         tag_amax(dx, slot)
         return dx, (dx if res is not None else None), dg, db, None, None, None, None, None

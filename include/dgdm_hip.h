@@ -273,6 +273,10 @@ DGDM_API int dgdm_rownorm_fwd(const float* x, const float* res, const float* gam
                               int32_t G, float eps, int32_t act, float drop_p, uint32_t seed, float* y, float* mean,
                               float* rstd, uint32_t* amax, void* stream);
 DGDM_API size_t dgdm_rownorm_bwd_workspace_bytes(int32_t N, int32_t C, int32_t G);
+/* dgamma == dbeta == NULL: only the row partials are written -- `workspace` then starts with [dgdm_rownorm_bwd_slots(N,C,G)][2C]
+ * floats whose column sums are dgamma | dbeta, for the caller to reduce later (dgdm_gemm_tn_reduce_many with N = 1, K = 2C,
+ * K0 = C takes them in the same launch as a backward pass's weight gradients). */
+DGDM_API int64_t dgdm_rownorm_bwd_slots(int32_t N, int32_t C, int32_t G);
 DGDM_API int dgdm_rownorm_bwd(const float* x, const float* res, const float* gamma, const float* beta, const float* mean,
                               const float* rstd, const float* dy, int32_t N, int32_t C, int32_t G, int32_t act, float drop_p,
                               uint32_t seed, float* dx, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,

@@ -154,3 +154,32 @@ def test_seed_epoch_changes_dropout_masks_and_zero_is_identity():
         assert torch.equal(fwd(), y0)
     finally:
         _lib.check(lib.dgdm_seed_epoch_set(0, st), "set")
+
+
+@pytest.mark.parametrize("n,c,groups", [(5000, 512, 1), (40000, 128, 1), (3000, 128, 8), (257, 768, 1)])
+def test_deferred_norm_parameter_gradients(n, c, groups):
+    """Inside ops.deferred_weight_grads() the column sums behind dgamma / dbeta run in the pass's one reduction launch
+    (dgdm_gemm_tn_reduce_many on the row partials) instead of a launch behind every norm: the same partials in another fixed
+    order -- equal to rounding, and repeatable bit for bit."""
+    from dgdm_histopath_lab_amd import ops
+    g = torch.Generator().manual_seed(n + c)
+    x = torch.randn(n, c, generator=g).to(DEV)
+    gy = torch.randn(n, c, generator=g).to(DEV)
+    w0, b0 = (1 + 0.1 * torch.randn(c, generator=g)).to(DEV), (0.1 * torch.randn(c, generator=g)).to(DEV)
+
+    def run(deferred):
+        w, b = w0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+        xx = x.clone().requires_grad_(True)
+        y = ops.row_norm(xx, w, b, groups=groups, act=ops.ACT_GELU)
+        if deferred:
+            with ops.deferred_weight_grads():
+                y.backward(gy)
+            assert not ops._PENDING_TN
+        else:
+            y.backward(gy)
+        return xx.grad, w.grad, b.grad
+    a, b1, b2 = run(False), run(True), run(True)
+    assert torch.equal(a[0], b1[0])
+    for u, v in zip(a[1:], b1[1:]):
+        assert float((u - v).abs().max()) <= 2e-6 * float(u.abs().max()) + 1e-7
+    assert all(torch.equal(u, v) for u, v in zip(b1, b2))
