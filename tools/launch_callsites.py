@@ -1,6 +1,6 @@
 """Which Python call sites launch the per-step small kernels (image_build_one, amax_bits, torch fills / copies / cats)?"""
 import collections, os, sys, traceback, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dgdm_histopath_lab_amd import DGDMModel, ops, _lib
 from dgdm_histopath_lab_amd.parallel import BalancedSlideLoader
 from dgdm_histopath_lab_amd.synthetic import synthetic_graph
