@@ -6,7 +6,6 @@ ctypes; tensors only provide device memory.  No CPU path exists.
 from __future__ import annotations
 
 import collections
-import os
 from typing import Optional
 
 import torch
@@ -1234,7 +1233,7 @@ def _defer_tn(desc, keep, stream, partial=None) -> bool:
 
 # A dW GEMM whose own grid has at most this many workgroups (row chunks x 128 x 128 tiles) is start-up bound as a launch of its
 # own: inside ``deferred_weight_grads()`` it is held back and runs in the many-problem launch at the end of the pass.
-TN_GROUP_MAX_BLOCKS = int(os.environ.get("DGDM_TN_GROUP_MAX_BLOCKS", "1000"))
+TN_GROUP_MAX_BLOCKS = 1000
 
 
 def gemm_tn_raw(dy, x, with_bias: bool, math="fp32", split: Optional[int] = None, out: Optional[torch.Tensor] = None,
