@@ -154,10 +154,18 @@ def projection_microbench(dev, iters=50):
     y = torch.empty(m, n, device=dev)
     for _ in range(5):
         ops.gemm_nt_raw(x, w, b, out=y, math=math)
+    # as in the step: the launches are recorded into a HIP graph and replayed (through the Python wrapper a launch costs ~15 us of
+    # host time, more than the device needs between two of these kernels)
+    ops.WEIGHT_IMAGES.prepare(torch.device(dev))
+    g = torch.cuda.CUDAGraph()
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g):
+        for _ in range(iters):
+            ops.gemm_nt_raw(x, w, b, out=y, math=math)
+    g.replay()
     a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(); a.record()
-    for _ in range(iters):
-        ops.gemm_nt_raw(x, w, b, out=y, math=math)
+    g.replay()
     e.record(); torch.cuda.synchronize()
     us = a.elapsed_time(e) * 1e3 / iters
     fl = 2.0 * m * k * n
@@ -172,7 +180,7 @@ def projection_microbench(dev, iters=50):
     peak = FP32_MFMA_PEAK_TFLOPS if math == "fp32" else FP16_MFMA_PEAK_TFLOPS      # bf16 and f16 dense peaks are equal
     out = {"kernel": info[0], "workload": f"[{m}, {k}] x [{n}, {k}]^T + bias", "bound": "mfma", "achieved": round(tf, 1), "peak": peak,
            "unit": "TFLOP/s", "frac": round(tf / peak, 4), "us_per_launch": round(us, 1), "algorithmic_flop": fl, "pipe": info[1],
-           "traffic": None}   # the committed PMC pass averages this kernel over all shapes of a step: not comparable per launch
+           "timed_with": f"HIP events around one replay of a HIP graph of {iters} launches", "traffic": None}   # the committed PMC pass averages this kernel over all shapes of a step: not comparable per launch
     if math != "fp32":
         out.update({"mfma_dtype": info[2], "issued_tflops": round(info[3] * tf, 1), "issued_frac": round(info[3] * tf / peak, 4),
                     "fp32_equivalent_frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4)})
