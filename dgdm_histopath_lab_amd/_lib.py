@@ -110,6 +110,7 @@ SIGNATURES = {
     "dgdm_gemm_tn_partial_f16x2": (C.c_int, [_p, _i64, _p, _i64, _i32, _i32, _i32, _i32, _p, _sz, _p, _p, _p]),
     "dgdm_gemm_tn_reduce_many": (C.c_int, [_p, _i32, _p]),
     "dgdm_gemm_tn_partial_many_f16x2": (C.c_int, [_p, _i32, _p]),
+    "dgdm_gemm_tn_chunks_grouped": (_i32, [_i32, _i32, _i32]),
     "dgdm_attn_pack_bytes": (_sz, [_i32, _i32, _i32]),
     "dgdm_amax_scale_workspace_bytes": (_sz, []),
     "dgdm_amax_pow2_scale": (C.c_int, [_p, _i64, C.c_float, _p, _p, _sz, _p]),

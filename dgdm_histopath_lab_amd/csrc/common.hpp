@@ -91,6 +91,18 @@ __device__ __forceinline__ void dgdm_amax_commit(unsigned m, unsigned* __restric
 // step counter ("seed epoch") that lives in device memory and is advanced by a kernel of its own
 // (dgdm_seed_epoch_advance, once per training step, before the forward).  Epoch 0 (the default, and the
 // only value outside graph replay) leaves the seed unchanged.
+// Workgroups a split-M dW GEMM aims for (row chunks x 128 x 128 tiles): ~2 per CU, all resident in one round, when the problem
+// runs alone (gemm3.hip, gemm_h.hip: the same rule, dgdm_gemm_tn_chunks reports it).
+#ifndef DGDM_TN_WANT
+#define DGDM_TN_WANT 496
+#endif
+// ... and inside a many-problem launch (dgdm_gemm_tn_partial_many_f16x2), where two dozen problems fill the chip together: fewer,
+// longer chunks -- a quarter of the partial sums to write and to reduce (same-box sweep 496 / 248 / 124 / 62 / 31:
+// 278.9 / 281.5 / 283.2 = 300.2 / 300.8 / 277.0 slides/s).
+#ifndef DGDM_TN_WANT_GROUPED
+#define DGDM_TN_WANT_GROUPED 96
+#endif
+
 struct DgdmSeed {
   uint32_t base;
   const uint32_t* epoch;

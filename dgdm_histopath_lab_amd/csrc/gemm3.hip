@@ -453,7 +453,7 @@ constexpr int LDS_BYTES = 2 * STAGE;   // 73728: above the 64 KiB static limit, 
 
 int tn3_chunk_rows(int M, int N, int K) {
   const int tiles = ((N + BM - 1) / BM) * ((K + BN - 1) / BN);
-  int want = (496 + tiles / 2) / tiles;   // ~2 workgroups per CU, all resident in one round
+  int want = (DGDM_TN_WANT + tiles / 2) / tiles;   // workgroups per problem: see common.hpp
   if (want < 1) want = 1;
   if (want > 256) want = 256;
   int chunk = (M + want - 1) / want;

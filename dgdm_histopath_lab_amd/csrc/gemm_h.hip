@@ -634,9 +634,9 @@ __global__ __launch_bounds__(256) void k_gemmh_tn_final(const float* __restrict_
 
 constexpr int LDS_BYTES = 2 * STAGE;   // 49152
 
-int tnh_chunk_rows(int M, int N, int K) {
+int tnh_chunk_rows(int M, int N, int K, int want_total = DGDM_TN_WANT) {
   const int tiles = ((N + BM - 1) / BM) * ((K + BN - 1) / BN);
-  int want = (496 + tiles / 2) / tiles;   // ~2 workgroups per CU, all resident in one round
+  int want = (want_total + tiles / 2) / tiles;   // workgroups per problem: see common.hpp
   if (want < 1) want = 1;
   if (want > 256) want = 256;
   int chunk = (M + want - 1) / want;
@@ -775,6 +775,13 @@ extern "C" int dgdm_gemm_tn_partial_f16x2(const float* dY, int64_t ldy, const fl
                  stream, true);
 }
 
+// row chunks (= partial slots) of one problem inside dgdm_gemm_tn_partial_many_f16x2
+extern "C" int32_t dgdm_gemm_tn_chunks_grouped(int32_t M, int32_t N, int32_t K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  const int chunk = tnh_chunk_rows(M, N, K, DGDM_TN_WANT_GROUPED);
+  return (M + chunk - 1) / chunk;
+}
+
 extern "C" int dgdm_gemm_tn_partial_many_f16x2(const DgdmTnPartial* descs, int32_t count, void* stream) {
   if (count < 0 || count > DGDM_TN_PARTIAL_MAX || (count && !descs)) return DGDM_ERR_INVALID_ARG;
   if (count == 0) return DGDM_OK;
@@ -785,7 +792,7 @@ extern "C" int dgdm_gemm_tn_partial_many_f16x2(const DgdmTnPartial* descs, int32
     if (d.M <= 0 || d.N <= 0 || d.K <= 0 || !d.dY || !d.X || !d.workspace || bad_amax(d.amax_dy, d.amax_x)) return DGDM_ERR_INVALID_ARG;
     if ((d.ldy & 3) || (d.ldx & 3) || (d.N & 3) || (d.K & 3) || d.ldy < d.N || d.ldx < d.K || !dgdm_aligned16(d.dY) || !dgdm_aligned16(d.X))
       return DGDM_ERR_UNSUPPORTED;
-    const int chunk = tnh_chunk_rows(d.M, d.N, d.K);
+    const int chunk = tnh_chunk_rows(d.M, d.N, d.K, DGDM_TN_WANT_GROUPED);     // the problems fill the chip TOGETHER
     const int nchunks = (d.M + chunk - 1) / chunk;
     const int64_t width = (int64_t)d.N * d.K + (d.with_bias ? d.N : 0);
     if (width > 0x7fffffffLL) return DGDM_ERR_UNSUPPORTED;

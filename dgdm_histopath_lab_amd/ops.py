@@ -1202,8 +1202,11 @@ def flush_deferred_tn() -> None:
     for desc, keep, stream, partial in pend:
         by_stream.setdefault(stream, []).append(desc)
         if partial is not None:
-            small.setdefault(stream, []).append(partial)
+            small.setdefault(stream, []).append((-(partial[8] // max(1, desc[6])), len(small.get(stream, ())), partial))
     for stream, parts in small.items():       # the partial GEMMs that were held back: up to TN_PARTIAL_MAX problems per launch
+        # longest workgroups first (rows per chunk = M / slots): the backward meets the largest layers LAST, and a launch that
+        # starts its longest workgroups last ends in a tail of a few of them
+        parts = [t[2] for t in sorted(parts)] if TN_GROUP_SORT else [t[2] for t in parts]
         for i in range(0, len(parts), _lib.TN_PARTIAL_MAX):
             part = parts[i:i + _lib.TN_PARTIAL_MAX]
             arr = (_lib.TnPartial * len(part))()
@@ -1231,9 +1234,11 @@ def _defer_tn(desc, keep, stream, partial=None) -> bool:
     return True
 
 
-# A dW GEMM whose own grid has at most this many workgroups (row chunks x 128 x 128 tiles) is start-up bound as a launch of its
-# own: inside ``deferred_weight_grads()`` it is held back and runs in the many-problem launch at the end of the pass.
-TN_GROUP_MAX_BLOCKS = 1000
+# Inside ``deferred_weight_grads()`` the fp16 hi+lo dW GEMMs themselves are held back and run in the many-problem launches at the
+# end of the pass (24 problems per launch, each cut into fewer and longer row chunks than a launch of its own would use: the
+# gradients equal the immediate ones up to fp32 summation order, and are repeatable bit for bit).  False: one launch per GEMM.
+TN_GROUPED = True
+TN_GROUP_SORT = True
 
 
 def gemm_tn_raw(dy, x, with_bias: bool, math="fp32", split: Optional[int] = None, out: Optional[torch.Tensor] = None,
@@ -1249,10 +1254,16 @@ def gemm_tn_raw(dy, x, with_bias: bool, math="fp32", split: Optional[int] = None
     M, N = dy.shape
     K = x.size(1)
     db = torch.empty(N, dtype=torch.float32, device=x.device) if with_bias else None
-    wsb = _lib.workspace_bytes("dgdm_gemm_tn_workspace_bytes" if math == "fp32" else f"dgdm_gemm_tn_{math}_workspace_bytes", M, N, K, int(with_bias))
-    ws = torch.empty(max(wsb, 4) // 4, dtype=torch.float32, device=x.device)
     extra = (ensure_amax(dy), ensure_amax(x)) if math == "f16x2" else ()
-    if _DEFER_TN and may_defer and math in ("bf16x3", "f16x2") and M > 0:
+    defer = _DEFER_TN and may_defer and math in ("bf16x3", "f16x2") and M > 0
+    grouped = defer and math == "f16x2" and TN_GROUPED
+    if grouped:     # part of the pass's many-problem launch: its own (coarser) chunking, see dgdm_gemm_tn_partial_many_f16x2
+        slots = _lib.workspace_bytes("dgdm_gemm_tn_chunks_grouped", M, N, K)
+        wsb = slots * (N * K + (N if with_bias else 0)) * 4
+    else:
+        wsb = _lib.workspace_bytes("dgdm_gemm_tn_workspace_bytes" if math == "fp32" else f"dgdm_gemm_tn_{math}_workspace_bytes", M, N, K, int(with_bias))
+    ws = torch.empty(max(wsb, 4) // 4, dtype=torch.float32, device=x.device)
+    if defer:
         if split is None:
             dW = torch.empty(N, K, dtype=torch.float32, device=x.device) if out is None else out
             d0, d1, k0 = dW, None, K
@@ -1262,16 +1273,20 @@ def gemm_tn_raw(dy, x, with_bias: bool, math="fp32", split: Optional[int] = None
             d0 = torch.empty(N, split, dtype=torch.float32, device=x.device)
             d1 = torch.empty(N, K - split, dtype=torch.float32, device=x.device)
             k0 = split
-        slots = lib.dgdm_gemm_tn_chunks(M, N, K)
+        if not grouped:
+            slots = lib.dgdm_gemm_tn_chunks(M, N, K)
         desc = (ws.data_ptr(), d0.data_ptr(), _lib.ptr(d1), _lib.ptr(db), d0.stride(0), d1.stride(0) if d1 is not None else 0, slots, N, K, k0)
         # keep-alive ALIASES of the outputs (same storage, other tensor objects): holding d0 itself would raise its reference count and
         # make the engine's AccumulateGrad CLONE it -- a copy of memory this launch has not filled yet -- instead of adopting it
         alias = lambda t: None if t is None else t.detach()
         keep = (ws, alias(d0), alias(d1), alias(db), dy, x)
-        if math == "f16x2" and slots * ((N + 127) // 128) * ((K + 127) // 128) <= TN_GROUP_MAX_BLOCKS:
+        if grouped:
             partial = (dy.data_ptr(), x.data_ptr(), ws.data_ptr(), extra[0], extra[1], dy.stride(0), x.stride(0), wsb, M, N, K, int(with_bias))
             if _defer_tn(desc, keep, _lib.stream_ptr(x.device), partial):
                 return (d0 if split is None else (d0, d1)), db
+            # no backward pass is running: the immediate launch below, with the workspace of its own chunking
+            wsb = _lib.workspace_bytes(f"dgdm_gemm_tn_{math}_workspace_bytes", M, N, K, int(with_bias))
+            ws = torch.empty(max(wsb, 4) // 4, dtype=torch.float32, device=x.device)
         elif _defer_tn(desc, keep, _lib.stream_ptr(x.device)):
             fn = getattr(lib, "dgdm_gemm_tn_partial_" + math)
             TIMERS.timed("gemm_tn", lambda: _lib.check(

@@ -499,9 +499,12 @@ DGDM_API int dgdm_gemm_tn_partial_f16x2(const float* dY, int64_t ldy, const floa
                                         int32_t N, int32_t K, void* workspace, size_t workspace_bytes, const uint32_t* amax_dy,
                                         const uint32_t* amax_x, void* stream);
 DGDM_API int dgdm_gemm_tn_reduce_many(const DgdmTnReduce* descs, int32_t count, void* stream);
-/* Up to DGDM_TN_PARTIAL_MAX dgdm_gemm_tn_partial_f16x2 calls as ONE launch (the dW GEMMs of small layers are start-up bound as
- * launches of their own).  `descs` is a HOST array; each entry has the arguments of the single call (M, N, K > 0) and fills its
- * workspace bit-identically to it. */
+/* Up to DGDM_TN_PARTIAL_MAX weight-gradient GEMMs as ONE launch (the dW GEMMs of small layers are start-up bound as launches of
+ * their own, and two dozen problems fill the chip together, so each is cut into fewer, longer row chunks than a launch of its own
+ * would be).  `descs` is a HOST array; each entry has the arguments of dgdm_gemm_tn_partial_f16x2 (M, N, K > 0) and leaves
+ * [dgdm_gemm_tn_chunks_grouped(M,N,K)][N*K (+N when with_bias)] floats in its workspace for dgdm_gemm_tn_reduce_many (slots =
+ * that chunk count).  Fixed summation order: repeatable bit for bit; equal to the single launch up to fp32 rounding (other chunk
+ * boundaries). */
 #define DGDM_TN_PARTIAL_MAX 24
 typedef struct DgdmTnPartial {
   const float* dY;
@@ -513,6 +516,7 @@ typedef struct DgdmTnPartial {
   size_t workspace_bytes;
   int32_t M, N, K, with_bias;
 } DgdmTnPartial;
+DGDM_API int32_t dgdm_gemm_tn_chunks_grouped(int32_t M, int32_t N, int32_t K);
 DGDM_API int dgdm_gemm_tn_partial_many_f16x2(const DgdmTnPartial* descs, int32_t count, void* stream);
 
 

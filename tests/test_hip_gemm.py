@@ -188,10 +188,11 @@ def test_producer_kernels_keep_the_operand_maximum():
         ops.configure(**prev)
 
 
-def test_many_problem_dw_launch_is_bitwise_the_single_launches():
-    """Inside ops.deferred_weight_grads() the dW GEMMs with small grids are held back and run as ONE launch per 24 problems at the
-    end of the pass (k_gemmh_tn32_many): each problem's partials -- and so the reduced gradients -- are bit-identical to its own
-    launch.  30 layers (two launches), ragged widths, row counts from one stage to many chunks, with and without bias."""
+def test_many_problem_dw_launch_against_the_single_launches():
+    """Inside ops.deferred_weight_grads() the fp16 hi+lo dW GEMMs are held back and run as ONE launch per 24 problems at the end of
+    the pass (k_gemmh_tn32_many, its own row chunking): the gradients equal those of the single launches up to the fp32 summation
+    order and are repeatable bit for bit.  30 layers (two launches), ragged widths, row counts from one stage to many chunks,
+    with and without bias."""
     from dgdm_histopath_lab_amd import ops
     prev = ops.configure(gemm="f16x2")
     try:
@@ -217,8 +218,10 @@ def test_many_problem_dw_launch_is_bitwise_the_single_launches():
                 else:
                     loss.backward()
                 return [p.grad for p in W + [b for b in Bv if b is not None]]
-            a, b = run(False), run(True)
-            assert all(torch.equal(u, v) for u, v in zip(a, b))
+            a, b, b2 = run(False), run(True), run(True)
+            for u, v in zip(a, b):
+                assert float((u - v).abs().max()) <= 4e-6 * float(u.abs().max()) + 1e-12
+            assert all(torch.equal(u, v) for u, v in zip(b, b2))
             assert all(torch.isfinite(v).all() for v in b) and sum(float(v.abs().max()) > 0 for v in b) > len(b) // 2
     finally:
         ops.configure(**prev)
@@ -254,8 +257,10 @@ def test_posenc_maximum_with_a_partial_last_wave():
 @pytest.mark.parametrize("math", ["bf16x3", "f16x2"])
 def test_deferred_weight_gradient_reduction_is_bitwise_the_immediate_one(math):
     """Inside ops.deferred_weight_grads() the dW GEMMs of a backward pass leave their chunk partials and ONE launch reduces them
-    when the pass ends (csrc/dw_reduce.hip): same sums in the same order -- weight and bias gradients are bit-identical, for few
-    and for many chunks, for the split form (two parameters behind one contraction) and for an output that is a column block."""
+    when the pass ends (csrc/dw_reduce.hip), for few and for many chunks, for the split form (two parameters behind one
+    contraction) and for an output that is a column block.  bf16x3: same sums in the same order -- bit-identical to the immediate
+    reduction.  f16x2: the GEMMs themselves run in the pass's many-problem launches with a coarser row chunking -- equal up to the
+    fp32 summation order, and repeatable bit for bit."""
     from dgdm_histopath_lab_amd import GraphStructure, ops
     prev = ops.configure(gemm=math)
     try:
@@ -283,7 +288,12 @@ def test_deferred_weight_gradient_reduction_is_bitwise_the_immediate_one(math):
                 loss.backward()
             return [p.grad for p in params]
         a, b = run(False), run(True)
-        assert all(torch.equal(u, v) for u, v in zip(a, b))
+        if math == "bf16x3":
+            assert all(torch.equal(u, v) for u, v in zip(a, b))
+        else:
+            for u, v in zip(a, b):
+                assert float((u - v).abs().max()) <= 4e-6 * float(u.abs().max()) + 1e-12
+            assert all(torch.equal(u, v) for u, v in zip(b, run(True)))
         assert all(torch.isfinite(v).all() and v.abs().max() > 0 for v in b)
     finally:
         ops.configure(**prev)

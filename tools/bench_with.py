@@ -1,5 +1,5 @@
 """Run bench.py with module attributes of dgdm_histopath_lab_amd.ops overridden first (same-box A/B of a switch that is not an
-environment variable):  python tools/bench_with.py FUSE_ACT_INTO_CONV=False TN_GROUP_MAX_BLOCKS=0 -- --no-cpu-baseline --no-strict"""
+environment variable):  python tools/bench_with.py TN_GROUPED=False TN_GROUP_SORT=False -- --no-cpu-baseline --no-strict"""
 import ast, os, runpy, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
