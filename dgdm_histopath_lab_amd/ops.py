@@ -1189,7 +1189,7 @@ class deferred_weight_grads:
 
 
 def flush_deferred_tn() -> None:
-    """Reduce every pending dW GEMM's partials (fixed order, bitwise the immediate reduction)."""
+    """Run the held-back dW GEMMs (many-problem launches) and reduce every pending GEMM's chunk partials, all in fixed order."""
     if not _PENDING_TN:
         return
     lib = _lib.load()
