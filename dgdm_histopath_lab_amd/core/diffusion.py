@@ -193,19 +193,26 @@ class DiffusionLayer(nn.Module):
             import gc
             gc_was = gc.isenabled()
             gc.disable()      # no cyclic collection inside the capture (it could destroy another recording: illegal during capture)
+            # the recording must rebuild the weight images it reads (the warm-up above built them, a plain capture would find them
+            # fresh and record no build: replays after an optimizer step / load_state_dict would then run on old weights), and the
+            # operand-maximum slots it takes must start on a chunk boundary so that every replay re-zeroes them
+            ops.weights_changed()
+            ops.begin_amax_recording()
             try:
                 with ops.collect_device_constants() as held, torch.cuda.graph(g):
                     out = self._sample_loop(sx, ts, sz)
             finally:
+                amax_rec = ops.end_amax_recording()
                 if gc_was:
                     gc.enable()
-            cache[key] = (g, sx, sz, out, held)
-        g, sx, sz, out, _ = cache[key]
+            cache[key] = (g, sx, sz, out, held, amax_rec)
+        g, sx, sz, out, _, amax_rec = cache[key]
         sx.copy_(x)
         if sz is not None:
             for dst, src in zip(sz, step_noise):
                 dst.copy_(src)
         g.replay()
+        ops.amax_recording_replayed(amax_rec)
         return out.clone()
 
     def _sample_loop(self, x: Tensor, ts: List[int], step_noise: Optional[List[Tensor]]) -> Tensor:

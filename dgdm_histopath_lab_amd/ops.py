@@ -502,6 +502,7 @@ class _RowNorm(torch.autograd.Function):
         ctx.save_for_backward(x, res, gamma, beta, mean, rstd)
         ctx.meta = (groups, act, drop_p, seed)
         ctx.leaf = gamma.is_leaf and beta.is_leaf
+        ctx.gb = (gamma, beta) if ctx.leaf else None      # the parameter objects themselves (see _claim_deferred)
         return tag_amax(y, slot)
 
     @staticmethod
@@ -519,7 +520,7 @@ class _RowNorm(torch.autograd.Function):
         # inside deferred_weight_grads(): the column sums of the row partials (dgamma | dbeta) join the pass's one reduction launch
         # (as a [1, 2C] "weight gradient" split at C) instead of a launch of their own behind every norm
         later = False
-        if _DEFER_TN and ctx.leaf and N > 0 and C % 4 == 0:
+        if _DEFER_TN and ctx.leaf and N > 0 and C % 4 == 0 and _claim_deferred(*ctx.gb):
             slots = int(_lib.workspace_bytes("dgdm_rownorm_bwd_slots", N, C, groups))       # (memoised call, not a byte count)
             alias = lambda t: t.detach()
             later = slots > 0 and _defer_tn((ws.data_ptr(), dg.data_ptr(), db.data_ptr(), None, C, C, slots, 1, 2 * C, C),
@@ -789,11 +790,15 @@ def attn_pool(kv, q_scaled, plan: AttnPlan, H: int, D: int, drop_p: float = 0.0,
 
 # ----------------------------------------------------------------------------- operand maxima for the fp16 hi+lo GEMMs
 class AmaxArena:
-    """Device slots holding the float bits of max|x| of GEMM operands (csrc/gemm_h.hip).  A ring of uint32 slots, zeroed chunk by
-    chunk as the bump pointer enters a chunk (one fill launch per CHUNK slots, also recorded by a graph capture at the same
-    position, so a replay re-zeroes exactly the slots it refills).  A slot's content is valid from the kernel that fills it to the
-    end of the training step that allocated it; the ring is far longer (SLOTS) than the ~300 slots a step takes, so a pending
-    backward never meets a recycled slot."""
+    """Device slots holding the float bits of max|x| of GEMM operands (csrc/gemm_h.hip).  A ring of uint32 slot groups, zeroed
+    chunk by chunk as the bump pointer enters a chunk (one fill launch per CHUNK groups, also recorded by a graph capture at the
+    same position, so a replay re-zeroes exactly the slots it refills).
+
+    Lifetime of a slot's content: from the kernel that fills it until the ring comes round and the slot's CHUNK is zeroed again
+    (SLOTS takes later; a step takes ~300).  Every chunk carries a generation counter (``chunk_gen``) bumped by each fill; a tag
+    or a saved handle records the generation it was made under and is dead once the chunk has been refilled -- a long-lived
+    tensor (a device-resident input reused over epochs) then falls back to a reduction launch instead of scaling by whatever
+    the recycled slot holds now."""
 
     SLOTS, CHUNK = 1 << 12, 1 << 6          # slot groups in the ring / groups zeroed per fill launch
     GROUP_WORDS = 32 * 64                   # DGDM_AMAX_WAYS * DGDM_AMAX_STRIDE (include/dgdm_hip.h): 8 KiB per slot group
@@ -802,6 +807,10 @@ class AmaxArena:
         self.buf = torch.zeros(self.SLOTS * self.GROUP_WORDS, dtype=torch.int32, device=device)     # 32 MiB
         self.next = 0
         self.base = self.buf.data_ptr()
+        self.end = self.base + 4 * self.SLOTS * self.GROUP_WORDS
+        self.chunk_gen = [0] * (self.SLOTS // self.CHUNK)
+        self.total_takes = 0
+        self.recording: Optional[set] = None    # chunks entered while a stream capture records (begin_amax_recording)
 
     def take(self) -> int:
         """Address of a zeroed slot group."""
@@ -809,8 +818,24 @@ class AmaxArena:
         if i % self.CHUNK == 0:
             _lib.check(_lib.load().dgdm_fill_u32(self.base + 4 * i * self.GROUP_WORDS, self.CHUNK * self.GROUP_WORDS, 0,
                                                  _lib.stream_ptr(self.buf.device)), "dgdm_fill_u32")
+            self.chunk_gen[i // self.CHUNK] += 1
+        if self.recording is not None:
+            self.recording.add(i // self.CHUNK)
         self.next = (i + 1) % self.SLOTS
+        self.total_takes += 1
         return self.base + 4 * i * self.GROUP_WORDS
+
+    def align(self) -> None:
+        """Advance to the next chunk boundary: the next ``take`` issues (and a capture records) the fill of its chunk.  Called
+        before every stream capture -- the slots a recording takes before its first boundary would otherwise never be re-zeroed by
+        a replay and keep the maximum over everything earlier replays, other recordings and eager steps left there."""
+        self.next = ((self.next + self.CHUNK - 1) // self.CHUNK * self.CHUNK) % self.SLOTS
+
+    def gen_of(self, addr: int) -> Optional[int]:
+        """Generation of the chunk that holds slot ``addr``; None for an address outside the ring (a weight's persistent slot)."""
+        if not self.base <= addr < self.end:
+            return None
+        return self.chunk_gen[(addr - self.base) // (4 * self.GROUP_WORDS * self.CHUNK)]
 
 
 _ARENAS: dict = {}
@@ -825,26 +850,77 @@ def _arena(device) -> AmaxArena:
     return a
 
 
+def begin_amax_recording() -> None:
+    """Call right before a stream capture that takes slots: every arena moves to a chunk boundary (AmaxArena.align), so the
+    recording's first ``take`` records the zero-fill of its chunk, and the chunks the recording enters are noted."""
+    for a in _ARENAS.values():
+        a.align()
+        a.recording = set()
+
+
+def end_amax_recording() -> list:
+    """After the capture: [(arena, chunk indices)] for ``amax_recording_replayed``; eager takes continue in a fresh chunk."""
+    rec = []
+    for a in _ARENAS.values():
+        if a.recording is not None:
+            rec.append((a, sorted(a.recording)))
+            a.recording = None
+            a.align()
+    return rec
+
+
+def amax_recording_replayed(rec: list) -> None:
+    """Call after every replay of a recording: the replay zero-filled and refilled the chunks it uses behind the host's back, so
+    every tag made under their old generation (an eager tensor that happened to sit in one of them) is dead from here on."""
+    for a, chunks in rec:
+        for c in chunks:
+            a.chunk_gen[c] += 1
+
+
 def new_amax_slot(device) -> Optional[int]:
     """A zeroed slot group for a producer kernel to fill -- or None when the fp16 hi+lo GEMMs are not selected."""
     return _arena(device).take() if GEMM_MATH == "f16x2" else None
 
 
-def amax_of(t: torch.Tensor) -> Optional[int]:
-    """Slot address of an upper bound of max|t| if a producer (or an earlier GEMM) left one, else None.  A tag is bound to the
-    tensor's version counter: an in-place write after tagging (the autograd engine sums a second gradient INTO the first one's
-    buffer; an accumulating GEMM epilogue) invalidates it, and the consumer falls back to a reduction launch."""
+def _slot_gen(slot: int, device) -> Optional[int]:
+    a = _ARENAS.get(device.index if device.index is not None else torch.cuda.current_device())
+    return None if a is None else a.gen_of(slot)
+
+
+def amax_handle(t: torch.Tensor):
+    """(slot address, chunk generation) of a live upper bound of max|t| if a producer (or an earlier GEMM) left one, else None.
+    A tag is bound to the tensor's version counter: an in-place write after tagging (the autograd engine sums a second gradient
+    INTO the first one's buffer; an accumulating GEMM epilogue) invalidates it; and to the generation of the slot's chunk: once
+    the ring has recycled the slot the tag is dead.  Either way the consumer falls back to a reduction launch."""
     tag = getattr(t, "_dgdm_amax", None)
     if tag is None:
         return None
     if isinstance(tag, tuple):
-        return tag[0] if tag[1] == t._version else None
-    return tag                      # parameters: refreshed at every forward (WeightAmax), never version-bound
+        slot, version, gen = tag
+        if version != t._version or (gen is not None and _slot_gen(slot, t.device) != gen):
+            return None
+        return (slot, gen)
+    return (tag, None)              # parameters: refreshed at every forward (WeightAmax), never version-bound, not in the ring
 
 
-def tag_amax(t: torch.Tensor, slot: Optional[int]) -> torch.Tensor:
-    if slot is not None:
-        t._dgdm_amax = (slot, t._version)
+def amax_of(t: torch.Tensor) -> Optional[int]:
+    """Slot address of a live upper bound of max|t| (see ``amax_handle``), else None."""
+    h = amax_handle(t)
+    return None if h is None else h[0]
+
+
+def tag_amax(t: torch.Tensor, slot) -> torch.Tensor:
+    """Bind an amax slot to ``t``.  ``slot``: the address of a slot just taken (int), or a handle saved earlier with
+    ``amax_handle`` (autograd contexts keep those from forward to backward): a handle whose slot has been recycled since is dropped."""
+    if slot is None:
+        return t
+    if isinstance(slot, tuple):
+        addr, gen = slot
+        if gen is not None and _slot_gen(addr, t.device) != gen:
+            return t
+    else:
+        addr, gen = slot, _slot_gen(slot, t.device)
+    t._dgdm_amax = (addr, t._version, gen)
     return t
 
 
@@ -1104,7 +1180,7 @@ def _gemm_entry(lib, name: str, math: str):
 def _rm_tagged(t: torch.Tensor) -> torch.Tensor:
     """_rowmajor that keeps the operand's amax tag when it has to copy."""
     r = _rowmajor(t)
-    return r if r is t else tag_amax(r, amax_of(t))
+    return r if r is t else tag_amax(r, amax_handle(t))
 
 
 def gemm_nt_raw(a, w, bias=None, out=None, accumulate=False, math="fp32"):
@@ -1131,7 +1207,7 @@ def gemm_nt_split_raw(a, w0, w1, bias=None, math="bf16x3"):
     a, w0, w1 = _rowmajor(a), _rowmajor(w0), _rowmajor(w1)
     for new, old in ((a, a0), (w0, w00), (w1, w10)):
         if new is not old:
-            tag_amax(new, amax_of(old))
+            tag_amax(new, amax_handle(old))
     M, K = a.shape
     N, K0 = w0.shape
     if w1.size(0) != N or K0 + w1.size(1) != K:
@@ -1173,12 +1249,14 @@ def gemm_nn_raw(a, w, out=None, accumulate=False, math="fp32"):
 # gradient before the pass ends must call ``flush_deferred_tn()`` first (parallel.FlatGradAllReducer's early bucket does).
 _DEFER_TN = False
 _PENDING_TN: list = []
+_DEFER_CLAIMED: set = set()      # ids of the parameters that already have a deferred producer in the running pass
 
 
 class deferred_weight_grads:
     def __enter__(self):
         global _DEFER_TN
         self.prev, _DEFER_TN = _DEFER_TN, True
+        _DEFER_CLAIMED.clear()
         return self
 
     def __exit__(self, *exc):
@@ -1188,6 +1266,24 @@ class deferred_weight_grads:
         return False
 
 
+def _claim_deferred(*params) -> bool:
+    """May the gradients of these parameters be returned UNFILLED and written at the end of the running pass?  Only if the engine's
+    AccumulateGrad merely stores the tensor it is handed: every parameter is a leaf whose ``.grad`` is None (an existing gradient
+    would be added to in place, right away) and has no other producer in this pass (the engine would sum the two tensors when the
+    second arrives).  A second producer flushes what is pending -- the first one's tensor is then filled before the engine adds --
+    and reduces immediately itself (tied weights, a module called twice per step, gradient accumulation)."""
+    if not _DEFER_TN:
+        return False
+    ps = [p for p in params if p is not None]
+    if any(id(p) in _DEFER_CLAIMED for p in ps):
+        flush_deferred_tn()
+        return False
+    if any((not p.is_leaf) or p.grad is not None for p in ps):
+        return False
+    _DEFER_CLAIMED.update(id(p) for p in ps)
+    return True
+
+
 def flush_deferred_tn() -> None:
     """Run the held-back dW GEMMs (many-problem launches) and reduce every pending GEMM's chunk partials, all in fixed order."""
     if not _PENDING_TN:
@@ -1195,6 +1291,8 @@ def flush_deferred_tn() -> None:
     lib = _lib.load()
     pend = list(_PENDING_TN)
     _PENDING_TN.clear()
+    if not _DEFER_TN:
+        _DEFER_CLAIMED.clear()
     # on the stream each GEMM's partials were launched on (the engine's end-of-pass callback may run under another current stream
     # than the backward nodes did, e.g. when the step runs on a side stream)
     by_stream: dict = {}
@@ -1345,12 +1443,13 @@ def configure(attention: Optional[str] = None, gemm: Optional[str] = None) -> di
 class _Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b):
+        ctx.leaf = w.is_leaf and (b is None or b.is_leaf)     # gradients go straight to parameters: their reduction may be deferred
+        ctx.wb = (w, b) if ctx.leaf else None                 # ... if the engine only stores them (_claim_deferred looks at these)
         x, w = _rm_tagged(x), _rm_tagged(w)
         ctx.save_for_backward(x, w)
         ctx.has_bias, ctx.math = b is not None, GEMM_MATH
-        ctx.leaf = w.is_leaf and (b is None or b.is_leaf)     # gradients go straight to parameters: their reduction may be deferred
         y = gemm_nt_raw(x, w, b, math=GEMM_MATH)
-        ctx.amax = (amax_of(x), amax_of(w))      # slots the forward GEMM used (or filled): the backward GEMMs reuse them
+        ctx.amax = (amax_handle(x), amax_handle(w))      # slots the forward GEMM used (or filled): the backward GEMMs reuse them while live
         return y
 
     @staticmethod
@@ -1361,7 +1460,7 @@ class _Linear(torch.autograd.Function):
         dx = gemm_nn_raw(gy, w, math=ctx.math) if ctx.needs_input_grad[0] else None
         dW = db = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            dW, db = gemm_tn_raw(gy, x, ctx.has_bias, math=ctx.math, may_defer=ctx.leaf)
+            dW, db = gemm_tn_raw(gy, x, ctx.has_bias, math=ctx.math, may_defer=ctx.leaf and _claim_deferred(*ctx.wb))
         return dx, dW, db
 
 
@@ -1448,12 +1547,13 @@ class _LinearAddInto(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, acc, x, w, b):
+        ctx.leaf = w.is_leaf and (b is None or b.is_leaf)
+        ctx.wb = (w, b) if ctx.leaf else None
         x, w = _rm_tagged(x), _rm_tagged(w)
         ctx.save_for_backward(x, w)
         ctx.has_bias, ctx.math = b is not None, GEMM_MATH
-        ctx.leaf = w.is_leaf and (b is None or b.is_leaf)
         gemm_nt_raw(x, w, b, out=acc, accumulate=True, math=GEMM_MATH)
-        ctx.amax = (amax_of(x), amax_of(w))
+        ctx.amax = (amax_handle(x), amax_handle(w))
         ctx.mark_dirty(acc)                     # bumps acc's version: a maximum tagged before no longer applies (amax_of checks)
         return acc
 
@@ -1465,7 +1565,7 @@ class _LinearAddInto(torch.autograd.Function):
         dx = gemm_nn_raw(gy, w, math=ctx.math) if ctx.needs_input_grad[1] else None
         dW = db = None
         if ctx.needs_input_grad[2] or (ctx.has_bias and ctx.needs_input_grad[3]):
-            dW, db = gemm_tn_raw(gy, x, ctx.has_bias, math=ctx.math, may_defer=ctx.leaf)
+            dW, db = gemm_tn_raw(gy, x, ctx.has_bias, math=ctx.math, may_defer=ctx.leaf and _claim_deferred(*ctx.wb))
         return gy, dx, dW, db
 
 
@@ -1488,16 +1588,17 @@ class _DenoiseFirstLayer(torch.autograd.Function):
         lib = _lib.load()
         x, te = _rm_tagged(x), _rows(te)
         C = x.size(1)
-        wx, wt = tag_amax(w[:, :C], amax_of(w)), w[:, C:]                       # a column block is bounded by the whole matrix's maximum
+        wx, wt = tag_amax(w[:, :C], amax_handle(w)), w[:, C:]                       # a column block is bounded by the whole matrix's maximum
         pg, _ = linear_small_fwd_raw(te, wt, b)                                # [B, N_out]
         h = gemm_nt_raw(x, wx, None, math=GEMM_MATH) if x.size(0) >= GEMM_MIN_ROWS else linear_small_fwd_raw(x, wx, None)[0]
-        ctx.amax = (amax_of(x), amax_of(wx))
+        ctx.amax = (amax_handle(x), amax_handle(wx))
         out = torch.empty_like(h)
         _lib.check(lib.dgdm_segment_bcast_add(h.data_ptr(), pg.data_ptr(), plan.ptr_dev.data_ptr(), plan.B, h.size(0), h.size(1), out.data_ptr(),
                                               _lib.stream_ptr(x.device)), "dgdm_segment_bcast_add")
         ctx.save_for_backward(x, te, w)
         ctx.plan, ctx.math, ctx.has_bias = plan, GEMM_MATH, b is not None
         ctx.leaf = w.is_leaf
+        ctx.wb = (w,) if ctx.leaf else None
         return out
 
     @staticmethod
@@ -1516,7 +1617,7 @@ class _DenoiseFirstLayer(torch.autograd.Function):
         gpg = segment_sum_raw(g, plan)                                         # [B, N_out]: gradient of the per-graph bias
         dw = torch.empty(N_out, K, dtype=torch.float32, device=dev)
         if big:
-            gemm_tn_raw(g, x, False, math=ctx.math, out=dw[:, :C], may_defer=ctx.leaf)
+            gemm_tn_raw(g, x, False, math=ctx.math, out=dw[:, :C], may_defer=ctx.leaf and _claim_deferred(*ctx.wb))
         else:
             _lib.check(lib.dgdm_linear_small_bwd(g.data_ptr(), _ld(g), None, 0, ACT_NONE, x.data_ptr(), _ld(x), None, 0, x.size(0), N_out, C,
                                                  None, 0, dw.data_ptr(), K, None, _lib.stream_ptr(dev)), "dgdm_linear_small_bwd")
@@ -1575,11 +1676,12 @@ class _GraphConvLinear(torch.autograd.Function):
         ctx.gs, ctx.cin, ctx.has_bias, ctx.skip, ctx.math = gs, cin, b is not None, skip, GEMM_MATH
         ctx.amax = (None, None)
         ctx.leaf = w.is_leaf and we.is_leaf and (b is None or b.is_leaf)
+        ctx.wb = (w, we, b) if ctx.leaf else None
         if GEMM_MATH in ("bf16x3", "f16x2") and cin % 4 == 0:
             w = _rm_tagged(w)
             ctx.save_for_backward(buf, w)          # the kernel reads the two weights side by side: no concatenated copy
             y = gemm_nt_split_raw(buf, w, we, b, math=GEMM_MATH)
-            ctx.amax = (amax_of(buf), amax_of(w))
+            ctx.amax = (amax_handle(buf), amax_handle(w))
         else:
             wcat = torch.cat([w, we], dim=1)
             ctx.save_for_backward(buf, wcat)
@@ -1598,12 +1700,12 @@ class _GraphConvLinear(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             # node_lin.weight itself, or a view into the concatenated copy (bounded by the copy's maximum)
-            w_only = wsaved if wsaved.size(1) == cin else tag_amax(wsaved[:, :cin], amax_of(wsaved))
+            w_only = wsaved if wsaved.size(1) == cin else tag_amax(wsaved[:, :cin], amax_handle(wsaved))
             dagg = gemm_nn_raw(gy, w_only, math=math)
             dx = spmm_raw(gs.rowptr_t, gs.col_t, gs.w_t, dagg, gs.num_nodes, addend=gskip)
         dw = dwe = db = None
         if ctx.needs_input_grad[3] or ctx.needs_input_grad[4] or (ctx.has_bias and ctx.needs_input_grad[5]):
-            (dw, dwe), db = gemm_tn_raw(gy, buf, ctx.has_bias, math=math, split=cin, may_defer=ctx.leaf)
+            (dw, dwe), db = gemm_tn_raw(gy, buf, ctx.has_bias, math=math, split=cin, may_defer=ctx.leaf and _claim_deferred(*ctx.wb))
         return dx, None, None, dw, dwe, db, None
 
 

@@ -35,6 +35,8 @@ class FlatGradAllReducer:
     * Recorded steps (training.GraphedPretrainStep) call ``pack()`` inside the recording (one multi-tensor copy, no host cost),
       ``reduce_packed()`` eagerly between the two graphs (ONE all-reduce of the whole buffer: nothing runs beside it there), and
       record the optimizer step on the views.
+    * The early launch and gradient accumulation (two backwards before one ``all_reduce()``) cannot be combined: ``begin_step``
+      detects the second forward and runs that step without overlap.
     """
 
     def __init__(self, module: torch.nn.Module, world_size: Optional[int] = None, group=None, always: bool = False,
@@ -49,15 +51,36 @@ class FlatGradAllReducer:
         self._probe = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
         self._fired = 0
         self._early = None            # in-flight work handle of bucket 0
+        self._forwards = 0            # grad-enabled forwards of the module since the last exchange (> 1: gradient accumulation)
+        self._fwd_probe = module.register_forward_pre_hook(lambda m, args: self.begin_step())
         self.capturing = False        # set by a recording: hooks stay passive, the recording calls pack() itself
         self.stats = {"early_launches": 0, "steps": 0}
 
     # ------------------------------------------------------------------ hooks
+    def begin_step(self) -> None:
+        """Called at the start of every grad-enabled forward of the module (a forward pre-hook does; call it yourself when the
+        loss does not go through ``module.__call__``).  The early-launch state belongs to ONE forward/backward/all_reduce() round:
+        * a step abandoned between backward and ``all_reduce()`` (an exception, a skipped non-finite step) leaves bucket 0's
+          collective in flight and the hook counter set -- waited for and cleared here, so that the next step launches early again
+          instead of waiting on a stale handle;
+        * a SECOND forward before ``all_reduce()`` is gradient accumulation: the early launch cannot be combined with it (bucket 0
+          would leave after the first micro-batch, and once ``.grad`` is a view of the flat buffer the second backward would
+          accumulate into memory the collective is still reducing).  Overlap is switched off for such a step: what is in flight
+          is waited for and discarded, ``all_reduce()`` packs and sends both buckets after the last backward."""
+        if self.capturing or not torch.is_grad_enabled():
+            return
+        self._forwards += 1
+        if self._forwards > 1 and self.live is not None and all(p.grad is None for p in self.live):
+            self._forwards = 1        # gradients were dropped since the last forward: the earlier step was abandoned, this is a new one
+        stale, self._early, self._fired = self._early, None, 0
+        if stale is not None:
+            stale.wait()
+
     def _on_grad(self, p: torch.nn.Parameter) -> None:
         if self.live is None:
             self._order.append(p)                 # first backward: learn the completion order
             return
-        if self.capturing or not self.overlap or not self._active():
+        if self.capturing or not self.overlap or not self._active() or self._forwards > 1:
             return
         if id(p) in self._bucket0_ids:
             self._fired += 1
@@ -100,7 +123,10 @@ class FlatGradAllReducer:
 
     def reset(self) -> None:
         """Forget the live set (call on every rank at the same step, e.g. when the training phase changes)."""
-        self.live, self.flat, self._order, self._fired, self._early = None, None, [], 0, None
+        stale = self._early
+        self.live, self.flat, self._order, self._fired, self._early, self._forwards = None, None, [], 0, None, 0
+        if stale is not None:
+            stale.wait()
 
     @property
     def nbytes(self) -> int:
@@ -146,6 +172,7 @@ class FlatGradAllReducer:
         """All-reduce the (already packed) buffer as ONE message: between two recorded graphs nothing can overlap with it, and a
         second collective only adds its latency (measured on one MI355X through a single-rank RCCL group,
         tools/dist_overhead_probe.py: +0.3 ms per step for the second message)."""
+        self._forwards = 0
         if self.flat.numel() == 0:
             return
         if dist.get_backend(self.group) == "nccl":
@@ -166,7 +193,7 @@ class FlatGradAllReducer:
         if self.live is None:
             self._setup()
         self._check_live()
-        early, self._early, self._fired = self._early, None, 0
+        early, self._early, self._fired, self._forwards = self._early, None, 0, 0
         if early is None:
             self._pack(0)
             early = self._launch(0, async_op=True)

@@ -472,6 +472,7 @@ class GraphedPretrainStep:
         mode = dict(capture_error_mode="thread_local")
         g1 = torch.cuda.CUDAGraph()
         from . import ops
+        ops.begin_amax_recording()               # the recording's first operand-maximum slot opens a chunk: its zero-fill is recorded too
         ops.WEIGHT_IMAGES.prepare(self.dev)      # the table of weight images the warm-up steps registered (a copy a capture cannot record)
         # the recording bakes the ADDRESSES of the batch-layout constants (graph offsets, per-graph sizes) into its kernel
         # arguments: hold them here, whatever the value cache of ops.device_constant evicts later
@@ -495,6 +496,7 @@ class GraphedPretrainStep:
                     self.opt.step()
                 self._graphs.append(g2)
         finally:
+            self._amax_rec = ops.end_amax_recording()
             if gc_was:
                 gc.enable()
             if self.reducer is not None:
@@ -532,9 +534,10 @@ class GraphedPretrainStep:
             self._record()          # recording launches nothing: the step itself is the replay below
         self._graphs[0].replay()
         if self.reducer is not None:
-            self.reducer.reduce_packed()    # the one eager piece: two bucket all-reduces of the buffer graph 0 just packed
+            self.reducer.reduce_packed()    # the one eager piece: ONE all-reduce of the whole buffer graph 0 just packed
             self._graphs[1].replay()
         from . import ops
+        ops.amax_recording_replayed(self._amax_rec)     # the replay rewrote the operand-maximum slots it owns
         ops.weights_changed()         # the replayed optimizer step wrote the weights without bumping their version counters
         return self._loss.clone()     # the recorded loss tensor is overwritten by the next replay
 

@@ -297,3 +297,85 @@ def test_deferred_weight_gradient_reduction_is_bitwise_the_immediate_one(math):
         assert all(torch.isfinite(v).all() and v.abs().max() > 0 for v in b)
     finally:
         ops.configure(**prev)
+
+
+def test_deferred_weight_gradients_with_shared_weights_and_existing_grads():
+    """a deferred dW tensor is filled at the END of the pass, which is only right if the engine merely stores
+    it.  A weight used by two nodes (tied weights / a module called twice) makes the engine ADD the two gradients when the second
+    arrives, and a backward that starts with ``.grad`` set adds in place right away -- both must give the immediate path's values."""
+    from dgdm_histopath_lab_amd import ops
+    prev = ops.configure(gemm="f16x2")
+    try:
+        g = torch.Generator().manual_seed(31)
+        x = torch.randn(3000, 128, generator=g).to(DEV)
+        w0 = (torch.randn(128, 128, generator=g) / 11).to(DEV)
+        b0 = torch.randn(128, generator=g).to(DEV)
+        w1 = (torch.randn(64, 128, generator=g) / 11).to(DEV)
+        gam, bet = torch.rand(128, generator=g).to(DEV) + 0.5, torch.randn(128, generator=g).to(DEV)
+
+        def run(deferred, accumulate):
+            W, B, W1, G, Be = (t.clone().requires_grad_(True) for t in (w0, b0, w1, gam, bet))
+            reps = 2 if accumulate else 1
+            for _ in range(reps):       # second round: .grad is already set -> AccumulateGrad adds in place
+                h = ops.linear(x, W, B)                               # the SAME weight twice in one graph ...
+                h = ops.row_norm(h, G, Be, act=ops.ACT_GELU)
+                h = ops.linear(h, W, B)
+                h = ops.row_norm(h, G, Be, act=ops.ACT_GELU)          # ... and the same norm parameters twice
+                loss = ops.linear(h, W1, None).square().mean()
+                if deferred:
+                    with ops.deferred_weight_grads():
+                        loss.backward()
+                    assert not ops._PENDING_TN
+                else:
+                    loss.backward()
+            return [p.grad.clone() for p in (W, B, W1, G, Be)]
+        for accumulate in (False, True):
+            a, b = run(False, accumulate), run(True, accumulate)
+            for name, u, v in zip(("W", "b", "W1", "gamma", "beta"), a, b):
+                assert torch.isfinite(v).all() and float(u.abs().max()) > 0
+                err = float((u - v).abs().max()) / float(u.abs().max())
+                assert err <= 4e-6, (accumulate, name, err)
+    finally:
+        ops.configure(**prev)
+
+
+def test_amax_tag_dies_when_the_ring_recycles_its_slot():
+    """the operand-maximum ring (4096 slot groups, ~300 taken per step) wraps after ~13 steps; a tag on a
+    long-lived tensor (a device-resident input reused over epochs) then points at a slot that was zeroed and handed to another
+    tensor.  Tags carry the generation of their slot's chunk: after the wrap the GEMM must take a fresh maximum instead of scaling by
+    whatever the recycled slot holds (here: the bits of 1e-6, which would scale the operand by 2^30 into fp16 infinity)."""
+    from dgdm_histopath_lab_amd import ops
+    prev = ops.configure(gemm="f16x2")
+    try:
+        g = torch.Generator().manual_seed(17)
+        x = (torch.randn(2048, 256, generator=g) * 3.0).to(DEV)
+        w = (torch.randn(128, 256, generator=g) / 16).to(DEV)
+        y0 = ops.gemm_nt_raw(x, w, None, math="f16x2")
+        sx, sw = ops.amax_of(x), ops.amax_of(w)
+        assert sx is not None and sw is not None
+        y1 = ops.gemm_nt_raw(x, w, None, math="f16x2")
+        assert ops.amax_of(x) == sx and torch.equal(y0, y1)          # live tag: reused, no new reduction
+        a = ops._arena(x.device)
+        other = torch.full((512, 128), 1e-6, device=DEV)
+        takes0 = a.total_takes
+        for _ in range(a.SLOTS + 2 * a.CHUNK):                        # more takes than the ring has slots, by tensors with a tiny maximum
+            other._dgdm_amax = None
+            ops.ensure_amax(other)
+        assert a.total_takes - takes0 > a.SLOTS
+        assert ops.amax_of(x) is None and ops.amax_of(w) is None       # the old tags are dead ...
+        y2 = ops.gemm_nt_raw(x, w, None, math="f16x2")                 # ... and the GEMM re-derives the maxima
+        assert torch.isfinite(y2).all() and torch.equal(y0, y2)
+        assert ops.amax_of(x) not in (None,)
+        # a handle saved by an autograd context across the wrap is dropped as well
+        xr = x.clone().requires_grad_(True)
+        wr = w.clone().requires_grad_(True)
+        y = ops.linear(xr, wr, None)
+        for _ in range(a.SLOTS + 2 * a.CHUNK):
+            other._dgdm_amax = None
+            ops.ensure_amax(other)
+        y.square().mean().backward()
+        ref = (2 * (x.double() @ w.double().t()) / y.numel())
+        assert float((xr.grad.double() - ref @ w.double()).abs().max()) <= 1e-5 * float((ref @ w.double()).abs().max())
+        assert float((wr.grad.double() - ref.t() @ x.double()).abs().max()) <= 1e-5 * float((ref.t() @ x.double()).abs().max())
+    finally:
+        ops.configure(**prev)

@@ -93,6 +93,61 @@ def test_recorded_step_is_bitwise_the_eager_step():
         assert torch.equal(pa.grad, pb.grad) and not torch.equal(pb, p0)
         live += 1
     assert live > 20
+    # The eager side above runs its backward inside deferred_weight_grads() (as the library's loops do): the many-problem dW launch
+    # chunks the rows coarser than a launch per GEMM, i.e. another fp32 summation order.  What that changes against a PLAIN
+    # loss.backward() is bounded here: same weights, same batch, gradients within 2e-6 of each other.
+    opt_b.zero_grad(set_to_none=True)
+    objective(b)(batches[0]).backward()
+    plain = {k: p.grad.clone() for k, p in b.named_parameters() if p.grad is not None}
+    opt_b.zero_grad(set_to_none=True)
+    with ops.deferred_weight_grads():
+        objective(b)(batches[0]).backward()
+    worst = 0.0
+    for k, p in b.named_parameters():
+        if p.grad is not None:
+            worst = max(worst, float((p.grad - plain[k]).norm() / plain[k].norm().clamp_min(1e-30)))
+    assert worst <= 2e-6, worst
+
+
+def test_recorded_step_rezeroes_every_operand_maximum_slot_it_takes():
+    """a capture used to start wherever the operand-maximum ring stood; the slots taken before the first chunk
+    boundary were never re-zeroed by a replay and kept the maximum over whatever had been there (atomic max only grows).  Poison the
+    whole ring with the bits of 1e20 and leave the bump pointer in mid-chunk: the recording aligns to a chunk boundary, every slot it
+    takes is zero-filled by a recorded launch, and the replayed step equals the eager step bit for bit."""
+    from dgdm_histopath_lab_amd import ops
+    from dgdm_histopath_lab_amd.synthetic import synthetic_batch
+    from dgdm_histopath_lab_amd.training import GraphedPretrainStep
+    batch = synthetic_batch(4, 2, 400, 1600, 64).to(DEV)
+    objective = lambda model: (lambda b: model(b, mode="inference")["graph_embedding"].pow(2).mean())
+    a, b = _small_model(0.0).eval(), _small_model(0.0).eval()
+    opt_a = torch.optim.AdamW(a.parameters(), lr=1e-3, weight_decay=1e-5, fused=True)
+    opt_b = torch.optim.AdamW(b.parameters(), lr=torch.tensor(1e-3, device=DEV), weight_decay=1e-5, fused=True, capturable=True)
+    step = GraphedPretrainStep(a, opt_a, step_fn=objective(a), warmup=1)
+    arena = ops._arena(torch.device(DEV))
+
+    def poison():
+        torch.cuda.synchronize()
+        arena.buf.copy_(torch.full((1,), 1e20, device=DEV).view(torch.int32).expand_as(arena.buf))
+        arena.chunk_gen = [g + 1 for g in arena.chunk_gen]      # as if other work had gone round the ring: every tag is dead
+        arena.align()
+        for _ in range(7):               # leave the pointer in mid-chunk: these slots are zero-filled by the chunk's launch
+            arena.take()
+
+    la, lb = [], []
+    for i in range(5):
+        poison()
+        la.append(float(step(batch)))     # call 1 eager (warm-up), call 2 records + replays, 3.. replay
+        poison()
+        opt_b.zero_grad(set_to_none=True)
+        loss = objective(b)(batch)
+        with ops.deferred_weight_grads():
+            loss.backward()
+        opt_b.step()
+        lb.append(float(loss.detach()))
+    assert step._graphs
+    assert la == lb
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        assert torch.equal(pa, pb)
 
 
 def test_recorded_pretrain_step_draws_fresh_masks_and_rejects_other_layouts():

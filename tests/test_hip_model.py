@@ -87,13 +87,15 @@ def test_model_matches_reference_golden(tag, attn, monkeypatch):
     assert_close(outq["graph_embedding"], g["pre_graph_embedding"], TOL, "graph_embedding (own decisions)")
 
 
-def _run_both(cfgd, seed0, trace, nodes=2000, edges=8000, graphs=2):
+def _run_both(cfgd, seed0, trace, nodes=2000, edges=8000, graphs=2, tweak=None):
     """One pretrain_step (masking + injected draws) on the HIP path and on the float64 oracle.
     The arbiter runs in float64 (same oracle code): fp32-vs-fp32 would fold the CPU path's own
     rounding into the comparison."""
     from dgdm_histopath_lab_amd.synthetic import synthetic_batch
     cfg = O.OracleConfig(**cfgd)
     P = O.init_params(cfg, seed=3, perturb=0.05)
+    if tweak is not None:
+        tweak(P)
     batch = synthetic_batch(seed0, graphs, nodes, edges)
     gen = torch.Generator().manual_seed(11 + seed0)
     n = batch.x.size(0)
@@ -152,12 +154,13 @@ def test_smooth_model_matches_oracle_2k_nodes_all_params(attn, monkeypatch):
     assert _assert_all_grads(m, gref, 1e-4) > 60
 
 
-def _full_model_against_oracle(cfgd, seed0, nodes, edges, graphs, min_live):
+def _full_model_against_oracle(cfgd, seed0, nodes, edges, graphs, min_live, tweak=None):
     """U-Net on (ReLU + top-k): outputs, traced activations, top-k selections and EVERY live parameter gradient against the
     float64 oracle at the 1e-3 contract -- one fixed instance, no retry, no skip.  The oracle's kink decisions are injected into
     the kernels (GraphUNet.forward `decisions`), and every decision the HIP path would have taken differently is held to the
     rounding margin inside _run_both (conftest.check_decision_margins)."""
-    m, out, ref, gref, tr, tr64 = _run_both(cfgd, seed0, trace=True, nodes=nodes, edges=edges, graphs=graphs)
+    m, out, ref, gref, tr, tr64 = _run_both(cfgd, seed0, trace=True, nodes=nodes, edges=edges, graphs=graphs, tweak=tweak)
+    _full_model_against_oracle.last = (m, tr64)
     for k in ("diffusion_loss", "graph_embedding", "noisy_embeddings"):
         assert_close(out[k], ref[k], TOL, k)
     for k in ("feature_encoder", "graph_encoder", "spatial_attention", "graph_unet"):
@@ -202,6 +205,50 @@ def test_large_config_matches_oracle_all_params():
     for k in ("diffusion_loss", "graph_embedding", "noisy_embeddings"):
         assert_close(out[k], ref[k], 1e-4, k)
     assert _assert_all_grads(m, gref, 2e-4) > 60
+
+
+def test_large_config_with_unet_matches_oracle_all_params():
+    """BASELINE configs[3] dims WITH the hierarchical U-Net (core/graph_layers.py:400-458 at hidden 256, 16 heads, T = 20; three
+    top-k levels) on 2 x 2000-node graphs: outputs, traced activations, bit-exact selections and every live gradient against the
+    float64 oracle, decisions injected and held to the rounding margin."""
+    cfgd = dict(node_features=768, hidden_dims=[1024, 512, 256], num_diffusion_steps=20, attention_heads=16)
+    torch.set_num_threads(32)
+    flips, total = _full_model_against_oracle(cfgd, 5, 2000, 8000, 2, 100)
+    assert total > 2_000_000
+
+
+def _attention_row_entropy(P, cfg, tr64, batch_pos, n, H):
+    """Mean row entropy (nats) of the spatial attention of the first graph, from the float64 trace."""
+    import math
+    h, pos = tr64["graph_encoder"][:n].double(), batch_pos[:n].double()
+    P64 = {k: v.double() for k, v in P.items() if k.startswith("spatial_attention.attention.")}
+    xp = h + O.sinusoid_pos_encoding(pos, h.size(1)).double()
+    q = O._lin(P64, "spatial_attention.attention.q_proj", xp).view(n, H, -1).transpose(0, 1)
+    k = O._lin(P64, "spatial_attention.attention.k_proj", xp).view(n, H, -1).transpose(0, 1)
+    w = torch.softmax(q @ k.transpose(1, 2) / math.sqrt(q.size(-1)) - torch.norm(pos[:, None] - pos[None], dim=-1), dim=-1)
+    return float(-(w * torch.log(w.clamp_min(1e-300))).sum(-1).mean())
+
+
+@pytest.mark.parametrize("qk_scale,max_entropy", [(3.0, 2.0), (4.0, 1.0)])
+def test_full_model_with_sharp_attention_rows_matches_oracle(qk_scale, max_entropy):
+    """The default path on TRAINED-LIKE attention: q_proj / k_proj weights scaled until the mean row entropy
+    is far below 0.5 ln N (1.4 and 0.65 nats at N = 2000, against 7.26 at the near-init weights every other model-level test uses);
+    2 x 2000 nodes, Base dims, U-Net on; outputs and every live gradient at the 1e-3 contract."""
+    import math
+    from dgdm_histopath_lab_amd.synthetic import synthetic_batch
+    cfgd = dict(node_features=768, hidden_dims=[512, 256, 128], num_diffusion_steps=10, attention_heads=8)
+    scaled = {}
+
+    def tweak(P):
+        for n in ("q_proj", "k_proj"):
+            P[f"spatial_attention.attention.{n}.weight"] *= qk_scale
+        scaled.update(P)
+    torch.set_num_threads(32)
+    _full_model_against_oracle(cfgd, 0, 2000, 8000, 2, 100, tweak=tweak)
+    _, tr64 = _full_model_against_oracle.last
+    ent = _attention_row_entropy(scaled, O.OracleConfig(**cfgd), tr64, synthetic_batch(0, 2, 2000, 8000).pos, 2000, 8)
+    print(f"qk_scale {qk_scale}: mean row entropy {ent:.2f} nats (ln N = {math.log(2000):.2f})")
+    assert ent < max_entropy <= 0.5 * math.log(2000)
 
 
 def test_large_config_full_size_graph_is_an_independent_unit():

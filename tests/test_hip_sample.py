@@ -104,3 +104,28 @@ def test_small_m_linear_forward_backward(M, N, K, act):
     # the generic entry point routes few-row inputs here (no library GEMM on the path)
     y2 = ops.linear(x.to(DEV), wfull.to(DEV)[:, 24:].contiguous(), b.to(DEV))
     assert_close(y2, F.linear(x.double(), wfull.double()[:, 24:], b.double()), 1e-5, "ops.linear")
+
+
+def test_graphed_sample_follows_weight_updates():
+    """the recorded sampling loop must rebuild the fp16 weight images it reads.  Sample graphed, change the
+    weights (in place, as an optimizer step or load_state_dict does), sample graphed again: equal to the eager path on the new
+    weights -- and different from the first result."""
+    cfg = O.OracleConfig()
+    P = O.init_params(cfg, seed=4, perturb=0.05)
+    dl = _layer(128, 256, 10, {k[len("diffusion_layer."):]: v for k, v in P.items() if k.startswith("diffusion_layer.")})
+    x_init, noises = sample_draws(2000, 128, 10, 123)
+    kw = dict(num_inference_steps=10, x_init=x_init, step_noise=noises)
+    first = dl.sample((2000, 128), DEV, graphed=True, **kw)
+    again = dl.sample((2000, 128), DEV, graphed=True, **kw)
+    assert torch.equal(first, again)
+    P2 = O.init_params(cfg, seed=5, perturb=0.05)
+    dl.load_state_dict({k[len("diffusion_layer."):]: v for k, v in P2.items() if k.startswith("diffusion_layer.")}, strict=True)
+    new_g = dl.sample((2000, 128), DEV, graphed=True, **kw)
+    new_e = dl.sample((2000, 128), DEV, graphed=False, **kw)
+    assert_close(new_g, new_e.double(), 1e-5, "graphed vs eager after a weight update")
+    assert float((new_g - first).abs().max()) > 1e-2
+    P64 = {k: v.double() for k, v in P2.items()}
+    sched = {k: v.double() for k, v in O.diffusion_schedule(10, "cosine").items()}
+    with torch.no_grad():
+        ref = O.ddpm_sample(P64, sched, 10, x_init.double(), [z.double() for z in noises], 10)
+    assert_close(new_g, ref, TOL, "graphed sample on the new weights vs oracle")

@@ -109,6 +109,55 @@ def test_reducer_reset_on_phase_switch_two_ranks_gloo():
         assert dead_bias_grad == [1.0, 1.0, 1.0]       # identical on both ranks: mean == value
 
 
+def _abandon_worker(rank, world, port, q):
+    """A step abandoned between backward and all_reduce() (exception, skipped non-finite step), then a normal step, then a step
+    with gradient accumulation (two backwards before one all_reduce()): ADVICE r2 (low) -- the early-launch state is reset per step
+    and accumulation runs without overlap."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    m = Tiny()
+    red = FlatGradAllReducer(m, world)
+    data = torch.arange(48, dtype=torch.float32).view(8, 6) / 10.0
+    mine = data[list(shard_slides(8, rank, world))]            # 4 rows per rank
+    m.zero_grad(set_to_none=True); m(mine).sum().backward(); red.all_reduce()           # step 1: learns the layout
+    m.zero_grad(set_to_none=True); m(mine * 3.0).sum().backward()                      # step 2: bucket 0 leaves early ... and the step is dropped
+    early_after_abandoned = red.stats["early_launches"]
+    m.zero_grad(set_to_none=True); m(mine).sum().backward(); red.all_reduce()           # step 3: a normal step again (launches early)
+    g3 = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+    early_after_normal = red.stats["early_launches"]
+    m.zero_grad(set_to_none=True)                                                       # step 4: two micro-batches, one exchange
+    m(mine[:2]).sum().backward()
+    m(mine[2:]).sum().backward()
+    red.all_reduce()
+    g4 = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+    m(mine[:2]).sum().backward()                                                        # step 5: accumulate INTO the flat buffer's views
+    m(mine[2:]).sum().backward()
+    red.all_reduce()
+    g5 = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+    q.put((rank, early_after_abandoned, early_after_normal, red.stats["early_launches"], {k: v.tolist() for k, v in g3.items()},
+           {k: v.tolist() for k, v in g4.items()}, {k: v.tolist() for k, v in g5.items()}))
+    dist.destroy_process_group()
+
+
+def test_reducer_abandoned_step_and_gradient_accumulation_two_ranks_gloo():
+    res = run_ranks(_abandon_worker, 2)
+    torch.manual_seed(0)
+    m = Tiny()
+    data = torch.arange(48, dtype=torch.float32).view(8, 6) / 10.0
+    (m(data).sum() / 2).backward()          # mean over the two ranks of the per-rank sums
+    want = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+    for rank, e_ab, e_norm, e_end, g3, g4, g5 in res:
+        # steps 2 and 3 launched early; in the accumulating steps 4 and 5 the first micro-batch's launch is waited for and discarded at
+        # the second forward (overlap off for the rest of the step): correct values below are what matters
+        assert e_ab == 1 and e_norm == 2 and e_end == 4
+        for k in want:
+            torch.testing.assert_close(torch.tensor(g3[k]), want[k], rtol=1e-6, atol=1e-6)
+            torch.testing.assert_close(torch.tensor(g4[k]), want[k], rtol=1e-6, atol=1e-6)
+            # step 5 added the same local gradients onto step 4's averaged ones (in the buffer) and averaged again
+            torch.testing.assert_close(torch.tensor(g5[k]), 2 * want[k], rtol=1e-6, atol=1e-6)
+
+
 def test_single_rank_always_flag_runs_the_collective():
     """`always=True` (bench rehearsal knob) must not return early with one rank."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
