@@ -231,8 +231,24 @@ def cpu_baseline(nodes, edges):
         step(2000, 8000)
     ts = sorted(step(2000, 8000) for _ in range(5))
     med = ts[2]
+    # BASELINE.md 2 "Reported: per-stage split": one more step of the same workload with the oracle's stage clock (forward wall
+    # time per stage; the backward is one autograd pass and is reported whole)
+    stages: dict = {}
+    b = synthetic_batch(0, 1, 2000, 8000, FEATS)
+    t0 = time.perf_counter()
+    Pg = {k: v.detach().clone().requires_grad_(True) for k, v in P.items()}
+    out = O.pretrain_step(Pg, cfg, b, mask_indices=torch.randperm(2000)[:300], mask_token=torch.randn(FEATS), training=True, stages=stages)
+    t1 = time.perf_counter()
+    out["total_pretrain_loss"].backward()
+    t2 = time.perf_counter()
+    fwd = sum(stages.values())
+    split = {"forward_s": round(t1 - t0, 4), "backward_s": round(t2 - t1, 4),
+             "forward_share": {k: round(v / fwd, 4) for k, v in stages.items()},
+             "forward_seconds": {k: round(v, 4) for k, v in stages.items()},
+             "stages": "graph_structure = CSR / degree normalisation; feature_encoder (a1); graph_encoder (a2-a4); spatial_attention "
+                       "(a5-a7, dense [H,N,N] scores + dropout mask); graph_unet (a8-a9); diffusion (a10-a12); pool (a14)"}
     big = step(nodes, edges)
-    return {"value": round(1.0 / med, 4), "unit": "slides/s", "cores": threads, "kind": "port",
+    return {"value": round(1.0 / med, 4), "unit": "slides/s", "cores": threads, "kind": "port", "stage_split": split,
             "sample": f"BASELINE configs[0]: 1 graph of 2000 nodes / 8000 edges, fwd+bwd (training mode, dropout 0.1), 3 warm-up + 5 timed "
                       f"steps, median {med:.3f} s (min {ts[0]:.3f}, max {ts[-1]:.3f}); CPU oracle = restatement of the reference path",
             "headline_size": {"value": round(1.0 / big, 5), "unit": "slides/s",
@@ -252,6 +268,9 @@ def main():
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--no-strict", action="store_true", help="skip the strict-fp32-attention leg")
     ap.add_argument("--eval-mode", action="store_true", help="dropout off (diagnostics only; not the headline)")
+    ap.add_argument("--precision", choices=["default", "fp32"], default="default",
+                    help="fp32: run the MAIN leg with fp32 operands on the fp32 matrix instructions in the attention and in every dense "
+                         "layer (what the `strict_fp32` object of the default run reports; used to take its rocprof / PMC profiles)")
     ap.add_argument("--mixed", action="store_true",
                     help="BASELINE configs[4] shape instead of the headline: a stream of batches whose graphs have 1k..10k nodes "
                          "(E = 5 N), 8 different batches resident in HBM and cycled; reported under config.workload, not comparable "
@@ -288,6 +307,8 @@ def main():
 
     import torch.distributed as dist
     from dgdm_histopath_lab_amd import DGDMModel, ops
+    if args.precision == "fp32":
+        ops.configure(attention="fp32", gemm="fp32")
     from dgdm_histopath_lab_amd.parallel import FlatGradAllReducer
     from dgdm_histopath_lab_amd.synthetic import synthetic_batch
 
@@ -427,52 +448,87 @@ def main():
             strict = {"value": round(args.batch / d32, 3), "unit": "slides/s", "ms_per_step": round(d32 * 1e3, 3), "steps": n32,
                       "attention": "fp32 operands on v_mfma_f32_16x16x4_f32 (csrc/attn_fwd.hip, attn_bwd.hip)",
                       "dense_layers": "fp32 operands on v_mfma_f32_32x32x2_f32 (csrc/gemm.hip)"}
+            # the dominant kernel of THIS leg, timed like the headline's: eager launches of the same step bracketed by HIP events
+            main_timers = ops.TIMERS.summary()
+            ops.TIMERS.start(timed)
+            for _ in range(3):
+                eager_step()
+            torch.cuda.synchronize()
+            ops.TIMERS.stop()
+            strict["_timers"] = ops.TIMERS.summary()
+            ops.TIMERS.events = {}
+            strict["_main_timers"] = main_timers
         finally:
             ops.configure(**prev)
+    per_rank = None
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        mine = torch.tensor([dt], device=dev, dtype=torch.float64)
+        allt = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allt, mine)
+        per = [float(t.item()) for t in allt]
+        per_rank = {"ms_per_step_min": round(min(per) / args.steps * 1e3, 3), "ms_per_step_max": round(max(per) / args.steps * 1e3, 3),
+                    "ms_per_step_by_rank": [round(v / args.steps * 1e3, 3) for v in per]}
+        dt = max(per)
     loss_val = float(loss.item())
 
     result = None
     if rank == 0:
-        timers = ops.TIMERS.summary()
+        timers = strict.pop("_main_timers") if strict is not None else ops.TIMERS.summary()
         heads, hd = cfg["attention_heads"], 16
         flops = {"attn_fwd": attention_flops(sizes, heads, hd, 2), "attn_bwd_dq": attention_flops(sizes, heads, hd, 3),
                  "attn_bwd_dkv": attention_flops(sizes, heads, hd, 4)}
         split = ops.ATTN_PRECISION == "fp16x2"
-        kernels = ({"attn_fwd": "k_attn_h_fwd<4,1,1,3>", "attn_bwd_dq": "k_attn_h_bwd_dq<4,1,1,1>", "attn_bwd_dkv": "k_attn_h_bwd_dkv<2,1,1,3>"}
-                   if split else {"attn_fwd": "k_attn_fwd<4,64>", "attn_bwd_dq": "k_attn_bwd_dq<4,64>", "attn_bwd_dkv": "k_attn_bwd_dkv<4,32>"})
-        dom = max((k for k in flops if k in timers), key=lambda k: timers[k][1]) if any(k in timers for k in flops) else None
-        roofline = {"note": "not computed for this run; see the fixed-size headline run"}
-        if dom is not None and not args.mixed:
-            ms = timers[dom][1]
+        k16 = {"attn_fwd": "k_attn_h_fwd<4,1,1,3>", "attn_bwd_dq": "k_attn_h_bwd_dq<4,1,1,1>", "attn_bwd_dkv": "k_attn_h_bwd_dkv<2,1,1,3>"}
+        k32 = {"attn_fwd": "k_attn_fwd<4,64>", "attn_bwd_dq": "k_attn_bwd_dq<4,64>", "attn_bwd_dkv": "k_attn_bwd_dkv<4,32>"}
+        # MFMAs the split-fp16 kernels issue per algorithmic product: Q'K and dO V as [hi|lo].[hi|hi] + [hi|lo].[lo|lo] (2 instructions
+        # of twice the reduction length: 4x the FLOP), P V / P^T dO / dS^T Q / dS K as hi.hi + lo.hi + hi.lo (3x), ones.P twice (forward)
+        issued_x = {"attn_fwd": (4 + 3 + 2 * 1.0) / 2, "attn_bwd_dq": (4 + 4 + 3) / 3, "attn_bwd_dkv": (4 + 4 + 3 + 3) / 4}
+
+        def attention_roofline(tm, names, fp16_pipe, graphed_note):
+            dom = max((k for k in flops if k in tm), key=lambda k: tm[k][1]) if any(k in tm for k in flops) else None
+            if dom is None:
+                return {"note": "no attention kernel was timed"}
+            ms = tm[dom][1]
             tf = flops[dom] / (ms * 1e-3) / 1e12
-            # `achieved`: ALGORITHMIC FLOP of the reference's products (2 N^2 H d each) per second of the dominant
-            # kernel, priced against the dense peak of the matrix pipe the kernel RUNS ON.  The split-fp16 kernels issue every
-            # product as two v_mfma_f32_16x16x32_f16 on [hi|lo] operand pairs (4x the algorithmic FLOP): `issued_*` is the pipe's
-            # real load; `fp32_equivalent_frac` relates the algorithmic rate to the fp32 matrix peak the reference's arithmetic
-            # would be bound by (it can exceed 1: these kernels do not use that pipe).  The limiter is the VALU (`valu`, PMC).
-            peak = FP16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
-            roofline = {"kernel": kernels[dom], "bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
-                        "frac": round(tf / peak, 4), "pipe": "f16 dense matrix pipe (v_mfma_f32_16x16x32_f16)" if split else "fp32 matrix pipe",
-                        "traffic": None if args.large else pmc_traffic(kernels[dom]),   # the PMC passes were taken on the headline workload
-                        "ms_per_launch": round(ms, 4), "launches_timed": timers[dom][0], "algorithmic_flop": flops[dom],
-                        "other_kernels_ms": {k: round(v[1], 4) for k, v in timers.items() if k != dom}}
-            roofline["timed_with"] = ("HIP events around eager launches of the same step right after the timed region (a graph replay "
-                                      "cannot carry events)" if graphed else "HIP events inside the timed region")
-            if split:
-                roofline.update({"mfma_dtype": "f16 hi+lo split operands, single-f16 P / dS, fp32 accumulate", "issued_flop": 4 * flops[dom],
-                                 "issued_tflops": round(4 * tf, 1), "issued_frac": round(4 * tf / FP16_MFMA_PEAK_TFLOPS, 4),
-                                 "fp32_equivalent_frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4)})
-            if not args.large:
-                roofline["valu"] = pmc_valu(kernels[dom])
+            peak = FP16_MFMA_PEAK_TFLOPS if fp16_pipe else FP32_MFMA_PEAK_TFLOPS
+            # ALGORITHMIC FLOP of the reference's products (2 N^2 H d each) per second of the dominant kernel,
+            # priced against the dense peak of the matrix pipe the kernel RUNS ON
+            mfma = {"bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
+                    "pipe": "f16 dense matrix pipe (v_mfma_f32_16x16x32_f16)" if fp16_pipe else "fp32 matrix pipe (v_mfma_f32_16x16x4_f32)",
+                    "algorithmic_flop": flops[dom]}
+            if fp16_pipe:
+                mfma.update({"mfma_dtype": "every operand (Q', K, V, dO, P, dS) as fp16 hi+lo, fp32 accumulate",
+                             "issued_tflops": round(issued_x[dom] * tf, 1), "issued_frac": round(issued_x[dom] * tf / peak, 4),
+                             "fp32_equivalent_frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4)})
+            common = {"kernel": names[dom], "ms_per_launch": round(ms, 4), "launches_timed": tm[dom][0],
+                      "traffic": None if args.large else pmc_traffic(names[dom]),    # the PMC passes were taken on the headline workload
+                      "other_kernels_ms": {k: round(v[1], 4) for k, v in tm.items() if k != dom}, "timed_with": graphed_note}
+            valu = None if args.large else pmc_valu(names[dom])
+            if fp16_pipe and valu is not None and "valu_busy" in valu:
+                # the split-fp16 kernels are bound by VALU issue, not by the matrix pipe (PMC pass of this command, committed under
+                # profiles/): `frac` = share of SIMD cycles in which a vector instruction was executing; the matrix-pipe pricing
+                # stays as `mfma`.  `valu_rate`: wave-instructions per launch (PMC) over the duration measured live here.
+                rate = valu.get("valu_insts_per_launch", 0) / (ms * 1e-3) / 1e9
+                return dict(common, bound="valu", achieved=round(100.0 * valu["valu_busy"], 2), peak=100.0,
+                            unit="% of SIMD cycles with the VALU executing", frac=round(valu["valu_busy"], 4), valu=valu,
+                            valu_rate={"achieved": round(rate, 1), "peak": 614.4, "unit": "G wave-instructions/s",
+                                       "frac": round(rate / 614.4, 4), "note": "peak = 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction; "
+                                       "transcendentals take more than one slot"}, mfma=mfma)
+            return dict(common, **mfma, valu=valu)
+
+        ev_note = ("HIP events around eager launches of the same step right after the timed region (a graph replay cannot carry events)"
+                   if graphed else "HIP events inside the timed region")
+        roofline = {"note": "not computed for this run; see the fixed-size headline run"}
+        if not args.mixed:
+            roofline = attention_roofline(timers, k16 if split else k32, split, ev_note)
+        if strict is not None:
+            strict["roofline"] = attention_roofline(strict.pop("_timers"), k32, False,
+                                                    "HIP events around eager launches of the fp32 step right after its timed region")
         result = {
             "metric": "slides/sec (DGDM fwd+bwd, 10k-node/768-feat graphs)", "value": round(world * args.batch * args.steps / dt, 3),
             "unit": "slides/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (" + ("attention products: split-fp16 hi+lo operands, single-fp16 P / dS, fp32 accumulate; " if split else "") +
+            "dtype": "f32 (" + ("attention products: every operand incl. P and dS as fp16 hi+lo pairs (~21 significand bits), fp32 accumulate; " if split else "attention: fp32 MFMA; ") +
                      {"f16x2": "dense layers: fp16 hi+lo operands with per-operand power-of-two scale, 3 MFMAs per product, fp32 accumulate",
                       "bf16x3": "dense layers: exact 3-way bf16 split, 6 MFMAs per product, fp32 accumulate",
                       "fp32": "dense layers: fp32 MFMA"}[ops.GEMM_MATH] + ")",
@@ -489,6 +545,12 @@ def main():
         }
         if balance_note is not None:
             result["config"].update(balance_note)
+        if per_rank is not None:
+            result["per_rank"] = per_rank
+        if reducer is not None and reducer.flat is not None:
+            result["gradient_exchange"] = {"collective": "all_reduce(AVG) of one flat fp32 buffer (RCCL), live parameters only",
+                                           "bytes": reducer.nbytes, "bucket_bytes": reducer.bucket_nbytes,
+                                           "messages_per_step": 1 if graphed else 2, "early_launches": reducer.stats.get("early_launches", 0)}
         if strict is not None:
             result["strict_fp32"] = strict
     if world > 1 or force_dist:

@@ -114,11 +114,12 @@ SIGNATURES = {
     "dgdm_attn_pack_bytes": (_sz, [_i32, _i32, _i32]),
     "dgdm_amax_scale_workspace_bytes": (_sz, []),
     "dgdm_amax_pow2_scale": (C.c_int, [_p, _i64, C.c_float, _p, _p, _sz, _p]),
-    "dgdm_attn_pack": (C.c_int, [_p, _i64, _i32, _i32, _i32, C.c_float, _p, _p, _i32, _i32, _i32, _p, _p, _p, _p, _p, _i64, _p, _p]),
-    "dgdm_spatial_attn_h_fwd": (C.c_int, [_p, _p, _p, _p, _p, _i32, _i32, _i32, C.c_float, C.c_float, C.c_uint32, _p, _i64, _p, _i32, _p]),
-    "dgdm_spatial_attn_h_bwd_dq": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, C.c_float, C.c_float, C.c_float,
+    "dgdm_attn_pack": (C.c_int, [_p, _i64, _i32, _i32, _i32, C.c_float, _p, _p, _i32, _i32, _i32, _p, _p, _i32, _p, C.c_float, _p, _p, _i64,
+                                 _p, _p, _p, _p]),
+    "dgdm_spatial_attn_h_fwd": (C.c_int, [_p, _p, _p, _p, _p, _i32, _i32, _i32, C.c_float, C.c_uint32, _p, _i64, _p, _i32, _p]),
+    "dgdm_spatial_attn_h_bwd_dq": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, C.c_float, C.c_float,
                                              C.c_uint32, _p, _p, _i64, _i32, _p]),
-    "dgdm_spatial_attn_h_bwd_dkv": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, C.c_float, C.c_float,
+    "dgdm_spatial_attn_h_bwd_dkv": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, C.c_float,
                                               C.c_uint32, _p, _p, _p, _i64, _i32, _p]),
     "dgdm_gemm_image_bytes": (_sz, [_i32, _i32]),
     "dgdm_gemm_image_blocks": (_i32, [_i32, _i32]),

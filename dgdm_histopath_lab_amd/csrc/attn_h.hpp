@@ -53,6 +53,75 @@ __device__ __forceinline__ f16x8 pack8(const f32x4 a, const f32x4 b) {
   return r;
 }
 
+// 8 fp32 values -> fp16 hi+lo pairs (hi = fp16(x) by v_cvt_pk_f16_f32, lo = fp16(x - hi) by one v_fma_mixlo/hi_f16 per value:
+// the mixed-precision FMA reads hi as fp16 and x as fp32 and rounds once -- 1.5 instructions per value; hipcc's own lowering of
+// the same expression converts hi back to fp32 first, 2.5).  Probabilities and dS are carried like every other operand of the
+// attention products: ~21 significand bits, not fp16's 11 (profiles/r03_sharp_rows_*: single-fp16 P / dS broke the 1e-3
+// contract on trained-like attention rows).
+__device__ __forceinline__ uint32_t pk_hi_f16(float x0, float x1) {
+  typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+  const f16x2_t h = {(_Float16)x0, (_Float16)x1};
+  return __builtin_bit_cast(uint32_t, h);
+}
+__device__ __forceinline__ uint32_t pk_lo_f16(uint32_t hi_pk, float x0, float x1) {
+  uint32_t r;
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+      : "=&v"(r)
+      : "v"(hi_pk), "v"(x0), "v"(x1));
+  return r;
+}
+__device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, f16x8* hi, f16x8* lo) {
+  typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+  u32x4_t h, l;
+  h[0] = pk_hi_f16(a[0], a[1]); h[1] = pk_hi_f16(a[2], a[3]); h[2] = pk_hi_f16(b[0], b[1]); h[3] = pk_hi_f16(b[2], b[3]);
+  l[0] = pk_lo_f16(h[0], a[0], a[1]); l[1] = pk_lo_f16(h[1], a[2], a[3]); l[2] = pk_lo_f16(h[2], b[0], b[1]); l[3] = pk_lo_f16(h[3], b[2], b[3]);
+  *hi = __builtin_bit_cast(f16x8, h);
+  *lo = __builtin_bit_cast(f16x8, l);
+}
+// B-operand register pair (hi parts, lo parts of the same 8 values) times a constant, re-split (once per workgroup)
+__device__ __forceinline__ void scale_b_pair(f16x8* b1, f16x8* b2, float c) {
+  f32x4 a, b;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    a[e] = ((float)(*b1)[e] + (float)(*b2)[e]) * c;
+    b[e] = ((float)(*b1)[4 + e] + (float)(*b2)[4 + e]) * c;
+  }
+  split8(a, b, b1, b2);
+}
+// Packed fp32 arithmetic (v_pk_add/mul/fma_f32: two values per instruction) for the per-pair distance and the C inputs of the score
+// products; written on 2-vectors because hipcc scalarises the same expressions on 4-vectors whose elements come out of v_sqrt.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// |p - k_r| for the four staged points k_r = (xs[r], ys[r]) (positions pre-scaled by log2(e)/tau in dgdm_attn_pack)
+__device__ __forceinline__ f32x4 dist4(const float* __restrict__ xs, const float* __restrict__ ys, float px, float py) {
+  const f32x4 kx = *reinterpret_cast<const f32x4*>(xs), ky = *reinterpret_cast<const f32x4*>(ys);
+  const f32x2 px2 = {px, px}, py2 = {py, py};
+  const f32x2 dxa = kx.xy - px2, dxb = kx.zw - px2, dya = ky.xy - py2, dyb = ky.zw - py2;
+  const f32x2 da = __builtin_elementwise_fma(dya, dya, dxa * dxa), db = __builtin_elementwise_fma(dyb, dyb, dxb * dxb);
+  return f32x4{__builtin_amdgcn_sqrtf(da.x), __builtin_amdgcn_sqrtf(da.y), __builtin_amdgcn_sqrtf(db.x), __builtin_amdgcn_sqrtf(db.y)};
+}
+// a - b on two values per instruction.  Inline asm: hipcc splits a 2-vector subtraction whose operand comes out of v_sqrt into two
+// v_sub_f32 whatever way it is written (fsub, fadd of fneg).
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
+  f32x2 r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ f32x4 sub4(const f32x4 a, const f32x4 b) {
+  const f32x2 lo = pk_sub(a.xy, b.xy), hi = pk_sub(a.zw, b.zw);
+  return f32x4{lo.x, lo.y, hi.x, hi.y};
+}
+__device__ __forceinline__ f32x4 sub4(float a, const f32x4 b) {
+  const f32x2 a2 = {a, a};
+  const f32x2 lo = pk_sub(a2, b.xy), hi = pk_sub(a2, b.zw);
+  return f32x4{lo.x, lo.y, hi.x, hi.y};
+}
+
+// log2 of the factor the backward kernels carry P with: P' = 2^P_SHIFT * P keeps the weights of a near-uniform row over 10^4..10^5
+// keys (p ~ 1e-4..1e-5, at the bottom of fp16's normal range, where a lo part has nothing left) well inside it.  Folded into the
+// log-sum-exp the kernels subtract, taken out again with the final scale: no instruction.
+#define DGDM_ATTN_P_SHIFT 8.0f
+
 // A operand of a transposed image for the tile pair (t0, t0+1): rows 16*t0 + 4G .. +3 and
 // 16*(t0+1) + 4G .. +3 of d-row `d` (two 8-byte LDS reads).
 __device__ __forceinline__ f16x8 load_t_pair(const _Float16* __restrict__ timg_part_head, int d, int t0, int G) {

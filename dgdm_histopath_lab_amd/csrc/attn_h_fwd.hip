@@ -3,8 +3,9 @@
 // online softmax in the log2 domain, distance bias shared by the head group, counter-hash dropout);
 // differences that matter for speed on gfx950:
 //   * both products run on v_mfma_f32_16x16x32_f16 with hi+lo operands (attn_h.hpp):
-//       S'^T = [K_hi|K_lo].[Q'_hi|Q'_hi] + [K_hi|K_lo].[Q'_lo|Q'_lo]  with C-in = -bias
-//       O^T += V^T_hi.P + V^T_lo.P        (P = fp16(exp2(S' - m)), pairs of 16-key tiles)
+//       S'^T = [K_hi|K_lo].[Q'_hi|Q'_hi] + [K_hi|K_lo].[Q'_lo|Q'_lo]  with C-in = -distance (packed fp32 arithmetic on
+//       positions pre-scaled by log2(e)/tau)
+//       O^T += V^T_hi.P_hi + V^T_lo.P_hi + V^T_hi.P_lo     (P = exp2(S' - m) carried as fp16 hi+lo like every operand)
 //     so the matrix work overlaps with the softmax VALU work (the fp32 MFMA cannot);
 //   * K / V^T / key positions are pre-packed, block-aligned images staged by direct-to-LDS DMA into a
 //     double buffer: no staging VGPRs, no staging VALU, one barrier per key block;
@@ -51,9 +52,10 @@ __global__ __launch_bounds__(256) void k_amax_final(const float* __restrict__ pa
 
 __global__ __launch_bounds__(256) void k_attn_pack(const float* __restrict__ X, int64_t ld, int col0, int cstride, float scale0,
                                                    const float* __restrict__ scale_dev, const int32_t* __restrict__ ptr, int B, int H, _Float16* __restrict__ R,
-                                                   int64_t r_tensor_stride, _Float16* __restrict__ Tt, int64_t t_tensor_stride,
-                                                   const float* __restrict__ pos, float* __restrict__ pos_b,
-                                                   const float* __restrict__ Oin, int64_t ldo, float* __restrict__ delta_b) {
+                                                   int64_t r_tensor_stride, _Float16* __restrict__ Tt, int t_tensor,
+                                                   const float* __restrict__ pos, float pos_scale, float* __restrict__ pos_b,
+                                                   const float* __restrict__ Oin, int64_t ldo, float* __restrict__ ndelta_b,
+                                                   const float* __restrict__ lse_in, float* __restrict__ lse_out) {
   __shared__ __attribute__((aligned(16))) _Float16 sm[2][16][T_STRIDE];
   const int blk = blockIdx.x, h = blockIdx.y, z = blockIdx.z;
   int n0, ng, lblk, blk0;
@@ -65,32 +67,41 @@ __global__ __launch_bounds__(256) void k_attn_pack(const float* __restrict__ X, 
   const float scale = (z == 0 ? scale0 : 1.0f) * (scale_dev ? scale_dev[0] : 1.0f);
   const float4 v = *reinterpret_cast<const float4*>(X + node * ld + col0 + z * cstride + h * 16 + part * 4);
   const float x[4] = {ok ? v.x * scale : 0.f, ok ? v.y * scale : 0.f, ok ? v.z * scale : 0.f, ok ? v.w * scale : 0.f};
+  const bool want_t = Tt != nullptr && z == t_tensor;
   f16x4 hi, lo;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     hi[e] = (_Float16)x[e];
     lo[e] = (_Float16)(x[e] - (float)hi[e]);
-    sm[0][part * 4 + e][row] = hi[e];
-    sm[1][part * 4 + e][row] = lo[e];
+    if (want_t) {
+      sm[0][part * 4 + e][row] = hi[e];
+      sm[1][part * 4 + e][row] = lo[e];
+    }
   }
   _Float16* rrow = R + z * r_tensor_stride + (((int64_t)blk * H + h) * HB + row) * 32;
   *reinterpret_cast<f16x4*>(rrow + part * 4) = hi;
   *reinterpret_cast<f16x4*>(rrow + 16 + part * 4) = lo;
-  if (Oin) {  // delta = rowsum(dO * O) (attention backward), block layout [blk][H][64]
+  if (Oin) {  // -delta = -rowsum(dO * O) (attention backward: C input of the dP products), block layout [blk][H][64]
     const float4 o = *reinterpret_cast<const float4*>(Oin + node * ldo + h * 16 + part * 4);
     float d = x[0] * o.x + x[1] * o.y + x[2] * o.z + x[3] * o.w;
     d += __shfl_xor(d, 1, 64);
     d += __shfl_xor(d, 2, 64);
-    if (part == 0) delta_b[((int64_t)blk * H + h) * HB + row] = ok ? d : 0.f;
+    if (part == 0) {
+      const int64_t idx = ((int64_t)blk * H + h) * HB + row;
+      ndelta_b[idx] = ok ? -d : 0.f;
+      if (lse_out) lse_out[idx] = DGDM_ATTN_P_SHIFT - lse_in[idx];   // the backward kernels carry P' = 2^P_SHIFT * P (attn_h.hpp)
+    }
   }
-  if (pos_b && z == 0 && h == 0 && tid < HB) {
+  if (pos_b && z == 0 && h == 0 && tid < HB) {   // planar, pre-scaled by log2(e)/tau: [blk][x | y][64]
     const int r2 = lblk * HB + tid;
     const float2 p = *reinterpret_cast<const float2*>(pos + 2 * (int64_t)(n0 + (r2 < ng ? r2 : ng - 1)));
-    *reinterpret_cast<float2*>(pos_b + ((int64_t)blk * HB + tid) * 2) = r2 < ng ? p : make_float2(0.f, 0.f);
+    pos_b[((int64_t)blk * 2 + 0) * HB + tid] = r2 < ng ? p.x * pos_scale : 0.f;
+    pos_b[((int64_t)blk * 2 + 1) * HB + tid] = r2 < ng ? p.y * pos_scale : 0.f;
   }
+  if (!want_t) return;     // uniform per workgroup
   __syncthreads();
   const int d = tid >> 4, rc = tid & 15;
-  _Float16* tb = Tt + z * t_tensor_stride + ((int64_t)blk * H + h) * T_HEAD;
+  _Float16* tb = Tt + ((int64_t)blk * H + h) * T_HEAD;
   *reinterpret_cast<f16x4*>(tb + d * T_STRIDE + 4 * rc) = *reinterpret_cast<const f16x4*>(&sm[0][d][4 * rc]);
   *reinterpret_cast<f16x4*>(tb + T_PART + d * T_STRIDE + 4 * rc) = *reinterpret_cast<const f16x4*>(&sm[1][d][4 * rc]);
 }
@@ -98,7 +109,7 @@ __global__ __launch_bounds__(256) void k_attn_pack(const float* __restrict__ X, 
 template <int HG, bool DROP, int NBUF = 2, int WPE = 2>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) void k_attn_h_fwd(const _Float16* __restrict__ Rq, const _Float16* __restrict__ Rk,
                                                     const _Float16* __restrict__ Tv, const float* __restrict__ pos_b, int H,
-                                                    const int32_t* __restrict__ ptr, int B, float bscale, float* __restrict__ O,
+                                                    const int32_t* __restrict__ ptr, int B, float* __restrict__ O,
                                                     int64_t ldo, float* __restrict__ lse2_b, float drop_p, DgdmSeed seed_in) {
   const uint32_t seed = seed_in.value();
   constexpr int NT = HB / 16;
@@ -127,20 +138,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
   stage(0, 0);
 
   f16x8 qb1[HG], qb2[HG];
-  f32x4 oacc[HG], lacc[HG];  // lacc: every register = sum over keys of the ROUNDED weights (ones . P)
+  f32x4 oacc[HG], lacc[HG];  // lacc: every register = sum over keys of the weights (ones . [P_hi + P_lo])
   float m[HG];
-  uint32_t hq[HG];
-  DropHead dh[HG];
+  DropLaneQ dl[HG];
   const _Float16 one = (_Float16)1.0f;
   const f16x8 ones = {one, one, one, one, one, one, one, one};
 #pragma unroll
   for (int h = 0; h < HG; ++h) {
     load_b_pair(Rq + (((int64_t)blockIdx.x * H + head0 + h) * HB + q_in_blk) * 32, G, &qb1[h], &qb2[h]);
     oacc[h] = f32x4{0.f, 0.f, 0.f, 0.f}; lacc[h] = f32x4{0.f, 0.f, 0.f, 0.f}; m[h] = NEG_BIG;
-    dh[h] = DropHead(seed, n0, head0 + h);
-    hq[h] = attn_hq(dh[h], q_local);
+    if (DROP) dl[h] = DropLaneQ(DropHead(seed, n0, head0 + h), q_local);
   }
-  const float2 pq = *reinterpret_cast<const float2*>(pos_b + ((int64_t)blockIdx.x * HB + q_in_blk) * 2);
+  const uint32_t lck = __umul24(2u * (uint32_t)G, DROP_CK);
+  const float px = pos_b[((int64_t)blockIdx.x * 2 + 0) * HB + q_in_blk], py = pos_b[((int64_t)blockIdx.x * 2 + 1) * HB + q_in_blk];
   __syncthreads();  // block 0 landed (vmcnt(0) + barrier)
 
   for (int kb = 0; kb < nbg; ++kb) {
@@ -151,24 +161,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
     const float* Ps = reinterpret_cast<const float*>(smem + buf * BUF_BYTES + RK_BYTES + TV_BYTES);
     const int kb0 = kb * HB;
 
-    f32x4 nbias[NT];  // minus the distance bias = C input of the first S MFMA; masked keys: -1e30
+    f32x4 ndist[NT];  // -log2(e)/tau * |p_q - p_k| = C input of the first S MFMA (packed fp32 arithmetic); masked keys: -1e30
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      const float4 pa = *reinterpret_cast<const float4*>(&Ps[2 * (16 * t + 4 * G)]);
-      const float4 pb = *reinterpret_cast<const float4*>(&Ps[2 * (16 * t + 4 * G) + 4]);
-      const float kx[4] = {pa.x, pa.z, pb.x, pb.z}, ky[4] = {pa.y, pa.w, pb.y, pb.w};
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float dx = pq.x - kx[r], dy = pq.y - ky[r];
-        nbias[t][r] = -(__builtin_amdgcn_sqrtf(fmaf(dx, dx, dy * dy)) * bscale);
-      }
+      ndist[t] = sub4(0.f, dist4(&Ps[16 * t + 4 * G], &Ps[HB + 16 * t + 4 * G], px, py));
     }
     if (kb0 + HB > ng) {   // only the last key block of a graph has keys to mask (wave-uniform branch)
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (kb0 + 16 * t + 4 * G + r >= ng) nbias[t][r] = NEG_BIG;
+          if (kb0 + 16 * t + 4 * G + r >= ng) ndist[t][r] = NEG_BIG;
     }
 
 #pragma unroll
@@ -177,7 +180,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const f16x8 kf = *reinterpret_cast<const f16x8*>(Kimg + h * R_HEAD + (16 * t + j) * 32 + 8 * G);
-        s[t] = mfma_h(kf, qb1[h], nbias[t]);
+        s[t] = mfma_h(kf, qb1[h], ndist[t]);
         s[t] = mfma_h(kf, qb2[h], s[t]);
       }
       float mloc = fmaxf(s[0][0], s[0][1]);   // a chain the compiler folds into v_max3_f32: two values per instruction
@@ -205,24 +208,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
       const _Float16* vh = Vimg + h * T_HEAD;
 #pragma unroll
       for (int tp = 0; tp < NT / 2; ++tp) {
-        // the softmax denominator is summed from the SAME fp16-rounded weights that multiply V, on the
-        // matrix pipe (ones . P): numerator and denominator stay consistent, no VALU adds, and the
-        // result already covers all four lane groups of a query
-        f16x8 pb = pack8(s[2 * tp], s[2 * tp + 1]);
-        lacc[h] = mfma_h(ones, pb, lacc[h]);
+        // the softmax denominator is summed from the same hi+lo weights that multiply V, on the matrix pipe (ones . P): no VALU
+        // adds, and the result already covers all four lane groups of a query
+        f16x8 ph, pl;
+        split8(s[2 * tp], s[2 * tp + 1], &ph, &pl);
+        lacc[h] = mfma_h(ones, ph, lacc[h]);
+        lacc[h] = mfma_h(ones, pl, lacc[h]);
         if (DROP) {  // dropout applies to the normalised weights: mask only what multiplies V.  The packed halfs are masked
                      // in place (0xFFFF / 0 per half-word); the constant 1/(1-p) multiplies the finished row below.
           typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
           u32x4 mk;
-          uint32_t a, b;
-          drop_masks_qmajor(hq[h], dh[h], q_local, kb0 + 32 * tp + 4 * G, dc, &a, &b);
-          mk[0] = a; mk[1] = b;
-          drop_masks_qmajor(hq[h], dh[h], q_local, kb0 + 32 * tp + 16 + 4 * G, dc, &a, &b);
-          mk[2] = a; mk[3] = b;
-          pb = __builtin_bit_cast(f16x8, __builtin_bit_cast(u32x4, pb) & mk);
+          uint32_t e[4];
+          drop_words_q(dl[h], (uint32_t)(kb0 + 32 * tp), lck, e);
+          mk[0] = drop_pair_mask(e[1], e[0], dc); mk[1] = drop_pair_mask(e[3], e[2], dc);
+          drop_words_q(dl[h], (uint32_t)(kb0 + 32 * tp + 16), lck, e);
+          mk[2] = drop_pair_mask(e[1], e[0], dc); mk[3] = drop_pair_mask(e[3], e[2], dc);
+          ph = __builtin_bit_cast(f16x8, __builtin_bit_cast(u32x4, ph) & mk);
+          pl = __builtin_bit_cast(f16x8, __builtin_bit_cast(u32x4, pl) & mk);
         }
-        oacc[h] = mfma_h(load_t_pair(vh, j, 2 * tp, G), pb, oacc[h]);
-        oacc[h] = mfma_h(load_t_pair(vh + T_PART, j, 2 * tp, G), pb, oacc[h]);   // lo part of V: same accumulator
+        const f16x8 vhi = load_t_pair(vh, j, 2 * tp, G);
+        oacc[h] = mfma_h(vhi, ph, oacc[h]);
+        oacc[h] = mfma_h(load_t_pair(vh + T_PART, j, 2 * tp, G), ph, oacc[h]);   // lo part of V: same accumulator
+        oacc[h] = mfma_h(vhi, pl, oacc[h]);                                      // lo part of P (V_lo . P_lo ~ 2^-22: dropped)
       }
     }
     __syncthreads();  // everyone is done with `buf`; the DMA of the next block has landed
@@ -259,9 +266,10 @@ extern "C" size_t dgdm_attn_pack_bytes(int32_t num_blocks, int32_t H, int32_t wh
   }
 }
 
-// Packs `ntensors` column blocks of X (tensor z = columns [col0 + z*cstride, +H*16)) into row and
-// transposed images; tensor 0 is scaled by scale0.  pos_b (nullable): block-aligned positions.
-// O (nullable): when given, delta_b[blk][H][64] = rowsum(X_0 * O) (X_0 = dO in the backward).
+// Packs `ntensors` column blocks of X (tensor z = columns [col0 + z*cstride, +H*16)) into row images (and a transposed image of
+// tensor `t_tensor` when T is given); tensor 0 is scaled by scale0.  pos_b (nullable): block-aligned positions, planar, times
+// pos_scale.  O (nullable): when given, ndelta_b[blk][H][64] = -rowsum(X_0 * O) (X_0 = dO in the backward) and, with lse_in /
+// lse_out, lse_out = DGDM_ATTN_P_SHIFT - lse_in.
 extern "C" size_t dgdm_amax_scale_workspace_bytes(void) { return 1024 * sizeof(float); }
 
 // out2[0] = alpha = 2^k such that alpha * max|x| lies in (target/2, target]; out2[1] = 1/alpha.  x: n contiguous floats.
@@ -281,23 +289,26 @@ extern "C" int dgdm_amax_pow2_scale(const float* x, int64_t n, float target, flo
 }
 
 extern "C" int dgdm_attn_pack(const float* X, int64_t ld, int32_t col0, int32_t cstride, int32_t ntensors, float scale0,
-                              const float* scale_dev, const int32_t* ptr, int32_t B, int32_t num_blocks, int32_t H, void* R, void* T, const float* pos,
-                              float* pos_b, const float* O, int64_t ldo, float* delta_b, void* stream) {
+                              const float* scale_dev, const int32_t* ptr, int32_t B, int32_t num_blocks, int32_t H, void* R, void* T,
+                              int32_t t_tensor, const float* pos, float pos_scale, float* pos_b, const float* O, int64_t ldo,
+                              float* ndelta_b, const float* lse_in, float* lse_out, void* stream) {
   DGDM_REQUIRE(B >= 0 && num_blocks >= 0 && H > 0 && ntensors > 0 && ntensors <= 4);
   if (num_blocks == 0 || B == 0) return DGDM_OK;
-  DGDM_REQUIRE(X && ptr && R && T);
-  DGDM_REQUIRE((pos == nullptr) == (pos_b == nullptr) && (O == nullptr) == (delta_b == nullptr));
-  if ((ld & 3) || (col0 & 3) || (cstride & 3) || !dgdm_aligned16(X) || !dgdm_aligned16(R) || !dgdm_aligned16(T) ||
+  DGDM_REQUIRE(X && ptr && R);
+  DGDM_REQUIRE(T == nullptr || (t_tensor >= 0 && t_tensor < ntensors));
+  DGDM_REQUIRE((pos == nullptr) == (pos_b == nullptr) && (O == nullptr) == (ndelta_b == nullptr));
+  DGDM_REQUIRE((lse_in == nullptr) == (lse_out == nullptr) && (lse_out == nullptr || O != nullptr));
+  if ((ld & 3) || (col0 & 3) || (cstride & 3) || !dgdm_aligned16(X) || !dgdm_aligned16(R) || (T && !dgdm_aligned16(T)) ||
       (O && ((ldo & 3) || !dgdm_aligned16(O))))
     return DGDM_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(k_attn_pack, dim3(num_blocks, H, ntensors), dim3(256), 0, static_cast<hipStream_t>(stream), X, ld, col0, cstride,
                      scale0, scale_dev, ptr, B, H, static_cast<_Float16*>(R), (int64_t)num_blocks * H * R_HEAD, static_cast<_Float16*>(T),
-                     (int64_t)num_blocks * H * T_HEAD, pos, pos_b, O, ldo, delta_b);
+                     t_tensor, pos, pos_scale, pos_b, O, ldo, ndelta_b, lse_in, lse_out);
   return dgdm_launch_status();
 }
 
 extern "C" int dgdm_spatial_attn_h_fwd(const void* Rq, const void* Rk, const void* Tv, const float* pos_b, const int32_t* ptr,
-                                       int32_t B, int32_t num_blocks, int32_t H, float inv_tau, float drop_p, uint32_t seed, float* O,
+                                       int32_t B, int32_t num_blocks, int32_t H, float drop_p, uint32_t seed, float* O,
                                        int64_t ldo, float* lse2_b, int32_t variant, void* stream_) {
   DGDM_REQUIRE(B >= 0 && H > 0 && num_blocks >= 0 && drop_p >= 0.f && drop_p < 1.f);
   if (num_blocks == 0 || B == 0) return DGDM_OK;
@@ -306,16 +317,15 @@ extern "C" int dgdm_spatial_attn_h_fwd(const void* Rq, const void* Rk, const voi
       !dgdm_aligned16(pos_b))
     return DGDM_ERR_UNSUPPORTED;
   hipStream_t s = static_cast<hipStream_t>(stream_);
-  const float bscale = inv_tau * DGDM_LOG2E;
   const _Float16 *q = static_cast<const _Float16*>(Rq), *k = static_cast<const _Float16*>(Rk), *v = static_cast<const _Float16*>(Tv);
 #define GO(HG, NBUF, WPE)                                                                                                   \
   do {                                                                                                                      \
     if (drop_p > 0.f)                                                                                                       \
       hipLaunchKernelGGL((k_attn_h_fwd<HG, true, NBUF, WPE>), dim3(num_blocks, H / HG), dim3(256), 0, s, q, k, v, pos_b, H, ptr, B,    \
-                         bscale, O, ldo, lse2_b, drop_p, dgdm_seed_arg(seed));                                                             \
+                         O, ldo, lse2_b, drop_p, dgdm_seed_arg(seed));                                                             \
     else                                                                                                                    \
       hipLaunchKernelGGL((k_attn_h_fwd<HG, false, NBUF, WPE>), dim3(num_blocks, H / HG), dim3(256), 0, s, q, k, v, pos_b, H, ptr, B,   \
-                         bscale, O, ldo, lse2_b, 0.f, dgdm_seed_arg(0u));                                                                  \
+                         O, ldo, lse2_b, 0.f, dgdm_seed_arg(0u));                                                                  \
   } while (0)
   // variant 0 = default; 1..3 select a tiling explicitly (tools/microbench_attn.py)
   if (H % 4 == 0 && variant == 1) GO(4, 2, 2);        // 4 heads, double-buffered, 2 workgroups per CU

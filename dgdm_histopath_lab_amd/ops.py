@@ -223,33 +223,38 @@ LOG2E = 1.4426950408889634
 
 
 class PackedOperands:
-    """Block-aligned fp16 hi+lo images of `ntensors` column blocks of one fp32 matrix (csrc/attn_h.hpp)."""
+    """Block-aligned fp16 hi+lo row images of `ntensors` column blocks of one fp32 matrix (csrc/attn_h.hpp), plus (forward pack)
+    the transposed image of V and the block-aligned, pre-scaled positions; (backward pack) -delta and 8 - lse2 per row."""
 
-    __slots__ = ("R", "T", "pos_b", "delta_b", "ntensors", "r_stride", "t_stride")
+    __slots__ = ("R", "T", "pos_b", "ndelta_b", "nlse_b", "ntensors", "r_stride")
 
     def r(self, z):
         return self.R[z * self.r_stride:]
 
-    def t(self, z):
-        return self.T[z * self.t_stride:]
+
+# dO is packed as alpha * dO with alpha * max|dO| in (TARGET/2, TARGET] (device-side power of two): with P' = 2^8 P the products
+# dS' = P' (keep dP - delta) stay ~4x further from fp16's maximum than round 2's (target 256, P unscaled) did
+ATTN_GRAD_TARGET = 0.25
 
 
-def attn_pack(x, col0: int, cstride: int, ntensors: int, scale0: float, plan: AttnPlan, H: int, pos=None, O=None,
-              scale_dev=None) -> PackedOperands:
+def attn_pack(x, col0: int, cstride: int, ntensors: int, scale0: float, plan: AttnPlan, H: int, pos=None, pos_scale: float = 1.0, O=None,
+              scale_dev=None, lse2_b=None, t_tensor: int = -1) -> PackedOperands:
     lib = _lib.load()
     dev, nb = x.device, plan.num_q_tiles
     pk = PackedOperands()
     pk.ntensors = ntensors
     pk.r_stride = lib.dgdm_attn_pack_bytes(nb, H, 0) // 2
-    pk.t_stride = lib.dgdm_attn_pack_bytes(nb, H, 1) // 2
     pk.R = torch.empty(max(ntensors * pk.r_stride, 8), dtype=torch.float16, device=dev)
-    pk.T = torch.empty(max(ntensors * pk.t_stride, 8), dtype=torch.float16, device=dev)
+    pk.T = torch.empty(max(lib.dgdm_attn_pack_bytes(nb, H, 1) // 2, 8), dtype=torch.float16, device=dev) if t_tensor >= 0 else None
     pk.pos_b = torch.empty(max(lib.dgdm_attn_pack_bytes(nb, H, 2) // 4, 4), dtype=torch.float32, device=dev) if pos is not None else None
-    pk.delta_b = torch.empty(max(lib.dgdm_attn_pack_bytes(nb, H, 3) // 4, 4), dtype=torch.float32, device=dev) if O is not None else None
+    nrow = max(lib.dgdm_attn_pack_bytes(nb, H, 3) // 4, 4)
+    pk.ndelta_b = torch.empty(nrow, dtype=torch.float32, device=dev) if O is not None else None
+    pk.nlse_b = torch.empty(nrow, dtype=torch.float32, device=dev) if lse2_b is not None else None
     _lib.check(lib.dgdm_attn_pack(x.data_ptr(), x.stride(0), col0, cstride, ntensors, scale0, _lib.ptr(scale_dev),
                                   plan.ptr_dev.data_ptr(), plan.B, nb, H,
-                                  pk.R.data_ptr(), pk.T.data_ptr(), _lib.ptr(pos), _lib.ptr(pk.pos_b), _lib.ptr(O),
-                                  O.stride(0) if O is not None else 0, _lib.ptr(pk.delta_b), _lib.stream_ptr(dev)), "dgdm_attn_pack")
+                                  pk.R.data_ptr(), _lib.ptr(pk.T), t_tensor, _lib.ptr(pos), pos_scale, _lib.ptr(pk.pos_b), _lib.ptr(O),
+                                  O.stride(0) if O is not None else 0, _lib.ptr(pk.ndelta_b), _lib.ptr(lse2_b), _lib.ptr(pk.nlse_b),
+                                  _lib.stream_ptr(dev)), "dgdm_attn_pack")
     return pk
 
 
@@ -258,19 +263,20 @@ def spatial_attn_h_fwd_raw(qkv, pos, plan: AttnPlan, H: int, scale: float, inv_t
     """Split-fp16 forward over a fused [N, 3*H*16] QKV buffer; returns (out, lse2_b, packed)."""
     lib = _lib.load()
     N, C = qkv.size(0), H * 16
-    pk = packed if packed is not None else attn_pack(qkv, 0, C, 3, scale * LOG2E, plan, H, pos=pos)
+    pk = packed if packed is not None else attn_pack(qkv, 0, C, 3, scale * LOG2E, plan, H, pos=pos, pos_scale=inv_tau * LOG2E, t_tensor=2)
     out = torch.empty(N, C, dtype=torch.float32, device=qkv.device)
     lse2_b = torch.empty(max(lib.dgdm_attn_pack_bytes(plan.num_q_tiles, H, 3) // 4, 4), dtype=torch.float32, device=qkv.device)
     TIMERS.timed("attn_fwd", lambda: _lib.check(
-        lib.dgdm_spatial_attn_h_fwd(pk.r(0).data_ptr(), pk.r(1).data_ptr(), pk.t(2).data_ptr(), pk.pos_b.data_ptr(),
-                                    plan.ptr_dev.data_ptr(), plan.B, plan.num_q_tiles, H, inv_tau, drop_p, seed, out.data_ptr(),
+        lib.dgdm_spatial_attn_h_fwd(pk.r(0).data_ptr(), pk.r(1).data_ptr(), pk.T.data_ptr(), pk.pos_b.data_ptr(),
+                                    plan.ptr_dev.data_ptr(), plan.B, plan.num_q_tiles, H, drop_p, seed, out.data_ptr(),
                                     out.stride(0), lse2_b.data_ptr(), variant, _lib.stream_ptr(qkv.device)), "dgdm_spatial_attn_h_fwd"))
     return out, lse2_b, pk
 
 
 def spatial_attn_h_bwd_raw(pk: PackedOperands, out, gout, plan: AttnPlan, H: int, scale: float, inv_tau: float, lse2_b, dqkv,
                            drop_p: float = 0.0, seed: int = 0, dq_variant: int = 0, dkv_variant: int = 0):
-    """Split-fp16 backward: packs dO (+ delta), then the dQ pass and the dK/dV pass."""
+    """Split-fp16 backward: packs dO (+ -delta, 8 - lse2), then the dQ pass and the dK/dV pass.  ``inv_tau`` is already in the
+    packed positions (kept in the signature for symmetry with the fp32 twin)."""
     lib = _lib.load()
     C = H * 16
     gout = _f32c(gout)
@@ -279,41 +285,41 @@ def spatial_attn_h_bwd_raw(pk: PackedOperands, out, gout, plan: AttnPlan, H: int
     gs = torch.empty(2, dtype=torch.float32, device=out.device)
     wsb = lib.dgdm_amax_scale_workspace_bytes()
     ws = torch.empty(wsb // 4, dtype=torch.float32, device=out.device)
-    _lib.check(lib.dgdm_amax_pow2_scale(gout.data_ptr(), gout.numel(), 256.0, gs.data_ptr(), ws.data_ptr(), wsb, st), "dgdm_amax_pow2_scale")
-    gk = attn_pack(gout, 0, C, 1, 1.0, plan, H, O=out, scale_dev=gs)
+    _lib.check(lib.dgdm_amax_pow2_scale(gout.data_ptr(), gout.numel(), ATTN_GRAD_TARGET, gs.data_ptr(), ws.data_ptr(), wsb, st), "dgdm_amax_pow2_scale")
+    gk = attn_pack(gout, 0, C, 1, 1.0, plan, H, O=out, scale_dev=gs, lse2_b=lse2_b)
     TIMERS.timed("attn_bwd_dq", lambda: _lib.check(
-        lib.dgdm_spatial_attn_h_bwd_dq(pk.r(0).data_ptr(), pk.r(1).data_ptr(), pk.r(2).data_ptr(), pk.t(1).data_ptr(), gk.r(0).data_ptr(),
-                                       pk.pos_b.data_ptr(), lse2_b.data_ptr(), gk.delta_b.data_ptr(), plan.ptr_dev.data_ptr(), plan.B,
-                                       plan.num_q_tiles, H, scale, inv_tau, drop_p, seed, gs.data_ptr(), dqkv[:, :C].data_ptr(), dqkv.stride(0), dq_variant, st),
+        lib.dgdm_spatial_attn_h_bwd_dq(pk.r(0).data_ptr(), pk.r(1).data_ptr(), pk.r(2).data_ptr(), gk.r(0).data_ptr(),
+                                       pk.pos_b.data_ptr(), gk.nlse_b.data_ptr(), gk.ndelta_b.data_ptr(), plan.ptr_dev.data_ptr(), plan.B,
+                                       plan.num_q_tiles, H, scale, drop_p, seed, gs.data_ptr(), dqkv[:, :C].data_ptr(), dqkv.stride(0), dq_variant, st),
         "dgdm_spatial_attn_h_bwd_dq"))
     TIMERS.timed("attn_bwd_dkv", lambda: _lib.check(
-        lib.dgdm_spatial_attn_h_bwd_dkv(pk.r(0).data_ptr(), pk.t(0).data_ptr(), pk.r(1).data_ptr(), pk.r(2).data_ptr(), gk.r(0).data_ptr(),
-                                        gk.t(0).data_ptr(), pk.pos_b.data_ptr(), lse2_b.data_ptr(), gk.delta_b.data_ptr(),
-                                        plan.ptr_dev.data_ptr(), plan.B, plan.num_q_tiles, H, inv_tau, drop_p, seed, gs.data_ptr(),
+        lib.dgdm_spatial_attn_h_bwd_dkv(pk.r(0).data_ptr(), pk.r(1).data_ptr(), pk.r(2).data_ptr(), gk.r(0).data_ptr(),
+                                        pk.pos_b.data_ptr(), gk.nlse_b.data_ptr(), gk.ndelta_b.data_ptr(),
+                                        plan.ptr_dev.data_ptr(), plan.B, plan.num_q_tiles, H, drop_p, seed, gs.data_ptr(),
                                         dqkv[:, C:2 * C].data_ptr(), dqkv[:, 2 * C:].data_ptr(), dqkv.stride(0), dkv_variant, st),
         "dgdm_spatial_attn_h_bwd_dkv"))
     return dqkv
 
 
 class _SpatialAttentionH(torch.autograd.Function):
-    """Split-fp16 version of _SpatialAttention (same math; products on the 16-bit matrix pipe with hi+lo
-    operands).  Default attention path: ~2x faster than the fp32-MFMA kernels on gfx950 at <= 2e-4
-    relative deviation (tests/test_hip_attention.py)."""
+    """Split-fp16 version of _SpatialAttention (same math; products on the 16-bit matrix pipe with EVERY operand -- Q', K, V,
+    dO, the probabilities and dS -- carried as fp16 hi+lo pairs, fp32 accumulation).  Default attention path: ~2x faster than the
+    fp32-MFMA kernels on gfx950 at the same error against float64 (tests/test_hip_attention.py)."""
 
     @staticmethod
     def forward(ctx, qkv, pos, plan: AttnPlan, H: int, scale: float, inv_tau: float, drop_p: float, seed: int):
         qkv, pos = _f32c(qkv), _f32c(pos)
         out, lse2_b, pk = spatial_attn_h_fwd_raw(qkv, pos, plan, H, scale, inv_tau, drop_p, seed)
-        ctx.save_for_backward(out, lse2_b, pk.R, pk.T, pk.pos_b)
-        ctx.meta = (plan, H, scale, inv_tau, drop_p, seed, pk.r_stride, pk.t_stride, qkv.shape)
+        ctx.save_for_backward(out, lse2_b, pk.R, pk.pos_b)
+        ctx.meta = (plan, H, scale, inv_tau, drop_p, seed, pk.r_stride, qkv.shape)
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        out, lse2_b, R, T, pos_b = ctx.saved_tensors
-        plan, H, scale, inv_tau, drop_p, seed, rs, ts, shape = ctx.meta
+        out, lse2_b, R, pos_b = ctx.saved_tensors
+        plan, H, scale, inv_tau, drop_p, seed, rs, shape = ctx.meta
         pk = PackedOperands()
-        pk.R, pk.T, pk.pos_b, pk.delta_b, pk.ntensors, pk.r_stride, pk.t_stride = R, T, pos_b, None, 3, rs, ts
+        pk.R, pk.T, pk.pos_b, pk.ndelta_b, pk.nlse_b, pk.ntensors, pk.r_stride = R, None, pos_b, None, None, 3, rs
         dqkv = torch.empty(shape, dtype=torch.float32, device=out.device)
         spatial_attn_h_bwd_raw(pk, out, gout, plan, H, scale, inv_tau, lse2_b, dqkv, drop_p, seed)
         return dqkv, None, None, None, None, None, None, None
@@ -1028,9 +1034,13 @@ class WeightImages:
         c1 = 0 if w1 is None else w1.size(1)
         return (rows, c0 + c1) if kind == 0 else (c0, rows)        # (image columns, reduction length)
 
-    def _new(self, kind, w0, w1) -> _WImage:
+    def _new(self, kind, w0, w1, keep_srcs: bool = True) -> _WImage:
         e = _WImage()
-        e.kind, e.srcs = kind, (w0, w1)
+        # an image of a TEMPORARY (the concatenated QKV weight, a tensor with a grad_fn) lives in that tensor's own __dict__: holding
+        # the tensor here as well would close a reference cycle that keeps the temporary -- and through its grad_fn the whole
+        # autograd graph of the step, AccumulateGrad nodes included -- alive until the cyclic collector runs (the source of torch's
+        # "AccumulateGrad node's stream does not match" warning when the next step runs on another stream)
+        e.kind, e.srcs = kind, ((w0, w1) if keep_srcs else None)
         e.cols, e.k = self._dims(kind, w0, w1)
         lib = _lib.load()
         e.img = torch.empty(lib.dgdm_gemm_image_bytes(e.cols, e.k), dtype=torch.uint8, device=w0.device)
@@ -1048,8 +1058,9 @@ class WeightImages:
         b = w._base if w._base is not None else w
         return getattr(b, "_dgdm_wamax", None)
 
-    def _build_one(self, e: _WImage) -> None:
-        w0, w1 = e.srcs
+    def _build_one(self, e: _WImage, w0=None, w1=None) -> None:
+        if w0 is None:
+            w0, w1 = e.srcs
         a0 = self._param_amax(w0) or ensure_amax(w0)
         a1 = (self._param_amax(w1) or ensure_amax(w1)) if w1 is not None else None
         _lib.check(_lib.load().dgdm_gemm_image_build(
@@ -1065,8 +1076,8 @@ class WeightImages:
             key = (kind, None if w1 is None else id(w1))
             e = holder.get(key)
             if e is None or e.versions != (w0._version, None if w1 is None else w1._version) or e.epoch != self.epoch:
-                e = holder[key] = self._new(kind, w0, w1)
-                self._build_one(e)
+                e = holder[key] = self._new(kind, w0, w1, keep_srcs=False)
+                self._build_one(e, w0, w1)
             for sink in _CONSTANT_SINKS:
                 sink.append(e.img)
             return e

@@ -203,18 +203,23 @@ DGDM_API int dgdm_spatial_attn_mean_weights(const float* Q, const float* K, int6
                                             void* stream);
 
 /* K4, split-fp16 path.  Same math as dgdm_spatial_attn_fwd/_bwd, but the products run on the 16-bit
- * matrix pipe with every fp32 operand carried as hi+lo halfs (csrc/attn_h.hpp): on gfx950 the fp32
+ * matrix pipe with every fp32 operand -- Q', K, V, dO AND the probabilities P and dS the kernels form --
+ * carried as hi+lo halfs (csrc/attn_h.hpp: ~21 significand bits, fp32 accumulation): on gfx950 the fp32
  * MFMA cannot overlap with the softmax's fp32 VALU work, the fp16 MFMA can.  Operands are packed
  * once per launch into graph-block-aligned images (64 rows per block, zero padded; block count =
  * num_q_tiles of the fp32 path) that the kernels stage with direct-to-LDS DMA:
  *   row image        R[blk][H][64][32] halfs  = [hi16 | lo16] per row
  *   transposed image T[blk][H][2][16][72] halfs (part 0 hi, 1 lo; [d][row], padded row stride)
  * dgdm_attn_pack_bytes(num_blocks, H, which): buffer sizes (which: 0 R, 1 T, 2 positions
- * [blk][64][2] fp32, 3 per-row scalars [blk][H][64] fp32).
+ * [blk][2][64] fp32 (planar x | y), 3 per-row scalars [blk][H][64] fp32).
  * dgdm_attn_pack: tensor z (z < ntensors) = columns [col0 + z*cstride, +H*16) of X [N_tot, *]; tensor 0
- * is scaled by scale0 (Q: log2(e)/sqrt(d)) times *scale_dev (nullable device scalar); R/T hold ntensors images back to back.  pos/pos_b
- * (nullable pair): block-aligned key/query positions.  O/delta_b (nullable pair): delta =
- * rowsum(X_0 * O) for the backward (X_0 = dO). */
+ * is scaled by scale0 (Q: log2(e)/sqrt(d)) times *scale_dev (nullable device scalar); R holds ntensors row images back to
+ * back; T (nullable) receives the transposed image of tensor t_tensor only (the forward reads V^T; nothing else is read
+ * transposed from memory).  pos / pos_b (nullable pair): block-aligned positions TIMES pos_scale (= log2(e)/tau: the kernels
+ * add the plain Euclidean distance of these to the negated log2-domain scores).  O / ndelta_b (nullable pair): ndelta =
+ * -rowsum(X_0 * O) for the backward (X_0 = dO); lse_in / lse_out (nullable pair, only with O): lse_out = 8 - lse_in, minus the
+ * log-sum-exp the backward kernels subtract (they carry P' = 2^8 P so that the weights of a near-uniform row over 10^4..10^5
+ * keys stay inside fp16's normal range; the factor leaves with the final scale). */
 DGDM_API size_t dgdm_attn_pack_bytes(int32_t num_blocks, int32_t H, int32_t which);
 /* fp16 range guard: out2 = {alpha, 1/alpha}, alpha = 2^k with alpha*max|x| in (target/2, target] (x: n
  * contiguous floats, n % 4 == 0).  The backward is linear in dO, so dO is packed as alpha*dO (scale_dev =
@@ -224,24 +229,25 @@ DGDM_API size_t dgdm_amax_scale_workspace_bytes(void);
 DGDM_API int dgdm_amax_pow2_scale(const float* x, int64_t n, float target, float* out2, void* workspace, size_t workspace_bytes,
                                   void* stream);
 DGDM_API int dgdm_attn_pack(const float* X, int64_t ld, int32_t col0, int32_t cstride, int32_t ntensors, float scale0,
-                            const float* scale_dev, const int32_t* ptr, int32_t B, int32_t num_blocks, int32_t H, void* R, void* T, const float* pos,
-                            float* pos_b, const float* O, int64_t ldo, float* delta_b, void* stream);
-/* forward: Rq = row image of Q', Rk = row image of K, Tv = transposed image of V; O [N_tot, H*16]
- * fp32 (row stride ldo); lse2_b [blk][H][64] (log2-domain log-sum-exp, block layout). */
+                            const float* scale_dev, const int32_t* ptr, int32_t B, int32_t num_blocks, int32_t H, void* R, void* T,
+                            int32_t t_tensor, const float* pos, float pos_scale, float* pos_b, const float* O, int64_t ldo,
+                            float* ndelta_b, const float* lse_in, float* lse_out, void* stream);
+/* forward: Rq = row image of Q', Rk = row image of K, Tv = transposed image of V; pos_b as packed (pre-scaled);
+ * O [N_tot, H*16] fp32 (row stride ldo); lse2_b [blk][H][64] (log2-domain log-sum-exp, block layout). */
 DGDM_API int dgdm_spatial_attn_h_fwd(const void* Rq, const void* Rk, const void* Tv, const float* pos_b, const int32_t* ptr,
-                                     int32_t B, int32_t num_blocks, int32_t H, float inv_tau, float drop_p, uint32_t seed, float* O,
+                                     int32_t B, int32_t num_blocks, int32_t H, float drop_p, uint32_t seed, float* O,
                                      int64_t ldo, float* lse2_b, int32_t variant, void* stream);
-/* backward: Rg/Tg = images of dO and delta_b = rowsum(dO*O) from a second dgdm_attn_pack call
- * (ntensors = 1, scale0 = 1, O given); lse2_b from the forward.  dQ/dK/dV fp32 [N_tot, H*16], row
+/* backward: Rg = row image of dO, ndelta_b and lse_adj_b (= lse_out) from a second dgdm_attn_pack call
+ * (ntensors = 1, scale0 = 1, O and the forward's lse2_b given).  dQ/dK/dV fp32 [N_tot, H*16], row
  * stride ldg.  Same drop_p/seed as the forward.  grad_scale2 = the {alpha, 1/alpha} pair dO was packed
- * with (dgdm_amax_pow2_scale).  variant: tiling selector (0 = default).  Two launches, no atomics. */
-DGDM_API int dgdm_spatial_attn_h_bwd_dq(const void* Rq, const void* Rk, const void* Rv, const void* Tk, const void* Rg,
-                                        const float* pos_b, const float* lse2_b, const float* delta_b, const int32_t* ptr, int32_t B,
-                                        int32_t num_blocks, int32_t H, float scale, float inv_tau, float drop_p, uint32_t seed,
+ * with (dgdm_amax_pow2_scale, target 0.25).  variant: tiling selector (0 = default).  Two launches, no atomics. */
+DGDM_API int dgdm_spatial_attn_h_bwd_dq(const void* Rq, const void* Rk, const void* Rv, const void* Rg,
+                                        const float* pos_b, const float* lse_adj_b, const float* ndelta_b, const int32_t* ptr, int32_t B,
+                                        int32_t num_blocks, int32_t H, float scale, float drop_p, uint32_t seed,
                                         const float* grad_scale2, float* dQ, int64_t ldg, int32_t variant, void* stream);
-DGDM_API int dgdm_spatial_attn_h_bwd_dkv(const void* Rq, const void* Tq, const void* Rk, const void* Rv, const void* Rg,
-                                         const void* Tg, const float* pos_b, const float* lse2_b, const float* delta_b,
-                                         const int32_t* ptr, int32_t B, int32_t num_blocks, int32_t H, float inv_tau, float drop_p,
+DGDM_API int dgdm_spatial_attn_h_bwd_dkv(const void* Rq, const void* Rk, const void* Rv, const void* Rg,
+                                         const float* pos_b, const float* lse_adj_b, const float* ndelta_b,
+                                         const int32_t* ptr, int32_t B, int32_t num_blocks, int32_t H, float drop_p,
                                          uint32_t seed, const float* grad_scale2, float* dK, float* dV, int64_t ldg, int32_t variant,
                                          void* stream);
 

@@ -546,10 +546,19 @@ def _ptr_from_batch(batch: Optional[Tensor], n: int) -> List[int]:
 def forward(P, cfg: OracleConfig, data, mode: str = "inference", *, training: bool = False,
             timesteps: Optional[Tensor] = None, noise: Optional[Tensor] = None,
             noise_target: Optional[Tensor] = None, return_attention=False, return_embeddings=False,
-            trace: Optional[dict] = None) -> Dict[str, Tensor]:
+            trace: Optional[dict] = None, stages: Optional[dict] = None) -> Dict[str, Tensor]:
     """DGDMModel.forward + _forward_continue + _compute_diffusion_loss
     (models/dgdm_model.py:271-445) with R1-R5.  ``timesteps`` [B], ``noise`` and
-    ``noise_target`` [N_tot, C] are the injected random draws (pretrain mode)."""
+    ``noise_target`` [N_tot, C] are the injected random draws (pretrain mode).  ``stages``: dict that
+    receives the forward wall time per stage in seconds (bench.py's CPU baseline split)."""
+    import time
+    _t0 = [time.perf_counter()]
+
+    def _stage(name):
+        if stages is not None:
+            now = time.perf_counter()
+            stages[name] = stages.get(name, 0.0) + now - _t0[0]
+            _t0[0] = now
     x = data.x
     dtype = x.dtype
     n = x.shape[0]
@@ -561,9 +570,12 @@ def forward(P, cfg: OracleConfig, data, mode: str = "inference", *, training: bo
     H = cfg.attention_heads
     out: Dict[str, Tensor] = {}
 
+    _stage("graph_structure")
     h = feature_encoder(P, x, cfg.dropout, training)
+    _stage("feature_encoder")
     if trace is not None: trace["feature_encoder"] = h
     h, layer_outs = graph_encoder(P, cfg, h, graph, ea_ext, training)
+    _stage("graph_encoder")
     if trace is not None:
         trace["graph_encoder"] = h
         for i, lo in enumerate(layer_outs): trace[f"graph_encoder.layer{i}"] = lo
@@ -576,11 +588,13 @@ def forward(P, cfg: OracleConfig, data, mode: str = "inference", *, training: bo
             o, w = spatial_attention_graph(P, h[ptr[g]:ptr[g + 1]], pos[ptr[g]:ptr[g + 1]], H, 1.0, cfg.dropout, training)
             outs.append(o); attn_w.append(w)
         h = torch.cat(outs, dim=0)
+        _stage("spatial_attention")
         if trace is not None: trace["spatial_attention"] = h
 
     if cfg.use_hierarchical:
         ea_for_unet = edge_attr if edge_attr is not None else None
         h = graph_unet(P, cfg, h, data.edge_index, ea_for_unet, training, trace=trace)
+        _stage("graph_unet")
         if trace is not None: trace["graph_unet"] = h
 
     if mode == "pretrain":
@@ -601,6 +615,7 @@ def forward(P, cfg: OracleConfig, data, mode: str = "inference", *, training: bo
             losses.append(F.mse_loss(pred, target.to(dtype)))
         out["diffusion_loss"] = torch.stack(losses).mean()
         out["noisy_embeddings"] = noisy.unsqueeze(0)  # last graph's, [1,N_g,C] (dgdm_model.py:442-445)
+        _stage("diffusion")
 
     if cfg.pooling == "attention":
         out["graph_embedding"] = attention_pool(P, h, ptr, H, 0.1, training)
@@ -610,6 +625,7 @@ def forward(P, cfg: OracleConfig, data, mode: str = "inference", *, training: bo
         out["graph_embedding"] = torch.stack([h[ptr[g]:ptr[g + 1]].max(0)[0] for g in range(B)])
     else:
         raise ValueError(cfg.pooling)
+    _stage("pool")
     g = out["graph_embedding"]
     if cfg.num_classes is not None and mode in ("inference", "finetune"):      # dgdm_model.py:383-391
         out["classification_logits"] = classification_head(P, g, cfg.activation, cfg.dropout, training)
