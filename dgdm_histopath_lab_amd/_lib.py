@@ -31,7 +31,10 @@ SIGNATURES = {
     "dgdm_csr_build": (C.c_int, [_p, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _sz, _p]),
     "dgdm_csr_build_pair_workspace_bytes": (_sz, [_i64, _i32, _i32]),
     "dgdm_csr_build_pair_status_offset": (_sz, [_i64, _i32, _i32]),
-    "dgdm_csr_build_pair": (C.c_int, [_p, _i64, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "dgdm_csr_build_pair": (C.c_int, [_p, _i64, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p, _p, _i32, _p]),
+    "dgdm_spmm_long_item_cap": (_i32, [_i64]),
+    "dgdm_spmm_long_slot_cap": (_i32, [_i64]),
+    "dgdm_spmm_long_table_words": (_sz, [_i64]),
     "dgdm_gcn_dinv": (C.c_int, [_p, _i32, _p, _p]),
     "dgdm_csr_edge_weights": (C.c_int, [_p, _p, _p, _i32, _p, _p]),
     "dgdm_spatial_attn_q_tile_rows": (_i32, []),
@@ -114,7 +117,7 @@ SIGNATURES = {
     "dgdm_attn_pack_bytes": (_sz, [_i32, _i32, _i32]),
     "dgdm_amax_scale_workspace_bytes": (_sz, []),
     "dgdm_amax_pow2_scale": (C.c_int, [_p, _i64, C.c_float, _p, _p, _sz, _p]),
-    "dgdm_attn_pack": (C.c_int, [_p, _i64, _i32, _i32, _i32, C.c_float, _p, _p, _i32, _i32, _i32, _p, _p, _i32, _p, C.c_float, _p, _p, _i64,
+    "dgdm_attn_pack": (C.c_int, [_p, _i64, _i32, _i32, _i32, C.c_float, _p, _p, _i32, _i32, _i32, _p, _p, C.c_float, _p, _p, _i64,
                                  _p, _p, _p, _p]),
     "dgdm_spatial_attn_h_fwd": (C.c_int, [_p, _p, _p, _p, _p, _i32, _i32, _i32, C.c_float, C.c_uint32, _p, _i64, _p, _i32, _p]),
     "dgdm_spatial_attn_h_bwd_dq": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, C.c_float, C.c_float,
@@ -126,9 +129,9 @@ SIGNATURES = {
     "dgdm_gemm_image_build_many": (C.c_int, [_p, _i32, _i32, _p]),
     "dgdm_gemm_image_build": (C.c_int, [_p, _i64, _p, _i64, _p, _p, _p, _i32, _i32, _i32, _i32, _p]),
     "dgdm_gemm_rows_img": (C.c_int, [_p, _i64, _i32, _i32, _p, _i32, _i32, _i32, _p, _p, _i64, _i32, _p, _p]),
-    "dgdm_spmm": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _p, _i64, _i32, _i32, _p, _i32, _p]),
-    "dgdm_spmm_add": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _p, _i64, _p, _i64, _i32, _i32, _p]),
-    "dgdm_spmm_concat": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _p, _i64, _i32, _p, _i64, _i32, _i32, _p, _p]),
+    "dgdm_spmm": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _p, _i64, _i32, _i32, _p, _i32, _p, _p]),
+    "dgdm_spmm_add": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _p, _i64, _p, _i64, _i32, _i32, _p, _p]),
+    "dgdm_spmm_concat": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _p, _i64, _i32, _p, _i64, _i32, _i32, _p, _p, _p]),
 }
 
 class TnReduce(C.Structure):
@@ -147,6 +150,11 @@ class TnPartial(C.Structure):
 
 
 TN_PARTIAL_MAX = 24
+
+
+class LongRows(C.Structure):
+    """struct DgdmLongRows of include/dgdm_hip.h (a HOST struct holding device pointers)"""
+    _fields_ = [("table", _p), ("partial", _p), ("ld", _i64), ("item_cap", _i32), ("slot_cap", _i32)]
 
 _lib: Optional[C.CDLL] = None
 

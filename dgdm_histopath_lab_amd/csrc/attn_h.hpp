@@ -16,12 +16,18 @@
 //
 // Packed operand images (written once per launch by k_attn_pack, graph-block aligned: block b of
 // graph g holds its rows 64*b .. 64*b+63, rows past the graph end are zero), all in halfs:
-//   row image   R[blk][H][64][32]        [hi16 | lo16] per row (64 B)     -- A operand with the row
-//                                          on the MFMA row, or per-lane B operands (load_b_pair)
-//   transposed  T[blk][H][2][16][72]     part 0 = hi, 1 = lo; [d][row], row stride 72 halfs (144 B)
-//                                          so the 8-byte reads of a 32-lane group hit distinct banks
-// Both are straight, contiguous byte ranges per (block, head group), so the attention kernels stage
-// them with direct-to-LDS DMA (global_load_lds_dwordx4: no VGPRs, no VALU), double-buffered.
+//   row image   R[blk][H][4 tiles][4 chunks][16][8]   per row 16 hi | 16 lo halfs, stored CHUNK-major inside a 16-row tile:
+//                                          chunk 0 / 1 = hi[0..7] / hi[8..15], chunk 2 / 3 = lo[0..7] / lo[8..15]; the 16-byte
+//                                          chunk of row j sits at position j (even chunks) or j ^ 12 (odd chunks) of its 256-byte
+//                                          chunk block (r_off).  With this order both reads of the kernels are free of LDS bank
+//                                          conflicts: the row read (ds_read_b128, lane (j, G) takes chunk G of row j -- A operand
+//                                          with the row on the MFMA row) sees 16 distinct 16-byte slots in every lane group, and the
+//                                          transposed read (ds_read_b64_tr_b16, load_tr_pair) finds the two chunks of a 32-lane half
+//                                          on opposite halves of the banks.  Plain 64-byte rows made the first 2-way and the second
+//                                          2-way conflicted (cdna_hip_programming.md T10): twice the LDS cycles for every fragment.
+// A (block, head group) is one straight, contiguous byte range, so the attention kernels stage it with direct-to-LDS DMA
+// (global_load_lds_dwordx4: no VGPRs, no VALU).  Operands whose reduction index is the ROW (V^T in the forward, K^T / Q'^T / dO^T
+// in the backward) are read out of the same image with transposed LDS reads (load_tr_pair): there is no transposed image.
 #pragma once
 #include "attn_common.hpp"
 
@@ -30,19 +36,20 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int HB = 64;                 // rows per packed block
 constexpr int R_HEAD = HB * 32;        // halfs per (block, head) in a row image      (4096 B)
-constexpr int T_STRIDE = HB + 8;       // halfs per d-row of a transposed image
-constexpr int T_PART = 16 * T_STRIDE;  // halfs per (block, head, part)
-constexpr int T_HEAD = 2 * T_PART;     // halfs per (block, head) in a transposed image (4608 B)
 
 __device__ __forceinline__ f32x4 mfma_h(f16x8 a, f16x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 
-// B-operand registers of a packed 16-wide row [hi16 | lo16]: lane group G reads hi[8*(G&1) .. +7]
-// for B1 and lo[8*(G&1) .. +7] for B2.
-__device__ __forceinline__ void load_b_pair(const _Float16* __restrict__ packed_row, int G, f16x8* b1, f16x8* b2) {
-  *b1 = *reinterpret_cast<const f16x8*>(packed_row + 8 * (G & 1));
-  *b2 = *reinterpret_cast<const f16x8*>(packed_row + 16 + 8 * (G & 1));
+// offset (halfs) of chunk c (0..3) of row `row` (0..63) inside the row image of one (block, head)
+__device__ __forceinline__ int r_off(int row, int c) { return (row >> 4) * 512 + c * 128 + 8 * ((row & 15) ^ (12 * (c & 1))); }
+// the row read of lane (j, G) for tile t: chunk G of row 16 t + j  (add t * 512)
+__device__ __forceinline__ int r_lane_off(int j, int G) { return G * 128 + 8 * (j ^ (12 * (G & 1))); }
+
+// B-operand registers of row `row` of a (block, head) row image: lane group G takes hi[8*(G&1) .. +7] for B1 and lo[8*(G&1) .. +7] for B2.
+__device__ __forceinline__ void load_b_pair(const _Float16* __restrict__ img_head, int row, int G, f16x8* b1, f16x8* b2) {
+  *b1 = *reinterpret_cast<const f16x8*>(img_head + r_off(row, G & 1));
+  *b2 = *reinterpret_cast<const f16x8*>(img_head + r_off(row, 2 + (G & 1)));
 }
 
 // 8 fp32 values (two accumulator quads) -> 8 halfs (B operand of the following product)
@@ -122,28 +129,22 @@ __device__ __forceinline__ f32x4 sub4(float a, const f32x4 b) {
 // log-sum-exp the kernels subtract, taken out again with the final scale: no instruction.
 #define DGDM_ATTN_P_SHIFT 8.0f
 
-// A operand of a transposed image for the tile pair (t0, t0+1): rows 16*t0 + 4G .. +3 and
-// 16*(t0+1) + 4G .. +3 of d-row `d` (two 8-byte LDS reads).
-__device__ __forceinline__ f16x8 load_t_pair(const _Float16* __restrict__ timg_part_head, int d, int t0, int G) {
-  const f16x4 a = *reinterpret_cast<const f16x4*>(timg_part_head + d * T_STRIDE + 16 * t0 + 4 * G);
-  const f16x4 b = *reinterpret_cast<const f16x4*>(timg_part_head + d * T_STRIDE + 16 * (t0 + 1) + 4 * G);
-  return f16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-}
-
-// The same A operand (tile pair t0, t0+1 of a [d][row] matrix, lane (d = j, G) holding rows 16*t0 + 4G .. +3 and 16*(t0+1) + 4G .. +3)
-// read TRANSPOSED out of the ROW image in LDS (64 B per row: 16 hi halfs | 16 lo halfs; `part` 0 = hi, 1 = lo) with gfx950's
+// A operand for the tile pair (t0, t0+1) of a [d][row] matrix, lane (d = j, G) holding rows 16*t0 + 4G .. +3 and 16*(t0+1) + 4G .. +3,
+// read TRANSPOSED out of the ROW image in LDS (chunk-major tiles, r_off; `part` 0 = hi, 1 = lo) with gfx950's
 // ds_read_b64_tr_b16: per group of 16 lanes a block of 4 rows x 16 halfs, lane 4q + p of the group supplies the address of row q,
 // halfs 4p .. 4p+3, lane i receives column i of the 4 rows.  A kernel that reads its transposed operands this way needs no
-// transposed image staged at all: half the LDS-DMA pieces per block and half the LDS footprint.  (Two-way bank conflict: the rows
-// r and r + 4 of a 32-lane half share banks at the 64-byte row pitch.)  EXEC must be all ones (no divergence around the call).
+// transposed image staged at all: half the LDS-DMA pieces per block and half the LDS footprint.  Conflict-free on the chunk-major
+// image (a 32-lane half reads rows 8n .. 8n+7 of two adjacent chunks: the odd chunk's rows sit 8 positions away).  EXEC must be
+// all ones (no divergence around the call).
 __device__ __forceinline__ f16x8 load_tr_pair(const _Float16* __restrict__ rimg_head, int part, int t0, int lane) {
   typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
   typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
   typedef short s16x8 __attribute__((__vector_size__(8 * sizeof(short))));
   const int j = lane & 15, G = lane >> 4;
-  const _Float16* p = rimg_head + (16 * t0 + 4 * G + (j >> 2)) * 32 + 16 * part + 4 * (j & 3);
+  // lane 4q + p of a 16-lane group supplies the address of row 4G + q, halfs 4p .. 4p+3 of the 16-half part: chunk 2 part + (p >> 1)
+  const _Float16* p = rimg_head + t0 * 512 + r_off(4 * G + (j >> 2), 2 * part + ((j & 3) >> 1)) + 4 * (j & 1);
   const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p);
-  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 16 * 32));
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 512));
   const s16x8 r = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
   return __builtin_bit_cast(f16x8, r);
 }

@@ -78,8 +78,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
 #pragma unroll
   for (int h = 0; h < HG; ++h) {
     const int64_t rowoff = (((int64_t)blockIdx.x * H + head0 + h) * HB + q_in_blk);
-    load_b_pair(Rq + rowoff * 32, G, &qb1[h], &qb2[h]);
-    load_b_pair(Rg + rowoff * 32, G, &gb1[h], &gb2[h]);
+    const int64_t imgoff = ((int64_t)blockIdx.x * H + head0 + h) * R_HEAD;
+    load_b_pair(Rq + imgoff, q_in_blk, G, &qb1[h], &qb2[h]);
+    load_b_pair(Rg + imgoff, q_in_blk, G, &gb1[h], &gb2[h]);
     if (DROP) scale_b_pair(&gb1[h], &gb2[h], dc.keep);
     nl2[h] = lse_b[rowoff];
     ndl[h] = ndelta_b[rowoff];
@@ -87,6 +88,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
     if (DROP) dl[h] = DropLaneQ(DropHead(seed, n0, head0 + h), q_local);
   }
   const uint32_t lck = __umul24(2u * (uint32_t)G, DROP_CK);
+  const int aoff = r_lane_off(j, G);
   const float px = pos_b[((int64_t)blockIdx.x * 2 + 0) * HB + q_in_blk], py = pos_b[((int64_t)blockIdx.x * 2 + 1) * HB + q_in_blk];
   __syncthreads();
 
@@ -117,8 +119,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
       const f32x4 cdl = {ndl[h], ndl[h], ndl[h], ndl[h]};
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        const f16x8 kf = *reinterpret_cast<const f16x8*>(Kimg + h * R_HEAD + (16 * t + j) * 32 + 8 * G);
-        const f16x8 vf = *reinterpret_cast<const f16x8*>(Vimg + h * R_HEAD + (16 * t + j) * 32 + 8 * G);
+        const f16x8 kf = *reinterpret_cast<const f16x8*>(Kimg + h * R_HEAD + t * 512 + aoff);
+        const f16x8 vf = *reinterpret_cast<const f16x8*>(Vimg + h * R_HEAD + t * 512 + aoff);
         f32x4 s = mfma_h(kf, qb1[h], sub4(nl2[h], dist[t]));  // S'^T - dist - lse2 + 8
         s = mfma_h(kf, qb2[h], s);
         f32x4 dp = mfma_h(vf, gb1[h], cdl);              // keep * dP^T - delta
@@ -206,15 +208,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
   DropLaneK dl[HG];
 #pragma unroll
   for (int h = 0; h < HG; ++h) {
-    const int64_t rowoff = (((int64_t)blockIdx.x * H + head0 + h) * HB + k_in_blk);
-    load_b_pair(Rk + rowoff * 32, G, &kb1[h], &kb2[h]);
-    load_b_pair(Rv + rowoff * 32, G, &vb1[h], &vb2[h]);
+    const int64_t imgoff = ((int64_t)blockIdx.x * H + head0 + h) * R_HEAD;
+    load_b_pair(Rk + imgoff, k_in_blk, G, &kb1[h], &kb2[h]);
+    load_b_pair(Rv + imgoff, k_in_blk, G, &vb1[h], &vb2[h]);
     if (DROP) scale_b_pair(&vb1[h], &vb2[h], dc.keep);
     dk[h] = f32x4{0.f, 0.f, 0.f, 0.f};
     dv[h] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (DROP) dl[h] = DropLaneK(DropHead(seed, n0, head0 + h), k_local);
   }
   const uint32_t lcq = __umul24(2u * (uint32_t)G, DROP_CQ);
+  const int aoff = r_lane_off(j, G);
   const float px = pos_b[((int64_t)blockIdx.x * 2 + 0) * HB + k_in_blk], py = pos_b[((int64_t)blockIdx.x * 2 + 1) * HB + k_in_blk];
   __syncthreads();
 
@@ -250,8 +253,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
       f32x4 p[NT], ds[NT];
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        const f16x8 qa = *reinterpret_cast<const f16x8*>(Qimg + h * R_HEAD + (16 * t + j) * 32 + 8 * G);
-        const f16x8 ga = *reinterpret_cast<const f16x8*>(Gimg + h * R_HEAD + (16 * t + j) * 32 + 8 * G);
+        const f16x8 qa = *reinterpret_cast<const f16x8*>(Qimg + h * R_HEAD + t * 512 + aoff);
+        const f16x8 ga = *reinterpret_cast<const f16x8*>(Gimg + h * R_HEAD + t * 512 + aoff);
         const f32x4 lq = *reinterpret_cast<const f32x4*>(&Ls[h * HB + 16 * t + 4 * G]);
         const f32x4 nd = *reinterpret_cast<const f32x4*>(&Ds[h * HB + 16 * t + 4 * G]);
         f32x4 s = mfma_h(qa, kb1[h], sub4(lq, dist[t]));   // S'[q][key] - dist - lse2[q] + 8   (lq = 8 - lse2)

@@ -7,8 +7,8 @@
 //       positions pre-scaled by log2(e)/tau)
 //       O^T += V^T_hi.P_hi + V^T_lo.P_hi + V^T_hi.P_lo     (P = exp2(S' - m) carried as fp16 hi+lo like every operand)
 //     so the matrix work overlaps with the softmax VALU work (the fp32 MFMA cannot);
-//   * K / V^T / key positions are pre-packed, block-aligned images staged by direct-to-LDS DMA into a
-//     double buffer: no staging VGPRs, no staging VALU, one barrier per key block;
+//   * K / V / key positions are pre-packed, block-aligned images staged by direct-to-LDS DMA: no staging VGPRs, no staging
+//     VALU; V^T fragments are read out of V's ROW image with transposed LDS reads (ds_read_b64_tr_b16);
 //   * lazy running maximum: the cross-lane max exchange (two LDS round trips) and the rescale of
 //     O / l only happen when some lane's block maximum exceeds the running maximum by > 2^LAZY_THR.
 #include "attn_h.hpp"
@@ -52,11 +52,10 @@ __global__ __launch_bounds__(256) void k_amax_final(const float* __restrict__ pa
 
 __global__ __launch_bounds__(256) void k_attn_pack(const float* __restrict__ X, int64_t ld, int col0, int cstride, float scale0,
                                                    const float* __restrict__ scale_dev, const int32_t* __restrict__ ptr, int B, int H, _Float16* __restrict__ R,
-                                                   int64_t r_tensor_stride, _Float16* __restrict__ Tt, int t_tensor,
+                                                   int64_t r_tensor_stride,
                                                    const float* __restrict__ pos, float pos_scale, float* __restrict__ pos_b,
                                                    const float* __restrict__ Oin, int64_t ldo, float* __restrict__ ndelta_b,
                                                    const float* __restrict__ lse_in, float* __restrict__ lse_out) {
-  __shared__ __attribute__((aligned(16))) _Float16 sm[2][16][T_STRIDE];
   const int blk = blockIdx.x, h = blockIdx.y, z = blockIdx.z;
   int n0, ng, lblk, blk0;
   if (!find_block(ptr, B, blk, &n0, &ng, &lblk, &blk0)) return;
@@ -67,20 +66,15 @@ __global__ __launch_bounds__(256) void k_attn_pack(const float* __restrict__ X, 
   const float scale = (z == 0 ? scale0 : 1.0f) * (scale_dev ? scale_dev[0] : 1.0f);
   const float4 v = *reinterpret_cast<const float4*>(X + node * ld + col0 + z * cstride + h * 16 + part * 4);
   const float x[4] = {ok ? v.x * scale : 0.f, ok ? v.y * scale : 0.f, ok ? v.z * scale : 0.f, ok ? v.w * scale : 0.f};
-  const bool want_t = Tt != nullptr && z == t_tensor;
   f16x4 hi, lo;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     hi[e] = (_Float16)x[e];
     lo[e] = (_Float16)(x[e] - (float)hi[e]);
-    if (want_t) {
-      sm[0][part * 4 + e][row] = hi[e];
-      sm[1][part * 4 + e][row] = lo[e];
-    }
   }
-  _Float16* rrow = R + z * r_tensor_stride + (((int64_t)blk * H + h) * HB + row) * 32;
-  *reinterpret_cast<f16x4*>(rrow + part * 4) = hi;
-  *reinterpret_cast<f16x4*>(rrow + 16 + part * 4) = lo;
+  _Float16* rimg = R + z * r_tensor_stride + ((int64_t)blk * H + h) * R_HEAD;      // chunk-major tiles (attn_h.hpp, r_off)
+  *reinterpret_cast<f16x4*>(rimg + r_off(row, part >> 1) + 4 * (part & 1)) = hi;
+  *reinterpret_cast<f16x4*>(rimg + r_off(row, 2 + (part >> 1)) + 4 * (part & 1)) = lo;
   if (Oin) {  // -delta = -rowsum(dO * O) (attention backward: C input of the dP products), block layout [blk][H][64]
     const float4 o = *reinterpret_cast<const float4*>(Oin + node * ldo + h * 16 + part * 4);
     float d = x[0] * o.x + x[1] * o.y + x[2] * o.z + x[3] * o.w;
@@ -98,22 +92,16 @@ __global__ __launch_bounds__(256) void k_attn_pack(const float* __restrict__ X, 
     pos_b[((int64_t)blk * 2 + 0) * HB + tid] = r2 < ng ? p.x * pos_scale : 0.f;
     pos_b[((int64_t)blk * 2 + 1) * HB + tid] = r2 < ng ? p.y * pos_scale : 0.f;
   }
-  if (!want_t) return;     // uniform per workgroup
-  __syncthreads();
-  const int d = tid >> 4, rc = tid & 15;
-  _Float16* tb = Tt + ((int64_t)blk * H + h) * T_HEAD;
-  *reinterpret_cast<f16x4*>(tb + d * T_STRIDE + 4 * rc) = *reinterpret_cast<const f16x4*>(&sm[0][d][4 * rc]);
-  *reinterpret_cast<f16x4*>(tb + T_PART + d * T_STRIDE + 4 * rc) = *reinterpret_cast<const f16x4*>(&sm[1][d][4 * rc]);
 }
 
 template <int HG, bool DROP, int NBUF = 2, int WPE = 2>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) void k_attn_h_fwd(const _Float16* __restrict__ Rq, const _Float16* __restrict__ Rk,
-                                                    const _Float16* __restrict__ Tv, const float* __restrict__ pos_b, int H,
+                                                    const _Float16* __restrict__ Rv, const float* __restrict__ pos_b, int H,
                                                     const int32_t* __restrict__ ptr, int B, float* __restrict__ O,
                                                     int64_t ldo, float* __restrict__ lse2_b, float drop_p, DgdmSeed seed_in) {
   const uint32_t seed = seed_in.value();
   constexpr int NT = HB / 16;
-  constexpr int RK_BYTES = HG * R_HEAD * 2, TV_BYTES = HG * T_HEAD * 2, POS_BYTES = HB * 8;
+  constexpr int RK_BYTES = HG * R_HEAD * 2, TV_BYTES = RK_BYTES, POS_BYTES = HB * 8;      // K and V row images (V^T is read transposed)
   constexpr int BUF_BYTES = RK_BYTES + TV_BYTES + POS_BYTES;
   __shared__ __attribute__((aligned(16))) char smem[NBUF * BUF_BYTES];
   const DropCfg dc(drop_p);
@@ -132,7 +120,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
     const int64_t gb = (int64_t)(blk0 + kb) * H + head0;
     char* base = smem + buf * BUF_BYTES;
     dma_to_lds<RK_BYTES>(Rk + gb * R_HEAD, base, tid);
-    dma_to_lds<TV_BYTES>(Tv + gb * T_HEAD, base + RK_BYTES, tid);
+    dma_to_lds<TV_BYTES>(Rv + gb * R_HEAD, base + RK_BYTES, tid);
     dma_to_lds<POS_BYTES>(pos_b + (int64_t)(blk0 + kb) * HB * 2, base + RK_BYTES + TV_BYTES, tid);
   };
   stage(0, 0);
@@ -145,11 +133,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
   const f16x8 ones = {one, one, one, one, one, one, one, one};
 #pragma unroll
   for (int h = 0; h < HG; ++h) {
-    load_b_pair(Rq + (((int64_t)blockIdx.x * H + head0 + h) * HB + q_in_blk) * 32, G, &qb1[h], &qb2[h]);
+    load_b_pair(Rq + ((int64_t)blockIdx.x * H + head0 + h) * R_HEAD, q_in_blk, G, &qb1[h], &qb2[h]);
     oacc[h] = f32x4{0.f, 0.f, 0.f, 0.f}; lacc[h] = f32x4{0.f, 0.f, 0.f, 0.f}; m[h] = NEG_BIG;
     if (DROP) dl[h] = DropLaneQ(DropHead(seed, n0, head0 + h), q_local);
   }
   const uint32_t lck = __umul24(2u * (uint32_t)G, DROP_CK);
+  const int aoff = r_lane_off(j, G);
   const float px = pos_b[((int64_t)blockIdx.x * 2 + 0) * HB + q_in_blk], py = pos_b[((int64_t)blockIdx.x * 2 + 1) * HB + q_in_blk];
   __syncthreads();  // block 0 landed (vmcnt(0) + barrier)
 
@@ -179,7 +168,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
       f32x4 s[NT];
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        const f16x8 kf = *reinterpret_cast<const f16x8*>(Kimg + h * R_HEAD + (16 * t + j) * 32 + 8 * G);
+        const f16x8 kf = *reinterpret_cast<const f16x8*>(Kimg + h * R_HEAD + t * 512 + aoff);
         s[t] = mfma_h(kf, qb1[h], ndist[t]);
         s[t] = mfma_h(kf, qb2[h], s[t]);
       }
@@ -205,7 +194,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
 #pragma unroll
         for (int r = 0; r < 4; ++r) s[t][r] = __builtin_amdgcn_exp2f(s[t][r]);
       }
-      const _Float16* vh = Vimg + h * T_HEAD;
+      const _Float16* vh = Vimg + h * R_HEAD;
 #pragma unroll
       for (int tp = 0; tp < NT / 2; ++tp) {
         // the softmax denominator is summed from the same hi+lo weights that multiply V, on the matrix pipe (ones . P): no VALU
@@ -226,9 +215,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
           ph = __builtin_bit_cast(f16x8, __builtin_bit_cast(u32x4, ph) & mk);
           pl = __builtin_bit_cast(f16x8, __builtin_bit_cast(u32x4, pl) & mk);
         }
-        const f16x8 vhi = load_t_pair(vh, j, 2 * tp, G);
+        const f16x8 vhi = load_tr_pair(vh, 0, 2 * tp, lane);                     // V^T[d = j][keys of the tile pair], out of the row image
         oacc[h] = mfma_h(vhi, ph, oacc[h]);
-        oacc[h] = mfma_h(load_t_pair(vh + T_PART, j, 2 * tp, G), ph, oacc[h]);   // lo part of V: same accumulator
+        oacc[h] = mfma_h(load_tr_pair(vh, 1, 2 * tp, lane), ph, oacc[h]);        // lo part of V: same accumulator
         oacc[h] = mfma_h(vhi, pl, oacc[h]);                                      // lo part of P (V_lo . P_lo ~ 2^-22: dropped)
       }
     }
@@ -255,19 +244,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
 }  // namespace
 
 extern "C" size_t dgdm_attn_pack_bytes(int32_t num_blocks, int32_t H, int32_t which) {
-  // which: 0 = row image, 1 = transposed image, 2 = [blk][64][2] positions, 3 = [blk][H][64] fp32 per-row scalars
+  // which: 0 = row image, 2 = [blk][2][64] positions, 3 = [blk][H][64] fp32 per-row scalars
   const size_t nb = num_blocks > 0 ? num_blocks : 0, h = H > 0 ? H : 0;
   switch (which) {
     case 0: return nb * h * R_HEAD * 2;
-    case 1: return nb * h * T_HEAD * 2;
     case 2: return nb * HB * 2 * sizeof(float);
     case 3: return nb * h * HB * sizeof(float);
     default: return 0;
   }
 }
 
-// Packs `ntensors` column blocks of X (tensor z = columns [col0 + z*cstride, +H*16)) into row images (and a transposed image of
-// tensor `t_tensor` when T is given); tensor 0 is scaled by scale0.  pos_b (nullable): block-aligned positions, planar, times
+// Packs `ntensors` column blocks of X (tensor z = columns [col0 + z*cstride, +H*16)) into row images; tensor 0 is scaled by scale0.  pos_b (nullable): block-aligned positions, planar, times
 // pos_scale.  O (nullable): when given, ndelta_b[blk][H][64] = -rowsum(X_0 * O) (X_0 = dO in the backward) and, with lse_in /
 // lse_out, lse_out = DGDM_ATTN_P_SHIFT - lse_in.
 extern "C" size_t dgdm_amax_scale_workspace_bytes(void) { return 1024 * sizeof(float); }
@@ -289,35 +276,34 @@ extern "C" int dgdm_amax_pow2_scale(const float* x, int64_t n, float target, flo
 }
 
 extern "C" int dgdm_attn_pack(const float* X, int64_t ld, int32_t col0, int32_t cstride, int32_t ntensors, float scale0,
-                              const float* scale_dev, const int32_t* ptr, int32_t B, int32_t num_blocks, int32_t H, void* R, void* T,
-                              int32_t t_tensor, const float* pos, float pos_scale, float* pos_b, const float* O, int64_t ldo,
+                              const float* scale_dev, const int32_t* ptr, int32_t B, int32_t num_blocks, int32_t H, void* R,
+                              const float* pos, float pos_scale, float* pos_b, const float* O, int64_t ldo,
                               float* ndelta_b, const float* lse_in, float* lse_out, void* stream) {
   DGDM_REQUIRE(B >= 0 && num_blocks >= 0 && H > 0 && ntensors > 0 && ntensors <= 4);
   if (num_blocks == 0 || B == 0) return DGDM_OK;
   DGDM_REQUIRE(X && ptr && R);
-  DGDM_REQUIRE(T == nullptr || (t_tensor >= 0 && t_tensor < ntensors));
   DGDM_REQUIRE((pos == nullptr) == (pos_b == nullptr) && (O == nullptr) == (ndelta_b == nullptr));
   DGDM_REQUIRE((lse_in == nullptr) == (lse_out == nullptr) && (lse_out == nullptr || O != nullptr));
-  if ((ld & 3) || (col0 & 3) || (cstride & 3) || !dgdm_aligned16(X) || !dgdm_aligned16(R) || (T && !dgdm_aligned16(T)) ||
+  if ((ld & 3) || (col0 & 3) || (cstride & 3) || !dgdm_aligned16(X) || !dgdm_aligned16(R) ||
       (O && ((ldo & 3) || !dgdm_aligned16(O))))
     return DGDM_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(k_attn_pack, dim3(num_blocks, H, ntensors), dim3(256), 0, static_cast<hipStream_t>(stream), X, ld, col0, cstride,
-                     scale0, scale_dev, ptr, B, H, static_cast<_Float16*>(R), (int64_t)num_blocks * H * R_HEAD, static_cast<_Float16*>(T),
-                     t_tensor, pos, pos_scale, pos_b, O, ldo, ndelta_b, lse_in, lse_out);
+                     scale0, scale_dev, ptr, B, H, static_cast<_Float16*>(R), (int64_t)num_blocks * H * R_HEAD,
+                     pos, pos_scale, pos_b, O, ldo, ndelta_b, lse_in, lse_out);
   return dgdm_launch_status();
 }
 
-extern "C" int dgdm_spatial_attn_h_fwd(const void* Rq, const void* Rk, const void* Tv, const float* pos_b, const int32_t* ptr,
+extern "C" int dgdm_spatial_attn_h_fwd(const void* Rq, const void* Rk, const void* Rv, const float* pos_b, const int32_t* ptr,
                                        int32_t B, int32_t num_blocks, int32_t H, float drop_p, uint32_t seed, float* O,
                                        int64_t ldo, float* lse2_b, int32_t variant, void* stream_) {
   DGDM_REQUIRE(B >= 0 && H > 0 && num_blocks >= 0 && drop_p >= 0.f && drop_p < 1.f);
   if (num_blocks == 0 || B == 0) return DGDM_OK;
-  DGDM_REQUIRE(Rq && Rk && Tv && pos_b && ptr && O && lse2_b);
-  if ((ldo & 3) || ldo < H * 16 || !dgdm_aligned16(Rq) || !dgdm_aligned16(Rk) || !dgdm_aligned16(Tv) || !dgdm_aligned16(O) ||
+  DGDM_REQUIRE(Rq && Rk && Rv && pos_b && ptr && O && lse2_b);
+  if ((ldo & 3) || ldo < H * 16 || !dgdm_aligned16(Rq) || !dgdm_aligned16(Rk) || !dgdm_aligned16(Rv) || !dgdm_aligned16(O) ||
       !dgdm_aligned16(pos_b))
     return DGDM_ERR_UNSUPPORTED;
   hipStream_t s = static_cast<hipStream_t>(stream_);
-  const _Float16 *q = static_cast<const _Float16*>(Rq), *k = static_cast<const _Float16*>(Rk), *v = static_cast<const _Float16*>(Tv);
+  const _Float16 *q = static_cast<const _Float16*>(Rq), *k = static_cast<const _Float16*>(Rk), *v = static_cast<const _Float16*>(Rv);
 #define GO(HG, NBUF, WPE)                                                                                                   \
   do {                                                                                                                      \
     if (drop_p > 0.f)                                                                                                       \

@@ -157,6 +157,8 @@ struct PairArrays {
                         // bit 1 = a row's extent fell outside the arrays.  The offending write is SKIPPED: stale or corrupted
                         // counters (the hipMemsetAsync-in-graph bug of round 1) become a readable flag, not a memory fault.
   int32_t n_entries;
+  int32_t* long_table[2];   // nullable: per orientation the list of rows longer than DGDM_SPMM_LONG_ROW (include/dgdm_hip.h)
+  int32_t long_item_cap;
 };
 
 __global__ void k_count_pair(const int64_t* __restrict__ ei, int64_t E, int32_t N, int32_t* __restrict__ cnt_dst,
@@ -204,6 +206,11 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_pair(PairArrays a, int32_t 
     ex += v[j];
   }
   if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) rowptr[N] = carry + tot;
+  if (blockIdx.x == 0 && a.long_table[o]) {     // header (count, slots) and the arrival counters behind the items start at zero
+    int32_t* t = a.long_table[o];
+    for (int i = threadIdx.x; i < 2; i += SCAN_BLOCK) t[i] = 0;
+    for (int i = threadIdx.x; i < a.long_item_cap; i += SCAN_BLOCK) t[2 + 2 * a.long_item_cap + i] = 0;
+  }
 }
 
 __global__ void k_fill_pair(const int64_t* __restrict__ ei, int64_t E, int32_t N, PairArrays a) {
@@ -243,6 +250,19 @@ __global__ void k_rank_pair(PairArrays a, int32_t N, int32_t E32, int add_loops,
       continue;
     }
     const float dr = dinv[r];
+    if (a.long_table[o] && n + (add_loops ? 1 : 0) > DGDM_SPMM_LONG_ROW) {
+      // a row one wave should not walk alone: dgdm_spmm* splits it into segments (csrc/spmm.hip), and its entries are ordered by
+      // k_rank_long (this loop is quadratic in the row length: 17 ms for one row of 5000 entries)
+      if (lane == 0) {
+        int32_t* t = a.long_table[o];
+        const int idx = atomicAdd(&t[0], 1);
+        const int nseg = (n + (add_loops ? 1 : 0) + DGDM_SPMM_SEGMENT - 1) / DGDM_SPMM_SEGMENT;
+        const int slot0 = atomicAdd(&t[1], nseg);
+        if (idx < a.long_item_cap) { t[2 + 2 * idx] = r; t[2 + 2 * idx + 1] = slot0; }
+        if (add_loops) { col[s + n] = r; eid[s + n] = E32 + r; w[s + n] = dr * dr; }
+      }
+      continue;
+    }
     for (int i = lane; i < n; i += 64) {
       const int my = teid[s + i];
       int rank = 0;
@@ -257,6 +277,44 @@ __global__ void k_rank_pair(PairArrays a, int32_t N, int32_t E32, int add_loops,
       eid[s + n] = E32 + r;
       w[s + n] = dr * dr;
     }
+  }
+}
+
+// Ordering of the LONG rows' entries (rank by edge id inside the row): segment `slot` of the table = 64 entries of one row, one
+// entry per lane, which counts the row's entries with a smaller edge id -- 64 at a time out of a register (v_readlane), so a row
+// of n entries costs n / 64 waves x n comparisons running side by side instead of one wave x n^2 / 64.
+static_assert(DGDM_SPMM_SEGMENT == 64, "k_rank_long hands one table segment to one wavefront");
+__global__ void k_rank_long(PairArrays a, int32_t N, const float* __restrict__ dinv, int add_loops) {
+  const int o = blockIdx.y;
+  const int32_t* __restrict__ t = a.long_table[o];
+  const int count = min(t[0], a.long_item_cap), slots = t[1];
+  const int slot = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (slot >= slots) return;
+  const int32_t* __restrict__ rowptr = a.rowptr[o];
+  int row = -1, slot0 = 0;
+  for (int i = 0; i < count; ++i) {
+    const int r_ = t[2 + 2 * i], s0 = t[2 + 2 * i + 1];
+    const int ns = (rowptr[r_ + 1] - rowptr[r_] + DGDM_SPMM_SEGMENT - 1) / DGDM_SPMM_SEGMENT;
+    if (slot >= s0 && slot < s0 + ns) { row = r_; slot0 = s0; }
+  }
+  if (row < 0) return;
+  const int s = rowptr[row];
+  const int n = rowptr[row + 1] - s - (add_loops ? 1 : 0);
+  if (s < 0 || n < 0 || (int64_t)s + n + (add_loops ? 1 : 0) > a.n_entries) return;      // k_rank_pair flagged it
+  const int32_t* __restrict__ teid = a.teid[o];
+  const int i = (slot - slot0) * 64 + lane;
+  const int my = i < n ? teid[s + i] : 0x7fffffff;
+  int rank = 0;
+  for (int j0 = 0; j0 < n; j0 += 64) {
+    const int v = j0 + lane < n ? teid[s + j0 + lane] : 0x7fffffff;
+#pragma unroll
+    for (int k = 0; k < 64; ++k) rank += (__builtin_amdgcn_readlane(v, k) < my) ? 1 : 0;
+  }
+  if (i < n) {
+    const int c = a.tcol[o][s + i];
+    a.col[o][s + rank] = c;
+    a.eid[o][s + rank] = my;
+    a.w[o][s + rank] = ((unsigned)c < (unsigned)N ? dinv[c] : 0.f) * dinv[row];
   }
 }
 
@@ -312,6 +370,12 @@ Workspace carve(void* base, int64_t E, int32_t N, int32_t add_loops) {
 }
 
 }  // namespace
+
+extern "C" int32_t dgdm_spmm_long_item_cap(int64_t n_entries) { return (int32_t)(n_entries / DGDM_SPMM_LONG_ROW + 1); }
+extern "C" int32_t dgdm_spmm_long_slot_cap(int64_t n_entries) {
+  return (int32_t)(n_entries / DGDM_SPMM_SEGMENT + n_entries / DGDM_SPMM_LONG_ROW + 2);
+}
+extern "C" size_t dgdm_spmm_long_table_words(int64_t n_entries) { return 2 + 3 * (size_t)dgdm_spmm_long_item_cap(n_entries); }
 
 extern "C" size_t dgdm_csr_build_workspace_bytes(int64_t E, int32_t N, int32_t add_loops) {
   if (E < 0 || N < 0) return 0;
@@ -384,7 +448,8 @@ extern "C" size_t dgdm_csr_build_pair_status_offset(int64_t E, int32_t N, int32_
 extern "C" int dgdm_csr_build_pair(const int64_t* edge_index, int64_t E, int32_t N, int32_t add_loops,
                                    int32_t* rowptr_dst, int32_t* col_dst, int32_t* eid_dst, float* w_dst,
                                    int32_t* rowptr_src, int32_t* col_src, int32_t* eid_src, float* w_src, float* dinv,
-                                   void* workspace, size_t workspace_bytes, void* stream_) {
+                                   void* workspace, size_t workspace_bytes, int32_t* long_table_dst, int32_t* long_table_src,
+                                   int32_t long_item_cap, void* stream_) {
   DGDM_REQUIRE(E >= 0 && N >= 0 && rowptr_dst && rowptr_src);
   DGDM_REQUIRE(E == 0 || edge_index);
   const int64_t n_entries = E + (add_loops ? N : 0);
@@ -405,6 +470,10 @@ extern "C" int dgdm_csr_build_pair(const int64_t* edge_index, int64_t E, int32_t
   a.rowptr[1] = rowptr_src; a.col[1] = col_src; a.eid[1] = eid_src; a.w[1] = w_src;
   a.status = ws.status;
   a.n_entries = (int32_t)n_entries;
+  DGDM_REQUIRE((long_table_dst == nullptr) == (long_table_src == nullptr));
+  if (long_table_dst && long_item_cap < dgdm_spmm_long_item_cap(n_entries)) return DGDM_ERR_WORKSPACE;
+  if (long_table_dst && N > (1 << 20)) return DGDM_ERR_UNSUPPORTED;    // the tables are zeroed by the one-pass scan kernel
+  a.long_table[0] = long_table_dst; a.long_table[1] = long_table_src; a.long_item_cap = long_item_cap;
   const int extra = add_loops ? 1 : 0;
   dgdm_fill_async(ws.cnt[0], 0, ws.counters_bytes, stream);
   const int eb = (int)((E + 255) / 256 < 4096 ? (E + 255) / 256 : 4096);
@@ -425,6 +494,10 @@ extern "C" int dgdm_csr_build_pair(const int64_t* edge_index, int64_t E, int32_t
   if (n_entries > 0) {
     const int rb = (N + 3) / 4 < 8192 ? (N + 3) / 4 : 8192;
     hipLaunchKernelGGL(k_rank_pair, dim3(rb, 2), dim3(256), 0, stream, a, N, (int32_t)E, extra, dinv);
+    if (long_table_dst) {   // one wave per possible segment; waves beyond the tables' slot counts leave at once
+      const int lb = (dgdm_spmm_long_slot_cap(n_entries) + 3) / 4;
+      hipLaunchKernelGGL(k_rank_long, dim3(lb, 2), dim3(256), 0, stream, a, N, dinv, extra);
+    }
   }
   return dgdm_launch_status();
 }

@@ -49,9 +49,16 @@ __device__ __forceinline__ float scale_of(unsigned amax_bits) {
 
 __device__ __forceinline__ void split_pair(float a, float b, unsigned* h, unsigned* l) {
   const f16x2 hh = __builtin_convertvector(f32x2{a, b}, f16x2);
-  const f16x2 ll = __builtin_convertvector(f32x2{a - (float)hh[0], b - (float)hh[1]}, f16x2);
-  *h = __builtin_bit_cast(unsigned, hh);
-  *l = __builtin_bit_cast(unsigned, ll);
+  const unsigned hb = __builtin_bit_cast(unsigned, hh);
+  // lo = fp16(x - hi) by one mixed-precision FMA per value (reads hi as fp16, x as fp32; x - hi is exact in fp32, so the result is
+  // bit for bit the two-step form's): 3 instructions per pair where hipcc's lowering of the plain expression takes 5
+  unsigned lb;
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+      : "=&v"(lb)
+      : "v"(hb), "v"(a), "v"(b));
+  *h = hb;
+  *l = lb;
 }
 
 struct ImgDesc {

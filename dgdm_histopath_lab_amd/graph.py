@@ -117,7 +117,15 @@ class GraphStructure:
                                        "were skipped")
 
     __slots__ = ("num_nodes", "num_edges", "num_entries", "rowptr", "col", "eid", "w",
-                 "rowptr_t", "col_t", "eid_t", "w_t", "dinv", "status")
+                 "rowptr_t", "col_t", "eid_t", "w_t", "dinv", "status", "long_tables", "long_partial", "_long")
+
+    LONG_PARTIAL_LD = 1024      # floats per partial slot: the widest row dgdm_spmm* takes
+
+    def long_rows(self, transposed: bool = False):
+        """The ``long_rows`` argument of dgdm_spmm* for the by-destination (forward) or by-source (backward) CSR: rows longer than
+        DGDM_SPMM_LONG_ROW entries (hubs) are cut into segments that run on lane groups of their own (include/dgdm_hip.h,
+        "Long rows").  None when the builder left no table (the "single" pipeline, more than 2^20 nodes)."""
+        return None if self._long is None else self._long[1 if transposed else 0]
 
     def __init__(self, edge_index: torch.Tensor, num_nodes: int, add_loops: bool = True, pipeline: str = "pair"):
         """``pipeline``: "pair" (dgdm_csr_build_pair) or "single" (one entry point per array set; same results)."""
@@ -139,16 +147,26 @@ class GraphStructure:
         self.w = torch.empty(n_ent, dtype=torch.float32, device=dev)
         self.w_t = torch.empty(n_ent, dtype=torch.float32, device=dev)
         self.status = None
+        self.long_tables = self.long_partial = self._long = None
         if pipeline == "pair":       # both orientations, dinv and the weights in five launches
             ws_bytes = _lib.workspace_bytes("dgdm_csr_build_pair_workspace_bytes", E, N, int(add_loops))
             ws = torch.empty(max(ws_bytes, 4), dtype=torch.uint8, device=dev)
             if N > 0:    # the builder's overflow flag (include/dgdm_hip.h): kept as a 4-byte view, read only by assert_ok()
                 off = _lib.workspace_bytes("dgdm_csr_build_pair_status_offset", E, N, int(add_loops))
                 self.status = ws[off:off + 4].view(torch.int32)
+            lt0 = lt1 = None
+            item_cap = 0
+            if 0 < N <= (1 << 20) and n_ent > 0:     # long-row tables (hubs): both orientations share one scratch for partial sums
+                words = lib.dgdm_spmm_long_table_words(n_ent)
+                item_cap, slot_cap = lib.dgdm_spmm_long_item_cap(n_ent), lib.dgdm_spmm_long_slot_cap(n_ent)
+                self.long_tables = torch.empty(2, words, **i32)
+                self.long_partial = torch.empty(slot_cap, self.LONG_PARTIAL_LD, dtype=torch.float32, device=dev)
+                lt0, lt1 = self.long_tables[0].data_ptr(), self.long_tables[1].data_ptr()
+                self._long = tuple(_lib.LongRows(t, self.long_partial.data_ptr(), self.LONG_PARTIAL_LD, item_cap, slot_cap) for t in (lt0, lt1))
             _lib.check(lib.dgdm_csr_build_pair(ei.data_ptr(), E, N, int(add_loops), self.rowptr.data_ptr(), self.col.data_ptr(),
                                                self.eid.data_ptr(), self.w.data_ptr(), self.rowptr_t.data_ptr(), self.col_t.data_ptr(),
                                                self.eid_t.data_ptr(), self.w_t.data_ptr(), self.dinv.data_ptr(), ws.data_ptr(),
-                                               ws_bytes, st), "dgdm_csr_build_pair")
+                                               ws_bytes, lt0, lt1, item_cap, st), "dgdm_csr_build_pair")
             return
         if pipeline != "single":
             raise ValueError(f"unknown CSR pipeline {pipeline!r}")

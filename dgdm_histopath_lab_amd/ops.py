@@ -53,10 +53,17 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
 
 
 # ----------------------------------------------------------------------------- K2 SpMM
+def _lr(long_rows):
+    import ctypes
+    return None if long_rows is None else ctypes.byref(long_rows)
+
+
 def spmm_raw(rowptr, col, w, X, num_rows: int, *, table_rows: Optional[int] = None, out: Optional[torch.Tensor] = None,
-             bias: Optional[torch.Tensor] = None, accumulate: bool = False, addend: Optional[torch.Tensor] = None) -> torch.Tensor:
+             bias: Optional[torch.Tensor] = None, accumulate: bool = False, addend: Optional[torch.Tensor] = None,
+             long_rows=None) -> torch.Tensor:
     """Y[r] = sum_p w[p] X[col[p]] (+bias): dgdm_spmm.  X may be a column-strided view
-    (row stride multiple of 4 floats); ``out`` likewise."""
+    (row stride multiple of 4 floats); ``out`` likewise.  ``long_rows``: ``GraphStructure.long_rows(transposed)`` of the CSR that
+    ``rowptr`` belongs to -- rows of hundreds of entries (hubs) are then split over many lane groups instead of one wavefront."""
     _lib.require_cuda(X, rowptr, col, w)
     lib = _lib.load()
     if X.dim() != 2 or X.stride(1) != 1:
@@ -75,11 +82,11 @@ def spmm_raw(rowptr, col, w, X, num_rows: int, *, table_rows: Optional[int] = No
         TIMERS.timed(f"spmm_c{C}", lambda: _lib.check(
             lib.dgdm_spmm_add(rowptr.data_ptr(), col.data_ptr(), w.data_ptr(), X.data_ptr() if X.numel() else None, ldx, tr, addend.data_ptr(),
                               addend.stride(0) if addend.size(0) > 1 else max(C, addend.stride(0)), out.data_ptr(), ldy, num_rows, C,
-                              _lib.stream_ptr(X.device)), "dgdm_spmm_add"))
+                              _lr(long_rows), _lib.stream_ptr(X.device)), "dgdm_spmm_add"))
         return out
     TIMERS.timed(f"spmm_c{C}", lambda: _lib.check(
         lib.dgdm_spmm(rowptr.data_ptr(), col.data_ptr(), w.data_ptr(), X.data_ptr() if X.numel() else None, ldx, tr,
-                      out.data_ptr(), ldy, num_rows, C, _lib.ptr(bias), int(accumulate), _lib.stream_ptr(X.device)), "dgdm_spmm"))
+                      out.data_ptr(), ldy, num_rows, C, _lib.ptr(bias), int(accumulate), _lr(long_rows), _lib.stream_ptr(X.device)), "dgdm_spmm"))
     return out
 
 
@@ -90,12 +97,12 @@ class _Aggregate(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gs: GraphStructure, out):
         ctx.gs = gs
-        return spmm_raw(gs.rowptr, gs.col, gs.w, x, gs.num_nodes, out=out)
+        return spmm_raw(gs.rowptr, gs.col, gs.w, x, gs.num_nodes, out=out, long_rows=gs.long_rows())
 
     @staticmethod
     def backward(ctx, gy):
         gs = ctx.gs
-        return spmm_raw(gs.rowptr_t, gs.col_t, gs.w_t, _f32c(gy), gs.num_nodes), None, None
+        return spmm_raw(gs.rowptr_t, gs.col_t, gs.w_t, _f32c(gy), gs.num_nodes, long_rows=gs.long_rows(True)), None, None
 
 
 def aggregate(x: torch.Tensor, gs: GraphStructure, out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -112,14 +119,14 @@ class _AggregateConcat(torch.autograd.Function):
         cin, ed = x.size(1), ea_hat.size(1)
         buf = torch.empty(x.size(0), cin + ed, dtype=torch.float32, device=x.device)
         buf[:, cin:] = ea_hat
-        spmm_raw(gs.rowptr, gs.col, gs.w, x, gs.num_nodes, out=buf[:, :cin])
+        spmm_raw(gs.rowptr, gs.col, gs.w, x, gs.num_nodes, out=buf[:, :cin], long_rows=gs.long_rows())
         ctx.gs, ctx.cin = gs, cin
         return buf
 
     @staticmethod
     def backward(ctx, gbuf):
         gs = ctx.gs
-        return spmm_raw(gs.rowptr_t, gs.col_t, gs.w_t, gbuf[:, :ctx.cin], gs.num_nodes), None, None
+        return spmm_raw(gs.rowptr_t, gs.col_t, gs.w_t, gbuf[:, :ctx.cin], gs.num_nodes, long_rows=gs.long_rows(True)), None, None
 
 
 def aggregate_concat(x: torch.Tensor, ea_hat: torch.Tensor, gs: GraphStructure) -> torch.Tensor:
@@ -135,7 +142,7 @@ def aggregate_edge_attr(edge_attr: Optional[torch.Tensor], gs: GraphStructure) -
     if edge_attr is None:
         return None
     ea = _f32c(edge_attr)
-    return spmm_raw(gs.rowptr, gs.eid, gs.w, ea, gs.num_nodes, table_rows=gs.num_edges)
+    return spmm_raw(gs.rowptr, gs.eid, gs.w, ea, gs.num_nodes, table_rows=gs.num_edges, long_rows=gs.long_rows())
 
 
 # ----------------------------------------------------------------------------- K4 attention
@@ -224,9 +231,9 @@ LOG2E = 1.4426950408889634
 
 class PackedOperands:
     """Block-aligned fp16 hi+lo row images of `ntensors` column blocks of one fp32 matrix (csrc/attn_h.hpp), plus (forward pack)
-    the transposed image of V and the block-aligned, pre-scaled positions; (backward pack) -delta and 8 - lse2 per row."""
+    the block-aligned, pre-scaled positions; (backward pack) -delta and 8 - lse2 per row."""
 
-    __slots__ = ("R", "T", "pos_b", "ndelta_b", "nlse_b", "ntensors", "r_stride")
+    __slots__ = ("R", "pos_b", "ndelta_b", "nlse_b", "ntensors", "r_stride")
 
     def r(self, z):
         return self.R[z * self.r_stride:]
@@ -238,21 +245,20 @@ ATTN_GRAD_TARGET = 0.25
 
 
 def attn_pack(x, col0: int, cstride: int, ntensors: int, scale0: float, plan: AttnPlan, H: int, pos=None, pos_scale: float = 1.0, O=None,
-              scale_dev=None, lse2_b=None, t_tensor: int = -1) -> PackedOperands:
+              scale_dev=None, lse2_b=None) -> PackedOperands:
     lib = _lib.load()
     dev, nb = x.device, plan.num_q_tiles
     pk = PackedOperands()
     pk.ntensors = ntensors
     pk.r_stride = lib.dgdm_attn_pack_bytes(nb, H, 0) // 2
     pk.R = torch.empty(max(ntensors * pk.r_stride, 8), dtype=torch.float16, device=dev)
-    pk.T = torch.empty(max(lib.dgdm_attn_pack_bytes(nb, H, 1) // 2, 8), dtype=torch.float16, device=dev) if t_tensor >= 0 else None
     pk.pos_b = torch.empty(max(lib.dgdm_attn_pack_bytes(nb, H, 2) // 4, 4), dtype=torch.float32, device=dev) if pos is not None else None
     nrow = max(lib.dgdm_attn_pack_bytes(nb, H, 3) // 4, 4)
     pk.ndelta_b = torch.empty(nrow, dtype=torch.float32, device=dev) if O is not None else None
     pk.nlse_b = torch.empty(nrow, dtype=torch.float32, device=dev) if lse2_b is not None else None
     _lib.check(lib.dgdm_attn_pack(x.data_ptr(), x.stride(0), col0, cstride, ntensors, scale0, _lib.ptr(scale_dev),
                                   plan.ptr_dev.data_ptr(), plan.B, nb, H,
-                                  pk.R.data_ptr(), _lib.ptr(pk.T), t_tensor, _lib.ptr(pos), pos_scale, _lib.ptr(pk.pos_b), _lib.ptr(O),
+                                  pk.R.data_ptr(), _lib.ptr(pos), pos_scale, _lib.ptr(pk.pos_b), _lib.ptr(O),
                                   O.stride(0) if O is not None else 0, _lib.ptr(pk.ndelta_b), _lib.ptr(lse2_b), _lib.ptr(pk.nlse_b),
                                   _lib.stream_ptr(dev)), "dgdm_attn_pack")
     return pk
@@ -263,11 +269,11 @@ def spatial_attn_h_fwd_raw(qkv, pos, plan: AttnPlan, H: int, scale: float, inv_t
     """Split-fp16 forward over a fused [N, 3*H*16] QKV buffer; returns (out, lse2_b, packed)."""
     lib = _lib.load()
     N, C = qkv.size(0), H * 16
-    pk = packed if packed is not None else attn_pack(qkv, 0, C, 3, scale * LOG2E, plan, H, pos=pos, pos_scale=inv_tau * LOG2E, t_tensor=2)
+    pk = packed if packed is not None else attn_pack(qkv, 0, C, 3, scale * LOG2E, plan, H, pos=pos, pos_scale=inv_tau * LOG2E)
     out = torch.empty(N, C, dtype=torch.float32, device=qkv.device)
     lse2_b = torch.empty(max(lib.dgdm_attn_pack_bytes(plan.num_q_tiles, H, 3) // 4, 4), dtype=torch.float32, device=qkv.device)
     TIMERS.timed("attn_fwd", lambda: _lib.check(
-        lib.dgdm_spatial_attn_h_fwd(pk.r(0).data_ptr(), pk.r(1).data_ptr(), pk.T.data_ptr(), pk.pos_b.data_ptr(),
+        lib.dgdm_spatial_attn_h_fwd(pk.r(0).data_ptr(), pk.r(1).data_ptr(), pk.r(2).data_ptr(), pk.pos_b.data_ptr(),
                                     plan.ptr_dev.data_ptr(), plan.B, plan.num_q_tiles, H, drop_p, seed, out.data_ptr(),
                                     out.stride(0), lse2_b.data_ptr(), variant, _lib.stream_ptr(qkv.device)), "dgdm_spatial_attn_h_fwd"))
     return out, lse2_b, pk
@@ -319,7 +325,7 @@ class _SpatialAttentionH(torch.autograd.Function):
         out, lse2_b, R, pos_b = ctx.saved_tensors
         plan, H, scale, inv_tau, drop_p, seed, rs, shape = ctx.meta
         pk = PackedOperands()
-        pk.R, pk.T, pk.pos_b, pk.ndelta_b, pk.nlse_b, pk.ntensors, pk.r_stride = R, None, pos_b, None, None, 3, rs
+        pk.R, pk.pos_b, pk.ndelta_b, pk.nlse_b, pk.ntensors, pk.r_stride = R, pos_b, None, None, 3, rs
         dqkv = torch.empty(shape, dtype=torch.float32, device=out.device)
         spatial_attn_h_bwd_raw(pk, out, gout, plan, H, scale, inv_tau, lse2_b, dqkv, drop_p, seed)
         return dqkv, None, None, None, None, None, None, None
@@ -1682,7 +1688,7 @@ class _GraphConvLinear(torch.autograd.Function):
         TIMERS.timed(f"spmm_c{cin}", lambda: _lib.check(
             lib.dgdm_spmm_concat(gs.rowptr.data_ptr(), gs.col.data_ptr(), gs.w.data_ptr(), x.data_ptr(), x.stride(0), x.size(0),
                                  ea_hat.data_ptr(), ea_hat.stride(0), ed, buf.data_ptr(), buf.stride(0), n, cin, slot,
-                                 _lib.stream_ptr(x.device)), "dgdm_spmm_concat"))
+                                 _lr(gs.long_rows()), _lib.stream_ptr(x.device)), "dgdm_spmm_concat"))
         tag_amax(buf, slot)
         ctx.gs, ctx.cin, ctx.has_bias, ctx.skip, ctx.math = gs, cin, b is not None, skip, GEMM_MATH
         ctx.amax = (None, None)
@@ -1713,7 +1719,7 @@ class _GraphConvLinear(torch.autograd.Function):
             # node_lin.weight itself, or a view into the concatenated copy (bounded by the copy's maximum)
             w_only = wsaved if wsaved.size(1) == cin else tag_amax(wsaved[:, :cin], amax_handle(wsaved))
             dagg = gemm_nn_raw(gy, w_only, math=math)
-            dx = spmm_raw(gs.rowptr_t, gs.col_t, gs.w_t, dagg, gs.num_nodes, addend=gskip)
+            dx = spmm_raw(gs.rowptr_t, gs.col_t, gs.w_t, dagg, gs.num_nodes, addend=gskip, long_rows=gs.long_rows(True))
         dw = dwe = db = None
         if ctx.needs_input_grad[3] or ctx.needs_input_grad[4] or (ctx.has_bias and ctx.needs_input_grad[5]):
             (dw, dwe), db = gemm_tn_raw(gy, buf, ctx.has_bias, math=math, split=cin, may_defer=ctx.leaf and _claim_deferred(*ctx.wb))

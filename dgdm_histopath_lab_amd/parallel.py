@@ -55,6 +55,9 @@ class FlatGradAllReducer:
         self._fwd_probe = module.register_forward_pre_hook(lambda m, args: self.begin_step())
         self.capturing = False        # set by a recording: hooks stay passive, the recording calls pack() itself
         self.stats = {"early_launches": 0, "steps": 0}
+        self.record_events = False    # diagnostics: HIP events at the early launch and at all_reduce() entry (see backward_tail_ms)
+        self._ev_early = self._ev_end = None
+        self.backward_tail_ms: List[float] = []     # per step: backward time left on the stream when bucket 0 left (record_events)
 
     # ------------------------------------------------------------------ hooks
     def begin_step(self) -> None:
@@ -90,6 +93,9 @@ class FlatGradAllReducer:
                 self._pack(0)
                 self._early = self._launch(0, async_op=True)
                 self.stats["early_launches"] += 1
+                if self.record_events:
+                    self._ev_early = torch.cuda.Event(enable_timing=True)
+                    self._ev_early.record()
 
     def _active(self) -> bool:
         return self.world > 1 or self.always
@@ -194,6 +200,11 @@ class FlatGradAllReducer:
             self._setup()
         self._check_live()
         early, self._early, self._fired, self._forwards = self._early, None, 0, 0
+        if self.record_events and self._ev_early is not None:
+            self._ev_end = torch.cuda.Event(enable_timing=True)
+            self._ev_end.record()
+            self._pending_tail = (self._ev_early, self._ev_end)
+            self._ev_early = None
         if early is None:
             self._pack(0)
             early = self._launch(0, async_op=True)
@@ -203,6 +214,11 @@ class FlatGradAllReducer:
             if w is not None:
                 w.wait()
         self.adopt_views()
+        if self.record_events and getattr(self, "_pending_tail", None) is not None:
+            a, b = self._pending_tail
+            self._pending_tail = None
+            b.synchronize()
+            self.backward_tail_ms.append(a.elapsed_time(b))
 
 
 class _ScaledWork:

@@ -108,10 +108,31 @@ DGDM_API size_t dgdm_csr_build_pair_workspace_bytes(int64_t E, int32_t N, int32_
  * offending writes are skipped, so inconsistent counters (e.g. a fill that did not re-execute in a graph replay) surface as
  * this flag instead of an out-of-bounds write.  0 after a healthy build; read it whenever a host sync is acceptable. */
 DGDM_API size_t dgdm_csr_build_pair_status_offset(int64_t E, int32_t N, int32_t add_loops);
+/* Long rows.  dgdm_spmm* gives every row to one wavefront, which walks the row's entries four at a time: fine for tissue graphs
+ * (kNN: <= ~20 neighbours), a 40x slowdown for a hub of 5000 neighbours (profiles/r03_gather_skew.txt; the builder's own
+ * per-row ordering pass is quadratic in the row length and was 400x slower on that graph).  dgdm_csr_build_pair can
+ * therefore leave, per orientation, a table of the rows longer than DGDM_SPMM_LONG_ROW entries; dgdm_spmm* (argument `long_rows`)
+ * then skips them in the row pass and hands every DGDM_SPMM_SEGMENT entries of such a row to a wave of its own; the waves leave
+ * partial sums, and the LAST one to arrive (an arrival counter per row) adds them in segment order and applies the epilogue --
+ * one launch, fixed summation order, bitwise reproducible.  A table is dgdm_spmm_long_table_words(n_entries) int32 words:
+ * [count, slots, {row, first slot} x item_cap, arrival counters x item_cap]; partial sums need dgdm_spmm_long_slot_cap(n_entries)
+ * slots of `ld` floats (ld >= the widest C used with the table).  n_entries = E + (add_loops ? N : 0). */
+#define DGDM_SPMM_LONG_ROW 128
+#define DGDM_SPMM_SEGMENT 64
+typedef struct DgdmLongRows {
+  int32_t* table;   /* device, written by dgdm_csr_build_pair (one orientation) */
+  float* partial;   /* device, slot_cap * ld floats of scratch */
+  int64_t ld;
+  int32_t item_cap, slot_cap;
+} DgdmLongRows;
+DGDM_API int32_t dgdm_spmm_long_item_cap(int64_t n_entries);
+DGDM_API int32_t dgdm_spmm_long_slot_cap(int64_t n_entries);
+DGDM_API size_t dgdm_spmm_long_table_words(int64_t n_entries);
 DGDM_API int dgdm_csr_build_pair(const int64_t* edge_index, int64_t E, int32_t N, int32_t add_loops,
                                  int32_t* rowptr_dst, int32_t* col_dst, int32_t* eid_dst, float* w_dst,
                                  int32_t* rowptr_src, int32_t* col_src, int32_t* eid_src, float* w_src, float* dinv,
-                                 void* workspace, size_t workspace_bytes, void* stream);
+                                 void* workspace, size_t workspace_bytes, int32_t* long_table_dst, int32_t* long_table_src,
+                                 int32_t long_item_cap, void* stream);   /* long_table_*: nullable pair, see "Long rows" */
 
 /* ---------------------------------------------------------------------------------------------
  * K2  CSR segmented gather-reduce  Y[r,:] = sum_{p in row r} w[p] * X[col[p],:]  (+ bias).
@@ -128,8 +149,9 @@ DGDM_API int dgdm_csr_build_pair(const int64_t* edge_index, int64_t E, int32_t N
 DGDM_API int dgdm_spmm(const int32_t* rowptr, const int32_t* col, const float* w,
                        const float* X, int64_t ldx, int32_t table_rows,
                        float* Y, int64_t ldy, int32_t N, int32_t C,
-                       const float* bias, int32_t accumulate, void* stream);
-/* Y[r, 0:C) as dgdm_spmm (no bias, no accumulate) and Y[r, C:C+Ct) = tail[r, :] in the same pass: the operand
+                       const float* bias, int32_t accumulate, const DgdmLongRows* long_rows, void* stream);
+/* long_rows (all three entry points): nullable HOST struct for the orientation of `rowptr` (see "Long rows" above).
+ * Y[r, 0:C) as dgdm_spmm (no bias, no accumulate) and Y[r, C:C+Ct) = tail[r, :] in the same pass: the operand
  * [A_hat x | EA_hat] of a graph convolution's single contraction (graph_layers.py:99-110) without a separate copy of the
  * per-graph edge-attribute aggregate.  Ct % 4 == 0, ldt % 4 == 0, ldy >= C + Ct. */
 /* Y = dgdm_spmm(...) + addend (addend [N, C], leading dimension lda; may not alias Y): the backward of a graph convolution
@@ -137,10 +159,10 @@ DGDM_API int dgdm_spmm(const int32_t* rowptr, const int32_t* col, const float* w
  * while it writes the scattered one, instead of leaving the sum to a separate element-wise pass. */
 DGDM_API int dgdm_spmm_add(const int32_t* rowptr, const int32_t* col, const float* w, const float* X, int64_t ldx,
                            int32_t table_rows, const float* addend, int64_t lda, float* Y, int64_t ldy, int32_t N, int32_t C,
-                           void* stream);
+                           const DgdmLongRows* long_rows, void* stream);
 DGDM_API int dgdm_spmm_concat(const int32_t* rowptr, const int32_t* col, const float* w, const float* X, int64_t ldx,
                               int32_t table_rows, const float* tail, int64_t ldt, int32_t Ct, float* Y, int64_t ldy,
-                              int32_t N, int32_t C, uint32_t* amax, void* stream);
+                              int32_t N, int32_t C, uint32_t* amax, const DgdmLongRows* long_rows, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K4  fused variable-length spatial attention (head dim 16), forward.
@@ -208,14 +230,14 @@ DGDM_API int dgdm_spatial_attn_mean_weights(const float* Q, const float* K, int6
  * MFMA cannot overlap with the softmax's fp32 VALU work, the fp16 MFMA can.  Operands are packed
  * once per launch into graph-block-aligned images (64 rows per block, zero padded; block count =
  * num_q_tiles of the fp32 path) that the kernels stage with direct-to-LDS DMA:
- *   row image        R[blk][H][64][32] halfs  = [hi16 | lo16] per row
- *   transposed image T[blk][H][2][16][72] halfs (part 0 hi, 1 lo; [d][row], padded row stride)
- * dgdm_attn_pack_bytes(num_blocks, H, which): buffer sizes (which: 0 R, 1 T, 2 positions
+ *   row image        R[blk][H][4 tiles][4 chunks][16 rows][8] halfs: per row 16 hi | 16 lo halfs, chunk-major inside a
+ *                    16-row tile (csrc/attn_h.hpp r_off: the order that makes row reads AND transposed reads of the LDS copy
+ *                    free of bank conflicts).  Operands needed transposed are read with ds_read_b64_tr_b16: no second image.
+ * dgdm_attn_pack_bytes(num_blocks, H, which): buffer sizes (which: 0 R, 2 positions
  * [blk][2][64] fp32 (planar x | y), 3 per-row scalars [blk][H][64] fp32).
  * dgdm_attn_pack: tensor z (z < ntensors) = columns [col0 + z*cstride, +H*16) of X [N_tot, *]; tensor 0
  * is scaled by scale0 (Q: log2(e)/sqrt(d)) times *scale_dev (nullable device scalar); R holds ntensors row images back to
- * back; T (nullable) receives the transposed image of tensor t_tensor only (the forward reads V^T; nothing else is read
- * transposed from memory).  pos / pos_b (nullable pair): block-aligned positions TIMES pos_scale (= log2(e)/tau: the kernels
+ * back.  pos / pos_b (nullable pair): block-aligned positions TIMES pos_scale (= log2(e)/tau: the kernels
  * add the plain Euclidean distance of these to the negated log2-domain scores).  O / ndelta_b (nullable pair): ndelta =
  * -rowsum(X_0 * O) for the backward (X_0 = dO); lse_in / lse_out (nullable pair, only with O): lse_out = 8 - lse_in, minus the
  * log-sum-exp the backward kernels subtract (they carry P' = 2^8 P so that the weights of a near-uniform row over 10^4..10^5
@@ -229,12 +251,12 @@ DGDM_API size_t dgdm_amax_scale_workspace_bytes(void);
 DGDM_API int dgdm_amax_pow2_scale(const float* x, int64_t n, float target, float* out2, void* workspace, size_t workspace_bytes,
                                   void* stream);
 DGDM_API int dgdm_attn_pack(const float* X, int64_t ld, int32_t col0, int32_t cstride, int32_t ntensors, float scale0,
-                            const float* scale_dev, const int32_t* ptr, int32_t B, int32_t num_blocks, int32_t H, void* R, void* T,
-                            int32_t t_tensor, const float* pos, float pos_scale, float* pos_b, const float* O, int64_t ldo,
+                            const float* scale_dev, const int32_t* ptr, int32_t B, int32_t num_blocks, int32_t H, void* R,
+                            const float* pos, float pos_scale, float* pos_b, const float* O, int64_t ldo,
                             float* ndelta_b, const float* lse_in, float* lse_out, void* stream);
-/* forward: Rq = row image of Q', Rk = row image of K, Tv = transposed image of V; pos_b as packed (pre-scaled);
+/* forward: Rq / Rk / Rv = row images of Q', K, V; pos_b as packed (pre-scaled);
  * O [N_tot, H*16] fp32 (row stride ldo); lse2_b [blk][H][64] (log2-domain log-sum-exp, block layout). */
-DGDM_API int dgdm_spatial_attn_h_fwd(const void* Rq, const void* Rk, const void* Tv, const float* pos_b, const int32_t* ptr,
+DGDM_API int dgdm_spatial_attn_h_fwd(const void* Rq, const void* Rk, const void* Rv, const float* pos_b, const int32_t* ptr,
                                      int32_t B, int32_t num_blocks, int32_t H, float drop_p, uint32_t seed, float* O,
                                      int64_t ldo, float* lse2_b, int32_t variant, void* stream);
 /* backward: Rg = row image of dO, ndelta_b and lse_adj_b (= lse_out) from a second dgdm_attn_pack call

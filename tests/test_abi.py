@@ -48,9 +48,10 @@ def test_host_side_argument_checks(lib_path):
     assert lib.dgdm_csr_build_workspace_bytes(50000, 10000, 1) > 4 * (2 * 60000 + 2 * 10000)
     assert lib.dgdm_csr_build(None, 10, 4, 1, 0, None, None, None, None, 0, None) == -1   # null pointers
     assert lib.dgdm_csr_build_pair_workspace_bytes(50000, 10000, 1) > 4 * (4 * 60000 + 4 * 10000)
-    assert lib.dgdm_csr_build_pair(None, 10, 4, 1, None, None, None, None, None, None, None, None, None, None, 0, None) == -1
-    assert lib.dgdm_spmm(None, None, None, None, 8, 4, None, 8, 4, 8, None, 0, None) == -1
-    assert lib.dgdm_spmm(1, 1, 1, 16, 6, 4, 16, 8, 4, 6, None, 0, None) == -2                 # C % 4 != 0
+    assert lib.dgdm_csr_build_pair(None, 10, 4, 1, None, None, None, None, None, None, None, None, None, None, 0, None, None, 0, None) == -1
+    assert lib.dgdm_spmm(None, None, None, None, 8, 4, None, 8, 4, 8, None, 0, None, None) == -1
+    assert lib.dgdm_spmm(1, 1, 1, 16, 6, 4, 16, 8, 4, 6, None, 0, None, None) == -2           # C % 4 != 0
+    assert lib.dgdm_spmm_long_item_cap(60000) == 60000 // 128 + 1 and lib.dgdm_spmm_long_slot_cap(60000) >= 60000 // 64 + 60000 // 128
 
 
 def test_kernels_with_asm_issued_loads_do_not_spill():

@@ -78,10 +78,12 @@ def test_spmm_forward_backward_vs_oracle(c):
     g = torch.Generator().manual_seed(c)
     x = torch.randn(n, c, generator=g)
     gy = torch.randn(n, c, generator=g)
-    src, dst, w = torch.from_numpy(o["src"]), torch.from_numpy(o["dst"]), torch.from_numpy(o["norm_coo"])
-    xr = x.clone().requires_grad_(True)
-    yr = torch.zeros(n, c).index_add_(0, dst, w[:, None] * xr[src])
-    yr.backward(gy)
+    # float64 reference: the hub rows (4000 / 2000 entries, half of them duplicates of one edge) are summed in segments by the
+    # kernel, and an fp32 reference adding 2000 equal terms one by one carries a rounding bias of ~1e-4 of its own
+    src, dst, w = torch.from_numpy(o["src"]), torch.from_numpy(o["dst"]), torch.from_numpy(o["norm_coo"]).double()
+    xr = x.double().clone().requires_grad_(True)
+    yr = torch.zeros(n, c, dtype=torch.float64).index_add_(0, dst, w[:, None] * xr[src])
+    yr.backward(gy.double())
     xd = x.to(_dev()).requires_grad_(True)
     y = ops.aggregate(xd, gs)
     y.backward(gy.to(_dev()))
@@ -89,6 +91,67 @@ def test_spmm_forward_backward_vs_oracle(c):
     assert_close(xd.grad, xr.grad, 1e-5, "dX")
     y2 = ops.aggregate(xd.detach(), gs)
     assert torch.equal(y2, y.detach())  # bitwise reproducible (no float atomics)
+
+
+@pytest.mark.parametrize("c", [32, 128, 512, 768])
+def test_spmm_long_rows_are_split_and_reduced_in_fixed_order(c):
+    """Hub rows: rows of 128 entries (not split), 129 (three segments), 1000 and 5000, by destination AND by
+    source; every entry point (plain + bias + accumulate, + addend, concat + operand maximum) against the float64 gather, bitwise
+    repeatable, and the short rows bit-identical to the run without the long-row table."""
+    from dgdm_histopath_lab_amd import GraphStructure, ops
+    dev = _dev()
+    n, e = 9000, 30000
+    rng = np.random.default_rng(c)
+    ei = rng.integers(100, n, size=(2, e)).astype(np.int64)          # the background edges stay clear of the special nodes below
+    at = 0
+    for node, deg in ((11, 127), (12, 128), (13, 999), (14, 4999)):        # + the self loop: 128, 129, 1000, 5000 entries
+        ei[1, at:at + deg] = node; ei[0, at:at + deg] = rng.choice(n, size=deg, replace=False); at += deg
+    for node, deg in ((21, 128), (22, 3000)):
+        ei[0, at:at + deg] = node; ei[1, at:at + deg] = rng.choice(n, size=deg, replace=False); at += deg
+    gs = GraphStructure(torch.from_numpy(ei).to(dev), n)
+    gs.assert_ok()
+    t0 = gs.long_tables.cpu()
+    assert int(t0[0, 0]) == 3 and int(t0[1, 0]) == 2          # rows longer than 128 entries: 3 by destination, 2 by source
+    for k in ("rowptr", "col", "eid", "rowptr_t", "col_t", "eid_t"):     # long rows are ordered by k_rank_long: still bit-exact
+        assert np.array_equal(getattr(gs, k).cpu().numpy(), csr_oracle.gcn_csr(ei, n)[k]), k
+    o = csr_oracle.gcn_csr(ei, n)
+    g = torch.Generator().manual_seed(c)
+    x, bias, add = torch.randn(n, c, generator=g), torch.randn(c, generator=g), torch.randn(n, c, generator=g)
+    src, dst, w = torch.from_numpy(o["src"]), torch.from_numpy(o["dst"]), torch.from_numpy(o["norm_coo"]).double()
+    fwd = torch.zeros(n, c, dtype=torch.float64).index_add_(0, dst, w[:, None] * x.double()[src])
+    bwd = torch.zeros(n, c, dtype=torch.float64).index_add_(0, src, w[:, None] * x.double()[dst])
+    xd = x.to(dev)
+    y = ops.spmm_raw(gs.rowptr, gs.col, gs.w, xd, n, bias=bias.to(dev), long_rows=gs.long_rows())
+    assert_close(y, fwd + bias.double(), 2e-6, "forward + bias")
+    ops.spmm_raw(gs.rowptr, gs.col, gs.w, xd, n, out=y, accumulate=True, long_rows=gs.long_rows())
+    assert_close(y, 2 * fwd + bias.double(), 2e-6, "accumulate")
+    yt = ops.spmm_raw(gs.rowptr_t, gs.col_t, gs.w_t, xd, n, addend=add.to(dev), long_rows=gs.long_rows(True))
+    assert_close(yt, bwd + add.double(), 2e-6, "transposed + addend")
+    plain = ops.spmm_raw(gs.rowptr, gs.col, gs.w, xd, n)                              # one wave per row, hubs walked serially
+    split = ops.spmm_raw(gs.rowptr, gs.col, gs.w, xd, n, long_rows=gs.long_rows())
+    deg = (gs.rowptr[1:] - gs.rowptr[:-1]).cpu()
+    short = deg <= 128
+    assert int((~short).sum()) == 3
+    assert torch.equal(plain.cpu()[short], split.cpu()[short])                        # short rows: same wave, same order
+    # the serial walk of 5000 fp32 terms is the less accurate of the two orders (the split result held 2e-6 against float64 above)
+    assert_close(split.cpu()[~short], plain.cpu()[~short].double(), 2e-5, "long rows, two summation orders")
+    for _ in range(3):                                                                # arrival order varies, the result does not
+        assert torch.equal(ops.spmm_raw(gs.rowptr, gs.col, gs.w, xd, n, long_rows=gs.long_rows()), split)
+    # the graph convolution's forward (concat + operand maximum) and backward (addend) go through the same tables
+    if c % 32 == 0:
+        prev = ops.configure(gemm="f16x2")
+        try:
+            ea = torch.randn(n, 32, generator=g).to(dev)
+            wgt, wge = (torch.randn(64, c, generator=g) / c ** 0.5).to(dev), (torch.randn(64, 32, generator=g) / 6).to(dev)
+            xg = xd.clone().requires_grad_(True)
+            out = ops.graph_conv_linear(xg, ea, gs, wgt, wge, None)
+            ref = torch.cat([fwd, ea.cpu().double()], 1) @ torch.cat([wgt, wge], 1).cpu().double().t()
+            assert_close(out, ref, 2e-5, "graph convolution over hub rows")
+            out.backward(torch.ones_like(out))
+            gref = torch.zeros(n, c, dtype=torch.float64).index_add_(0, src, w[:, None] * (torch.ones(n, 64, dtype=torch.float64) @ wgt.cpu().double())[dst])
+            assert_close(xg.grad, gref, 2e-5, "its input gradient")
+        finally:
+            ops.configure(**prev)
 
 
 def test_spmm_strided_bias_accumulate_and_edge_attr():

@@ -25,9 +25,9 @@ for p in (0.0, 0.1):
     for var in ([] if os.environ.get("SPLIT_ONLY") else variants):
         ms = t(lambda: ops.spatial_attn_fwd_raw(qkv[:, :C], qkv[:, C:2*C], qkv[:, 2*C:], pos, plan, H, 0.25, 1.0, var, p, 123))
         print(json.dumps(dict(kernel="fwd", variant=var, drop=p, ms=round(ms, 3), TF=round(2 * fl / ms / 1e9, 1))))
-    ms = t(lambda: ops.attn_pack(qkv, 0, C, 3, 0.25 * ops.LOG2E, plan, H, pos=pos, pos_scale=ops.LOG2E, t_tensor=2))
+    ms = t(lambda: ops.attn_pack(qkv, 0, C, 3, 0.25 * ops.LOG2E, plan, H, pos=pos, pos_scale=ops.LOG2E))
     print(json.dumps(dict(kernel="attn_pack qkv", ms=round(ms, 3))))
-    packed = ops.attn_pack(qkv, 0, C, 3, 0.25 * ops.LOG2E, plan, H, pos=pos, pos_scale=ops.LOG2E, t_tensor=2)
+    packed = ops.attn_pack(qkv, 0, C, 3, 0.25 * ops.LOG2E, plan, H, pos=pos, pos_scale=ops.LOG2E)
     for var in (1, 2, 3):
         ms = t(lambda: ops.spatial_attn_h_fwd_raw(qkv, pos, plan, H, 0.25, 1.0, p, 123, packed, var))
         print(json.dumps(dict(kernel="fwd split-fp16", variant=var, drop=p, ms=round(ms, 3), TF=round(2 * fl / ms / 1e9, 1))))

@@ -25,8 +25,15 @@ def main():
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--widths", type=int, nargs="*", default=[768, 512, 256, 128, 32])
+    ap.add_argument("--skew", action="store_true",
+                    help="degree-skew cases at the north-star size (VERDICT r2 item 9): the synthetic kNN-like graph, a Poisson multigraph "
+                         "(torch.randint endpoints, core/graph_layers.py:92 sees whatever the builder emits), and a graph with ONE hub of "
+                         "5000 in-neighbours -- one wave walks a destination row serially (csrc/spmm.hip), so a hub row is the worst case")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
+    if a.skew:
+        skew_cases(dev, a.nodes, a.edges, a.iters)
+        return
     b = synthetic_batch(0, a.batch, a.nodes, a.edges, 8)
     n, e = b.x.size(0), b.edge_index.size(1)
     gs = GraphStructure(b.edge_index.to(dev), n)
@@ -53,6 +60,48 @@ def main():
         GraphStructure(ei, n)
     t1.record(); torch.cuda.synchronize()
     print(json.dumps(dict(kernel="graph_structure_build", nodes=n, edges=e, us=round(t0.elapsed_time(t1) * 1e3 / 20, 1))))
+
+
+def skew_cases(dev, n, e, iters, c=768):
+    g = torch.Generator().manual_seed(5)
+    cases = {"synthetic (uniform undirected pairs, both directions)": synthetic_batch(0, 1, n, e, 8).edge_index}
+    cases["poisson multigraph (independent uniform endpoints, duplicates and loops kept)"] = torch.randint(0, n, (2, e), generator=g)
+    hub = torch.randint(0, n, (2, e), generator=g)
+    hub[1, :5000] = 17                                   # 5000 edges INTO node 17 (its row of the by-destination CSR)
+    hub[0, :5000] = torch.randperm(n, generator=g)[:5000]
+    cases["one hub: 5000 in-neighbours of one node among 10000 (rest uniform)"] = hub
+    both = hub.clone()
+    both[0, 5000:10000] = 17                             # and 5000 edges OUT of it (the transposed CSR of the backward)
+    cases["hub with 5000 in- and 5000 out-edges, by-source orientation (the backward's gather)"] = both
+    for name, ei in cases.items():
+        gs = GraphStructure(ei.to(dev), n)
+        x = torch.randn(n, c, device=dev)
+        y = torch.empty(n, c, device=dev)
+        tr = name.startswith("hub with")
+        rp, cl, w = (gs.rowptr_t, gs.col_t, gs.w_t) if tr else (gs.rowptr, gs.col, gs.w)
+        deg = (rp[1:] - rp[:-1])
+        by = algorithmic_bytes(n, ei.size(1), c)
+        for label, lr in (("one wave per row", None), ("long rows split (default)", gs.long_rows(tr))):
+            for _ in range(10):
+                ops.spmm_raw(rp, cl, w, x, n, out=y, long_rows=lr)
+            t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize(); t0.record()
+            for _ in range(iters):
+                ops.spmm_raw(rp, cl, w, x, n, out=y, long_rows=lr)
+            t1.record(); torch.cuda.synchronize()
+            us = t0.elapsed_time(t1) * 1e3 / iters
+            print(json.dumps(dict(kernel="dgdm_spmm", case=name, mode=label, nodes=n, edges=int(ei.size(1)), C=c, max_row=int(deg.max()),
+                                  mean_row=round(float(deg.float().mean()), 2), us=round(us, 2), algorithmic_MB=round(by / 1e6, 1),
+                                  GBps=round(by / us / 1e3, 1), frac_of_8TBps=round(by / us / 1e3 / 8000, 3))))
+        ei_d = ei.to(dev)
+        for _ in range(3):
+            GraphStructure(ei_d, n)
+        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(); t0.record()
+        for _ in range(10):
+            GraphStructure(ei_d, n)
+        t1.record(); torch.cuda.synchronize()
+        print(json.dumps(dict(kernel="graph_structure_build (K1)", case=name, us=round(t0.elapsed_time(t1) * 1e3 / 10, 1))))
 
 
 if __name__ == "__main__":
