@@ -17,6 +17,10 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libdgdm_hip.so")
+# diagnostic twin of the library: the GEMM kernels that issue their loads as inline asm, built with -DDGDM_STAGE_CANARY (their staging
+# registers hold NaN until a load lands; tests/test_hip_gemm_img.py runs them).  Never loaded by the product path.
+CANARY_PATH = os.path.join(LIB_DIR, "canary", "libdgdm_hip.so")
+CANARY_SOURCES = ("gemm_img.hip", "gemm_h.hip")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
          "-I", os.path.join(ROOT, "include"), "-I", CSRC]
 
@@ -55,15 +59,16 @@ def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(LIB_DIR, exist_ok=True)
     stamp = os.path.join(LIB_DIR, "build.sha256")
     dig = _digest()
-    if not force and os.path.exists(LIB_PATH) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
+    if (not force and os.path.exists(LIB_PATH) and os.path.exists(CANARY_PATH) and os.path.exists(stamp)
+            and open(stamp).read().strip() == dig):
         return LIB_PATH
     hipcc = _hipcc()
     objdir = os.path.join(LIB_DIR, "obj")
     os.makedirs(objdir, exist_ok=True)
 
-    def compile_one(src):
-        obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
-        cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(os.path.basename(src), []), "-c", src, "-o", obj]
+    def compile_one(src, canary=False):
+        obj = os.path.join(objdir, os.path.basename(src)[:-4] + (".canary.o" if canary else ".o"))
+        cmd = [hipcc, *FLAGS, *(["-DDGDM_STAGE_CANARY"] if canary else []), *EXTRA_FLAGS.get(os.path.basename(src), []), "-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
@@ -73,9 +78,13 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     with cf.ThreadPoolExecutor(max_workers=4) as ex:
         objs = list(ex.map(compile_one, _sources()))
-    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH, *objs], capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+        cobjs = list(ex.map(lambda f: compile_one(os.path.join(CSRC, f), True), CANARY_SOURCES))
+    os.makedirs(os.path.dirname(CANARY_PATH), exist_ok=True)
+    swapped = [o for o in objs if os.path.basename(o)[:-2] + ".hip" not in CANARY_SOURCES] + cobjs
+    for out, files in ((LIB_PATH, objs), (CANARY_PATH, swapped)):
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *files], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
     open(stamp, "w").write(dig)
     if verbose:
         print(f"built {LIB_PATH}")

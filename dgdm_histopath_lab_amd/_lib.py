@@ -185,6 +185,15 @@ def load(build_if_missing: bool = False) -> C.CDLL:
     return lib
 
 
+def open_library(path: str) -> C.CDLL:
+    """Another build of the library (diagnostic twins: lib/canary, lib/stamps) with the same signature table; not cached."""
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    return lib
+
+
 def check(code: int, what: str) -> None:
     if code != 0:
         msg = load().dgdm_error_string(code).decode()

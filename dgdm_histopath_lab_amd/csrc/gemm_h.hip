@@ -420,9 +420,19 @@ struct Loader {
     unsigned ok = 0;
 #pragma unroll
     for (int e = 0; e < 4; ++e) ok |= (colok && m + e < mend) ? (1u << e) : 0u;
+#ifdef DGDM_STAGE_CANARY      // see csrc/gemm_img.hip: the registers hold NaN until the load lands
+    {
+      const float nan_ = __builtin_nanf("");
+      R.v[0] = R.v[1] = R.v[2] = R.v[3] = f32x4r{nan_, nan_, nan_, nan_};
+    }
+    asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %5, off\n\t"
+                 "global_load_dwordx4 %2, %6, off\n\tglobal_load_dwordx4 %3, %7, off"
+                 : "+v"(R.v[0]), "+v"(R.v[1]), "+v"(R.v[2]), "+v"(R.v[3]) : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]) : "memory");
+#else
     asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %5, off\n\t"
                  "global_load_dwordx4 %2, %6, off\n\tglobal_load_dwordx4 %3, %7, off"
                  : "=&v"(R.v[0]), "=&v"(R.v[1]), "=&v"(R.v[2]), "=&v"(R.v[3]) : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]) : "memory");
+#endif
 #pragma unroll
     for (int e = 0; e < 4; ++e) p[e] += (m + e + KS2 < mlim) ? step : 0;         // stop at the end of memory; those rows are masked anyway
     R.ok = ok;

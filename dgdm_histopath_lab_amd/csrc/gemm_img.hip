@@ -61,6 +61,24 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned* h, unsign
   *l = lb;
 }
 
+// Staging canary (tests/test_hip_gemm_img.py, the lib/canary build: -DDGDM_STAGE_CANARY).  The activation loads below are inline asm
+// retired by ONE hand-placed s_waitcnt per stage; nothing but the kernel's own text order keeps a consumer behind that wait.  In the
+// canary build every destination register holds a NaN when its load is issued (the registers become in/out operands of the asm, so
+// the compiler has to materialise the poison in front of it): a consumer that runs before the wait -- a scheduler that moved it, a
+// copy the allocator slipped in -- multiplies NaNs into the result instead of silently using the previous stage's numbers.
+#ifdef DGDM_STAGE_CANARY
+#define DGDM_CANARY_OUT(r_) "+v"(r_)
+#define DGDM_CANARY_POISON(a_, b_, c_, d_)                                                                          \
+  {                                                                                                                 \
+    const float nan__ = __builtin_nanf("");                                                                         \
+    typedef float canary_f32x4 __attribute__((ext_vector_type(4)));                                                 \
+    a_ = b_ = c_ = d_ = canary_f32x4{nan__, nan__, nan__, nan__};                                                    \
+  }
+#else
+#define DGDM_CANARY_OUT(r_) "=&v"(r_)
+#define DGDM_CANARY_POISON(a_, b_, c_, d_)
+#endif
+
 struct ImgDesc {
   const float* w0; const float* w1;     // sources (w1: second matrix of a column-concatenated weight, or null)
   long long ld0, ld1;
@@ -192,9 +210,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_gemm_img(const float* __res
 #define DGDM_LOAD_CHUNK(c_, r0_, r1_, r2_, r3_)                                                                     \
   {                                                                                                                 \
     const float* p__ = arow + min(32 * (c_) + klane, K - 16);                                                       \
+    DGDM_CANARY_POISON(r0_, r1_, r2_, r3_)                                                                            \
     asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:16\n\t"                \
                  "global_load_dwordx4 %2, %4, off offset:32\n\tglobal_load_dwordx4 %3, %4, off offset:48"            \
-                 : "=&v"(r0_), "=&v"(r1_), "=&v"(r2_), "=&v"(r3_) : "v"(p__) : "memory");                              \
+                 : DGDM_CANARY_OUT(r0_), DGDM_CANARY_OUT(r1_), DGDM_CANARY_OUT(r2_), DGDM_CANARY_OUT(r3_) : "v"(p__) : "memory"); \
   }
 #define DGDM_CONVERT(cc_, r0_, r1_, r2_, r3_)                                                                       \
   {                                                                                                                 \
@@ -374,9 +393,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_img8(const float* __restrict__ 
 #define DGDM_LOAD_CHUNK(c_, r0_, r1_, r2_, r3_)                                                                     \
   {                                                                                                                 \
     const float* p__ = arow + min(32 * (c_) + klane, K - 16);                                                       \
+    DGDM_CANARY_POISON(r0_, r1_, r2_, r3_)                                                                            \
     asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:16\n\t"                \
                  "global_load_dwordx4 %2, %4, off offset:32\n\tglobal_load_dwordx4 %3, %4, off offset:48"            \
-                 : "=&v"(r0_), "=&v"(r1_), "=&v"(r2_), "=&v"(r3_) : "v"(p__) : "memory");                              \
+                 : DGDM_CANARY_OUT(r0_), DGDM_CANARY_OUT(r1_), DGDM_CANARY_OUT(r2_), DGDM_CANARY_OUT(r3_) : "v"(p__) : "memory"); \
   }
   f32x16 acc[NT8];
 #pragma unroll

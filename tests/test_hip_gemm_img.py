@@ -88,3 +88,49 @@ def test_image_follows_the_weight():
             assert_close(ops.gemm_nn_raw(torch.ones(1000, 96, device=DEV), w, math="f16x2"),
                          torch.ones(1000, 96, dtype=torch.float64) @ w.double().cpu(), 1e-5, "nn after refresh")
         assert ops.WEIGHT_IMAGES.table is not None and ops.WEIGHT_IMAGES.table_n >= 2
+
+
+def test_asm_issued_loads_are_retired_before_use_staging_canary(monkeypatch):
+    """the image GEMMs and the dW kernel issue their activation loads as inline asm and retire them with
+    one hand-placed s_waitcnt per stage; the compile-time zero-spill check (tests/test_abi.py) cannot see a consumer that the
+    scheduler moved above the wait.  The canary build of the same kernels (lib/canary, -DDGDM_STAGE_CANARY) poisons every staging
+    register with NaN when its load is issued: on cache-cold operands (a 1 GiB buffer rewritten before each call, so the loads take
+    their full HBM latency) a premature read multiplies NaNs into the result.  Results must be finite AND bit-identical to the
+    shipped build's."""
+    import os
+    from dgdm_histopath_lab_amd import _build, _lib, ops
+    assert os.path.exists(_build.CANARY_PATH), "lib/canary/libdgdm_hip.so is built by __graft_entry__.build()"
+    canary = _lib.open_library(_build.CANARY_PATH)
+    prev = ops.configure(gemm="f16x2")
+    try:
+        g = torch.Generator().manual_seed(12)
+        evict = torch.zeros(256 * 1024 * 1024, dtype=torch.float32, device=DEV)     # 1 GiB: L2 and the Infinity Cache turn over
+        cases = [(40000, 768, 512), (40000, 512, 128), (20000, 160, 128), (5000, 128, 128), (4099, 144, 36)]
+        for m, k, n in cases:
+            x = torch.randn(m, k, generator=g).to(DEV)
+            w = (torch.randn(n, k, generator=g) / k ** 0.5).to(DEV)
+            b = torch.randn(n, generator=g).to(DEV)
+            gy = torch.randn(m, n, generator=g).to(DEV)
+
+            def run():
+                ops.weights_changed()
+                evict.add_(1.0)
+                y = ops.gemm_nt_raw(x, w, b, math="f16x2")                # k_gemm_img8 / k_gemm_img<4,1> (weight image as B)
+                evict.add_(1.0)
+                dx = ops.gemm_nn_raw(gy, w, math="f16x2")                 # the dx form of the same kernels
+                evict.add_(1.0)
+                dw, db = ops.gemm_tn_raw(gy, x, True, math="f16x2")       # k_gemmh_tn32
+                torch.cuda.synchronize()
+                return y, dx, dw, db
+            want = run()
+            monkeypatch.setattr(_lib, "_lib", canary)
+            got = run()
+            monkeypatch.undo()
+            for name, a, c in zip(("y", "dx", "dW", "db"), want, got):
+                assert torch.isfinite(c).all(), f"{name} at {(m, k, n)}: a staging register was read before its load landed"
+                assert torch.equal(a, c), f"{name} at {(m, k, n)}"
+            ref = x.double() @ w.double().t() + b.double()
+            assert_close(got[0], ref, 1e-5, "y vs float64")
+        del evict
+    finally:
+        ops.configure(**prev)
