@@ -49,6 +49,8 @@ def _latest_profile(stem):
 
 PMC_TRAFFIC = _latest_profile("pmc_traffic")   # tools/pmc_traffic.py, separate --pmc passes
 PMC_VALU = _latest_profile("pmc_valu")         # tools/pmc_valu.py, one --pmc pass
+PMC_TRAFFIC_FP32 = _latest_profile("fp32_pmc_traffic")   # the same passes of `bench.py --precision fp32` (the strict_fp32 leg's kernels)
+PMC_VALU_FP32 = _latest_profile("fp32_pmc_valu")
 
 
 def attention_flops(num_graph_nodes, heads, head_dim, products):
@@ -74,20 +76,21 @@ def _pmc_kernel(path, kernel):
     return None
 
 
-def pmc_traffic(kernel):
+def pmc_traffic(kernel, path=None):
     """HBM bytes per launch of `kernel` from the committed PMC passes (same command, same sizes), or None."""
-    v = _pmc_kernel(PMC_TRAFFIC, kernel)
+    v = _pmc_kernel(path or PMC_TRAFFIC, kernel)
     return None if v is None else v["hbm_bytes_per_launch"]
 
 
-def pmc_valu(kernel):
+def pmc_valu(kernel, path=None):
     """VALU / matrix-pipe occupancy and the wave-cycle split of `kernel` from the committed PMC pass, or None."""
-    v = _pmc_kernel(PMC_VALU, kernel)
+    path = path or PMC_VALU
+    v = _pmc_kernel(path, kernel)
     if v is None:
         return None
     keep = ("valu_busy", "mfma_busy", "wave_cycles_active", "wave_cycles_issue_stalled", "wave_cycles_parked", "valu_share_of_active",
             "valu_insts_per_launch", "mfma_insts_per_launch", "occupancy_waves_per_simd", "profiled_instantiation")
-    return dict({k: v[k] for k in keep if k in v}, source=os.path.relpath(PMC_VALU, ROOT))
+    return dict({k: v[k] for k in keep if k in v}, source=os.path.relpath(path, ROOT))
 
 
 def gather_bytes(n, e, c):
@@ -484,7 +487,7 @@ def main():
         # of twice the reduction length: 4x the FLOP), P V / P^T dO / dS^T Q / dS K as hi.hi + lo.hi + hi.lo (3x), ones.P twice (forward)
         issued_x = {"attn_fwd": (4 + 3 + 2 * 1.0) / 2, "attn_bwd_dq": (4 + 4 + 3) / 3, "attn_bwd_dkv": (4 + 4 + 3 + 3) / 4}
 
-        def attention_roofline(tm, names, fp16_pipe, graphed_note):
+        def attention_roofline(tm, names, fp16_pipe, graphed_note, valu_path=None, traffic_path=None):
             dom = max((k for k in flops if k in tm), key=lambda k: tm[k][1]) if any(k in tm for k in flops) else None
             if dom is None:
                 return {"note": "no attention kernel was timed"}
@@ -501,9 +504,9 @@ def main():
                              "issued_tflops": round(issued_x[dom] * tf, 1), "issued_frac": round(issued_x[dom] * tf / peak, 4),
                              "fp32_equivalent_frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4)})
             common = {"kernel": names[dom], "ms_per_launch": round(ms, 4), "launches_timed": tm[dom][0],
-                      "traffic": None if args.large else pmc_traffic(names[dom]),    # the PMC passes were taken on the headline workload
+                      "traffic": None if args.large else pmc_traffic(names[dom], traffic_path),    # the PMC passes were taken on the headline workload
                       "other_kernels_ms": {k: round(v[1], 4) for k, v in tm.items() if k != dom}, "timed_with": graphed_note}
-            valu = None if args.large else pmc_valu(names[dom])
+            valu = None if args.large else pmc_valu(names[dom], valu_path)
             if fp16_pipe and valu is not None and "valu_busy" in valu:
                 # the split-fp16 kernels are bound by VALU issue, not by the matrix pipe (PMC pass of this command, committed under
                 # profiles/): `frac` = share of SIMD cycles in which a vector instruction was executing; the matrix-pipe pricing
@@ -520,10 +523,12 @@ def main():
                    if graphed else "HIP events inside the timed region")
         roofline = {"note": "not computed for this run; see the fixed-size headline run"}
         if not args.mixed:
-            roofline = attention_roofline(timers, k16 if split else k32, split, ev_note)
+            roofline = attention_roofline(timers, k16 if split else k32, split, ev_note,
+                                          None if split else PMC_VALU_FP32, None if split else PMC_TRAFFIC_FP32)
         if strict is not None:
             strict["roofline"] = attention_roofline(strict.pop("_timers"), k32, False,
-                                                    "HIP events around eager launches of the fp32 step right after its timed region")
+                                                    "HIP events around eager launches of the fp32 step right after its timed region",
+                                                    PMC_VALU_FP32, PMC_TRAFFIC_FP32)
         result = {
             "metric": "slides/sec (DGDM fwd+bwd, 10k-node/768-feat graphs)", "value": round(world * args.batch * args.steps / dt, 3),
             "unit": "slides/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -597,7 +597,7 @@ __global__ __launch_bounds__(256, 2) void k_gemmh_tn32(const float* __restrict__
 struct TnProb {
   const float* dY; const float* X; float* partial; const unsigned* amax_dy; const unsigned* amax_x;
   int64_t ldy, ldx;
-  int M, N, K, chunk, with_bias, gx, gy, block0;
+  int M, N, K, chunk, with_bias, gx, gy, block0, nchunks, cpad;
 };
 struct TnMany { TnProb p[DGDM_TN_PARTIAL_MAX]; int n; };
 
@@ -606,9 +606,14 @@ __global__ __launch_bounds__(256, 2) void k_gemmh_tn32_many(const TnMany b) {
   int i = 0;
   for (int j = 1; j < b.n; ++j) i = ((int)blockIdx.x >= b.p[j].block0) ? j : i;        // wave-uniform: scalar loads of the arguments
   const TnProb& q = b.p[i];
+  // XCD-aware order.  Workgroups go to the 8 XCDs round-robin and every XCD has an L2 of its own; the tiles of one ROW CHUNK read
+  // the same rows of dY and X.  With the chunk as the fastest index (chunk counts are powers of two, block0 a multiple of 8) a
+  // chunk's tiles all land on the XCD(s) chunk % 8, whose L2 then serves the re-reads: tile-fastest order spread them over all 8
+  // and every L2 fetched the rows again (2.7x the operands' bytes over the fabric: profiles/r03_pmc_traffic.json).
   const int local = (int)blockIdx.x - q.block0;
-  const int bx = local % q.gx, rest = local / q.gx;
-  tn32_tile<true>(q.dY, q.ldy, q.X, q.ldx, q.M, q.N, q.K, q.chunk, q.with_bias, q.partial, q.amax_dy, q.amax_x, bx, rest % q.gy, rest / q.gy, smem);
+  const int mc = local % q.cpad, t = local / q.cpad;
+  if (mc >= q.nchunks || t >= q.gx * q.gy) return;
+  tn32_tile<true>(q.dY, q.ldy, q.X, q.ldx, q.M, q.N, q.K, q.chunk, q.with_bias, q.partial, q.amax_dy, q.amax_x, t % q.gx, t / q.gx, mc, smem);
 }
 
 // dW[n][k] / db[n] = sum over slots of in[slot][n*K + k] / in[slot][N*K + n]; fixed order: thread (column, part)
@@ -792,10 +797,26 @@ extern "C" int dgdm_gemm_tn_partial_f16x2(const float* dY, int64_t ldy, const fl
                  stream, true);
 }
 
+// rows per chunk of one problem inside dgdm_gemm_tn_partial_many_f16x2: the chunk COUNT aimed for is a power of two (the XCD-aware
+// workgroup order of k_gemmh_tn32_many wants chunk % 8 to name an XCD)
+static int tnh_chunk_rows_grouped(int M, int N, int K) {
+  const int tiles = ((N + BM - 1) / BM) * ((K + BN - 1) / BN);
+  int want = (DGDM_TN_WANT_GROUPED + tiles / 2) / tiles;
+  if (want < 1) want = 1;
+  if (want > 256) want = 256;
+  int p2 = 1;
+  while (2 * p2 <= want) p2 *= 2;
+  if (2 * p2 - want < want - p2) p2 *= 2;        // nearest power of two
+  int chunk = (M + p2 - 1) / p2;
+  chunk = (chunk + 2 * KS - 1) / (2 * KS) * (2 * KS);
+  if (chunk < 8 * KS) chunk = 8 * KS;
+  return chunk;
+}
+
 // row chunks (= partial slots) of one problem inside dgdm_gemm_tn_partial_many_f16x2
 extern "C" int32_t dgdm_gemm_tn_chunks_grouped(int32_t M, int32_t N, int32_t K) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
-  const int chunk = tnh_chunk_rows(M, N, K, DGDM_TN_WANT_GROUPED);
+  const int chunk = tnh_chunk_rows_grouped(M, N, K);
   return (M + chunk - 1) / chunk;
 }
 
@@ -809,16 +830,18 @@ extern "C" int dgdm_gemm_tn_partial_many_f16x2(const DgdmTnPartial* descs, int32
     if (d.M <= 0 || d.N <= 0 || d.K <= 0 || !d.dY || !d.X || !d.workspace || bad_amax(d.amax_dy, d.amax_x)) return DGDM_ERR_INVALID_ARG;
     if ((d.ldy & 3) || (d.ldx & 3) || (d.N & 3) || (d.K & 3) || d.ldy < d.N || d.ldx < d.K || !dgdm_aligned16(d.dY) || !dgdm_aligned16(d.X))
       return DGDM_ERR_UNSUPPORTED;
-    const int chunk = tnh_chunk_rows(d.M, d.N, d.K, DGDM_TN_WANT_GROUPED);     // the problems fill the chip TOGETHER
+    const int chunk = tnh_chunk_rows_grouped(d.M, d.N, d.K);     // the problems fill the chip TOGETHER
     const int nchunks = (d.M + chunk - 1) / chunk;
+    int cpad = 1;
+    while (cpad < nchunks) cpad *= 2;
     const int64_t width = (int64_t)d.N * d.K + (d.with_bias ? d.N : 0);
     if (width > 0x7fffffffLL) return DGDM_ERR_UNSUPPORTED;
     if (d.workspace_bytes < (size_t)nchunks * width * sizeof(float)) return DGDM_ERR_WORKSPACE;
     TnProb& q = b.p[i];
     q.dY = d.dY; q.X = d.X; q.partial = static_cast<float*>(d.workspace); q.amax_dy = d.amax_dy; q.amax_x = d.amax_x;
     q.ldy = d.ldy; q.ldx = d.ldx; q.M = d.M; q.N = d.N; q.K = d.K; q.chunk = chunk; q.with_bias = d.with_bias ? 1 : 0;
-    q.gx = (d.N + BM - 1) / BM; q.gy = (d.K + BN - 1) / BN; q.block0 = blocks;
-    const int64_t nb = (int64_t)q.gx * q.gy * nchunks;
+    q.gx = (d.N + BM - 1) / BM; q.gy = (d.K + BN - 1) / BN; q.block0 = blocks; q.nchunks = nchunks; q.cpad = cpad;
+    const int64_t nb = ((int64_t)q.gx * q.gy * cpad + 7) / 8 * 8;       // block0 of the next problem stays a multiple of 8
     if (nb + blocks > 0x3fffffff) return DGDM_ERR_UNSUPPORTED;
     blocks += (int)nb;
   }
