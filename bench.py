@@ -482,7 +482,8 @@ def main():
                  "attn_bwd_dkv": attention_flops(sizes, heads, hd, 4)}
         split = ops.ATTN_PRECISION == "fp16x2"
         k16 = {"attn_fwd": "k_attn_h_fwd<4,1,1,3>", "attn_bwd_dq": "k_attn_h_bwd_dq<4,1,1,1>", "attn_bwd_dkv": "k_attn_h_bwd_dkv<2,1,1,3>"}
-        k32 = {"attn_fwd": "k_attn_fwd<4,64>", "attn_bwd_dq": "k_attn_bwd_dq<4,64>", "attn_bwd_dkv": "k_attn_bwd_dkv<4,32>"}
+        dr = "false" if args.eval_mode else "true"
+        k32 = {"attn_fwd": f"k_attn_fwd<4,64,{dr}>", "attn_bwd_dq": f"k_attn_bwd_dq<4,64,{dr}>", "attn_bwd_dkv": f"k_attn_bwd_dkv<4,32,{dr}>"}
         # MFMAs the split-fp16 kernels issue per algorithmic product: Q'K and dO V as [hi|lo].[hi|hi] + [hi|lo].[lo|lo] (2 instructions
         # of twice the reduction length: 4x the FLOP), P V / P^T dO / dS^T Q / dS K as hi.hi + lo.hi + hi.lo (3x), ones.P twice (forward)
         issued_x = {"attn_fwd": (4 + 3 + 2 * 1.0) / 2, "attn_bwd_dq": (4 + 4 + 3) / 3, "attn_bwd_dkv": (4 + 4 + 3 + 3) / 4}

@@ -136,11 +136,9 @@ class AdaptiveGraphPooling(nn.Module):
     def __init__(self, in_channels: int, ratio: float = 0.5, min_score: Optional[float] = None, multiplier: float = 1.0,
                  nonlinearity: str = "tanh"):
         super().__init__()
-        if min_score is not None:
-            raise NotImplementedError("min_score pooling is not on the DGDM path")
         self.in_channels, self.ratio, self.min_score, self.multiplier = in_channels, ratio, min_score, multiplier
         self.score_net = nn.Sequential(nn.Linear(in_channels, in_channels // 2), nn.ReLU(), nn.Linear(in_channels // 2, 1))
-        self._nl = nonlinearity
+        self._nl = nonlinearity if nonlinearity in ("tanh", "softmax") else "sigmoid"      # graph_layers.py:277-283: anything else is sigmoid
 
     def forward(self, x: Tensor, edge_index: Tensor, edge_attr: Optional[Tensor] = None, batch: Optional[Tensor] = None,
                 compact: bool = False, return_node_map: bool = False, *, relu_decisions: Optional[Tensor] = None,
@@ -153,14 +151,21 @@ class AdaptiveGraphPooling(nn.Module):
         k = max(1, int(self.ratio * n))
         h = ops.lin(self.score_net[0], x)
         w2, b2 = self.score_net[2].weight, self.score_net[2].bias
-        fused = (x.is_cuda and self._nl == "tanh" and x.dtype == torch.float32 and ops.pool_supported(x.size(1), h.size(1))
-                 and n < 2 ** 31)
+        fused = x.is_cuda and x.dtype == torch.float32 and ops.pool_supported(x.size(1), h.size(1)) and n < 2 ** 31
         if (relu_decisions is not None or perm_decision is not None) and not fused:
             raise NotImplementedError("decision injection is wired into the K9 kernels only")
-        if fused:   # K9 kernels: no host sync, no data-dependent shapes
-            s = ops.pool_score(h, w2, b2, decide=relu_decisions)
+        if fused:   # K9 kernels: no data-dependent shapes; no host sync unless min_score is set
+            s = ops.pool_score(h, w2, b2, decide=relu_decisions, nonlinearity=self._nl)
             if trace is not None:
                 trace[f"pre.pool{trace_tag}"], trace[f"score{trace_tag}"] = h.detach(), s.detach()
+            if self.min_score is not None:
+                # the reference keeps scores >= min_score (graph_layers.py:302-303): a data-dependent count, read back once; the
+                # nodes with a score >= the threshold ARE the `count` largest, so the exact top-k selection below yields that set
+                k = ops.count_ge(s, self.min_score)
+                if k == 0:
+                    raise ValueError(f"min_score={self.min_score} keeps no node of this batch (largest score {float(s.max()):.4g})")
+                if perm_decision is not None and perm_decision.numel() != k:
+                    raise ValueError(f"injected perm has {perm_decision.numel()} entries, min_score keeps {k}")
             perm, node_map = ops.topk_perm(s, k)
             if trace is not None:
                 trace[f"own_perm{trace_tag}"] = perm

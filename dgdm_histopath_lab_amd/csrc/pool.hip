@@ -24,7 +24,7 @@ namespace {
 // 16 lanes per row, float4 per lane per 64-column chunk; 16 rows per 256-thread block.
 __global__ __launch_bounds__(256) void k_pool_score_fwd(const float* __restrict__ h, int64_t ldh, const float* __restrict__ w2,
                                                         const float* __restrict__ b2, int N, int C, float* __restrict__ s,
-                                                        const uint8_t* __restrict__ decide) {
+                                                        const uint8_t* __restrict__ decide, int nl) {
   const int sub = threadIdx.x & 15, row = blockIdx.x * 16 + (threadIdx.x >> 4);
   float acc = 0.f;
   if (row < N)
@@ -40,14 +40,17 @@ __global__ __launch_bounds__(256) void k_pool_score_fwd(const float* __restrict_
     }
 #pragma unroll
   for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-  if (sub == 0 && row < N) s[row] = tanhf(acc + b2[0]);
+  if (sub == 0 && row < N) {
+    const float z = acc + b2[0];     // nl: 0 tanh (DGDMModel's pools), 1 sigmoid, 2 none (the logit; softmax over all nodes follows)
+    s[row] = nl == 0 ? tanhf(z) : nl == 1 ? 1.f / (1.f + __expf(-z)) : z;
+  }
 }
 
 // dh[i] = t_i * w2 * [h > 0], t_i = ds_i (1 - s_i^2); partial[b] = [sum_i t_i relu(h[i]) (C) | sum_i t_i] over the block's rows
 __global__ __launch_bounds__(256) void k_pool_score_bwd(const float* __restrict__ h, int64_t ldh, const float* __restrict__ w2,
                                                         const float* __restrict__ s, const float* __restrict__ ds, int N, int C,
                                                         int rows_per_block, float* __restrict__ dh, int64_t lddh,
-                                                        float* __restrict__ partial, const uint8_t* __restrict__ decide) {
+                                                        float* __restrict__ partial, const uint8_t* __restrict__ decide, int nl) {
   // thread = (float4 column c4, row lane): C/4 <= 64 columns x (256 / cols) row lanes
   const int cols = C / 4;
   const int c4 = threadIdx.x % cols, rl = threadIdx.x / cols, nrl = 256 / cols;
@@ -58,7 +61,7 @@ __global__ __launch_bounds__(256) void k_pool_score_bwd(const float* __restrict_
     const float4 w = *reinterpret_cast<const float4*>(w2 + 4 * c4);
     for (int r = r0 + rl; r < r1; r += nrl) {
       const float sv = s[r];
-      const float t = ds[r] * (1.f - sv * sv);
+      const float t = ds[r] * (nl == 0 ? 1.f - sv * sv : nl == 1 ? sv * (1.f - sv) : 1.f);
       const float4 v = *reinterpret_cast<const float4*>(h + (int64_t)r * ldh + 4 * c4);
       bool px = v.x > 0.f, py = v.y > 0.f, pz = v.z > 0.f, pw = v.w > 0.f;
       if (decide) {
@@ -91,6 +94,44 @@ __global__ __launch_bounds__(256) void k_pool_score_bwd(const float* __restrict_
 }
 
 constexpr int SCORE_BWD_BLOCKS = 256;
+
+// ------------------------------------------------------------------ softmax over ALL nodes (nonlinearity='softmax',
+// core/graph_layers.py:280-281: torch.softmax(scores, dim=0)) and the count behind min_score pooling.  One workgroup, fixed-order
+// reductions: N is the node count of a batch, the vector a few hundred KB.
+__device__ __forceinline__ float block_reduce_1024(float v, bool is_max, float* sm) {
+  v = is_max ? wave_max(v) : wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float r = sm[0];
+  for (int i = 1; i < 16; ++i) r = is_max ? fmaxf(r, sm[i]) : r + sm[i];
+  return r;
+}
+__global__ __launch_bounds__(1024) void k_vec_softmax_fwd(const float* __restrict__ z, int N, float* __restrict__ s) {
+  __shared__ float sm[16];
+  float m = -INFINITY;
+  for (int i = threadIdx.x; i < N; i += 1024) m = fmaxf(m, z[i]);
+  m = block_reduce_1024(m, true, sm);
+  float l = 0.f;
+  for (int i = threadIdx.x; i < N; i += 1024) l += __expf(z[i] - m);
+  l = block_reduce_1024(l, false, sm);
+  const float inv = 1.f / l;
+  for (int i = threadIdx.x; i < N; i += 1024) s[i] = __expf(z[i] - m) * inv;
+}
+__global__ __launch_bounds__(1024) void k_vec_softmax_bwd(const float* __restrict__ s, const float* __restrict__ ds, int N, float* __restrict__ dz) {
+  __shared__ float sm[16];
+  float d = 0.f;
+  for (int i = threadIdx.x; i < N; i += 1024) d += s[i] * ds[i];
+  d = block_reduce_1024(d, false, sm);
+  for (int i = threadIdx.x; i < N; i += 1024) dz[i] = s[i] * (ds[i] - d);
+}
+__global__ __launch_bounds__(1024) void k_count_ge(const float* __restrict__ s, int N, float thr, int32_t* __restrict__ out) {
+  __shared__ float sm[16];
+  float c = 0.f;
+  for (int i = threadIdx.x; i < N; i += 1024) c += s[i] >= thr ? 1.f : 0.f;     // exact below 2^24 per thread
+  c = block_reduce_1024(c, false, sm);
+  if (threadIdx.x == 0) out[0] = (int32_t)c;
+}
 
 // ------------------------------------------------------------------ top-k
 // order-preserving map float -> uint32 (larger float <=> larger key); -0 == +0, NaNs by bit pattern
@@ -390,14 +431,36 @@ inline bool rows_ok(const float* p, int64_t ld, int C) { return p && (ld & 3) ==
 
 }  // namespace
 
+extern "C" int dgdm_vec_softmax_fwd(const float* z, int32_t N, float* s, void* stream) {
+  if (N < 0) return DGDM_ERR_INVALID_ARG;
+  if (N == 0) return DGDM_OK;
+  if (!z || !s) return DGDM_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(k_vec_softmax_fwd, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), z, N, s);
+  return dgdm_launch_status();
+}
+extern "C" int dgdm_vec_softmax_bwd(const float* s, const float* ds, int32_t N, float* dz, void* stream) {
+  if (N < 0) return DGDM_ERR_INVALID_ARG;
+  if (N == 0) return DGDM_OK;
+  if (!s || !ds || !dz) return DGDM_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(k_vec_softmax_bwd, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), s, ds, N, dz);
+  return dgdm_launch_status();
+}
+extern "C" int dgdm_count_ge(const float* s, int32_t N, float threshold, int32_t* out, void* stream) {
+  if (N < 0 || !out) return DGDM_ERR_INVALID_ARG;
+  if (N > 0 && !s) return DGDM_ERR_INVALID_ARG;
+  if (N >= (1 << 24) * 64) return DGDM_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(k_count_ge, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), s, N, threshold, out);
+  return dgdm_launch_status();
+}
+
 extern "C" int dgdm_pool_score_fwd(const float* h, int64_t ldh, const float* w2, const float* b2, int32_t N, int32_t C, float* s,
-                                   const uint8_t* decide, void* stream) {
-  if (N < 0 || C <= 0) return DGDM_ERR_INVALID_ARG;
+                                   const uint8_t* decide, int32_t nonlinearity, void* stream) {
+  if (N < 0 || C <= 0 || nonlinearity < 0 || nonlinearity > 2) return DGDM_ERR_INVALID_ARG;
   if (N == 0) return DGDM_OK;
   if (!h || !w2 || !b2 || !s) return DGDM_ERR_INVALID_ARG;
   if ((C & 3) || !rows_ok(h, ldh, C) || !dgdm_aligned16(w2)) return DGDM_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(k_pool_score_fwd, dim3((N + 15) / 16), dim3(256), 0, static_cast<hipStream_t>(stream), h, ldh, w2, b2, N, C, s,
-                     decide);
+                     decide, nonlinearity);
   return dgdm_launch_status();
 }
 
@@ -407,9 +470,9 @@ extern "C" size_t dgdm_pool_score_bwd_workspace_bytes(int32_t N, int32_t C) {
 }
 
 extern "C" int dgdm_pool_score_bwd(const float* h, int64_t ldh, const float* w2, const float* s, const float* ds, int32_t N, int32_t C,
-                                   float* dh, int64_t lddh, float* dw2, float* db2, const uint8_t* decide, void* workspace,
-                                   size_t workspace_bytes, void* stream_) {
-  if (N < 0 || C <= 0) return DGDM_ERR_INVALID_ARG;
+                                   float* dh, int64_t lddh, float* dw2, float* db2, const uint8_t* decide, int32_t nonlinearity,
+                                   void* workspace, size_t workspace_bytes, void* stream_) {
+  if (N < 0 || C <= 0 || nonlinearity < 0 || nonlinearity > 2) return DGDM_ERR_INVALID_ARG;
   if (!dw2 || !db2) return DGDM_ERR_INVALID_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream_);
   if (N == 0) {
@@ -423,7 +486,7 @@ extern "C" int dgdm_pool_score_bwd(const float* h, int64_t ldh, const float* w2,
   const int rpb = (N + SCORE_BWD_BLOCKS - 1) / SCORE_BWD_BLOCKS;
   const int nb = (N + rpb - 1) / rpb;
   float* partial = static_cast<float*>(workspace);
-  hipLaunchKernelGGL(k_pool_score_bwd, dim3(nb), dim3(256), 0, st, h, ldh, w2, s, ds, N, C, rpb, dh, lddh, partial, decide);
+  hipLaunchKernelGGL(k_pool_score_bwd, dim3(nb), dim3(256), 0, st, h, ldh, w2, s, ds, N, C, rpb, dh, lddh, partial, decide, nonlinearity);
   colsum_final_launch(partial, nb, C + 1, dw2, C, db2, st);
   return dgdm_launch_status();
 }

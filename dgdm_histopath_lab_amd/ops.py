@@ -1736,20 +1736,23 @@ def pool_supported(C: int, C2: int) -> bool:
     return C % 4 == 0 and C2 % 4 == 0 and C2 <= 256 and 256 % (C2 // 4) == 0
 
 
+POOL_NONLINEARITY = {"tanh": 0, "sigmoid": 1, "none": 2}
+
+
 class _PoolScore(torch.autograd.Function):
-    """s = tanh(w2 . relu(h) + b2); h [N, C2] is the first score layer's output (a GEMM through `lin`)."""
+    """s = f(w2 . relu(h) + b2), f = tanh / sigmoid / identity; h [N, C2] is the first score layer's output (a GEMM through `lin`)."""
 
     @staticmethod
-    def forward(ctx, h, w2, b2, decide=None):
+    def forward(ctx, h, w2, b2, decide=None, nl: int = 0):
         lib = _lib.load()
         h = _rowmajor(h)
         w2c, b2c = _f32c(w2.reshape(-1)), _f32c(b2.reshape(-1))
         N, C2 = h.shape
         s = torch.empty(N, dtype=torch.float32, device=h.device)
         _lib.check(lib.dgdm_pool_score_fwd(h.data_ptr(), h.stride(0), w2c.data_ptr(), b2c.data_ptr(), N, C2, s.data_ptr(),
-                                           _lib.ptr(decide), _lib.stream_ptr(h.device)), "dgdm_pool_score_fwd")
+                                           _lib.ptr(decide), nl, _lib.stream_ptr(h.device)), "dgdm_pool_score_fwd")
         ctx.save_for_backward(h, w2c, s)
-        ctx.w2_shape, ctx.b2_shape, ctx.decide = w2.shape, b2.shape, decide
+        ctx.w2_shape, ctx.b2_shape, ctx.decide, ctx.nl = w2.shape, b2.shape, decide, nl
         return s
 
     @staticmethod
@@ -1764,13 +1767,46 @@ class _PoolScore(torch.autograd.Function):
         wsb = _lib.workspace_bytes("dgdm_pool_score_bwd_workspace_bytes", N, C2)
         ws = torch.empty(max(wsb, 4) // 4, dtype=torch.float32, device=h.device)
         _lib.check(lib.dgdm_pool_score_bwd(h.data_ptr(), h.stride(0), w2c.data_ptr(), s.data_ptr(), ds.data_ptr(), N, C2, dh.data_ptr(),
-                                           dh.stride(0), dw2.data_ptr(), db2.data_ptr(), _lib.ptr(ctx.decide), ws.data_ptr(), wsb,
+                                           dh.stride(0), dw2.data_ptr(), db2.data_ptr(), _lib.ptr(ctx.decide), ctx.nl, ws.data_ptr(), wsb,
                                            _lib.stream_ptr(h.device)), "dgdm_pool_score_bwd")
-        return dh, dw2.view(ctx.w2_shape), db2.view(ctx.b2_shape), None
+        return dh, dw2.view(ctx.w2_shape), db2.view(ctx.b2_shape), None, None
 
 
-def pool_score(h, w2, b2, decide=None):
-    return _PoolScore.apply(h, w2, b2, _decide_arg(decide, h))
+class _VecSoftmax(torch.autograd.Function):
+    """softmax over ALL entries of a vector (AdaptiveGraphPooling(nonlinearity='softmax'), graph_layers.py:280-281)."""
+
+    @staticmethod
+    def forward(ctx, z):
+        z = _f32c(z)
+        _lib.require_cuda(z)
+        s = torch.empty_like(z)
+        _lib.check(_lib.load().dgdm_vec_softmax_fwd(z.data_ptr(), z.numel(), s.data_ptr(), _lib.stream_ptr(z.device)), "dgdm_vec_softmax_fwd")
+        ctx.save_for_backward(s)
+        return s
+
+    @staticmethod
+    def backward(ctx, ds):
+        (s,) = ctx.saved_tensors
+        ds = _f32c(ds)
+        dz = torch.empty_like(s)
+        _lib.check(_lib.load().dgdm_vec_softmax_bwd(s.data_ptr(), ds.data_ptr(), s.numel(), dz.data_ptr(), _lib.stream_ptr(s.device)),
+                   "dgdm_vec_softmax_bwd")
+        return dz
+
+
+def pool_score(h, w2, b2, decide=None, nonlinearity: str = "tanh"):
+    """Node scores of AdaptiveGraphPooling (graph_layers.py:276-296): tanh / sigmoid of the score MLP, or its softmax over all nodes."""
+    if nonlinearity == "softmax":
+        return _VecSoftmax.apply(_PoolScore.apply(h, w2, b2, _decide_arg(decide, h), POOL_NONLINEARITY["none"]))
+    return _PoolScore.apply(h, w2, b2, _decide_arg(decide, h), POOL_NONLINEARITY[nonlinearity])
+
+
+def count_ge(s: torch.Tensor, threshold: float) -> int:
+    """#{i : s[i] >= threshold} -- ONE host sync (min_score pooling keeps a data-dependent number of nodes, graph_layers.py:302-303)."""
+    s = _f32c(s.detach())
+    out = torch.empty(1, dtype=torch.int32, device=s.device)
+    _lib.check(_lib.load().dgdm_count_ge(s.data_ptr(), s.numel(), float(threshold), out.data_ptr(), _lib.stream_ptr(s.device)), "dgdm_count_ge")
+    return int(out.item())
 
 
 def topk_perm(s: torch.Tensor, k: int):

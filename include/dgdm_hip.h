@@ -553,8 +553,13 @@ DGDM_API int dgdm_gemm_tn_partial_many_f16x2(const DgdmTnPartial* descs, int32_t
  * replaces: AdaptiveGraphPooling.forward -- core/graph_layers.py:285-329 (score MLP tail, topk,
  *           mask.nonzero, x[perm] * score, edge filter + relabel) and the unpool / skip / activation
  *           of GraphUNet.forward -- core/graph_layers.py:441-448.
- *   dgdm_pool_score_fwd : s[i] = tanh(w2 . relu(h[i]) + b2[0]);  h [N, C] = first score layer's output
+ *   dgdm_pool_score_fwd : s[i] = f(w2 . relu(h[i]) + b2[0]);  h [N, C] = first score layer's output; f by `nonlinearity`
+ *                         (graph_layers.py:276-283): 0 tanh (DGDMModel's pools), 1 sigmoid, 2 identity -- the logit, for
+ *                         nonlinearity='softmax', whose softmax runs over ALL nodes of the batch: dgdm_vec_softmax_fwd/bwd
  *   dgdm_pool_score_bwd : dh, dw2 [C], db2 [1] from ds (fixed-order reductions)
+ *   dgdm_vec_softmax_fwd/bwd : s = softmax(z) over a vector of N floats; dz = s * (ds - <s, ds>)   (one workgroup, fixed order)
+ *   dgdm_count_ge       : out[0] = #{i : s[i] >= threshold}  (min_score pooling, graph_layers.py:302-303: the kept count is
+ *                         data dependent -- the caller reads it back, ONE host sync, and selects the top `count`)
  *   dgdm_topk_perm      : exact top-k of s.  perm [k] int64 = kept node ids in ascending order,
  *                         node_map [N] int32 = new id or -1.  Ties at the k-th value keep the lowest
  *                         ids.  Integer work: bit-exact and deterministic.  0 <= k <= N.
@@ -566,11 +571,14 @@ DGDM_API int dgdm_gemm_tn_partial_many_f16x2(const DgdmTnPartial* descs, int32_t
  *   dgdm_unpool_add_relu_bwd : dskip[i] = g[i] * [out[i] > 0];  dxc[node_map[i]] = dskip[i]
  * All row pointers: C % 4 == 0, row strides % 4 == 0, 16-byte aligned. */
 DGDM_API int dgdm_pool_score_fwd(const float* h, int64_t ldh, const float* w2, const float* b2, int32_t N, int32_t C, float* s,
-                                 const uint8_t* decide, void* stream);
+                                 const uint8_t* decide, int32_t nonlinearity, void* stream);
+DGDM_API int dgdm_vec_softmax_fwd(const float* z, int32_t N, float* s, void* stream);
+DGDM_API int dgdm_vec_softmax_bwd(const float* s, const float* ds, int32_t N, float* dz, void* stream);
+DGDM_API int dgdm_count_ge(const float* s, int32_t N, float threshold, int32_t* out, void* stream);
 DGDM_API size_t dgdm_pool_score_bwd_workspace_bytes(int32_t N, int32_t C);
 DGDM_API int dgdm_pool_score_bwd(const float* h, int64_t ldh, const float* w2, const float* s, const float* ds, int32_t N, int32_t C,
-                                 float* dh, int64_t lddh, float* dw2, float* db2, const uint8_t* decide, void* workspace,
-                                 size_t workspace_bytes, void* stream);
+                                 float* dh, int64_t lddh, float* dw2, float* db2, const uint8_t* decide, int32_t nonlinearity,
+                                 void* workspace, size_t workspace_bytes, void* stream);
 DGDM_API size_t dgdm_topk_perm_workspace_bytes(int32_t N);
 DGDM_API int dgdm_topk_perm(const float* s, int32_t N, int32_t k, int64_t* perm, int32_t* node_map, void* workspace,
                             size_t workspace_bytes, void* stream);

@@ -145,3 +145,58 @@ def test_relu_kernels_take_injected_decisions():
     for name, a, b in (("dx", xd.grad, X.grad), ("dh", hd.grad, H.grad), ("dw2", w2d.grad, W2.grad), ("db2", b2d.grad, B2.grad),
                        ("dskip", skd.grad, SK.grad)):
         assert_close(a, b, 2e-5, name)
+
+
+def _reference_pool(x, ei, w1, b1, w2, b2, nonlinearity, ratio=0.5, min_score=None, multiplier=1.0):
+    """AdaptiveGraphPooling.forward restated in float64 torch (core/graph_layers.py:276-329)."""
+    s = (torch.relu(x @ w1.t() + b1) @ w2.t() + b2).squeeze(-1)
+    s = torch.tanh(s) if nonlinearity == "tanh" else torch.softmax(s, 0) if nonlinearity == "softmax" else torch.sigmoid(s)
+    if min_score is not None:
+        mask = s >= min_score
+    else:
+        k = max(1, int(ratio * x.size(0)))
+        mask = torch.zeros_like(s, dtype=torch.bool)
+        mask[torch.topk(s, k, sorted=False).indices] = True
+    perm = mask.nonzero().squeeze(-1)
+    pooled = x[perm] * s[perm].unsqueeze(-1) * multiplier
+    node_map = torch.full((x.size(0),), -1, dtype=torch.long)
+    node_map[perm] = torch.arange(perm.numel())
+    keep = (node_map[ei[0]] >= 0) & (node_map[ei[1]] >= 0)
+    return pooled, node_map[ei[:, keep]], perm, s
+
+
+@pytest.mark.parametrize("nonlinearity,min_score", [("sigmoid", None), ("softmax", None), ("tanh", 0.1), ("sigmoid", 0.55), ("anything-else", None)])
+def test_adaptive_pooling_nonlinearities_and_min_score_on_the_kernels(nonlinearity, min_score):
+    """VERDICT r2 'missing' 6: nonlinearity in {softmax, sigmoid} (anything but tanh / softmax is sigmoid in the reference,
+    graph_layers.py:277-283) and min_score pooling (:302-303) on the K9 kernels: scores, kept node ids (bit-exact), pooled features,
+    relabelled edges and all gradients against the float64 restatement.  min_score costs one host sync for the kept count."""
+    from dgdm_histopath_lab_amd.core.graph_layers import AdaptiveGraphPooling
+    g = torch.Generator().manual_seed(7)
+    n, c = 3000, 128
+    x = torch.randn(n, c, generator=g)
+    ei = torch.randint(0, n, (2, 12000), generator=g)
+    pool = AdaptiveGraphPooling(c, ratio=0.5, min_score=min_score, multiplier=1.5, nonlinearity=nonlinearity)
+    with torch.no_grad():
+        pool.score_net[2].weight.mul_(3.0)                      # spread the scores (fewer near-ties with the threshold)
+    ref_p = [p.detach().double().clone().requires_grad_(True) for p in (pool.score_net[0].weight, pool.score_net[0].bias,
+                                                                         pool.score_net[2].weight, pool.score_net[2].bias)]
+    xr = x.double().clone().requires_grad_(True)
+    nl = nonlinearity if nonlinearity in ("tanh", "softmax") else "sigmoid"
+    rp, rei, rperm, rs = _reference_pool(xr, ei, *ref_p, nl, 0.5, min_score, 1.5)
+    gout = torch.randn(rp.shape, generator=g, dtype=torch.float64)
+    (rp * gout).sum().backward()
+    pool = pool.to(DEV)
+    xd = x.to(DEV).requires_grad_(True)
+    tr = {}
+    px, pei, _, perm = pool(xd, ei.to(DEV), None, compact=True, trace=tr, trace_tag="0")
+    assert_close(tr["score0"], rs, 1e-5, "scores")
+    assert torch.equal(perm.cpu(), rperm), "kept node ids"
+    assert torch.equal(pei.cpu(), rei), "relabelled, compacted edges"
+    assert_close(px, rp, 1e-5, "pooled features")
+    (px * gout.to(DEV).float()).sum().backward()
+    assert_close(xd.grad, xr.grad, 2e-5, "dx")
+    for name, p, r in zip(("w1", "b1", "w2", "b2"), (pool.score_net[0].weight, pool.score_net[0].bias, pool.score_net[2].weight,
+                                                     pool.score_net[2].bias), ref_p):
+        assert_close(p.grad, r.grad, 5e-5, "d" + name)
+    if min_score is not None:
+        assert 0 < perm.numel() < n and perm.numel() != n // 2      # the count came from the threshold, not from the ratio
