@@ -320,10 +320,23 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+        # RCCL prints a version banner on STDOUT when its first communicator comes up; the contract of this script is ONE JSON
+        # line on stdout, so file descriptor 1 points at stderr until the communicator exists (first collective included)
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev)
+            else:
+                dist.init_process_group(backend)
+            warm = torch.zeros(1, device=dev)
+            dist.all_reduce(warm)
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     cfg = dict(MODEL_CFG)
     if args.large:
@@ -420,7 +433,10 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
+    t_local = None
     if world > 1:
+        torch.cuda.synchronize()
+        t_local = time.perf_counter() - t0      # this rank's own work done (its GPU idle), before it waits for the others
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -465,13 +481,14 @@ def main():
             ops.configure(**prev)
     per_rank = None
     if world > 1:
-        mine = torch.tensor([dt], device=dev, dtype=torch.float64)
-        allt = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(allt, mine)
-        per = [float(t.item()) for t in allt]
-        per_rank = {"ms_per_step_min": round(min(per) / args.steps * 1e3, 3), "ms_per_step_max": round(max(per) / args.steps * 1e3, 3),
-                    "ms_per_step_by_rank": [round(v / args.steps * 1e3, 3) for v in per]}
-        dt = max(per)
+        per = [None] * world
+        dist.all_gather_object(per, (float(dt), float(t_local)))      # any backend (the rehearsal runs over gloo)
+        own = [v[1] for v in per]
+        per_rank = {"ms_per_step_min": round(min(own) / args.steps * 1e3, 3), "ms_per_step_max": round(max(own) / args.steps * 1e3, 3),
+                    "ms_per_step_by_rank": [round(v / args.steps * 1e3, 3) for v in own],
+                    "note": "time until the rank's own GPU work of the K steps was done, before the closing barrier (every step holds one "
+                            "gradient all-reduce, so ranks cannot drift apart by more than a step); `ms_per_step` is the barrier-bracketed maximum"}
+        dt = max(v[0] for v in per)
     loss_val = float(loss.item())
 
     result = None
