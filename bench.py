@@ -554,7 +554,10 @@ def main():
             "dtype": "f32 (" + ("attention products: every operand incl. P and dS as fp16 hi+lo pairs (~21 significand bits), fp32 accumulate; " if split else "attention: fp32 MFMA; ") +
                      {"f16x2": "dense layers: fp16 hi+lo operands with per-operand power-of-two scale, 3 MFMAs per product, fp32 accumulate",
                       "bf16x3": "dense layers: exact 3-way bf16 split, 6 MFMAs per product, fp32 accumulate",
-                      "fp32": "dense layers: fp32 MFMA"}[ops.GEMM_MATH] + ")",
+                      "fp32": "dense layers: fp32 MFMA"}[ops.GEMM_MATH] +
+                     ("; every parameter gradient of the step sits as close to float64 as the fp32-operand kernels and torch fp32 do (max rel-L2 "
+                      "1.5e-6 / 1.9e-6 / 1.2e-6: profiles/r03_arithmetic_error_vs_float64.txt, tests/test_hip_model.py::"
+                      "test_default_arithmetic_is_at_the_error_level_of_fp32)" if split and ops.GEMM_MATH == "f16x2" else "") + ")",
             "data": "synthetic",
             "config": {"workload": (f"MIXED-SIZE STREAM (configs[4]): DGDM-Base pretrain_step fwd+bwd+AdamW, batch={args.batch} graphs of "
                                     f"1k..10k nodes (E = 5 N) per GPU, 8 batches cycled, feat={FEATS}, edge_attr=32, T=10, heads=8, "

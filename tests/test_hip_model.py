@@ -140,6 +140,53 @@ def _assert_all_grads(m, gref, tol):
     return live
 
 
+def test_default_arithmetic_is_at_the_error_level_of_fp32():
+    """The reference computes in fp32 ("everything is fp32"); the default kernels form every product on fp16 hi+lo
+    operand pairs with fp32 accumulation.  Is that narrower IN EFFECT?  Same step, same draws, every live gradient against the
+    float64 oracle: the default arithmetic, fp32 operands on the fp32 matrix instructions, and torch fp32 on the CPU (the
+    oracle code in float32 = the reference's own arithmetic) must sit at the same distance from exact -- within 4x at the
+    worst gradient and 2.5x at the median, all ~1e-6 (tools/arithmetic_error_report.py prints the table;
+    profiles/r03_arithmetic_error_vs_float64.txt)."""
+    from dgdm_histopath_lab_amd import ops
+    from dgdm_histopath_lab_amd.synthetic import synthetic_batch
+    cfgd = dict(node_features=768, hidden_dims=[512, 256, 128], num_diffusion_steps=10, attention_heads=8, use_hierarchical=False)
+    assert ops.configure() == dict(attention="fp16x2", gemm="f16x2")        # the arithmetic bench.py's headline runs on
+    m, out, ref, gref, _, _ = _run_both(cfgd, 0, trace=False)
+    cfg = O.OracleConfig(**cfgd)
+    P = O.init_params(cfg, seed=3, perturb=0.05)
+    batch = synthetic_batch(0, 2, 2000, 8000)
+    gen = torch.Generator().manual_seed(11)
+    n = batch.x.size(0)
+    rng = dict(timesteps=torch.tensor([2, 9]), noise=torch.randn(n, 128, generator=gen), noise_target=torch.randn(n, 128, generator=gen))
+    mask_idx = torch.randperm(n, generator=gen)[: int(n * 0.15)]
+    mask_tok = torch.randn(768, generator=gen)
+    _, g32 = O.loss_and_grads(P, cfg, batch, mask_indices=mask_idx, mask_token=mask_tok, **rng)      # torch fp32 on the CPU
+    prev = ops.configure(attention="fp32", gemm="fp32")
+    try:
+        m32 = _model(cfgd, P)
+        o32 = m32.pretrain_step(batch.to(DEV), mask_indices=mask_idx.to(DEV), mask_token=mask_tok.to(DEV), **{k: v.to(DEV) for k, v in rng.items()})
+        o32["total_pretrain_loss"].backward()
+    finally:
+        ops.configure(**prev)
+    named, named32 = dict(m.named_parameters()), dict(m32.named_parameters())
+    e_def, e_hip32, e_cpu32 = [], [], []
+    for k, g in gref.items():
+        if g.abs().max() < 1e-12:
+            continue
+        nb = g.norm()
+        e_def.append(float((named[k].grad.double().cpu() - g).norm() / nb))
+        e_hip32.append(float((named32[k].grad.double().cpu() - g).norm() / nb))
+        e_cpu32.append(float((g32[k].double() - g).norm() / nb))
+    assert len(e_def) >= 80
+    med = lambda v: sorted(v)[len(v) // 2]
+    print("default max %.2e med %.2e | HIP fp32 max %.2e med %.2e | torch CPU fp32 max %.2e med %.2e" % (
+        max(e_def), med(e_def), max(e_hip32), med(e_hip32), max(e_cpu32), med(e_cpu32)))
+    assert max(e_def) <= 5e-6 and max(e_hip32) <= 5e-6 and max(e_cpu32) <= 5e-6          # all three ~200x inside the 1e-3 contract
+    for other in (e_hip32, e_cpu32):
+        assert max(e_def) <= 4.0 * max(other), (max(e_def), max(other))
+        assert med(e_def) <= 2.5 * med(other), (med(e_def), med(other))
+
+
 @pytest.mark.parametrize("attn", ["fp32", "fp16x2"])
 def test_smooth_model_matches_oracle_2k_nodes_all_params(attn, monkeypatch):
     """cfg1-sized graphs (2 x 2000 nodes / 8000 edges), Base dims, use_hierarchical=False: the
