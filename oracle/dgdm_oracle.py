@@ -230,8 +230,20 @@ def _ext_edge_attr(edge_attr: Optional[Tensor], graph: OracleGraph, dtype) -> Te
 # --------------------------------------------------------------------------------------
 # layers
 # --------------------------------------------------------------------------------------
-def _drop(x: Tensor, p: float, training: bool) -> Tensor:
-    return F.dropout(x, p, True) if (training and p > 0) else x
+# Test infrastructure for training-mode parity: when set, every dropout site asks the hook for its multiplier (0 or
+# 1/(1-p) per element) instead of drawing one, so that a checker can hand this restatement the very masks a device kernel
+# generated.  hook(site, x, p, graph) -> tensor like x; `site` names the call site, `graph` is the index of the graph the
+# per-graph loops (attention, diffusion loss, pooling) are working on, None where the site sees the whole batch.
+DROPOUT_HOOK = None
+_DROP_GRAPH = None
+
+
+def _drop(x: Tensor, p: float, training: bool, site: Optional[str] = None) -> Tensor:
+    if not (training and p > 0):
+        return x
+    if DROPOUT_HOOK is not None:
+        return x * DROPOUT_HOOK(site, x, p, _DROP_GRAPH)
+    return F.dropout(x, p, True)
 
 
 def _ln(P, pre, x):
@@ -266,9 +278,9 @@ def dynamic_graph_layer(P, pre, x, graph, ea_ext, p_drop=0.0, training=False) ->
     reference -- it influences neither outputs nor gradients, so it is not restated.
     """
     h = F.gelu(graph_conv(P, f"{pre}.graph_conv1", x, graph, ea_ext))
-    h = _drop(h, p_drop, training)
+    h = _drop(h, p_drop, training, f"{pre}.drop1")
     h = F.gelu(graph_conv(P, f"{pre}.graph_conv2", h, graph, ea_ext))
-    h = _drop(h, p_drop, training)
+    h = _drop(h, p_drop, training, f"{pre}.drop2")
     out = _lin(P, f"{pre}.output_proj", h)
     return _ln(P, f"{pre}.norm1", out + x)
 
@@ -276,8 +288,8 @@ def dynamic_graph_layer(P, pre, x, graph, ea_ext, p_drop=0.0, training=False) ->
 def feature_encoder(P, x, p_drop=0.0, training=False) -> Tensor:
     """FeatureEncoder.forward (models/encoders.py:104-124)."""
     pre = "feature_encoder"
-    h = _drop(F.gelu(_ln(P, f"{pre}.encoder.1", _lin(P, f"{pre}.encoder.0", x))), p_drop, training)
-    h = _drop(F.gelu(_ln(P, f"{pre}.encoder.5", _lin(P, f"{pre}.encoder.4", h))), p_drop, training)
+    h = _drop(F.gelu(_ln(P, f"{pre}.encoder.1", _lin(P, f"{pre}.encoder.0", x))), p_drop, training, f"{pre}.encoder.3")
+    h = _drop(F.gelu(_ln(P, f"{pre}.encoder.5", _lin(P, f"{pre}.encoder.4", h))), p_drop, training, f"{pre}.encoder.7")
     res = _lin(P, f"{pre}.residual_proj", x) if f"{pre}.residual_proj.weight" in P else x
     return h + res
 
@@ -290,7 +302,7 @@ def graph_encoder(P, cfg: OracleConfig, x, graph, ea_ext, training=False):
         h = dynamic_graph_layer(P, f"graph_encoder.graph_layers.{i}", h, graph, ea_ext, cfg.dropout, training)
         if din != dout:
             h = _lin(P, f"graph_encoder.dim_proj.{i}", h)
-        h = _drop(F.gelu(_ln(P, f"graph_encoder.norm_layers.{i}", h)), cfg.dropout, training)
+        h = _drop(F.gelu(_ln(P, f"graph_encoder.norm_layers.{i}", h)), cfg.dropout, training, f"graph_encoder.dropout.{i}")
         outs.append(h)
     return _lin(P, "graph_encoder.output_proj", h), outs
 
@@ -334,9 +346,9 @@ def mha(P, pre, query, key, value, H, bias=None, p_drop=0.0, training=False):
     s = torch.matmul(q, k.transpose(-2, -1)) / math.sqrt(d)
     if bias is not None:
         s = s + bias
-    w = _drop(F.softmax(s, dim=-1), p_drop, training)
+    w = _drop(F.softmax(s, dim=-1), p_drop, training, f"{pre}.attn_dropout")
     o = torch.matmul(w, v).transpose(0, 1).reshape(Lq, C)
-    o = _drop(_lin(P, f"{pre}.out_proj", o), p_drop, training)
+    o = _drop(_lin(P, f"{pre}.out_proj", o), p_drop, training, f"{pre}.resid_dropout")
     return o, w.mean(dim=0)
 
 
@@ -447,10 +459,10 @@ def predict_noise(P, x_noisy: Tensor, t: Tensor, p_drop=0.1, training=False, pre
     inp = torch.cat([x_noisy, te.expand(x_noisy.shape[0], -1)], dim=-1)
     h = _lin(P, f"{pre}.denoise_net.0", inp)
     h = F.group_norm(h, 8, P[f"{pre}.denoise_net.1.weight"], P[f"{pre}.denoise_net.1.bias"], 1e-5)
-    h = _drop(F.silu(h), p_drop, training)
+    h = _drop(F.silu(h), p_drop, training, f"{pre}.denoise_net.3")
     h = _lin(P, f"{pre}.denoise_net.4", h)
     h = F.group_norm(h, 8, P[f"{pre}.denoise_net.5.weight"], P[f"{pre}.denoise_net.5.bias"], 1e-5)
-    h = _drop(F.silu(h), p_drop, training)
+    h = _drop(F.silu(h), p_drop, training, f"{pre}.denoise_net.7")
     return _lin(P, f"{pre}.denoise_net.8", h)
 
 
@@ -485,9 +497,12 @@ def attention_pool(P, x, ptr, H, p_drop=0.1, training=False, pre="global_pool"):
     MultiHeadAttention's own default dropout=0.1 applies (dgdm_model.py:593)."""
     out = []
     tok = P[f"{pre}.global_token"].view(1, -1)
+    global _DROP_GRAPH
     for g in range(len(ptr) - 1):
         xg = x[ptr[g]:ptr[g + 1]]
+        _DROP_GRAPH = g
         o, _ = mha(P, f"{pre}.attention", tok, xg, xg, H, None, p_drop, training)
+        _DROP_GRAPH = None
         out.append(o)
     return torch.cat(out, dim=0)
 
@@ -504,7 +519,7 @@ def _head_features(P, lin: str, bn: str, x, act: str, p_drop: float, training: b
     if rm is None:
         rm, rv = torch.zeros(h.shape[1], dtype=h.dtype), torch.ones(h.shape[1], dtype=h.dtype)
     h = F.batch_norm(h, rm.detach().to(h.dtype).clone(), rv.detach().to(h.dtype).clone(), P[f"{bn}.weight"], P[f"{bn}.bias"], training, 0.1, 1e-5)
-    return _drop(_head_act(act)(h), p_drop, training)
+    return _drop(_head_act(act)(h), p_drop, training, f"{lin}.dropout")
 
 
 def classification_head(P, x, act="gelu", p_drop=0.1, training=False, pre="classification_head") -> Tensor:
@@ -584,9 +599,12 @@ def forward(P, cfg: OracleConfig, data, mode: str = "inference", *, training: bo
     pos = getattr(data, "pos", None)
     if cfg.use_spatial_attention and pos is not None:
         outs, attn_w = [], []
+        global _DROP_GRAPH
         for g in range(B):
+            _DROP_GRAPH = g
             o, w = spatial_attention_graph(P, h[ptr[g]:ptr[g + 1]], pos[ptr[g]:ptr[g + 1]], H, 1.0, cfg.dropout, training)
             outs.append(o); attn_w.append(w)
+        _DROP_GRAPH = None
         h = torch.cat(outs, dim=0)
         _stage("spatial_attention")
         if trace is not None: trace["spatial_attention"] = h
@@ -610,7 +628,9 @@ def forward(P, cfg: OracleConfig, data, mode: str = "inference", *, training: bo
             sl = slice(ptr[g], ptr[g + 1])
             t = timesteps[g:g + 1]
             noisy = add_noise(sched, h[sl], noise[sl].to(dtype), t)
+            _DROP_GRAPH = g
             pred = predict_noise(P, noisy, t, 0.1, training)
+            _DROP_GRAPH = None
             target = noise_target[sl] if cfg.strict_reference else noise[sl]  # D8 (dgdm_model.py:429-430)
             losses.append(F.mse_loss(pred, target.to(dtype)))
         out["diffusion_loss"] = torch.stack(losses).mean()

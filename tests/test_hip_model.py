@@ -187,6 +187,169 @@ def test_default_arithmetic_is_at_the_error_level_of_fp32():
         assert med(e_def) <= 2.5 * med(other), (med(e_def), med(other))
 
 
+class _DropoutSites:
+    """Records every dropout site of one HIP forward (kind, seed, shape) in execution order, regenerates each site's mask with the
+    kernels themselves, and serves them to the oracle (oracle.DROPOUT_HOOK) -- so that the TRAINING-mode step bench.py times can be
+    compared with the restatement draw for draw, although the two sides have different random number generators.
+      act_dropout / row_norm sites: the mask is a function of (seed, element index): the activation kernel on a tensor of ones
+      attention weights:            the forward kernel itself on Q = K = 0, pos = 0 (uniform probabilities 1/n) and one-hot V
+                                    blocks, 16 key columns per run (as test_attn_dropout_mask_consistent... does)
+    The attention-pool weights' dropout is switched off on both sides (its mask is a third hash; the pooled row is not on the
+    pretraining loss)."""
+
+    def __init__(self, ops, monkeypatch):
+        self.ops, self.sites, self.masks = ops, [], None
+        for name, kind in (("act_dropout", "act"), ("row_norm", "rownorm"), ("spatial_attention", "attn")):
+            monkeypatch.setattr(ops, name, self._wrap(getattr(ops, name), kind))
+
+    def _wrap(self, fn, kind):
+        def wrapped(*a, **k):
+            c0 = self.ops._seed_counter
+            out = fn(*a, **k)
+            if self.ops._seed_counter != c0:                     # the site drew a seed: dropout was live
+                assert self.ops._seed_counter == c0 + 1
+                seed = (torch.initial_seed() * 0x9E3779B1 + self.ops._seed_counter * 0x85EBCA6B) & 0xFFFFFFFF
+                if kind == "attn":
+                    self.sites.append(dict(kind=kind, seed=seed, plan=a[2], H=a[3], p=float(a[6] if len(a) > 6 else k["drop_p"]), n=a[0].size(0)))
+                else:
+                    p_ = k.get("drop_p", a[2] if kind == "act" and len(a) > 2 else None)
+                    self.sites.append(dict(kind=kind, seed=seed, shape=tuple(out.shape), p=float(p_)))
+            return out
+        return wrapped
+
+    def build_masks(self):
+        from dgdm_histopath_lab_amd import _lib
+        ops, lib = self.ops, _lib.load()
+        self.masks = []
+        for s in self.sites:
+            if s["kind"] != "attn":
+                n = 1
+                for d in s["shape"]:
+                    n *= d
+                ones, y = torch.ones(n, device=DEV), torch.empty(n, device=DEV)
+                _lib.check(lib.dgdm_act_dropout_fwd(ones.data_ptr(), n, 0, s["p"], s["seed"], y.data_ptr(), None, None,
+                                                    _lib.stream_ptr(ones.device)), "mask probe")
+                self.masks.append(y.view(s["shape"]).cpu().double())
+                continue
+            plan, H, n = s["plan"], s["H"], s["n"]
+            C = 16 * H
+            ptr = plan.ptr_dev.cpu().tolist()
+            F = [torch.zeros(H, ptr[g + 1] - ptr[g], ptr[g + 1] - ptr[g], dtype=torch.float64) for g in range(len(ptr) - 1)]
+            pos0 = torch.zeros(n, 2, device=DEV)
+            for c in range((n + 15) // 16):
+                buf = torch.zeros(n, 3 * C, device=DEV)
+                for kk in range(16 * c, min(n, 16 * c + 16)):
+                    buf[kk, 2 * C + torch.arange(H) * 16 + (kk - 16 * c)] = 1.0
+                if ops.ATTN_PRECISION == "fp32":
+                    o, _ = ops.spatial_attn_fwd_raw(buf[:, :C], buf[:, C:2 * C], buf[:, 2 * C:], pos0, plan, H, 0.25, 1.0, 0, s["p"], s["seed"])
+                else:
+                    o, _, _ = ops.spatial_attn_h_fwd_raw(buf, pos0, plan, H, 0.25, 1.0, s["p"], s["seed"])
+                o = o.cpu().double().view(n, H, 16)
+                for g in range(len(ptr) - 1):
+                    a, b = ptr[g], ptr[g + 1]
+                    lo, hi = max(16 * c, a), min(16 * c + 16, b)
+                    if lo < hi:      # keys lo..hi-1 of graph g: o[q, h, k - 16c] = F[h, q, k] / n_g
+                        F[g][:, :, lo - a:hi - a] = (o[a:b, :, lo - 16 * c:hi - 16 * c] * (b - a)).permute(1, 0, 2)
+            keep = 1.0 / (1.0 - int(s["p"] * 65536) / 65536)
+            for f in F:
+                assert bool(((f.abs() < 1e-3) | ((f - keep).abs() < 1e-2)).all())
+            self.masks.append([torch.where(f > 0.5 * keep, torch.full_like(f, keep), torch.zeros_like(f)) for f in F])
+        return self
+
+    def oracle_hook(self, ptr):
+        order = {}
+
+        def hook(site, x, p, graph):
+            if site == "global_pool.attention.attn_dropout":
+                return torch.ones_like(x)
+            if site not in order:
+                order[site] = len(order)
+            s, m = self.sites[order[site]], self.masks[order[site]]
+            assert abs(s["p"] - p) < 1e-12, (site, s, p)
+            if s["kind"] == "attn":
+                assert site.endswith("attn_dropout"), site
+                m = m[graph]
+            elif graph is not None:
+                m = m[graph:graph + 1] if site.startswith("global_pool") else m[ptr[graph]:ptr[graph + 1]]
+            assert m.shape == x.shape, (site, tuple(m.shape), tuple(x.shape))
+            return m.to(x.dtype)
+        hook.order = order
+        return hook
+
+
+@pytest.mark.parametrize("hierarchical", [False, True])
+def test_training_mode_step_matches_oracle_under_the_kernels_own_masks(hierarchical, monkeypatch):
+    """The step bench.py times runs in TRAINING mode: hash dropout at ~35 sites (kernel-level evidence only).
+    Draw-for-draw parity with the reference's Philox masks is impossible, but the masks are deterministic functions of
+    (seed, index): the kernels' own masks of one step are extracted site by site (_DropoutSites), handed to the float64 oracle
+    (every F.dropout of the restatement multiplies by the kernel's mask of the same site instead of drawing), and the loss and
+    EVERY live parameter gradient of the training-mode step must agree at the 1e-3 contract -- which proves, at model level, that
+    each site applies its mask where the reference applies dropout (core/attention.py:154,168, graph_layers.py:233-239,
+    encoders.py:73-91,267, diffusion.py:94-104), that forward and backward of every site regenerate the same mask, and that
+    nothing on the path drops twice or not at all."""
+    from dgdm_histopath_lab_amd import ops
+    from dgdm_histopath_lab_amd.synthetic import synthetic_batch
+    cfgd = dict(node_features=768, hidden_dims=[512, 256, 128], num_diffusion_steps=10, attention_heads=8, use_hierarchical=hierarchical)
+    cfg = O.OracleConfig(**cfgd)
+    P = O.init_params(cfg, seed=3, perturb=0.05)
+    batch = synthetic_batch(7, 2, 208, 832)
+    gen = torch.Generator().manual_seed(23)
+    n = batch.x.size(0)
+    rng = dict(timesteps=torch.tensor([3, 8]), noise=torch.randn(n, 128, generator=gen), noise_target=torch.randn(n, 128, generator=gen))
+    mask_idx = torch.randperm(n, generator=gen)[: int(n * 0.15)]
+    mask_tok = torch.randn(768, generator=gen)
+    ptr = [0, 208, 416]
+
+    def hip_step(trace=None, decisions=None):
+        m = _model(cfgd, P).train()
+        m.global_pool.attention.attn_dropout.p = 0.0
+        ops._seed_counter = 1000                      # both HIP runs draw the same seeds, site by site
+        out = m.pretrain_step(batch.to(DEV), mask_indices=mask_idx.to(DEV), mask_token=mask_tok.to(DEV), trace=trace, decisions=decisions,
+                              **{k: v.to(DEV) for k, v in rng.items()})
+        return m, out
+
+    rec = _DropoutSites(ops, monkeypatch)
+    hip_step()                                        # run 1: which sites drop, with which seeds, on which shapes
+    sites = list(rec.sites)
+    assert len(sites) >= (15 if not hierarchical else 30), len(sites)
+    assert sum(s["kind"] == "attn" for s in sites) == 1
+    rec.build_masks()
+    for s, mk in zip(rec.sites, rec.masks):           # every mask drops about p of its elements
+        for t in (mk if isinstance(mk, list) else [mk]):
+            assert abs(float((t == 0).double().mean()) - s["p"]) < 0.02, s
+    # oracle, float64, training mode, the kernels' masks injected
+    torch.set_num_threads(16)
+    b64 = types.SimpleNamespace(x=batch.x.double(), edge_index=batch.edge_index, edge_attr=batch.edge_attr.double(),
+                                pos=batch.pos.double(), batch=batch.batch)
+    tr64 = {} if hierarchical else None
+    hook = rec.oracle_hook(ptr)
+    monkeypatch.setattr(O, "DROPOUT_HOOK", hook)
+    ref, gref = O.loss_and_grads({k: v.double() for k, v in P.items()}, cfg, b64, mask_indices=mask_idx, mask_token=mask_tok.double(),
+                                 training=True, trace=tr64, **{k: (v.double() if v.is_floating_point() else v) for k, v in rng.items()})
+    monkeypatch.setattr(O, "DROPOUT_HOOK", None)
+    assert len(hook.order) == len(sites), (len(hook.order), len(sites))       # the restatement has exactly the kernels' sites
+    # run 2: same seeds (same masks), the checker's ReLU / top-k decisions injected where the U-Net is on
+    rec.sites = []
+    tr = {} if hierarchical else None
+    dec = decisions_from_trace(tr64) if hierarchical else None
+    m, out = hip_step(tr, dec)
+    assert [(s["kind"], s["seed"]) for s in rec.sites] == [(s["kind"], s["seed"]) for s in sites]
+    out["total_pretrain_loss"].backward()
+    if hierarchical:
+        check_decision_margins(tr, dec)
+    assert_close(out["diffusion_loss"], ref["diffusion_loss"], TOL, "training-mode diffusion_loss")
+    live = _assert_all_grads(m, gref, TOL)
+    assert live >= 85
+    named = dict(m.named_parameters())
+    worst = max(float((named[k].grad.double().cpu() - g).norm() / g.norm()) for k, g in gref.items() if g.abs().max() > 1e-12)
+    print(f"training mode, {len(sites)} dropout sites ({sum(s['kind'] == 'rownorm' for s in sites)} fused into row kernels), "
+          f"loss {float(out['diffusion_loss'].detach()):.6f} vs {float(ref['diffusion_loss'].detach()):.6f}, {live} live gradients, worst rel-L2 {worst:.2e}")
+    # and the masks matter: the eval-mode loss of the same weights is a different number
+    ev = _model(cfgd, P).pretrain_step(batch.to(DEV), mask_indices=mask_idx.to(DEV), mask_token=mask_tok.to(DEV),
+                                       **{k: v.to(DEV) for k, v in rng.items()})
+    assert abs(float(ev["diffusion_loss"].detach()) - float(out["diffusion_loss"].detach())) > 1e-3 * float(out["diffusion_loss"].detach())
+
+
 @pytest.mark.parametrize("attn", ["fp32", "fp16x2"])
 def test_smooth_model_matches_oracle_2k_nodes_all_params(attn, monkeypatch):
     """cfg1-sized graphs (2 x 2000 nodes / 8000 edges), Base dims, use_hierarchical=False: the
