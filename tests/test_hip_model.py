@@ -308,6 +308,7 @@ def test_training_mode_step_matches_oracle_under_the_kernels_own_masks(hierarchi
                               **{k: v.to(DEV) for k, v in rng.items()})
         return m, out
 
+    torch.manual_seed(20240)                          # the seeds of the sites derive from torch.initial_seed()
     rec = _DropoutSites(ops, monkeypatch)
     hip_step()                                        # run 1: which sites drop, with which seeds, on which shapes
     sites = list(rec.sites)
@@ -316,7 +317,7 @@ def test_training_mode_step_matches_oracle_under_the_kernels_own_masks(hierarchi
     rec.build_masks()
     for s, mk in zip(rec.sites, rec.masks):           # every mask drops about p of its elements
         for t in (mk if isinstance(mk, list) else [mk]):
-            assert abs(float((t == 0).double().mean()) - s["p"]) < 0.02, s
+            assert abs(float((t == 0).double().mean()) - s["p"]) < max(0.02, 5.0 * (s["p"] * (1 - s["p"]) / t.numel()) ** 0.5), s
     # oracle, float64, training mode, the kernels' masks injected
     torch.set_num_threads(16)
     b64 = types.SimpleNamespace(x=batch.x.double(), edge_index=batch.edge_index, edge_attr=batch.edge_attr.double(),
