@@ -32,6 +32,7 @@ SIGNATURES = {
     "dgdm_csr_build_pair_workspace_bytes": (_sz, [_i64, _i32, _i32]),
     "dgdm_csr_build_pair_status_offset": (_sz, [_i64, _i32, _i32]),
     "dgdm_csr_build_pair": (C.c_int, [_p, _i64, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p, _p, _i32, _p]),
+    "dgdm_csr_extend": (C.c_int, [_p] * 10 + [_i32, _i64, _i32, _i32, _i64] + [_p] * 11),
     "dgdm_spmm_long_item_cap": (_i32, [_i64]),
     "dgdm_spmm_long_slot_cap": (_i32, [_i64]),
     "dgdm_spmm_long_table_words": (_sz, [_i64]),

@@ -38,6 +38,15 @@ class GraphContext:
         self.edge_index, self.edge_attr = edge_index, edge_attr
 
 
+    def extended(self, num_nodes: int) -> "GraphContext":
+        """The context of the same edge list over more nodes (GraphStructure.extended): one launch instead of a CSR build and
+        an edge-attribute aggregation."""
+        c = GraphContext.__new__(GraphContext)
+        c.gs, c.ea_hat = self.gs.extended(num_nodes, self.ea_hat)
+        c.num_nodes, c.edge_index, c.edge_attr = num_nodes, self.edge_index, self.edge_attr
+        return c
+
+
 def _context(edge_index: Union[Tensor, GraphContext], x: Tensor, edge_attr: Optional[Tensor], add_loops=True) -> GraphContext:
     if isinstance(edge_index, GraphContext):
         return edge_index
@@ -242,9 +251,17 @@ class GraphUNet(nn.Module):
         eis, eas = [ctx0.edge_index], [ctx0.edge_attr]
         ctxs = {(0, x.size(0)): ctx0}
 
+        sizes = {0: x.size(0)}       # nodes of level k (the relabelled edge list of level k has ids < sizes[k])
+
         def level(k: int, n: int) -> GraphContext:
             if (k, n) not in ctxs:
-                ctxs[(k, n)] = GraphContext(eis[k], n, eas[k])
+                base = ctxs.get((k, sizes.get(k, -1)))
+                if ops.CSR_EXTEND and base is not None and n > base.num_nodes > 0:
+                    # the reference's decoder (D10): the edge list of the coarser level over the finer level's nodes -- the
+                    # coarser level's index set plus one self loop per extra node, copied instead of built
+                    ctxs[(k, n)] = base.extended(n)
+                else:
+                    ctxs[(k, n)] = GraphContext(eis[k], n, eas[k])
             return ctxs[(k, n)]
 
         x = self.down_convs[0](x, ctx0)
@@ -261,6 +278,7 @@ class GraphUNet(nn.Module):
                                                   relu_decisions=dec.get(f"relu.pool{i}"), perm_decision=dec.get(f"perm{i}"),
                                                   trace=trace, trace_tag=str(i))
             eis.append(ei); eas.append(ea); perms.append(perm); nmaps.append(nmap)
+            sizes[i + 1] = x.size(0)
             if trace is not None:
                 trace[f"relu.pool{i}"] = F.relu(trace[f"pre.pool{i}"])
                 trace[f"perm{i}"] = perm

@@ -369,6 +369,43 @@ Workspace carve(void* base, int64_t E, int32_t N, int32_t add_loops) {
   return w;
 }
 
+
+// The index set of the SAME edge list over MORE nodes (add_loops = 1): every edge id is < n_old, so rows < n_old keep their
+// entries (edges in ascending id, the loop last) and their degrees; a node in [n_old, n_new) has its self loop only (degree 1,
+// dinv 1, weight 1).  The extended arrays are therefore the old ones with (n_new - n_old) one-entry rows appended -- a copy,
+// not a build.  One orientation per blockIdx.y; blockIdx.y == 2 pads the aggregated edge attributes with zero rows.
+struct ExtendArrays {
+  const int32_t *rowptr[2], *col[2], *eid[2];
+  const float *w[2], *dinv, *ea;
+  int32_t *rowptr_o[2], *col_o[2], *eid_o[2];
+  float *w_o[2], *dinv_o, *ea_o;
+  int32_t n_old, n_new, E, ea_dim;
+};
+__global__ __launch_bounds__(256) void k_csr_extend(const ExtendArrays a) {
+  const int o = blockIdx.y;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x, t0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (o == 2) {
+    const int64_t keep = (int64_t)a.n_old * a.ea_dim, total = (int64_t)a.n_new * a.ea_dim;
+    for (int64_t i = t0; i < total; i += stride) a.ea_o[i] = i < keep ? a.ea[i] : 0.f;
+    return;
+  }
+  const int32_t end = a.rowptr[o][a.n_old];        // entries in use (the arrays may be longer: edges marked -1 take no entry)
+  for (int64_t i = t0; i <= a.n_new; i += stride) a.rowptr_o[o][i] = i <= a.n_old ? a.rowptr[o][i] : end + (int32_t)(i - a.n_old);
+  for (int64_t p = t0; p < end; p += stride) {
+    a.col_o[o][p] = a.col[o][p];
+    a.eid_o[o][p] = a.eid[o][p];
+    a.w_o[o][p] = a.w[o][p];
+  }
+  for (int64_t i = a.n_old + t0; i < a.n_new; i += stride) {
+    const int64_t p = end + (i - a.n_old);
+    a.col_o[o][p] = (int32_t)i;
+    a.eid_o[o][p] = a.E + (int32_t)i;
+    a.w_o[o][p] = 1.0f;
+  }
+  if (o == 0)
+    for (int64_t i = t0; i < a.n_new; i += stride) a.dinv_o[i] = i < a.n_old ? a.dinv[i] : 1.0f;
+}
+
 }  // namespace
 
 extern "C" int32_t dgdm_spmm_long_item_cap(int64_t n_entries) { return (int32_t)(n_entries / DGDM_SPMM_LONG_ROW + 1); }
@@ -499,5 +536,31 @@ extern "C" int dgdm_csr_build_pair(const int64_t* edge_index, int64_t E, int32_t
       hipLaunchKernelGGL(k_rank_long, dim3(lb, 2), dim3(256), 0, stream, a, N, dinv, extra);
     }
   }
+  return dgdm_launch_status();
+}
+
+extern "C" int dgdm_csr_extend(const int32_t* rowptr_dst, const int32_t* col_dst, const int32_t* eid_dst, const float* w_dst,
+                               const int32_t* rowptr_src, const int32_t* col_src, const int32_t* eid_src, const float* w_src,
+                               const float* dinv, const float* ea_hat, int32_t ea_dim, int64_t E, int32_t n_old, int32_t n_new,
+                               int64_t entry_capacity, int32_t* rowptr_dst_out, int32_t* col_dst_out, int32_t* eid_dst_out,
+                               float* w_dst_out, int32_t* rowptr_src_out, int32_t* col_src_out, int32_t* eid_src_out,
+                               float* w_src_out, float* dinv_out, float* ea_hat_out, void* stream) {
+  DGDM_REQUIRE(E >= 0 && n_old > 0 && n_new >= n_old && ea_dim >= 0 && entry_capacity >= 0);
+  DGDM_REQUIRE(rowptr_dst && col_dst && eid_dst && w_dst && rowptr_src && col_src && eid_src && w_src && dinv);
+  DGDM_REQUIRE(rowptr_dst_out && col_dst_out && eid_dst_out && w_dst_out && rowptr_src_out && col_src_out && eid_src_out &&
+               w_src_out && dinv_out);
+  DGDM_REQUIRE((ea_hat == nullptr) == (ea_hat_out == nullptr) && (ea_hat == nullptr || ea_dim > 0));
+  if (E + (int64_t)n_new > 0x7fffffffLL) return DGDM_ERR_UNSUPPORTED;
+  if (entry_capacity < E + (int64_t)n_new) return DGDM_ERR_WORKSPACE;     // the output arrays hold E + n_new entries
+  ExtendArrays a;
+  a.rowptr[0] = rowptr_dst; a.col[0] = col_dst; a.eid[0] = eid_dst; a.w[0] = w_dst;
+  a.rowptr[1] = rowptr_src; a.col[1] = col_src; a.eid[1] = eid_src; a.w[1] = w_src;
+  a.rowptr_o[0] = rowptr_dst_out; a.col_o[0] = col_dst_out; a.eid_o[0] = eid_dst_out; a.w_o[0] = w_dst_out;
+  a.rowptr_o[1] = rowptr_src_out; a.col_o[1] = col_src_out; a.eid_o[1] = eid_src_out; a.w_o[1] = w_src_out;
+  a.dinv = dinv; a.dinv_o = dinv_out; a.ea = ea_hat; a.ea_o = ea_hat_out;
+  a.n_old = n_old; a.n_new = n_new; a.E = (int32_t)E; a.ea_dim = ea_dim;
+  const int64_t work = E + (int64_t)n_new > (int64_t)n_new * (ea_dim > 0 ? ea_dim : 1) ? E + (int64_t)n_new : (int64_t)n_new * ea_dim;
+  const int blocks = (int)((work + 255) / 256 < 2048 ? (work + 255) / 256 : 2048);
+  hipLaunchKernelGGL(k_csr_extend, dim3(blocks > 0 ? blocks : 1, ea_hat ? 3 : 2), dim3(256), 0, static_cast<hipStream_t>(stream), a);
   return dgdm_launch_status();
 }

@@ -127,6 +127,42 @@ class GraphStructure:
         "Long rows").  None when the builder left no table (the "single" pipeline, more than 2^20 nodes)."""
         return None if self._long is None else self._long[1 if transposed else 0]
 
+    def extended(self, num_nodes: int, ea_hat: Optional[torch.Tensor] = None):
+        """The index set of the same edge list over ``num_nodes`` >= self.num_nodes nodes (self loops on): what
+        ``GraphStructure(edge_index, num_nodes)`` builds, derived by ONE copying launch (dgdm_csr_extend) -- the nodes beyond
+        ``self.num_nodes`` have their self loop only.  That is the decoder of the reference's graph U-Net (D10,
+        core/graph_layers.py:420,453: level j convolves its n_j nodes with the edge list of level j + 1).  Returns
+        ``(structure, ea_hat padded with zero rows or None)``.  The long-row tables (and their scratch) are shared with ``self``:
+        no appended row is long, and the two structures are used one after the other on one stream."""
+        n_old, n_new = self.num_nodes, int(num_nodes)
+        if n_new < n_old or n_old <= 0 or self.num_entries != self.num_edges + n_old:
+            raise ValueError("extended() needs a structure built with self loops and a node count that does not shrink")
+        lib = _lib.load()
+        dev = self.rowptr.device
+        g = GraphStructure.__new__(GraphStructure)
+        n_ent = self.num_edges + n_new
+        g.num_nodes, g.num_edges, g.num_entries = n_new, self.num_edges, n_ent
+        i32 = dict(dtype=torch.int32, device=dev)
+        g.rowptr, g.rowptr_t = torch.empty(n_new + 1, **i32), torch.empty(n_new + 1, **i32)
+        g.col, g.col_t = torch.empty(n_ent, **i32), torch.empty(n_ent, **i32)
+        g.eid, g.eid_t = torch.empty(n_ent, **i32), torch.empty(n_ent, **i32)
+        g.dinv = torch.empty(n_new, dtype=torch.float32, device=dev)
+        g.w, g.w_t = torch.empty(n_ent, dtype=torch.float32, device=dev), torch.empty(n_ent, dtype=torch.float32, device=dev)
+        g.status = None
+        g.long_tables, g.long_partial, g._long = self.long_tables, self.long_partial, self._long
+        ea_out = None
+        if ea_hat is not None:
+            if ea_hat.dtype != torch.float32 or not ea_hat.is_contiguous() or ea_hat.size(0) != n_old:
+                raise ValueError("ea_hat must be a contiguous float32 [num_nodes, edge_dim] tensor")
+            ea_out = torch.empty(n_new, ea_hat.size(1), dtype=torch.float32, device=dev)
+        _lib.check(lib.dgdm_csr_extend(self.rowptr.data_ptr(), self.col.data_ptr(), self.eid.data_ptr(), self.w.data_ptr(),
+                                       self.rowptr_t.data_ptr(), self.col_t.data_ptr(), self.eid_t.data_ptr(), self.w_t.data_ptr(),
+                                       self.dinv.data_ptr(), _lib.ptr(ea_hat), 0 if ea_hat is None else ea_hat.size(1),
+                                       self.num_edges, n_old, n_new, n_ent, g.rowptr.data_ptr(), g.col.data_ptr(), g.eid.data_ptr(),
+                                       g.w.data_ptr(), g.rowptr_t.data_ptr(), g.col_t.data_ptr(), g.eid_t.data_ptr(), g.w_t.data_ptr(),
+                                       g.dinv.data_ptr(), _lib.ptr(ea_out), _lib.stream_ptr(dev)), "dgdm_csr_extend")
+        return g, ea_out
+
     def __init__(self, edge_index: torch.Tensor, num_nodes: int, add_loops: bool = True, pipeline: str = "pair"):
         """``pipeline``: "pair" (dgdm_csr_build_pair) or "single" (one entry point per array set; same results)."""
         _lib.require_cuda(edge_index)

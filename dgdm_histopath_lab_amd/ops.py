@@ -133,6 +133,12 @@ def aggregate_concat(x: torch.Tensor, ea_hat: torch.Tensor, gs: GraphStructure) 
     return _AggregateConcat.apply(x, ea_hat, gs)
 
 
+# The graph U-Net's decoder convolves level j's nodes with the edge list of level j + 1 (reference defect D10, replicated under
+# strict_reference): True derives those three index sets from the encoder side's by one copying launch each
+# (GraphStructure.extended); False builds them from the edge list (six launches each; same arrays bit for bit).
+CSR_EXTEND = True
+
+
 def aggregate_edge_attr(edge_attr: Optional[torch.Tensor], gs: GraphStructure) -> torch.Tensor:
     """EA_hat[d] = sum_{e -> d} norm_e * edge_attr[e]  ([N, edge_dim]); the appended self-loop
     entries carry a zero attribute row (repair R1) and ``edge_attr=None`` means zeros

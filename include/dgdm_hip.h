@@ -133,6 +133,20 @@ DGDM_API int dgdm_csr_build_pair(const int64_t* edge_index, int64_t E, int32_t N
                                  int32_t* rowptr_src, int32_t* col_src, int32_t* eid_src, float* w_src, float* dinv,
                                  void* workspace, size_t workspace_bytes, int32_t* long_table_dst, int32_t* long_table_src,
                                  int32_t long_item_cap, void* stream);   /* long_table_*: nullable pair, see "Long rows" */
+/* The index set of the SAME edge list (add_loops = 1, every edge id < n_old) over n_new >= n_old nodes, derived from the set
+ * built for n_old nodes by ONE copying launch instead of a build: rows < n_old keep their entries, degrees and weights; a node
+ * in [n_old, n_new) has its self loop only (eid E + node, dinv 1, weight 1), appended in node order.  Bit for bit what
+ * dgdm_csr_build_pair(edge_index, E, n_new, 1, ...) writes into the entries in use.  This is the reference's decoder (D10,
+ * core/graph_layers.py:420,453: level j convolves its n_j nodes with the edge list of level j + 1, whose ids are < n_{j+1});
+ * ea_hat (nullable, [n_old, ea_dim] aggregated edge attributes) is padded with zero rows into ea_hat_out [n_new, ea_dim].
+ * The output arrays hold entry_capacity >= E + n_new entries; long-row tables of the n_old set stay valid for the extended
+ * one (no appended row is long). */
+DGDM_API int dgdm_csr_extend(const int32_t* rowptr_dst, const int32_t* col_dst, const int32_t* eid_dst, const float* w_dst,
+                             const int32_t* rowptr_src, const int32_t* col_src, const int32_t* eid_src, const float* w_src,
+                             const float* dinv, const float* ea_hat, int32_t ea_dim, int64_t E, int32_t n_old, int32_t n_new,
+                             int64_t entry_capacity, int32_t* rowptr_dst_out, int32_t* col_dst_out, int32_t* eid_dst_out,
+                             float* w_dst_out, int32_t* rowptr_src_out, int32_t* col_src_out, int32_t* eid_src_out,
+                             float* w_src_out, float* dinv_out, float* ea_hat_out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K2  CSR segmented gather-reduce  Y[r,:] = sum_{p in row r} w[p] * X[col[p],:]  (+ bias).

@@ -51,6 +51,41 @@ def test_csr_build_no_loops_and_determinism():
     assert torch.equal(a.col, b.col) and torch.equal(a.eid, b.eid)  # atomics only order-free counts
 
 
+@pytest.mark.parametrize("n_old,n_new,e,hub", [(1000, 1700, 6000, False), (3000, 6000, 20000, True), (10000, 20000, 100000, False),
+                                               (500, 500, 2000, False)])
+def test_csr_extend_is_bit_for_bit_the_build_over_more_nodes(n_old, n_new, e, hub):
+    """dgdm_csr_extend (GraphStructure.extended): the index set of an edge list with ids < n_old over n_new nodes equals what the
+    builder produces for n_new nodes -- rowptr, the entries in use of col / eid / w in both orientations, dinv -- and so do the
+    aggregated edge attributes and a gather through either structure, hub rows (segmented long-row path) and edges marked -1
+    included.  The U-Net's decoder (D10, core/graph_layers.py:420,453) takes its three index sets this way."""
+    from dgdm_histopath_lab_amd import GraphStructure, ops
+    ei = _rand_edges(n_old, e, 11 + n_old, hub)
+    ei[0, ::9] = -1                      # dropped edges of the sync-free pooling
+    t = torch.from_numpy(ei).to(_dev())
+    base, full = GraphStructure(t, n_old), GraphStructure(t, n_new)
+    ea = torch.randn(e, 32, generator=torch.Generator().manual_seed(3)).to(_dev())
+    ea_base = ops.aggregate_edge_attr(ea, base)
+    ext, ea_ext = base.extended(n_new, ea_base)
+    m = int(full.rowptr[-1])
+    assert m == int(ext.rowptr[-1]) == int(ext.rowptr_t[-1]) and (ext.num_nodes, ext.num_edges, ext.num_entries) == (n_new, e, e + n_new)
+    assert torch.equal(ext.rowptr, full.rowptr) and torch.equal(ext.rowptr_t, full.rowptr_t) and torch.equal(ext.dinv, full.dinv)
+    for k in ("col", "eid", "w", "col_t", "eid_t", "w_t"):
+        assert torch.equal(getattr(ext, k)[:m], getattr(full, k)[:m]), k
+    assert torch.equal(ea_ext, ops.aggregate_edge_attr(ea, full))
+    if hub:
+        assert int((base.rowptr[1:] - base.rowptr[:-1]).max()) > 128 and ext.long_rows() is not None
+    x = torch.randn(n_new, 64, generator=torch.Generator().manual_seed(5)).to(_dev())
+    for tr in (False, True):
+        rp, cl, w = (ext.rowptr_t, ext.col_t, ext.w_t) if tr else (ext.rowptr, ext.col, ext.w)
+        rf, cf, wf = (full.rowptr_t, full.col_t, full.w_t) if tr else (full.rowptr, full.col, full.w)
+        a = ops.spmm_raw(rp, cl, w, x, n_new, long_rows=ext.long_rows(tr))
+        b = ops.spmm_raw(rf, cf, wf, x, n_new, long_rows=full.long_rows(tr))
+        assert torch.equal(a, b), tr
+        assert torch.equal(a[n_old:], x[n_old:])          # a node beyond the edge list's range sees its self loop only
+    with pytest.raises(ValueError):
+        base.extended(n_old - 1)
+
+
 def test_csr_pipelines_agree_with_dropped_edges():
     """Edges with an endpoint outside [0, N) (how the sync-free pooling marks dropped edges) are skipped by both pipelines;
     every defined array entry and all weights agree bit for bit."""
