@@ -63,8 +63,17 @@ __global__ __launch_bounds__(256) void k_segment_sum_stage2(const float* __restr
   const int64_t g = i / c4;
   const int k = (int)(i % c4);
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int c = 0; c < nchunks; ++c) {
-    const float4 t = reinterpret_cast<const float4*>(part)[(g * nchunks + c) * c4 + k];
+  const float4* p = reinterpret_cast<const float4*>(part) + g * nchunks * c4 + k;
+  int c = 0;
+  for (; c + 16 <= nchunks; c += 16) {   // 16 loads in flight, added in chunk order (the sum keeps its fixed order): the plain loop
+    float4 t[16];                        // waited for every load before issuing the next -- 64 round trips, 17 us for 8 KB of output
+#pragma unroll
+    for (int u = 0; u < 16; ++u) t[u] = p[(int64_t)(c + u) * c4];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) { acc.x += t[u].x; acc.y += t[u].y; acc.z += t[u].z; acc.w += t[u].w; }
+  }
+  for (; c < nchunks; ++c) {
+    const float4 t = p[(int64_t)c * c4];
     acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
   }
   reinterpret_cast<float4*>(out)[i] = acc;
