@@ -34,7 +34,7 @@ for p in (0.0, 0.1):
     if os.environ.get("FWD_ONLY"): continue
     outh, lse2_b, pk = ops.spatial_attn_h_fwd_raw(qkv, pos, plan, H, 0.25, 1.0, p, 123, packed)
     dq2 = torch.empty_like(qkv)
-    for var in (0, 3, 4, 5):
+    for var in [int(v) for v in os.environ.get("BWD_VARIANTS", "0,3,4,5").split(",")]:
         ops.TIMERS.start()
         for _ in range(6):
             ops.spatial_attn_h_bwd_raw(pk, outh, gout, plan, H, 0.25, 1.0, lse2_b, dq2, p, 123, var, var)
