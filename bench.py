@@ -51,6 +51,9 @@ PMC_TRAFFIC = _latest_profile("pmc_traffic")   # tools/pmc_traffic.py, separate 
 PMC_VALU = _latest_profile("pmc_valu")         # tools/pmc_valu.py, one --pmc pass
 PMC_TRAFFIC_FP32 = _latest_profile("fp32_pmc_traffic")   # the same passes of `bench.py --precision fp32` (the strict_fp32 leg's kernels)
 PMC_VALU_FP32 = _latest_profile("fp32_pmc_valu")
+PMC_TRAFFIC_LARGE = _latest_profile("large_pmc_traffic")   # the same passes of `bench.py --large` (configs[3])
+PMC_VALU_LARGE = _latest_profile("large_pmc_valu")
+PMC_GATHER = _latest_profile("gather_pmc_traffic")       # tools/profile_gather.sh: the north-star gather microbenchmark, warm and cold
 
 
 def attention_flops(num_graph_nodes, heads, head_dim, products):
@@ -69,11 +72,7 @@ def _pmc_kernel(path, kernel):
     for name, v in ks.items():
         if name.replace(" ", "") == want:
             return v
-    base = want.split("<")[0] + "<"          # same kernel, another instantiation (the summary names what was profiled)
-    for name, v in ks.items():
-        if name.replace(" ", "").startswith(base):
-            return dict(v, profiled_instantiation=name)
-    return None
+    return None          # a kernel that was not profiled has NO counter figure (never another instantiation's)
 
 
 def pmc_traffic(kernel, path=None):
@@ -89,8 +88,8 @@ def pmc_valu(kernel, path=None):
     if v is None:
         return None
     keep = ("valu_busy", "mfma_busy", "wave_cycles_active", "wave_cycles_issue_stalled", "wave_cycles_parked", "valu_share_of_active",
-            "valu_insts_per_launch", "mfma_insts_per_launch", "occupancy_waves_per_simd", "profiled_instantiation")
-    return dict({k: v[k] for k in keep if k in v}, source=os.path.relpath(path, ROOT))
+            "valu_insts_per_launch", "mfma_insts_per_launch", "occupancy_waves_per_simd")
+    return dict({k: v[k] for k in keep if k in v}, source=f"committed PMC pass {os.path.relpath(path, ROOT)}, kernel {kernel}")
 
 
 def gather_bytes(n, e, c):
@@ -135,10 +134,22 @@ def gather_microbench(dev, iters=200, cold_iters=12):
     del evict
     cold.sort()
     cus = cold[len(cold) // 2]
+    kname = "k_spmm<64, 3, 4, false>"
+    warm_pmc, cold_pmc = _pmc_kernel(PMC_GATHER, kname), None
+    try:
+        with open(PMC_GATHER) as f:
+            cold_pmc = json.load(f)["cases"]["cold"].get(kname)
+    except (OSError, KeyError, ValueError, TypeError):
+        pass
+    src = None if PMC_GATHER is None else f"committed PMC passes {os.path.relpath(PMC_GATHER, ROOT)} (tools/profile_gather.sh), kernel {kname}"
+    traffic = None if warm_pmc is None else warm_pmc["hbm_bytes_per_launch"]
     return {"kernel": "dgdm_spmm (k_spmm<64,3,4,false>)", "workload": f"{NODES} nodes x {FEATS} feat, {EDGES}+{NODES} entries",
             "bound": "hbm", "achieved": round(by / us / 1e3, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": round(min(by / us / 1e3 / HBM_PEAK_GBPS, 1.0), 4), "traffic": pmc_traffic("k_spmm<64, 3, 4, false>"), "us_per_launch": round(us, 2),
-            "algorithmic_bytes": by, "unique_bytes": ub,
+            "frac": round(min(by / us / 1e3 / HBM_PEAK_GBPS, 1.0), 4), "traffic": traffic, "traffic_source": src,
+            "traffic_over_algorithmic": None if traffic is None else round(traffic / by, 3),
+            "traffic_over_unique": None if traffic is None else round(traffic / ub, 3),
+            "cold_traffic": None if cold_pmc is None else cold_pmc["hbm_bytes_per_launch"],
+            "us_per_launch": round(us, 2), "algorithmic_bytes": by, "unique_bytes": ub,
             "note": "back-to-back launches: the table is re-read from L2 / Infinity Cache (cache-resident figure)",
             "unique_bytes_GBps": round(ub / us / 1e3, 1), "unique_frac": round(ub / us / 1e3 / HBM_PEAK_GBPS, 4),
             "cold": {"us_per_launch": round(cus, 2), "launches": cold_iters, "evicted_with": "1 GiB buffer rewritten before every launch",
@@ -281,6 +292,10 @@ def main():
     ap.add_argument("--large", action="store_true",
                     help="BASELINE configs[3] instead of the headline: the Large model (hidden 1024/512/256, 16 heads, T=20) on 50k-node / "
                          "300k-edge graphs, 1 graph per GPU unless --batch is given; reported under config.workload")
+    ap.add_argument("--sustain-seconds", type=float, default=6.0,
+                    help="N=1 only: after the timed K steps, keep replaying the same step for this many seconds and report the rate as "
+                         "`sustained` (steady-state clocks; also gives an external GPU-activity sampler a window of pure GPU work well "
+                         "before the CPU baseline starts); 0 switches it off")
     ap.add_argument("--eager", action="store_true",
                     help="launch every kernel of the step from the host instead of replaying the step from HIP graphs "
                          "(training.GraphedPretrainStep, the default for the fixed-shape headline workload)")
@@ -448,6 +463,16 @@ def main():
             eager_step()
         torch.cuda.synchronize()
     ops.TIMERS.stop()
+    sustained = None
+    if world == 1 and args.sustain_seconds > 0:
+        n_s = max(args.steps, int(args.sustain_seconds / max(dt / args.steps, 1e-4)) + 1)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        for _ in range(n_s):
+            step()
+        torch.cuda.synchronize()
+        d_s = time.perf_counter() - t1
+        sustained = {"value": round(args.batch * n_s / d_s, 3), "unit": "slides/s", "steps": n_s, "seconds": round(d_s, 2),
+                     "ms_per_step": round(d_s / n_s * 1e3, 3), "note": "the same step, replayed back to back after the timed region"}
     # the same step at the reference's own arithmetic (fp32 operands on the fp32 matrix instructions, in the attention and in every
     # dense layer): measured here, in the same process on the same box, so the two numbers are comparable
     strict = None
@@ -521,21 +546,27 @@ def main():
                 mfma.update({"mfma_dtype": "every operand (Q', K, V, dO, P, dS) as fp16 hi+lo, fp32 accumulate",
                              "issued_tflops": round(issued_x[dom] * tf, 1), "issued_frac": round(issued_x[dom] * tf / peak, 4),
                              "fp32_equivalent_frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4)})
-            common = {"kernel": names[dom], "ms_per_launch": round(ms, 4), "launches_timed": tm[dom][0],
-                      "traffic": None if args.large else pmc_traffic(names[dom], traffic_path),    # the PMC passes were taken on the headline workload
+            tpath = traffic_path or (PMC_TRAFFIC_LARGE if args.large else PMC_TRAFFIC)
+            vpath = valu_path or (PMC_VALU_LARGE if args.large else PMC_VALU)
+            traffic = None if tpath is None else pmc_traffic(names[dom], tpath)
+            common = {"kernel": names[dom], "ms_per_launch": round(ms, 4), "launches_timed": tm[dom][0], "traffic": traffic,
+                      "traffic_source": None if traffic is None else f"committed PMC passes {os.path.relpath(tpath, ROOT)}, kernel {names[dom]}",
                       "other_kernels_ms": {k: round(v[1], 4) for k, v in tm.items() if k != dom}, "timed_with": graphed_note}
-            valu = None if args.large else pmc_valu(names[dom], valu_path)
-            if fp16_pipe and valu is not None and "valu_busy" in valu:
-                # the split-fp16 kernels are bound by VALU issue, not by the matrix pipe (PMC pass of this command, committed under
-                # profiles/): `frac` = share of SIMD cycles in which a vector instruction was executing; the matrix-pipe pricing
-                # stays as `mfma`.  `valu_rate`: wave-instructions per launch (PMC) over the duration measured live here.
-                rate = valu.get("valu_insts_per_launch", 0) / (ms * 1e-3) / 1e9
-                return dict(common, bound="valu", achieved=round(100.0 * valu["valu_busy"], 2), peak=100.0,
-                            unit="% of SIMD cycles with the VALU executing", frac=round(valu["valu_busy"], 4), valu=valu,
-                            valu_rate={"achieved": round(rate, 1), "peak": 614.4, "unit": "G wave-instructions/s",
-                                       "frac": round(rate / 614.4, 4), "note": "peak = 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction; "
-                                       "transcendentals take more than one slot"}, mfma=mfma)
-            return dict(common, **mfma, valu=valu)
+            valu = None if vpath is None else pmc_valu(names[dom], vpath)
+            if fp16_pipe and valu is not None and valu.get("valu_insts_per_launch"):
+                # the split-fp16 kernels are bound by VALU issue, not by the matrix pipe.  `achieved` / `frac` are recomputable from this
+                # line alone: vector wave-instructions per launch (a property of the code and the shapes; counted by the committed PMC
+                # pass named in `frac_inputs`) over the duration measured LIVE in this run, against 1024 SIMDs x 2.4 GHz / 4 cycles per
+                # wave64 instruction.  The utilisation counters of that pass (valu_busy, wave-cycle split) ride along as `valu_pmc`
+                # -- a committed measurement, not a product of this run.  The matrix-pipe pricing stays as `mfma`.
+                rate = valu["valu_insts_per_launch"] / (ms * 1e-3) / 1e9
+                return dict(common, bound="valu", achieved=round(rate, 1), peak=614.4, unit="G vector wave-instructions/s",
+                            frac=round(rate / 614.4, 4),
+                            frac_inputs={"valu_insts_per_launch": valu["valu_insts_per_launch"], "valu_insts_source": valu["source"],
+                                         "ms_per_launch": round(ms, 4), "ms_source": "HIP events in this run",
+                                         "peak": "1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction (transcendentals take two slots)"},
+                            valu_pmc=valu, mfma=mfma)
+            return dict(common, **mfma, valu_pmc=valu)
 
         ev_note = ("HIP events around eager launches of the same step right after the timed region (a graph replay cannot carry events)"
                    if graphed else "HIP events inside the timed region")
@@ -579,6 +610,8 @@ def main():
                                            "messages_per_step": 1 if graphed else 2, "early_launches": reducer.stats.get("early_launches", 0)}
         if strict is not None:
             result["strict_fp32"] = strict
+        if sustained is not None:
+            result["sustained"] = sustained
     if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -23,6 +23,7 @@ import torch.nn.functional as F
 from torch import Tensor
 
 from .. import ops
+from .._lib import DGDMKernelError
 from ..graph import GraphStructure
 
 
@@ -160,52 +161,48 @@ class AdaptiveGraphPooling(nn.Module):
         k = max(1, int(self.ratio * n))
         h = ops.lin(self.score_net[0], x)
         w2, b2 = self.score_net[2].weight, self.score_net[2].bias
-        fused = x.is_cuda and x.dtype == torch.float32 and ops.pool_supported(x.size(1), h.size(1)) and n < 2 ** 31
-        if (relu_decisions is not None or perm_decision is not None) and not fused:
-            raise NotImplementedError("decision injection is wired into the K9 kernels only")
-        if fused:   # K9 kernels: no data-dependent shapes; no host sync unless min_score is set
-            s = ops.pool_score(h, w2, b2, decide=relu_decisions, nonlinearity=self._nl)
-            if trace is not None:
-                trace[f"pre.pool{trace_tag}"], trace[f"score{trace_tag}"] = h.detach(), s.detach()
-            if self.min_score is not None:
-                # the reference keeps scores >= min_score (graph_layers.py:302-303): a data-dependent count, read back once; the
-                # nodes with a score >= the threshold ARE the `count` largest, so the exact top-k selection below yields that set
-                k = ops.count_ge(s, self.min_score)
-                if k == 0:
-                    raise ValueError(f"min_score={self.min_score} keeps no node of this batch (largest score {float(s.max()):.4g})")
-                if perm_decision is not None and perm_decision.numel() != k:
-                    raise ValueError(f"injected perm has {perm_decision.numel()} entries, min_score keeps {k}")
-            perm, node_map = ops.topk_perm(s, k)
-            if trace is not None:
-                trace[f"own_perm{trace_tag}"] = perm
-            if perm_decision is not None:
-                perm = perm_decision.to(device=x.device, dtype=torch.int64)
-                if perm.numel() != k:
-                    raise ValueError(f"injected perm has {perm.numel()} entries, this level keeps {k}")
+        if not (x.is_cuda and x.dtype == torch.float32 and ops.pool_supported(x.size(1), h.size(1)) and n < 2 ** 31):
+            # no torch branch: a silent change of arithmetic (and, before round 4, of the min_score semantics) is worse than an error
+            raise DGDMKernelError(f"AdaptiveGraphPooling: the K9 kernels take fp32 CUDA tensors whose node width and score width are "
+                                  f"multiples of 4 with a score width <= 256 that ops.pool_supported accepts; got {x.dtype} on {x.device}, "
+                                  f"node width {x.size(1)}, score width {h.size(1)}")
+        # K9 kernels: no data-dependent shapes; no host sync unless min_score is set
+        s = ops.pool_score(h, w2, b2, decide=relu_decisions, nonlinearity=self._nl)
+        if trace is not None:
+            trace[f"pre.pool{trace_tag}"], trace[f"score{trace_tag}"] = h.detach(), s.detach()
+        if self.min_score is not None:
+            # the reference keeps scores >= min_score (graph_layers.py:302-303): a data-dependent count, read back once; the
+            # nodes with a score >= the threshold ARE the `count` largest, so the exact top-k selection below yields that set
+            k = ops.count_ge(s, self.min_score)
+            if perm_decision is not None and perm_decision.numel() != k:
+                raise ValueError(f"injected perm has {perm_decision.numel()} entries, min_score keeps {k}")
+            if k == 0:
+                # as the reference (mask.nonzero() is empty, graph_layers.py:302-310): an empty pooled graph, every edge dropped
+                perm = torch.empty(0, dtype=torch.int64, device=x.device)
                 node_map = torch.full((n,), -1, dtype=torch.int32, device=x.device)
-                node_map[perm] = torch.arange(k, dtype=torch.int32, device=x.device)
-            pooled_x = ops.pool_gather(x, s, perm, node_map, self.multiplier)
-            mapped_keep = ops.edge_relabel(edge_index, node_map)     # dropped edges (now or earlier) are (-1, -1)
-            if compact:  # reference layout (graph_layers.py:322-327); boolean indexing syncs
-                keep = mapped_keep[0] >= 0
-                out = (pooled_x, mapped_keep[:, keep], (edge_attr[keep] if edge_attr is not None else None), perm)
-            else:
-                out = (pooled_x, mapped_keep, edge_attr, perm)
-            return out + (node_map,) if return_node_map else out
-        s = F.linear(F.relu(h), w2, b2).squeeze(-1)
-        s = torch.tanh(s) if self._nl == "tanh" else (torch.softmax(s, 0) if self._nl == "softmax" else torch.sigmoid(s))
-        perm = torch.topk(s, k, sorted=False).indices.sort().values        # ascending node ids
-        pooled_x = x[perm] * s[perm].unsqueeze(-1) * self.multiplier
-        node_map = torch.full((n,), -1, dtype=torch.long, device=x.device)
-        node_map[perm] = torch.arange(k, device=x.device)
-        alive = (edge_index[0] >= 0) & (edge_index[1] >= 0)            # edges dropped by an earlier level are -1
-        mapped = node_map[edge_index.clamp_min(0)]
-        keep = alive & (mapped[0] >= 0) & (mapped[1] >= 0)
-        if compact:
-            out = (pooled_x, mapped[:, keep], (edge_attr[keep] if edge_attr is not None else None), perm)
+                pooled_x = x[:0] * s[:0].unsqueeze(-1)       # [0, C], attached to the graph of x and s
+                if compact:
+                    out = (pooled_x, edge_index[:, :0], (edge_attr[:0] if edge_attr is not None else None), perm)
+                else:
+                    out = (pooled_x, torch.full_like(edge_index, -1), edge_attr, perm)
+                return out + (node_map,) if return_node_map else out
+        perm, node_map = ops.topk_perm(s, k)
+        if trace is not None:
+            trace[f"own_perm{trace_tag}"] = perm
+        if perm_decision is not None:
+            perm = perm_decision.to(device=x.device, dtype=torch.int64)
+            if perm.numel() != k:
+                raise ValueError(f"injected perm has {perm.numel()} entries, this level keeps {k}")
+            node_map = torch.full((n,), -1, dtype=torch.int32, device=x.device)
+            node_map[perm] = torch.arange(k, dtype=torch.int32, device=x.device)
+        pooled_x = ops.pool_gather(x, s, perm, node_map, self.multiplier)
+        mapped_keep = ops.edge_relabel(edge_index, node_map)     # dropped edges (now or earlier) are (-1, -1)
+        if compact:  # reference layout (graph_layers.py:322-327); boolean indexing syncs
+            keep = mapped_keep[0] >= 0
+            out = (pooled_x, mapped_keep[:, keep], (edge_attr[keep] if edge_attr is not None else None), perm)
         else:
-            out = (pooled_x, torch.where(keep.unsqueeze(0), mapped, torch.full_like(mapped, -1)), edge_attr, perm)
-        return out + (node_map.to(torch.int32),) if return_node_map else out
+            out = (pooled_x, mapped_keep, edge_attr, perm)
+        return out + (node_map,) if return_node_map else out
 
 
 class GraphUNet(nn.Module):
@@ -231,8 +228,8 @@ class GraphUNet(nn.Module):
         self.final_conv = nn.Linear(hidden_channels, out_channels)
 
     def _relu(self, x: Tensor, decide: Optional[Tensor] = None) -> Tensor:
-        if self.act is F.relu and x.is_cuda and x.dtype == torch.float32 and x.numel() % 4 == 0:
-            return ops.act_dropout(x, ops.ACT_RELU, decide=decide)
+        if self.act is F.relu:
+            return ops.act_dropout(x, ops.ACT_RELU, decide=decide)      # raises DGDMKernelError for shapes / devices without a kernel
         if decide is not None:
             raise NotImplementedError("decision injection is wired into the ReLU kernels only")
         return self.act(x)
@@ -296,7 +293,7 @@ class GraphUNet(nn.Module):
             j = self.depth - 1 - i
             if trace is not None:   # the fused kernel below never materialises its pre-activation: rebuilt here for the margin check
                 trace[f"pre.up{i}"] = (torch.zeros_like(xs[j + 1]).index_copy(0, perms[j], x.detach()) + xs[j + 1].detach())
-            if self.act is F.relu and x.is_cuda and x.dtype == torch.float32 and x.size(1) % 4 == 0:
+            if self.act is F.relu:
                 x = ops.unpool_add_relu(x, xs[j + 1], nmaps[j], decide=dec.get(f"relu.up{i}"))  # K9: gather by node_map, no zero fill
             elif dec.get(f"relu.up{i}") is not None:
                 raise NotImplementedError("decision injection is wired into the K9 kernels only")

@@ -46,17 +46,20 @@ __global__ __launch_bounds__(256) void k_pool_score_fwd(const float* __restrict_
   }
 }
 
-// dh[i] = t_i * w2 * [h > 0], t_i = ds_i (1 - s_i^2); partial[b] = [sum_i t_i relu(h[i]) (C) | sum_i t_i] over the block's rows
+// dh[i] = t_i * w2 * [h > 0], t_i = ds_i (1 - s_i^2); partial[b] = [sum_i t_i relu(h[i]) (C) | sum_i t_i] over the block's rows.
+// The sums are carried in float64 from the first add to the last (round 4): db2 = sum_i t_i is ONE sum over every node of the batch
+// whose terms cancel (to 1e-4 of their magnitude at trained weights), so an fp32 accumulation puts its own rounding -- eps * sum|t_i|
+// -- on top of whatever the terms carry.  With float64 partials the reduction adds nothing: the result is the sum of the fp32
+// terms, correctly rounded once.  (N * C adds in float64: nothing beside the GEMM that produced h.)
 __global__ __launch_bounds__(256) void k_pool_score_bwd(const float* __restrict__ h, int64_t ldh, const float* __restrict__ w2,
                                                         const float* __restrict__ s, const float* __restrict__ ds, int N, int C,
                                                         int rows_per_block, float* __restrict__ dh, int64_t lddh,
-                                                        float* __restrict__ partial, const uint8_t* __restrict__ decide, int nl) {
+                                                        double* __restrict__ partial, const uint8_t* __restrict__ decide, int nl) {
   // thread = (float4 column c4, row lane): C/4 <= 64 columns x (256 / cols) row lanes
   const int cols = C / 4;
   const int c4 = threadIdx.x % cols, rl = threadIdx.x / cols, nrl = 256 / cols;
   const int r0 = blockIdx.x * rows_per_block, r1 = min(N, r0 + rows_per_block);
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  float tsum = 0.f;
+  double ax = 0., ay = 0., az = 0., aw = 0., tsum = 0.;
   if (rl < nrl) {
     const float4 w = *reinterpret_cast<const float4*>(w2 + 4 * c4);
     for (int r = r0 + rl; r < r1; r += nrl) {
@@ -72,25 +75,39 @@ __global__ __launch_bounds__(256) void k_pool_score_bwd(const float* __restrict_
       g.x = px ? t * w.x : 0.f; g.y = py ? t * w.y : 0.f;
       g.z = pz ? t * w.z : 0.f; g.w = pw ? t * w.w : 0.f;
       *reinterpret_cast<float4*>(dh + (int64_t)r * lddh + 4 * c4) = g;
-      acc.x += px ? t * v.x : 0.f; acc.y += py ? t * v.y : 0.f; acc.z += pz ? t * v.z : 0.f; acc.w += pw ? t * v.w : 0.f;
-      if (c4 == 0) tsum += t;
+      const double td = (double)t;
+      if (px) ax += td * (double)v.x;
+      if (py) ay += td * (double)v.y;
+      if (pz) az += td * (double)v.z;
+      if (pw) aw += td * (double)v.w;
+      if (c4 == 0) tsum += td;
     }
   }
-  __shared__ float4 sm[256];
-  __shared__ float st[256];
-  sm[threadIdx.x] = acc;
+  __shared__ double sm[256][4];
+  __shared__ double st[256];
+  sm[threadIdx.x][0] = ax; sm[threadIdx.x][1] = ay; sm[threadIdx.x][2] = az; sm[threadIdx.x][3] = aw;
   st[threadIdx.x] = tsum;
   __syncthreads();
   if (rl == 0) {
     for (int j = 1; j < nrl; ++j) {  // fixed order
-      const float4 t = sm[j * cols + c4];
-      acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+      const double* t = sm[j * cols + c4];
+      ax += t[0]; ay += t[1]; az += t[2]; aw += t[3];
       if (c4 == 0) tsum += st[j * cols];
     }
-    float* P = partial + (int64_t)blockIdx.x * (C + 1);
-    P[4 * c4 + 0] = acc.x; P[4 * c4 + 1] = acc.y; P[4 * c4 + 2] = acc.z; P[4 * c4 + 3] = acc.w;
+    double* P = partial + (int64_t)blockIdx.x * (C + 1);
+    P[4 * c4 + 0] = ax; P[4 * c4 + 1] = ay; P[4 * c4 + 2] = az; P[4 * c4 + 3] = aw;
     if (c4 == 0) P[C] = tsum;
   }
+}
+
+// column sums of the float64 block partials, fixed order, rounded to fp32 once: columns [0, C) -> dw2, column C -> db2
+__global__ __launch_bounds__(256) void k_pool_score_bwd_final(const double* __restrict__ partial, int nb, int C, float* __restrict__ dw2,
+                                                              float* __restrict__ db2) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col > C) return;
+  double t = 0.;
+  for (int b = 0; b < nb; ++b) t += partial[(int64_t)b * (C + 1) + col];
+  if (col < C) dw2[col] = (float)t; else db2[0] = (float)t;
 }
 
 constexpr int SCORE_BWD_BLOCKS = 256;
@@ -126,11 +143,19 @@ __global__ __launch_bounds__(1024) void k_vec_softmax_bwd(const float* __restric
   for (int i = threadIdx.x; i < N; i += 1024) dz[i] = s[i] * (ds[i] - d);
 }
 __global__ __launch_bounds__(1024) void k_count_ge(const float* __restrict__ s, int N, float thr, int32_t* __restrict__ out) {
-  __shared__ float sm[16];
-  float c = 0.f;
-  for (int i = threadIdx.x; i < N; i += 1024) c += s[i] >= thr ? 1.f : 0.f;     // exact below 2^24 per thread
-  c = block_reduce_1024(c, false, sm);
-  if (threadIdx.x == 0) out[0] = (int32_t)c;
+  // integer count all the way (a float sum loses exactness beyond 2^24 nodes; the entry point admits N < 2^30)
+  __shared__ int32_t sm[16];
+  int32_t c = 0;
+  for (int i = threadIdx.x; i < N; i += 1024) c += s[i] >= thr ? 1 : 0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int32_t r = 0;
+    for (int i = 0; i < 16; ++i) r += sm[i];
+    out[0] = r;
+  }
 }
 
 // ------------------------------------------------------------------ top-k
@@ -466,7 +491,7 @@ extern "C" int dgdm_pool_score_fwd(const float* h, int64_t ldh, const float* w2,
 
 extern "C" size_t dgdm_pool_score_bwd_workspace_bytes(int32_t N, int32_t C) {
   if (N <= 0 || C <= 0) return 0;
-  return (size_t)(SCORE_BWD_BLOCKS + 16) * (C + 1) * sizeof(float);
+  return (size_t)(SCORE_BWD_BLOCKS + 16) * (C + 1) * sizeof(double);
 }
 
 extern "C" int dgdm_pool_score_bwd(const float* h, int64_t ldh, const float* w2, const float* s, const float* ds, int32_t N, int32_t C,
@@ -485,9 +510,10 @@ extern "C" int dgdm_pool_score_bwd(const float* h, int64_t ldh, const float* w2,
   if (workspace_bytes < dgdm_pool_score_bwd_workspace_bytes(N, C)) return DGDM_ERR_WORKSPACE;
   const int rpb = (N + SCORE_BWD_BLOCKS - 1) / SCORE_BWD_BLOCKS;
   const int nb = (N + rpb - 1) / rpb;
-  float* partial = static_cast<float*>(workspace);
+  double* partial = static_cast<double*>(workspace);       // torch allocations are 256-byte aligned; checked below
+  if (reinterpret_cast<uintptr_t>(workspace) & 7) return DGDM_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(k_pool_score_bwd, dim3(nb), dim3(256), 0, st, h, ldh, w2, s, ds, N, C, rpb, dh, lddh, partial, decide, nonlinearity);
-  colsum_final_launch(partial, nb, C + 1, dw2, C, db2, st);
+  hipLaunchKernelGGL(k_pool_score_bwd_final, dim3((C + 1 + 255) / 256), dim3(256), 0, st, partial, nb, C, dw2, db2);
   return dgdm_launch_status();
 }
 

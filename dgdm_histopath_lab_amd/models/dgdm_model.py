@@ -327,7 +327,9 @@ class DGDMModel(nn.Module):
         """dgdm_model.py:447-480: entity masking + forward(pretrain); total = diffusion_loss (the
         reconstruction branch is unreachable in the reference: it tests the unmasked ``data``)."""
         masked = self._apply_entity_masking(data, mask_ratio, mask_indices, mask_token)
-        outputs = self.forward(masked, mode="pretrain", **rng)
+        # through __call__, not self.forward: module hooks must see the step (parallel.FlatGradAllReducer.begin_step is a forward
+        # pre-hook: it is what detects gradient accumulation and a step abandoned between backward and all_reduce())
+        outputs = self(masked, mode="pretrain", **rng)
         outputs["total_pretrain_loss"] = outputs["diffusion_loss"]
         return outputs
 

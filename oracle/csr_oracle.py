@@ -78,7 +78,7 @@ def gcn_csr(edge_index: np.ndarray, num_nodes: int, add_loops: bool = True) -> d
                 norm_coo=norm_coo, num_nodes=num_nodes, num_input_edges=int(edge_index.shape[1]))
 
 
-def topk_pool_indices(scores: np.ndarray, edge_index: np.ndarray, ratio: float = 0.5) -> dict:
+def topk_pool_indices(scores: np.ndarray, edge_index: np.ndarray, ratio: float = 0.5, perm=None) -> dict:
     """AdaptiveGraphPooling index work (graph_layers.py:306-324).
 
     k = max(1, int(ratio*N)); keep the k largest scores (ties: lowest node id first -- the
@@ -89,9 +89,13 @@ def topk_pool_indices(scores: np.ndarray, edge_index: np.ndarray, ratio: float =
     scores = np.asarray(scores)
     n = scores.shape[0]
     k = max(1, int(ratio * n))
-    order = np.lexsort((np.arange(n), -scores.astype(np.float64)))  # score desc, id asc
     keep = np.zeros(n, dtype=bool)
-    keep[order[:k]] = True
+    if perm is not None:      # kept node ids handed in (dgdm_oracle.DECISIONS): the index work below is the same
+        keep[np.asarray(perm, dtype=np.int64)] = True
+        assert keep.sum() == k, "injected perm must keep exactly k nodes"
+    else:
+        order = np.lexsort((np.arange(n), -scores.astype(np.float64)))  # score desc, id asc
+        keep[order[:k]] = True
     perm = np.nonzero(keep)[0].astype(np.int64)
     node_map = np.full(n, -1, dtype=np.int64)
     node_map[perm] = np.arange(perm.shape[0], dtype=np.int64)

@@ -236,6 +236,17 @@ def _ext_edge_attr(edge_attr: Optional[Tensor], graph: OracleGraph, dtype) -> Te
 # per-graph loops (attention, diffusion loss, pooling) are working on, None where the site sees the whole batch.
 DROPOUT_HOOK = None
 _DROP_GRAPH = None
+# Optional injection of the graph U-Net's discrete decisions (tests / tools only; None = decide here, as the reference does): a dict
+# with the keys of conftest.decisions_from_trace -- ``relu.down{i}`` / ``relu.pool{i}`` / ``relu.bottom`` / ``relu.up{i}`` (bool
+# masks: which elements pass the ReLU) and ``perm{i}`` (kept node ids).  Lets a float32 run of this restatement differentiate the
+# SAME piecewise-linear function as the float64 run (tools/arithmetic_error_report.py compares their gradients).
+DECISIONS = None
+
+
+def _relu(x: Tensor, key: str) -> Tensor:
+    if DECISIONS is not None and key in DECISIONS:
+        return torch.where(DECISIONS[key].reshape(x.shape), x, torch.zeros_like(x))
+    return F.relu(x)
 
 
 def _drop(x: Tensor, p: float, training: bool, site: Optional[str] = None) -> Tensor:
@@ -363,11 +374,13 @@ def spatial_attention_graph(P, x, pos, H, temperature=1.0, p_drop=0.0, training=
     return _ln(P, f"{pre}.norm", x + o), w
 
 
-def adaptive_pool(P, pre, x, edge_index, edge_attr, ratio=0.5):
+def adaptive_pool(P, pre, x, edge_index, edge_attr, ratio=0.5, level: Optional[int] = None):
     """AdaptiveGraphPooling.forward (core/graph_layers.py:285-329); top-k over ALL nodes."""
-    s = _lin(P, f"{pre}.score_net.2", F.relu(_lin(P, f"{pre}.score_net.0", x))).squeeze(-1)
+    s = _lin(P, f"{pre}.score_net.2", _relu(_lin(P, f"{pre}.score_net.0", x), f"relu.pool{level}")).squeeze(-1)
     s = torch.tanh(s)
-    idx = csr_oracle.topk_pool_indices(s.detach().cpu().numpy(), edge_index.cpu().numpy(), ratio)
+    forced = None if DECISIONS is None else DECISIONS.get(f"perm{level}")
+    idx = csr_oracle.topk_pool_indices(s.detach().cpu().numpy(), edge_index.cpu().numpy(), ratio,
+                                       **({} if forced is None else {"perm": forced.cpu().numpy()}))
     perm = torch.from_numpy(idx["perm"])
     keep = torch.from_numpy(idx["edge_keep"])
     px = x[perm] * s[perm].unsqueeze(-1)
@@ -392,18 +405,18 @@ def graph_unet(P, cfg: OracleConfig, x, edge_index, edge_attr, training=False, p
     xs, perms = [x], []
     for i in range(depth):
         g, e = level(i, x.shape[0])  # graph_layers.py:420: edge_indices[-1] == level i here
-        xr = F.relu(x)
+        xr = _relu(x, f"relu.down{i}")
         if trace is not None: trace[f"relu.down{i}"] = xr
         x = dynamic_graph_layer(P, f"{pre}.down_convs.{i+1}", xr, g, e, p_drop, training)
         xs.append(x)
         if trace is not None:
             trace[f"relu.pool{i}"] = F.relu(_lin(P, f"{pre}.pools.{i}.score_net.0", x))
-        x, ei2, ea2, perm, score = adaptive_pool(P, f"{pre}.pools.{i}", x, eis[-1], eas[-1])
+        x, ei2, ea2, perm, score = adaptive_pool(P, f"{pre}.pools.{i}", x, eis[-1], eas[-1], level=i)
         eis.append(ei2); eas.append(ea2); perms.append(perm)
         if trace is not None:
             trace[f"perm{i}"] = perm; trace[f"score{i}"] = score; trace[f"edge_index{i+1}"] = ei2
     g, e = level(depth, x.shape[0])
-    xr = F.relu(x)
+    xr = _relu(x, "relu.bottom")
     if trace is not None: trace["relu.bottom"] = xr
     x = dynamic_graph_layer(P, f"{pre}.bottom_conv", xr, g, e, p_drop, training)
     if trace is not None:
@@ -412,7 +425,7 @@ def graph_unet(P, cfg: OracleConfig, x, edge_index, edge_attr, training=False, p
     for i in range(depth):
         j = depth - 1 - i
         up = torch.zeros(xs[j + 1].shape[0], x.shape[1], dtype=dtype).index_copy(0, perms[j], x)
-        x = F.relu(up + xs[j + 1])
+        x = _relu(up + xs[j + 1], f"relu.up{i}")
         if trace is not None: trace[f"unet.up{i}.in"] = x; trace[f"relu.up{i}"] = x
         lvl = j + 1 if cfg.strict_reference else j  # D10: graph_layers.py:453 uses edge_indices[j+1]
         gg, ee = level(lvl, x.shape[0])  # level-lvl edge list applied to x.shape[0] nodes

@@ -200,3 +200,35 @@ def test_adaptive_pooling_nonlinearities_and_min_score_on_the_kernels(nonlineari
         assert_close(p.grad, r.grad, 5e-5, "d" + name)
     if min_score is not None:
         assert 0 < perm.numel() < n and perm.numel() != n // 2      # the count came from the threshold, not from the ratio
+
+
+def test_adaptive_pooling_without_a_kernel_raises_and_min_score_may_keep_nothing():
+    """VERDICT r3 item 7 / ADVICE r3: no torch branch behind AdaptiveGraphPooling -- a width the K9 kernels do not take raises
+    DGDMKernelError (it used to run F.linear / torch.topk and ignored min_score there); a threshold above every score returns the
+    reference's EMPTY pooled graph (mask.nonzero() empty, graph_layers.py:302-310) instead of raising."""
+    from dgdm_histopath_lab_amd import DGDMKernelError
+    from dgdm_histopath_lab_amd.core.graph_layers import AdaptiveGraphPooling
+    g = torch.Generator().manual_seed(3)
+    n = 600
+    ei = torch.randint(0, n, (2, 2400), generator=g).to(DEV)
+    # score width 1032 / 2 = 516 > 256: ops.pool_supported says no
+    pool = AdaptiveGraphPooling(1032, ratio=0.5, min_score=0.2).to(DEV)
+    with pytest.raises(DGDMKernelError):
+        pool(torch.randn(n, 1032, generator=g).to(DEV), ei)
+    pool = AdaptiveGraphPooling(64, ratio=0.5, min_score=2.0).to(DEV)        # tanh never reaches 2
+    x = torch.randn(n, 64, generator=g).to(DEV).requires_grad_(True)
+    px, pei, pea, perm, nmap = pool(x, ei, None, return_node_map=True)
+    assert px.shape == (0, 64) and perm.numel() == 0 and pei.shape == ei.shape and bool((pei == -1).all()) and bool((nmap == -1).all())
+    pxc, peic, _, _ = pool(x, ei, None, compact=True)
+    assert pxc.shape == (0, 64) and peic.shape == (2, 0)
+    px.sum().backward()                                                        # differentiable (all-zero gradient), as the reference's
+    assert x.grad is not None and float(x.grad.abs().max()) == 0.0
+
+
+def test_count_ge_is_an_integer_count():
+    """the kept count of min_score pooling is accumulated in int32 (a float sum is inexact beyond 2^24)."""
+    from dgdm_histopath_lab_amd import ops
+    n = (1 << 24) + 4097
+    s = torch.ones(n, device=DEV)
+    s[::3] = -1.0
+    assert ops.count_ge(s, 0.5) == n - (n + 2) // 3

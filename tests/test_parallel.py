@@ -3,6 +3,9 @@ slide sharding helpers (the GPU path uses the same code with backend nccl == RCC
 import os
 import socket
 
+import json
+
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -205,3 +208,32 @@ def test_balanced_slide_loader_partitions_every_step_and_balances_the_cost():
     assert naive > 1.25
     b0 = next(iter(BalancedSlideLoader([GraphData(x=torch.randn(n, 4), edge_index=torch.randint(0, n, (2, 3 * n))) for n in (5, 9, 7, 3)], 4, 2, 1)))
     assert b0.num_graphs == 2 and b0.x.size(0) in (12, 14, 16, 10, 8)
+
+
+@pytest.mark.gpu
+def test_bench_two_rank_rehearsal_prints_one_json_line():
+    """the N > 1 branch of bench.py (init_process_group, split recording around the collective, per-rank
+    timing, max over ranks, ONE JSON line from rank 0) run unattended: `python -m torch.distributed.run --nproc-per-node 2 bench.py
+    --gpus 2 ...` as fresh child processes started by conftest.pytest_configure before this session touched the GPU
+    (DGDM_BENCH_ONE_DEVICE=1: both ranks on the box's one GPU; gloo, since RCCL refuses two ranks on one device)."""
+    from conftest import BENCH_REHEARSAL
+    if not BENCH_REHEARSAL:
+        pytest.skip("rehearsal not started (run as `pytest -m gpu` on a GPU box)")
+    proc = BENCH_REHEARSAL["proc"]
+    try:
+        rc = proc.wait(900)
+    except Exception:
+        proc.kill()
+        raise
+    out, err = open(BENCH_REHEARSAL["out"]).read(), open(BENCH_REHEARSAL["err"]).read()
+    assert rc == 0, f"{BENCH_REHEARSAL['cmd']} exited with {rc}:\n{err[-3000:]}"
+    lines = [ln for ln in out.splitlines() if ln.strip()]
+    assert len(lines) == 1, f"stdout must hold exactly one line, got {len(lines)}:\n{out[:2000]}"
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 3 and r["warmup"] == 1 and r["scaling"] == "weak" and r["unit"] == "slides/s"
+    assert r["config"]["global_batch"] == 8 and r["config"]["parallelism"] == "dp2"
+    assert r["value"] > 0 and abs(r["value"] - 8 * 1e3 / r["ms_per_step"]) < 1e-2 * r["value"]
+    pr, ge = r["per_rank"], r["gradient_exchange"]
+    assert len(pr["ms_per_step_by_rank"]) == 2 and pr["ms_per_step_max"] <= r["ms_per_step"] * 1.001
+    assert ge["bytes"] > 1e6 and ge["messages_per_step"] in (1, 2) and sum(ge["bucket_bytes"]) == ge["bytes"]
+    assert "HIP graph replay" in r["config"]["launch"], r["config"]["launch"]      # the split recording was taken, not the eager fallback

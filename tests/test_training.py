@@ -400,16 +400,5 @@ def test_config4_mixed_size_pretrain_stream_through_the_trainer():
     for k, gr in gref.items():
         if gr.abs().max() < 1e-12:
             continue
-        if gr.numel() == 1 and k.endswith(".bias"):
-            # the bias of a one-output Linear (the pooling score): its gradient is ONE sum over all nodes that cancels to ~1e-4 of
-            # its terms at these weights, so a relative error of the scalar alone measures the conditioning of that sum (seen: 2e-3
-            # while every other gradient held 3e-5).  It is held together with its weight row -- [W | b] acting on [h ; 1] is one
-            # parameter vector of the layer -- and absolutely against the layer's gradient scale.
-            wk = k[:-len("bias")] + "weight"
-            both = torch.cat([named[wk].grad.flatten(), named[k].grad.flatten()])
-            assert_close(both, torch.cat([gref[wk].flatten(), gr.flatten()]), 1e-3, "grad [" + wk + " | bias]")
-            assert abs(float(named[k].grad) - float(gr)) <= 1e-3 * float(gref[wk].abs().max()), k
-            live += 1
-            continue
         assert_close(named[k].grad, gr, 1e-3, "grad " + k); live += 1
     assert live > 100

@@ -29,8 +29,14 @@ def main():
                     help="degree-skew cases at the north-star size (VERDICT r2 item 9): the synthetic kNN-like graph, a Poisson multigraph "
                          "(torch.randint endpoints, core/graph_layers.py:92 sees whatever the builder emits), and a graph with ONE hub of "
                          "5000 in-neighbours -- one wave walks a destination row serially (csrc/spmm.hip), so a hub row is the worst case")
+    ap.add_argument("--cold", action="store_true",
+                    help="every launch behind a rewrite of a 1 GiB buffer (L2 and the 256 MiB Infinity Cache evicted): single launches, "
+                         "median; what the rocprofv3 kernel-trace / PMC passes of tools/profile_gather.sh call the cold case")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
+    if a.cold:
+        cold_case(dev, a.nodes, a.edges, a.widths[0], a.iters)
+        return
     if a.skew:
         skew_cases(dev, a.nodes, a.edges, a.iters)
         return
@@ -60,6 +66,28 @@ def main():
         GraphStructure(ei, n)
     t1.record(); torch.cuda.synchronize()
     print(json.dumps(dict(kernel="graph_structure_build", nodes=n, edges=e, us=round(t0.elapsed_time(t1) * 1e3 / 20, 1))))
+
+
+def cold_case(dev, n, e, c, iters):
+    b = synthetic_batch(0, 1, n, e, 8)
+    gs = GraphStructure(b.edge_index.to(dev), n)
+    x = torch.randn(n, c, device=dev)
+    y = torch.empty(n, c, device=dev)
+    evict = torch.zeros(256 * 1024 * 1024, dtype=torch.float32, device=dev)       # 1 GiB
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ts = []
+    for _ in range(iters):
+        evict.add_(1.0)
+        t0.record()
+        ops.spmm_raw(gs.rowptr, gs.col, gs.w, x, n, out=y)
+        t1.record(); torch.cuda.synchronize()
+        ts.append(t0.elapsed_time(t1) * 1e3)
+    ts.sort()
+    us = ts[len(ts) // 2]
+    by = algorithmic_bytes(n, e, c)
+    print(json.dumps(dict(kernel="dgdm_spmm", case="cold: 1 GiB rewritten before every launch", nodes=n, edges=e, C=c, launches=iters,
+                          us_median=round(us, 2), us_min=round(ts[0], 2), algorithmic_MB=round(by / 1e6, 1), GBps=round(by / us / 1e3, 1),
+                          frac_of_8TBps=round(by / us / 1e3 / 8000, 3))))
 
 
 def skew_cases(dev, n, e, iters, c=768):
