@@ -164,7 +164,8 @@ def test_default_arithmetic_is_at_the_error_level_of_fp32(case):
     print("%s: default max %.2e med %.2e | HIP fp32 max %.2e med %.2e | torch CPU fp32 max %.2e med %.2e" % (case, mx_d, md_d, mx_h, md_h, mx_c, md_c))
     if case == "sharp":
         assert res["entropy"] < 1.0, res["entropy"]                         # the rows really are sharp (ln N = 7.6)
-    assert max(mx_d, mx_h, mx_c) <= 5e-5                                    # all three >= 20x inside the 1e-3 contract
+    # all three well inside the 1e-3 contract; the level itself is the problem's conditioning (Large: 2e-4 for fp32 operands too)
+    assert max(mx_d, mx_h, mx_c) <= {"smooth": 5e-6, "unet": 5e-5, "sharp": 5e-5, "large": 5e-4}[case]
     for mx_o, md_o in ((mx_h, md_h), (mx_c, md_c)):
         assert mx_d <= 4.0 * mx_o, (mx_d, mx_o)
         assert md_d <= 2.5 * md_o, (md_d, md_o)

@@ -89,26 +89,27 @@ def test_pool_score_gather_unpool_against_fp64(n, c, c2):
         assert_close(a, b, 2e-5, name)
 
 
-def test_pooling_module_matches_torch_path():
-    """AdaptiveGraphPooling on the K9 kernels == its torch restatement (same module, kernels off)."""
-    from dgdm_histopath_lab_amd import ops
+def test_pooling_module_matches_the_float64_restatement():
+    """AdaptiveGraphPooling on the K9 kernels against the float64 restatement of core/graph_layers.py:276-329 (`_reference_pool`
+    below; the module has no torch branch any more): kept node ids, node map and relabelled edges bit-exact in both edge layouts,
+    pooled features at 1e-5."""
     from dgdm_histopath_lab_amd.core import AdaptiveGraphPooling
     torch.manual_seed(0)
     pool = AdaptiveGraphPooling(128).to(DEV)
     n = 3000
     x = torch.randn(n, 128, device=DEV); ei = torch.randint(0, n, (2, 9000), device=DEV); ea = torch.randn(9000, 32, device=DEV)
     a = pool(x, ei, ea, None, return_node_map=True)
-    saved = ops.pool_supported
-    try:
-        ops.pool_supported = lambda *_: False
-        b = pool(x, ei, ea, None, return_node_map=True)
-    finally:
-        ops.pool_supported = saved
-    assert torch.equal(a[3], b[3]) and torch.equal(a[1], b[1]) and torch.equal(a[4], b[4])
-    assert_close(a[0], b[0].double(), 1e-5, "pooled x")
-    ac, bc = pool(x, ei, ea, None, compact=True), None
+    sn = pool.score_net
+    rp, rei, rperm, _ = _reference_pool(x.cpu().double(), ei.cpu(), sn[0].weight.detach().cpu().double(), sn[0].bias.detach().cpu().double(),
+                                        sn[2].weight.detach().cpu().double(), sn[2].bias.detach().cpu().double(), "tanh")
+    want_map = torch.full((n,), -1, dtype=torch.int32)
+    want_map[rperm] = torch.arange(rperm.numel(), dtype=torch.int32)
+    assert torch.equal(a[3].cpu(), rperm) and torch.equal(a[4].cpu(), want_map)
     keep = a[1][0] >= 0
-    assert torch.equal(ac[1], a[1][:, keep]) and torch.equal(ac[2], ea[keep])
+    assert torch.equal(a[1][:, keep].cpu(), rei) and bool((a[1][:, ~keep] == -1).all())      # un-compacted layout: dropped edges are (-1, -1)
+    assert_close(a[0], rp, 1e-5, "pooled x")
+    ac = pool(x, ei, ea, None, compact=True)
+    assert torch.equal(ac[1].cpu(), rei) and torch.equal(ac[2], ea[keep])
 
 
 def test_relu_kernels_take_injected_decisions():
