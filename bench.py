@@ -363,8 +363,9 @@ def main():
     torch.manual_seed(0)
     model = DGDMModel(**cfg).to(dev)
     model.train(not args.eval_mode)
-    # training/trainer.py:221-226 defaults; fused=True: one multi-tensor kernel instead of ~10 foreach launches
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-5, fused=True)
+    # training/trainer.py:221-226 defaults (AdamW, lr 1e-4, weight decay 1e-5); optim.DGDMAdamW: torch's AdamW arithmetic in one launch
+    from dgdm_histopath_lab_amd.optim import DGDMAdamW
+    opt = DGDMAdamW(model.parameters(), lr=1e-4, weight_decay=1e-5)
     reducer = FlatGradAllReducer(model, world, always=force_dist) if (world > 1 or force_dist) else None
     # rank r owns slides [r*B, (r+1)*B): independent units, no data-path collective
     batch = synthetic_batch(rank * args.batch, args.batch, args.nodes, args.edges, FEATS).to(dev)
@@ -416,7 +417,10 @@ def main():
     elif not args.eager and stream is None:
         from dgdm_histopath_lab_amd.training import GraphedPretrainStep
         gstep = GraphedPretrainStep(model, opt, mask_ratio=0.15, grad_reducer=reducer)
-        graph_step = (lambda: gstep(batch))
+        # the batch is resident in HBM before the timed region (contract of this script): after the first call it lives in the
+        # recording's own input buffers (GraphedPretrainStep.input_buffers, where a loader's host-to-device copy would put it) and
+        # is handed over from there -- no device-to-device copy of 130 MB of inputs per step that the reference's step does not have
+        graph_step = (lambda: gstep(gstep.input_buffers if gstep.input_buffers is not None else batch))
         done = 0
         try:
             for _ in range(gstep.warmup + 1):     # eager priming + recording: setup, not part of the W warmup steps
@@ -481,12 +485,13 @@ def main():
         prev = ops.configure(attention="fp32", gemm="fp32")
         try:
             g32 = GraphedPretrainStep(model, opt, mask_ratio=0.15)
+            in32 = lambda: g32.input_buffers if g32.input_buffers is not None else batch
             for _ in range(g32.warmup + 1 + 2):
-                g32(batch)
+                g32(in32())
             n32 = max(5, min(args.steps, 20))
             torch.cuda.synchronize(); t1 = time.perf_counter()
             for _ in range(n32):
-                g32(batch)
+                g32(in32())
             torch.cuda.synchronize()
             d32 = (time.perf_counter() - t1) / n32
             strict = {"value": round(args.batch / d32, 3), "unit": "slides/s", "ms_per_step": round(d32 * 1e3, 3), "steps": n32,

@@ -7,4 +7,5 @@ from .graph import GraphBatch, GraphData, GraphStructure  # noqa: F401
 
 __version__ = "0.1.0"
 from .models.dgdm_model import DGDMModel, ModelConfigurationError, ModelInferenceError, ValidationError  # noqa: F401,E402
+from .optim import DGDMAdamW  # noqa: F401,E402
 from .training import BatchLayoutError, DGDMTrainer, GraphedPretrainStep, predict_graph  # noqa: F401,E402

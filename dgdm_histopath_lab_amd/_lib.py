@@ -65,6 +65,7 @@ SIGNATURES = {
     "dgdm_gemm_nn": (C.c_int, [_p, _i64, _p, _i64, _p, _i64, _i32, _i32, _i32, _i32, _p]),
     "dgdm_gemm_tn_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
     "dgdm_gemm_tn": (C.c_int, [_p, _i64, _p, _i64, _p, _i64, _p, _i32, _i32, _i32, _p, _sz, _p]),
+    "dgdm_adamw_step": (C.c_int, [_p, _i32, _p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _p, _p, _p]),
     "dgdm_seed_epoch_advance": (C.c_int, [_p]),
     "dgdm_seed_epoch_set": (C.c_int, [C.c_uint32, _p]),
     "dgdm_linear_small_fwd": (C.c_int, [_p, _i64, _p, _i64, _p, _i32, _i32, _i32, _i32, _p, _i64, _p, _i64, _p]),
@@ -159,6 +160,11 @@ TN_PARTIAL_MAX = 24
 class LongRows(C.Structure):
     """struct DgdmLongRows of include/dgdm_hip.h (a HOST struct holding device pointers)"""
     _fields_ = [("table", _p), ("partial", _p), ("ld", _i64), ("item_cap", _i32), ("slot_cap", _i32)]
+
+class AdamTensor(C.Structure):
+    """struct DgdmAdamTensor of include/dgdm_hip.h (a HOST struct holding device pointers)"""
+    _fields_ = [("param", _p), ("grad", _p), ("exp_avg", _p), ("exp_avg_sq", _p), ("numel", _i64)]
+
 
 _lib: Optional[C.CDLL] = None
 

@@ -214,7 +214,11 @@ class DGDMTrainer(nn.Module):
     def configure_optimizers(self, total_steps: int):
         """``total_steps`` = Lightning's ``trainer.estimated_stepping_batches``."""
         on_gpu = next(self.model.parameters()).is_cuda
-        opt = AdamW(self.model.parameters(), lr=self.learning_rate, weight_decay=self.weight_decay, fused=True if on_gpu else None)
+        if on_gpu:      # the same AdamW arithmetic on one HIP launch (optim.py); CPU models (host-logic tests) keep torch's
+            from .optim import DGDMAdamW
+            opt = DGDMAdamW(self.model.parameters(), lr=self.learning_rate, weight_decay=self.weight_decay)
+        else:
+            opt = AdamW(self.model.parameters(), lr=self.learning_rate, weight_decay=self.weight_decay)
         if self.scheduler_type == "cosine":
             sched = CosineAnnealingLR(opt, T_max=total_steps, eta_min=self.learning_rate * 0.01)
         elif self.scheduler_type == "onecycle":
@@ -366,8 +370,8 @@ class GraphedPretrainStep:
     generator is graph-aware), and the dropout sites fold in the device-side seed epoch, advanced by a
     kernel at the head of the graph (csrc/common.hpp, DgdmSeed).
 
-    * ``optimizer`` must be a fused AdamW; it is switched to ``capturable`` (device-side step count and
-      learning rate).  Set the learning rate with :meth:`set_lr` (an asynchronous fill, no host sync).
+    * ``optimizer``: ``optim.DGDMAdamW`` (one launch) or torch's fused AdamW; it is switched to ``capturable`` (device-side
+      step count and learning rate).  Set the learning rate with :meth:`set_lr` (an asynchronous fill, no host sync).
     * the first ``warmup`` calls run eagerly on a side stream (they are real training steps), the next call
       records, every later call replays.  A batch of another shape raises ``BatchLayoutError`` (a ``ValueError``) -- run it eagerly.
     * ``validate=True`` keeps the model's input checks (NaN / inf / edge range, one host readback per batch) in
@@ -388,7 +392,7 @@ class GraphedPretrainStep:
             raise _lib.DGDMKernelError("GraphedPretrainStep records HIP graphs: the model must live on the GPU")
         for group in optimizer.param_groups:
             if not group.get("fused"):
-                raise ValueError("GraphedPretrainStep needs a fused optimizer (torch.optim.AdamW(..., fused=True))")
+                raise ValueError("GraphedPretrainStep needs optim.DGDMAdamW or a fused optimizer (torch.optim.AdamW(..., fused=True))")
             group["capturable"] = True
             if not isinstance(group["lr"], torch.Tensor):
                 group["lr"] = torch.tensor(float(group["lr"]), dtype=torch.float32, device=self.dev)
@@ -438,7 +442,16 @@ class GraphedPretrainStep:
         for k in self.FIELDS:
             v = getattr(batch, k, None)
             if isinstance(v, torch.Tensor):
-                getattr(self.static, k).copy_(v, non_blocking=True)
+                dst = getattr(self.static, k)
+                if v.data_ptr() != dst.data_ptr():      # a loader that fills `input_buffers` in place hands the buffers back: nothing to copy
+                    dst.copy_(v, non_blocking=True)
+
+    @property
+    def input_buffers(self):
+        """The recording's own input tensors (a ``GraphBatch``; ``None`` before the first call).  A data pipeline that writes the
+        next batch of the same layout INTO these tensors (e.g. the host-to-device copy of its loader) and passes this object to
+        ``__call__`` saves the device-to-device copy of the batch (130 MB per step at 4 x 10k nodes x 768 features)."""
+        return self.static
 
     def set_lr(self, lr: float, group: int = 0) -> None:
         self.opt.param_groups[group]["lr"].fill_(float(lr))

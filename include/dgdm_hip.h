@@ -649,6 +649,24 @@ DGDM_API int dgdm_edge_emit(const int32_t* sidx, const float* sdist, int32_t Ks1
                             int32_t N, float threshold, const void* workspace, int64_t U, int32_t edge_dim, int64_t* edge_index,
                             float* edge_attr, int64_t* edge_type, float* edge_weight, void* stream);
 
+/* ---- optimizer step (reference training/trainer.py:217-226: torch.optim.AdamW(lr, weight_decay)) ------------
+ * One launch per 96 tensors for ALL live parameters of the model.  `tensors`: HOST array of descriptors holding DEVICE
+ * pointers (fp32, 4-byte aligned; 16-byte aligned tensors take the vector path), numel elements each; descriptors travel in
+ * the kernel arguments, so a launch recorded in a HIP graph replays on the same addresses.  lr_dev (nullable): device fp32
+ * learning rate (takes precedence over `lr`, for schedulers that write it without a host sync).  step_dev: device fp32 count
+ * of the steps taken so far by this set of tensors -- read by every workgroup (t = step + 1 enters the bias corrections),
+ * advanced by the launch itself; ticket_dev: one device uint32, zero before the first call, left zero.
+ * Arithmetic of torch/optim/adamw.py (decoupled weight decay; no amsgrad, no maximize). */
+typedef struct DgdmAdamTensor {
+  float* param;
+  const float* grad;
+  float* exp_avg;
+  float* exp_avg_sq;
+  int64_t numel;
+} DgdmAdamTensor;
+DGDM_API int dgdm_adamw_step(const DgdmAdamTensor* tensors, int32_t count, const float* lr_dev, float lr, float beta1, float beta2,
+                             float eps, float weight_decay, float* step_dev, uint32_t* ticket_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

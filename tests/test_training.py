@@ -402,3 +402,81 @@ def test_config4_mixed_size_pretrain_stream_through_the_trainer():
             continue
         assert_close(named[k].grad, gr, 1e-3, "grad " + k); live += 1
     assert live > 100
+
+
+@pytest.mark.gpu
+def test_dgdm_adamw_matches_torch_adamw_and_exchanges_state_dicts():
+    """optim.DGDMAdamW (one HIP launch per 96 tensors) against torch.optim.AdamW in float64 on the CPU, the reference's optimizer
+    (training/trainer.py:217-226): 150 tensors of odd sizes (two launches; tails that are not multiples of 4; a 4-byte-aligned
+    view), one parameter that never gets a gradient (skipped, as torch skips it), one that gets its first gradient at step 3 (its
+    own step count, as in torch).  Then: the state dict loads into torch's AdamW and back, and both continue identically; a
+    device-tensor learning rate; the step recorded into a HIP graph."""
+    from dgdm_histopath_lab_amd.optim import DGDMAdamW
+    DEV = "cuda:0"
+    g = torch.Generator().manual_seed(0)
+    sizes = [1, 3, 4, 5, 127, 128, 4096, 4097, 8191, 70001] + [int(torch.randint(1, 3000, (1,), generator=g)) for _ in range(140)]
+    base = [torch.randn(n, generator=g) for n in sizes]
+    flat = torch.zeros(1001, device=DEV)
+    ref = [torch.nn.Parameter(b.double().clone()) for b in base]
+    own = [torch.nn.Parameter(b.to(DEV).clone()) for b in base]
+    own[7] = torch.nn.Parameter(flat[1:])       # a parameter whose storage starts 4 bytes off a 16-byte boundary: scalar path
+    ref[7] = torch.nn.Parameter(torch.zeros(1000, dtype=torch.float64))
+    kw = dict(lr=3e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
+    o_ref, o_own = torch.optim.AdamW(ref, **kw), DGDMAdamW(own, **kw)
+
+    def grads(step):
+        for i, (a, b) in enumerate(zip(ref, own)):
+            if i == 5 or (i == 9 and step < 3):          # 5: never a gradient; 9: joins at step 3
+                a.grad = b.grad = None
+                continue
+            gr = torch.randn(a.shape, generator=g)
+            a.grad, b.grad = gr.double(), gr.to(DEV)
+
+    def same(tol=2e-6):
+        for i, (a, b) in enumerate(zip(ref, own)):
+            d = (b.detach().cpu().double() - a.detach()).abs().max().item()
+            assert d <= tol * max(1.0, a.detach().abs().max().item()), (i, d)
+    for s in range(6):
+        grads(s)
+        o_ref.step(); o_own.step()
+    same()
+    assert torch.equal(own[5].detach().cpu(), base[5])                                   # no gradient: untouched (no weight decay either)
+    assert float(o_own.state[own[0]]["step"]) == 6.0 and float(o_own.state[own[9]]["step"]) == 3.0 and own[5] not in o_own.state
+    # state dict -> torch.optim.AdamW (fp32, GPU) and back
+    twin = [torch.nn.Parameter(p.detach().clone()) for p in own]
+    o_twin = torch.optim.AdamW(twin, **kw)
+    o_twin.load_state_dict(o_own.state_dict())
+    o_back = DGDMAdamW(own, **kw)
+    o_back.load_state_dict(o_twin.state_dict())
+    for s in range(6, 9):
+        grads(s)
+        for a, b in zip(own, twin):
+            b.grad = None if a.grad is None else a.grad.clone()
+        o_ref.step(); o_back.step(); o_twin.step()
+    same()
+    for a, b in zip(own, twin):
+        assert (a.detach() - b.detach()).abs().max().item() <= 2e-6 * max(1.0, b.detach().abs().max().item())
+    assert float(o_back.state[own[9]]["step"]) == 6.0 and float(o_back.state[own[0]]["step"]) == 9.0
+    # device-side learning rate + HIP graph replay: three replays == three steps of the CPU optimizer
+    lr_dev = torch.tensor(3e-3, device=DEV)
+    for grp in o_back.param_groups:
+        grp["lr"] = lr_dev
+    grads(9)
+    static = [None if p.grad is None else p.grad.clone() for p in own]
+    for p, sg in zip(own, static):
+        p.grad = sg
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(gr):
+            o_back.step()
+    torch.cuda.current_stream().wait_stream(side)
+    for s in range(3):
+        for a, sg in zip(ref, static):
+            a.grad = None if sg is None else sg.cpu().double()
+        o_ref.step()
+        gr.replay()
+    torch.cuda.synchronize()
+    same(4e-6)
+    assert float(o_back.state[own[0]]["step"]) == 12.0

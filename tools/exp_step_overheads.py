@@ -1,0 +1,41 @@
+"""Where does the host side of a replayed step cost GPU time?  Times the headline step (bench.py's workload) with the pieces of
+GraphedPretrainStep.__call__ switched off one by one: input validation (a kernel + a host readback per step), the copies of the
+batch into the recording's input buffers, the loss clone.  GPU box only."""
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dgdm_histopath_lab_amd import DGDMModel, ops
+from dgdm_histopath_lab_amd.synthetic import synthetic_batch
+from dgdm_histopath_lab_amd.training import GraphedPretrainStep
+
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+model = DGDMModel(node_features=768, hidden_dims=[512, 256, 128], num_diffusion_steps=10, attention_heads=8).to(dev).train()
+opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-5, fused=True)
+batch = synthetic_batch(0, 4, 10000, 50000, 768).to(dev)
+g = GraphedPretrainStep(model, opt, mask_ratio=0.15)
+for _ in range(g.warmup + 3):
+    g(batch)
+
+
+def timeit(fn, n=40):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t) / n * 1e3
+
+
+print("default __call__            %.3f ms/step" % timeit(lambda: g(batch)))
+g.validate = False
+print("validate=False              %.3f ms/step" % timeit(lambda: g(batch)))
+print("validate=False, static in   %.3f ms/step" % timeit(lambda: g(g.static)))
+g.validate = True
+print("validate=True,  static in   %.3f ms/step" % timeit(lambda: g(g.static)))
+
+
+def bare():
+    g._graphs[0].replay()
+print("bare graph replay           %.3f ms/step" % timeit(bare))
