@@ -248,6 +248,16 @@ class PackedOperands:
 # dO is packed as alpha * dO with alpha * max|dO| in (TARGET/2, TARGET] (device-side power of two): with P' = 2^8 P the products
 # dS' = P' (keep dP - delta) stay ~4x further from fp16's maximum than round 2's (target 256, P unscaled) did
 ATTN_GRAD_TARGET = 0.25
+ATTN_BWD_CONCURRENT = False     # dQ pass on a side stream beside the dK/dV pass (tools/bench_with.py A/B switch)
+_SIDE_STREAMS: dict = {}
+
+
+def _side_stream(device) -> "torch.cuda.Stream":
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    s = _SIDE_STREAMS.get(idx)
+    if s is None:
+        s = _SIDE_STREAMS[idx] = torch.cuda.Stream(device)
+    return s
 
 
 def attn_pack(x, col0: int, cstride: int, ntensors: int, scale0: float, plan: AttnPlan, H: int, pos=None, pos_scale: float = 1.0, O=None,
@@ -299,17 +309,33 @@ def spatial_attn_h_bwd_raw(pk: PackedOperands, out, gout, plan: AttnPlan, H: int
     ws = torch.empty(wsb // 4, dtype=torch.float32, device=out.device)
     _lib.check(lib.dgdm_amax_pow2_scale(gout.data_ptr(), gout.numel(), ATTN_GRAD_TARGET, gs.data_ptr(), ws.data_ptr(), wsb, st), "dgdm_amax_pow2_scale")
     gk = attn_pack(gout, 0, C, 1, 1.0, plan, H, O=out, scale_dev=gs, lse2_b=lse2_b)
-    TIMERS.timed("attn_bwd_dq", lambda: _lib.check(
-        lib.dgdm_spatial_attn_h_bwd_dq(pk.r(0).data_ptr(), pk.r(1).data_ptr(), pk.r(2).data_ptr(), gk.r(0).data_ptr(),
-                                       pk.pos_b.data_ptr(), gk.nlse_b.data_ptr(), gk.ndelta_b.data_ptr(), plan.ptr_dev.data_ptr(), plan.B,
-                                       plan.num_q_tiles, H, scale, drop_p, seed, gs.data_ptr(), dqkv[:, :C].data_ptr(), dqkv.stride(0), dq_variant, st),
-        "dgdm_spatial_attn_h_bwd_dq"))
-    TIMERS.timed("attn_bwd_dkv", lambda: _lib.check(
-        lib.dgdm_spatial_attn_h_bwd_dkv(pk.r(0).data_ptr(), pk.r(1).data_ptr(), pk.r(2).data_ptr(), gk.r(0).data_ptr(),
-                                        pk.pos_b.data_ptr(), gk.nlse_b.data_ptr(), gk.ndelta_b.data_ptr(),
-                                        plan.ptr_dev.data_ptr(), plan.B, plan.num_q_tiles, H, drop_p, seed, gs.data_ptr(),
-                                        dqkv[:, C:2 * C].data_ptr(), dqkv[:, 2 * C:].data_ptr(), dqkv.stride(0), dkv_variant, st),
-        "dgdm_spatial_attn_h_bwd_dkv"))
+    def run_dq(stream):
+        _lib.check(
+            lib.dgdm_spatial_attn_h_bwd_dq(pk.r(0).data_ptr(), pk.r(1).data_ptr(), pk.r(2).data_ptr(), gk.r(0).data_ptr(),
+                                           pk.pos_b.data_ptr(), gk.nlse_b.data_ptr(), gk.ndelta_b.data_ptr(), plan.ptr_dev.data_ptr(), plan.B,
+                                           plan.num_q_tiles, H, scale, drop_p, seed, gs.data_ptr(), dqkv[:, :C].data_ptr(), dqkv.stride(0), dq_variant,
+                                           stream), "dgdm_spatial_attn_h_bwd_dq")
+
+    def run_dkv(stream):
+        _lib.check(
+            lib.dgdm_spatial_attn_h_bwd_dkv(pk.r(0).data_ptr(), pk.r(1).data_ptr(), pk.r(2).data_ptr(), gk.r(0).data_ptr(),
+                                            pk.pos_b.data_ptr(), gk.nlse_b.data_ptr(), gk.ndelta_b.data_ptr(),
+                                            plan.ptr_dev.data_ptr(), plan.B, plan.num_q_tiles, H, drop_p, seed, gs.data_ptr(),
+                                            dqkv[:, C:2 * C].data_ptr(), dqkv[:, 2 * C:].data_ptr(), dqkv.stride(0), dkv_variant, stream),
+            "dgdm_spatial_attn_h_bwd_dkv")
+    if ATTN_BWD_CONCURRENT and not TIMERS.enabled:
+        # the two passes are independent (dQ | dK, dV: disjoint columns of dqkv) and each leaves the chip partly empty in its last
+        # round of workgroups (1256 / 2512 workgroups on 512 / 768 resident slots): side by side the one fills the other's tail.
+        # One fork / join pair; inside a recording the side stream joins the capture through the two waits.
+        cur, side = torch.cuda.current_stream(out.device), _side_stream(out.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            run_dq(_lib.stream_ptr(out.device))
+        run_dkv(st)
+        cur.wait_stream(side)
+    else:
+        TIMERS.timed("attn_bwd_dq", lambda: run_dq(st))
+        TIMERS.timed("attn_bwd_dkv", lambda: run_dkv(st))
     return dqkv
 
 

@@ -67,6 +67,14 @@ class DGDMAdamW(torch.optim.Optimizer):
             st["step"] = c["step"]
         self._cohorts[gi] = list(by_value.values())
 
+    def state_dict(self):
+        """torch's layout; every parameter gets a COPY of its cohort's count (torch.optim.AdamW advances each parameter's own
+        ``step`` tensor: handing it one shared tensor would advance that tensor once per parameter)."""
+        sd = super().state_dict()
+        sd["state"] = {k: {n: (v.clone() if n == "step" and isinstance(v, torch.Tensor) else v) for n, v in st.items()}
+                       for k, st in sd["state"].items()}
+        return sd
+
     def load_state_dict(self, state_dict) -> None:
         super().load_state_dict(state_dict)
         self._cohorts, self._tables = {}, {}

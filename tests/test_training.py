@@ -445,9 +445,11 @@ def test_dgdm_adamw_matches_torch_adamw_and_exchanges_state_dicts():
     # state dict -> torch.optim.AdamW (fp32, GPU) and back
     twin = [torch.nn.Parameter(p.detach().clone()) for p in own]
     o_twin = torch.optim.AdamW(twin, **kw)
-    o_twin.load_state_dict(o_own.state_dict())
+    import copy
+    # deep copies: Optimizer.load_state_dict casts with .to(), which hands back the SAME tensors when dtype and device already match
+    o_twin.load_state_dict(copy.deepcopy(o_own.state_dict()))
     o_back = DGDMAdamW(own, **kw)
-    o_back.load_state_dict(o_twin.state_dict())
+    o_back.load_state_dict(copy.deepcopy(o_twin.state_dict()))
     for s in range(6, 9):
         grads(s)
         for a, b in zip(own, twin):
