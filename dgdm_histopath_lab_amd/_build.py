@@ -91,5 +91,53 @@ def build(force: bool = False, verbose: bool = True) -> str:
     return LIB_PATH
 
 
+# ---- sanitizer twin (host code only): tests/test_abi.py runs the argument checks, workspace-size arithmetic and descriptor packing of
+# every entry point under AddressSanitizer + UndefinedBehaviorSanitizer ON THE CPU (GPU ASan / XNACK are not available on this
+# pool; hipcc ignores -fsanitize for the gfx950 side, the host side of every .hip file is instrumented).  Never loaded by the product.
+ASAN_PATH = os.path.join(LIB_DIR, "asan", "libdgdm_hip.so")
+ASAN_FLAGS = ["-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-fno-sanitize=vptr", "-fno-sanitize-recover=undefined",
+              "-shared-libsan", "-Wno-option-ignored"]
+
+
+def asan_runtime() -> str:
+    """Path of the shared ASan runtime of ROCm's clang (to LD_PRELOAD into the python that loads the twin), or ''."""
+    r = subprocess.run([_hipcc(), "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True)
+    cand = r.stdout.strip()
+    if os.path.isabs(cand) and os.path.exists(cand):
+        return cand
+    import glob
+    hits = glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so")
+    return hits[0] if hits else ""
+
+
+def build_sanitized(verbose: bool = False) -> str:
+    os.makedirs(os.path.dirname(ASAN_PATH), exist_ok=True)
+    stamp = os.path.join(os.path.dirname(ASAN_PATH), "build.sha256")
+    dig = _digest() + hashlib.sha256(" ".join(ASAN_FLAGS).encode()).hexdigest()
+    if os.path.exists(ASAN_PATH) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
+        return ASAN_PATH
+    hipcc = _hipcc()
+    objdir = os.path.join(os.path.dirname(ASAN_PATH), "obj")
+    os.makedirs(objdir, exist_ok=True)
+    base = [f for f in FLAGS if f != "-O3"]
+
+    def compile_one(src):
+        obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
+        r = subprocess.run([hipcc, *base, *ASAN_FLAGS, *EXTRA_FLAGS.get(os.path.basename(src), []), "-c", src, "-o", obj], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc (sanitized) failed on {src}:\n{r.stdout}\n{r.stderr}")
+        return obj
+    with cf.ThreadPoolExecutor(max_workers=4) as ex:
+        objs = list(ex.map(compile_one, _sources()))
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fsanitize=address,undefined", "-shared-libsan", "-o", ASAN_PATH, *objs],
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link (sanitized) failed:\n{r.stdout}\n{r.stderr}")
+    open(stamp, "w").write(dig)
+    if verbose:
+        print(f"built {ASAN_PATH}")
+    return ASAN_PATH
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv)

@@ -329,7 +329,7 @@ PairWorkspace carve_pair(void* base, int64_t E, int32_t N, int32_t add_loops) {
   char* p = static_cast<char*>(base);
   size_t off = 0;
   auto take = [&](size_t count) {
-    int32_t* r = reinterpret_cast<int32_t*>(p + off);
+    int32_t* r = p ? reinterpret_cast<int32_t*>(p + off) : nullptr;      // size queries carve a null base: no arithmetic on it
     off += dgdm_align_up(count * sizeof(int32_t), 256);
     return r;
   };
@@ -356,7 +356,7 @@ Workspace carve(void* base, int64_t E, int32_t N, int32_t add_loops) {
   char* p = static_cast<char*>(base);
   size_t off = 0;
   auto take = [&](size_t count) {
-    int32_t* r = reinterpret_cast<int32_t*>(p + off);
+    int32_t* r = p ? reinterpret_cast<int32_t*>(p + off) : nullptr;      // size queries carve a null base: no arithmetic on it
     off += dgdm_align_up(count * sizeof(int32_t), 256);
     return r;
   };

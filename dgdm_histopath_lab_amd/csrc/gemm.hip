@@ -306,14 +306,15 @@ constexpr int TN_STAGE_SLOTS = 16;   // more than 32 chunks: first fold them int
 
 int tn_chunk_rows(int M, int N, int K) {
   // enough workgroups to fill 256 CUs ~2x, chunks a multiple of BK rows, at most 256 chunks
-  const int tiles = ((N + BM - 1) / BM) * ((K + BN - 1) / BN);
-  int want = (496 + tiles / 2) / tiles;   // ~2 workgroups per CU, all resident in one round
+  // 64-bit throughout (sizes up to INT32_MAX must not overflow: see gemm3.hip, tn3_chunk_rows)
+  const int64_t tiles = (((int64_t)N + BM - 1) / BM) * (((int64_t)K + BN - 1) / BN);
+  int64_t want = (496 + tiles / 2) / tiles;   // ~2 workgroups per CU, all resident in one round
   if (want < 1) want = 1;
   if (want > 256) want = 256;
-  int chunk = (M + want - 1) / want;
+  int64_t chunk = ((int64_t)M + want - 1) / want;
   chunk = (chunk + BK - 1) / BK * BK;
   if (chunk < 4 * BK) chunk = 4 * BK;
-  return chunk;
+  return (int)(chunk > 0x7fffff00 ? 0x7fffff00 : chunk);
 }
 
 }  // namespace
@@ -364,7 +365,7 @@ extern "C" int dgdm_gemm_nn(const float* A, int64_t lda, const float* W, int64_t
 extern "C" size_t dgdm_gemm_tn_workspace_bytes(int32_t M, int32_t N, int32_t K, int32_t with_bias) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   const int chunk = tn_chunk_rows(M, N, K);
-  const int nchunks = (M + chunk - 1) / chunk;
+  const int nchunks = (int)(((int64_t)M + chunk - 1) / chunk);
   const size_t width = (size_t)N * K + (with_bias ? N : 0);
   return (size_t)(nchunks + (nchunks > 32 ? TN_STAGE_SLOTS : 0)) * width * sizeof(float);
 }
@@ -385,7 +386,7 @@ static int tn_impl(const float* dY, int64_t ldy, const float* X, int64_t ldx, fl
   if ((ldy & 3) || (ldx & 3) || (N & 3) || (K & 3) || ldy < N || ldx < K || !dgdm_aligned16(dY) || !dgdm_aligned16(X))
     return DGDM_ERR_UNSUPPORTED;
   const int chunk = tn_chunk_rows(M, N, K);
-  const int nchunks = (M + chunk - 1) / chunk;
+  const int nchunks = (int)(((int64_t)M + chunk - 1) / chunk);
   const int64_t width = (int64_t)N * K + (db ? N : 0);
   if (width > 0x7fffffffLL) return DGDM_ERR_UNSUPPORTED;
   const bool staged = nchunks > 32;

@@ -452,14 +452,16 @@ __global__ __launch_bounds__(256) void k_gemm3_tn_final(const float* __restrict_
 constexpr int LDS_BYTES = 2 * STAGE;   // 73728: above the 64 KiB static limit, so dynamic
 
 int tn3_chunk_rows(int M, int N, int K) {
-  const int tiles = ((N + BM - 1) / BM) * ((K + BN - 1) / BN);
-  int want = (DGDM_TN_WANT + tiles / 2) / tiles;   // workgroups per problem: see common.hpp
+  // 64-bit throughout: N, K, M up to INT32_MAX must not overflow (the tile count of a 2^31 x 2^31 problem does not fit an int;
+  // found by the argument battery of tests/test_abi.py: a zero tile count divided)
+  const int64_t tiles = (((int64_t)N + BM - 1) / BM) * (((int64_t)K + BN - 1) / BN);
+  int64_t want = (DGDM_TN_WANT + tiles / 2) / tiles;   // workgroups per problem: see common.hpp
   if (want < 1) want = 1;
   if (want > 256) want = 256;
-  int chunk = (M + want - 1) / want;
+  int64_t chunk = ((int64_t)M + want - 1) / want;
   chunk = (chunk + 2 * KS - 1) / (2 * KS) * (2 * KS);
   if (chunk < 8 * KS) chunk = 8 * KS;
-  return chunk;
+  return (int)(chunk > 0x7fffff00 ? 0x7fffff00 : chunk);
 }
 
 // 72 KiB of dynamic LDS needs the opt-in once per kernel (per process; one device per process)
@@ -530,7 +532,7 @@ extern "C" int dgdm_gemm_nn_bf16x3(const float* A, int64_t lda, const float* W, 
 extern "C" size_t dgdm_gemm_tn_bf16x3_workspace_bytes(int32_t M, int32_t N, int32_t K, int32_t with_bias) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   const int chunk = tn3_chunk_rows(M, N, K);
-  const int nchunks = (M + chunk - 1) / chunk;
+  const int nchunks = (int)(((int64_t)M + chunk - 1) / chunk);
   const size_t width = (size_t)N * K + (with_bias ? N : 0);
   return (size_t)nchunks * width * sizeof(float);
 }
@@ -552,7 +554,7 @@ static int tn_impl(const float* dY, int64_t ldy, const float* X, int64_t ldx, fl
   if ((ldy & 3) || (ldx & 3) || (N & 3) || (K & 3) || ldy < N || ldx < K || !dgdm_aligned16(dY) || !dgdm_aligned16(X))
     return DGDM_ERR_UNSUPPORTED;
   const int chunk = tn3_chunk_rows(M, N, K);
-  const int nchunks = (M + chunk - 1) / chunk;
+  const int nchunks = (int)(((int64_t)M + chunk - 1) / chunk);
   const int64_t width = (int64_t)N * K + (db ? N : 0);
   if (width > 0x7fffffffLL) return DGDM_ERR_UNSUPPORTED;
   if (workspace_bytes < (size_t)nchunks * width * sizeof(float)) return DGDM_ERR_WORKSPACE;
@@ -588,7 +590,7 @@ extern "C" int dgdm_gemm_tn_partial_bf16x3(const float* dY, int64_t ldy, const f
 extern "C" int32_t dgdm_gemm_tn_chunks(int32_t M, int32_t N, int32_t K) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   const int chunk = tn3_chunk_rows(M, N, K);
-  return (M + chunk - 1) / chunk;
+  return (int32_t)(((int64_t)M + chunk - 1) / chunk);
 }
 
 extern "C" int dgdm_gemm_tn_split_bf16x3(const float* dY, int64_t ldy, const float* X, int64_t ldx, float* dW0, int64_t ld0, int32_t K0, float* dW1,

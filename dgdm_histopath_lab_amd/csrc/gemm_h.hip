@@ -657,14 +657,15 @@ __global__ __launch_bounds__(256) void k_gemmh_tn_final(const float* __restrict_
 constexpr int LDS_BYTES = 2 * STAGE;   // 49152
 
 int tnh_chunk_rows(int M, int N, int K, int want_total = DGDM_TN_WANT) {
-  const int tiles = ((N + BM - 1) / BM) * ((K + BN - 1) / BN);
-  int want = (want_total + tiles / 2) / tiles;   // workgroups per problem: see common.hpp
+  // 64-bit throughout (see gemm3.hip, tn3_chunk_rows)
+  const int64_t tiles = (((int64_t)N + BM - 1) / BM) * (((int64_t)K + BN - 1) / BN);
+  int64_t want = (want_total + tiles / 2) / tiles;   // workgroups per problem: see common.hpp
   if (want < 1) want = 1;
   if (want > 256) want = 256;
-  int chunk = (M + want - 1) / want;
+  int64_t chunk = ((int64_t)M + want - 1) / want;
   chunk = (chunk + 2 * KS - 1) / (2 * KS) * (2 * KS);
   if (chunk < 8 * KS) chunk = 8 * KS;
-  return chunk;
+  return (int)(chunk > 0x7fffff00 ? 0x7fffff00 : chunk);
 }
 
 // dynamic LDS opt-in once per kernel (per process; one device per process)
@@ -740,7 +741,7 @@ extern "C" int dgdm_gemm_nn_f16x2(const float* A, int64_t lda, const float* W, i
 extern "C" size_t dgdm_gemm_tn_f16x2_workspace_bytes(int32_t M, int32_t N, int32_t K, int32_t with_bias) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   const int chunk = tnh_chunk_rows(M, N, K);
-  const int nchunks = (M + chunk - 1) / chunk;
+  const int nchunks = (int)(((int64_t)M + chunk - 1) / chunk);
   const size_t width = (size_t)N * K + (with_bias ? N : 0);
   return (size_t)nchunks * width * sizeof(float);
 }
@@ -762,7 +763,7 @@ static int tn_impl(const float* dY, int64_t ldy, const float* X, int64_t ldx, fl
   if ((ldy & 3) || (ldx & 3) || (N & 3) || (K & 3) || ldy < N || ldx < K || !dgdm_aligned16(dY) || !dgdm_aligned16(X))
     return DGDM_ERR_UNSUPPORTED;
   const int chunk = tnh_chunk_rows(M, N, K);
-  const int nchunks = (M + chunk - 1) / chunk;
+  const int nchunks = (int)(((int64_t)M + chunk - 1) / chunk);
   const int64_t width = (int64_t)N * K + (db ? N : 0);
   if (width > 0x7fffffffLL) return DGDM_ERR_UNSUPPORTED;
   if (workspace_bytes < (size_t)nchunks * width * sizeof(float)) return DGDM_ERR_WORKSPACE;
@@ -800,24 +801,24 @@ extern "C" int dgdm_gemm_tn_partial_f16x2(const float* dY, int64_t ldy, const fl
 // rows per chunk of one problem inside dgdm_gemm_tn_partial_many_f16x2: the chunk COUNT aimed for is a power of two (the XCD-aware
 // workgroup order of k_gemmh_tn32_many wants chunk % 8 to name an XCD)
 static int tnh_chunk_rows_grouped(int M, int N, int K) {
-  const int tiles = ((N + BM - 1) / BM) * ((K + BN - 1) / BN);
-  int want = (DGDM_TN_WANT_GROUPED + tiles / 2) / tiles;
+  const int64_t tiles = (((int64_t)N + BM - 1) / BM) * (((int64_t)K + BN - 1) / BN);     // 64-bit: see tnh_chunk_rows
+  int64_t want = (DGDM_TN_WANT_GROUPED + tiles / 2) / tiles;
   if (want < 1) want = 1;
   if (want > 256) want = 256;
-  int p2 = 1;
+  int64_t p2 = 1;
   while (2 * p2 <= want) p2 *= 2;
   if (2 * p2 - want < want - p2) p2 *= 2;        // nearest power of two
-  int chunk = (M + p2 - 1) / p2;
+  int64_t chunk = ((int64_t)M + p2 - 1) / p2;
   chunk = (chunk + 2 * KS - 1) / (2 * KS) * (2 * KS);
   if (chunk < 8 * KS) chunk = 8 * KS;
-  return chunk;
+  return (int)(chunk > 0x7fffff00 ? 0x7fffff00 : chunk);
 }
 
 // row chunks (= partial slots) of one problem inside dgdm_gemm_tn_partial_many_f16x2
 extern "C" int32_t dgdm_gemm_tn_chunks_grouped(int32_t M, int32_t N, int32_t K) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   const int chunk = tnh_chunk_rows_grouped(M, N, K);
-  return (M + chunk - 1) / chunk;
+  return (int32_t)(((int64_t)M + chunk - 1) / chunk);
 }
 
 extern "C" int dgdm_gemm_tn_partial_many_f16x2(const DgdmTnPartial* descs, int32_t count, void* stream) {

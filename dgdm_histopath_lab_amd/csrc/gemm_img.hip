@@ -153,6 +153,13 @@ __device__ unsigned long long* dgdm_stamp_buf;
 #define DGDM_STAMP(i_)
 #endif
 
+// widest output the narrow kernel (wave = 32 x 128) takes; beyond it the wide one (wave = 32 x 256).  Round 4, same-box A/B
+// (tools/build_variant_lib.sh -DDGDM_IMG_NARROW_MAX=128 vs 256, tools/microbench_gemm.py): at N = 256 and M = 40 000 the wide
+// kernel has 313 workgroups for 512 resident slots, the narrow one 626 half-size ones: 54.8 -> 52.2, 36.0 -> 32.8 / 35.5,
+// 48.3 -> 47.0 us (K = 544 / 288 / 512).  A small, consistent gain; beyond 256 columns the wide kernel wins by 25-40 %.
+#ifndef DGDM_IMG_NARROW_MAX
+#define DGDM_IMG_NARROW_MAX 256
+#endif
 constexpr int NTW = 4;    // 32-column tiles per wave (128 columns)
 constexpr int CPS = 2;    // 32-k chunks per LDS stage (64 k); images are padded to whole stages
 
@@ -550,12 +557,13 @@ int launch_img(hipStream_t s, const float* A, int64_t lda, int M, int K, const c
 
 extern "C" size_t dgdm_gemm_image_bytes(int32_t cols, int32_t k) {
   if (cols <= 0 || k <= 0) return 0;
-  return (size_t)IMG_HDR + (size_t)((cols + 31) / 32) * (2 * ((k + 63) / 64)) * BLK;
+  return (size_t)IMG_HDR + (size_t)(((int64_t)cols + 31) / 32) * (size_t)(2 * (((int64_t)k + 63) / 64)) * BLK;
 }
 
 extern "C" int32_t dgdm_gemm_image_blocks(int32_t cols, int32_t k) {
   if (cols <= 0 || k <= 0) return 0;
-  return ((cols + 31) / 32) * (2 * ((k + 63) / 64));
+  const int64_t blocks = (((int64_t)cols + 31) / 32) * (2 * (((int64_t)k + 63) / 64));
+  return blocks > 0x7fffffff ? 0 : (int32_t)blocks;       // an image that large cannot be built (0 = "none", as for empty shapes)
 }
 
 extern "C" int dgdm_gemm_image_build_many(const void* table, int32_t count, int32_t total_blocks, void* stream) {
@@ -594,7 +602,7 @@ extern "C" int dgdm_gemm_rows_img(const float* A, int64_t lda, int32_t M, int32_
   if (lda < K || ldc < ncols || tile_begin + (ncols + 31) / 32 > image_tiles) return DGDM_ERR_INVALID_ARG;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const char* img = static_cast<const char*>(image);
-  if (ncols <= 128)
+  if (ncols <= DGDM_IMG_NARROW_MAX)
     return launch_img<4, 1>(s, A, lda, M, K, img, image_tiles, tile_begin, ncols, bias, C, ldc, accumulate, amax_a);
   return launch_img8(s, A, lda, M, K, img, image_tiles, tile_begin, ncols, bias, C, ldc, accumulate, amax_a);
 }

@@ -370,7 +370,7 @@ extern "C" size_t dgdm_knn_gram_workspace_bytes(int32_t B, int32_t K) {
 extern "C" int dgdm_knn_gram(const float* G, int64_t ldg, const float* sq, int32_t N, int32_t q0, int32_t B, int32_t K, int32_t* idx,
                              float* sim, void* workspace, size_t workspace_bytes, void* stream) {
   (void)workspace; (void)workspace_bytes;
-  if (N < 0 || B < 0 || q0 < 0 || K < 1 || q0 + B > N) return DGDM_ERR_INVALID_ARG;
+  if (N < 0 || B < 0 || q0 < 0 || K < 1 || (int64_t)q0 + B > N) return DGDM_ERR_INVALID_ARG;
   if (B == 0) return DGDM_OK;
   if (!G || !sq || !idx || !sim || ldg < N) return DGDM_ERR_INVALID_ARG;
   if (K > N) return DGDM_ERR_INVALID_ARG;
@@ -393,7 +393,9 @@ extern "C" int dgdm_pair_cosine(const float* X, int64_t ldx, const float* sq, co
 
 extern "C" size_t dgdm_edge_dedup_workspace_bytes(int32_t N, int32_t Ks1, int32_t Km1) {
   if (N <= 0 || Ks1 < 1 || Km1 < 1) return 0;
-  const int64_t L = (int64_t)N * ((Ks1 - 1) + (Km1 - 1));
+  const int64_t per = ((int64_t)Ks1 - 1) + ((int64_t)Km1 - 1);     // candidate pairs per node
+  if (per > ((int64_t)1 << 24)) return 0;                           // not a neighbour table any more (and N * per must fit 64 bits)
+  const int64_t L = (int64_t)N * per;
   return L > 0 ? dedup_layout(L).bytes : 16;
 }
 
@@ -404,7 +406,8 @@ extern "C" int dgdm_edge_dedup_count(const int32_t* sidx, const float* sdist, in
   if (N < 0 || Ks1 < 1 || Km1 < 1 || !n_edges) return DGDM_ERR_INVALID_ARG;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int ks = Ks1 - 1, km = Km1 - 1;
-  const int64_t L = (int64_t)N * (ks + km);
+  if ((int64_t)ks + km > ((int64_t)1 << 24)) return DGDM_ERR_UNSUPPORTED;      // N * (ks + km) must fit 64 bits
+  const int64_t L = (int64_t)N * ((int64_t)ks + km);
   if (L == 0) { dgdm_fill_async(n_edges, 0, sizeof(int64_t), s); return dgdm_launch_status(); }
   if (!sidx || !sdist || !midx || !msim || !workspace) return DGDM_ERR_INVALID_ARG;
   if (L >= 0x7fffffffLL) return DGDM_ERR_UNSUPPORTED;
@@ -435,7 +438,9 @@ extern "C" int dgdm_edge_emit(const int32_t* sidx, const float* sdist, int32_t K
   if (U == 0) return DGDM_OK;
   if (!sidx || !sdist || !midx || !msim || !workspace || !edge_index || !edge_attr || !edge_type) return DGDM_ERR_INVALID_ARG;
   const int ks = Ks1 - 1, km = Km1 - 1;
-  const int64_t L = (int64_t)N * (ks + km);
+  if ((int64_t)ks + km > ((int64_t)1 << 24)) return DGDM_ERR_UNSUPPORTED;
+  const int64_t L = (int64_t)N * ((int64_t)ks + km);
+  if (L >= 0x7fffffffLL) return DGDM_ERR_UNSUPPORTED;                          // as dgdm_edge_dedup_count refuses it
   const DedupLayout l = dedup_layout(L);
   const char* w = static_cast<const char*>(workspace);
   hipLaunchKernelGGL(k_edge_emit, dim3(l.nb), dim3(256), 0, static_cast<hipStream_t>(stream),

@@ -491,7 +491,7 @@ extern "C" int dgdm_pool_score_fwd(const float* h, int64_t ldh, const float* w2,
 
 extern "C" size_t dgdm_pool_score_bwd_workspace_bytes(int32_t N, int32_t C) {
   if (N <= 0 || C <= 0) return 0;
-  return (size_t)(SCORE_BWD_BLOCKS + 16) * (C + 1) * sizeof(double);
+  return (size_t)(SCORE_BWD_BLOCKS + 16) * ((size_t)C + 1) * sizeof(double);
 }
 
 extern "C" int dgdm_pool_score_bwd(const float* h, int64_t ldh, const float* w2, const float* s, const float* ds, int32_t N, int32_t C,

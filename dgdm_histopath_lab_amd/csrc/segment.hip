@@ -311,11 +311,11 @@ extern "C" int dgdm_segment_sum(const float* x, const int32_t* ptr, int32_t B, i
     default: return DGDM_ERR_UNSUPPORTED;                                                                        \
   }
 
-static int pool_chunks(int32_t max_rows) { return max_rows <= 0 ? 1 : (max_rows + POOL_ROWS - 1) / POOL_ROWS; }
+static int pool_chunks(int32_t max_rows) { return max_rows <= 0 ? 1 : (int)(((int64_t)max_rows + POOL_ROWS - 1) / POOL_ROWS); }
 
 extern "C" size_t dgdm_attn_pool_fwd_workspace_bytes(int32_t B, int32_t H, int32_t D, int32_t max_rows) {
   if (B <= 0 || H <= 0 || D <= 0) return 0;
-  return (size_t)B * H * pool_chunks(max_rows) * (D + 2) * sizeof(float);
+  return (size_t)B * H * pool_chunks(max_rows) * ((size_t)D + 2) * sizeof(float);
 }
 
 // max_rows: number of nodes of the largest graph of the batch (the caller knows the offsets on the host)

@@ -705,3 +705,50 @@ def test_generate_embeddings_and_direct_diffusion_loss_match_the_oracle():
     a = float(m._compute_diffusion_loss(hd.detach(), dev_batch)["diffusion_loss"])
     b = float(m._compute_diffusion_loss(hd.detach(), dev_batch)["diffusion_loss"])
     assert np.isfinite(a) and np.isfinite(b) and a != b
+
+
+def test_unet_step_that_took_its_own_decisions_matches_the_oracle_under_those_decisions():
+    """every other U-Net gradient test differentiates under the CHECKER's ReLU / top-k decisions (handed to the
+    kernels).  Here the direction is reversed: the HIP model runs one pretrain step end to end with NOTHING injected -- its own
+    ReLU sides, its own top-k selections -- and the float64 oracle is then told those decisions (oracle.DECISIONS: which elements
+    passed each ReLU, which nodes each pooling level kept).  Loss, embeddings and every live gradient of the kernels' own run at
+    the 1e-3 contract; the oracle, left to itself, must disagree with those decisions only inside the rounding margin."""
+    from dgdm_histopath_lab_amd.synthetic import synthetic_batch
+    cfgd = dict(node_features=768, hidden_dims=[512, 256, 128], num_diffusion_steps=10, attention_heads=8)
+    cfg = O.OracleConfig(**cfgd)
+    P = O.init_params(cfg, seed=3, perturb=0.05)
+    batch = synthetic_batch(7, 2, 2000, 8000)
+    gen = torch.Generator().manual_seed(23)
+    n = batch.x.size(0)
+    rng = dict(timesteps=torch.tensor([4, 8]), noise=torch.randn(n, 128, generator=gen), noise_target=torch.randn(n, 128, generator=gen))
+    mask_idx, mask_tok = torch.randperm(n, generator=gen)[: int(n * 0.15)], torch.randn(768, generator=gen)
+    m = _model(cfgd, P)
+    own = {}
+    out = m.pretrain_step(batch.to(DEV), mask_indices=mask_idx.to(DEV), mask_token=mask_tok.to(DEV), trace=own,
+                          **{k: v.to(DEV) for k, v in rng.items()})          # no `decisions=`: the kernels decide
+    out["total_pretrain_loss"].backward()
+    dec = {}
+    for k, v in own.items():
+        if k.startswith("pre."):
+            dec["relu." + k[4:]] = (v.detach() > 0).cpu()
+        elif k.startswith("own_perm"):
+            dec["perm" + k[8:]] = v.detach().cpu()
+    assert sorted(dec) == sorted([f"relu.down{i}" for i in range(3)] + [f"relu.pool{i}" for i in range(3)] + [f"relu.up{i}" for i in range(3)] +
+                                 ["relu.bottom"] + [f"perm{i}" for i in range(3)])
+    torch.set_num_threads(32)
+    b64 = types.SimpleNamespace(x=batch.x.double(), edge_index=batch.edge_index, edge_attr=batch.edge_attr.double(), pos=batch.pos.double(),
+                                batch=batch.batch)
+    kw = dict(mask_indices=mask_idx, mask_token=mask_tok.double(), **{k: (v.double() if v.is_floating_point() else v) for k, v in rng.items()})
+    O.DECISIONS = dec
+    try:
+        ref, gref = O.loss_and_grads({k: v.double() for k, v in P.items()}, cfg, b64, **kw)
+    finally:
+        O.DECISIONS = None
+    for k in ("diffusion_loss", "graph_embedding", "noisy_embeddings"):
+        assert_close(out[k], ref[k], TOL, k)
+    assert _assert_all_grads(m, gref, TOL) >= 170
+    # the oracle's own decisions (no injection) against the kernels' pre-activations and scores: differences only within the margin
+    free = {}
+    O.loss_and_grads({k: v.double() for k, v in P.items()}, cfg, b64, trace=free, **kw)
+    flips, total = check_decision_margins(own, decisions_from_trace(free))
+    print(f"decisions differing between the kernels' own run and the float64 run: {flips} of {total}")
