@@ -39,6 +39,7 @@ def _hipcc() -> str:
 # -fno-honor-nans: fmaxf on MFMA results otherwise gets a canonicalising v_max_f32 x, x per operand (masked scores are -1e30, never
 # NaN or inf).
 EXTRA_FLAGS = {"attn_h_bwd.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-fno-honor-nans"],
+               "attn_h_bwd_fused.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-fno-honor-nans"],
                "attn_h_fwd.hip": ["-fno-honor-nans"]}
 
 

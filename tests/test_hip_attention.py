@@ -277,3 +277,84 @@ def test_attn_backward_on_sharp_rows_matches_dense(kind, max_entropy, impl):
             assert_close(d.grad[:, C:2 * C], gk, tol, "dK"), assert_close(d.grad[:, 2 * C:], gv, tol, "dV")]
     print(f"{impl} {kind}: row entropy {ent:.2f} nats; rel-L2 O %.1e dQ %.1e dK %.1e dV %.1e; max-abs %.1e %.1e %.1e %.1e" %
           (tuple(e[1] for e in errs) + tuple(e[0] for e in errs)))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# One-pass backward (csrc/attn_h_bwd_fused.hip): dQ, dK and dV from the key-stationary pass + a fixed-order reduction of partial dQ tiles
+@pytest.fixture
+def fused_backward(monkeypatch):
+    from dgdm_histopath_lab_amd import ops
+    monkeypatch.setattr(ops, "ATTN_BWD_FUSED", True)
+    return ops
+
+
+@pytest.mark.parametrize("ptr,H,gscale", [([0, 17], 8, 1.0), ([0, 65, 130, 131], 8, 1.0), ([0, 200, 263], 2, 1.0), ([0, 333, 1000], 8, 1.0),
+                                           ([0, 129, 500], 16, 1.0), ([0, 333, 1000], 8, 1e-7), ([0, 64, 128, 1100, 1101], 4, 3e4)])
+def test_attn_fused_backward_matches_dense(fused_backward, ptr, H, gscale):
+    """Same cases and tolerances as test_attn_split_fp16_backward_matches_dense, through the one-pass backward: all three gradients
+    against the dense float64 reference, bitwise repeatable, and dK / dV BIT-IDENTICAL to the two-pass kernels' (the key-stationary
+    arithmetic is the same; only dQ is summed in another order)."""
+    ops = fused_backward
+    qkv, pos = make(ptr, H, 7 * sum(ptr) + H)
+    C = H * 16
+    g = torch.Generator().manual_seed(2)
+    gout = torch.randn(ptr[-1], C, generator=g) * gscale
+    plan = ops.AttnPlan(ptr, DEV)
+    d = qkv.to(DEV).requires_grad_(True)
+    o = ops._SpatialAttentionH.apply(d, pos.to(DEV), plan, H, 0.25, 1.0, 0.0, 0)
+    o.backward(gout.to(DEV))
+    ro, gq, gk, gv = dense_reference(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], pos, ptr, H, 1.0, gout)
+    errs = [assert_close(d.grad[:, :C], gq, 5e-4, "dQ"), assert_close(d.grad[:, C:2 * C], gk, 5e-4, "dK"), assert_close(d.grad[:, 2 * C:], gv, 5e-4, "dV")]
+    print("one-pass bwd rel-L2: dQ %.1e dK %.1e dV %.1e" % tuple(e[1] for e in errs))
+    d2 = qkv.to(DEV).requires_grad_(True)
+    ops._SpatialAttentionH.apply(d2, pos.to(DEV), plan, H, 0.25, 1.0, 0.0, 0).backward(gout.to(DEV))
+    assert torch.equal(d.grad, d2.grad)                                  # fixed-order reduction: bitwise repeatable
+    ops.ATTN_BWD_FUSED = False
+    d3 = qkv.to(DEV).requires_grad_(True)
+    ops._SpatialAttentionH.apply(d3, pos.to(DEV), plan, H, 0.25, 1.0, 0.0, 0).backward(gout.to(DEV))
+    assert torch.equal(d.grad[:, C:], d3.grad[:, C:])                    # dK, dV: the same arithmetic as k_attn_h_bwd_dkv
+    assert_close(d.grad[:, :C], d3.grad[:, :C].double(), 2e-5, "dQ one-pass vs two-pass")
+
+
+def test_attn_fused_backward_with_dropout_and_scratch_groups(fused_backward, monkeypatch):
+    """Dropout on: the one-pass backward regenerates the forward's mask (dK / dV bit-identical to the two-pass kernels, dQ equal up to
+    summation order, everything against the two-pass result that test_attn_dropout_mask_consistent... holds to the dense formula).
+    Then the same backward with a scratch budget so small that the key blocks are cut into many groups, some in the middle of a
+    graph: dQ accumulates group after group and must agree with the one-group result up to fp32 summation order."""
+    ops = fused_backward
+    ptr, H, p, seed = [0, 333, 1000, 1400, 1401], 8, 0.25, 424242
+    C = H * 16
+    qkv, pos = make(ptr, H, 31)
+    g = torch.Generator().manual_seed(9)
+    gout = torch.randn(ptr[-1], C, generator=g)
+    plan = ops.AttnPlan(ptr, DEV)
+
+    def grads():
+        d = qkv.to(DEV).requires_grad_(True)
+        ops._SpatialAttentionH.apply(d, pos.to(DEV), plan, H, 0.25, 1.0, p, seed).backward(gout.to(DEV))
+        return d.grad
+    one = grads()
+    monkeypatch.setattr(ops, "ATTN_BWD_FUSED_BUDGET", 3 * 11 * H * 4096)          # ~3 key blocks of the 11-block graph per launch
+    many = grads()
+    monkeypatch.setattr(ops, "ATTN_BWD_FUSED", False)
+    two = grads()
+    assert torch.equal(one[:, C:], two[:, C:]) and torch.equal(many[:, C:], two[:, C:])
+    assert_close(one[:, :C], two[:, :C].double(), 2e-5, "dQ one-pass vs two-pass (dropout)")
+    assert_close(many[:, :C], one[:, :C].double(), 2e-6, "dQ in many scratch groups vs one")
+
+
+@pytest.mark.parametrize("kind,max_entropy", [("x16", 0.5), ("dominant", 0.5), ("shifted", 2.5)])
+def test_attn_fused_backward_on_sharp_rows_matches_dense(fused_backward, kind, max_entropy):
+    ops = fused_backward
+    ptr, H = [0, 700, 1500], 8
+    C = H * 16
+    qkv, pos = _sharp_case(kind, ptr, H, 3)
+    assert _row_entropy(qkv, pos, ptr, H) < max_entropy
+    g = torch.Generator().manual_seed(4)
+    gout = torch.randn(ptr[-1], C, generator=g)
+    d = qkv.to(DEV).requires_grad_(True)
+    plan = ops.AttnPlan(ptr, DEV)
+    ops._SpatialAttentionH.apply(d, pos.to(DEV), plan, H, 0.25, 1.0, 0.0, 0).backward(gout.to(DEV))
+    ro, gq, gk, gv = dense_reference(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], pos, ptr, H, 1.0, gout)
+    for name, a, b in (("dQ", d.grad[:, :C], gq), ("dK", d.grad[:, C:2 * C], gk), ("dV", d.grad[:, 2 * C:], gv)):
+        assert_close(a, b, 1e-4, name)

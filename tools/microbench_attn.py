@@ -42,6 +42,15 @@ for p in (0.0, 0.1):
         for k, (cnt, ms) in ops.TIMERS.summary().items():
             prod = 3 if k.endswith("dq") else 4
             print(json.dumps(dict(kernel=k + " split-fp16", variant=var, drop=p, ms=round(ms, 3), TF=round(prod * fl / ms / 1e9, 1))))
+    # the one-pass backward (csrc/attn_h_bwd_fused.hip): dQ + dK + dV in one key-stationary launch + the partial-tile reduction
+    ops.ATTN_BWD_FUSED = True
+    ops.TIMERS.start()
+    for _ in range(6):
+        ops.spatial_attn_h_bwd_raw(pk, outh, gout, plan, H, 0.25, 1.0, lse2_b, dq2, p, 123)
+    torch.cuda.synchronize(); ops.TIMERS.stop()
+    ops.ATTN_BWD_FUSED = False
+    for k, (cnt, ms) in ops.TIMERS.summary().items():
+        print(json.dumps(dict(kernel=k + " (one pass: dQ + dK + dV + reduction)", drop=p, ms=round(ms, 3), TF=round(7 * fl / ms / 1e9, 1))))
     if os.environ.get("SPLIT_ONLY"): continue
     out, lse2 = ops.spatial_attn_fwd_raw(qkv[:, :C], qkv[:, C:2*C], qkv[:, 2*C:], pos, plan, H, 0.25, 1.0, 0, p, 123)
     dqkv = torch.empty_like(qkv)
