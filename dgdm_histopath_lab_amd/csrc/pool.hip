@@ -100,14 +100,23 @@ __global__ __launch_bounds__(256) void k_pool_score_bwd(const float* __restrict_
   }
 }
 
-// column sums of the float64 block partials, fixed order, rounded to fp32 once: columns [0, C) -> dw2, column C -> db2
+// column sums of the float64 block partials, rounded to fp32 once: columns [0, C) -> dw2, column C -> db2.  One workgroup per column,
+// one partial per thread (nb <= SCORE_BWD_BLOCKS = 256), a pairwise tree in LDS: the association is fixed by the thread index, so
+// the sum is bitwise repeatable.  (A first version looped over the partials in one thread per column: 62 us of load latency.)
 __global__ __launch_bounds__(256) void k_pool_score_bwd_final(const double* __restrict__ partial, int nb, int C, float* __restrict__ dw2,
                                                               float* __restrict__ db2) {
-  const int col = blockIdx.x * 256 + threadIdx.x;
-  if (col > C) return;
-  double t = 0.;
-  for (int b = 0; b < nb; ++b) t += partial[(int64_t)b * (C + 1) + col];
-  if (col < C) dw2[col] = (float)t; else db2[0] = (float)t;
+  __shared__ double sm[256];
+  const int col = blockIdx.x, t = threadIdx.x;
+  sm[t] = t < nb ? partial[(int64_t)t * (C + 1) + col] : 0.;
+  __syncthreads();
+#pragma unroll
+  for (int o = 128; o > 0; o >>= 1) {
+    if (t < o) sm[t] += sm[t + o];
+    __syncthreads();
+  }
+  if (t == 0) {
+    if (col < C) dw2[col] = (float)sm[0]; else db2[0] = (float)sm[0];
+  }
 }
 
 constexpr int SCORE_BWD_BLOCKS = 256;
@@ -513,7 +522,7 @@ extern "C" int dgdm_pool_score_bwd(const float* h, int64_t ldh, const float* w2,
   double* partial = static_cast<double*>(workspace);       // torch allocations are 256-byte aligned; checked below
   if (reinterpret_cast<uintptr_t>(workspace) & 7) return DGDM_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(k_pool_score_bwd, dim3(nb), dim3(256), 0, st, h, ldh, w2, s, ds, N, C, rpb, dh, lddh, partial, decide, nonlinearity);
-  hipLaunchKernelGGL(k_pool_score_bwd_final, dim3((C + 1 + 255) / 256), dim3(256), 0, st, partial, nb, C, dw2, db2);
+  hipLaunchKernelGGL(k_pool_score_bwd_final, dim3(C + 1), dim3(256), 0, st, partial, nb, C, dw2, db2);
   return dgdm_launch_status();
 }
 
