@@ -445,7 +445,7 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    timed = ["attn_fwd", "attn_bwd_dq", "attn_bwd_dkv", "spmm_c512"]
+    timed = ["attn_fwd", "attn_bwd_dq", "attn_bwd_dkv", "attn_bwd_fused", "attn_bwd_dq_reduce", "spmm_c512"]
     graphed = step is not eager_step
     if not graphed:
         ops.TIMERS.start(timed)
@@ -525,15 +525,21 @@ def main():
     if rank == 0:
         timers = strict.pop("_main_timers") if strict is not None else ops.TIMERS.summary()
         heads, hd = cfg["attention_heads"], 16
+        # products of 2 N^2 H d FLOP each: forward S, PV; two-pass backward dQ: S, dP, dS K / dK,dV: S, dP, P^T dO, dS^T Q; one-pass
+        # backward (default): S, dP, P^T dO, dS^T Q, dS K -- each score evaluated once
         flops = {"attn_fwd": attention_flops(sizes, heads, hd, 2), "attn_bwd_dq": attention_flops(sizes, heads, hd, 3),
-                 "attn_bwd_dkv": attention_flops(sizes, heads, hd, 4)}
+                 "attn_bwd_dkv": attention_flops(sizes, heads, hd, 4), "attn_bwd_fused": attention_flops(sizes, heads, hd, 5)}
         split = ops.ATTN_PRECISION == "fp16x2"
-        k16 = {"attn_fwd": "k_attn_h_fwd<4,1,1,3>", "attn_bwd_dq": "k_attn_h_bwd_dq<4,1,1,1>", "attn_bwd_dkv": "k_attn_h_bwd_dkv<2,1,1,3>"}
+        k16 = {"attn_fwd": "k_attn_h_fwd<4,1,1,3>", "attn_bwd_dq": "k_attn_h_bwd_dq<4,1,1,1>", "attn_bwd_dkv": "k_attn_h_bwd_dkv<2,1,1,3>",
+               "attn_bwd_fused": f"k_attn_h_bwd_fused<{0 if args.eval_mode else 1},2>"}
         dr = "false" if args.eval_mode else "true"
-        k32 = {"attn_fwd": f"k_attn_fwd<4,64,{dr}>", "attn_bwd_dq": f"k_attn_bwd_dq<4,64,{dr}>", "attn_bwd_dkv": f"k_attn_bwd_dkv<4,32,{dr}>"}
+        k32 = {"attn_fwd": f"k_attn_fwd<4,64,{dr}>", "attn_bwd_dq": f"k_attn_bwd_dq<4,64,{dr}>", "attn_bwd_dkv": f"k_attn_bwd_dkv<4,32,{dr}>",
+               "attn_bwd_fused": "(fp32 path has no one-pass backward)"}
         # MFMAs the split-fp16 kernels issue per algorithmic product: Q'K and dO V as [hi|lo].[hi|hi] + [hi|lo].[lo|lo] (2 instructions
         # of twice the reduction length: 4x the FLOP), P V / P^T dO / dS^T Q / dS K as hi.hi + lo.hi + hi.lo (3x), ones.P twice (forward)
-        issued_x = {"attn_fwd": (4 + 3 + 2 * 1.0) / 2, "attn_bwd_dq": (4 + 4 + 3) / 3, "attn_bwd_dkv": (4 + 4 + 3 + 3) / 4}
+        # ... the one-pass backward's dS K as two MFMAs whose 32 reduction slots hold 16 keys x {hi, lo} (4x the FLOP of a 16-deep product)
+        issued_x = {"attn_fwd": (4 + 3 + 2 * 1.0) / 2, "attn_bwd_dq": (4 + 4 + 3) / 3, "attn_bwd_dkv": (4 + 4 + 3 + 3) / 4,
+                    "attn_bwd_fused": (4 + 4 + 3 + 3 + 4) / 5}
 
         def attention_roofline(tm, names, fp16_pipe, graphed_note, valu_path=None, traffic_path=None):
             dom = max((k for k in flops if k in tm), key=lambda k: tm[k][1]) if any(k in tm for k in flops) else None
@@ -549,6 +555,8 @@ def main():
                     "algorithmic_flop": flops[dom]}
             if fp16_pipe:
                 mfma.update({"mfma_dtype": "every operand (Q', K, V, dO, P, dS) as fp16 hi+lo, fp32 accumulate",
+                             "products": {"attn_fwd": "S, PV", "attn_bwd_dq": "S, dP, dS K", "attn_bwd_dkv": "S, dP, P^T dO, dS^T Q",
+                                          "attn_bwd_fused": "S, dP, P^T dO, dS^T Q, dS K (one pass: dQ, dK, dV)"}[dom],
                              "issued_tflops": round(issued_x[dom] * tf, 1), "issued_frac": round(issued_x[dom] * tf / peak, 4),
                              "fp32_equivalent_frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4)})
             tpath = traffic_path or (PMC_TRAFFIC_LARGE if args.large else PMC_TRAFFIC)

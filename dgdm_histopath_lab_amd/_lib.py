@@ -129,9 +129,11 @@ SIGNATURES = {
                                              C.c_uint32, _p, _p, _i64, _i32, _p]),
     "dgdm_spatial_attn_h_bwd_dkv": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, C.c_float,
                                               C.c_uint32, _p, _p, _p, _i64, _i32, _p]),
+    "dgdm_spatial_attn_h_bwd_fused_superblocks": (_i32, [_p, _i32]),
     "dgdm_spatial_attn_h_bwd_fused_workspace_bytes": (_sz, [_p, _i32, _i32, _i32, _i32]),
-    "dgdm_spatial_attn_h_bwd_fused": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, C.c_float, C.c_float, C.c_uint32,
-                                                _p, _p, _p, _p, _i64, _i32, _i32, _p, _sz, _p]),
+    "dgdm_spatial_attn_h_bwd_fused": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, C.c_float, C.c_uint32,
+                                                _p, _p, _p, _i64, _i32, _i32, _p, _sz, _p]),
+    "dgdm_spatial_attn_h_bwd_fused_reduce": (C.c_int, [_p, _p, _i32, _i32, _i32, C.c_float, _p, _p, _i64, _i32, _i32, _p, _sz, _p]),
     "dgdm_gemm_image_bytes": (_sz, [_i32, _i32]),
     "dgdm_gemm_image_blocks": (_i32, [_i32, _i32]),
     "dgdm_gemm_image_build_many": (C.c_int, [_p, _i32, _i32, _p]),

@@ -55,56 +55,72 @@ __device__ __forceinline__ f16x4 tr4_image(const _Float16* __restrict__ rimg_hea
 }
 __device__ __forceinline__ f16x8 cat4(f16x4 a, f16x4 b) { return f16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}; }
 
-// find_block plus the graph's first PAIR slot: slots number the (key block, query block) pairs of all graphs, graph by graph, key
-// block major: slot(kb, qb) = pair0(graph) + (kb - blk0) * nbg + qb.  One 64 x 16 fp32 tile per (slot, head).
-__device__ __forceinline__ bool find_block_pairs(const int32_t* __restrict__ ptr, int B, int blk, int* n0, int* ng, int* lblk, int* blk0,
-                                                 int64_t* pair0) {
-  int base = 0;
+// Key SUPER-blocks: 4 consecutive 64-key blocks of ONE graph (the last super-block of a graph may hold fewer); super-blocks are
+// numbered graph by graph.  One partial dQ tile (64 x 16 fp32 per head) exists per (super-block, query block of its graph):
+// slot(sb, qb) = spair0(graph) + (sb - sb0(graph)) * nbg + qb.
+constexpr int KT = 4;                 // key tiles of 16 per wave = one 64-key block per wave; 4 waves = 256 keys per workgroup
+__device__ __forceinline__ bool find_sblock(const int32_t* __restrict__ ptr, int B, int sb, int* n0, int* ng, int* sbl, int* blk0,
+                                            int* sb0, int64_t* spair0) {
+  int base = 0, sbase = 0;
   int64_t pairs = 0;
   for (int g = 0; g < B; ++g) {
     const int a = ptr[g], b = ptr[g + 1];
-    const int nb = (b - a + HB - 1) / HB;
-    if (blk < base + nb) { *n0 = a; *ng = b - a; *lblk = blk - base; *blk0 = base; *pair0 = pairs; return true; }
-    base += nb;
-    pairs += (int64_t)nb * nb;
+    const int nb = (b - a + HB - 1) / HB, nsb = (nb + 3) >> 2;
+    if (sb < sbase + nsb) { *n0 = a; *ng = b - a; *sbl = sb - sbase; *blk0 = base; *sb0 = sbase; *spair0 = pairs; return true; }
+    base += nb; sbase += nsb;
+    pairs += (int64_t)nsb * nb;
+  }
+  return false;
+}
+// the same lookup by packed (64-row) block: used by the reduction, whose workgroups are query blocks
+__device__ __forceinline__ bool find_block_s(const int32_t* __restrict__ ptr, int B, int blk, int* n0, int* ng, int* lblk, int* sb0,
+                                             int64_t* spair0) {
+  int base = 0, sbase = 0;
+  int64_t pairs = 0;
+  for (int g = 0; g < B; ++g) {
+    const int a = ptr[g], b = ptr[g + 1];
+    const int nb = (b - a + HB - 1) / HB, nsb = (nb + 3) >> 2;
+    if (blk < base + nb) { *n0 = a; *ng = b - a; *lblk = blk - base; *sb0 = sbase; *spair0 = pairs; return true; }
+    base += nb; sbase += nsb;
+    pairs += (int64_t)nsb * nb;
   }
   return false;
 }
 
-// LDS: stage buffer (Rq | Rg | 8 - lse2 | -delta | pos, as k_attn_h_bwd_dkv) | T (4 waves) | X[HG][4 waves][64 q][16 d] fp32
-template <int HG, bool DROP, int WPE = 1>
+// One head per workgroup, wave w = key block 4 sb + w of the graph (64 keys = KT key tiles, processed one after the other against
+// the staged query block).  LDS: stage buffer (Rq | Rg | 8 - lse2 | -delta | pos of ONE head) | the four waves' own K row images |
+// T (4 waves) | X[4 waves][64 q][16 d] fp32.
+template <bool DROP, int WPE = 1>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) void k_attn_h_bwd_fused(
     const _Float16* __restrict__ Rq, const _Float16* __restrict__ Rk, const _Float16* __restrict__ Rv, const _Float16* __restrict__ Rg,
     const float* __restrict__ pos_b, const float* __restrict__ lse_b, const float* __restrict__ ndelta_b, int H,
     const int32_t* __restrict__ ptr, int B, float kscale, const float* __restrict__ unscale_dev, float* __restrict__ dK,
-    float* __restrict__ dV, int64_t ldg, float* __restrict__ dq_part, int kb_first, int kb_count, int64_t slot_first, float drop_p,
+    float* __restrict__ dV, int64_t ldg, float* __restrict__ dq_part, int sb_first, int sb_count, int64_t slot_first, float drop_p,
     DgdmSeed seed_in) {
   const uint32_t seed = seed_in.value();
   constexpr int NT = HB / 16;
-  constexpr int R_BYTES = HG * R_HEAD * 2, SC_BYTES = HG * HB * 4, POS_BYTES = HB * 8;
+  constexpr int R_BYTES = R_HEAD * 2, SC_BYTES = HB * 4, POS_BYTES = HB * 8;
   constexpr int BUF_BYTES = 2 * R_BYTES + 2 * SC_BYTES + POS_BYTES;
-  constexpr int T_BYTES = 4 * T_WAVE * 2;
-  constexpr int X_BYTES = HG * 4 * HB * 16 * 4;
-  __shared__ __attribute__((aligned(16))) char smem[BUF_BYTES + T_BYTES + X_BYTES];
+  constexpr int KOWN_BYTES = 4 * R_BYTES;
+  constexpr int T_BYTES = 2 * 4 * T_WAVE * 2;      // two tiles per wave: the dQ product of key tile kt runs under the score phase of kt + 1
+  constexpr int X_BYTES = 4 * HB * 16 * 4;
+  __shared__ __attribute__((aligned(16))) char smem[BUF_BYTES + KOWN_BYTES + T_BYTES + X_BYTES];
   const DropCfg dc(drop_p);
 
-  // blockIdx.x counts the key blocks of this launch's group: global packed block = kb_first + blockIdx.x
-  int n0, ng, lblk, blk0;
-  int64_t pair0;
-  if ((int)blockIdx.x >= kb_count || !find_block_pairs(ptr, B, kb_first + blockIdx.x, &n0, &ng, &lblk, &blk0, &pair0)) return;
-  const int blk = kb_first + blockIdx.x;
+  int n0, ng, sbl, blk0, sb0;
+  int64_t spair0;
+  if ((int)blockIdx.x >= sb_count || !find_sblock(ptr, B, sb_first + blockIdx.x, &n0, &ng, &sbl, &blk0, &sb0, &spair0)) return;
   const int nbg = (ng + HB - 1) / HB;
-  const int head0 = blockIdx.y * HG;
+  const int head = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, G = lane >> 4;
-  const int k_in_blk = wave * 16 + j;
-  const int k_local = lblk * HB + k_in_blk;
-  const bool k_ok = k_local < ng;
-  const bool pad_blk = (lblk + 1) * HB > ng;       // block-uniform: this key block runs past the end of its graph
+  const int lblk_w = 4 * sbl + wave;                       // this wave's key block inside the graph ...
+  const bool blk_ok = lblk_w < nbg;                        // ... which the graph's last super-block may not have
+  const int lblk = blk_ok ? lblk_w : nbg - 1;              // (such a wave runs on the last block with every key masked: it takes part
+  const int blk = blk0 + lblk;                             //  in the barriers and the cross-wave stage, contributes zeros, stores nothing)
 
-  auto stage = [&](int qb, int buf) {
-    (void)buf;
-    const int64_t gb = (int64_t)(blk0 + qb) * H + head0;
+  auto stage = [&](int qb) {
+    const int64_t gb = (int64_t)(blk0 + qb) * H + head;
     char* base = smem;
     dma_to_lds<R_BYTES>(Rq + gb * R_HEAD, base, tid);
     dma_to_lds<R_BYTES>(Rg + gb * R_HEAD, base + R_BYTES, tid);
@@ -112,44 +128,49 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
     dma_to_lds<SC_BYTES>(ndelta_b + gb * HB, base + 2 * R_BYTES + SC_BYTES, tid);
     dma_to_lds<POS_BYTES>(pos_b + (int64_t)(blk0 + qb) * HB * 2, base + 2 * R_BYTES + 2 * SC_BYTES, tid);
   };
-  _Float16* Tw = reinterpret_cast<_Float16*>(smem + BUF_BYTES) + wave * T_WAVE;
-  float* X = reinterpret_cast<float*>(smem + BUF_BYTES + T_BYTES);
+  const _Float16* Kown = reinterpret_cast<const _Float16*>(smem + BUF_BYTES) + wave * R_HEAD;      // this wave's K row image (64 keys)
+  _Float16* Tw0 = reinterpret_cast<_Float16*>(smem + BUF_BYTES + KOWN_BYTES) + wave * 2 * T_WAVE;
+  float* X = reinterpret_cast<float*>(smem + BUF_BYTES + KOWN_BYTES + T_BYTES);
 
-  // ---- the workgroup's own key block: K^T fragments of the dQ product (loop invariant), out of the K row image staged once
-  dma_to_lds<R_BYTES>(Rk + ((int64_t)blk * H + head0) * R_HEAD, smem, tid);
-  __syncthreads();
-  f16x8 ka1[HG], ka2[HG];
+  // the four waves' K images: each wave copies its own (4 KiB = 4 pieces of 1 KiB), then the first query block
   {
-    const _Float16 z = (_Float16)0.0f;
-    const f16x4 zero4 = {z, z, z, z};
+    const char* g = reinterpret_cast<const char*>(Rk + ((int64_t)blk * H + head) * R_HEAD);
+    char* l = smem + BUF_BYTES + wave * R_BYTES;
 #pragma unroll
-    for (int h = 0; h < HG; ++h) {
-      const _Float16* kr = reinterpret_cast<const _Float16*>(smem) + h * R_HEAD;
-      const f16x4 khi = tr4_image(kr, 0, wave, lane), klo = tr4_image(kr, 1, wave, lane);
-      ka1[h] = cat4(khi, khi);
-      ka2[h] = cat4(klo, zero4);
-    }
+    for (int p = 0; p < R_BYTES / 1024; ++p)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + p * 1024 + lane * 16),
+                                       (__attribute__((address_space(3))) void*)(l + p * 1024), 16, 0, 0);
   }
-  __syncthreads();
-  stage(0, 0);
+  stage(0);
 
-  f16x8 kb1[HG], kb2[HG], vb1[HG], vb2[HG];   // K and (keep *) V of the lane's key
-  f32x4 dk[HG], dv[HG];
-  DropLaneK dl[HG];
+  f16x8 vb1[KT], vb2[KT];                 // (keep *) V of the lane's key in key tile kt (K comes out of Kown at every use)
+  f32x4 dk[KT], dv[KT];
+  uint32_t dlF[KT];                       // dropout: folded hash of the lane's key pair per key tile; multipliers by key parity
+  uint32_t dl_me = 0, dl_mo = 0;
+  float px[KT], py[KT];
+  bool k_ok[KT];
 #pragma unroll
-  for (int h = 0; h < HG; ++h) {
-    const int64_t imgoff = ((int64_t)blk * H + head0 + h) * R_HEAD;
-    load_b_pair(Rk + imgoff, k_in_blk, G, &kb1[h], &kb2[h]);
-    load_b_pair(Rv + imgoff, k_in_blk, G, &vb1[h], &vb2[h]);
-    if (DROP) scale_b_pair(&vb1[h], &vb2[h], dc.keep);
-    dk[h] = f32x4{0.f, 0.f, 0.f, 0.f};
-    dv[h] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (DROP) dl[h] = DropLaneK(DropHead(seed, n0, head0 + h), k_local);
+  for (int kt = 0; kt < KT; ++kt) {
+    const int k_in_blk = 16 * kt + j;
+    const int k_local = lblk * HB + k_in_blk;
+    k_ok[kt] = blk_ok && k_local < ng;
+    const int64_t imgoff = ((int64_t)blk * H + head) * R_HEAD;
+    load_b_pair(Rv + imgoff, k_in_blk, G, &vb1[kt], &vb2[kt]);
+    if (DROP) scale_b_pair(&vb1[kt], &vb2[kt], dc.keep);
+    dk[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    dv[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (DROP) {
+      const DropLaneK d(DropHead(seed, n0, head), k_local);
+      dlF[kt] = d.F; dl_me = d.me; dl_mo = d.mo;      // 16 kt is even: the key parity (and with it me / mo) is the same for every kt
+    }
+    px[kt] = pos_b[((int64_t)blk * 2 + 0) * HB + k_in_blk];
+    py[kt] = pos_b[((int64_t)blk * 2 + 1) * HB + k_in_blk];
   }
   const uint32_t lcq = __umul24(2u * (uint32_t)G, DROP_CQ);
   const int aoff = r_lane_off(j, G);
-  const float px = pos_b[((int64_t)blk * 2 + 0) * HB + k_in_blk], py = pos_b[((int64_t)blk * 2 + 1) * HB + k_in_blk];
-  const int64_t slot0 = pair0 + (int64_t)lblk * nbg - slot_first;     // this key block's first slot inside the launch's scratch
+  const int64_t slot0 = spair0 + (int64_t)sbl * nbg - slot_first;     // this super-block's first slot inside the launch's scratch
+  const _Float16 zh = (_Float16)0.0f;
+  const f16x4 zero4 = {zh, zh, zh, zh};
   __syncthreads();
 
   for (int qb = 0; qb < nbg; ++qb) {
@@ -157,50 +178,72 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
     const _Float16* Qimg = reinterpret_cast<const _Float16*>(base);
     const _Float16* Gimg = reinterpret_cast<const _Float16*>(base + R_BYTES);
     const float* Ls = reinterpret_cast<const float*>(base + 2 * R_BYTES);
-    const float* Ds = Ls + HG * HB;
-    const float* Ps = Ds + HG * HB;
+    const float* Ds = Ls + HB;
+    const float* Ps = Ds + HB;
     const int qb0 = qb * HB;
+    const bool q_tail = qb0 + HB > ng;      // only the last query block of a graph has rows to mask
+    f32x4 dqp[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) dqp[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // lane (key=j, G), reg r <-> query 16t + 4G + r
-    f32x4 dist[NT];
+    // dQ^T[d][q] += K^T[d][key] dS'^T[key][q] over key tile kt: lane (q = j, G) supplies reduction slots = keys 4G .. 4G+3, hi | lo,
+    // read TRANSPOSED out of the tile the wave wrote during kt's score phase.  Called one key tile LATE (after the score phase of
+    // kt + 1 has been issued), so that the LDS round trip of the tile is not on the critical path.
+    auto dq_product = [&](int kt) {
+      if (DGDM_FUSED_SKIP & 4) return;
+      const _Float16* Tr = Tw0 + (kt & 1) * T_WAVE;
+      const f16x4 khi = tr4_image(Kown, 0, kt, lane), klo = tr4_image(Kown, 1, kt, lane);
+      const f16x8 ka1 = cat4(khi, khi), ka2 = cat4(klo, zero4);
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      dist[t] = dist4(&Ps[16 * t + 4 * G], &Ps[HB + 16 * t + 4 * G], px, py);
-    }
-    if (qb0 + HB > ng) {   // only the last query block of a graph has rows to mask: P' = 0, they contribute nothing
+      for (int t = 0; t < NT; ++t) {
+        const f16x8 b = cat4(tr4_tile(Tr, 16 * t, lane), tr4_tile(Tr + T_PART, 16 * t, lane));
+        dqp[t] = mfma_h(ka1, b, dqp[t]);
+        dqp[t] = mfma_h(ka2, b, dqp[t]);
+      }
+    };
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
+    for (int kt = 0; kt < KT; ++kt) {
+      _Float16* Tw = Tw0 + (kt & 1) * T_WAVE;
+      // lane (key = 16 kt + j, G), reg r <-> query 16t + 4G + r
+      f32x4 dist[NT];
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (qb0 + 16 * t + 4 * G + r >= ng) dist[t][r] = -NEG_BIG;
-    }
-    if (pad_blk) {         // the graph's last key block: lanes past the graph end hold zero K / V rows.  k_attn_h_bwd_dkv lets them run
-                           // (their dK / dV rows are never stored); here their dS' feeds dQ, and a row whose real scores are all far
-                           // below zero has P' = exp2(0 - lse2 + 8) = inf there (inf x K = 0 is NaN): P' = 0 for those lanes
+      for (int t = 0; t < NT; ++t) dist[t] = dist4(&Ps[16 * t + 4 * G], &Ps[HB + 16 * t + 4 * G], px[kt], py[kt]);
+      if (q_tail) {
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dist[t][r] = k_ok ? dist[t][r] : -NEG_BIG;
-    }
+          for (int r = 0; r < 4; ++r)
+            if (qb0 + 16 * t + 4 * G + r >= ng) dist[t][r] = -NEG_BIG;
+      }
+      // keys past the graph end (its last block; every key of a wave without a block): zero K / V rows.  Their dS' would feed dQ,
+      // and a row whose real scores are all far below zero has P' = exp2(0 - lse2 + 8) = inf there (inf x K = 0 is NaN): P' = 0
+      if (!__builtin_amdgcn_readfirstlane((int)__all(k_ok[kt]))) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dist[t][r] = k_ok[kt] ? dist[t][r] : -NEG_BIG;
+      }
+      f16x8 kb1, kb2;
+      load_b_pair(Kown, 16 * kt + j, G, &kb1, &kb2);
+      DropLaneK dl;
+      dl.F = dlF[kt]; dl.me = dl_me; dl.mo = dl_mo;
 
-#pragma unroll
-    for (int h = 0; h < HG; ++h) {
       f32x4 p[NT], ds[NT];
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        const f16x8 qa = *reinterpret_cast<const f16x8*>(Qimg + h * R_HEAD + t * 512 + aoff);
-        const f16x8 ga = *reinterpret_cast<const f16x8*>(Gimg + h * R_HEAD + t * 512 + aoff);
-        const f32x4 lq = *reinterpret_cast<const f32x4*>(&Ls[h * HB + 16 * t + 4 * G]);
-        const f32x4 nd = *reinterpret_cast<const f32x4*>(&Ds[h * HB + 16 * t + 4 * G]);
-        f32x4 s = mfma_h(qa, kb1[h], sub4(lq, dist[t]));   // S'[q][key] - dist - lse2[q] + 8   (lq = 8 - lse2)
-        s = mfma_h(qa, kb2[h], s);
-        f32x4 dpv = mfma_h(ga, vb1[h], nd);            // keep * dP[q][key] - delta[q]
-        dpv = mfma_h(ga, vb2[h], dpv);
+        const f16x8 qa = *reinterpret_cast<const f16x8*>(Qimg + t * 512 + aoff);
+        const f16x8 ga = *reinterpret_cast<const f16x8*>(Gimg + t * 512 + aoff);
+        const f32x4 lq = *reinterpret_cast<const f32x4*>(&Ls[16 * t + 4 * G]);
+        const f32x4 nd = *reinterpret_cast<const f32x4*>(&Ds[16 * t + 4 * G]);
+        f32x4 s = mfma_h(qa, kb1, sub4(lq, dist[t]));   // S'[q][key] - dist - lse2[q] + 8   (lq = 8 - lse2)
+        s = mfma_h(qa, kb2, s);
+        f32x4 dpv = mfma_h(ga, vb1[kt], nd);            // keep * dP[q][key] - delta[q]
+        dpv = mfma_h(ga, vb2[kt], dpv);
 #pragma unroll
         for (int r = 0; r < 4; ++r) p[t][r] = __builtin_amdgcn_exp2f(s[r]);
         if (DROP) {
           uint32_t e[4];
-          drop_words_k(dl[h], (uint32_t)(qb0 + 16 * t), lcq, e);
+          drop_words_k(dl, (uint32_t)(qb0 + 16 * t), lcq, e);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const bool kept = (int)e[r] >= dc.ts32;
@@ -212,14 +255,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
           for (int r = 0; r < 4; ++r) ds[t][r] = p[t][r] * dpv[r];
         }
       }
-      const _Float16* gr = Gimg + h * R_HEAD;
-      const _Float16* qr = Qimg + h * R_HEAD;
+      if (kt > 0) dq_product(kt - 1);
 #pragma unroll
       for (int tp = 0; tp < NT / 2; ++tp) {
         f16x8 ph, pl, sh, sl;
         split8(p[2 * tp], p[2 * tp + 1], &ph, &pl);
         split8(ds[2 * tp], ds[2 * tp + 1], &sh, &sl);
-        // dS' of the wave's key j for queries 32 tp + 4G .. +3 and 32 tp + 16 + 4G .. +3 -> the transposition tile [part][key][q]
+        // dS' of the lane's key for queries 32 tp + 4G .. +3 and 32 tp + 16 + 4G .. +3 -> the transposition tile [part][key][q]
         if (!(DGDM_FUSED_SKIP & 4)) {
           typedef _Float16 h4 __attribute__((ext_vector_type(4)));
           _Float16* th = Tw + j * T_LD + 32 * tp + 4 * G;
@@ -228,87 +270,83 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
           *reinterpret_cast<h4*>(th + T_PART) = h4{sl[0], sl[1], sl[2], sl[3]};
           *reinterpret_cast<h4*>(th + T_PART + 16) = h4{sl[4], sl[5], sl[6], sl[7]};
         }
-        const f16x8 ghi = load_tr_pair(gr, 0, 2 * tp, lane), qhi = load_tr_pair(qr, 0, 2 * tp, lane);
-        dv[h] = mfma_h(ghi, ph, dv[h]);                                       // dV^T[d=j][key] += dO^T[d][q] P[q][key]
-        dv[h] = mfma_h(load_tr_pair(gr, 1, 2 * tp, lane), ph, dv[h]);
-        dv[h] = mfma_h(ghi, pl, dv[h]);
-        dk[h] = mfma_h(qhi, sh, dk[h]);                                       // dK^T[d=j][key] += Q'^T[d][q] dS[q][key]
-        dk[h] = mfma_h(load_tr_pair(qr, 1, 2 * tp, lane), sh, dk[h]);
-        dk[h] = mfma_h(qhi, sl, dk[h]);
-      }
-      // dQ^T[d][q] of this wave's 16 keys: the tile is this wave's own (its writes above are complete in program order once
-      // lgkmcnt has drained: hipcc waits before the dependent reads); lane (q = j, G) supplies reduction slots = keys 4G .. 4G+3, hi | lo
-      float* Xw = X + ((h * 4 + wave) * HB) * 16;
-#pragma unroll
-      for (int t = 0; t < NT && !(DGDM_FUSED_SKIP & 4); ++t) {
-        const f16x8 b = cat4(tr4_tile(Tw, 16 * t, lane), tr4_tile(Tw + T_PART, 16 * t, lane));
-        f32x4 dqp = mfma_h(ka1[h], b, f32x4{0.f, 0.f, 0.f, 0.f});
-        dqp = mfma_h(ka2[h], b, dqp);
-        if (!(DGDM_FUSED_SKIP & 2)) *reinterpret_cast<f32x4*>(Xw + (16 * t + j) * 16 + 4 * G) = dqp;      // X[h][wave][q = 16 t + j][d = 4G .. 4G+3]
-        else if (dqp[0] == 123.456f) Xw[0] = dqp[1];      // (diagnostic build: keep the product alive)
+        const f16x8 ghi = load_tr_pair(Gimg, 0, 2 * tp, lane), qhi = load_tr_pair(Qimg, 0, 2 * tp, lane);
+        dv[kt] = mfma_h(ghi, ph, dv[kt]);                                       // dV^T[d=j][key] += dO^T[d][q] P[q][key]
+        dv[kt] = mfma_h(load_tr_pair(Gimg, 1, 2 * tp, lane), ph, dv[kt]);
+        dv[kt] = mfma_h(ghi, pl, dv[kt]);
+        dk[kt] = mfma_h(qhi, sh, dk[kt]);                                       // dK^T[d=j][key] += Q'^T[d][q] dS[q][key]
+        dk[kt] = mfma_h(load_tr_pair(Qimg, 1, 2 * tp, lane), sh, dk[kt]);
+        dk[kt] = mfma_h(qhi, sl, dk[kt]);
       }
     }
-    __syncthreads();      // everyone is done with the staged block; every wave's dQ tiles are in X
-    if (qb + 1 < nbg) stage(qb + 1, 0);
-    if (!(DGDM_FUSED_SKIP & 6)) {   // ... and while the next block's DMA is in flight: the four waves' tiles summed (fixed order) and stored as one partial tile
-      const int q = tid >> 2, d4 = tid & 3;
-      const int64_t slot = (slot0 + qb) * H + head0;                          // [pair slot][head][64 q][16 d]
+    dq_product(KT - 1);
+    if (!(DGDM_FUSED_SKIP & 6)) {
+      float* Xw = X + (wave * HB) * 16;
 #pragma unroll
-      for (int h = 0; h < HG; ++h) {
-        const float* xs = X + (h * 4 * HB + q) * 16 + 4 * d4;
-        const f32x4 a0 = *reinterpret_cast<const f32x4*>(xs), a1 = *reinterpret_cast<const f32x4*>(xs + HB * 16);
-        const f32x4 a2 = *reinterpret_cast<const f32x4*>(xs + 2 * HB * 16), a3 = *reinterpret_cast<const f32x4*>(xs + 3 * HB * 16);
-        const f32x4 sum = (a0 + a1) + (a2 + a3);
-        if (!(DGDM_FUSED_SKIP & 1)) *reinterpret_cast<f32x4*>(dq_part + ((slot + h) * HB + q) * 16 + 4 * d4) = sum;
-        else if (sum[0] == 123.456f) dq_part[0] = sum[1];
-      }
+      for (int t = 0; t < NT; ++t) *reinterpret_cast<f32x4*>(Xw + (16 * t + j) * 16 + 4 * G) = dqp[t];      // X[wave][q = 16 t + j][d = 4G .. 4G+3]
+    } else if (dqp[0][0] == 123.456f) {
+      X[0] = dqp[1][0] + dqp[2][1] + dqp[3][2];      // (diagnostic build: keep the product alive)
+    }
+    __syncthreads();      // everyone is done with the staged block; every wave's dQ tile (its 64 keys) is in X
+    if (qb + 1 < nbg) stage(qb + 1);
+    if (!(DGDM_FUSED_SKIP & 6)) {   // ... and while the next block's DMA is in flight: the four waves' tiles summed (fixed order) and stored
+      const int q = tid >> 2, d4 = tid & 3;
+      const float* xs = X + q * 16 + 4 * d4;
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(xs), a1 = *reinterpret_cast<const f32x4*>(xs + HB * 16);
+      const f32x4 a2 = *reinterpret_cast<const f32x4*>(xs + 2 * HB * 16), a3 = *reinterpret_cast<const f32x4*>(xs + 3 * HB * 16);
+      const f32x4 sum = (a0 + a1) + (a2 + a3);
+      float* o = dq_part + (((slot0 + qb) * H + head) * HB + q) * 16 + 4 * d4;        // [slot][head][64 q][16 d]
+      if (!(DGDM_FUSED_SKIP & 1)) *reinterpret_cast<f32x4*>(o) = sum;
+      else if (sum[0] == 123.456f) dq_part[0] = sum[1];
     }
     __syncthreads();      // the DMA has landed; X and T may be rewritten
   }
 
-  if (k_ok) {
+  if (blk_ok) {
     const float un = unscale_dev[1] * exp2f(-DGDM_ATTN_P_SHIFT);
     const float unk = kscale * un, unv = DROP ? dc.keep * un : un;
 #pragma unroll
-    for (int h = 0; h < HG; ++h) {
-      const int64_t off = (int64_t)(n0 + k_local) * ldg + (head0 + h) * 16 + 4 * G;
-      const f32x4 a = dk[h] * unk, b = dv[h] * unv;
-      *reinterpret_cast<float4*>(dK + off) = make_float4(a[0], a[1], a[2], a[3]);
-      *reinterpret_cast<float4*>(dV + off) = make_float4(b[0], b[1], b[2], b[3]);
+    for (int kt = 0; kt < KT; ++kt) {
+      if (k_ok[kt]) {
+        const int64_t off = (int64_t)(n0 + lblk * HB + 16 * kt + j) * ldg + head * 16 + 4 * G;
+        const f32x4 a = dk[kt] * unk, b = dv[kt] * unv;
+        *reinterpret_cast<float4*>(dK + off) = make_float4(a[0], a[1], a[2], a[3]);
+        *reinterpret_cast<float4*>(dV + off) = make_float4(b[0], b[1], b[2], b[3]);
+      }
     }
   }
 }
 
-// dQ[q block][head] (+)= scale * sum over the launch's key blocks of that graph, in key-block order (fixed order: bitwise repeatable).
-// grid (all query blocks, H); a thread owns one float4 of the 64 x 16 tile.  A query block whose graph has key blocks in an EARLIER
-// launch (blk0 < kb_first) adds to what that launch left in dQ; one whose graph has none in this launch is left alone.
+// dQ[q block][head] (+)= scale * sum over the launch's key super-blocks of that graph, in order (fixed order: bitwise repeatable).
+// grid (all query blocks, H); a thread owns one float4 of the 64 x 16 tile.  A query block whose graph has super-blocks in an
+// EARLIER launch (sb0 < sb_first) adds to what that launch left in dQ; one whose graph has none in this launch is left alone.
 __global__ __launch_bounds__(256) void k_attn_dq_reduce(const float* __restrict__ dq_part, const int32_t* __restrict__ ptr, int B, int H,
-                                                        int kb_first, int kb_count, int64_t slot_first, float scale,
+                                                        int sb_first, int sb_count, int64_t slot_first, float scale,
                                                         const float* __restrict__ unscale_dev, float* __restrict__ dQ, int64_t ldg) {
-  int n0, ng, lblk, blk0;
-  int64_t pair0;
-  if (!find_block_pairs(ptr, B, blockIdx.x, &n0, &ng, &lblk, &blk0, &pair0)) return;
-  const int nbg = (ng + HB - 1) / HB;
+  int n0, ng, lblk, sb0;
+  int64_t spair0;
+  if (!find_block_s(ptr, B, blockIdx.x, &n0, &ng, &lblk, &sb0, &spair0)) return;
+  const int nbg = (ng + HB - 1) / HB, nsb = (nbg + 3) >> 2;
   const int h = blockIdx.y, tid = threadIdx.x, q = tid >> 2, d4 = tid & 3;
-  const int lo = max(blk0, kb_first), hi = min(blk0 + nbg, kb_first + kb_count);      // this graph's key blocks inside the launch
+  const int lo = max(sb0, sb_first), hi = min(sb0 + nsb, sb_first + sb_count);      // this graph's super-blocks inside the launch
   if (hi <= lo) return;
   f32x4 acc[4] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-  // slot(kb, this query block) = pair0 + (kb - blk0) * nbg + lblk - slot_first: consecutive key blocks are nbg slots apart
-  const float* base = dq_part + (((pair0 + lblk - slot_first) * H + h) * HB + q) * 16 + 4 * d4;
+  // slot(sb, this query block) = spair0 + (sb - sb0) * nbg + lblk - slot_first: consecutive super-blocks are nbg slots apart
+  const float* base = dq_part + (((spair0 + lblk - slot_first) * H + h) * HB + q) * 16 + 4 * d4;
   const int64_t stride = (int64_t)nbg * H * HB * 16;
-  int kb = lo;
-  for (; kb + 3 < hi; kb += 4) {        // four loads in flight; fixed association: ((k0 + k4 + ..) + (k1 + k5 + ..)) + ((k2 ..) + (k3 ..))
+  int sb = lo;
+  for (; sb + 3 < hi; sb += 4) {        // four loads in flight; fixed association
 #pragma unroll
-    for (int u = 0; u < 4; ++u) acc[u] += *reinterpret_cast<const f32x4*>(base + (int64_t)(kb + u - blk0) * stride);
+    for (int u = 0; u < 4; ++u) acc[u] += *reinterpret_cast<const f32x4*>(base + (int64_t)(sb + u - sb0) * stride);
   }
-  for (; kb < hi; ++kb) acc[0] += *reinterpret_cast<const f32x4*>(base + (int64_t)(kb - blk0) * stride);
+  for (; sb < hi; ++sb) acc[0] += *reinterpret_cast<const f32x4*>(base + (int64_t)(sb - sb0) * stride);
   const f32x4 sum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
   const int q_local = lblk * HB + q;
   if (q_local < ng) {
     const float un = scale * unscale_dev[1] * exp2f(-DGDM_ATTN_P_SHIFT);
     float* o = dQ + (int64_t)(n0 + q_local) * ldg + h * 16 + 4 * d4;
     f32x4 r = sum * un;
-    if (blk0 < kb_first) {          // an earlier launch covered the graph's first key blocks
+    if (sb0 < sb_first) {          // an earlier launch covered the graph's first super-blocks
       const float4 old = *reinterpret_cast<const float4*>(o);
       r += f32x4{old.x, old.y, old.z, old.w};
     }
@@ -318,62 +356,88 @@ __global__ __launch_bounds__(256) void k_attn_dq_reduce(const float* __restrict_
 
 }  // namespace
 
-// First pair slot of packed block `blk` (query block 0) and the slot count of [kb_first, kb_first + kb_count): host mirror of
-// find_block_pairs over the HOST copy of the graph offsets.
-static bool pair_slots_host(const int32_t* ptr_host, int32_t B, int64_t kb_first, int64_t kb_count, int64_t* first, int64_t* count) {
-  int64_t base = 0, pairs = 0, f = -1, l = -1;
-  const int64_t kb_last = kb_first + kb_count - 1;
+// Host mirror of find_sblock over the HOST copy of the graph offsets: total super-blocks; first slot and slot count of a range.
+static bool sblock_slots_host(const int32_t* ptr_host, int32_t B, int64_t sb_first, int64_t sb_count, int64_t* first, int64_t* count,
+                              int64_t* total_sb) {
+  int64_t sbase = 0, pairs = 0, f = -1, l = -1;
+  const int64_t sb_last = sb_first + sb_count - 1;
   for (int g = 0; g < B; ++g) {
     const int64_t nb = ((int64_t)ptr_host[g + 1] - ptr_host[g] + HB - 1) / HB;
     if (nb < 0) return false;
-    if (f < 0 && kb_first < base + nb) f = pairs + (kb_first - base) * nb;
-    if (l < 0 && kb_last < base + nb) l = pairs + (kb_last - base) * nb + nb;     // one past the last slot of the last key block
-    base += nb;
-    pairs += nb * nb;
+    const int64_t nsb = (nb + 3) / 4;
+    if (f < 0 && sb_first < sbase + nsb) f = pairs + (sb_first - sbase) * nb;
+    if (l < 0 && sb_last < sbase + nsb) l = pairs + (sb_last - sbase) * nb + nb;     // one past the last slot of the last super-block
+    sbase += nsb;
+    pairs += nsb * nb;
   }
+  *total_sb = sbase;
+  if (sb_count <= 0) { *first = 0; *count = 0; return true; }
   if (f < 0 || l < 0) return false;
   *first = f; *count = l - f;
   return true;
 }
 
-// bytes of partial-tile scratch the key blocks [kb_first, kb_first + kb_count) need (one 64 x 16 fp32 tile per (key block, query
+// number of key super-blocks (4 consecutive 64-key blocks of one graph) of a batch: the unit the one-pass backward is launched over
+extern "C" int32_t dgdm_spatial_attn_h_bwd_fused_superblocks(const int32_t* ptr_host, int32_t B) {
+  if (!ptr_host || B <= 0) return 0;
+  int64_t f, c, total;
+  if (!sblock_slots_host(ptr_host, B, 0, 0, &f, &c, &total)) return 0;
+  return total > 0x7fffffff ? 0 : (int32_t)total;
+}
+
+// bytes of partial-tile scratch the super-blocks [sb_first, sb_first + sb_count) need (one 64 x 16 fp32 tile per (super-block, query
 // block of its graph, head)); 0 for an empty / out-of-range request.  ptr_host: the B + 1 graph offsets ON THE HOST.
-extern "C" size_t dgdm_spatial_attn_h_bwd_fused_workspace_bytes(const int32_t* ptr_host, int32_t B, int32_t H, int32_t kb_first,
-                                                                int32_t kb_count) {
-  if (!ptr_host || B <= 0 || H <= 0 || kb_first < 0 || kb_count <= 0) return 0;
-  int64_t first, count;
-  if (!pair_slots_host(ptr_host, B, kb_first, kb_count, &first, &count)) return 0;
+extern "C" size_t dgdm_spatial_attn_h_bwd_fused_workspace_bytes(const int32_t* ptr_host, int32_t B, int32_t H, int32_t sb_first,
+                                                                int32_t sb_count) {
+  if (!ptr_host || B <= 0 || H <= 0 || sb_first < 0 || sb_count <= 0) return 0;
+  int64_t first, count, total;
+  if (!sblock_slots_host(ptr_host, B, sb_first, sb_count, &first, &count, &total)) return 0;
   return (size_t)count * (size_t)H * HB * 16 * sizeof(float);
 }
 
 extern "C" int dgdm_spatial_attn_h_bwd_fused(const void* Rq, const void* Rk, const void* Rv, const void* Rg, const float* pos_b,
                                              const float* lse_adj_b, const float* ndelta_b, const int32_t* ptr, const int32_t* ptr_host,
-                                             int32_t B, int32_t num_blocks, int32_t H, float scale, float drop_p, uint32_t seed,
-                                             const float* grad_scale2, float* dQ, float* dK, float* dV, int64_t ldg,
-                                             int32_t kb_first, int32_t kb_count, void* workspace, size_t workspace_bytes, void* stream_) {
-  DGDM_REQUIRE(B >= 0 && H > 0 && num_blocks >= 0 && drop_p >= 0.f && drop_p < 1.f && kb_first >= 0 && kb_count >= 0);
-  if (num_blocks == 0 || B == 0 || kb_count == 0) return DGDM_OK;
-  DGDM_REQUIRE(kb_first + (int64_t)kb_count <= num_blocks);
-  DGDM_REQUIRE(Rq && Rk && Rv && Rg && pos_b && lse_adj_b && ndelta_b && ptr && ptr_host && dQ && dK && dV && grad_scale2 && workspace);
-  if ((ldg & 3) || ldg < H * 16 || !dgdm_aligned16(dQ) || !dgdm_aligned16(dK) || !dgdm_aligned16(dV) || !dgdm_aligned16(workspace))
+                                             int32_t B, int32_t num_blocks, int32_t H, float drop_p, uint32_t seed,
+                                             const float* grad_scale2, float* dK, float* dV, int64_t ldg,
+                                             int32_t sb_first, int32_t sb_count, void* workspace, size_t workspace_bytes, void* stream_) {
+  DGDM_REQUIRE(B >= 0 && H > 0 && num_blocks >= 0 && drop_p >= 0.f && drop_p < 1.f && sb_first >= 0 && sb_count >= 0);
+  if (num_blocks == 0 || B == 0 || sb_count == 0) return DGDM_OK;
+  DGDM_REQUIRE(Rq && Rk && Rv && Rg && pos_b && lse_adj_b && ndelta_b && ptr && ptr_host && dK && dV && grad_scale2 && workspace);
+  if ((ldg & 3) || ldg < H * 16 || !dgdm_aligned16(dK) || !dgdm_aligned16(dV) || !dgdm_aligned16(workspace))
     return DGDM_ERR_UNSUPPORTED;
-  if (H % 2) return DGDM_ERR_UNSUPPORTED;      // two heads per workgroup (odd head counts: the two-pass kernels)
-  int64_t slot_first, slots;
-  if (!pair_slots_host(ptr_host, B, kb_first, kb_count, &slot_first, &slots)) return DGDM_ERR_INVALID_ARG;
+  int64_t slot_first, slots, total_sb;
+  if (!sblock_slots_host(ptr_host, B, sb_first, sb_count, &slot_first, &slots, &total_sb)) return DGDM_ERR_INVALID_ARG;
+  DGDM_REQUIRE(sb_first + (int64_t)sb_count <= total_sb);
   if (workspace_bytes < (size_t)slots * (size_t)H * HB * 16 * sizeof(float)) return DGDM_ERR_WORKSPACE;
   hipStream_t s = static_cast<hipStream_t>(stream_);
   const float kscale = 0.6931471805599453f;  // Q' carries scale*log2(e): dK = sum dS Q' / log2(e)
   auto h16 = [](const void* p) { return static_cast<const _Float16*>(p); };
   float* part = static_cast<float*>(workspace);
   if (drop_p > 0.f)
-    hipLaunchKernelGGL((k_attn_h_bwd_fused<2, true, 2>), dim3(kb_count, H / 2), dim3(256), 0, s, h16(Rq), h16(Rk), h16(Rv), h16(Rg), pos_b,
-                       lse_adj_b, ndelta_b, H, ptr, B, kscale, grad_scale2, dK, dV, ldg, part, kb_first, kb_count, slot_first, drop_p,
+    hipLaunchKernelGGL((k_attn_h_bwd_fused<true, 2>), dim3(sb_count, H), dim3(256), 0, s, h16(Rq), h16(Rk), h16(Rv), h16(Rg), pos_b,
+                       lse_adj_b, ndelta_b, H, ptr, B, kscale, grad_scale2, dK, dV, ldg, part, sb_first, sb_count, slot_first, drop_p,
                        dgdm_seed_arg(seed));
   else
-    hipLaunchKernelGGL((k_attn_h_bwd_fused<2, false, 2>), dim3(kb_count, H / 2), dim3(256), 0, s, h16(Rq), h16(Rk), h16(Rv), h16(Rg), pos_b,
-                       lse_adj_b, ndelta_b, H, ptr, B, kscale, grad_scale2, dK, dV, ldg, part, kb_first, kb_count, slot_first, 0.f,
+    hipLaunchKernelGGL((k_attn_h_bwd_fused<false, 2>), dim3(sb_count, H), dim3(256), 0, s, h16(Rq), h16(Rk), h16(Rv), h16(Rg), pos_b,
+                       lse_adj_b, ndelta_b, H, ptr, B, kscale, grad_scale2, dK, dV, ldg, part, sb_first, sb_count, slot_first, 0.f,
                        dgdm_seed_arg(0u));
-  hipLaunchKernelGGL(k_attn_dq_reduce, dim3(num_blocks, H), dim3(256), 0, s, part, ptr, B, H, kb_first, kb_count, slot_first, scale,
-                     grad_scale2, dQ, ldg);
+  return dgdm_launch_status();
+}
+
+// second stage of the call above (same sb_first / sb_count / workspace): dQ rows of every query block whose graph has super-blocks in
+// the range (+)= scale * sum of their partial tiles, in super-block order
+extern "C" int dgdm_spatial_attn_h_bwd_fused_reduce(const int32_t* ptr, const int32_t* ptr_host, int32_t B, int32_t num_blocks, int32_t H,
+                                                    float scale, const float* grad_scale2, float* dQ, int64_t ldg, int32_t sb_first,
+                                                    int32_t sb_count, const void* workspace, size_t workspace_bytes, void* stream_) {
+  DGDM_REQUIRE(B >= 0 && H > 0 && num_blocks >= 0 && sb_first >= 0 && sb_count >= 0);
+  if (num_blocks == 0 || B == 0 || sb_count == 0) return DGDM_OK;
+  DGDM_REQUIRE(ptr && ptr_host && dQ && grad_scale2 && workspace);
+  if ((ldg & 3) || ldg < H * 16 || !dgdm_aligned16(dQ) || !dgdm_aligned16(workspace)) return DGDM_ERR_UNSUPPORTED;
+  int64_t slot_first, slots, total_sb;
+  if (!sblock_slots_host(ptr_host, B, sb_first, sb_count, &slot_first, &slots, &total_sb)) return DGDM_ERR_INVALID_ARG;
+  DGDM_REQUIRE(sb_first + (int64_t)sb_count <= total_sb);
+  if (workspace_bytes < (size_t)slots * (size_t)H * HB * 16 * sizeof(float)) return DGDM_ERR_WORKSPACE;
+  hipLaunchKernelGGL(k_attn_dq_reduce, dim3(num_blocks, H), dim3(256), 0, static_cast<hipStream_t>(stream_),
+                     static_cast<const float*>(workspace), ptr, B, H, sb_first, sb_count, slot_first, scale, grad_scale2, dQ, ldg);
   return dgdm_launch_status();
 }

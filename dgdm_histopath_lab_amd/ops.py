@@ -249,8 +249,8 @@ class PackedOperands:
 # dS' = P' (keep dP - delta) stay ~4x further from fp16's maximum than round 2's (target 256, P unscaled) did
 ATTN_GRAD_TARGET = 0.25
 ATTN_BWD_CONCURRENT = False     # dQ pass on a side stream beside the dK/dV pass (tools/bench_with.py A/B switch)
-ATTN_BWD_FUSED = False          # dQ, dK, dV in one key-stationary pass + a fixed-order reduction of the partial dQ tiles
-ATTN_BWD_FUSED_BUDGET = 8 << 30  # bytes of partial-tile scratch per launch (3.2 GB at 4 x 10k nodes x 8 heads; 40 GB at 50k nodes x 16)
+ATTN_BWD_FUSED = True           # dQ, dK, dV in one key-stationary pass + a fixed-order reduction of the partial dQ tiles (False: two passes)
+ATTN_BWD_FUSED_BUDGET = 8 << 30  # bytes of partial-tile scratch per launch (0.8 GB at 4 x 10k nodes x 8 heads; 10 GB at 50k nodes x 16)
 _SIDE_STREAMS: dict = {}
 
 
@@ -325,28 +325,29 @@ def spatial_attn_h_bwd_raw(pk: PackedOperands, out, gout, plan: AttnPlan, H: int
                                             plan.ptr_dev.data_ptr(), plan.B, plan.num_q_tiles, H, drop_p, seed, gs.data_ptr(),
                                             dqkv[:, C:2 * C].data_ptr(), dqkv[:, 2 * C:].data_ptr(), dqkv.stride(0), dkv_variant, stream),
             "dgdm_spatial_attn_h_bwd_dkv")
-    if ATTN_BWD_FUSED and H % 2 == 0:
-        # one pass for dQ, dK, dV (csrc/attn_h_bwd_fused.hip): key blocks in groups whose partial-dQ scratch stays within the budget
+    if ATTN_BWD_FUSED:
+        # one pass for dQ, dK, dV (csrc/attn_h_bwd_fused.hip): key super-blocks in groups whose partial-dQ scratch stays within the budget
         import ctypes
         ph = (ctypes.c_int32 * (plan.B + 1))(*plan.ptr_host)
-        nb, kb = plan.num_q_tiles, 0
+        nsb, sb = lib.dgdm_spatial_attn_h_bwd_fused_superblocks(ph, plan.B), 0
         groups = []
-        while kb < nb:
-            cnt = nb - kb
-            while cnt > 1 and lib.dgdm_spatial_attn_h_bwd_fused_workspace_bytes(ph, plan.B, H, kb, cnt) > ATTN_BWD_FUSED_BUDGET:
+        while sb < nsb:
+            cnt = nsb - sb
+            while cnt > 1 and lib.dgdm_spatial_attn_h_bwd_fused_workspace_bytes(ph, plan.B, H, sb, cnt) > ATTN_BWD_FUSED_BUDGET:
                 cnt = (cnt + 1) // 2
-            groups.append((kb, cnt, lib.dgdm_spatial_attn_h_bwd_fused_workspace_bytes(ph, plan.B, H, kb, cnt)))
-            kb += cnt
-        ws = torch.empty(max(g[2] for g in groups) // 4, dtype=torch.float32, device=out.device)
+            groups.append((sb, cnt, lib.dgdm_spatial_attn_h_bwd_fused_workspace_bytes(ph, plan.B, H, sb, cnt)))
+            sb += cnt
+        ws = torch.empty(max(max(g[2] for g in groups), 16) // 4, dtype=torch.float32, device=out.device)
 
-        def run_fused():
-            for kb0, cnt, wsb in groups:
-                _lib.check(lib.dgdm_spatial_attn_h_bwd_fused(
-                    pk.r(0).data_ptr(), pk.r(1).data_ptr(), pk.r(2).data_ptr(), gk.r(0).data_ptr(), pk.pos_b.data_ptr(), gk.nlse_b.data_ptr(),
-                    gk.ndelta_b.data_ptr(), plan.ptr_dev.data_ptr(), ph, plan.B, nb, H, scale, drop_p, seed, gs.data_ptr(),
-                    dqkv[:, :C].data_ptr(), dqkv[:, C:2 * C].data_ptr(), dqkv[:, 2 * C:].data_ptr(), dqkv.stride(0), kb0, cnt, ws.data_ptr(),
-                    ws.numel() * 4, st), "dgdm_spatial_attn_h_bwd_fused")
-        TIMERS.timed("attn_bwd_fused", run_fused)
+        for sb0, cnt, wsb in groups:
+            TIMERS.timed("attn_bwd_fused", lambda: _lib.check(lib.dgdm_spatial_attn_h_bwd_fused(
+                pk.r(0).data_ptr(), pk.r(1).data_ptr(), pk.r(2).data_ptr(), gk.r(0).data_ptr(), pk.pos_b.data_ptr(), gk.nlse_b.data_ptr(),
+                gk.ndelta_b.data_ptr(), plan.ptr_dev.data_ptr(), ph, plan.B, plan.num_q_tiles, H, drop_p, seed, gs.data_ptr(),
+                dqkv[:, C:2 * C].data_ptr(), dqkv[:, 2 * C:].data_ptr(), dqkv.stride(0), sb0, cnt, ws.data_ptr(), ws.numel() * 4, st),
+                "dgdm_spatial_attn_h_bwd_fused"))
+            TIMERS.timed("attn_bwd_dq_reduce", lambda: _lib.check(lib.dgdm_spatial_attn_h_bwd_fused_reduce(
+                plan.ptr_dev.data_ptr(), ph, plan.B, plan.num_q_tiles, H, scale, gs.data_ptr(), dqkv[:, :C].data_ptr(), dqkv.stride(0), sb0, cnt,
+                ws.data_ptr(), ws.numel() * 4, st), "dgdm_spatial_attn_h_bwd_fused_reduce"))
     elif ATTN_BWD_CONCURRENT and not TIMERS.enabled:
         # the two passes are independent (dQ | dK, dV: disjoint columns of dqkv) and each leaves the chip partly empty in its last
         # round of workgroups (1256 / 2512 workgroups on 512 / 768 resident slots): side by side the one fills the other's tail.

@@ -287,21 +287,27 @@ DGDM_API int dgdm_spatial_attn_h_bwd_dkv(const void* Rq, const void* Rk, const v
                                          uint32_t seed, const float* grad_scale2, float* dK, float* dV, int64_t ldg, int32_t variant,
                                          void* stream);
 
-/* backward in ONE pass (round 4): the key-stationary pass also produces dQ.  Every workgroup (key block, head pair) writes, per query
- * block of its graph, its 64 x 16 fp32 share of dQ as a partial tile; a second launch sums the key blocks' tiles of every query
- * block in key-block order (no atomics, bitwise repeatable) and applies the scale.  The scores, the distance, exp2 and the dropout
- * word are evaluated once instead of twice.  Key blocks [kb_first, kb_first + kb_count) of the packed block numbering are
- * processed per call (callers cut the range so that the scratch -- 4 KiB per (key block, query block of its graph, head) -- stays
- * within their budget and call in ascending order; a later call ADDS to the dQ rows of a graph an earlier call has started);
- * dK / dV rows of those key blocks are final after the call.  ptr_host: the B + 1 graph offsets in HOST memory (the same values
- * `ptr` holds on the device).  Even head counts only (DGDM_ERR_UNSUPPORTED otherwise: use the two-pass entry points). */
-DGDM_API size_t dgdm_spatial_attn_h_bwd_fused_workspace_bytes(const int32_t* ptr_host, int32_t B, int32_t H, int32_t kb_first,
-                                                              int32_t kb_count);
+/* backward in ONE pass (round 4): the key-stationary pass also produces dQ.  A workgroup owns a key SUPER-block -- 4 consecutive
+ * 64-key blocks of one graph, one per wave -- and one head; per query block of its graph it writes its 64 x 16 fp32 share of dQ
+ * as a partial tile, and a second launch sums the super-blocks' tiles of every query block in order (no atomics, bitwise
+ * repeatable) and applies the scale.  The scores, the distance, exp2 and the dropout word are evaluated once instead of twice.
+ * Super-blocks are numbered graph by graph (dgdm_spatial_attn_h_bwd_fused_superblocks gives their count); a call processes
+ * [sb_first, sb_first + sb_count) (callers cut the range so that the scratch -- 4 KiB per (super-block, query block of its graph,
+ * head) -- stays within their budget and call in ascending order; a later call ADDS to the dQ rows of a graph an earlier call has
+ * started); dK / dV rows of those keys are final after the call.  ptr_host: the B + 1 graph offsets in HOST memory (the same
+ * values `ptr` holds on the device). */
+DGDM_API int32_t dgdm_spatial_attn_h_bwd_fused_superblocks(const int32_t* ptr_host, int32_t B);
+DGDM_API size_t dgdm_spatial_attn_h_bwd_fused_workspace_bytes(const int32_t* ptr_host, int32_t B, int32_t H, int32_t sb_first,
+                                                              int32_t sb_count);
 DGDM_API int dgdm_spatial_attn_h_bwd_fused(const void* Rq, const void* Rk, const void* Rv, const void* Rg, const float* pos_b,
                                            const float* lse_adj_b, const float* ndelta_b, const int32_t* ptr, const int32_t* ptr_host,
-                                           int32_t B, int32_t num_blocks, int32_t H, float scale, float drop_p, uint32_t seed,
-                                           const float* grad_scale2, float* dQ, float* dK, float* dV, int64_t ldg,
-                                           int32_t kb_first, int32_t kb_count, void* workspace, size_t workspace_bytes, void* stream);
+                                           int32_t B, int32_t num_blocks, int32_t H, float drop_p, uint32_t seed,
+                                           const float* grad_scale2, float* dK, float* dV, int64_t ldg,
+                                           int32_t sb_first, int32_t sb_count, void* workspace, size_t workspace_bytes, void* stream);
+/* ... and its second stage (same range, same workspace, right behind it on the stream): the partial tiles summed into dQ */
+DGDM_API int dgdm_spatial_attn_h_bwd_fused_reduce(const int32_t* ptr, const int32_t* ptr_host, int32_t B, int32_t num_blocks, int32_t H,
+                                                  float scale, const float* grad_scale2, float* dQ, int64_t ldg, int32_t sb_first,
+                                                  int32_t sb_count, const void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K5  out = x + sinusoidal_2d_posenc(pos)  for a whole batch.  Replaces

@@ -101,12 +101,14 @@ def test_attn_backward_matches_dense(ptr, H):
     assert torch.equal(d.grad, d2.grad)
 
 
-@pytest.mark.parametrize("impl", ["fp32", "fp16x2"])
-def test_attn_dropout_mask_consistent_between_forward_and_both_backward_kernels(impl):
+@pytest.mark.parametrize("impl", ["fp32", "fp16x2", "fp16x2-two-pass"])
+def test_attn_dropout_mask_consistent_between_forward_and_both_backward_kernels(impl, monkeypatch):
     """Dropout on the attention weights: extract the kernel's own mask F (V = one-hot blocks), then
     check O = (P*F)V and dQ/dK/dV against float64 autograd of the same masked formula: proves the dQ
     (q-major) and dK/dV (k-major) kernels regenerate exactly the forward's mask."""
     from dgdm_histopath_lab_amd import ops
+    monkeypatch.setattr(ops, "ATTN_BWD_FUSED", impl != "fp16x2-two-pass")     # the one-pass backward (default) / the dQ + dK,dV pair
+    two_pass, impl = impl.endswith("two-pass"), impl.split("-")[0]
     ptr, H, p, seed = [0, 37, 100], 2, 0.25, 1234567
     C, n = H * 16, ptr[-1]
     qkv, pos = make(ptr, H, 99)
@@ -197,10 +199,12 @@ def test_attn_split_fp16_forward_matches_dense(ptr, H, scale):
 @pytest.mark.parametrize("ptr,H,gscale", [([0, 17], 8, 1.0), ([0, 65, 130, 131], 8, 1.0), ([0, 200, 263], 2, 1.0), ([0, 100], 1, 1.0),
                                            ([0, 333, 1000], 8, 1.0), ([0, 129, 500], 16, 1.0), ([0, 333, 1000], 8, 1e-7),
                                            ([0, 333, 1000], 8, 3e4)])
-def test_attn_split_fp16_backward_matches_dense(ptr, H, gscale):
+@pytest.mark.parametrize("one_pass", [True, False], ids=["one-pass", "two-pass"])
+def test_attn_split_fp16_backward_matches_dense(ptr, H, gscale, one_pass, monkeypatch):
     """gscale: incoming gradients far below / above fp16's range (1e-7, 3e4) exercise the device-side
-    power-of-two scaling of dO."""
+    power-of-two scaling of dO.  Both backward forms: the one-pass kernel (default) and the dQ + dK,dV pair."""
     from dgdm_histopath_lab_amd import ops
+    monkeypatch.setattr(ops, "ATTN_BWD_FUSED", one_pass)
     qkv, pos = make(ptr, H, 7 * sum(ptr) + H)
     C = H * 16
     g = torch.Generator().manual_seed(2)
@@ -251,14 +255,15 @@ def _sharp_case(kind, ptr, H, seed):
     return qkv, pos
 
 
-@pytest.mark.parametrize("impl", ["fp16x2", "fp32"])
+@pytest.mark.parametrize("impl", ["fp16x2", "fp16x2-two-pass", "fp32"])
 @pytest.mark.parametrize("kind,max_entropy", [("x4", 2.5), ("x16", 0.5), ("dominant", 0.5), ("shifted", 2.5)])
-def test_attn_backward_on_sharp_rows_matches_dense(kind, max_entropy, impl):
+def test_attn_backward_on_sharp_rows_matches_dense(kind, max_entropy, impl, monkeypatch):
     """Forward and all three gradients at the 1e-3 contract on rows far from uniform (row entropy < 1 nat for `dominant`, against
     ln N = 7 for the near-init rows every other case has): the regime where fp16-rounded probabilities / dS would spend the budget.
     The shipped kernels carry P and dS as fp16 hi+lo pairs like every other operand; the observed error is printed and held to a
     tenth of the contract."""
     from dgdm_histopath_lab_amd import ops
+    monkeypatch.setattr(ops, "ATTN_BWD_FUSED", impl != "fp16x2-two-pass")
     ptr, H = [0, 900, 2000], 8
     C = H * 16
     qkv, pos = _sharp_case(kind, ptr, H, 41)
@@ -268,7 +273,7 @@ def test_attn_backward_on_sharp_rows_matches_dense(kind, max_entropy, impl):
     gout = torch.randn(ptr[-1], C, generator=g)
     d = qkv.to(DEV).requires_grad_(True)
     plan = ops.AttnPlan(ptr, DEV)
-    fn = ops._SpatialAttentionH if impl == "fp16x2" else ops._SpatialAttention
+    fn = ops._SpatialAttentionH if impl.startswith("fp16x2") else ops._SpatialAttention
     o = fn.apply(d, pos.to(DEV), plan, H, 0.25, 1.0, 0.0, 0)
     o.backward(gout.to(DEV))
     ro, gq, gk, gv = dense_reference(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], pos, ptr, H, 1.0, gout)
@@ -289,7 +294,8 @@ def fused_backward(monkeypatch):
 
 
 @pytest.mark.parametrize("ptr,H,gscale", [([0, 17], 8, 1.0), ([0, 65, 130, 131], 8, 1.0), ([0, 200, 263], 2, 1.0), ([0, 333, 1000], 8, 1.0),
-                                           ([0, 129, 500], 16, 1.0), ([0, 333, 1000], 8, 1e-7), ([0, 64, 128, 1100, 1101], 4, 3e4)])
+                                           ([0, 129, 500], 16, 1.0), ([0, 333, 1000], 8, 1e-7), ([0, 64, 128, 1100, 1101], 4, 3e4),
+                                           ([0, 100], 1, 1.0), ([0, 257, 600, 1112], 3, 1.0)])
 def test_attn_fused_backward_matches_dense(fused_backward, ptr, H, gscale):
     """Same cases and tolerances as test_attn_split_fp16_backward_matches_dense, through the one-pass backward: all three gradients
     against the dense float64 reference, bitwise repeatable, and dK / dV BIT-IDENTICAL to the two-pass kernels' (the key-stationary
@@ -334,7 +340,7 @@ def test_attn_fused_backward_with_dropout_and_scratch_groups(fused_backward, mon
         ops._SpatialAttentionH.apply(d, pos.to(DEV), plan, H, 0.25, 1.0, p, seed).backward(gout.to(DEV))
         return d.grad
     one = grads()
-    monkeypatch.setattr(ops, "ATTN_BWD_FUSED_BUDGET", 3 * 11 * H * 4096)          # ~3 key blocks of the 11-block graph per launch
+    monkeypatch.setattr(ops, "ATTN_BWD_FUSED_BUDGET", 11 * H * 4096)              # one key super-block of the 11-block graph per launch
     many = grads()
     monkeypatch.setattr(ops, "ATTN_BWD_FUSED", False)
     two = grads()
