@@ -10,7 +10,7 @@ rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $OUT -- python3 $R/bench.py --steps 16 --warmup 3 --no-cpu-baseline --no-gather --no-strict --sustain-seconds 0 "$@" > $OUT/bench_line.json 2> $OUT/bench.err
 DB=$(find $OUT -name "*results.db" | head -1)
-python3 $R/tools/kernel_stats_from_db.py $DB "${MARKER:-k_attn_h_bwd_dkv}" 60 $R/gpurun_out/${TAG}_launch_sequence.txt > $R/gpurun_out/${TAG}_bench_kernel_stats.txt
+python3 $R/tools/kernel_stats_from_db.py $DB "${MARKER:-k_attn_h_fwd}" 60 $R/gpurun_out/${TAG}_launch_sequence.txt > $R/gpurun_out/${TAG}_bench_kernel_stats.txt
 cp $OUT/bench_line.json $R/gpurun_out/${TAG}_bench_kernel_stats_bench_line.json
 rm -f $DB
 head -40 $R/gpurun_out/${TAG}_bench_kernel_stats.txt

@@ -14,7 +14,7 @@ cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_$TAG && mkdir -p /tmp/prof_$TAG
 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG/trace -o bench -- python3 $BENCH_PROF > $OUT/${TAG}_trace_bench_line.json 2> /tmp/prof_$TAG/trace.err || { tail -5 /tmp/prof_$TAG/trace.err; exit 1; }
 DB=$(find /tmp/prof_$TAG/trace -name "*.db" | head -1)
-python3 $REPO/tools/kernel_stats_from_db.py $DB k_attn_h_bwd_dkv 400 $OUT/${TAG}_sequence.txt > $OUT/${TAG}_kernel_stats.txt && head -30 $OUT/${TAG}_kernel_stats.txt
+python3 $REPO/tools/kernel_stats_from_db.py $DB k_attn_h_fwd 400 $OUT/${TAG}_sequence.txt > $OUT/${TAG}_kernel_stats.txt && head -30 $OUT/${TAG}_kernel_stats.txt
 echo "trace done"
 [ -n "$ONLY_TRACE" ] && exit 0      # ONLY_TRACE=1: no PMC passes
 PMCB="$REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-gather --no-strict --sustain-seconds 0"
