@@ -26,6 +26,16 @@
 #ifndef DGDM_FUSED_SKIP
 #define DGDM_FUSED_SKIP 0
 #endif
+// tuning switches of round 4, both measured and left OFF (same-box A/B through tools/build_variant_lib.sh, kernel alone, dropout on,
+// 4 x 10k nodes): plain 3.02 ms | DEFER (the dQ product of key tile kt runs after the score phase of kt + 1, out of a second
+// transposition tile) 3.05-3.08 | RAWBAR (the closing barrier of an iteration leaves the partial store in flight: s_waitcnt
+// vmcnt(1) + s_barrier instead of __syncthreads) 3.19-3.20 | a second staging buffer for the query blocks 3.13.
+#ifndef DGDM_FUSED_DEFER
+#define DGDM_FUSED_DEFER 0
+#endif
+#ifndef DGDM_FUSED_RAWBAR
+#define DGDM_FUSED_RAWBAR 0
+#endif
 
 namespace {
 
@@ -102,7 +112,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
   constexpr int R_BYTES = R_HEAD * 2, SC_BYTES = HB * 4, POS_BYTES = HB * 8;
   constexpr int BUF_BYTES = 2 * R_BYTES + 2 * SC_BYTES + POS_BYTES;
   constexpr int KOWN_BYTES = 4 * R_BYTES;
-  constexpr int T_BYTES = 2 * 4 * T_WAVE * 2;      // two tiles per wave: the dQ product of key tile kt runs under the score phase of kt + 1
+  constexpr int T_BYTES = (DGDM_FUSED_DEFER ? 2 : 1) * 4 * T_WAVE * 2;      // two tiles per wave: the dQ product of key tile kt runs under the score phase of kt + 1
   constexpr int X_BYTES = 4 * HB * 16 * 4;
   __shared__ __attribute__((aligned(16))) char smem[BUF_BYTES + KOWN_BYTES + T_BYTES + X_BYTES];
   const DropCfg dc(drop_p);
@@ -129,7 +139,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
     dma_to_lds<POS_BYTES>(pos_b + (int64_t)(blk0 + qb) * HB * 2, base + 2 * R_BYTES + 2 * SC_BYTES, tid);
   };
   const _Float16* Kown = reinterpret_cast<const _Float16*>(smem + BUF_BYTES) + wave * R_HEAD;      // this wave's K row image (64 keys)
-  _Float16* Tw0 = reinterpret_cast<_Float16*>(smem + BUF_BYTES + KOWN_BYTES) + wave * 2 * T_WAVE;
+  _Float16* Tw0 = reinterpret_cast<_Float16*>(smem + BUF_BYTES + KOWN_BYTES) + wave * (DGDM_FUSED_DEFER ? 2 : 1) * T_WAVE;
   float* X = reinterpret_cast<float*>(smem + BUF_BYTES + KOWN_BYTES + T_BYTES);
 
   // the four waves' K images: each wave copies its own (4 KiB = 4 pieces of 1 KiB), then the first query block
@@ -191,7 +201,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
     // kt + 1 has been issued), so that the LDS round trip of the tile is not on the critical path.
     auto dq_product = [&](int kt) {
       if (DGDM_FUSED_SKIP & 4) return;
-      const _Float16* Tr = Tw0 + (kt & 1) * T_WAVE;
+      const _Float16* Tr = Tw0 + (DGDM_FUSED_DEFER ? (kt & 1) : 0) * T_WAVE;
       const f16x4 khi = tr4_image(Kown, 0, kt, lane), klo = tr4_image(Kown, 1, kt, lane);
       const f16x8 ka1 = cat4(khi, khi), ka2 = cat4(klo, zero4);
 #pragma unroll
@@ -203,7 +213,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
     };
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) {
-      _Float16* Tw = Tw0 + (kt & 1) * T_WAVE;
+      _Float16* Tw = Tw0 + (DGDM_FUSED_DEFER ? (kt & 1) : 0) * T_WAVE;
       // lane (key = 16 kt + j, G), reg r <-> query 16t + 4G + r
       f32x4 dist[NT];
 #pragma unroll
@@ -255,7 +265,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
           for (int r = 0; r < 4; ++r) ds[t][r] = p[t][r] * dpv[r];
         }
       }
-      if (kt > 0) dq_product(kt - 1);
+      if (DGDM_FUSED_DEFER && kt > 0) dq_product(kt - 1);
 #pragma unroll
       for (int tp = 0; tp < NT / 2; ++tp) {
         f16x8 ph, pl, sh, sl;
@@ -278,8 +288,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
         dk[kt] = mfma_h(load_tr_pair(Qimg, 1, 2 * tp, lane), sh, dk[kt]);
         dk[kt] = mfma_h(qhi, sl, dk[kt]);
       }
+      if (!DGDM_FUSED_DEFER) dq_product(kt);
     }
-    dq_product(KT - 1);
+    if (DGDM_FUSED_DEFER) dq_product(KT - 1);
     if (!(DGDM_FUSED_SKIP & 6)) {
       float* Xw = X + (wave * HB) * 16;
 #pragma unroll
@@ -299,7 +310,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
       if (!(DGDM_FUSED_SKIP & 1)) *reinterpret_cast<f32x4*>(o) = sum;
       else if (sum[0] == 123.456f) dq_part[0] = sum[1];
     }
-    __syncthreads();      // the DMA has landed; X and T may be rewritten
+    // closing barrier: the next block's DMA has landed and every wave has read X.  The partial-tile store was issued AFTER this wave's
+    // DMA pieces, so waiting for all but the youngest vector-memory operation retires the DMA and leaves the store in flight (a full
+    // __syncthreads waits for its acknowledgement as well: ~1-2 us per iteration)
+#if DGDM_FUSED_RAWBAR
+    if (!(DGDM_FUSED_SKIP & 7)) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#else
+    __syncthreads();
+#endif
   }
 
   if (blk_ok) {

@@ -7,7 +7,8 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd); OUT=$ROOT/dgdm_histopath_lab_amd/lib/$NA
 FLAGS="-O3 --offload-arch=gfx950 -std=c++17 -fPIC -fvisibility=hidden -Wno-unused-function $* -I $ROOT/include -I $ROOT/dgdm_histopath_lab_amd/csrc"
 for f in $ROOT/dgdm_histopath_lab_amd/csrc/*.hip; do
   b=$(basename $f .hip); extra=""
-  case $b in attn_h_bwd) extra="-mllvm -amdgpu-mfma-vgpr-form=1 -fno-honor-nans";; attn_h_fwd) extra="-fno-honor-nans";; esac
+  case $b in attn_h_bwd) extra="-mllvm -amdgpu-mfma-vgpr-form=1 -fno-honor-nans";; attn_h_fwd) extra="-fno-honor-nans";;
+             attn_h_bwd_fused) extra="${FUSED_EXTRA--mllvm -amdgpu-mfma-vgpr-form=1 -fno-honor-nans}";; esac
   /opt/rocm/bin/hipcc $FLAGS $extra -c $f -o $OUT/obj/$b.o 2>/dev/null &
   while [ $(jobs -r | wc -l) -ge 6 ]; do sleep 0.2; done
 done
