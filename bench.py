@@ -541,18 +541,20 @@ def main():
         issued_x = {"attn_fwd": (4 + 3 + 2 * 1.0) / 2, "attn_bwd_dq": (4 + 4 + 3) / 3, "attn_bwd_dkv": (4 + 4 + 3 + 3) / 4,
                     "attn_bwd_fused": (4 + 4 + 3 + 3 + 4) / 5}
 
-        def attention_roofline(tm, names, fp16_pipe, graphed_note, valu_path=None, traffic_path=None):
-            dom = max((k for k in flops if k in tm), key=lambda k: tm[k][1]) if any(k in tm for k in flops) else None
+        def attention_roofline(tm, names, fp16_pipe, graphed_note, valu_path=None, traffic_path=None, timed_steps=1):
+            dom = max((k for k in flops if k in tm), key=lambda k: tm[k][1] * tm[k][0]) if any(k in tm for k in flops) else None
             if dom is None:
                 return {"note": "no attention kernel was timed"}
             ms = tm[dom][1]
-            tf = flops[dom] / (ms * 1e-3) / 1e12
+            # launches of the kernel per step (the one-pass backward runs once per scratch group: 1 at the headline batch)
+            per_step = max(1.0, tm[dom][0] / max(1, timed_steps))
+            tf = flops[dom] / per_step / (ms * 1e-3) / 1e12
             peak = FP16_MFMA_PEAK_TFLOPS if fp16_pipe else FP32_MFMA_PEAK_TFLOPS
             # ALGORITHMIC FLOP of the reference's products (2 N^2 H d each) per second of the dominant kernel,
             # priced against the dense peak of the matrix pipe the kernel RUNS ON
             mfma = {"bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
                     "pipe": "f16 dense matrix pipe (v_mfma_f32_16x16x32_f16)" if fp16_pipe else "fp32 matrix pipe (v_mfma_f32_16x16x4_f32)",
-                    "algorithmic_flop": flops[dom]}
+                    "algorithmic_flop": flops[dom] / per_step, "launches_per_step": per_step}
             if fp16_pipe:
                 mfma.update({"mfma_dtype": "every operand (Q', K, V, dO, P, dS) as fp16 hi+lo, fp32 accumulate",
                              "products": {"attn_fwd": "S, PV", "attn_bwd_dq": "S, dP, dS K", "attn_bwd_dkv": "S, dP, P^T dO, dS^T Q",
@@ -586,11 +588,12 @@ def main():
         roofline = {"note": "not computed for this run; see the fixed-size headline run"}
         if not args.mixed:
             roofline = attention_roofline(timers, k16 if split else k32, split, ev_note,
-                                          None if split else PMC_VALU_FP32, None if split else PMC_TRAFFIC_FP32)
+                                          None if split else PMC_VALU_FP32, None if split else PMC_TRAFFIC_FP32,
+                                          timed_steps=(min(args.steps, 5) if graphed and stream is None else args.steps))
         if strict is not None:
             strict["roofline"] = attention_roofline(strict.pop("_timers"), k32, False,
                                                     "HIP events around eager launches of the fp32 step right after its timed region",
-                                                    PMC_VALU_FP32, PMC_TRAFFIC_FP32)
+                                                    PMC_VALU_FP32, PMC_TRAFFIC_FP32, timed_steps=3)
         result = {
             "metric": "slides/sec (DGDM fwd+bwd, 10k-node/768-feat graphs)", "value": round(world * args.batch * args.steps / dt, 3),
             "unit": "slides/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -250,7 +250,7 @@ class PackedOperands:
 ATTN_GRAD_TARGET = 0.25
 ATTN_BWD_CONCURRENT = False     # dQ pass on a side stream beside the dK/dV pass (tools/bench_with.py A/B switch)
 ATTN_BWD_FUSED = True           # dQ, dK, dV in one key-stationary pass + a fixed-order reduction of the partial dQ tiles (False: two passes)
-ATTN_BWD_FUSED_BUDGET = 8 << 30  # bytes of partial-tile scratch per launch (0.8 GB at 4 x 10k nodes x 8 heads; 10 GB at 50k nodes x 16)
+ATTN_BWD_FUSED_BUDGET = 16 << 30  # bytes of partial-tile scratch per launch (0.8 GB at 4 x 10k nodes x 8 heads; 10 GB for one 50k-node graph x 16 heads)
 _SIDE_STREAMS: dict = {}
 
 
