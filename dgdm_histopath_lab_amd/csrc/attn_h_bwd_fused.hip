@@ -36,6 +36,9 @@
 #ifndef DGDM_FUSED_RAWBAR
 #define DGDM_FUSED_RAWBAR 0
 #endif
+#ifndef DGDM_FUSED_PAIRWISE
+#define DGDM_FUSED_PAIRWISE 1
+#endif
 
 namespace {
 
@@ -238,6 +241,44 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
       DropLaneK dl;
       dl.F = dlF[kt]; dl.me = dl_me; dl.mo = dl_mo;
 
+      if (DGDM_FUSED_DEFER && kt > 0) dq_product(kt - 1);
+#if DGDM_FUSED_PAIRWISE
+      // scores of ONE pair of query tiles at a time (32 queries = the reduction depth of one dV / dK MFMA), split and consumed
+      // before the next pair is formed: half the live score registers of the all-tiles-first order
+#pragma unroll
+      for (int tp = 0; tp < NT / 2; ++tp) {
+        f32x4 p[2], ds[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int t = 2 * tp + u;
+          const f16x8 qa = *reinterpret_cast<const f16x8*>(Qimg + t * 512 + aoff);
+          const f16x8 ga = *reinterpret_cast<const f16x8*>(Gimg + t * 512 + aoff);
+          const f32x4 lq = *reinterpret_cast<const f32x4*>(&Ls[16 * t + 4 * G]);
+          const f32x4 nd = *reinterpret_cast<const f32x4*>(&Ds[16 * t + 4 * G]);
+          f32x4 s = mfma_h(qa, kb1, sub4(lq, dist[t]));
+          s = mfma_h(qa, kb2, s);
+          f32x4 dpv = mfma_h(ga, vb1[kt], nd);
+          dpv = mfma_h(ga, vb2[kt], dpv);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) p[u][r] = __builtin_amdgcn_exp2f(s[r]);
+          if (DROP) {
+            uint32_t e[4];
+            drop_words_k(dl, (uint32_t)(qb0 + 16 * t), lcq, e);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const bool kept = (int)e[r] >= dc.ts32;
+              ds[u][r] = p[u][r] * (kept ? dpv[r] : nd[r]);
+              p[u][r] = kept ? p[u][r] : 0.f;
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ds[u][r] = p[u][r] * dpv[r];
+          }
+        }
+        f16x8 ph, pl, sh, sl;
+        split8(p[0], p[1], &ph, &pl);
+        split8(ds[0], ds[1], &sh, &sl);
+#else
       f32x4 p[NT], ds[NT];
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
@@ -265,12 +306,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
           for (int r = 0; r < 4; ++r) ds[t][r] = p[t][r] * dpv[r];
         }
       }
-      if (DGDM_FUSED_DEFER && kt > 0) dq_product(kt - 1);
 #pragma unroll
       for (int tp = 0; tp < NT / 2; ++tp) {
         f16x8 ph, pl, sh, sl;
         split8(p[2 * tp], p[2 * tp + 1], &ph, &pl);
         split8(ds[2 * tp], ds[2 * tp + 1], &sh, &sl);
+#endif
         // dS' of the lane's key for queries 32 tp + 4G .. +3 and 32 tp + 16 + 4G .. +3 -> the transposition tile [part][key][q]
         if (!(DGDM_FUSED_SKIP & 4)) {
           typedef _Float16 h4 __attribute__((ext_vector_type(4)));
