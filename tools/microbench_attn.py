@@ -3,6 +3,7 @@ import json, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dgdm_histopath_lab_amd import ops
+ops.ATTN_BWD_FUSED = False        # the variant loops below time the two-pass kernels; the one-pass backward has its own section
 dev = "cuda:0"
 B, n, H = int(os.environ.get("B", 4)), int(os.environ.get("N", 10000)), 8
 ptr = [i * n for i in range(B + 1)]
