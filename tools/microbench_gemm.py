@@ -24,6 +24,8 @@ def t(fn, iters=40):
 dev = "cuda:0"
 shapes = [(40000, 768, 512), (40000, 512, 512), (40000, 544, 512), (40000, 544, 256), (40000, 288, 256), (40000, 160, 128), (40000, 128, 128),
           (40000, 128, 384), (40000, 512, 256), (40000, 256, 128), (20000, 160, 128), (10000, 160, 128), (5000, 160, 128)]
+if os.environ.get("SHAPES") == "unet":     # the narrow kernel's shapes at the U-Net's levels (N <= 128)
+    shapes = [(m, k, n) for m in (40000, 20000, 10000, 5000) for (k, n) in ((160, 128), (128, 128), (128, 64))]
 maths = os.environ.get("MATHS", "bf16x3,f16x2reg,f16x2").split(",")   # f16x2reg: the register-staged kernels (weight images off)
 
 
