@@ -1,24 +1,28 @@
-// K4 backward, split-fp16 path, ONE pass for dQ, dK and dV (round 4).
+// K4 backward, split-fp16 path, ONE pass for dQ, dK and dV (round 4; the default backward).
 //
-// attn_h_bwd.hip recomputes S, dP, exp2, the distance and the dropout word twice -- once per query tile for dQ (lane = query) and
+// attn_h_bwd.hip evaluates S, dP, exp2, the distance and the dropout word twice -- once per query tile for dQ (lane = query) and
 // once per key tile for dK / dV (lane = key) -- because an MFMA product reduces over the index its operands hold in REGISTERS:
 // dK / dV reduce over queries (scores as [query rows in registers][key in lanes]), dQ reduces over keys (the transposed
 // arrangement).  Here the key-stationary pass of k_attn_h_bwd_dkv also produces dQ:
-//   * per (head, query block) every wave has dS'[64 q][its 16 keys] in registers, already split into fp16 hi / lo for the dK
-//     product.  The same halfs go through a wave-private LDS tile T[part][key][q] (8-byte writes) and come back TRANSPOSED
+//   * a workgroup owns a key SUPER-block -- 4 consecutive 64-key blocks of one graph, one per wave -- and ONE head; per staged
+//     query block (64 queries) a wave runs its 4 key tiles of 16 keys one after the other, each exactly as k_attn_h_bwd_dkv does
+//     (S' and keep.dP - delta out of the MFMAs, P' = exp2, dropout word, dS', fp16 hi / lo splits, dV and dK products);
+//   * the dS' halfs of a key tile also go through a wave-private LDS tile T[part][key][q] (8-byte writes) and come back TRANSPOSED
 //     (ds_read_b64_tr_b16: 4 keys x 16 queries per lane group) as the B operand of
-//         dQ^T[d][q] += K^T[d][key] dS'^T[key][q]          (reduction over the wave's 16 keys)
+//         dQ^T[d][q] += K^T[d][key] dS'^T[key][q]          (reduction over the tile's 16 keys)
 //     with the 32 reduction slots of v_mfma_f32_16x16x32_f16 = 16 keys x {hi, lo}:  A1 = [K_hi | K_hi], A2 = [K_lo | 0],
 //     B = [dS_hi ; dS_lo]  =>  A1.B + A2.B = K_hi (dS_hi + dS_lo) + K_lo dS_hi   (lo.lo dropped, as everywhere else).
-//     No vector instruction is added: the transposition is LDS traffic, the product two MFMAs per 16 x 16 queries x keys;
-//   * the four waves' partial dQ tiles (their 16 keys each) meet in LDS between the two barriers the single-buffered loop has
-//     anyway (write before "everyone is done with the block", sum + store while the next block's DMA is in flight), and leave as
-//     ONE 64 x 16 fp32 tile per (key block, query block, head) into a partial buffer;
-//   * k_attn_dq_reduce sums the key blocks' partials of a query block in key-block order (fixed order: bitwise repeatable, no
-//     float atomics) and applies the final scale.
-// Cost of the second stage: N^2 H / 64 * 64 B of partials written and read once (3.2 GB at 4 x 10k nodes, 8 heads), against a
-// whole second evaluation of every score.  The host cuts the key blocks into groups so that the buffer stays within a budget
-// (ops.py); the reduction then accumulates group after group.
+//     No vector instruction is added: the transposition is LDS traffic, the product two MFMAs per 16 x 16 queries x keys, and the
+//     wave's dQ tile (64 q x 16 d over its 64 keys) accumulates in registers across the four key tiles;
+//   * the four waves' dQ tiles meet in LDS between the two barriers the single-buffered loop has anyway (written before "everyone
+//     is done with the block", summed in fixed order + stored while the next block's DMA is in flight) and leave as ONE 64 x 16
+//     fp32 tile per (super-block, query block, head) into a scratch buffer;
+//   * k_attn_dq_reduce sums the super-blocks' tiles of a query block in super-block order (fixed association: bitwise repeatable,
+//     no float atomics) and applies the final scale.
+// Cost of the second stage: N^2 H / 256 * 64 B of partials written and read once (0.8 GB at 4 x 10k nodes, 8 heads), against a
+// whole second evaluation of every score.  A first form with one 64-key block per workgroup (3.2 GB of partials, four times the
+// cross-wave stages) was slower than the two passes; with 256 keys it is 3.18 against 3.59 ms.  The host cuts
+// the super-blocks into groups so that the scratch stays within a budget (ops.py); the reduction accumulates group after group.
 #include "attn_h.hpp"
 
 // diagnostic builds only (tools/build_variant_lib.sh -DDGDM_FUSED_SKIP=n): 1 = no partial store, 2 = no cross-wave stage either,
