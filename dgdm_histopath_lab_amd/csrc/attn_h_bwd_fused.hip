@@ -52,17 +52,31 @@
 namespace {
 
 constexpr float NEG_BIG = -1.0e30f;
-constexpr int T_LD = 72;                       // halfs per key row of the transposition tile (64 queries + 8: 144-byte rows spread the
-                                               // four rows of a transposed read over distinct banks)
+// The transposition tile [key 0..15][query 0..63] of a wave (hi part, lo part).  It is WRITTEN by key rows (lane = key j, 8-byte
+// chunks of 4 queries: a 16-lane store group holds ONE chunk column of 16 rows) and READ transposed (a 32-lane read group holds 8
+// rows x 4 consecutive chunks).  DGDM_FUSED_SWIZZLE 1 (shipped): unpadded 128-byte rows, chunk c of row k stored at chunk
+// c ^ g(k), g = the bit permutation (k2 k1 k3 k0) of the row number: the 16 rows of a store group land in 16 distinct bank pairs
+// and the 8 x 4 chunks of a read group in 32 distinct ones -- no bank conflict on either side.  0: the round-4 layout, rows padded
+// to 144 bytes: stores two-way conflicted (rows k and k + 8), transposed reads two-way on 4 of 64 banks (row 7 wraps onto row 0);
+// together with the four-way conflicts of the X stores below that was 72 extra LDS cycles per key tile, 12.7 % of the CU cycles of
+// the kernel (SQ_LDS_BANK_CONFLICT, profiles/r04_pmc_lds.json).
+#ifndef DGDM_FUSED_SWIZZLE
+#define DGDM_FUSED_SWIZZLE 1
+#endif
+constexpr int T_LD = DGDM_FUSED_SWIZZLE ? 64 : 72;      // halfs per key row
 constexpr int T_PART = 16 * T_LD;              // halfs per part (hi / lo)
 constexpr int T_WAVE = 2 * T_PART;             // halfs per wave
+__device__ __forceinline__ int t_swz(int k) {   // g(k) in units of halfs (4 per chunk)
+  return DGDM_FUSED_SWIZZLE ? 4 * ((((k >> 1) & 3) << 2) | (((k >> 3) & 1) << 1) | (k & 1)) : 0;
+}
 
-// 4 rows x 16 halfs, transposed: lane (j, G) receives column j of rows 4G .. 4G+3 of a [row][T_LD] tile starting at column c0
+// 4 rows x 16 halfs, transposed: lane (j, G) receives column j of rows 4G .. 4G+3 of the tile, columns c0 .. c0 + 15
 __device__ __forceinline__ f16x4 tr4_tile(const _Float16* __restrict__ tile, int c0, int lane) {
   typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
   typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
   const int j = lane & 15, G = lane >> 4;
-  const _Float16* p = tile + (4 * G + (j >> 2)) * T_LD + c0 + 4 * (j & 3);
+  const int k = 4 * G + (j >> 2);
+  const _Float16* p = tile + k * T_LD + ((c0 + 4 * (j & 3)) ^ t_swz(k));
   const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p);
   return __builtin_bit_cast(f16x4, a);
 }
@@ -75,6 +89,7 @@ __device__ __forceinline__ f16x4 tr4_image(const _Float16* __restrict__ rimg_hea
   const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p);
   return __builtin_bit_cast(f16x4, a);
 }
+__device__ __forceinline__ int x_swz(int q) { return DGDM_FUSED_SWIZZLE ? (q >> 1) & 3 : 0; }
 __device__ __forceinline__ f16x8 cat4(f16x4 a, f16x4 b) { return f16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}; }
 
 // Key SUPER-blocks: 4 consecutive 64-key blocks of ONE graph (the last super-block of a graph may hold fewer); super-blocks are
@@ -326,11 +341,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
         // dS' of the lane's key for queries 32 tp + 4G .. +3 and 32 tp + 16 + 4G .. +3 -> the transposition tile [part][key][q]
         if (!(DGDM_FUSED_SKIP & 4)) {
           typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-          _Float16* th = Tw + j * T_LD + 32 * tp + 4 * G;
-          *reinterpret_cast<h4*>(th) = h4{sh[0], sh[1], sh[2], sh[3]};
-          *reinterpret_cast<h4*>(th + 16) = h4{sh[4], sh[5], sh[6], sh[7]};
-          *reinterpret_cast<h4*>(th + T_PART) = h4{sl[0], sl[1], sl[2], sl[3]};
-          *reinterpret_cast<h4*>(th + T_PART + 16) = h4{sl[4], sl[5], sl[6], sl[7]};
+          _Float16* tr = Tw + j * T_LD;
+          const int c0 = (32 * tp + 4 * G) ^ t_swz(j), c1 = (32 * tp + 4 * G + 16) ^ t_swz(j);
+          *reinterpret_cast<h4*>(tr + c0) = h4{sh[0], sh[1], sh[2], sh[3]};
+          *reinterpret_cast<h4*>(tr + c1) = h4{sh[4], sh[5], sh[6], sh[7]};
+          *reinterpret_cast<h4*>(tr + T_PART + c0) = h4{sl[0], sl[1], sl[2], sl[3]};
+          *reinterpret_cast<h4*>(tr + T_PART + c1) = h4{sl[4], sl[5], sl[6], sl[7]};
         }
         const f16x8 ghi = load_tr_pair(Gimg, 0, 2 * tp, lane), qhi = load_tr_pair(Qimg, 0, 2 * tp, lane);
         dv[kt] = mfma_h(ghi, ph, dv[kt]);                                       // dV^T[d=j][key] += dO^T[d][q] P[q][key]
@@ -346,7 +362,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
     if (!(DGDM_FUSED_SKIP & 6)) {
       float* Xw = X + (wave * HB) * 16;
 #pragma unroll
-      for (int t = 0; t < NT; ++t) *reinterpret_cast<f32x4*>(Xw + (16 * t + j) * 16 + 4 * G) = dqp[t];      // X[wave][q = 16 t + j][d = 4G .. 4G+3]
+      for (int t = 0; t < NT; ++t)      // X[wave][q = 16 t + j][d = 4G .. 4G+3]; the row's four 16-byte pieces rotated by (q >> 1) & 3:
+        *reinterpret_cast<f32x4*>(Xw + (16 * t + j) * 16 + 4 * (G ^ x_swz(j))) = dqp[t];      // 8 rows of a store group -> 8 distinct bank quads
     } else if (dqp[0][0] == 123.456f) {
       X[0] = dqp[1][0] + dqp[2][1] + dqp[3][2];      // (diagnostic build: keep the product alive)
     }
@@ -354,7 +371,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
     if (DGDM_FUSED_NBUF == 1 && qb + 1 < nbg) stage(qb + 1);
     if (!(DGDM_FUSED_SKIP & 6)) {   // ... and while the next block's DMA is in flight: the four waves' tiles summed (fixed order) and stored
       const int q = tid >> 2, d4 = tid & 3;
-      const float* xs = X + q * 16 + 4 * d4;
+      const float* xs = X + q * 16 + 4 * (d4 ^ x_swz(q));
       const f32x4 a0 = *reinterpret_cast<const f32x4*>(xs), a1 = *reinterpret_cast<const f32x4*>(xs + HB * 16);
       const f32x4 a2 = *reinterpret_cast<const f32x4*>(xs + 2 * HB * 16), a3 = *reinterpret_cast<const f32x4*>(xs + 3 * HB * 16);
       const f32x4 sum = (a0 + a1) + (a2 + a3);
