@@ -18,7 +18,9 @@ def _oracle(scores, ei, ratio):
 
 @pytest.mark.parametrize("n,ratio,kind", [(1, 0.5, "rand"), (2, 0.5, "rand"), (7, 0.5, "rand"), (1024, 0.5, "rand"), (1025, 0.5, "rand"),
                                           (40000, 0.5, "rand"), (40000, 0.5, "tanh"), (5000, 0.25, "ties"), (3000, 0.5, "allsame"),
-                                          (4097, 0.9, "signed0"), (100000, 0.1, "rand"), (2048, 1.0, "rand")])
+                                          (4097, 0.9, "signed0"), (100000, 0.1, "rand"), (2048, 1.0, "rand"),
+                                          (20000, 0.5, "ties"), (20481, 0.3, "rand"), (50000, 0.5, "rand"), (53248, 0.5, "tanh"),
+                                          (53249, 0.5, "rand"), (40960, 1.0, "allsame"), (12289, 0.5, "signed0")])
 def test_topk_perm_bit_exact(n, ratio, kind):
     from dgdm_histopath_lab_amd import ops
     g = torch.Generator().manual_seed(n)
