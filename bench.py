@@ -37,6 +37,9 @@ MODEL_CFG = dict(node_features=FEATS, hidden_dims=[512, 256, 128], num_diffusion
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md, dense fp32 matrix peak
 FP16_MFMA_PEAK_TFLOPS = 2516.6  # MI355X_MICROARCH.md, dense fp16 matrix peak
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md, HBM3E spec
+# what the PMC passes count (TCC_EA0_RDREQ / WRREQ and FETCH/WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes): bytes that left
+# the L2 towards the fabric.  Reads served by the 256 MiB Infinity Cache are INCLUDED -- an upper bound of what HBM itself moved.
+TRAFFIC_KIND = "fabric bytes per launch (L2 misses: Infinity-Cache hits included, so an upper bound of the HBM bytes)"
 
 
 def _latest_profile(stem):
@@ -54,6 +57,30 @@ PMC_VALU_FP32 = _latest_profile("fp32_pmc_valu")
 PMC_TRAFFIC_LARGE = _latest_profile("large_pmc_traffic")   # the same passes of `bench.py --large` (configs[3])
 PMC_VALU_LARGE = _latest_profile("large_pmc_valu")
 PMC_GATHER = _latest_profile("gather_pmc_traffic")       # tools/profile_gather.sh: the north-star gather microbenchmark, warm and cold
+
+
+def arithmetic_error_note():
+    """The sentence of the `dtype` field that says how far the default arithmetic sits from float64, built from the committed
+    report it cites (tools/arithmetic_error_report.py -> profiles/rNN_arithmetic_error_vs_float64.txt: the `ALL` row of every
+    case); empty when no report is committed -- the line never carries a literal that no file backs."""
+    import glob
+    import re
+    c = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_arithmetic_error_vs_float64.txt")))
+    if not c:
+        return ""
+    case, rows = None, []
+    for ln in open(c[-1]):
+        m = re.match(r"# case (\w+):", ln)
+        if m:
+            case = m.group(1)
+        m = re.match(r"ALL\s+\d+\s+(\S+) \| \S+\s+(\S+) \| \S+\s+(\S+) \|", ln)
+        if m and case:
+            rows.append(f"{case} {m.group(1)} / {m.group(2)} / {m.group(3)}")
+    if not rows:
+        return ""
+    return ("; worst rel-L2 of any live parameter gradient of one step against the float64 oracle, default arithmetic / HIP kernels with "
+            "fp32 operands / torch fp32 on the CPU: " + ", ".join(rows) + f" ({os.path.relpath(c[-1], ROOT)}, held by tests/test_hip_model.py::"
+            "test_default_arithmetic_is_at_the_error_level_of_fp32)")
 
 
 def attention_flops(num_graph_nodes, heads, head_dim, products):
@@ -75,10 +102,16 @@ def _pmc_kernel(path, kernel):
     return None          # a kernel that was not profiled has NO counter figure (never another instantiation's)
 
 
+def _fabric_bytes(entry):
+    """Bytes per launch of a PMC summary entry (`fabric_bytes_per_launch`; summaries of rounds 1-4 call the same figure
+    `hbm_bytes_per_launch`)."""
+    return entry.get("fabric_bytes_per_launch", entry.get("hbm_bytes_per_launch"))
+
+
 def pmc_traffic(kernel, path=None):
     """HBM bytes per launch of `kernel` from the committed PMC passes (same command, same sizes), or None."""
     v = _pmc_kernel(path or PMC_TRAFFIC, kernel)
-    return None if v is None else v["hbm_bytes_per_launch"]
+    return None if v is None else _fabric_bytes(v)
 
 
 def pmc_valu(kernel, path=None):
@@ -142,13 +175,13 @@ def gather_microbench(dev, iters=200, cold_iters=12):
     except (OSError, KeyError, ValueError, TypeError):
         pass
     src = None if PMC_GATHER is None else f"committed PMC passes {os.path.relpath(PMC_GATHER, ROOT)} (tools/profile_gather.sh), kernel {kname}"
-    traffic = None if warm_pmc is None else warm_pmc["hbm_bytes_per_launch"]
+    traffic = None if warm_pmc is None else _fabric_bytes(warm_pmc)
     return {"kernel": "dgdm_spmm (k_spmm<64,3,4,false>)", "workload": f"{NODES} nodes x {FEATS} feat, {EDGES}+{NODES} entries",
             "bound": "hbm", "achieved": round(by / us / 1e3, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": round(min(by / us / 1e3 / HBM_PEAK_GBPS, 1.0), 4), "traffic": traffic, "traffic_source": src,
+            "frac": round(by / us / 1e3 / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": src,
             "traffic_over_algorithmic": None if traffic is None else round(traffic / by, 3),
             "traffic_over_unique": None if traffic is None else round(traffic / ub, 3),
-            "cold_traffic": None if cold_pmc is None else cold_pmc["hbm_bytes_per_launch"],
+            "cold_traffic": None if cold_pmc is None else _fabric_bytes(cold_pmc), "traffic_kind": TRAFFIC_KIND,
             "us_per_launch": round(us, 2), "algorithmic_bytes": by, "unique_bytes": ub,
             "note": "back-to-back launches: the table is re-read from L2 / Infinity Cache (cache-resident figure)",
             "unique_bytes_GBps": round(ub / us / 1e3, 1), "unique_frac": round(ub / us / 1e3 / HBM_PEAK_GBPS, 4),
@@ -270,6 +303,44 @@ def cpu_baseline(nodes, edges):
             "cpu": model, "physical_cores": physical, "logical_cpus": logical}
 
 
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher around it: start the N ranks as FRESH child processes through
+    `python -m torch.distributed.run` (one process per GPU, rendezvous on 127.0.0.1 at a port found free by bind(0)), hand rank 0's
+    ONE JSON line through to stdout and return the launcher's exit code.  Must run before this process touches the GPU: no
+    `torch.cuda.is_available()`, no import of the kernels -- `torch.cuda.device_count()` does not initialise HIP on this image --
+    and the children are started with subprocess (fork + exec of a process that has NOT initialised HIP), never by replacing
+    this process."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n and os.environ.get("DGDM_BENCH_ONE_DEVICE") != "1":
+        print(f"bench.py: --gpus {n} but this node shows {have} GPU(s)", file=sys.stderr)
+        return 2
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *argv]
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)     # stderr is inherited: progress and errors stay visible
+    lines = []
+    for ln in proc.stdout:
+        if ln.strip():
+            lines.append(ln.rstrip("\n"))
+    rc = proc.wait()
+    result = [ln for ln in lines if ln.lstrip().startswith("{")]
+    for ln in lines:                 # anything a rank printed beside the result goes to stderr: stdout carries ONE line
+        if not result or ln is not result[-1]:
+            print(ln, file=sys.stderr)
+    if result:
+        print(result[-1], flush=True)
+    elif rc == 0:
+        print("bench.py: the ranks exited without printing a result line", file=sys.stderr)
+        rc = 1
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -305,12 +376,17 @@ def main():
         # it is not forced on steps of tiny graphs, and a recorded step does not care).  Read by the HIP runtime at its first call.
         os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process becomes the launcher (the reference gets its ranks from
+        # pl.Trainer(accelerator="gpu", devices=gpus), cli/train.py:346-359).  Nothing here has touched the GPU yet.
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} in the environment (a launcher's world size must equal "
+                  f"--gpus; without WORLD_SIZE this script starts its own ranks)", file=sys.stderr)
         sys.exit(2)
     if not torch.cuda.is_available():
         print("bench.py needs a GPU (the HIP path has no CPU fallback)", file=sys.stderr)
@@ -402,10 +478,11 @@ def main():
 
     graph_note = None
     eager_step = step
-    if not args.eager and stream is not None and reducer is None:
-        # the 8 layouts of the stream recur: one recording per layout (training.GraphedStepCache)
+    if not args.eager and stream is not None:
+        # the 8 layouts of the stream recur: one recording per layout (training.GraphedStepCache); with a reducer every recording is
+        # split around ONE all-reduce of the same flat gradient buffer (warm-up steps of a layout exchange the same single message)
         from dgdm_histopath_lab_amd.training import GraphedStepCache
-        cache = GraphedStepCache(model, opt, mask_ratio=0.15, max_layouts=len(stream))
+        cache = GraphedStepCache(model, opt, mask_ratio=0.15, max_layouts=len(stream), grad_reducer=reducer)
 
         def step():
             cur = stream[step_no[0] % len(stream)]
@@ -413,7 +490,8 @@ def main():
             return cache(cur)
         for _ in range(len(stream) * (cache.warmup + 2)):     # every layout primed and recorded: setup, not part of the W warmup steps
             step()
-        graph_note = f"HIP graph replay, one recording per layout ({len(cache.steps)} layouts, training.GraphedStepCache)"
+        graph_note = (f"HIP graph replay, one recording per layout ({len(cache.steps)} layouts, training.GraphedStepCache"
+                      + (", each split around the gradient all-reduce" if reducer is not None else "") + ")")
     elif not args.eager and stream is None:
         from dgdm_histopath_lab_amd.training import GraphedPretrainStep
         gstep = GraphedPretrainStep(model, opt, mask_ratio=0.15, grad_reducer=reducer)
@@ -565,23 +643,24 @@ def main():
             vpath = valu_path or (PMC_VALU_LARGE if args.large else PMC_VALU)
             traffic = None if tpath is None else pmc_traffic(names[dom], tpath)
             common = {"kernel": names[dom], "ms_per_launch": round(ms, 4), "launches_timed": tm[dom][0], "traffic": traffic,
+                      "traffic_kind": TRAFFIC_KIND,
                       "traffic_source": None if traffic is None else f"committed PMC passes {os.path.relpath(tpath, ROOT)}, kernel {names[dom]}",
                       "other_kernels_ms": {k: round(v[1], 4) for k, v in tm.items() if k != dom}, "timed_with": graphed_note}
             valu = None if vpath is None else pmc_valu(names[dom], vpath)
+            out = dict(common, **mfma, valu_pmc=valu)
             if fp16_pipe and valu is not None and valu.get("valu_insts_per_launch"):
-                # the split-fp16 kernels are bound by VALU issue, not by the matrix pipe.  `achieved` / `frac` are recomputable from this
-                # line alone: vector wave-instructions per launch (a property of the code and the shapes; counted by the committed PMC
-                # pass named in `frac_inputs`) over the duration measured LIVE in this run, against 1024 SIMDs x 2.4 GHz / 4 cycles per
-                # wave64 instruction.  The utilisation counters of that pass (valu_busy, wave-cycle split) ride along as `valu_pmc`
-                # -- a committed measurement, not a product of this run.  The matrix-pipe pricing stays as `mfma`.
+                # NAMED SECONDARY (not the roofline): what holds the split-fp16 kernels is VALU issue, not the matrix pipe.  Vector
+                # wave-instructions per launch (a property of the code and the shapes; counted by the committed PMC pass named in
+                # `inputs`) over the duration measured LIVE in this run, against 1024 SIMDs x 2.4 GHz / 4 cycles per wave64
+                # instruction.  It says how busy the vector pipe is with the instructions THIS kernel chose to issue -- a kernel
+                # that issued more would score higher -- so `frac` above stays the algorithmic figure of SURVEY.md 8(d).
                 rate = valu["valu_insts_per_launch"] / (ms * 1e-3) / 1e9
-                return dict(common, bound="valu", achieved=round(rate, 1), peak=614.4, unit="G vector wave-instructions/s",
-                            frac=round(rate / 614.4, 4),
-                            frac_inputs={"valu_insts_per_launch": valu["valu_insts_per_launch"], "valu_insts_source": valu["source"],
-                                         "ms_per_launch": round(ms, 4), "ms_source": "HIP events in this run",
-                                         "peak": "1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction (transcendentals take two slots)"},
-                            valu_pmc=valu, mfma=mfma)
-            return dict(common, **mfma, valu_pmc=valu)
+                out["valu_issue_frac"] = round(rate / 614.4, 4)
+                out["valu_issue"] = {"achieved": round(rate, 1), "peak": 614.4, "unit": "G vector wave-instructions/s",
+                                     "inputs": {"valu_insts_per_launch": valu["valu_insts_per_launch"], "valu_insts_source": valu["source"],
+                                                "ms_per_launch": round(ms, 4), "ms_source": "HIP events in this run",
+                                                "peak": "1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction (transcendentals take two slots)"}}
+            return out
 
         ev_note = ("HIP events around eager launches of the same step right after the timed region (a graph replay cannot carry events)"
                    if graphed else "HIP events inside the timed region")
@@ -602,9 +681,7 @@ def main():
                      {"f16x2": "dense layers: fp16 hi+lo operands with per-operand power-of-two scale, 3 MFMAs per product, fp32 accumulate",
                       "bf16x3": "dense layers: exact 3-way bf16 split, 6 MFMAs per product, fp32 accumulate",
                       "fp32": "dense layers: fp32 MFMA"}[ops.GEMM_MATH] +
-                     ("; every parameter gradient of the step sits as close to float64 as the fp32-operand kernels and torch fp32 do (max rel-L2 "
-                      "1.5e-6 / 1.9e-6 / 1.2e-6: profiles/r03_arithmetic_error_vs_float64.txt, tests/test_hip_model.py::"
-                      "test_default_arithmetic_is_at_the_error_level_of_fp32)" if split and ops.GEMM_MATH == "f16x2" else "") + ")",
+                     (arithmetic_error_note() if split and ops.GEMM_MATH == "f16x2" else "") + ")",
             "data": "synthetic",
             "config": {"workload": (f"MIXED-SIZE STREAM (configs[4]): DGDM-Base pretrain_step fwd+bwd+AdamW, batch={args.batch} graphs of "
                                     f"1k..10k nodes (E = 5 N) per GPU, 8 batches cycled, feat={FEATS}, edge_attr=32, T=10, heads=8, "
@@ -613,7 +690,12 @@ def main():
                                     f"graphs per GPU, feat={FEATS}, edge_attr=32, T={cfg['num_diffusion_steps']}, heads={cfg['attention_heads']}, ") +
                                    f"{'eval (dropout off)' if args.eval_mode else 'training mode (dropout 0.1)'}",
                        "global_batch": world * args.batch, "parallelism": f"dp{world}", "final_loss": round(loss_val, 5),
-                       "launch": (graph_note or "HIP graph replay (training.GraphedPretrainStep)") if graphed else (graph_note or "eager")},
+                       "launch": (graph_note or "HIP graph replay (training.GraphedPretrainStep)") if graphed else (graph_note or "eager"),
+                       "input_copy": ("excluded: the batch is resident in the recording's own input buffers (GraphedPretrainStep.input_buffers) "
+                                      "before the timed region; rounds 1-3 copied it device-to-device every step (130 MB, ~0.09 ms)"
+                                      if graphed and stream is None else
+                                      "device-to-device copy of each batch into its recording's buffers, inside the timed region" if graphed
+                                      else "none (eager step reads the resident batch)")},
             "roofline": roofline,
         }
         if balance_note is not None:

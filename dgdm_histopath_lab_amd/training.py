@@ -279,11 +279,9 @@ class DGDMTrainer(nn.Module):
                 loss = None
                 if graphed and self.current_phase == "pretrain":
                     if self._graphed is None:
-                        # one rank: a recording per recurring layout; data parallel: one recording split around the collective
-                        self._graphed = (GraphedStepCache(self.model, self._optimizer, self.masking_ratio, step_fn=lambda b: self._pretrain_step(b))
-                                         if grad_reducer is None else
-                                         GraphedPretrainStep(self.model, self._optimizer, grad_reducer=grad_reducer,
-                                                             step_fn=lambda b: self._pretrain_step(b)))
+                        # a recording per recurring layout; data parallel: each split around the collective, all on ONE flat buffer
+                        self._graphed = GraphedStepCache(self.model, self._optimizer, self.masking_ratio,
+                                                         step_fn=lambda b: self._pretrain_step(b), grad_reducer=grad_reducer)
                     try:
                         loss = self._graphed(batch)
                     except BatchLayoutError:    # another batch layout: eager step below
@@ -377,14 +375,17 @@ class GraphedPretrainStep:
     * ``validate=True`` keeps the model's input checks (NaN / inf / edge range, one host readback per batch) in
       front of every step, as the eager forward has them; the recorded region itself cannot hold a readback.
     * with ``grad_reducer`` the graph is split around the collective: [forward+backward] -> all-reduce
-      (eager, RCCL) -> [optimizer step].
+      (eager, RCCL) -> [optimizer step].  ``one_message=True`` makes the eager warm-up steps exchange their gradients the way a
+      replay does -- hooks passive, ONE all-reduce of the whole flat buffer -- so that a rank which replays and a rank which is
+      still warming a layout up issue the same collective (``GraphedStepCache`` sets it).
     """
 
     def __init__(self, model: nn.Module, optimizer: torch.optim.Optimizer, mask_ratio: float = 0.15, grad_reducer=None,
-                 warmup: int = 2, step_fn=None, validate: bool = True):
+                 warmup: int = 2, step_fn=None, validate: bool = True, one_message: bool = False):
         from . import _lib
         self._lib = _lib
         self.validate = validate
+        self.one_message = one_message
         self.model, self.opt, self.mask_ratio, self.reducer, self.warmup = model, optimizer, mask_ratio, grad_reducer, warmup
         self.step_fn = step_fn or (lambda batch: model.pretrain_step(batch, mask_ratio=self.mask_ratio)["total_pretrain_loss"])
         self.dev = next(model.parameters()).device
@@ -469,6 +470,17 @@ class GraphedPretrainStep:
         return loss.detach()
 
     def _eager(self):
+        if self.reducer is not None and self.one_message:
+            self.reducer.capturing = True   # hooks passive: no early bucket, the exchange below is the replay's single message
+            try:
+                loss = self._forward_backward()
+            finally:
+                self.reducer.capturing = False
+            self.reducer.pack()
+            self.reducer.reduce_packed()
+            self.reducer.adopt_views()
+            self.opt.step()
+            return loss
         loss = self._forward_backward()
         if self.reducer is not None:
             self.reducer.all_reduce()       # leaves p.grad as views of the reducer's flat buffer
@@ -559,16 +571,21 @@ class GraphedStepCache:
     """Recorded steps for a stream of batches whose layouts RECUR (the same batch compositions epoch after epoch, a cycled
     validation-style set, fixed-size batches): one ``GraphedPretrainStep`` per layout signature, least-recently-used eviction.
     All recordings share the model, the optimizer and its state; each owns the activations and gradient buffers of its layout
-    (``param.grad`` points at the buffers of the layout recorded last -- with a gradient reducer use one recording, or eager steps).
+    (without a reducer ``param.grad`` points at the buffers of the layout recorded last).
+
+    Data parallel (``grad_reducer``): every layout's first graph ends by packing its gradients into the reducer's ONE flat buffer,
+    the all-reduce of that buffer runs eagerly, and every layout's second graph is the optimizer step on the buffer's slices --
+    ``param.grad`` is the same set of views whatever layout ran last.  Warm-up steps of a new layout exchange the same single
+    message (``one_message``), so ranks whose layouts recur at different times still issue identical collectives, one per step.
 
     A layout seen for the first time runs ``warmup`` eager steps (they are real training steps; the first one also creates the
     layout's device constants, which a capture cannot), is recorded on the next, and replays from then on.  Graph padding to
     bucket sizes is NOT done: top-k pooling and attention are defined over the true node sets (graph_layers.py:306-310)."""
 
     def __init__(self, model: nn.Module, optimizer: torch.optim.Optimizer, mask_ratio: float = 0.15, step_fn=None, max_layouts: int = 16,
-                 warmup: int = 1, validate: bool = True):
+                 warmup: int = 1, validate: bool = True, grad_reducer=None):
         import collections
-        self.model, self.opt, self.mask_ratio, self.step_fn = model, optimizer, mask_ratio, step_fn
+        self.model, self.opt, self.mask_ratio, self.step_fn, self.reducer = model, optimizer, mask_ratio, step_fn, grad_reducer
         self.max_layouts, self.warmup, self.validate = max_layouts, warmup, validate
         self.steps: "collections.OrderedDict" = collections.OrderedDict()
         self.replays = self.eager = 0
@@ -578,7 +595,7 @@ class GraphedStepCache:
         st = self.steps.get(sig)
         if st is None:
             st = GraphedPretrainStep(self.model, self.opt, self.mask_ratio, warmup=self.warmup if self.steps else max(self.warmup, 2),
-                                     step_fn=self.step_fn, validate=self.validate)
+                                     step_fn=self.step_fn, validate=self.validate, grad_reducer=self.reducer, one_message=True)
             self.steps[sig] = st
             while len(self.steps) > self.max_layouts:
                 self.steps.popitem(last=False)

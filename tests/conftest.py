@@ -15,24 +15,17 @@ BENCH_REHEARSAL = {}      # filled by pytest_configure on a GPU run: {"proc": Po
 
 
 def _start_bench_rehearsal():
-    """`bench.py --gpus 2` as FRESH child processes (python -m torch.distributed.run, two ranks on the one GPU of the box over gloo),
-    started here -- before anything in this process has touched the GPU: a process that has initialised HIP must not fork+exec
-    on this pool.  tests/test_parallel.py::test_bench_two_rank_rehearsal_prints_one_json_line waits for it and checks the line; the
-    ranks run beside the first tests of the session (3 processes on the card, limit 6)."""
-    import socket
+    """The N > 1 forms of bench.py (plain `python bench.py --gpus 2`, the same with `--mixed`, and the launcher form the driver
+    uses), run ONE AFTER THE OTHER by the child process tests/_bench_rehearsal.py as fresh processes, two ranks on the one GPU of
+    the box over gloo, started here -- before anything in this process has touched the GPU: a process that has initialised HIP
+    must not fork+exec on this pool.  tests/test_parallel.py::test_bench_two_rank_rehearsal_* wait for it and check the lines; the
+    ranks run beside the first tests of the session (3 processes on the card at any time, limit 6)."""
     import subprocess
     import tempfile
-    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
     d = tempfile.mkdtemp(prefix="dgdm_bench_rehearsal_")
-    out, err = os.path.join(d, "stdout.txt"), os.path.join(d, "stderr.txt")
-    env = dict(os.environ, DGDM_BENCH_ONE_DEVICE="1", DGDM_BENCH_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--nodes", "500",
-           "--edges", "2000", "--no-cpu-baseline", "--no-gather"]
-    proc = subprocess.Popen(cmd, stdout=open(out, "w"), stderr=open(err, "w"), env=env, cwd=ROOT)
-    BENCH_REHEARSAL.update(proc=proc, out=out, err=err, cmd=" ".join(cmd))
+    log = open(os.path.join(d, "driver.log"), "w")
+    proc = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_bench_rehearsal.py"), d], stdout=log, stderr=log, cwd=ROOT)
+    BENCH_REHEARSAL.update(proc=proc, dir=d)
 
 
 def pytest_configure(config):
@@ -45,10 +38,9 @@ def pytest_configure(config):
 
 def pytest_unconfigure(config):
     proc = BENCH_REHEARSAL.get("proc")
-    if proc is not None and proc.poll() is None:      # the waiting test was deselected or never reached: do not leave ranks behind
-        proc.terminate()
-        try:
-            proc.wait(30)
+    if proc is not None and proc.poll() is None:      # the waiting test was deselected or never reached: let the running case finish
+        try:                                           # (its ranks are grandchildren: killing the driver would orphan them on the card)
+            proc.wait(900)
         except Exception:
             proc.kill()
 

@@ -310,6 +310,51 @@ def test_split_recording_around_the_collective_is_bitwise_the_plain_step():
         dist.destroy_process_group()
 
 
+def test_step_cache_with_a_reducer_replays_every_layout_on_one_flat_buffer():
+    """recorded steps for a mixed-size stream UNDER data parallelism.  Three batch layouts cycled through a
+    ``GraphedStepCache`` with a gradient reducer (single-rank RCCL group: the average over one rank is the identity) against the
+    same cache without one: losses and parameters bit for bit; every layout is recorded as two graphs around ONE all-reduce of
+    the same flat buffer, warm-up steps included (one message per step whatever state a layout is in), and ``p.grad`` is the same
+    set of buffer views whichever layout ran last."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from dgdm_histopath_lab_amd import GraphBatch
+    from dgdm_histopath_lab_amd.parallel import FlatGradAllReducer
+    from dgdm_histopath_lab_amd.synthetic import synthetic_graph
+    from dgdm_histopath_lab_amd.training import GraphedStepCache
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        sizes = [(300, 500), (420, 260), (640, 200)]
+        batches = [GraphBatch.from_data_list([synthetic_graph(10 * i + j, n, 4 * n, 64) for j, n in enumerate(ns)]).to(DEV)
+                   for i, ns in enumerate(sizes)]
+        objective = lambda model: (lambda b: model(b, mode="inference")["graph_embedding"].pow(2).mean())
+        plain, dp = _small_model(0.0).eval(), _small_model(0.0).eval()
+        mk = lambda m: torch.optim.AdamW(m.parameters(), lr=1e-3, weight_decay=1e-5, fused=True)
+        c_plain = GraphedStepCache(plain, mk(plain), step_fn=objective(plain))
+        red = FlatGradAllReducer(dp, 1, always=True)
+        calls = []
+        real = red.reduce_packed
+        red.reduce_packed = lambda: (calls.append(1), real())[1]
+        c_dp = GraphedStepCache(dp, mk(dp), step_fn=objective(dp), grad_reducer=red)
+        la, lb = [], []
+        for i in range(15):
+            la.append(float(c_plain(batches[i % 3])))
+            lb.append(float(c_dp(batches[i % 3])))
+            assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(red.live, red.views))
+        assert la == lb
+        assert len(calls) == 15 and red.stats["early_launches"] == 0       # ONE message per step, eager warm-up steps included
+        assert len(c_dp.steps) == 3 and all(len(st._graphs) == 2 for st in c_dp.steps.values()) and c_dp.replays >= 6
+        for pa, pb in zip(plain.parameters(), dp.parameters()):
+            assert torch.equal(pa, pb)
+    finally:
+        dist.destroy_process_group()
+
+
 def test_eager_reducer_on_the_base_model_overlaps_bucket0_with_the_backward_tail():
     """Multi-GPU readiness on one GPU: the EAGER reducer on the real DGDM-Base model through a single-rank
     RCCL group, at the headline batch (4 x 10k nodes): bucket 0 leaves from the gradient hook on every step after the first, the two

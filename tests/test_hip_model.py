@@ -145,8 +145,8 @@ def test_default_arithmetic_is_at_the_error_level_of_fp32(case):
     """The reference computes in fp32 ("everything is fp32"); the default kernels form every product on fp16 hi+lo
     operand pairs with fp32 accumulation.  Is that narrower IN EFFECT?  Same step, same draws, every live gradient against the
     float64 oracle: the default arithmetic, fp32 operands on the fp32 matrix instructions, and torch fp32 on the CPU (the
-    oracle code in float32 = the reference's own arithmetic) must sit at the same distance from exact -- the default within 4x of
-    either fp32 run at the worst gradient and within 2.5x at the median.  Round 4: not only on the smooth
+    oracle code in float32 = the reference's own arithmetic) must sit at the same distance from exact -- the default within 2x of
+    either fp32 run at the worst gradient and within 1.6x at the median.  Round 4: not only on the smooth
     near-init Base model, but also with the U-Net on (the float64 run's kink decisions injected into all three), on sharp
     attention rows (q_proj / k_proj x 4, core/attention.py:135-157) and at Large widths (hidden 1024/512/256, 16 heads, K = 1024
     reductions, core/graph_layers.py:400-458).  tools/arithmetic_error_report.py prints the tables
@@ -166,9 +166,12 @@ def test_default_arithmetic_is_at_the_error_level_of_fp32(case):
         assert res["entropy"] < 1.0, res["entropy"]                         # the rows really are sharp (ln N = 7.6)
     # all three well inside the 1e-3 contract; the level itself is the problem's conditioning (Large: 2e-4 for fp32 operands too)
     assert max(mx_d, mx_h, mx_c) <= {"smooth": 5e-6, "unet": 5e-5, "sharp": 5e-5, "large": 5e-4}[case]
+    # observed (profiles/r04_arithmetic_error_vs_float64.txt), default over the NEARER-to-exact of the two fp32 runs: worst gradient
+    # 1.23 / 1.04 / 1.53 / 1.88 x, median 1.26 / 1.07 / 1.46 / 1.53 x (smooth / unet / sharp / large) -- the bounds sit just above,
+    # so an emulation that lost a few operand bits fails here (round 4 allowed 4 x / 2.5 x)
     for mx_o, md_o in ((mx_h, md_h), (mx_c, md_c)):
-        assert mx_d <= 4.0 * mx_o, (mx_d, mx_o)
-        assert md_d <= 2.5 * md_o, (md_d, md_o)
+        assert mx_d <= 2.0 * mx_o, (mx_d, mx_o)
+        assert md_d <= 1.6 * md_o, (md_d, md_o)
 
 
 class _DropoutSites:

@@ -210,26 +210,36 @@ def test_balanced_slide_loader_partitions_every_step_and_balances_the_cost():
     assert b0.num_graphs == 2 and b0.x.size(0) in (12, 14, 16, 10, 8)
 
 
-@pytest.mark.gpu
-def test_bench_two_rank_rehearsal_prints_one_json_line():
-    """the N > 1 branch of bench.py (init_process_group, split recording around the collective, per-rank
-    timing, max over ranks, ONE JSON line from rank 0) run unattended: `python -m torch.distributed.run --nproc-per-node 2 bench.py
-    --gpus 2 ...` as fresh child processes started by conftest.pytest_configure before this session touched the GPU
-    (DGDM_BENCH_ONE_DEVICE=1: both ranks on the box's one GPU; gloo, since RCCL refuses two ranks on one device)."""
+def _rehearsal_case(name):
     from conftest import BENCH_REHEARSAL
     if not BENCH_REHEARSAL:
         pytest.skip("rehearsal not started (run as `pytest -m gpu` on a GPU box)")
-    proc = BENCH_REHEARSAL["proc"]
+    proc, d = BENCH_REHEARSAL["proc"], BENCH_REHEARSAL["dir"]
     try:
-        rc = proc.wait(900)
+        proc.wait(1500)
     except Exception:
         proc.kill()
         raise
-    out, err = open(BENCH_REHEARSAL["out"]).read(), open(BENCH_REHEARSAL["err"]).read()
-    assert rc == 0, f"{BENCH_REHEARSAL['cmd']} exited with {rc}:\n{err[-3000:]}"
+    done = os.path.join(d, "done.json")
+    assert os.path.exists(done), f"rehearsal driver died:\n{open(os.path.join(d, 'driver.log')).read()[-3000:]}"
+    st = json.load(open(done))[name]
+    out, err = open(os.path.join(d, f"{name}.out")).read(), open(os.path.join(d, f"{name}.err")).read()
+    assert st["rc"] == 0, f"{st['cmd']} exited with {st['rc']}:\n{err[-3000:]}"
     lines = [ln for ln in out.splitlines() if ln.strip()]
     assert len(lines) == 1, f"stdout must hold exactly one line, got {len(lines)}:\n{out[:2000]}"
-    r = json.loads(lines[0])
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form", ["plain", "launcher"])
+def test_bench_two_rank_rehearsal_prints_one_json_line(form):
+    """The N > 1 branch of bench.py (init_process_group, split recording around the collective, per-rank timing, max over ranks,
+    ONE JSON line from rank 0) run unattended as fresh child processes started before this session touched the GPU
+    (DGDM_BENCH_ONE_DEVICE=1: both ranks on the box's one GPU; gloo, since RCCL refuses two ranks on one device).
+    `plain`: `python bench.py --gpus 2 ...` with no launcher and no WORLD_SIZE -- the script starts its own
+    ranks (the reference: pl.Trainer(devices=gpus), cli/train.py:346-359), relays the line and the return code; `launcher`:
+    `python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 ...`, the form the driver uses."""
+    r = _rehearsal_case(form)
     assert r["n_gpus"] == 2 and r["steps"] == 3 and r["warmup"] == 1 and r["scaling"] == "weak" and r["unit"] == "slides/s"
     assert r["config"]["global_batch"] == 8 and r["config"]["parallelism"] == "dp2"
     assert r["value"] > 0 and abs(r["value"] - 8 * 1e3 / r["ms_per_step"]) < 1e-2 * r["value"]
@@ -237,3 +247,31 @@ def test_bench_two_rank_rehearsal_prints_one_json_line():
     assert len(pr["ms_per_step_by_rank"]) == 2 and pr["ms_per_step_max"] <= r["ms_per_step"] * 1.001
     assert ge["bytes"] > 1e6 and ge["messages_per_step"] in (1, 2) and sum(ge["bucket_bytes"]) == ge["bytes"]
     assert "HIP graph replay" in r["config"]["launch"], r["config"]["launch"]      # the split recording was taken, not the eager fallback
+
+
+@pytest.mark.gpu
+def test_bench_two_rank_rehearsal_of_the_mixed_stream_replays_graphs():
+    """`python bench.py --gpus 2 --mixed` (BASELINE configs[4] shape) -- every layout of the stream recorded
+    under the gradient reducer (training.GraphedStepCache on one flat buffer), one message per step."""
+    r = _rehearsal_case("mixed")
+    assert r["n_gpus"] == 2 and r["config"]["global_batch"] == 4 and "MIXED-SIZE STREAM" in r["config"]["workload"]
+    assert "HIP graph replay, one recording per layout (8 layouts" in r["config"]["launch"] and "all-reduce" in r["config"]["launch"]
+    assert r["gradient_exchange"]["messages_per_step"] == 1 and r["gradient_exchange"]["early_launches"] == 0
+    assert r["value"] > 0 and len(r["per_rank"]["ms_per_step_by_rank"]) == 2 and r["config"]["max_over_mean_rank_load"] < 1.3
+
+
+def test_bench_starts_its_own_ranks_and_relays_their_failure_without_a_gpu():
+    """Host logic of `python bench.py --gpus N` without a launcher (CPU container: no GPU, so the ranks can only fail): the parent
+    refuses a node with fewer GPUs than ranks (rc 2, nothing on stdout), and with the one-device rehearsal knob it starts
+    `torch.distributed.run`, whose ranks exit with bench.py's "needs a GPU" -- return code and empty stdout are relayed."""
+    import subprocess
+    import sys
+    if torch.cuda.device_count() > 0:
+        pytest.skip("CPU-side check (the GPU run has the rehearsal tests)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "DGDM_BENCH_ONE_DEVICE")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 2 and r.stdout == "" and "shows 0 GPU" in r.stderr
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                       env=dict(env, DGDM_BENCH_ONE_DEVICE="1"), timeout=300)
+    assert r.returncode != 0 and r.stdout == "" and "needs a GPU" in r.stderr

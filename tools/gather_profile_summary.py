@@ -47,7 +47,7 @@ def main():
             rd, wr = 2.0 * f * 1024 / max(nf, 1), w * 1024 / max(nw, 1)
             us = v[len(v) // 2] if mode == "cold" else sum(v) / len(v)
             ent = {"launches": len(v), "us_per_launch": round(us, 2), "read_bytes_per_launch": round(rd), "write_bytes_per_launch": round(wr),
-                   "hbm_bytes_per_launch": round(rd + wr), "traffic_over_algorithmic": round((rd + wr) / ALG, 3),
+                   "fabric_bytes_per_launch": round(rd + wr), "traffic_over_algorithmic": round((rd + wr) / ALG, 3),
                    "traffic_over_unique": round((rd + wr) / UNIQ, 3), "algorithmic_GBps": round(ALG / us / 1e3, 1),
                    "algorithmic_frac_of_8TBps": round(ALG / us / 1e3 / 8000, 4)}
             res["cases"].setdefault(mode, {})[k] = ent

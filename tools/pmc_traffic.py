@@ -58,7 +58,7 @@ def main():
         rd = 2.0 * f * 1024 / max(nf, 1)   # gfx950 correction: x2
         wr = w * 1024 / max(nw, 1)
         out[name] = {"launches": max(nf, nw), "read_bytes_per_launch": round(rd), "write_bytes_per_launch": round(wr),
-                     "hbm_bytes_per_launch": round(rd + wr)}
+                     "fabric_bytes_per_launch": round(rd + wr)}
     json.dump({"unit": "bytes per launch (FETCH_SIZE KB x2 gfx950 correction + WRITE_SIZE KB)", "kernels": out}, sys.stdout, indent=1)
 
 
