@@ -20,6 +20,7 @@
 // 1 lo, at (2j + p) KiB; lane l's 8 halfs at 16 l: B(col = 32t + (l & 31), k = 32c + 16 (l >> 5) + 8j + i), i = 0..7.
 // The column count is zero-padded to a multiple of 32, K to a multiple of 64 (whole LDS stages).
 #include "common.hpp"
+#include "rowmath.hpp"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -153,6 +154,252 @@ __device__ unsigned long long* dgdm_stamp_buf;
 #define DGDM_STAMP(i_)
 #endif
 
+// ---- fused epilogues (round 5).  A GEMM whose result goes through an element-wise or row-wise layer before anything else reads
+// it finishes that layer in its own registers:
+//   EPI_ACT     C = dropout(act(A.B + bias)), the pre-activation optionally stored beside it (the backward needs it)
+//               core/graph_layers.py:233-239  h = dropout(GELU(conv(x)))
+//   EPI_ACTBWD  C = (A.B) * act'(pre) * mask  -- the backward of that layer as the epilogue of the GEMM that produces its
+//               incoming gradient (dh = do . W_o, or dh = (A_hat^T dpre) . W for the second convolution)
+//   EPI_NORM    C = dropout(act(norm_G(A.B + bias [+ res]) * gamma + beta)), the pre-norm sum stored beside it
+//               core/graph_layers.py:241-245  norm1(output_proj(h) + x);  models/encoders.py:267-269;  core/diffusion.py:94-102
+// These variants run the MFMAs with the operands SWAPPED (weight fragment as A, activation fragment as B: the two fragments have
+// the same lane layout), so the accumulators hold the TRANSPOSED tile: lane (l & 31) owns output row r0 + (l & 31), and its 16
+// registers of tile t are the channels 32 t + 8 (r >> 2) + 4 (l >> 5) + (r & 3) -- runs of four consecutive channels.  That is
+// the shape the row kernels work in: the dropout word of rowmath.hpp covers four consecutive elements (the mask is the SAME
+// function of (seed, element index) as in k_act_dropout / k_rownorm, so the backward kernels and the parity tests regenerate
+// it), bias / gamma / beta / pre / res are 16-byte accesses, a row's statistics are an in-lane sum plus ONE exchange with lane
+// l ^ 32, and the stores are float4.
+enum { EPI_NONE = 0, EPI_ACT = 1, EPI_ACTBWD = 2, EPI_NORM = 3 };
+
+struct EpiArgs {
+  const float* pre_in;              // ACTBWD: pre-activation [M, ncols], leading dimension ldp
+  float* pre_out;                   // ACT: nullable; receives A.B + bias (ldp)
+  int64_t ldp;
+  const float* res; int64_t ldr;    // NORM: nullable residual
+  const float* gamma; const float* beta;
+  float* sum_out; int64_t lds;      // NORM: nullable; receives A.B + bias + res (what the norm's backward reads as its input)
+  float* mean; float* rstd;         // NORM: [M * G]
+  float eps; int L;                 // NORM: channels per group, a multiple of 32 that divides the wave's column count
+  int act; float drop_p; DgdmSeed seed;
+  unsigned* amax_out;               // nullable: slot group that receives max|C|
+};
+
+__device__ __forceinline__ float4 act4(int act, const float4 v) {
+  switch (act) {
+    case DGDM_ACT_GELU: return make_float4(act_f<DGDM_ACT_GELU>(v.x), act_f<DGDM_ACT_GELU>(v.y), act_f<DGDM_ACT_GELU>(v.z), act_f<DGDM_ACT_GELU>(v.w));
+    case DGDM_ACT_RELU: return make_float4(act_f<DGDM_ACT_RELU>(v.x), act_f<DGDM_ACT_RELU>(v.y), act_f<DGDM_ACT_RELU>(v.z), act_f<DGDM_ACT_RELU>(v.w));
+    case DGDM_ACT_SILU: return make_float4(act_f<DGDM_ACT_SILU>(v.x), act_f<DGDM_ACT_SILU>(v.y), act_f<DGDM_ACT_SILU>(v.z), act_f<DGDM_ACT_SILU>(v.w));
+    default: return v;
+  }
+}
+__device__ __forceinline__ float4 act_d4(int act, const float4 v) {
+  switch (act) {
+    case DGDM_ACT_GELU: return make_float4(act_df<DGDM_ACT_GELU>(v.x), act_df<DGDM_ACT_GELU>(v.y), act_df<DGDM_ACT_GELU>(v.z), act_df<DGDM_ACT_GELU>(v.w));
+    case DGDM_ACT_RELU: return make_float4(act_df<DGDM_ACT_RELU>(v.x), act_df<DGDM_ACT_RELU>(v.y), act_df<DGDM_ACT_RELU>(v.z), act_df<DGDM_ACT_RELU>(v.w));
+    case DGDM_ACT_SILU: return make_float4(act_df<DGDM_ACT_SILU>(v.x), act_df<DGDM_ACT_SILU>(v.y), act_df<DGDM_ACT_SILU>(v.z), act_df<DGDM_ACT_SILU>(v.w));
+    default: return make_float4(1.f, 1.f, 1.f, 1.f);
+  }
+}
+
+// predicated 16-byte load (written as a branch: `ok ? *p : zero` makes hipcc select between the ADDRESS and a private copy of the zero)
+__device__ __forceinline__ float4 ld4_if(const float* p, bool ok) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (ok) v = *reinterpret_cast<const float4*>(p);
+  return v;
+}
+
+#define DGDM_Q4(a_, q_) make_float4((a_)[4 * (q_)], (a_)[4 * (q_) + 1], (a_)[4 * (q_) + 2], (a_)[4 * (q_) + 3])
+#define DGDM_SETQ4(a_, q_, v_) { (a_)[4 * (q_)] = (v_).x; (a_)[4 * (q_) + 1] = (v_).y; (a_)[4 * (q_) + 2] = (v_).z; (a_)[4 * (q_) + 3] = (v_).w; }
+
+// Epilogue of a wave that holds TRANSPOSED accumulators of NT column tiles starting at column `col0`; `row` = this lane's output
+// row (may be >= M: nothing is stored for it), hi = lane >> 5.  Every thread of the workgroup must call it (amax commit).
+//
+// The per-element work (erf, the dropout word) is ROLLED: a real loop over pairs of tiles that always works on acc[0] and acc[1]
+// and then moves the remaining tiles two places down (16 v_mov per tile and round -- a tenth of the arithmetic).  Fully
+// unrolled, the wide kernel's 128 outputs per lane are 15 000 instructions whose interleaved erf chains push the allocator past
+// 256 registers: these kernels must not spill at all (their activation loads are retired by hand, tests/test_abi.py).  Stores
+// leave straight from the round's temporaries; the next round's arithmetic covers their flight.
+template <int NT, int EPI>
+__device__ __forceinline__ void epilogue_tr(f32x16 (&acc)[NT], const float inv, const int row, const int M, const int col0, const int Ncols,
+                                            const float* __restrict__ bias, float* __restrict__ C, const int64_t ldc, const EpiArgs& e,
+                                            const int hi) {
+  static_assert(NT % 2 == 0, "tiles are taken in pairs");
+  const bool rok = row < M;
+  const int cl = col0 + 4 * hi;                      // this lane's channels: cl + 32 t + 8 q + (0..3)
+  const uint32_t seed = e.seed.value();
+  const uint32_t thresh = (uint32_t)(e.drop_p * 65536.0f);
+  const float keep_scale = e.drop_p > 0.f ? 1.0f / (1.0f - (float)thresh / 65536.0f) : 1.0f;
+  const uint64_t e0 = (uint64_t)row * (uint64_t)Ncols;   // element index of (row, 0) in the contiguous [M, Ncols] output
+  unsigned am = 0;
+#define DGDM_ROTATE2(arr_)                                                                                          \
+  _Pragma("unroll") for (int i__ = 0; i__ + 2 < NT; ++i__) arr_[i__] = arr_[i__ + 2];
+
+  if (EPI == EPI_ACT) {
+#pragma clang loop unroll(disable)
+    for (int t0 = 0; t0 < NT; t0 += 2) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int col = cl + 32 * (t0 + u) + 8 * q;
+          const bool ok = rok && col < Ncols;
+          const float4 b = ld4_if(bias + col, bias && col < Ncols);
+          const float4 v = make_float4(fmaf(acc[u][4 * q], inv, b.x), fmaf(acc[u][4 * q + 1], inv, b.y), fmaf(acc[u][4 * q + 2], inv, b.z),
+                                       fmaf(acc[u][4 * q + 3], inv, b.w));
+          float4 o = act4(e.act, v);
+          if (e.drop_p > 0.f) {
+            const float4 m = dropout_scale4(seed, e0 + (uint64_t)col, thresh, keep_scale);
+            o.x *= m.x; o.y *= m.y; o.z *= m.z; o.w *= m.w;
+          }
+          if (ok) {
+            am = dgdm_amax4(am, o);
+            if (e.pre_out) *reinterpret_cast<float4*>(e.pre_out + (int64_t)row * e.ldp + col) = v;
+            *reinterpret_cast<float4*>(C + (int64_t)row * ldc + col) = o;
+          }
+        }
+      DGDM_ROTATE2(acc)
+    }
+  } else if (EPI == EPI_ACTBWD) {
+    // narrow kernel: the pre-activations of the next pair of tiles are on their way while this pair is finished; the wide kernel
+    // (128 accumulators) has no registers for a second set and loads each pair at the top of its round
+    constexpr bool AHEAD = NT <= 4;
+    float4 p[2][4], pn[2][4];
+#define DGDM_LOAD_PRE(dst_, t_)                                                                                     \
+  _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                                     \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                 \
+      const int col = cl + 32 * ((t_) + u) + 8 * q;                                                                 \
+      dst_[u][q] = ld4_if(e.pre_in + (int64_t)row * e.ldp + col, rok && col < Ncols);                               \
+    }
+    if (AHEAD) DGDM_LOAD_PRE(p, 0)
+#pragma clang loop unroll(disable)
+    for (int t0 = 0; t0 < NT; t0 += 2) {
+      if (AHEAD) {
+        DGDM_LOAD_PRE(pn, t0 + 2)                    // past the last tile: col >= Ncols or a re-read inside the row -- never used
+      } else {
+        DGDM_LOAD_PRE(p, t0)
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int col = cl + 32 * (t0 + u) + 8 * q;
+          const float4 d = act_d4(e.act, p[u][q]);
+          float4 o = make_float4(acc[u][4 * q] * inv * d.x, acc[u][4 * q + 1] * inv * d.y, acc[u][4 * q + 2] * inv * d.z,
+                                 acc[u][4 * q + 3] * inv * d.w);
+          if (e.drop_p > 0.f) {
+            const float4 m = dropout_scale4(seed, e0 + (uint64_t)col, thresh, keep_scale);
+            o.x *= m.x; o.y *= m.y; o.z *= m.z; o.w *= m.w;
+          }
+          if (rok && col < Ncols) {
+            am = dgdm_amax4(am, o);
+            *reinterpret_cast<float4*>(C + (int64_t)row * ldc + col) = o;
+          }
+        }
+      DGDM_ROTATE2(acc)
+      if (AHEAD) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) p[u][q] = pn[u][q];
+      }
+    }
+#undef DGDM_LOAD_PRE
+  } else if (EPI == EPI_NORM) {
+    // pass 1 (unrolled: adds only): A.B + bias [+ res] in place, stored as the norm's input for the backward, per-tile sums
+    const int tpg = e.L >> 5;
+    const float invL = 1.0f / (float)e.L;
+    float mu[NT], rs[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      float s = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int col = cl + 32 * t + 8 * q;
+        const bool ok = rok && col < Ncols;
+        const float4 b = ld4_if(bias + col, bias && col < Ncols);
+        const float4 r4 = ld4_if(e.res + (int64_t)row * e.ldr + col, e.res && ok);
+        const float4 v = make_float4(fmaf(acc[t][4 * q], inv, b.x) + r4.x, fmaf(acc[t][4 * q + 1], inv, b.y) + r4.y,
+                                     fmaf(acc[t][4 * q + 2], inv, b.z) + r4.z, fmaf(acc[t][4 * q + 3], inv, b.w) + r4.w);
+        DGDM_SETQ4(acc[t], q, v)
+        if (e.sum_out && ok) *reinterpret_cast<float4*>(e.sum_out + (int64_t)row * e.lds + col) = v;
+        s += (v.x + v.y) + (v.z + v.w);
+      }
+      mu[t] = s;
+    }
+    // statistics of the groups of tpg = L / 32 consecutive tiles: per-tile sums (in-lane + the other half-wave), then a tree over
+    // the tiles of a group -- static register indices, wave-uniform conditions
+#define DGDM_GROUP_TREE(v_)                                                                                         \
+  {                                                                                                                 \
+    _Pragma("unroll") for (int t = 0; t < NT; ++t) v_[t] += __shfl_xor(v_[t], 32, 64);                              \
+    _Pragma("unroll") for (int w = 1; w < NT; w <<= 1)                                                              \
+      if (tpg > w) {                                                                                                \
+        _Pragma("unroll") for (int t = 0; t < NT; t += 2 * w) {                                                     \
+          const float s__ = v_[t] + v_[t + w];                                                                      \
+          _Pragma("unroll") for (int u = 0; u < 2 * w; ++u) v_[t + u] = s__;                                        \
+        }                                                                                                           \
+      }                                                                                                             \
+  }
+    DGDM_GROUP_TREE(mu)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      mu[t] *= invL;
+      float s = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float a = acc[t][4 * q] - mu[t], b = acc[t][4 * q + 1] - mu[t], c = acc[t][4 * q + 2] - mu[t], d = acc[t][4 * q + 3] - mu[t];
+        s += (a * a + b * b) + (c * c + d * d);
+      }
+      rs[t] = s;
+    }
+    DGDM_GROUP_TREE(rs)
+#undef DGDM_GROUP_TREE
+    const int G = Ncols / e.L;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      rs[t] = 1.0f / sqrtf(rs[t] * invL + e.eps);
+      const int c0 = col0 + 32 * t;
+      if (rok && hi == 0 && c0 < Ncols && (c0 % e.L) == 0) {
+        e.mean[(int64_t)row * G + c0 / e.L] = mu[t];
+        e.rstd[(int64_t)row * G + c0 / e.L] = rs[t];
+      }
+    }
+    // pass 2 (rolled): normalise, affine, activation, dropout, store
+#pragma clang loop unroll(disable)
+    for (int t0 = 0; t0 < NT; t0 += 2) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int col = cl + 32 * (t0 + u) + 8 * q;
+          const bool cok = col < Ncols;
+          const float4 g4 = ld4_if(e.gamma + col, cok);
+          const float4 b4 = ld4_if(e.beta + col, cok);
+          float4 o = make_float4((acc[u][4 * q] - mu[u]) * rs[u] * g4.x + b4.x, (acc[u][4 * q + 1] - mu[u]) * rs[u] * g4.y + b4.y,
+                                 (acc[u][4 * q + 2] - mu[u]) * rs[u] * g4.z + b4.z, (acc[u][4 * q + 3] - mu[u]) * rs[u] * g4.w + b4.w);
+          o = act4(e.act, o);
+          if (e.drop_p > 0.f) {
+            const float4 m = dropout_scale4(seed, e0 + (uint64_t)col, thresh, keep_scale);
+            o.x *= m.x; o.y *= m.y; o.z *= m.z; o.w *= m.w;
+          }
+          if (rok && cok) {
+            am = dgdm_amax4(am, o);
+            *reinterpret_cast<float4*>(C + (int64_t)row * ldc + col) = o;
+          }
+        }
+      DGDM_ROTATE2(acc)
+      DGDM_ROTATE2(mu)
+      DGDM_ROTATE2(rs)
+    }
+  }
+#undef DGDM_ROTATE2
+  if (e.amax_out) dgdm_amax_commit(am, e.amax_out);   // workgroup-uniform condition: every thread reaches the barrier inside
+}
+
+template <bool TR>
+__device__ __forceinline__ f32x16 mfma_o(f16x8 a, f16x8 b, f32x16 c) {
+  return TR ? mfma_hf(b, a, c) : mfma_hf(a, b, c);
+}
+
 // widest output the narrow kernel (wave = 32 x 128) takes; beyond it the wide one (wave = 32 x 256).  Round 4, same-box A/B
 // (tools/build_variant_lib.sh -DDGDM_IMG_NARROW_MAX=128 vs 256, tools/microbench_gemm.py): at N = 256 and M = 40 000 the wide
 // kernel has 313 workgroups for 512 resident slots, the narrow one 626 half-size ones: 54.8 -> 52.2, 36.0 -> 32.8 / 35.5,
@@ -167,11 +414,13 @@ constexpr int CPS = 2;    // 32-k chunks per LDS stage (64 k); images are padded
 // Workgroup = WM x WN waves; wave (wm, wn) owns rows 32 (WM rowtile + wm) .. +31 and columns 128 (WN colgroup + wn) .. +127.
 // The main loop has no data-dependent branch: a wave always runs its four column tiles (tiles past the end of the matrix
 // multiply whatever the LDS holds and are never stored), A loads past K re-read the row's last float4 (the image is zero there).
-template <int WM, int WN, bool ACCUM>
+template <int WM, int WN, bool ACCUM, int EPI>
 __global__ __launch_bounds__(64 * WM * WN, 2) void k_gemm_img(const float* __restrict__ A, int64_t lda, int M, int K,
                                                             const char* __restrict__ img, int T_img, int t_begin, int Ncols,
                                                             const float* __restrict__ bias, float* __restrict__ C, int64_t ldc,
-                                                            const unsigned* __restrict__ amax_a) {
+                                                            const unsigned* __restrict__ amax_a, const EpiArgs epi) {
+  static_assert(EPI == EPI_NONE || !ACCUM, "the fused epilogues write C, they do not accumulate into it");
+  constexpr bool TR = EPI != EPI_NONE;
   constexpr int WAVES = WM * WN, NT_WG = NTW * WN, STAGE = CPS * NT_WG * BLK;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 * STAGE
   const int tid = threadIdx.x, lane = tid & 63;
@@ -290,9 +539,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_gemm_img(const float* __res
   }
 #define DGDM_MFMA_BATCH(b_, slot_)                                                                                  \
   _Pragma("unroll") for (int t = 0; t < NTW; ++t) {                                                                 \
-    acc[t] = mfma_hf(al[(b_) >> 1][(b_) & 1], bh[slot_][t], acc[t]);      /* smaller terms first */                 \
-    acc[t] = mfma_hf(ah[(b_) >> 1][(b_) & 1], bl[slot_][t], acc[t]);                                                \
-    acc[t] = mfma_hf(ah[(b_) >> 1][(b_) & 1], bh[slot_][t], acc[t]);                                                \
+    acc[t] = mfma_o<TR>(al[(b_) >> 1][(b_) & 1], bh[slot_][t], acc[t]);    /* smaller terms first */                 \
+    acc[t] = mfma_o<TR>(ah[(b_) >> 1][(b_) & 1], bl[slot_][t], acc[t]);                                             \
+    acc[t] = mfma_o<TR>(ah[(b_) >> 1][(b_) & 1], bh[slot_][t], acc[t]);                                             \
   }
     DGDM_READ_BATCH(0, 0)
     DGDM_CONVERT(0, a00, a01, a02, a03)
@@ -327,6 +576,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_gemm_img(const float* __res
   // recycled for the next value makes hipcc wait vmcnt(0) in front of every store (64 round trips = 7 us per launch, measured
   // with tools/ubench/gemm_img_stamps.hip -- more than the main loop of the U-Net's GEMMs).
   const float inv = (1.0f / sca) * (1.0f / scb);     // exact: powers of two
+  if (TR) {
+    epilogue_tr<NTW, EPI>(acc, inv, r0 + (lane & 31), M, 32 * (tg0 + wn * NTW), Ncols, bias, C, ldc, epi, lane >> 5);
+    return;
+  }
   const int jc = lane & 31, hi = lane >> 5;
   const int rbase = r0 + 4 * hi;
 #pragma unroll
@@ -362,10 +615,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_gemm_img(const float* __res
 // workgroups drift apart and one's staging / conversion / LDS latency hides under the other's MFMAs.  Against the 4 x 2-wave form
 // the conversion work per MFMA halves as well (16 floats per lane feed 48 MFMAs instead of 24).
 constexpr int NT8 = 8;
-template <bool ACCUM>
+template <bool ACCUM, int EPI>
 __global__ __launch_bounds__(256, 2) void k_gemm_img8(const float* __restrict__ A, int64_t lda, int M, int K, const char* __restrict__ img,
                                                       int T_img, int t_begin, int Ncols, const float* __restrict__ bias,
-                                                      float* __restrict__ C, int64_t ldc, const unsigned* __restrict__ amax_a) {
+                                                      float* __restrict__ C, int64_t ldc, const unsigned* __restrict__ amax_a,
+                                                      const EpiArgs epi) {
+  static_assert(EPI == EPI_NONE || !ACCUM, "the fused epilogues write C, they do not accumulate into it");
+  constexpr bool TR = EPI != EPI_NONE;
   constexpr int SLOT = NT8 * BLK;                                  // 32 KiB: one chunk of 8 column tiles
   extern __shared__ __attribute__((aligned(16))) char smem[];      // 2 * SLOT
   const int tid = threadIdx.x, lane = tid & 63;
@@ -477,9 +733,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_img8(const float* __restrict__ 
       __builtin_amdgcn_sched_barrier(0);                                                                            \
       _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                               \
         const int t = 2 * (b & 3) + u;                                                                              \
-        acc[t] = mfma_hf(al[b >> 2], bh[b & 1][u], acc[t]);      /* smaller terms first */                          \
-        acc[t] = mfma_hf(ah[b >> 2], bl[b & 1][u], acc[t]);                                                         \
-        acc[t] = mfma_hf(ah[b >> 2], bh[b & 1][u], acc[t]);                                                         \
+        acc[t] = mfma_o<TR>(al[b >> 2], bh[b & 1][u], acc[t]);   /* smaller terms first */                          \
+        acc[t] = mfma_o<TR>(ah[b >> 2], bl[b & 1][u], acc[t]);                                                      \
+        acc[t] = mfma_o<TR>(ah[b >> 2], bh[b & 1][u], acc[t]);                                                      \
       }                                                                                                             \
     }                                                                                                               \
   }
@@ -493,6 +749,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_img8(const float* __restrict__ 
   DGDM_STAMP(8)
 
   const float inv = (1.0f / sca) * (1.0f / scb);
+  if (TR) {
+    epilogue_tr<NT8, EPI>(acc, inv, r0 + (lane & 31), M, 32 * tg0, Ncols, bias, C, ldc, epi, lane >> 5);
+    return;
+  }
   const int jc = lane & 31, hi = lane >> 5;
   const int rbase = r0 + 4 * hi;
 #pragma unroll
@@ -521,27 +781,29 @@ __global__ __launch_bounds__(256, 2) void k_gemm_img8(const float* __restrict__ 
   DGDM_STAMP(9)
 }
 
+template <int EPI>
 int launch_img8(hipStream_t s, const float* A, int64_t lda, int M, int K, const char* img, int T_img, int t_begin, int Ncols,
-                const float* bias, float* C, int64_t ldc, int accumulate, const unsigned* amax_a) {
+                const float* bias, float* C, int64_t ldc, int accumulate, const unsigned* amax_a, const EpiArgs& epi) {
   constexpr int LDS = 2 * NT8 * BLK;
   static int status[2] = {1, 1};
-  auto kern = accumulate ? k_gemm_img8<true> : k_gemm_img8<false>;
+  auto kern = (EPI == EPI_NONE && accumulate) ? k_gemm_img8<EPI == EPI_NONE, EPI> : k_gemm_img8<false, EPI>;
   int& st = status[accumulate ? 1 : 0];
   if (st == 1)
     st = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess
              ? DGDM_OK : DGDM_ERR_LAUNCH;
   if (st != DGDM_OK) return st;
   const int gcol = (Ncols + 255) / 256, grow = (M + 127) / 128;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(gcol * grow)), dim3(256), LDS, s, A, lda, M, K, img, T_img, t_begin, Ncols, bias, C, ldc, amax_a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(gcol * grow)), dim3(256), LDS, s, A, lda, M, K, img, T_img, t_begin, Ncols, bias, C, ldc, amax_a,
+                     epi);
   return dgdm_launch_status();
 }
 
-template <int WM, int WN>
+template <int WM, int WN, int EPI>
 int launch_img(hipStream_t s, const float* A, int64_t lda, int M, int K, const char* img, int T_img, int t_begin, int Ncols,
-               const float* bias, float* C, int64_t ldc, int accumulate, const unsigned* amax_a) {
+               const float* bias, float* C, int64_t ldc, int accumulate, const unsigned* amax_a, const EpiArgs& epi) {
   constexpr int LDS = 2 * CPS * NTW * WN * BLK;
   static int status[2] = {1, 1};
-  auto kern = accumulate ? k_gemm_img<WM, WN, true> : k_gemm_img<WM, WN, false>;
+  auto kern = (EPI == EPI_NONE && accumulate) ? k_gemm_img<WM, WN, EPI == EPI_NONE, EPI> : k_gemm_img<WM, WN, false, EPI>;
   int& st = status[accumulate ? 1 : 0];
   if (st == 1)
     st = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess
@@ -549,7 +811,7 @@ int launch_img(hipStream_t s, const float* A, int64_t lda, int M, int K, const c
   if (st != DGDM_OK) return st;
   const int gcol = (Ncols + 128 * WN - 1) / (128 * WN), grow = (M + 32 * WM - 1) / (32 * WM);
   hipLaunchKernelGGL(kern, dim3((unsigned)(gcol * grow)), dim3(64 * WM * WN), LDS, s, A, lda, M, K, img, T_img, t_begin, Ncols, bias, C,
-                     ldc, amax_a);
+                     ldc, amax_a, epi);
   return dgdm_launch_status();
 }
 
@@ -602,7 +864,89 @@ extern "C" int dgdm_gemm_rows_img(const float* A, int64_t lda, int32_t M, int32_
   if (lda < K || ldc < ncols || tile_begin + (ncols + 31) / 32 > image_tiles) return DGDM_ERR_INVALID_ARG;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const char* img = static_cast<const char*>(image);
+  const EpiArgs none{};
   if (ncols <= DGDM_IMG_NARROW_MAX)
-    return launch_img<4, 1>(s, A, lda, M, K, img, image_tiles, tile_begin, ncols, bias, C, ldc, accumulate, amax_a);
-  return launch_img8(s, A, lda, M, K, img, image_tiles, tile_begin, ncols, bias, C, ldc, accumulate, amax_a);
+    return launch_img<4, 1, EPI_NONE>(s, A, lda, M, K, img, image_tiles, tile_begin, ncols, bias, C, ldc, accumulate, amax_a, none);
+  return launch_img8<EPI_NONE>(s, A, lda, M, K, img, image_tiles, tile_begin, ncols, bias, C, ldc, accumulate, amax_a, none);
+}
+
+namespace {
+
+int epi_common_checks(const float* A, int64_t lda, int32_t M, int32_t K, const void* image, int32_t image_tiles, int32_t tile_begin,
+                      int32_t ncols, float* C, int64_t ldc, const uint32_t* amax_a, int32_t act, float drop_p) {
+  if (M < 0 || K < 0 || ncols < 0 || image_tiles <= 0 || tile_begin < 0 || act < 0 || act > 3 || !(drop_p >= 0.f && drop_p < 1.f))
+    return DGDM_ERR_INVALID_ARG;
+  if (M == 0 || ncols == 0) return 1;    // nothing to do
+  if (!A || !image || !C || !amax_a) return DGDM_ERR_INVALID_ARG;
+  if (K == 0) return DGDM_ERR_UNSUPPORTED;
+  if ((K & 15) || (lda & 3) || (ncols & 3) || (ldc & 3) || !dgdm_aligned16(A) || !dgdm_aligned16(image) || !dgdm_aligned16(C))
+    return DGDM_ERR_UNSUPPORTED;
+  if (lda < K || ldc < ncols || tile_begin + (ncols + 31) / 32 > image_tiles) return DGDM_ERR_INVALID_ARG;
+  return DGDM_OK;
+}
+
+}  // namespace
+
+extern "C" int dgdm_gemm_rows_img_act(const float* A, int64_t lda, int32_t M, int32_t K, const void* image, int32_t image_tiles,
+                                      int32_t tile_begin, int32_t ncols, const float* bias, float* pre, int64_t ldp, float* Y,
+                                      int64_t ldy, int32_t act, float drop_p, uint32_t seed, const uint32_t* amax_a,
+                                      uint32_t* amax_y, void* stream) {
+  const int st = epi_common_checks(A, lda, M, K, image, image_tiles, tile_begin, ncols, Y, ldy, amax_a, act, drop_p);
+  if (st != DGDM_OK) return st > 0 ? DGDM_OK : st;
+  if (bias && !dgdm_aligned16(bias)) return DGDM_ERR_UNSUPPORTED;
+  if (pre && ((ldp & 3) || ldp < ncols || !dgdm_aligned16(pre))) return DGDM_ERR_UNSUPPORTED;
+  EpiArgs e{};
+  e.pre_out = pre; e.ldp = ldp; e.act = act; e.drop_p = drop_p; e.seed = dgdm_seed_arg(seed); e.amax_out = amax_y;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const char* img = static_cast<const char*>(image);
+  if (ncols <= DGDM_IMG_NARROW_MAX)
+    return launch_img<4, 1, EPI_ACT>(s, A, lda, M, K, img, image_tiles, tile_begin, ncols, bias, Y, ldy, 0, amax_a, e);
+  return launch_img8<EPI_ACT>(s, A, lda, M, K, img, image_tiles, tile_begin, ncols, bias, Y, ldy, 0, amax_a, e);
+}
+
+extern "C" int dgdm_gemm_rows_img_act_bwd(const float* A, int64_t lda, int32_t M, int32_t K, const void* image, int32_t image_tiles,
+                                          int32_t tile_begin, int32_t ncols, const float* pre, int64_t ldp, float* G, int64_t ldg,
+                                          int32_t act, float drop_p, uint32_t seed, const uint32_t* amax_a, uint32_t* amax_g,
+                                          void* stream) {
+  const int st = epi_common_checks(A, lda, M, K, image, image_tiles, tile_begin, ncols, G, ldg, amax_a, act, drop_p);
+  if (st != DGDM_OK) return st > 0 ? DGDM_OK : st;
+  if (!pre) return DGDM_ERR_INVALID_ARG;
+  if ((ldp & 3) || ldp < ncols || !dgdm_aligned16(pre)) return DGDM_ERR_UNSUPPORTED;
+  EpiArgs e{};
+  e.pre_in = pre; e.ldp = ldp; e.act = act; e.drop_p = drop_p; e.seed = dgdm_seed_arg(seed); e.amax_out = amax_g;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const char* img = static_cast<const char*>(image);
+  if (ncols <= DGDM_IMG_NARROW_MAX)
+    return launch_img<4, 1, EPI_ACTBWD>(s, A, lda, M, K, img, image_tiles, tile_begin, ncols, nullptr, G, ldg, 0, amax_a, e);
+  return launch_img8<EPI_ACTBWD>(s, A, lda, M, K, img, image_tiles, tile_begin, ncols, nullptr, G, ldg, 0, amax_a, e);
+}
+
+extern "C" int32_t dgdm_gemm_rows_img_norm_supported(int32_t ncols, int32_t groups) {
+  if (ncols <= 0 || groups <= 0 || ncols % groups) return 0;
+  const int L = ncols / groups;
+  if (L % 32 || (L & (L - 1))) return 0;               // whole 32-column tiles, a power of two of them per group
+  // a group must lie inside one wave's columns: 128 per wave on the narrow kernel (taken up to DGDM_IMG_NARROW_MAX columns), 256 on the wide one
+  return (ncols <= 128 || (ncols <= DGDM_IMG_NARROW_MAX && L <= 128) || L <= 256) ? 1 : 0;
+}
+
+extern "C" int dgdm_gemm_rows_img_norm(const float* A, int64_t lda, int32_t M, int32_t K, const void* image, int32_t image_tiles,
+                                       int32_t tile_begin, int32_t ncols, const float* bias, const float* res, int64_t ldr,
+                                       const float* gamma, const float* beta, int32_t groups, float eps, float* sum, int64_t lds,
+                                       float* Y, int64_t ldy, float* mean, float* rstd, int32_t act, float drop_p, uint32_t seed,
+                                       const uint32_t* amax_a, uint32_t* amax_y, void* stream) {
+  const int st = epi_common_checks(A, lda, M, K, image, image_tiles, tile_begin, ncols, Y, ldy, amax_a, act, drop_p);
+  if (st != DGDM_OK) return st > 0 ? DGDM_OK : st;
+  if (!gamma || !beta || !mean || !rstd || groups <= 0) return DGDM_ERR_INVALID_ARG;
+  if (!dgdm_gemm_rows_img_norm_supported(ncols, groups)) return DGDM_ERR_UNSUPPORTED;
+  if ((bias && !dgdm_aligned16(bias)) || !dgdm_aligned16(gamma) || !dgdm_aligned16(beta)) return DGDM_ERR_UNSUPPORTED;
+  if (res && ((ldr & 3) || ldr < ncols || !dgdm_aligned16(res))) return DGDM_ERR_UNSUPPORTED;
+  if (sum && ((lds & 3) || lds < ncols || !dgdm_aligned16(sum))) return DGDM_ERR_UNSUPPORTED;
+  EpiArgs e{};
+  e.res = res; e.ldr = ldr; e.gamma = gamma; e.beta = beta; e.sum_out = sum; e.lds = lds; e.mean = mean; e.rstd = rstd;
+  e.eps = eps; e.L = ncols / groups; e.act = act; e.drop_p = drop_p; e.seed = dgdm_seed_arg(seed); e.amax_out = amax_y;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const char* img = static_cast<const char*>(image);
+  if (ncols <= DGDM_IMG_NARROW_MAX && e.L <= 128)
+    return launch_img<4, 1, EPI_NORM>(s, A, lda, M, K, img, image_tiles, tile_begin, ncols, bias, Y, ldy, 0, amax_a, e);
+  return launch_img8<EPI_NORM>(s, A, lda, M, K, img, image_tiles, tile_begin, ncols, bias, Y, ldy, 0, amax_a, e);
 }

@@ -542,6 +542,36 @@ DGDM_API int dgdm_gemm_rows_img(const float* A, int64_t lda, int32_t M, int32_t 
                                 int32_t tile_begin, int32_t ncols, const float* bias, float* C, int64_t ldc, int32_t accumulate,
                                 const uint32_t* amax_a, void* stream);
 
+/* K3-img with fused epilogues (round 5).  The layer that follows a Linear on the path is finished in the GEMM's registers
+ * instead of by a kernel of its own (SURVEY.md 2c, K3/K6 "fused epilogues"); operands and arithmetic as dgdm_gemm_rows_img,
+ * ncols % 4 == 0, every matrix 16-byte aligned with a leading dimension that is a multiple of 4.  Dropout masks are the function
+ * of (seed, row * ncols + col) that dgdm_act_dropout_* / dgdm_rownorm_* use on a contiguous [M, ncols] tensor (csrc/rowmath.hpp),
+ * so either side can regenerate the other's mask.  amax_y / amax_g: nullable amax slot that receives max|output|.
+ *   dgdm_gemm_rows_img_act:      pre = A.B + bias (stored when `pre` is not NULL: the backward needs it),
+ *                                Y = dropout(act(pre))                     core/graph_layers.py:233-239  dropout(GELU(conv(x)))
+ *   dgdm_gemm_rows_img_act_bwd:  G = (A.B) * act'(pre) * mask              the backward of that layer, as the epilogue of the GEMM
+ *                                                                          that forms its incoming gradient (A = dY_next, B = W_next)
+ *   dgdm_gemm_rows_img_norm:     S = A.B + bias [+ res] (stored when `sum` is not NULL: it is the input dgdm_rownorm_bwd reads),
+ *                                Y = dropout(act(norm_groups(S) * gamma + beta)), mean / rstd [M * groups]
+ *                                core/graph_layers.py:241-245 norm1(output_proj(h) + x); models/encoders.py:267-269;
+ *                                core/diffusion.py:94-102 GroupNorm(8) + SiLU + dropout behind the denoiser's Linears.
+ *     A (row, group) must lie inside one wave's columns: dgdm_gemm_rows_img_norm_supported(ncols, groups) says whether the
+ *     shape is taken (ncols / groups a power-of-two multiple of 32, at most 256; LayerNorm: ncols <= 256). */
+DGDM_API int dgdm_gemm_rows_img_act(const float* A, int64_t lda, int32_t M, int32_t K, const void* image, int32_t image_tiles,
+                                    int32_t tile_begin, int32_t ncols, const float* bias, float* pre, int64_t ldp, float* Y,
+                                    int64_t ldy, int32_t act, float drop_p, uint32_t seed, const uint32_t* amax_a, uint32_t* amax_y,
+                                    void* stream);
+DGDM_API int dgdm_gemm_rows_img_act_bwd(const float* A, int64_t lda, int32_t M, int32_t K, const void* image, int32_t image_tiles,
+                                        int32_t tile_begin, int32_t ncols, const float* pre, int64_t ldp, float* G, int64_t ldg,
+                                        int32_t act, float drop_p, uint32_t seed, const uint32_t* amax_a, uint32_t* amax_g,
+                                        void* stream);
+DGDM_API int32_t dgdm_gemm_rows_img_norm_supported(int32_t ncols, int32_t groups);
+DGDM_API int dgdm_gemm_rows_img_norm(const float* A, int64_t lda, int32_t M, int32_t K, const void* image, int32_t image_tiles,
+                                     int32_t tile_begin, int32_t ncols, const float* bias, const float* res, int64_t ldr,
+                                     const float* gamma, const float* beta, int32_t groups, float eps, float* sum, int64_t lds,
+                                     float* Y, int64_t ldy, float* mean, float* rstd, int32_t act, float drop_p, uint32_t seed,
+                                     const uint32_t* amax_a, uint32_t* amax_y, void* stream);
+
 /* Deferred reduction of the split-M weight-gradient GEMMs.  dgdm_gemm_tn_partial_* run only the first half of dgdm_gemm_tn_*
  * (chunk partials into `workspace`, [dgdm_gemm_tn_chunks(M,N,K)][N*K (+N when with_bias)] floats); dgdm_gemm_tn_reduce_many then
  * reduces up to DGDM_TN_REDUCE_MAX such workspaces in ONE launch, with the arithmetic (fixed order) of the immediate reduction.
