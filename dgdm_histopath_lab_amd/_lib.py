@@ -142,8 +142,8 @@ SIGNATURES = {
     "dgdm_gemm_rows_img_act": (C.c_int, [_p, _i64, _i32, _i32, _p, _i32, _i32, _i32, _p, _p, _i64, _p, _i64, _i32, C.c_float, C.c_uint32, _p, _p, _p]),
     "dgdm_gemm_rows_img_act_bwd": (C.c_int, [_p, _i64, _i32, _i32, _p, _i32, _i32, _i32, _p, _i64, _p, _i64, _i32, C.c_float, C.c_uint32, _p, _p, _p]),
     "dgdm_gemm_rows_img_norm_supported": (_i32, [_i32, _i32]),
-    "dgdm_gemm_rows_img_norm": (C.c_int, [_p, _i64, _i32, _i32, _p, _i32, _i32, _i32, _p, _p, _i64, _p, _p, _i32, C.c_float, _p, _i64, _p, _i64,
-                                          _p, _p, _i32, C.c_float, C.c_uint32, _p, _p, _p]),
+    "dgdm_gemm_rows_img_norm": (C.c_int, [_p, _i64, _i32, _i32, _p, _i32, _i32, _i32, _p, C.c_float, C.c_uint32, _p, _i64, _p, _i32, _p, _p, _i32,
+                                          C.c_float, _p, _i64, _p, _i64, _p, _p, _i32, C.c_float, C.c_uint32, _p, _p, _p]),
     "dgdm_spmm": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _p, _i64, _i32, _i32, _p, _i32, _p, _p]),
     "dgdm_spmm_add": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _p, _i64, _p, _i64, _i32, _i32, _p, _p]),
     "dgdm_spmm_concat": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _p, _i64, _i32, _p, _i64, _i32, _i32, _p, _p, _p]),

@@ -89,9 +89,11 @@ class SpatialAttention(nn.Module):
         qkv = att.fused_qkv(xp)
         o = ops.spatial_attention(qkv, pos, plan, att.num_heads, 1.0 / math.sqrt(att.head_dim), 1.0 / self.temperature,
                                   att.attn_dropout.p, att.training)
-        o = ops.act_dropout(ops.lin(att.out_proj, att.unpad_heads(o)), ops.ACT_NONE, att.resid_dropout.p, att.training)
         if ops.row_norm_supported(self.embed_dim, 1):
-            return ops.row_norm(o, self.norm.weight, self.norm.bias, res=x, eps=self.norm.eps)
+            # LN(x + dropout(out_proj(o))): projection, residual dropout, residual add and norm in one launch where the row fits
+            return ops.linear_norm(att.unpad_heads(o), att.out_proj.weight, att.out_proj.bias, self.norm.weight, self.norm.bias, eps=self.norm.eps,
+                                   res=x, pre_drop_p=att.resid_dropout.p, training=att.training)
+        o = ops.act_dropout(ops.lin(att.out_proj, att.unpad_heads(o)), ops.ACT_NONE, att.resid_dropout.p, att.training)
         return self.norm(x + o)
 
     def attention_weights(self, x: Tensor, pos: Tensor, plan: ops.AttnPlan) -> List[Tensor]:

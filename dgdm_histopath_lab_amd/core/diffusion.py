@@ -109,16 +109,20 @@ class DiffusionLayer(nn.Module):
             tabs[key] = self.get_timestep_embedding(torch.arange(self.num_timesteps, device=device)).contiguous()
         return tabs[key]
 
-    def _denoise_tail(self, h: Tensor) -> Tensor:
+    def _check_group_norms(self) -> None:
         for i in (1, 5):
-            gn, drop, lin = self.denoise_net[i], self.denoise_net[i + 2], self.denoise_net[i + 3]
-            if not ops.row_norm_supported(h.size(1), gn.num_groups):
-                raise ops._lib.DGDMKernelError(f"GroupNorm({gn.num_groups}, {h.size(1)}): the fused row kernels need group widths that are "
-                                               "multiples of 4 channels")
-            h = ops.row_norm(h, gn.weight, gn.bias, groups=gn.num_groups, eps=gn.eps, act=ops.ACT_SILU, drop_p=drop.p,
-                             training=self.training)
-            h = ops.lin(lin, h)
-        return h
+            gn = self.denoise_net[i]
+            if not ops.row_norm_supported(gn.num_channels, gn.num_groups):
+                raise ops._lib.DGDMKernelError(f"GroupNorm({gn.num_groups}, {gn.num_channels}): the fused row kernels need group widths that "
+                                               "are multiples of 4 channels")
+
+    def _denoise_tail(self, h: Tensor) -> Tensor:
+        """``h``: the first layer's output AFTER its GroupNorm + SiLU + dropout (``ops.denoise_first_layer(..., norm=...)``).
+        Linear -> GroupNorm -> SiLU -> dropout (one launch where the GEMM takes the norm as its epilogue), then the last Linear."""
+        gn, drop, lin = self.denoise_net[5], self.denoise_net[7], self.denoise_net[4]
+        h = ops.linear_norm(h, lin.weight, lin.bias, gn.weight, gn.bias, groups=gn.num_groups, eps=gn.eps, act=ops.ACT_SILU, drop_p=drop.p,
+                            training=self.training)
+        return ops.lin(self.denoise_net[8], h)
 
     def predict_noise_segments(self, x_noisy: Tensor, timesteps: Tensor, seg: Tensor, plan=None) -> Tensor:
         """x_noisy [N_tot, C]; timesteps [B]; seg [N_tot] graph id per row; ``plan`` (ops.AttnPlan)
@@ -128,7 +132,9 @@ class DiffusionLayer(nn.Module):
                 raise ValueError("predict_noise_segments needs the batch plan when graphs carry different timesteps")
             plan = ops.AttnPlan([0, x_noisy.size(0)], x_noisy.device)
         lin0 = self.denoise_net[0]
-        h = ops.denoise_first_layer(x_noisy, self.time_features(timesteps), lin0.weight, lin0.bias, plan)
+        self._check_group_norms()
+        h = ops.denoise_first_layer(x_noisy, self.time_features(timesteps), lin0.weight, lin0.bias, plan, norm=self.denoise_net[1],
+                                    drop_p=self.denoise_net[3].p, training=self.training)
         return self._denoise_tail(h)
 
     # -- reference-shaped API (same graph for every row) --------------------------------------
@@ -225,12 +231,13 @@ class DiffusionLayer(nn.Module):
         bias = self.time_bias(ops.device_constant(range(self.num_timesteps), torch.long, device))       # [T, 2*hidden]
         row = list(range(self.num_timesteps))
         w0x = self.denoise_net[0].weight[:, :C]
+        gn1 = self.denoise_net[1]
+        self._check_group_norms()
         for i, t in enumerate(ts):
             last = i == len(ts) - 1
-            if x.size(0) >= ops.GEMM_MIN_ROWS:
-                h = ops.gemm_nt_raw(x, w0x, bias[row[t]], math=ops.GEMM_MATH)
-            else:
-                h = ops.linear_small_fwd_raw(x, w0x, bias[row[t]])[0]
+            # first layer (the time half of its weight enters as the bias) with its GroupNorm + SiLU + dropout
+            h = ops.linear_norm(x, w0x, bias[row[t]], gn1.weight, gn1.bias, groups=gn1.num_groups, eps=gn1.eps, act=ops.ACT_SILU,
+                                drop_p=self.denoise_net[3].p, training=self.training)
             eps = self._denoise_tail(h)
             z = None if last else (torch.randn_like(x) if step_noise is None else step_noise[i])
             x = ops.ddpm_step(x, eps, z, s1mac[t], sac[t], salpha[t], svar[t], last)

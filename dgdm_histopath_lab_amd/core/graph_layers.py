@@ -124,6 +124,12 @@ class DynamicGraphLayer(nn.Module):
     def forward(self, x: Tensor, edge_index: Union[Tensor, GraphContext], edge_attr: Optional[Tensor] = None) -> Tensor:
         ctx = _context(edge_index, x, edge_attr)
         p, tr = self.dropout.p, self.training
+        c1, c2 = self.graph_conv1, self.graph_conv2
+        if (isinstance(self.norm1, nn.LayerNorm) and c1.edge_lin is not None and c2.edge_lin is not None and c1.bias is not None
+                and c2.bias is not None and c1.add_self_loops and c2.add_self_loops
+                and ops.graph_layer_supported(x, ctx.ea_hat, self.node_dim, self.hidden_dim, self.edge_dim)):
+            # the whole layer as one autograd node: 5 launches forward, 6 backward, activations and the norm as GEMM epilogues
+            return ops.graph_layer(x, ctx.ea_hat, ctx.gs, c1, c2, self.output_proj, self.norm1, p, tr)
         h, xs = self.graph_conv1(x, ctx, return_skip=True)      # xs: x for the residual below (see GraphConvolution.forward)
         h = ops.act_dropout(h, ops.ACT_GELU, p, tr)
         h = ops.act_dropout(self.graph_conv2(h, ctx), ops.ACT_GELU, p, tr)

@@ -175,7 +175,9 @@ struct EpiArgs {
   const float* pre_in;              // ACTBWD: pre-activation [M, ncols], leading dimension ldp
   float* pre_out;                   // ACT: nullable; receives A.B + bias (ldp)
   int64_t ldp;
-  const float* res; int64_t ldr;    // NORM: nullable residual
+  const float* res; int64_t ldr;    // NORM: nullable residual [M, ncols] -- or, with res_ptr, one row per SEGMENT of rows
+  const int* res_ptr; int res_segments;   // NORM: nullable offsets [res_segments + 1]; row r takes res row g, res_ptr[g] <= r < res_ptr[g+1]
+  float pre_drop_p; DgdmSeed pre_seed;    // NORM: dropout of A.B + bias BEFORE the residual is added (core/attention.py:176-181)
   const float* gamma; const float* beta;
   float* sum_out; int64_t lds;      // NORM: nullable; receives A.B + bias + res (what the norm's backward reads as its input)
   float* mean; float* rstd;         // NORM: [M * G]
@@ -309,6 +311,18 @@ __device__ __forceinline__ void epilogue_tr(f32x16 (&acc)[NT], const float inv, 
     const int tpg = e.L >> 5;
     const float invL = 1.0f / (float)e.L;
     float mu[NT], rs[NT];
+    int64_t rrow = row;                               // the residual's row: this row, or the row of this row's segment
+    if (e.res_ptr && rok) {
+      int lo = 0, hi_ = e.res_segments - 1;           // last g with res_ptr[g] <= row
+      while (lo < hi_) {
+        const int mid = (lo + hi_ + 1) >> 1;
+        if (e.res_ptr[mid] <= row) lo = mid; else hi_ = mid - 1;
+      }
+      rrow = lo;
+    }
+    const uint32_t pseed = e.pre_seed.value();
+    const uint32_t pthresh = (uint32_t)(e.pre_drop_p * 65536.0f);
+    const float pkeep = e.pre_drop_p > 0.f ? 1.0f / (1.0f - (float)pthresh / 65536.0f) : 1.0f;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       float s = 0.f;
@@ -317,9 +331,14 @@ __device__ __forceinline__ void epilogue_tr(f32x16 (&acc)[NT], const float inv, 
         const int col = cl + 32 * t + 8 * q;
         const bool ok = rok && col < Ncols;
         const float4 b = ld4_if(bias + col, bias && col < Ncols);
-        const float4 r4 = ld4_if(e.res + (int64_t)row * e.ldr + col, e.res && ok);
-        const float4 v = make_float4(fmaf(acc[t][4 * q], inv, b.x) + r4.x, fmaf(acc[t][4 * q + 1], inv, b.y) + r4.y,
-                                     fmaf(acc[t][4 * q + 2], inv, b.z) + r4.z, fmaf(acc[t][4 * q + 3], inv, b.w) + r4.w);
+        const float4 r4 = ld4_if(e.res + rrow * e.ldr + col, e.res && ok);
+        float4 v = make_float4(fmaf(acc[t][4 * q], inv, b.x), fmaf(acc[t][4 * q + 1], inv, b.y), fmaf(acc[t][4 * q + 2], inv, b.z),
+                               fmaf(acc[t][4 * q + 3], inv, b.w));
+        if (e.pre_drop_p > 0.f) {
+          const float4 m = dropout_scale4(pseed, e0 + (uint64_t)col, pthresh, pkeep);
+          v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
+        }
+        v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
         DGDM_SETQ4(acc[t], q, v)
         if (e.sum_out && ok) *reinterpret_cast<float4*>(e.sum_out + (int64_t)row * e.lds + col) = v;
         s += (v.x + v.y) + (v.z + v.w);
@@ -930,19 +949,23 @@ extern "C" int32_t dgdm_gemm_rows_img_norm_supported(int32_t ncols, int32_t grou
 }
 
 extern "C" int dgdm_gemm_rows_img_norm(const float* A, int64_t lda, int32_t M, int32_t K, const void* image, int32_t image_tiles,
-                                       int32_t tile_begin, int32_t ncols, const float* bias, const float* res, int64_t ldr,
+                                       int32_t tile_begin, int32_t ncols, const float* bias, float pre_drop_p, uint32_t pre_seed,
+                                       const float* res, int64_t ldr, const int32_t* res_ptr, int32_t res_segments,
                                        const float* gamma, const float* beta, int32_t groups, float eps, float* sum, int64_t lds,
                                        float* Y, int64_t ldy, float* mean, float* rstd, int32_t act, float drop_p, uint32_t seed,
                                        const uint32_t* amax_a, uint32_t* amax_y, void* stream) {
   const int st = epi_common_checks(A, lda, M, K, image, image_tiles, tile_begin, ncols, Y, ldy, amax_a, act, drop_p);
   if (st != DGDM_OK) return st > 0 ? DGDM_OK : st;
-  if (!gamma || !beta || !mean || !rstd || groups <= 0) return DGDM_ERR_INVALID_ARG;
+  if (!gamma || !beta || !mean || !rstd || groups <= 0 || !(pre_drop_p >= 0.f && pre_drop_p < 1.f)) return DGDM_ERR_INVALID_ARG;
+  if (res_ptr && (!res || res_segments <= 0)) return DGDM_ERR_INVALID_ARG;
   if (!dgdm_gemm_rows_img_norm_supported(ncols, groups)) return DGDM_ERR_UNSUPPORTED;
   if ((bias && !dgdm_aligned16(bias)) || !dgdm_aligned16(gamma) || !dgdm_aligned16(beta)) return DGDM_ERR_UNSUPPORTED;
   if (res && ((ldr & 3) || ldr < ncols || !dgdm_aligned16(res))) return DGDM_ERR_UNSUPPORTED;
   if (sum && ((lds & 3) || lds < ncols || !dgdm_aligned16(sum))) return DGDM_ERR_UNSUPPORTED;
   EpiArgs e{};
-  e.res = res; e.ldr = ldr; e.gamma = gamma; e.beta = beta; e.sum_out = sum; e.lds = lds; e.mean = mean; e.rstd = rstd;
+  e.res = res; e.ldr = ldr; e.res_ptr = res ? res_ptr : nullptr; e.res_segments = res_segments;
+  e.pre_drop_p = pre_drop_p; e.pre_seed = dgdm_seed_arg(pre_seed);
+  e.gamma = gamma; e.beta = beta; e.sum_out = sum; e.lds = lds; e.mean = mean; e.rstd = rstd;
   e.eps = eps; e.L = ncols / groups; e.act = act; e.drop_p = drop_p; e.seed = dgdm_seed_arg(seed); e.amax_out = amax_y;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const char* img = static_cast<const char*>(image);

@@ -111,8 +111,14 @@ class GraphEncoder(nn.Module):
         h, outs = x, []
         for i, (layer, norm) in enumerate(zip(self.graph_layers, self.norm_layers)):
             h = layer(h, ctx)
-            if str(i) in self.dim_proj:
-                h = ops.lin(self.dim_proj[str(i)], h)
-            h = _norm_act_dropout(h, norm, self.activation, self.dropout, self.training)
+            aid = ops.act_id(self.activation)
+            if str(i) in self.dim_proj and isinstance(norm, nn.LayerNorm) and aid is not None:
+                dp = self.dim_proj[str(i)]      # Linear -> LayerNorm -> act -> dropout: the norm as the GEMM's epilogue where it fits
+                h = ops.linear_norm(h, dp.weight, dp.bias, norm.weight, norm.bias, eps=norm.eps, act=aid, drop_p=self.dropout.p,
+                                    training=self.training)
+            else:
+                if str(i) in self.dim_proj:
+                    h = ops.lin(self.dim_proj[str(i)], h)
+                h = _norm_act_dropout(h, norm, self.activation, self.dropout, self.training)
             outs.append(h)
         return {"embeddings": ops.lin(self.output_proj, h), "layer_outputs": outs, "num_nodes": x.size(0)}

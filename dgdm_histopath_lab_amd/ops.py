@@ -576,31 +576,37 @@ class _RowNorm(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy):
-        lib = _lib.load()
         x, res, gamma, beta, mean, rstd = ctx.saved_tensors
         groups, act, drop_p, seed = ctx.meta
-        gy = _f32c(gy)
-        N, C = x.shape
-        dx = torch.empty_like(x)
-        dg, db = torch.empty_like(gamma), torch.empty_like(beta)
-        wsb = _lib.workspace_bytes("dgdm_rownorm_bwd_workspace_bytes", N, C, groups)
-        ws = torch.empty(max(wsb, 4) // 4, dtype=torch.float32, device=x.device)
-        slot = new_amax_slot(x.device)
-        # inside deferred_weight_grads(): the column sums of the row partials (dgamma | dbeta) join the pass's one reduction launch
-        # (as a [1, 2C] "weight gradient" split at C) instead of a launch of their own behind every norm
-        later = False
-        if _DEFER_TN and ctx.leaf and N > 0 and C % 4 == 0 and _claim_deferred(*ctx.gb):
-            slots = int(_lib.workspace_bytes("dgdm_rownorm_bwd_slots", N, C, groups))       # (memoised call, not a byte count)
-            alias = lambda t: t.detach()
-            later = slots > 0 and _defer_tn((ws.data_ptr(), dg.data_ptr(), db.data_ptr(), None, C, C, slots, 1, 2 * C, C),
-                                            (ws, alias(dg), alias(db)), _lib.stream_ptr(x.device))
-        _lib.check(lib.dgdm_rownorm_bwd(x.data_ptr(), _lib.ptr(res), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(),
-                                        rstd.data_ptr(), gy.data_ptr(), N, C, groups, act, drop_p, seed, dx.data_ptr(),
-                                        None if later else dg.data_ptr(), None if later else db.data_ptr(), ws.data_ptr(), wsb, slot,
-                                        _lib.stream_ptr(x.device)),
-                   "dgdm_rownorm_bwd")
-        tag_amax(dx, slot)
+        dx, dg, db = rownorm_bwd_raw(x, res, gamma, beta, mean, rstd, gy, groups, act, drop_p, seed, ctx.gb if ctx.leaf else None)
         return dx, (dx if res is not None else None), dg, db, None, None, None, None, None
+
+
+def rownorm_bwd_raw(x, res, gamma, beta, mean, rstd, gy, groups: int, act: int, drop_p: float, seed: int, leaf_params=None):
+    """Backward of dropout(act(norm_groups(x [+ res]) * gamma + beta)): (dx, dgamma, dbeta); dx also is the residual's gradient.
+    ``leaf_params``: the (gamma, beta) PARAMETER objects when their gradients go straight to them -- inside
+    ``deferred_weight_grads()`` the column sums of the row partials then join the pass's one reduction launch (as a [1, 2C]
+    "weight gradient" split at C) instead of a launch of their own behind every norm."""
+    lib = _lib.load()
+    gy = _f32c(gy)
+    N, C = x.shape
+    dx = torch.empty_like(x)
+    dg, db = torch.empty_like(gamma), torch.empty_like(beta)
+    wsb = _lib.workspace_bytes("dgdm_rownorm_bwd_workspace_bytes", N, C, groups)
+    ws = torch.empty(max(wsb, 4) // 4, dtype=torch.float32, device=x.device)
+    slot = new_amax_slot(x.device)
+    later = False
+    if _DEFER_TN and leaf_params is not None and N > 0 and C % 4 == 0 and _claim_deferred(*leaf_params):
+        slots = int(_lib.workspace_bytes("dgdm_rownorm_bwd_slots", N, C, groups))       # (memoised call, not a byte count)
+        alias = lambda t: t.detach()
+        later = slots > 0 and _defer_tn((ws.data_ptr(), dg.data_ptr(), db.data_ptr(), None, C, C, slots, 1, 2 * C, C),
+                                        (ws, alias(dg), alias(db)), _lib.stream_ptr(x.device))
+    _lib.check(lib.dgdm_rownorm_bwd(x.data_ptr(), _lib.ptr(res), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(),
+                                    rstd.data_ptr(), gy.data_ptr(), N, C, groups, act, drop_p, seed, dx.data_ptr(),
+                                    None if later else dg.data_ptr(), None if later else db.data_ptr(), ws.data_ptr(), wsb, slot,
+                                    _lib.stream_ptr(x.device)),
+               "dgdm_rownorm_bwd")
+    return tag_amax(dx, slot), dg, db
 
 
 def row_norm(x, weight, bias, *, res=None, groups: int = 1, eps: float = 1e-5, act: int = ACT_NONE, drop_p: float = 0.0,
@@ -1658,27 +1664,44 @@ class _DenoiseFirstLayer(torch.autograd.Function):
     by the split-M GEMM, the block of the time half by the small-M kernel) instead of two slice gradients that autograd pads and adds."""
 
     @staticmethod
-    def forward(ctx, x, te, w, b, plan: AttnPlan):
+    def forward(ctx, x, te, w, b, plan: AttnPlan, gamma=None, beta=None, norm=None):
+        """``norm`` = (groups, eps, act, drop_p, seed) with ``gamma`` / ``beta``: the GroupNorm + SiLU + dropout behind the layer
+        (core/diffusion.py:96-98) runs as the GEMM's epilogue, the per-graph time bias enters there as a per-segment residual --
+        ONE launch instead of GEMM + broadcast add + row norm."""
         lib = _lib.load()
         x, te = _rm_tagged(x), _rows(te)
         C = x.size(1)
         wx, wt = tag_amax(w[:, :C], amax_handle(w)), w[:, C:]                       # a column block is bounded by the whole matrix's maximum
         pg, _ = linear_small_fwd_raw(te, wt, b)                                # [B, N_out]
+        ctx.plan, ctx.math, ctx.has_bias, ctx.norm = plan, GEMM_MATH, b is not None, norm
+        ctx.leaf = w.is_leaf and (gamma is None or (gamma.is_leaf and beta.is_leaf))
+        ctx.wb = (w,) if ctx.leaf else None
+        ctx.gb = (gamma, beta) if (ctx.leaf and gamma is not None) else None
+        if norm is not None:
+            groups, eps, act, drop_p, seed = norm
+            out, ssum, mean, rstd = gemm_img_norm_raw(x, WEIGHT_IMAGES.get(0, wx), w.size(0), None, pg, gamma, beta, groups, eps, act, drop_p,
+                                                      seed, res_plan=plan)
+            ctx.amax = (amax_handle(x), amax_handle(wx))
+            ctx.save_for_backward(x, te, w, ssum, mean, rstd, gamma, beta)
+            return out
         h = gemm_nt_raw(x, wx, None, math=GEMM_MATH) if x.size(0) >= GEMM_MIN_ROWS else linear_small_fwd_raw(x, wx, None)[0]
         ctx.amax = (amax_handle(x), amax_handle(wx))
         out = torch.empty_like(h)
         _lib.check(lib.dgdm_segment_bcast_add(h.data_ptr(), pg.data_ptr(), plan.ptr_dev.data_ptr(), plan.B, h.size(0), h.size(1), out.data_ptr(),
                                               _lib.stream_ptr(x.device)), "dgdm_segment_bcast_add")
         ctx.save_for_backward(x, te, w)
-        ctx.plan, ctx.math, ctx.has_bias = plan, GEMM_MATH, b is not None
-        ctx.leaf = w.is_leaf
-        ctx.wb = (w,) if ctx.leaf else None
         return out
 
     @staticmethod
     def backward(ctx, g):
         lib = _lib.load()
-        x, te, w = ctx.saved_tensors
+        dgam = dbet = None
+        if ctx.norm is not None:
+            x, te, w, ssum, mean, rstd, gamma, beta = ctx.saved_tensors
+            groups, eps, act, drop_p, seed = ctx.norm
+            g, dgam, dbet = rownorm_bwd_raw(ssum, None, gamma, beta, mean, rstd, g, groups, act, drop_p, seed, ctx.gb)
+        else:
+            x, te, w = ctx.saved_tensors
         plan, C = ctx.plan, x.size(1)
         g = _rm_tagged(g)
         tag_amax(x, ctx.amax[0])
@@ -1701,7 +1724,7 @@ class _DenoiseFirstLayer(torch.autograd.Function):
         _lib.check(lib.dgdm_linear_small_bwd(gpg.data_ptr(), _ld(gpg), None, 0, ACT_NONE, te.data_ptr(), _ld(te), wt.data_ptr(), _ld(wt), te.size(0),
                                              N_out, K - C, _lib.ptr(dte), K - C, dw[:, C:].data_ptr(), K, _lib.ptr(db), _lib.stream_ptr(dev)),
                    "dgdm_linear_small_bwd")
-        return dx, dte, dw, db, None
+        return dx, dte, dw, db, None, dgam, dbet, None
 
 
 def _small_dx(g, w):
@@ -1713,10 +1736,19 @@ def _small_dx(g, w):
     return dx
 
 
-def denoise_first_layer(x, te, weight, bias, plan: AttnPlan):
+def denoise_first_layer(x, te, weight, bias, plan: AttnPlan, norm=None, drop_p: float = 0.0, training: bool = False):
+    """First denoiser Linear on [x_t | t_emb]; with ``norm`` (the nn.GroupNorm behind it) also that norm + SiLU + dropout
+    (core/diffusion.py:94-98) -- as the GEMM's epilogue where the shape is taken, by the row-norm kernel otherwise."""
     if weight.size(0) % 4 or x.size(1) % 4 or (weight.size(1) - x.size(1)) > SMALL_MAX_K or not weight.is_contiguous():
         raise _lib.DGDMKernelError("denoiser widths must be multiples of 4 (and the time embedding at most 2048 wide)")
-    return _DenoiseFirstLayer.apply(x, te, weight, bias, plan)
+    if norm is None:
+        return _DenoiseFirstLayer.apply(x, te, weight, bias, plan)
+    p = float(drop_p) if training else 0.0
+    if (x.size(0) >= GEMM_MIN_ROWS and epilogues_available(x.size(1)) and gemm_img_norm_supported(weight.size(0), norm.num_groups)):
+        return _DenoiseFirstLayer.apply(x, te, weight, bias, plan, norm.weight, norm.bias,
+                                        (norm.num_groups, norm.eps, ACT_SILU, p, next_dropout_seed() if p > 0 else 0))
+    h = _DenoiseFirstLayer.apply(x, te, weight, bias, plan)
+    return row_norm(h, norm.weight, norm.bias, groups=norm.num_groups, eps=norm.eps, act=ACT_SILU, drop_p=p, training=training)
 
 
 def lin(module, x: torch.Tensor) -> torch.Tensor:
@@ -1785,6 +1817,225 @@ class _GraphConvLinear(torch.autograd.Function):
 
 def graph_conv_linear(x, ea_hat, gs: GraphStructure, w, we, b, skip: bool = False):
     return _GraphConvLinear.apply(x, ea_hat, gs, w, we, b, skip)
+
+
+# ----------------------------------------------------------------------------- K3 + K6 in one launch: GEMMs with fused epilogues
+FUSE_EPILOGUES = True     # tools/ A/B switch: False keeps every activation / norm behind a GEMM in a kernel of its own (the round-4 path)
+
+
+def epilogues_available(*widths: int) -> bool:
+    """The fused-epilogue GEMMs are the weight-image kernels: fp16 hi+lo arithmetic, every reduction length a multiple of 16."""
+    return FUSE_EPILOGUES and USE_WEIGHT_IMAGES and GEMM_MATH == "f16x2" and all(w % 16 == 0 and w >= 16 for w in widths)
+
+
+def gemm_img_act_raw(a, e: "_WImage", ncols: int, bias, act: int, drop_p: float, seed: int, want_pre: bool = True):
+    """(Y, pre): pre = a . B + bias, Y = dropout(act(pre)) from ONE launch (dgdm_gemm_rows_img_act); Y carries its operand maximum."""
+    M, K = a.shape
+    y = torch.empty(M, ncols, dtype=torch.float32, device=a.device)
+    pre = torch.empty_like(y) if want_pre else None
+    slot = new_amax_slot(a.device)
+    TIMERS.timed("gemm_img_act", lambda: _lib.check(_lib.load().dgdm_gemm_rows_img_act(
+        a.data_ptr(), a.stride(0), M, K, e.img.data_ptr(), e.tiles, 0, ncols, _lib.ptr(bias), _lib.ptr(pre), ncols, y.data_ptr(), ncols,
+        act, drop_p, seed, ensure_amax(a), slot, _lib.stream_ptr(a.device)), "dgdm_gemm_rows_img_act"))
+    return tag_amax(y, slot), pre
+
+
+def gemm_img_act_bwd_raw(a, e: "_WImage", ncols: int, pre, act: int, drop_p: float, seed: int):
+    """G = (a . B) * act'(pre) * mask (dgdm_gemm_rows_img_act_bwd): the activation's backward as the epilogue of the GEMM that
+    forms its incoming gradient."""
+    M, K = a.shape
+    g = torch.empty(M, ncols, dtype=torch.float32, device=a.device)
+    slot = new_amax_slot(a.device)
+    TIMERS.timed("gemm_img_act_bwd", lambda: _lib.check(_lib.load().dgdm_gemm_rows_img_act_bwd(
+        a.data_ptr(), a.stride(0), M, K, e.img.data_ptr(), e.tiles, 0, ncols, pre.data_ptr(), pre.stride(0), g.data_ptr(), ncols,
+        act, drop_p, seed, ensure_amax(a), slot, _lib.stream_ptr(a.device)), "dgdm_gemm_rows_img_act_bwd"))
+    return tag_amax(g, slot)
+
+
+def gemm_img_norm_supported(ncols: int, groups: int) -> bool:
+    return bool(_lib.load().dgdm_gemm_rows_img_norm_supported(ncols, groups))
+
+
+def gemm_img_norm_raw(a, e: "_WImage", ncols: int, bias, res, gamma, beta, groups: int, eps: float, act: int = ACT_NONE,
+                      drop_p: float = 0.0, seed: int = 0, want_sum: bool = True, res_plan: Optional[AttnPlan] = None,
+                      pre_drop_p: float = 0.0, pre_seed: int = 0):
+    """(Y, S, mean, rstd): S = dropout_pre(a . B + bias) [+ res], Y = dropout(act(norm_groups(S) * gamma + beta)) from ONE launch
+    (dgdm_gemm_rows_img_norm).  S is what ``rownorm_bwd_raw`` takes as the norm's input (with res=None).  ``res_plan``: ``res`` has
+    one row per graph of the plan (broadcast over the graph's rows)."""
+    M, K = a.shape
+    y = torch.empty(M, ncols, dtype=torch.float32, device=a.device)
+    ssum = torch.empty_like(y) if want_sum else None
+    mean = torch.empty(M * groups, dtype=torch.float32, device=a.device)
+    rstd = torch.empty_like(mean)
+    slot = new_amax_slot(a.device)
+    rp, rs = (None, 0) if res_plan is None else (res_plan.ptr_dev.data_ptr(), res_plan.B)
+    TIMERS.timed("gemm_img_norm", lambda: _lib.check(_lib.load().dgdm_gemm_rows_img_norm(
+        a.data_ptr(), a.stride(0), M, K, e.img.data_ptr(), e.tiles, 0, ncols, _lib.ptr(bias), pre_drop_p, pre_seed, _lib.ptr(res),
+        0 if res is None else _ld(res), rp, rs, gamma.data_ptr(), beta.data_ptr(), groups, eps, _lib.ptr(ssum), ncols, y.data_ptr(), ncols,
+        mean.data_ptr(), rstd.data_ptr(), act, drop_p, seed, ensure_amax(a), slot, _lib.stream_ptr(a.device)), "dgdm_gemm_rows_img_norm"))
+    return tag_amax(y, slot), ssum, mean, rstd
+
+
+class _LinearNorm(torch.autograd.Function):
+    """dropout(act(norm_groups(dropout_pre(x W^T + b) [+ res]) * gamma + beta)) with the norm as the GEMM's epilogue: ONE launch for a
+    Linear followed by a LayerNorm / GroupNorm site (models/encoders.py:262-269 dim_proj -> LayerNorm -> GELU -> dropout;
+    core/diffusion.py:98-102 Linear -> GroupNorm(8) -> SiLU -> dropout; core/attention.py:176-181,325 LN(x + dropout(out_proj(o)))).
+    Backward: the row-norm backward kernel on the stored pre-norm sum, then the Linear's two GEMMs."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, res, gamma, beta, groups, eps, act, drop_p, seed, pre_drop_p, pre_seed):
+        x, w = _rm_tagged(x), _rm_tagged(w)
+        n_out = w.size(0)
+        y, ssum, mean, rstd = gemm_img_norm_raw(x, WEIGHT_IMAGES.get(0, w), n_out, b, None if res is None else _rowmajor(res), gamma, beta,
+                                                groups, eps, act, drop_p, seed, pre_drop_p=pre_drop_p, pre_seed=pre_seed)
+        ctx.save_for_backward(x, w, ssum, mean, rstd, gamma, beta)
+        ctx.meta = (groups, act, drop_p, seed, pre_drop_p, pre_seed, b is not None, res is not None)
+        ctx.amax = (amax_handle(x), amax_handle(w))
+        params = (w, b, gamma, beta)
+        ctx.leaf = all(p is None or p.is_leaf for p in params)
+        ctx.params = params if ctx.leaf else None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, ssum, mean, rstd, gamma, beta = ctx.saved_tensors
+        groups, act, drop_p, seed, pre_drop_p, pre_seed, has_bias, has_res = ctx.meta
+        tag_amax(x, ctx.amax[0]); tag_amax(w, ctx.amax[1])
+        P = ctx.params
+        ds, dgam, dbet = rownorm_bwd_raw(ssum, None, gamma, beta, mean, rstd, gy, groups, act, drop_p, seed, (P[2], P[3]) if ctx.leaf else None)
+        do = ds
+        if pre_drop_p > 0:       # the projection's gradient passes the residual dropout's mask; the residual's does not
+            do = torch.empty_like(ds)
+            slot = new_amax_slot(ds.device)
+            _lib.check(_lib.load().dgdm_act_dropout_bwd(ds.data_ptr(), ds.data_ptr(), ds.numel(), ACT_NONE, pre_drop_p, pre_seed, do.data_ptr(),
+                                                        None, slot, _lib.stream_ptr(ds.device)), "dgdm_act_dropout_bwd")
+            tag_amax(do, slot)
+        dx = gemm_nn_raw(do, w, math="f16x2") if ctx.needs_input_grad[0] else None
+        dw, db = gemm_tn_raw(do, x, has_bias, math="f16x2", may_defer=ctx.leaf and _claim_deferred(P[0], P[1]))
+        return dx, dw, db, (ds if has_res else None), dgam, dbet, None, None, None, None, None, None, None
+
+
+def linear_norm(x, weight, bias, norm_weight, norm_bias, *, groups: int = 1, eps: float = 1e-5, res=None, act: int = ACT_NONE,
+                drop_p: float = 0.0, pre_drop_p: float = 0.0, training: bool = False):
+    """``row_norm(dropout_pre(linear(x, weight, bias)), ..., res=res)``; one launch (the norm as the GEMM's epilogue) where the shape
+    is taken, the separate kernels otherwise.  Dropout seeds are drawn in the order the separate kernels draw them."""
+    p, pp = (float(drop_p), float(pre_drop_p)) if training else (0.0, 0.0)
+    if (x.dim() == 2 and x.is_cuda and x.dtype == torch.float32 and x.size(0) >= GEMM_MIN_ROWS and epilogues_available(x.size(1))
+            and weight.size(0) % 4 == 0 and gemm_img_norm_supported(weight.size(0), groups)):
+        pre_seed = next_dropout_seed() if pp > 0 else 0
+        seed = next_dropout_seed() if p > 0 else 0
+        return _LinearNorm.apply(x, weight, bias, res, norm_weight, norm_bias, groups, eps, act, p, seed, pp, pre_seed)
+    h = linear(x, weight, bias)
+    if pp > 0:
+        h = act_dropout(h, ACT_NONE, pp, True)
+    return row_norm(h, norm_weight, norm_bias, res=res, groups=groups, eps=eps, act=act, drop_p=p, training=training)
+
+
+def _spmm_concat_raw(x, ea_hat, gs: GraphStructure):
+    """[A_hat x | EA_hat] with its operand maximum (dgdm_spmm_concat)."""
+    n, cin, ed = gs.num_nodes, x.size(1), ea_hat.size(1)
+    buf = torch.empty(n, cin + ed, dtype=torch.float32, device=x.device)
+    slot = new_amax_slot(x.device)
+    TIMERS.timed(f"spmm_c{cin}", lambda: _lib.check(
+        _lib.load().dgdm_spmm_concat(gs.rowptr.data_ptr(), gs.col.data_ptr(), gs.w.data_ptr(), x.data_ptr(), x.stride(0), x.size(0),
+                                     ea_hat.data_ptr(), ea_hat.stride(0), ed, buf.data_ptr(), buf.stride(0), n, cin, slot,
+                                     _lr(gs.long_rows()), _lib.stream_ptr(x.device)), "dgdm_spmm_concat"))
+    return tag_amax(buf, slot)
+
+
+def _spmm_t_amax_raw(g, gs: GraphStructure):
+    """A_hat^T g with its operand maximum (the result feeds a GEMM): dgdm_spmm_concat on the transposed index, no tail."""
+    n, c = gs.num_nodes, g.size(1)
+    out = torch.empty(n, c, dtype=torch.float32, device=g.device)
+    slot = new_amax_slot(g.device)
+    TIMERS.timed(f"spmm_c{c}", lambda: _lib.check(
+        _lib.load().dgdm_spmm_concat(gs.rowptr_t.data_ptr(), gs.col_t.data_ptr(), gs.w_t.data_ptr(), g.data_ptr(), g.stride(0), g.size(0),
+                                     None, 0, 0, out.data_ptr(), out.stride(0), n, c, slot, _lr(gs.long_rows(True)),
+                                     _lib.stream_ptr(g.device)), "dgdm_spmm_concat"))
+    return tag_amax(out, slot)
+
+
+class _GraphLayer(torch.autograd.Function):
+    """DynamicGraphLayer (core/graph_layers.py:207-247 of the reference) as ONE autograd node:
+
+        norm1( output_proj( drop(GELU( conv2( drop(GELU( conv1(x) )) ) )) ) + x )
+
+    forward, 5 launches (8 before): [A x | EA] -> GEMM + bias + GELU + dropout -> [A h1 | EA] -> GEMM + bias + GELU + dropout ->
+    GEMM + bias + residual + LayerNorm (a GEMM and a row-norm launch when the row does not fit one wave's columns);
+    backward, 6 launches (8): LayerNorm backward -> GEMM (. W_o) * GELU'(pre2) * mask -> A^T -> GEMM (. W_2) * GELU'(pre1) * mask
+    -> GEMM (. W_1) -> A^T + residual gradient; the second convolution's input gradient is formed as (A^T dpre2) . W_2 instead of
+    A^T (dpre2 . W_2) -- the same sum, associated so that the activation's backward is a GEMM epilogue.  The three weight-gradient
+    GEMMs and the norm's dgamma / dbeta join the pass's deferred reduction launches exactly as the separate nodes did."""
+
+    @staticmethod
+    def forward(ctx, x, ea_hat, gs, w1, we1, b1, w2, we2, b2, wo, bo, gamma, beta, eps, drop_p, seeds):
+        x = x if (x.dim() == 2 and x.stride(1) == 1 and x.stride(0) % 4 == 0) else _f32c(x)
+        ea_hat = _rowmajor(ea_hat)
+        w1, w2, wo = _rm_tagged(w1), _rm_tagged(w2), _rm_tagged(wo)
+        hid, node = w1.size(0), wo.size(0)
+        z1 = _spmm_concat_raw(x, ea_hat, gs)
+        h1, pre1 = gemm_img_act_raw(z1, WEIGHT_IMAGES.get(0, w1, we1), hid, b1, ACT_GELU, drop_p, seeds[0])
+        z2 = _spmm_concat_raw(h1, ea_hat, gs)
+        h2, pre2 = gemm_img_act_raw(z2, WEIGHT_IMAGES.get(0, w2, we2), hid, b2, ACT_GELU, drop_p, seeds[1])
+        fused_norm = gemm_img_norm_supported(node, 1)
+        if fused_norm:
+            y, ssum, mean, rstd = gemm_img_norm_raw(h2, WEIGHT_IMAGES.get(0, wo), node, bo, x, gamma, beta, 1, eps)
+            res = None
+        else:
+            ssum = _gemm_rows_img(h2, WEIGHT_IMAGES.get(0, wo), 0, node, bo, None, False)
+            y = torch.empty_like(ssum)
+            mean = torch.empty(ssum.size(0), dtype=torch.float32, device=x.device)
+            rstd = torch.empty_like(mean)
+            slot = new_amax_slot(x.device)
+            _lib.check(_lib.load().dgdm_rownorm_fwd(ssum.data_ptr(), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), ssum.size(0), node, 1,
+                                                    eps, ACT_NONE, 0.0, 0, y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), slot,
+                                                    _lib.stream_ptr(x.device)), "dgdm_rownorm_fwd")
+            tag_amax(y, slot)
+            res = x
+        ctx.save_for_backward(z1, pre1, z2, pre2, h2, ssum, res, mean, rstd, w1, w2, wo, gamma, beta)
+        ctx.gs, ctx.meta = gs, (x.size(1), hid, node, drop_p, tuple(seeds))
+        ctx.amax = tuple(amax_handle(t) for t in (z1, z2, h2, w1, w2, wo))
+        params = (w1, we1, b1, w2, we2, b2, wo, bo, gamma, beta)
+        ctx.leaf = all(p.is_leaf for p in params)
+        ctx.params = params if ctx.leaf else None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        z1, pre1, z2, pre2, h2, ssum, res, mean, rstd, w1, w2, wo, gamma, beta = ctx.saved_tensors
+        gs = ctx.gs
+        cin, hid, node, drop_p, seeds = ctx.meta
+        for t, h in zip((z1, z2, h2, w1, w2, wo), ctx.amax):
+            tag_amax(t, h)
+        P = ctx.params
+        claim = lambda *idx: ctx.leaf and _claim_deferred(*(P[i] for i in idx))
+        ds, dgam, dbet = rownorm_bwd_raw(ssum, res, gamma, beta, mean, rstd, gy, 1, ACT_NONE, 0.0, 0, (P[8], P[9]) if ctx.leaf else None)
+        dwo, dbo = gemm_tn_raw(ds, h2, True, math="f16x2", may_defer=claim(6, 7))
+        dpre2 = gemm_img_act_bwd_raw(ds, WEIGHT_IMAGES.get(1, wo), hid, pre2, ACT_GELU, drop_p, seeds[1])
+        (dw2, dwe2), db2 = gemm_tn_raw(dpre2, z2, True, math="f16x2", split=hid, may_defer=claim(3, 4, 5))
+        g2 = _spmm_t_amax_raw(dpre2, gs)
+        dpre1 = gemm_img_act_bwd_raw(g2, WEIGHT_IMAGES.get(1, w2), hid, pre1, ACT_GELU, drop_p, seeds[0])
+        (dw1, dwe1), db1 = gemm_tn_raw(dpre1, z1, True, math="f16x2", split=cin, may_defer=claim(0, 1, 2))
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dagg = _gemm_rows_img(dpre1, WEIGHT_IMAGES.get(1, w1), 0, cin, None, None, False)
+            dx = spmm_raw(gs.rowptr_t, gs.col_t, gs.w_t, dagg, gs.num_nodes, addend=ds, long_rows=gs.long_rows(True))
+        return dx, None, None, dw1, dwe1, db1, dw2, dwe2, db2, dwo, dbo, dgam, dbet, None, None, None
+
+
+def graph_layer_supported(x, ea_hat, node_dim: int, hidden: int, edge_dim: int) -> bool:
+    return (ea_hat is not None and x.dim() == 2 and x.dtype == torch.float32 and x.is_cuda and x.size(0) >= GEMM_MIN_ROWS
+            and x.size(1) == node_dim and ea_hat.size(1) == edge_dim
+            and epilogues_available(node_dim + edge_dim, hidden + edge_dim, hidden, node_dim))
+
+
+def graph_layer(x, ea_hat, gs: GraphStructure, conv1, conv2, output_proj, norm, drop_p: float, training: bool):
+    """The whole DynamicGraphLayer through `_GraphLayer` (conv1 / conv2: GraphConvolution modules, norm: nn.LayerNorm)."""
+    p = float(drop_p) if training else 0.0
+    seeds = (next_dropout_seed(), next_dropout_seed()) if p > 0 else (0, 0)
+    return _GraphLayer.apply(x, ea_hat, gs, conv1.node_lin.weight, conv1.edge_lin.weight, conv1.bias, conv2.node_lin.weight,
+                             conv2.edge_lin.weight, conv2.bias, output_proj.weight, output_proj.bias, norm.weight, norm.bias,
+                             norm.eps, p, seeds)
 
 
 # ----------------------------------------------------------------------------- K9 top-k pooling / unpooling

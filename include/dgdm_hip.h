@@ -551,7 +551,11 @@ DGDM_API int dgdm_gemm_rows_img(const float* A, int64_t lda, int32_t M, int32_t 
  *                                Y = dropout(act(pre))                     core/graph_layers.py:233-239  dropout(GELU(conv(x)))
  *   dgdm_gemm_rows_img_act_bwd:  G = (A.B) * act'(pre) * mask              the backward of that layer, as the epilogue of the GEMM
  *                                                                          that forms its incoming gradient (A = dY_next, B = W_next)
- *   dgdm_gemm_rows_img_norm:     S = A.B + bias [+ res] (stored when `sum` is not NULL: it is the input dgdm_rownorm_bwd reads),
+ *   dgdm_gemm_rows_img_norm:     S = dropout_pre(A.B + bias) [+ res] (stored when `sum` is not NULL: it is the input
+ *                                dgdm_rownorm_bwd reads); pre_drop_p > 0: the dropout between a projection and the residual it
+ *                                is added to (core/attention.py:176-181, resid dropout), mask of (pre_seed, element index);
+ *                                res [M, ncols], or with res_ptr (int32 [res_segments + 1], ascending row offsets) ONE row per
+ *                                segment of rows -- the per-graph time bias of the denoiser's first layer (core/diffusion.py:165-170);
  *                                Y = dropout(act(norm_groups(S) * gamma + beta)), mean / rstd [M * groups]
  *                                core/graph_layers.py:241-245 norm1(output_proj(h) + x); models/encoders.py:267-269;
  *                                core/diffusion.py:94-102 GroupNorm(8) + SiLU + dropout behind the denoiser's Linears.
@@ -567,7 +571,8 @@ DGDM_API int dgdm_gemm_rows_img_act_bwd(const float* A, int64_t lda, int32_t M, 
                                         void* stream);
 DGDM_API int32_t dgdm_gemm_rows_img_norm_supported(int32_t ncols, int32_t groups);
 DGDM_API int dgdm_gemm_rows_img_norm(const float* A, int64_t lda, int32_t M, int32_t K, const void* image, int32_t image_tiles,
-                                     int32_t tile_begin, int32_t ncols, const float* bias, const float* res, int64_t ldr,
+                                     int32_t tile_begin, int32_t ncols, const float* bias, float pre_drop_p, uint32_t pre_seed,
+                                     const float* res, int64_t ldr, const int32_t* res_ptr, int32_t res_segments,
                                      const float* gamma, const float* beta, int32_t groups, float eps, float* sum, int64_t lds,
                                      float* Y, int64_t ldy, float* mean, float* rstd, int32_t act, float drop_p, uint32_t seed,
                                      const uint32_t* amax_a, uint32_t* amax_y, void* stream);

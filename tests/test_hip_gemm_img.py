@@ -134,3 +134,110 @@ def test_asm_issued_loads_are_retired_before_use_staging_canary(monkeypatch):
         del evict
     finally:
         ops.configure(**prev)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# fused epilogues (round 5): the layer behind a Linear finished in the GEMM's registers
+
+def _amax_bits(t, slot):
+    """Maximum over the ways of an amax slot group (device address `slot`), as the integer the kernels keep (float bits)."""
+    from dgdm_histopath_lab_amd.ops import _arena
+    ar = _arena(t.device)
+    words = ar.buf.view(torch.int32)
+    i0 = (slot - ar.buf.data_ptr()) // 4
+    return int(words[i0:i0 + 32 * 64:64].max().item())       # DGDM_AMAX_WAYS x DGDM_AMAX_STRIDE (include/dgdm_hip.h)
+
+
+def _operands(m, k, n, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(m, k, generator=g).to(DEV)
+    w = (torch.randn(n, k, generator=g) / k ** 0.5).to(DEV)
+    b = torch.randn(n, generator=g).to(DEV)
+    return x, w, b
+
+
+@pytest.mark.parametrize("m,k,n", [(1000, 160, 128), (4100, 544, 512), (300, 288, 256), (257, 64, 36), (40000, 160, 128), (2049, 128, 384)])
+@pytest.mark.parametrize("act,p", [(1, 0.1), (1, 0.0), (3, 0.25), (2, 0.1), (0, 0.5)])
+def test_act_epilogue_is_the_gemm_followed_by_the_activation_kernel(m, k, n, act, p):
+    """dgdm_gemm_rows_img_act (core/graph_layers.py:233-239, dropout(GELU(conv(x))) as the GEMM's epilogue) against the two launches
+    it replaces: the stored pre-activation equals the plain GEMM's output to fp32 rounding, the output is dgdm_act_dropout_fwd of
+    that pre-activation bit for bit (same activation code, same (seed, element index) mask), and against float64."""
+    from dgdm_histopath_lab_amd import _lib, ops
+    x, w, b = _operands(m, k, n, m + k + n + act)
+    seed = 0x1234567 + act
+    e = ops.WEIGHT_IMAGES.get(0, w)
+    y, pre = ops.gemm_img_act_raw(x, e, n, b, act, p, seed)
+    plain = ops.gemm_nt_raw(x, w, b, math="f16x2")
+    ref = x.double() @ w.double().t() + b.double()
+    assert_close(pre, ref, 1e-5, "pre vs float64")
+    assert float((pre - plain).abs().max()) <= 2e-6 * float(ref.abs().max())
+    want = torch.empty_like(pre)
+    _lib.check(_lib.load().dgdm_act_dropout_fwd(pre.data_ptr(), pre.numel(), act, p, seed, want.data_ptr(), None, None,
+                                                _lib.stream_ptr(pre.device)), "act")
+    assert torch.equal(y, want)
+    if p > 0:
+        kept = float((y != 0).float().mean()) / max(float((torch.nn.functional.gelu(pre) != 0).float().mean()) if act == 1 else 1.0, 1e-9)
+        if act in (0, 1, 3):
+            assert abs(kept - (1 - p)) < 0.02, kept
+    # the operand maximum the epilogue kept is max|y| exactly (integer maximum of float bits)
+    slot = ops.amax_of(y)
+    assert slot is not None and _amax_bits(y, slot) == int(y.abs().max().view(torch.int32).item())
+
+
+@pytest.mark.parametrize("m,k,n", [(1000, 128, 128), (4100, 512, 512), (300, 256, 256), (40000, 128, 128), (2049, 384, 128)])
+@pytest.mark.parametrize("act,p", [(1, 0.1), (1, 0.0), (3, 0.25), (2, 0.1)])
+def test_act_backward_epilogue_is_the_gemm_followed_by_the_activation_backward(m, k, n, act, p):
+    """dgdm_gemm_rows_img_act_bwd: G = (dY . W) * act'(pre) * mask from one launch, against dgdm_gemm_rows_img followed by
+    dgdm_act_dropout_bwd (same derivative code, same mask)."""
+    from dgdm_histopath_lab_amd import _lib, ops
+    g = torch.Generator().manual_seed(m + k + n)
+    dy = torch.randn(m, k, generator=g).to(DEV)
+    w = (torch.randn(k, n, generator=g) / k ** 0.5).to(DEV)          # dx = dy . w
+    pre = torch.randn(m, n, generator=g).to(DEV)
+    seed = 0x7654321
+    e = ops.WEIGHT_IMAGES.get(1, w)
+    got = ops.gemm_img_act_bwd_raw(dy, e, n, pre, act, p, seed)
+    plain = ops.gemm_nn_raw(dy, w, math="f16x2")
+    want = torch.empty_like(plain)
+    _lib.check(_lib.load().dgdm_act_dropout_bwd(pre.data_ptr(), plain.data_ptr(), plain.numel(), act, p, seed, want.data_ptr(), None, None,
+                                                _lib.stream_ptr(pre.device)), "act bwd")
+    assert torch.equal(got == 0, want == 0)
+    assert float((got - want).abs().max()) <= 4e-6 * float(want.abs().max())
+    assert ops.amax_of(got) is not None
+
+
+@pytest.mark.parametrize("m,k,n,groups", [(1000, 128, 128, 1), (4100, 128, 256, 1), (300, 384, 512, 8), (2049, 512, 256, 8), (40000, 128, 128, 1),
+                                          (777, 64, 64, 2), (513, 256, 256, 2), (1500, 64, 32, 1)])
+@pytest.mark.parametrize("with_res,act,p", [(True, 0, 0.0), (False, 3, 0.1), (True, 1, 0.25)])
+def test_norm_epilogue_is_the_gemm_followed_by_the_row_norm_kernel(m, k, n, groups, with_res, act, p):
+    """dgdm_gemm_rows_img_norm (LayerNorm(out_proj(h) + x), core/graph_layers.py:241-245; GroupNorm(8) + SiLU + dropout behind the
+    denoiser's Linears, core/diffusion.py:94-102) against dgdm_gemm_rows_img + dgdm_rownorm_fwd and against float64."""
+    from dgdm_histopath_lab_amd import _lib, ops
+    assert ops.gemm_img_norm_supported(n, groups)
+    x, w, b = _operands(m, k, n, m + k + n + groups)
+    g = torch.Generator().manual_seed(5)
+    res = torch.randn(m, n, generator=g).to(DEV) if with_res else None
+    gamma, beta = (1 + 0.3 * torch.randn(n, generator=g)).to(DEV), (0.2 * torch.randn(n, generator=g)).to(DEV)
+    seed = 0x13572468
+    e = ops.WEIGHT_IMAGES.get(0, w)
+    y, ssum, mean, rstd = ops.gemm_img_norm_raw(x, e, n, b, res, gamma, beta, groups, 1e-5, act, p, seed)
+    s64 = x.double() @ w.double().t() + b.double() + (res.double() if with_res else 0)
+    assert_close(ssum, s64, 1e-5, "sum")
+    v = s64.view(m * groups, n // groups)
+    mu, var = v.mean(1), v.var(1, unbiased=False)
+    assert_close(mean, mu, 1e-5, "mean")
+    assert_close(rstd, (var + 1e-5).rsqrt(), 1e-4, "rstd")
+    plain = ops.gemm_nt_raw(x, w, b, math="f16x2")
+    want, m2, r2 = torch.empty_like(plain), torch.empty_like(mean), torch.empty_like(rstd)
+    _lib.check(_lib.load().dgdm_rownorm_fwd(plain.data_ptr(), _lib.ptr(res), gamma.data_ptr(), beta.data_ptr(), m, n, groups, 1e-5, act, p,
+                                            seed, want.data_ptr(), m2.data_ptr(), r2.data_ptr(), None, _lib.stream_ptr(plain.device)), "rownorm")
+    assert torch.equal(y == 0, want == 0) or p == 0            # the same dropout mask
+    assert float((y - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
+    assert ops.amax_of(y) is not None
+
+
+def test_norm_epilogue_shapes_that_are_not_taken():
+    from dgdm_histopath_lab_amd import ops
+    assert not ops.gemm_img_norm_supported(512, 1)        # a 512-wide row spans two workgroups
+    assert not ops.gemm_img_norm_supported(96, 1) and not ops.gemm_img_norm_supported(192, 2)   # 96 is not a power-of-two number of tiles
+    assert ops.gemm_img_norm_supported(512, 8) and ops.gemm_img_norm_supported(256, 1) and ops.gemm_img_norm_supported(128, 4)

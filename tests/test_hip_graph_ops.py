@@ -277,3 +277,69 @@ def test_graph_conv_skip_alias_adds_the_residual_gradient_in_the_backward_kernel
     _, xs3 = ops.graph_conv_linear(x3, ea_hat, gs, w2.detach(), we2.detach(), b2.detach(), skip=True)
     (xs3 * gres).sum().backward()                                      # only the alias used
     assert torch.equal(x3.grad, gres)
+
+
+@pytest.mark.parametrize("node,hid,n,e", [(128, 128, 3000, 12000), (512, 256, 1500, 6000), (256, 128, 700, 3000), (64, 32, 300, 900)])
+@pytest.mark.parametrize("training", [False, True])
+def test_graph_layer_as_one_node_is_the_layer_of_separate_kernels(node, hid, n, e, training):
+    """DynamicGraphLayer through ops._GraphLayer (activations and LayerNorm as GEMM epilogues, the second convolution's input gradient
+    associated as (A^T dpre) . W) against the same module on the separate kernels (ops.FUSE_EPILOGUES = False): output and every
+    gradient, eval mode and TRAINING mode -- both paths draw the same two dropout seeds in the same order and the epilogues' mask is
+    the streaming kernels' function of (seed, element index), so the training-mode results agree to rounding as well; and against a
+    float64 composition of the reference's formula in eval mode (core/graph_layers.py:207-247)."""
+    from dgdm_histopath_lab_amd import ops
+    from dgdm_histopath_lab_amd.core.graph_layers import DynamicGraphLayer, GraphContext
+    DEV = "cuda:0"
+    torch.manual_seed(node + hid + n)
+    layer = DynamicGraphLayer(node, 32, hid, num_heads=8).to(DEV).train(training)
+    with torch.no_grad():
+        for p in layer.parameters():
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn_like(p))
+    g = torch.Generator().manual_seed(n)
+    x0 = torch.randn(n, node, generator=g).to(DEV)
+    ei = torch.randint(0, n, (2, e), generator=g).to(DEV)
+    ea = torch.randn(e, 32, generator=g).to(DEV)
+    gy = torch.randn(n, node, generator=g).to(DEV)
+    ctx = GraphContext(ei, n, ea)
+    names = [k for k, p in layer.named_parameters() if not k.startswith(("node_to_qkv", "edge_to_key", "norm2"))]
+
+    def run(fused):
+        ops.FUSE_EPILOGUES = fused
+        ops._seed_counter = 1000
+        layer.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_(True)
+        try:
+            y = layer(x, ctx)
+            y.backward(gy)
+        finally:
+            ops.FUSE_EPILOGUES = True
+        return y.detach(), x.grad, {k: dict(layer.named_parameters())[k].grad.clone() for k in names}, type(y.grad_fn).__name__
+
+    yf, dxf, gf, nf = run(True)
+    yu, dxu, gu, nu = run(False)
+    assert "GraphLayer" in nf and "GraphLayer" not in nu
+    assert_close(yf, yu, 2e-5, "output")
+    assert_close(dxf, dxu, 2e-5, "dx")
+    for k in names:
+        assert_close(gf[k], gu[k], 5e-5, k)
+    if training:
+        assert float((yf == 0).float().mean()) < 1e-3       # LayerNorm output: no dropout behind it
+        return
+    # float64 composition of the reference formula
+    P = {k: v.detach().double().cpu() for k, v in layer.named_parameters()}
+    xd = x0.double().cpu().requires_grad_(True)
+    src, dst = torch.cat([ei[0].cpu(), torch.arange(n)]), torch.cat([ei[1].cpu(), torch.arange(n)])
+    ead = torch.cat([ea.double().cpu(), torch.zeros(n, 32, dtype=torch.float64)])
+    deg = torch.zeros(n, dtype=torch.float64).index_add_(0, dst, torch.ones(e + n, dtype=torch.float64))
+    norm = deg[src].rsqrt() * deg[dst].rsqrt()
+
+    def conv(h, pre):
+        msg = (h @ P[pre + ".node_lin.weight"].t())[src] + ead @ P[pre + ".edge_lin.weight"].t()
+        return torch.zeros(n, P[pre + ".bias"].numel(), dtype=torch.float64).index_add_(0, dst, msg * norm[:, None]) + P[pre + ".bias"]
+    gelu = torch.nn.functional.gelu
+    h = gelu(conv(gelu(conv(xd, "graph_conv1")), "graph_conv2"))
+    out = torch.nn.functional.layer_norm(h @ P["output_proj.weight"].t() + P["output_proj.bias"] + xd, (node,), P["norm1.weight"], P["norm1.bias"])
+    out.backward(gy.double().cpu())
+    assert_close(yf, out.detach(), 1e-4, "output vs float64")
+    assert_close(dxf, xd.grad, 1e-4, "dx vs float64")
