@@ -61,7 +61,7 @@ def test_kernels_with_asm_issued_loads_do_not_spill():
     kernels to zero spills (compile-time check, no GPU)."""
     import subprocess
     from dgdm_histopath_lab_amd import _build
-    for src, names in (("gemm_img.hip", ("k_gemm_img",)), ("gemm_h.hip", ("k_gemmh_tn32",))):
+    for src, names in (("gemm_img.hip", ("k_gemm_img",)), ("gemm_h.hip", ("k_gemmh_tn32",)), ("gemm_ws.hip", ("k_gemm_ws",))):
         r = subprocess.run([_build._hipcc(), *_build.FLAGS, *_build.EXTRA_FLAGS.get(src, []), "--cuda-device-only", "-S", "-o", "/dev/null",
                             "-Rpass-analysis=kernel-resource-usage", os.path.join(_build.CSRC, src)], capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-2000:]
@@ -70,10 +70,10 @@ def test_kernels_with_asm_issued_loads_do_not_spill():
             m = re.search(r"Function Name: (\S+)", line)
             if m:
                 cur = m.group(1)
-            m = re.search(r"VGPRs Spill: (\d+)", line)
+            m = re.search(r"(VGPRs Spill|ScratchSize \[bytes/lane\]): (\d+)", line)
             if m and cur and any(n in cur for n in names):
-                seen += 1
-                assert int(m.group(1)) == 0, f"{cur} spills {m.group(1)} VGPRs"
+                seen += m.group(1) == "VGPRs Spill"
+                assert int(m.group(2)) == 0, f"{cur}: {m.group(1)} = {m.group(2)}"
         assert seen >= 2, (src, seen)
 
 

@@ -105,7 +105,9 @@ def test_asm_issued_loads_are_retired_before_use_staging_canary(monkeypatch):
     try:
         g = torch.Generator().manual_seed(12)
         evict = torch.zeros(256 * 1024 * 1024, dtype=torch.float32, device=DEV)     # 1 GiB: L2 and the Infinity Cache turn over
-        cases = [(40000, 768, 512), (40000, 512, 128), (20000, 160, 128), (5000, 128, 128), (4099, 144, 36)]
+        # (150000, 160, 128) / (70001, 128, 128): the weight-stationary kernel (csrc/gemm_ws.hip) with MORE than one 32-row tile per
+        # wave (2048 resident waves) -- its activation loads are in flight across the tile loop's back edge
+        cases = [(40000, 768, 512), (40000, 512, 128), (20000, 160, 128), (5000, 128, 128), (4099, 144, 36), (150000, 160, 128), (70001, 128, 128)]
         for m, k, n in cases:
             x = torch.randn(m, k, generator=g).to(DEV)
             w = (torch.randn(n, k, generator=g) / k ** 0.5).to(DEV)
@@ -120,13 +122,23 @@ def test_asm_issued_loads_are_retired_before_use_staging_canary(monkeypatch):
                 dx = ops.gemm_nn_raw(gy, w, math="f16x2")                 # the dx form of the same kernels
                 evict.add_(1.0)
                 dw, db = ops.gemm_tn_raw(gy, x, True, math="f16x2")       # k_gemmh_tn32
+                extra = ()
+                if n % 32 == 0 and n <= 256:                              # the fused epilogues of the same kernels (round 5)
+                    e = ops.WEIGHT_IMAGES.get(0, w)
+                    evict.add_(1.0)
+                    ya, pre = ops.gemm_img_act_raw(x, e, n, b, 1, 0.1, 77)
+                    evict.add_(1.0)
+                    yn, ssum, mean, rstd = ops.gemm_img_norm_raw(x, e, n, b, gy, b, b, 1, 1e-5, 1, 0.1, 78)
+                    evict.add_(1.0)
+                    gb = ops.gemm_img_act_bwd_raw(gy, ops.WEIGHT_IMAGES.get(1, w), k, x, 1, 0.1, 79) if k % 32 == 0 and k <= 256 else ya
+                    extra = (ya, pre, yn, ssum, mean, rstd, gb)
                 torch.cuda.synchronize()
-                return y, dx, dw, db
+                return (y, dx, dw, db) + extra
             want = run()
             monkeypatch.setattr(_lib, "_lib", canary)
             got = run()
             monkeypatch.undo()
-            for name, a, c in zip(("y", "dx", "dW", "db"), want, got):
+            for name, a, c in zip(("y", "dx", "dW", "db", "act y", "act pre", "norm y", "norm sum", "norm mean", "norm rstd", "act-bwd g"), want, got):
                 assert torch.isfinite(c).all(), f"{name} at {(m, k, n)}: a staging register was read before its load landed"
                 assert torch.equal(a, c), f"{name} at {(m, k, n)}"
             ref = x.double() @ w.double().t() + b.double()
