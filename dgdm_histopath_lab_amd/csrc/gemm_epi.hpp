@@ -132,11 +132,28 @@ __device__ __forceinline__ float4 ld4_if(const float* p, bool ok) {
   return v;
 }
 
+// Where an epilogue takes its per-column vectors (bias, gamma, beta) from.  EpiVecGlobal: 16-byte loads (L1 / L2 hits, but a round
+// trip the wave waits for with nothing beside it).  EpiVecLanes: the weight-stationary kernel loads each vector ONCE per launch, four
+// columns per lane (lane l holds columns 4 l .. 4 l + 3, up to 128 columns in lanes 0 .. 31), and an epilogue fetches the float4 of
+// column c from lane c / 4 through the LDS crossbar (ds_bpermute): no memory access after the kernel's first microsecond.
+struct EpiVecGlobal {
+  const float* p; int n;
+  __device__ __forceinline__ float4 get(int col) const { return ld4_if(p + col, p && col < n); }
+};
+struct EpiVecLanes {
+  float4 v;
+  __device__ __forceinline__ float4 get(int col) const {
+    const int src = col >> 2;           // columns past the matrix were loaded as zeros (or belong to lanes >= 32: also zeros)
+    return make_float4(__shfl(v.x, src, 64), __shfl(v.y, src, 64), __shfl(v.z, src, 64), __shfl(v.w, src, 64));
+  }
+};
+
 #define DGDM_Q4(a_, q_) make_float4((a_)[4 * (q_)], (a_)[4 * (q_) + 1], (a_)[4 * (q_) + 2], (a_)[4 * (q_) + 3])
 #define DGDM_SETQ4(a_, q_, v_) { (a_)[4 * (q_)] = (v_).x; (a_)[4 * (q_) + 1] = (v_).y; (a_)[4 * (q_) + 2] = (v_).z; (a_)[4 * (q_) + 3] = (v_).w; }
 
 // Epilogue of a wave that holds TRANSPOSED accumulators of NT column tiles starting at column `col0`; `row` = this lane's output
-// row (may be >= M: nothing is stored for it), hi = lane >> 5; `am` collects max|C| (the caller commits it: dgdm_amax_commit has a
+// row (may be >= M: nothing is stored for it), hi = lane >> 5; seed / pseed: the dropout sites' seed values (DgdmSeed::value(), read by
+// the caller before its main loop: one memory round trip less behind it); `am` collects max|C| (the caller commits it: dgdm_amax_commit has a
 // workgroup barrier inside).
 //
 // The per-element work (erf, the dropout word) is ROLLED: a real loop over pairs of tiles that always works on acc[0] and acc[1]
@@ -144,14 +161,13 @@ __device__ __forceinline__ float4 ld4_if(const float* p, bool ok) {
 // unrolled, the wide kernel's 128 outputs per lane are 15 000 instructions whose interleaved erf chains push the allocator past
 // 256 registers: these kernels must not spill at all (their activation loads are retired by hand, tests/test_abi.py).  Stores
 // leave straight from the round's temporaries; the next round's arithmetic covers their flight.
-template <int NT, int EPI>
+template <int NT, int EPI, class VEC>
 __device__ __forceinline__ void epilogue_tr(f32x16 (&acc)[NT], const float inv, const int row, const int M, const int col0, const int Ncols,
-                                            const float* __restrict__ bias, float* __restrict__ C, const int64_t ldc, const EpiArgs& e,
-                                            const int hi, unsigned& am) {
+                                            const VEC& bias, const VEC& gamma, const VEC& beta, float* __restrict__ C, const int64_t ldc,
+                                            const EpiArgs& e, const int hi, unsigned& am, const uint32_t seed, const uint32_t pseed) {
   static_assert(NT % 2 == 0, "tiles are taken in pairs");
   const bool rok = row < M;
   const int cl = col0 + 4 * hi;                      // this lane's channels: cl + 32 t + 8 q + (0..3)
-  const uint32_t seed = e.seed.value();
   const uint32_t thresh = (uint32_t)(e.drop_p * 65536.0f);
   const float keep_scale = e.drop_p > 0.f ? 1.0f / (1.0f - (float)thresh / 65536.0f) : 1.0f;
   const uint64_t e0 = (uint64_t)row * (uint64_t)Ncols;   // element index of (row, 0) in the contiguous [M, Ncols] output
@@ -164,7 +180,7 @@ __device__ __forceinline__ void epilogue_tr(f32x16 (&acc)[NT], const float inv, 
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int col = cl + 32 * t + 8 * q;
-        const float4 b = ld4_if(bias + col, bias && col < Ncols);
+        const float4 b = bias.get(col);
         acc[t][4 * q] = fmaf(acc[t][4 * q], inv, b.x); acc[t][4 * q + 1] = fmaf(acc[t][4 * q + 1], inv, b.y);
         acc[t][4 * q + 2] = fmaf(acc[t][4 * q + 2], inv, b.z); acc[t][4 * q + 3] = fmaf(acc[t][4 * q + 3], inv, b.w);
       }
@@ -185,7 +201,7 @@ __device__ __forceinline__ void epilogue_tr(f32x16 (&acc)[NT], const float inv, 
         for (int q = 0; q < 4; ++q) {
           const int col = cl + 32 * (t0 + u) + 8 * q;
           const bool ok = rok && col < Ncols;
-          const float4 b = ld4_if(bias + col, bias && col < Ncols);
+          const float4 b = bias.get(col);
           const float4 v = make_float4(fmaf(acc[u][4 * q], inv, b.x), fmaf(acc[u][4 * q + 1], inv, b.y), fmaf(acc[u][4 * q + 2], inv, b.z),
                                        fmaf(acc[u][4 * q + 3], inv, b.w));
           float4 o = act4(e.act, v);
@@ -260,31 +276,43 @@ __device__ __forceinline__ void epilogue_tr(f32x16 (&acc)[NT], const float inv, 
       }
       rrow = lo;
     }
-    const uint32_t pseed = e.pre_seed.value();
     const uint32_t pthresh = (uint32_t)(e.pre_drop_p * 65536.0f);
     const float pkeep = e.pre_drop_p > 0.f ? 1.0f / (1.0f - (float)pthresh / 65536.0f) : 1.0f;
+    // (rolled like pass 2: two tiles per round, then every array moves two places down -- after NT / 2 rounds all are back in order)
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      float s = 0.f;
-      __builtin_amdgcn_sched_barrier(0);                 // one tile of residual loads in flight at a time (register budget)
+    for (int t = 0; t < NT; ++t) mu[t] = 0.f;
+#pragma clang loop unroll(disable)
+    for (int t0 = 0; t0 < NT; t0 += 2) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int col = cl + 32 * t + 8 * q;
-        const bool ok = rok && col < Ncols;
-        const float4 b = ld4_if(bias + col, bias && col < Ncols);
-        const float4 r4 = ld4_if(e.res + rrow * e.ldr + col, e.res && ok);
-        float4 v = make_float4(fmaf(acc[t][4 * q], inv, b.x), fmaf(acc[t][4 * q + 1], inv, b.y), fmaf(acc[t][4 * q + 2], inv, b.z),
-                               fmaf(acc[t][4 * q + 3], inv, b.w));
-        if (e.pre_drop_p > 0.f) {
-          const float4 m = dropout_scale4(pseed, e0 + (uint64_t)col, pthresh, pkeep);
-          v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
+      for (int u = 0; u < 2; ++u) {
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int col = cl + 32 * (t0 + u) + 8 * q;
+          const bool ok = rok && col < Ncols;
+          const float4 b = bias.get(col);
+          const float4 r4 = ld4_if(e.res + rrow * e.ldr + col, e.res && ok);
+          float4 v = make_float4(fmaf(acc[u][4 * q], inv, b.x), fmaf(acc[u][4 * q + 1], inv, b.y), fmaf(acc[u][4 * q + 2], inv, b.z),
+                                 fmaf(acc[u][4 * q + 3], inv, b.w));
+          if (e.pre_drop_p > 0.f) {
+            const float4 m = dropout_scale4(pseed, e0 + (uint64_t)col, pthresh, pkeep);
+            v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
+          }
+          v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+          if (col >= Ncols) v = make_float4(0.f, 0.f, 0.f, 0.f);      // columns past the matrix: nothing for the statistics
+          DGDM_SETQ4(acc[u], q, v)
+          if (e.sum_out && ok) *reinterpret_cast<float4*>(e.sum_out + (int64_t)row * e.lds + col) = v;
+          s += (v.x + v.y) + (v.z + v.w);
         }
-        v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
-        DGDM_SETQ4(acc[t], q, v)
-        if (e.sum_out && ok) *reinterpret_cast<float4*>(e.sum_out + (int64_t)row * e.lds + col) = v;
-        s += (v.x + v.y) + (v.z + v.w);
+        mu[u] = s;
       }
-      mu[t] = s;
+      {   // a true rotation: the finished pair goes to the end (pass 2 needs every tile again)
+        const f32x16 a0 = acc[0], a1 = acc[1];
+        const float m0 = mu[0], m1 = mu[1];
+        DGDM_ROTATE2(acc)
+        DGDM_ROTATE2(mu)
+        acc[NT - 2] = a0; acc[NT - 1] = a1; mu[NT - 2] = m0; mu[NT - 1] = m1;
+      }
     }
     // statistics of the groups of tpg = L / 32 consecutive tiles: per-tile sums (in-lane + the other half-wave), then a tree over
     // the tiles of a group -- static register indices, wave-uniform conditions
@@ -332,8 +360,8 @@ __device__ __forceinline__ void epilogue_tr(f32x16 (&acc)[NT], const float inv, 
         for (int q = 0; q < 4; ++q) {
           const int col = cl + 32 * (t0 + u) + 8 * q;
           const bool cok = col < Ncols;
-          const float4 g4 = ld4_if(e.gamma + col, cok);
-          const float4 b4 = ld4_if(e.beta + col, cok);
+          const float4 g4 = gamma.get(col);
+          const float4 b4 = beta.get(col);
           float4 o = make_float4((acc[u][4 * q] - mu[u]) * rs[u] * g4.x + b4.x, (acc[u][4 * q + 1] - mu[u]) * rs[u] * g4.y + b4.y,
                                  (acc[u][4 * q + 2] - mu[u]) * rs[u] * g4.z + b4.z, (acc[u][4 * q + 3] - mu[u]) * rs[u] * g4.w + b4.w);
           o = act4(e.act, o);

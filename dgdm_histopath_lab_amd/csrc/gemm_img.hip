@@ -210,6 +210,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_gemm_img(const float* __res
     sca = scale_of(amax_group(amax_a));
     scb = *reinterpret_cast<const float*>(img);
   }
+  uint32_t seed_v = 0, pseed_v = 0;     // the fused epilogues' dropout seeds: read here, not behind the main loop
+  if (EPI != EPI_NONE) { seed_v = epi.seed.value(); pseed_v = EPI == EPI_NORM ? epi.pre_seed.value() : 0u; }
 
   for (int s = 0; s < nst; ++s) {
     // stage s has landed (this wave's pieces: vmcnt; everybody's: the barrier), and every wave is done reading the other buffer
@@ -272,7 +274,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_gemm_img(const float* __res
   const float inv = (1.0f / sca) * (1.0f / scb);     // exact: powers of two
   if (TR) {
     unsigned am = 0;
-    epilogue_tr<NTW, EPI>(acc, inv, r0 + (lane & 31), M, 32 * (tg0 + wn * NTW), Ncols, bias, C, ldc, epi, lane >> 5, am);
+    const EpiVecGlobal vb{bias, Ncols}, vg{epi.gamma, Ncols}, vbe{epi.beta, Ncols};
+    epilogue_tr<NTW, EPI>(acc, inv, r0 + (lane & 31), M, 32 * (tg0 + wn * NTW), Ncols, vb, vg, vbe, C, ldc, epi, lane >> 5, am, seed_v, pseed_v);
     if (epi.amax_out) dgdm_amax_commit(am, epi.amax_out);   // workgroup-uniform condition: every thread reaches the barrier inside
     return;
   }
@@ -385,6 +388,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_img8(const float* __restrict__ 
     sca = scale_of(amax_group(amax_a));
     scb = *reinterpret_cast<const float*>(img);
   }
+  uint32_t seed_v = 0, pseed_v = 0;     // the fused epilogues' dropout seeds: read here, not behind the main loop
+  if (EPI != EPI_NONE) { seed_v = epi.seed.value(); pseed_v = EPI == EPI_NORM ? epi.pre_seed.value() : 0u; }
 
   // one chunk: wait for its B slot (and the A set), restage the other slot, convert the A set and refill it two chunks ahead,
   // then 8 batches (j, tile pair) of four fragment reads + six MFMAs, the reads one batch ahead
@@ -447,7 +452,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_img8(const float* __restrict__ 
   const float inv = (1.0f / sca) * (1.0f / scb);
   if (TR) {
     unsigned am = 0;
-    epilogue_tr<NT8, EPI>(acc, inv, r0 + (lane & 31), M, 32 * tg0, Ncols, bias, C, ldc, epi, lane >> 5, am);
+    const EpiVecGlobal vb{bias, Ncols}, vg{epi.gamma, Ncols}, vbe{epi.beta, Ncols};
+    epilogue_tr<NT8, EPI>(acc, inv, r0 + (lane & 31), M, 32 * tg0, Ncols, vb, vg, vbe, C, ldc, epi, lane >> 5, am, seed_v, pseed_v);
     if (epi.amax_out) dgdm_amax_commit(am, epi.amax_out);
     return;
   }

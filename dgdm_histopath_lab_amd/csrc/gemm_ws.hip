@@ -96,6 +96,15 @@ __global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void k_gemm_ws(const float* 
   const float sca = scale_of(amax_group(amax_a));
   const float scb = *reinterpret_cast<const float*>(img);
   const float inv = (1.0f / sca) * (1.0f / scb);      // exact: powers of two
+  // everything an epilogue needs that does not depend on the tile is fetched NOW, under the image copy: the dropout seeds, and the
+  // per-column vectors four columns per lane (EpiVecLanes; lanes past the matrix hold zeros)
+  uint32_t seed_v = 0, pseed_v = 0;
+  if (EPI != EPI_NONE) { seed_v = epi.seed.value(); pseed_v = EPI == EPI_NORM ? epi.pre_seed.value() : 0u; }
+  EpiVecLanes vbias{ld4_if(bias + 4 * lane, bias && 4 * lane < Ncols)}, vgamma{make_float4(0.f, 0.f, 0.f, 0.f)}, vbeta{make_float4(0.f, 0.f, 0.f, 0.f)};
+  if (EPI == EPI_NORM) {
+    vgamma.v = ld4_if(epi.gamma + 4 * lane, 4 * lane < Ncols);
+    vbeta.v = ld4_if(epi.beta + 4 * lane, 4 * lane < Ncols);
+  }
   WS_WAIT_AHEAD                                        // the image pieces this wave copied (and the first tile's rows)
   __syncthreads();                                     // ... and everybody else's: the only barrier before the end
 
@@ -110,51 +119,97 @@ __global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void k_gemm_ws(const float* 
     for (int t = 0; t < WS_NT; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    // one chunk: split the 16 floats into the two 16-k fragments (hi, lo), refill the registers for the next tile, then per fragment
-    // 8 reads of the weight's fragments (4 tiles x hi / lo) and 12 MFMAs with the WEIGHT as the A operand (transposed accumulators)
-#define WS_CHUNK(c_, a_, b_, c4_, d_)                                                                               \
-  if constexpr ((c_) < NCH) {                                                                                       \
-    if constexpr (LATE && (c_) == NCH - 1)    /* loaded at the top of this tile; younger: the 4 (NCH - 1) loads of the next tile */ \
+    // A tile is 4 NCH batches (chunk c, half j, column-tile pair p): 4 reads of the weight's fragments (2 column tiles x hi / lo) +
+    // 6 MFMAs with the WEIGHT as the A operand (transposed accumulators).  The reads of the next batch are issued BEFORE the MFMAs of
+    // this one and pinned there (sched_barrier): left alone, hipcc sinks every read to just in front of its MFMA and a wave that has a
+    // SIMD to itself eats the LDS latency 8 NCH times per tile (the first version of this kernel: +3 us per launch against
+    // k_gemm_img).  The split of the next 16-k half (and, behind a chunk's second half, the refill of its registers for the next
+    // tile) sits among the MFMAs of the current half's first pair; ah / al have one slot per half j.
+    f16x8 ah[2], al[2];                                // [half j]
+    f16x8 bh[2][2], bl[2][2];                          // [pair parity][tile of the pair]
+#define WS_SPLIT_HALF(c_, j_, x_, y_, a_, b_, c4_, d_)     /* floats 8 j .. 8 j + 7 of the chunk = registers (x_, y_) */ \
+  {                                                                                                                 \
+    if constexpr (LATE && (c_) == NCH - 1 && (j_) == 0)  /* loaded at the top of this tile; younger: the 16 loads of the next tile */ \
       asm volatile("s_waitcnt vmcnt(16)" : "+v"(a_), "+v"(b_), "+v"(c4_), "+v"(d_) :: "memory");                      \
-    f16x8 ah[2], al[2];                                                                                             \
-    {                                                                                                               \
-      uint4 h__, l__;                                                                                               \
-      split_pair(a_[0] * sca, a_[1] * sca, &h__.x, &l__.x);                                                         \
-      split_pair(a_[2] * sca, a_[3] * sca, &h__.y, &l__.y);                                                         \
-      split_pair(b_[0] * sca, b_[1] * sca, &h__.z, &l__.z);                                                         \
-      split_pair(b_[2] * sca, b_[3] * sca, &h__.w, &l__.w);                                                         \
-      ah[0] = __builtin_bit_cast(f16x8, h__);                                                                       \
-      al[0] = __builtin_bit_cast(f16x8, l__);                                                                       \
-      split_pair(c4_[0] * sca, c4_[1] * sca, &h__.x, &l__.x);                                                       \
-      split_pair(c4_[2] * sca, c4_[3] * sca, &h__.y, &l__.y);                                                       \
-      split_pair(d_[0] * sca, d_[1] * sca, &h__.z, &l__.z);                                                         \
-      split_pair(d_[2] * sca, d_[3] * sca, &h__.w, &l__.w);                                                         \
-      ah[1] = __builtin_bit_cast(f16x8, h__);                                                                       \
-      al[1] = __builtin_bit_cast(f16x8, l__);                                                                       \
-    }                                                                                                               \
-    __builtin_amdgcn_sched_barrier(0);                                                                              \
-    if constexpr ((c_) < AHEAD) WS_LOAD(next, c_, a_, b_, c4_, d_)                                                  \
-    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                 \
-      f16x8 bh[WS_NT], bl[WS_NT];                                                                                   \
-      const char* q__ = lbase + (c_) * WS_NT * BLK + (2 * j) * 1024;                                                \
-      _Pragma("unroll") for (int t = 0; t < WS_NT; ++t) {                                                           \
-        bh[t] = *reinterpret_cast<const f16x8*>(q__ + t * BLK);                                                     \
-        bl[t] = *reinterpret_cast<const f16x8*>(q__ + t * BLK + 1024);                                              \
-      }                                                                                                             \
-      _Pragma("unroll") for (int t = 0; t < WS_NT; ++t) {                                                           \
-        acc[t] = mfma_hf(bh[t], al[j], acc[t]);        /* smaller terms first */                                    \
-        acc[t] = mfma_hf(bl[t], ah[j], acc[t]);                                                                     \
-        acc[t] = mfma_hf(bh[t], ah[j], acc[t]);                                                                     \
-      }                                                                                                             \
+    uint4 h__, l__;                                                                                                 \
+    split_pair(x_[0] * sca, x_[1] * sca, &h__.x, &l__.x);                                                           \
+    split_pair(x_[2] * sca, x_[3] * sca, &h__.y, &l__.y);                                                           \
+    split_pair(y_[0] * sca, y_[1] * sca, &h__.z, &l__.z);                                                           \
+    split_pair(y_[2] * sca, y_[3] * sca, &h__.w, &l__.w);                                                           \
+    ah[j_] = __builtin_bit_cast(f16x8, h__);                                                                        \
+    al[j_] = __builtin_bit_cast(f16x8, l__);                                                                        \
+    if constexpr ((j_) == 1 && (c_) < AHEAD) WS_LOAD(next, c_, a_, b_, c4_, d_)   /* both halves taken: refill */     \
+  }
+#define WS_READ(c_, j_, p_)                                                                                         \
+  {                                                                                                                 \
+    const char* q__ = lbase + (c_) * WS_NT * BLK + (2 * (j_)) * 1024 + (2 * (p_)) * BLK;                            \
+    _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                                 \
+      bh[p_][u] = *reinterpret_cast<const f16x8*>(q__ + u * BLK);                                                   \
+      bl[p_][u] = *reinterpret_cast<const f16x8*>(q__ + u * BLK + 1024);                                            \
     }                                                                                                               \
   }
-    WS_CHUNK(0, r0a, r0b, r0c, r0d)
-    WS_CHUNK(1, r1a, r1b, r1c, r1d)
-    WS_CHUNK(2, r2a, r2b, r2c, r2d)
-    WS_CHUNK(3, r3a, r3b, r3c, r3d)
-    WS_CHUNK(4, r4a, r4b, r4c, r4d)
-#undef WS_CHUNK
-    epilogue_tr<WS_NT, EPI>(acc, inv, 32 * tile + (lane & 31), M, 0, Ncols, bias, C, ldc, epi, lane >> 5, am);
+#define WS_MFMA(j_, p_)                                                                                             \
+  _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                                   \
+    acc[2 * (p_) + u] = mfma_hf(bh[p_][u], al[j_], acc[2 * (p_) + u]);        /* smaller terms first */             \
+    acc[2 * (p_) + u] = mfma_hf(bl[p_][u], ah[j_], acc[2 * (p_) + u]);                                              \
+    acc[2 * (p_) + u] = mfma_hf(bh[p_][u], ah[j_], acc[2 * (p_) + u]);                                              \
+  }
+    // half (c, j): [reads of its pair 1] | MFMAs of pair 0 + split of the NEXT half | [reads of the next half's pair 0] | MFMAs of pair 1
+#define WS_FENCE __builtin_amdgcn_sched_barrier(0);
+    WS_SPLIT_HALF(0, 0, r0a, r0b, r0a, r0b, r0c, r0d)
+    WS_READ(0, 0, 0)
+    if constexpr (0 < NCH) {
+      WS_FENCE WS_READ(0, 0, 1) WS_FENCE WS_MFMA(0, 0)
+      WS_SPLIT_HALF(0, 1, r0c, r0d, r0a, r0b, r0c, r0d)
+      WS_FENCE WS_READ(0, 1, 0) WS_FENCE WS_MFMA(0, 1)
+      WS_FENCE WS_READ(0, 1, 1) WS_FENCE WS_MFMA(1, 0)
+      if constexpr (1 < NCH) WS_SPLIT_HALF(1, 0, r1a, r1b, r1a, r1b, r1c, r1d)
+      WS_FENCE
+      if constexpr (1 < NCH) WS_READ(1, 0, 0)
+      WS_FENCE WS_MFMA(1, 1)
+    }
+    if constexpr (1 < NCH) {
+      WS_FENCE WS_READ(1, 0, 1) WS_FENCE WS_MFMA(0, 0)
+      WS_SPLIT_HALF(1, 1, r1c, r1d, r1a, r1b, r1c, r1d)
+      WS_FENCE WS_READ(1, 1, 0) WS_FENCE WS_MFMA(0, 1)
+      WS_FENCE WS_READ(1, 1, 1) WS_FENCE WS_MFMA(1, 0)
+      if constexpr (2 < NCH) WS_SPLIT_HALF(2, 0, r2a, r2b, r2a, r2b, r2c, r2d)
+      WS_FENCE
+      if constexpr (2 < NCH) WS_READ(2, 0, 0)
+      WS_FENCE WS_MFMA(1, 1)
+    }
+    if constexpr (2 < NCH) {
+      WS_FENCE WS_READ(2, 0, 1) WS_FENCE WS_MFMA(0, 0)
+      WS_SPLIT_HALF(2, 1, r2c, r2d, r2a, r2b, r2c, r2d)
+      WS_FENCE WS_READ(2, 1, 0) WS_FENCE WS_MFMA(0, 1)
+      WS_FENCE WS_READ(2, 1, 1) WS_FENCE WS_MFMA(1, 0)
+      if constexpr (3 < NCH) WS_SPLIT_HALF(3, 0, r3a, r3b, r3a, r3b, r3c, r3d)
+      WS_FENCE
+      if constexpr (3 < NCH) WS_READ(3, 0, 0)
+      WS_FENCE WS_MFMA(1, 1)
+    }
+    if constexpr (3 < NCH) {
+      WS_FENCE WS_READ(3, 0, 1) WS_FENCE WS_MFMA(0, 0)
+      WS_SPLIT_HALF(3, 1, r3c, r3d, r3a, r3b, r3c, r3d)
+      WS_FENCE WS_READ(3, 1, 0) WS_FENCE WS_MFMA(0, 1)
+      WS_FENCE WS_READ(3, 1, 1) WS_FENCE WS_MFMA(1, 0)
+      if constexpr (4 < NCH) WS_SPLIT_HALF(4, 0, r4a, r4b, r4a, r4b, r4c, r4d)
+      WS_FENCE
+      if constexpr (4 < NCH) WS_READ(4, 0, 0)
+      WS_FENCE WS_MFMA(1, 1)
+    }
+    if constexpr (4 < NCH) {
+      WS_FENCE WS_READ(4, 0, 1) WS_FENCE WS_MFMA(0, 0)
+      WS_SPLIT_HALF(4, 1, r4c, r4d, r4a, r4b, r4c, r4d)
+      WS_FENCE WS_READ(4, 1, 0) WS_FENCE WS_MFMA(0, 1)
+      WS_FENCE WS_READ(4, 1, 1) WS_FENCE WS_MFMA(1, 0)
+      WS_FENCE WS_MFMA(1, 1)
+    }
+#undef WS_FENCE
+#undef WS_MFMA
+#undef WS_READ
+#undef WS_SPLIT_HALF
+    epilogue_tr<WS_NT, EPI>(acc, inv, 32 * tile + (lane & 31), M, 0, Ncols, vbias, vgamma, vbeta, C, ldc, epi, lane >> 5, am, seed_v, pseed_v);
     tile = next;
   }
   WS_WAIT_AHEAD            // the prefetch of the tile past the wave's last one: retired before the registers are given back
@@ -227,7 +282,11 @@ int cu_count() {
 
 int dgdm_gemm_ws_launch(int epi_kind, hipStream_t s, const float* A, int64_t lda, int M, int K, const char* img, int T_img, int t_begin,
                         int Ncols, const float* bias, float* C, int64_t ldc, const unsigned* amax_a, const EpiArgs& epi) {
-#ifdef DGDM_NO_WS
+  // MEASURED AND LEFT OFF (round 5, tools/microbench_epilogues.py, profiles/r05_epilogue_microbench.txt): against k_gemm_img<4,1> this
+  // kernel is 1.3 - 3.2 us SLOWER per launch at every U-Net level (a wave owns a whole 32 x 128 output tile: one B-stage shared by
+  // four waves and double-buffered by DMA already hides what the stationary image saves, and the image copy is a serial prologue).
+  // Built only with -DDGDM_WS (tools/ab_ws.sh); the default library answers "unsupported" and the caller takes k_gemm_img.
+#ifndef DGDM_WS
   return DGDM_ERR_UNSUPPORTED;
 #else
   if (Ncols > 32 * WS_NT || K > 32 * WS_MAXCH || K < 16 || (K & 15) || (Ncols & 3) || (ldc & 3) || !dgdm_aligned16(C) || M <= 0 ||

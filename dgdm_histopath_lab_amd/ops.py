@@ -1820,7 +1820,14 @@ def graph_conv_linear(x, ea_hat, gs: GraphStructure, w, we, b, skip: bool = Fals
 
 
 # ----------------------------------------------------------------------------- K3 + K6 in one launch: GEMMs with fused epilogues
-FUSE_EPILOGUES = True     # tools/ A/B switch: False keeps every activation / norm behind a GEMM in a kernel of its own (the round-4 path)
+# Round 5, measured (tools/microbench_epilogues.py -> profiles/r05_epilogue_microbench.txt; tools/ab_ws.sh -> profiles/r05_fusion_ab.txt):
+# the fused epilogues are correct (tests/test_hip_gemm_img.py, test_hip_graph_ops.py) and SLOWER than the launches they replace
+# wherever the GEMM has fewer waves than the chip has SIMDs: a wave finishes a 32 x 128 tile = 64 outputs per lane alone
+# (GELU + dropout: ~28 vector instructions per output, 4 cycles each = 3.5 us of one SIMD), while the streaming kernel spreads the
+# same instructions over all 1024 SIMDs.  At 5 000 rows: GEMM 7.3 us, + activation kernel 10.5, fused 16.9; at 40 000 rows a draw
+# (22.3 / 22.3); LayerNorm epilogue 29.4 against 25.9; whole step 13.07 against 13.00 ms.  So the default keeps every activation /
+# norm behind a GEMM in a kernel of its own; True selects the fused path (same-box A/B, the parity tests run both).
+FUSE_EPILOGUES = False
 
 
 def epilogues_available(*widths: int) -> bool:

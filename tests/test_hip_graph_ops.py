@@ -304,6 +304,8 @@ def test_graph_layer_as_one_node_is_the_layer_of_separate_kernels(node, hid, n, 
     ctx = GraphContext(ei, n, ea)
     names = [k for k, p in layer.named_parameters() if not k.startswith(("node_to_qkv", "edge_to_key", "norm2"))]
 
+    was = ops.FUSE_EPILOGUES
+
     def run(fused):
         ops.FUSE_EPILOGUES = fused
         ops._seed_counter = 1000
@@ -313,7 +315,7 @@ def test_graph_layer_as_one_node_is_the_layer_of_separate_kernels(node, hid, n, 
             y = layer(x, ctx)
             y.backward(gy)
         finally:
-            ops.FUSE_EPILOGUES = True
+            ops.FUSE_EPILOGUES = was
         return y.detach(), x.grad, {k: dict(layer.named_parameters())[k].grad.clone() for k in names}, type(y.grad_fn).__name__
 
     yf, dxf, gf, nf = run(True)

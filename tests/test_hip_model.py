@@ -279,8 +279,9 @@ class _DropoutSites:
         return hook
 
 
+@pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("hierarchical", [False, True])
-def test_training_mode_step_matches_oracle_under_the_kernels_own_masks(hierarchical, monkeypatch):
+def test_training_mode_step_matches_oracle_under_the_kernels_own_masks(hierarchical, fused, monkeypatch):
     """The step bench.py times runs in TRAINING mode: hash dropout at ~35 sites (kernel-level evidence only).
     Draw-for-draw parity with the reference's Philox masks is impossible, but the masks are deterministic functions of
     (seed, index): the kernels' own masks of one step are extracted site by site (_DropoutSites), handed to the float64 oracle
@@ -288,9 +289,12 @@ def test_training_mode_step_matches_oracle_under_the_kernels_own_masks(hierarchi
     EVERY live parameter gradient of the training-mode step must agree at the 1e-3 contract -- which proves, at model level, that
     each site applies its mask where the reference applies dropout (core/attention.py:154,168, graph_layers.py:233-239,
     encoders.py:73-91,267, diffusion.py:94-104), that forward and backward of every site regenerate the same mask, and that
-    nothing on the path drops twice or not at all."""
+    nothing on the path drops twice or not at all.  ``fused`` (round 5): the same step with the activations / norms behind the
+    GEMMs as their epilogues (ops.FUSE_EPILOGUES; off by default -- measured slower -- but a complete second implementation of the
+    same sites: same seeds in the same order, same (seed, element index) masks)."""
     from dgdm_histopath_lab_amd import ops
     from dgdm_histopath_lab_amd.synthetic import synthetic_batch
+    monkeypatch.setattr(ops, "FUSE_EPILOGUES", fused)
     cfgd = dict(node_features=768, hidden_dims=[512, 256, 128], num_diffusion_steps=10, attention_heads=8, use_hierarchical=hierarchical)
     cfg = O.OracleConfig(**cfgd)
     P = O.init_params(cfg, seed=3, perturb=0.05)
