@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void k_act_dropout(const float* __restrict__ x
 template <bool BWD>
 int launch(const float* x, const float* dy, int64_t n, int32_t act, float drop_p, uint32_t seed, float* out, const uint8_t* decide,
            uint32_t* amax, hipStream_t s) {
-  if (n < 0 || act < 0 || act > 3 || !(drop_p >= 0.f && drop_p < 1.f)) return DGDM_ERR_INVALID_ARG;
+  if (n < 0 || act < 0 || act > DGDM_ACT_ELU || !(drop_p >= 0.f && drop_p < 1.f)) return DGDM_ERR_INVALID_ARG;
   if (decide && act != DGDM_ACT_RELU) return DGDM_ERR_INVALID_ARG;
   if (n == 0) return DGDM_OK;
   if (!x || !out || (BWD && !dy)) return DGDM_ERR_INVALID_ARG;
@@ -60,6 +60,7 @@ int launch(const float* x, const float* dy, int64_t n, int32_t act, float drop_p
     case DGDM_ACT_GELU: GO(DGDM_ACT_GELU); break;
     case DGDM_ACT_RELU: GO(DGDM_ACT_RELU); break;
     case DGDM_ACT_SILU: GO(DGDM_ACT_SILU); break;
+    case DGDM_ACT_ELU: GO(DGDM_ACT_ELU); break;
     default: GO(DGDM_ACT_NONE); break;
   }
 #undef GO

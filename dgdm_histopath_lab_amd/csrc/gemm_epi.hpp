@@ -113,6 +113,7 @@ __device__ __forceinline__ float4 act4(int act, const float4 v) {
     case DGDM_ACT_GELU: return make_float4(act_f<DGDM_ACT_GELU>(v.x), act_f<DGDM_ACT_GELU>(v.y), act_f<DGDM_ACT_GELU>(v.z), act_f<DGDM_ACT_GELU>(v.w));
     case DGDM_ACT_RELU: return make_float4(act_f<DGDM_ACT_RELU>(v.x), act_f<DGDM_ACT_RELU>(v.y), act_f<DGDM_ACT_RELU>(v.z), act_f<DGDM_ACT_RELU>(v.w));
     case DGDM_ACT_SILU: return make_float4(act_f<DGDM_ACT_SILU>(v.x), act_f<DGDM_ACT_SILU>(v.y), act_f<DGDM_ACT_SILU>(v.z), act_f<DGDM_ACT_SILU>(v.w));
+    case DGDM_ACT_ELU: return make_float4(act_f<DGDM_ACT_ELU>(v.x), act_f<DGDM_ACT_ELU>(v.y), act_f<DGDM_ACT_ELU>(v.z), act_f<DGDM_ACT_ELU>(v.w));
     default: return v;
   }
 }
@@ -121,6 +122,7 @@ __device__ __forceinline__ float4 act_d4(int act, const float4 v) {
     case DGDM_ACT_GELU: return make_float4(act_df<DGDM_ACT_GELU>(v.x), act_df<DGDM_ACT_GELU>(v.y), act_df<DGDM_ACT_GELU>(v.z), act_df<DGDM_ACT_GELU>(v.w));
     case DGDM_ACT_RELU: return make_float4(act_df<DGDM_ACT_RELU>(v.x), act_df<DGDM_ACT_RELU>(v.y), act_df<DGDM_ACT_RELU>(v.z), act_df<DGDM_ACT_RELU>(v.w));
     case DGDM_ACT_SILU: return make_float4(act_df<DGDM_ACT_SILU>(v.x), act_df<DGDM_ACT_SILU>(v.y), act_df<DGDM_ACT_SILU>(v.z), act_df<DGDM_ACT_SILU>(v.w));
+    case DGDM_ACT_ELU: return make_float4(act_df<DGDM_ACT_ELU>(v.x), act_df<DGDM_ACT_ELU>(v.y), act_df<DGDM_ACT_ELU>(v.z), act_df<DGDM_ACT_ELU>(v.w));
     default: return make_float4(1.f, 1.f, 1.f, 1.f);
   }
 }

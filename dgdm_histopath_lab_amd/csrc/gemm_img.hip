@@ -582,7 +582,7 @@ namespace {
 
 int epi_common_checks(const float* A, int64_t lda, int32_t M, int32_t K, const void* image, int32_t image_tiles, int32_t tile_begin,
                       int32_t ncols, float* C, int64_t ldc, const uint32_t* amax_a, int32_t act, float drop_p) {
-  if (M < 0 || K < 0 || ncols < 0 || image_tiles <= 0 || tile_begin < 0 || act < 0 || act > 3 || !(drop_p >= 0.f && drop_p < 1.f))
+  if (M < 0 || K < 0 || ncols < 0 || image_tiles <= 0 || tile_begin < 0 || act < 0 || act > DGDM_ACT_ELU || !(drop_p >= 0.f && drop_p < 1.f))
     return DGDM_ERR_INVALID_ARG;
   if (M == 0 || ncols == 0) return 1;    // nothing to do
   if (!A || !image || !C || !amax_a) return DGDM_ERR_INVALID_ARG;

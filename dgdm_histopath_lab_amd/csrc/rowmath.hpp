@@ -56,6 +56,7 @@ __device__ __forceinline__ float act_f(float z) {
   if (ACT == DGDM_ACT_GELU) return gelu_f(z);
   if (ACT == DGDM_ACT_RELU) return fmaxf(z, 0.f);
   if (ACT == DGDM_ACT_SILU) return z / (1.0f + __expf(-z));
+  if (ACT == DGDM_ACT_ELU) return z > 0.f ? z : expm1f(z);
   return z;
 }
 template <int ACT>
@@ -66,5 +67,6 @@ __device__ __forceinline__ float act_df(float z) {
     const float s = 1.0f / (1.0f + __expf(-z));
     return s * (1.0f + z * (1.0f - s));
   }
+  if (ACT == DGDM_ACT_ELU) return z > 0.f ? 1.f : __expf(z);
   return 1.f;
 }

@@ -252,6 +252,7 @@ int64_t bwd_slots(int64_t ng, int G, const Geo& geo) {
           case DGDM_ACT_GELU: KERNEL(LPR_, R_, DGDM_ACT_GELU, __VA_ARGS__); break;         \
           case DGDM_ACT_RELU: KERNEL(LPR_, R_, DGDM_ACT_RELU, __VA_ARGS__); break;         \
           case DGDM_ACT_SILU: KERNEL(LPR_, R_, DGDM_ACT_SILU, __VA_ARGS__); break;         \
+          case DGDM_ACT_ELU: KERNEL(LPR_, R_, DGDM_ACT_ELU, __VA_ARGS__); break;           \
           default: KERNEL(LPR_, R_, DGDM_ACT_NONE, __VA_ARGS__); break;                    \
         }                                                                                  \
       }                                                                                    \
@@ -271,7 +272,7 @@ int64_t bwd_slots(int64_t ng, int G, const Geo& geo) {
 
 static int check_common(const float* x, const float* gamma, const float* beta, int32_t N, int32_t C, int32_t G, int32_t act,
                         float drop_p) {
-  if (N < 0 || C <= 0 || G <= 0 || act < 0 || act > 3 || !(drop_p >= 0.f && drop_p < 1.f)) return DGDM_ERR_INVALID_ARG;
+  if (N < 0 || C <= 0 || G <= 0 || act < 0 || act > DGDM_ACT_ELU || !(drop_p >= 0.f && drop_p < 1.f)) return DGDM_ERR_INVALID_ARG;
   if (N > 0 && (!x || !gamma || !beta)) return DGDM_ERR_INVALID_ARG;
   if (C % G) return DGDM_ERR_UNSUPPORTED;
   return DGDM_OK;

@@ -302,6 +302,106 @@ extern "C" int dgdm_segment_sum(const float* x, const int32_t* ptr, int32_t B, i
   return dgdm_launch_status();
 }
 
+// ------------------------------------------------------------------ segment max (GlobalMaxPool, models/dgdm_model.py:570-585)
+// out[g][c] = max over the rows of graph g of x[r][c], arg[g][c] = the row that attains it (the FIRST one on ties -- what
+// torch.max(dim=0) returns on the CPU, and where its backward sends the gradient); a graph without rows gives 0 / -1 (the reference
+// leaves its zero-initialised row untouched).  Two stages like the segment sum: block (chunk, g) reduces a slice of the graph's
+// rows, thread = one channel x one of 256 / cp row lanes (cp = power of two >= C, <= 256), then the chunk winners are merged in
+// chunk order.  Workspace: [B][SEG_CHUNKS][C] values + the same of int32 row ids.
+__global__ __launch_bounds__(256) void k_segment_max_stage1(const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ ptr, int C,
+                                                            int cp, int c_base, int nchunks, float* __restrict__ pv, int32_t* __restrict__ pi) {
+  const int g = blockIdx.y, chunk = blockIdx.x;
+  const int a = ptr[g], b = ptr[g + 1];
+  const int per = (b - a + nchunks - 1) / nchunks;
+  const int r0 = a + chunk * per, r1 = min(b, r0 + per);
+  const int k = c_base + (int)(threadIdx.x % cp), rl = threadIdx.x / cp, nrl = 256 / cp;
+  float best = -INFINITY;
+  int bi = -1;
+  if (k < C)
+    for (int r = r0 + rl; r < r1; r += nrl) {
+      const float v = x[(int64_t)r * ldx + k];
+      if (v > best || bi < 0) { best = v; bi = r; }      // strict: the first row wins a tie (rows ascend per lane)
+    }
+  __shared__ float sv[256];
+  __shared__ int si[256];
+  sv[threadIdx.x] = best; si[threadIdx.x] = bi;
+  __syncthreads();
+  if (rl == 0 && k < C) {
+    for (int j = 1; j < nrl; ++j) {
+      const float v = sv[j * cp + (threadIdx.x % cp)];
+      const int i = si[j * cp + (threadIdx.x % cp)];
+      if (i >= 0 && (bi < 0 || v > best || (v == best && i < bi))) { best = v; bi = i; }
+    }
+    pv[((int64_t)g * nchunks + chunk) * C + k] = best;
+    pi[((int64_t)g * nchunks + chunk) * C + k] = bi;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_segment_max_stage2(const float* __restrict__ pv, const int32_t* __restrict__ pi, int C, int nchunks,
+                                                            int64_t total, float* __restrict__ out, int32_t* __restrict__ arg) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;  // over B * C
+  if (i >= total) return;
+  const int64_t g = i / C;
+  const int k = (int)(i % C);
+  float best = 0.f;
+  int bi = -1;
+  for (int c = 0; c < nchunks; ++c) {          // chunks hold ascending row ranges: the first maximum wins
+    const float v = pv[(g * nchunks + c) * C + k];
+    const int r = pi[(g * nchunks + c) * C + k];
+    if (r >= 0 && (bi < 0 || v > best)) { best = v; bi = r; }
+  }
+  out[i] = bi < 0 ? 0.f : best;
+  arg[i] = bi;
+}
+
+// dx = 0 everywhere except dx[arg[g][c]][c] = gout[g][c]: the zero fill and the scatter in one launch over the rows
+__global__ __launch_bounds__(256) void k_segment_max_bwd(const float* __restrict__ gout, const int32_t* __restrict__ arg,
+                                                         const int32_t* __restrict__ ptr, int B, int C, int64_t total, float* __restrict__ dx) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int r = (int)(i / C), k = (int)(i % C);
+    int g = 0;
+    while (g + 1 < B && ptr[g + 1] <= r) ++g;
+    dx[i] = arg[(int64_t)g * C + k] == r ? gout[(int64_t)g * C + k] : 0.f;
+  }
+}
+
+extern "C" size_t dgdm_segment_max_workspace_bytes(int32_t B, int32_t C) {
+  return (B <= 0 || C <= 0) ? 0 : (size_t)B * SEG_CHUNKS * C * (sizeof(float) + sizeof(int32_t));
+}
+
+extern "C" int dgdm_segment_max_fwd(const float* x, int64_t ldx, const int32_t* ptr, int32_t B, int32_t C, float* out, int32_t* arg,
+                                    void* workspace, size_t workspace_bytes, void* stream_) {
+  DGDM_REQUIRE(B >= 0 && C > 0);
+  if (B == 0) return DGDM_OK;
+  DGDM_REQUIRE(x && ptr && out && arg && workspace);
+  if (ldx < C) return DGDM_ERR_INVALID_ARG;
+  if (workspace_bytes < dgdm_segment_max_workspace_bytes(B, C)) return DGDM_ERR_WORKSPACE;
+  hipStream_t s = static_cast<hipStream_t>(stream_);
+  float* pv = static_cast<float*>(workspace);
+  int32_t* pi = reinterpret_cast<int32_t*>(pv + (size_t)B * SEG_CHUNKS * C);
+  for (int c_base = 0; c_base < C; c_base += 256) {         // 256 channels per launch (one launch for every width of the path)
+    int cp = 1;
+    while (cp < C - c_base && cp < 256) cp <<= 1;
+    hipLaunchKernelGGL(k_segment_max_stage1, dim3(SEG_CHUNKS, B), dim3(256), 0, s, x, ldx, ptr, C, cp, c_base, SEG_CHUNKS, pv, pi);
+  }
+  const int64_t total = (int64_t)B * C;
+  hipLaunchKernelGGL(k_segment_max_stage2, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, pv, pi, C, SEG_CHUNKS, total, out, arg);
+  return dgdm_launch_status();
+}
+
+extern "C" int dgdm_segment_max_bwd(const float* gout, const int32_t* arg, const int32_t* ptr, int32_t B, int32_t N, int32_t C, float* dx,
+                                    void* stream_) {
+  DGDM_REQUIRE(B >= 0 && N >= 0 && C > 0);
+  if (N == 0) return DGDM_OK;
+  DGDM_REQUIRE(gout && arg && ptr && dx && B > 0);
+  const int64_t total = (int64_t)N * C;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(k_segment_max_bwd, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream_), gout, arg, ptr, B, C, total, dx);
+  return dgdm_launch_status();
+}
+
 #define POOL_DISPATCH(D_, KERNEL, ...)                                                                           \
   switch (D_) {                                                                                                  \
     case 4: hipLaunchKernelGGL((KERNEL<4>), dim3(H, B), dim3(256), 0, s, __VA_ARGS__); break;                    \

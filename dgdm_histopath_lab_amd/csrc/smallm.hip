@@ -119,7 +119,7 @@ inline bool small_ok(int M, int N, int K) { return M >= 0 && N > 0 && K > 0 && K
 
 extern "C" int dgdm_linear_small_fwd(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* b, int32_t M, int32_t N,
                                      int32_t K, int32_t act, float* y, int64_t ldy, float* pre, int64_t ldp, void* stream) {
-  if (M < 0 || N <= 0 || K <= 0 || act < 0 || act > 3) return DGDM_ERR_INVALID_ARG;
+  if (M < 0 || N <= 0 || K <= 0 || act < 0 || act > DGDM_ACT_ELU) return DGDM_ERR_INVALID_ARG;
   if (M == 0) return DGDM_OK;
   if (!x || !w || !y) return DGDM_ERR_INVALID_ARG;
   if (!small_ok(M, N, K) || ldx < K || ldw < K || ldy < N || (pre && ldp < N)) return DGDM_ERR_UNSUPPORTED;
@@ -130,6 +130,7 @@ extern "C" int dgdm_linear_small_fwd(const float* x, int64_t ldx, const float* w
     case DGDM_ACT_GELU: GO(DGDM_ACT_GELU); break;
     case DGDM_ACT_RELU: GO(DGDM_ACT_RELU); break;
     case DGDM_ACT_SILU: GO(DGDM_ACT_SILU); break;
+    case DGDM_ACT_ELU: GO(DGDM_ACT_ELU); break;
     default: GO(DGDM_ACT_NONE); break;
   }
 #undef GO
@@ -139,7 +140,7 @@ extern "C" int dgdm_linear_small_fwd(const float* x, int64_t ldx, const float* w
 extern "C" int dgdm_linear_small_bwd(const float* gy, int64_t ldg, const float* pre, int64_t ldp, int32_t act, const float* x, int64_t ldx,
                                      const float* w, int64_t ldw, int32_t M, int32_t N, int32_t K, float* dx, int64_t lddx, float* dw,
                                      int64_t lddw, float* db, void* stream) {
-  if (M < 0 || N <= 0 || K <= 0 || act < 0 || act > 3) return DGDM_ERR_INVALID_ARG;
+  if (M < 0 || N <= 0 || K <= 0 || act < 0 || act > DGDM_ACT_ELU) return DGDM_ERR_INVALID_ARG;
   if (!gy && M > 0) return DGDM_ERR_INVALID_ARG;
   if (act != DGDM_ACT_NONE && !pre && M > 0) return DGDM_ERR_INVALID_ARG;
   if ((dx && !w) || ((dw || db) && !x && M > 0)) return DGDM_ERR_INVALID_ARG;
@@ -158,6 +159,7 @@ extern "C" int dgdm_linear_small_bwd(const float* gy, int64_t ldg, const float* 
     case DGDM_ACT_GELU: GO(DGDM_ACT_GELU); break;
     case DGDM_ACT_RELU: GO(DGDM_ACT_RELU); break;
     case DGDM_ACT_SILU: GO(DGDM_ACT_SILU); break;
+    case DGDM_ACT_ELU: GO(DGDM_ACT_ELU); break;
     default: GO(DGDM_ACT_NONE); break;
   }
 #undef GO

@@ -405,13 +405,11 @@ class GlobalMeanPool(nn.Module):
 
 
 class GlobalMaxPool(nn.Module):
-    """dgdm_model.py:570-585."""
+    """dgdm_model.py:570-585 (``x[batch == i].max(dim=0)[0]`` per graph, zeros for a graph without nodes) as one two-stage segmented
+    reduction over the whole batch (csrc/segment.hip, dgdm_segment_max_*); the gradient goes to the maximising row."""
 
     def forward(self, x: Tensor, batch: Optional[Tensor] = None, plan=None) -> Tensor:
-        B, seg = _num_graphs(batch, plan), _seg(x, batch)
-        out = torch.full((B, x.size(1)), float("-inf"), device=x.device, dtype=x.dtype)
-        out = out.scatter_reduce(0, seg.unsqueeze(-1).expand_as(x), x, "amax")
-        return torch.where(torch.isinf(out), torch.zeros_like(out), out)
+        return ops.segment_max(x, _plan_for(x, batch, plan))
 
 
 class GlobalSet2SetPool(nn.Module):

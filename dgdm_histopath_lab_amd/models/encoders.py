@@ -29,11 +29,20 @@ def _norm(kind: str, dim: int) -> nn.Module:
 
 
 def _norm_act_dropout(h: Tensor, norm: nn.Module, act: nn.Module, drop: nn.Dropout, training: bool) -> Tensor:
-    """dropout(act(norm(h))): one fused HIP kernel for LayerNorm + {GELU, ReLU}; other norm kinds
-    (batch / instance / identity) run as separate GPU ops."""
+    """dropout(act(norm(h))).  LayerNorm and InstanceNorm1d: ONE fused HIP kernel (csrc/rownorm.hip) with any of the reference's
+    activations (ReLU / GELU / ELU, encoders.py:57-62).  ``nn.InstanceNorm1d(dim)`` on a 2-D ``[N, dim]`` input (encoders.py:95-100
+    builds it with the defaults affine=False, track_running_stats=False) treats the rows as the channels of ONE unbatched sample and
+    normalises each row over its ``dim`` entries: a LayerNorm without affine parameters -- the row kernel with gamma = 1, beta = 0.
+    ``nn.BatchNorm1d`` (statistics over the NODES of the batch, running averages in eval mode) stays torch's own module -- an ATen
+    kernel, documented in DESIGN.md 1 -- followed by the fused activation + dropout kernel; Identity: that kernel alone."""
     aid = ops.act_id(act)
-    if isinstance(norm, nn.LayerNorm) and aid is not None and ops.row_norm_supported(h.size(1), 1):
-        return ops.row_norm(h, norm.weight, norm.bias, eps=norm.eps, act=aid, drop_p=drop.p, training=training)
+    if aid is not None and ops.row_norm_supported(h.size(1), 1):
+        if isinstance(norm, nn.LayerNorm):
+            return ops.row_norm(h, norm.weight, norm.bias, eps=norm.eps, act=aid, drop_p=drop.p, training=training)
+        if isinstance(norm, nn.InstanceNorm1d) and not norm.affine and not norm.track_running_stats:
+            one = ops.device_constant([1.0] * h.size(1), torch.float32, h.device)
+            zero = ops.device_constant([0.0] * h.size(1), torch.float32, h.device)
+            return ops.row_norm(h, one, zero, eps=norm.eps, act=aid, drop_p=drop.p, training=training)
     h = norm(h)
     if aid is not None and h.numel() % 4 == 0:
         return ops.act_dropout(h, aid, drop.p, training)

@@ -250,7 +250,10 @@ class PackedOperands:
 ATTN_GRAD_TARGET = 0.25
 ATTN_BWD_CONCURRENT = False     # dQ pass on a side stream beside the dK/dV pass (tools/bench_with.py A/B switch)
 ATTN_BWD_FUSED = True           # dQ, dK, dV in one key-stationary pass + a fixed-order reduction of the partial dQ tiles (False: two passes)
-ATTN_BWD_FUSED_BUDGET = 16 << 30  # bytes of partial-tile scratch per launch (0.8 GB at 4 x 10k nodes x 8 heads; 10 GB for one 50k-node graph x 16 heads)
+# bytes of partial-dQ scratch per launch of the one-pass backward.  The scratch grows with N^2 * H / 256 * 64 B (0.8 GB at 4 x 10k nodes x
+# 8 heads; 10 GB for one 50k-node graph x 16 heads) and, inside a recorded step, stays in the recording's private pool for good: the
+# budget bounds it (more groups = a few more launches: 86.6 against 85.8 ms per step at configs[3] with two groups, round 4).
+ATTN_BWD_FUSED_BUDGET = 4 << 30
 _SIDE_STREAMS: dict = {}
 
 
@@ -330,6 +333,8 @@ def spatial_attn_h_bwd_raw(pk: PackedOperands, out, gout, plan: AttnPlan, H: int
         import ctypes
         ph = (ctypes.c_int32 * (plan.B + 1))(*plan.ptr_host)
         nsb, sb = lib.dgdm_spatial_attn_h_bwd_fused_superblocks(ph, plan.B), 0
+        if nsb == 0:              # no keys at all (an empty batch / only empty graphs): nothing to launch, no gradient
+            return dqkv.zero_()
         groups = []
         while sb < nsb:
             cnt = nsb - sb
@@ -518,8 +523,8 @@ def spatial_attention_mean_weights(qkv, pos, plan: AttnPlan, H: int, scale: floa
 
 
 # ----------------------------------------------------------------------------- K6/K7 fused row kernels
-ACT_NONE, ACT_GELU, ACT_RELU, ACT_SILU = 0, 1, 2, 3
-_ACT_IDS = {"none": ACT_NONE, "gelu": ACT_GELU, "relu": ACT_RELU, "silu": ACT_SILU}
+ACT_NONE, ACT_GELU, ACT_RELU, ACT_SILU, ACT_ELU = 0, 1, 2, 3, 4
+_ACT_IDS = {"none": ACT_NONE, "gelu": ACT_GELU, "relu": ACT_RELU, "silu": ACT_SILU, "elu": ACT_ELU}
 _seed_counter = 0
 
 
@@ -543,6 +548,8 @@ def act_id(module_or_name) -> Optional[int]:
         return ACT_RELU
     if isinstance(module_or_name, nn.SiLU):
         return ACT_SILU
+    if isinstance(module_or_name, nn.ELU):
+        return ACT_ELU if module_or_name.alpha == 1.0 else None
     if isinstance(module_or_name, nn.Identity):
         return ACT_NONE
     return None
@@ -766,6 +773,42 @@ def segment_sum_raw(x, plan: AttnPlan) -> torch.Tensor:
     _lib.check(lib.dgdm_segment_sum(x.data_ptr(), plan.ptr_dev.data_ptr(), plan.B, C, out.data_ptr(), ws.data_ptr(), wsb,
                                     _lib.stream_ptr(x.device)), "dgdm_segment_sum")
     return out
+
+
+class _SegmentMax(torch.autograd.Function):
+    """Per-graph maximum over the rows, [N, C] -> [B, C] (GlobalMaxPool, models/dgdm_model.py:570-585): csrc/segment.hip; the
+    gradient goes to the row that attained the maximum (the first on ties), as torch.max(dim=0) sends it."""
+
+    @staticmethod
+    def forward(ctx, x, plan: AttnPlan):
+        lib = _lib.load()
+        x = _f32c(x)
+        _lib.require_cuda(x)
+        C = x.size(1)
+        out = torch.empty(plan.B, C, dtype=torch.float32, device=x.device)
+        arg = torch.empty(plan.B, C, dtype=torch.int32, device=x.device)
+        wsb = _lib.workspace_bytes("dgdm_segment_max_workspace_bytes", plan.B, C)
+        ws = torch.empty(max(wsb, 4) // 4, dtype=torch.float32, device=x.device)
+        _lib.check(lib.dgdm_segment_max_fwd(x.data_ptr(), x.stride(0), plan.ptr_dev.data_ptr(), plan.B, C, out.data_ptr(), arg.data_ptr(),
+                                            ws.data_ptr(), wsb, _lib.stream_ptr(x.device)), "dgdm_segment_max_fwd")
+        ctx.save_for_backward(arg)
+        ctx.plan, ctx.n = plan, x.size(0)
+        ctx.mark_non_differentiable(arg)
+        return out, arg
+
+    @staticmethod
+    def backward(ctx, g, _garg=None):
+        (arg,) = ctx.saved_tensors
+        g = _f32c(g)
+        dx = torch.empty(ctx.n, g.size(1), dtype=torch.float32, device=g.device)
+        _lib.check(_lib.load().dgdm_segment_max_bwd(g.data_ptr(), arg.data_ptr(), ctx.plan.ptr_dev.data_ptr(), ctx.plan.B, ctx.n, g.size(1),
+                                                    dx.data_ptr(), _lib.stream_ptr(g.device)), "dgdm_segment_max_bwd")
+        return dx, None
+
+
+def segment_max(x, plan: AttnPlan, return_arg: bool = False):
+    out, arg = _SegmentMax.apply(x, plan)
+    return (out, arg) if return_arg else out
 
 
 class _SegmentBcastAdd(torch.autograd.Function):

@@ -47,7 +47,7 @@ enum {
 #define DGDM_AMAX_STRIDE 64
 
 /* activation ids shared by the fused row kernels */
-enum { DGDM_ACT_NONE = 0, DGDM_ACT_GELU = 1, DGDM_ACT_RELU = 2, DGDM_ACT_SILU = 3 };
+enum { DGDM_ACT_NONE = 0, DGDM_ACT_GELU = 1, DGDM_ACT_RELU = 2, DGDM_ACT_SILU = 3, DGDM_ACT_ELU = 4 };   /* ELU: alpha = 1 (nn.ELU(), encoders.py:62,207) */
 
 DGDM_API int dgdm_abi_version(void);
 DGDM_API const char* dgdm_error_string(int code);
@@ -393,6 +393,14 @@ DGDM_API int dgdm_segment_bcast_add(const float* x, const float* src, const int3
 DGDM_API size_t dgdm_segment_sum_workspace_bytes(int32_t B, int32_t C);
 DGDM_API int dgdm_segment_sum(const float* x, const int32_t* ptr, int32_t B, int32_t C, float* out, void* workspace,
                               size_t workspace_bytes, void* stream);
+/* Segment max (GlobalMaxPool, models/dgdm_model.py:570-585: out[g] = x[batch == g].max(dim=0)[0]): out [B, C] and arg [B, C] (the
+ * row that attains the maximum, the first one on ties; -1 and out = 0 for a graph without rows).  The backward writes the whole
+ * dx [N, C]: gout[g][c] at row arg[g][c], zero elsewhere (torch.max(dim)'s gradient).  Any C; x rows at stride ldx. */
+DGDM_API size_t dgdm_segment_max_workspace_bytes(int32_t B, int32_t C);
+DGDM_API int dgdm_segment_max_fwd(const float* x, int64_t ldx, const int32_t* ptr, int32_t B, int32_t C, float* out, int32_t* arg,
+                                  void* workspace, size_t workspace_bytes, void* stream);
+DGDM_API int dgdm_segment_max_bwd(const float* gout, const int32_t* arg, const int32_t* ptr, int32_t B, int32_t N, int32_t C, float* dx,
+                                  void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K7 / K11  element-wise pieces of the diffusion objective and of entity masking, one launch for the whole batch

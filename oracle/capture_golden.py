@@ -16,6 +16,7 @@ Fixture inventory:
   G5  DiffusionLayer add_noise/predict_noise/forward/sample (2-D input)  as-is
   G5b DiffusionLayer.sample at Base widths, 10 and 50 inference steps     as-is
   G6  FeatureEncoder, AdaptiveGraphPooling, GlobalAttentionPool          as-is
+  G10 FeatureEncoder x {relu, elu} x {batch, instance, layer, none} (eval + training mode), GlobalMaxPool / GlobalMeanPool   as-is
   G9  ClassificationHead / RegressionHead forward + every compute_loss branch   models/decoders.py as-is
   G7  DynamicGraphLayer (R1), GraphEncoder (R1+R2), GraphUNet (R1+R5), full model
       forward/pretrain_step (R1-R5): reference leaf classes, repaired wiring
@@ -259,6 +260,29 @@ def g6_small_modules(ref):
     out = gp(xg, batch); go = torch.randn(out.shape)
     gxg, gtok = grads_of((out * go).sum(), [xg, gp.global_token])
     save("g6_attention_pool", x=xg, batch=batch, out=out, go=go, gx=gxg, gtok=gtok, **sd_np(gp))
+
+
+def g10_encoder_options(ref):
+    """FeatureEncoder with every non-default (activation, normalization) the constructor accepts (models/encoders.py:57-64,
+    95-100), as-is, in eval AND in training mode (dropout 0: BatchNorm1d then normalises with the statistics of the batch of nodes,
+    InstanceNorm1d row by row), and the reference's GlobalMaxPool / GlobalMeanPool (models/dgdm_model.py:552-585) on a ragged batch."""
+    for tag, act, norm in (("relu_batch", "relu", "batch"), ("elu_instance", "elu", "instance"), ("elu_layer", "elu", "layer"), ("relu_none", "relu", "none")):
+        for mode in ("eval", "train"):
+            torch.manual_seed(101)
+            fe = ref.encoders.FeatureEncoder(48, 32, dropout=0.0, activation=act, normalization=norm)
+            randomize_(fe, 1010)
+            fe.train(mode == "train")
+            x = torch.randn(37, 48, requires_grad=True)
+            y = fe(x); gy = torch.randn(y.shape)
+            gx, gw = grads_of((y * gy).sum(), [x, fe.encoder[0].weight])
+            save(f"g10_feature_encoder_{tag}_{mode}", x=x, y=y, gy=gy, gx=gx, gw=gw, **sd_np(fe))
+    torch.manual_seed(102)
+    xg = torch.randn(33, 32, requires_grad=True)
+    batch = torch.cat([torch.zeros(9), torch.ones(14), torch.full((10,), 2)]).long()
+    for name, cls in (("max", ref.dgdm_model.GlobalMaxPool), ("mean", ref.dgdm_model.GlobalMeanPool)):
+        out = cls()(xg, batch); go = torch.randn(out.shape)
+        gxg, = grads_of((out * go).sum(), [xg])
+        save(f"g10_pool_{name}", x=xg, batch=batch, out=out, go=go, gx=gxg)
 
 
 def g9_heads(ref):
@@ -509,7 +533,7 @@ def main():
     ref = load_reference()
     print("reference modules loaded from", REF_ROOT)
     only = set(sys.argv[1:])
-    for fn in (g1_scheduler, g2_graph_conv, g2b_plain_encoder, g4_attention, g5_diffusion, g5b_sample_base, g6_small_modules, g7_repaired, g9_heads):
+    for fn in (g1_scheduler, g2_graph_conv, g2b_plain_encoder, g4_attention, g5_diffusion, g5b_sample_base, g6_small_modules, g7_repaired, g9_heads, g10_encoder_options):
         if not only or fn.__name__ in only:
             fn(ref)
 

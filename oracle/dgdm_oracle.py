@@ -60,7 +60,8 @@ class OracleConfig:
     pooling: str = "attention"
     strict_reference: bool = True
     unet_depth: int = 3  # models/dgdm_model.py:154
-    activation: str = "gelu"
+    activation: str = "gelu"              # FeatureEncoder / GraphEncoder / heads: "relu" | "gelu" | "elu" (models/encoders.py:57-62,202-209)
+    normalization: str = "layer"          # FeatureEncoder / GraphEncoder norms: "layer" | "batch" | "instance" (models/encoders.py:95-100,211-219)
     num_classes: Optional[int] = None     # models/dgdm_model.py:168-175 (heads)
     regression_targets: int = 0           # models/dgdm_model.py:177-184
 
@@ -95,16 +96,19 @@ def param_shapes(cfg: OracleConfig) -> Dict[str, tuple]:
     C = H[-1]
     s: Dict[str, tuple] = {}
     # FeatureEncoder (models/encoders.py:73-91)
+    affine = cfg.normalization in ("layer", "batch")     # nn.InstanceNorm1d(dim) has no parameters (affine=False), nn.Identity none
     s["feature_encoder.encoder.0.weight"] = (H[0], F0); s["feature_encoder.encoder.0.bias"] = (H[0],)
-    s["feature_encoder.encoder.1.weight"] = (H[0],); s["feature_encoder.encoder.1.bias"] = (H[0],)
     s["feature_encoder.encoder.4.weight"] = (H[0], H[0]); s["feature_encoder.encoder.4.bias"] = (H[0],)
-    s["feature_encoder.encoder.5.weight"] = (H[0],); s["feature_encoder.encoder.5.bias"] = (H[0],)
+    if affine:
+        s["feature_encoder.encoder.1.weight"] = (H[0],); s["feature_encoder.encoder.1.bias"] = (H[0],)
+        s["feature_encoder.encoder.5.weight"] = (H[0],); s["feature_encoder.encoder.5.bias"] = (H[0],)
     if F0 != H[0]:
         s["feature_encoder.residual_proj.weight"] = (H[0], F0); s["feature_encoder.residual_proj.bias"] = (H[0],)
     # GraphEncoder (models/encoders.py:173-215) + R2
     for i, (din, dout) in enumerate(cfg.encoder_dims()):
         s.update(_dyn_layer_shapes(f"graph_encoder.graph_layers.{i}", din, dout))
-        s[f"graph_encoder.norm_layers.{i}.weight"] = (dout,); s[f"graph_encoder.norm_layers.{i}.bias"] = (dout,)
+        if affine:
+            s[f"graph_encoder.norm_layers.{i}.weight"] = (dout,); s[f"graph_encoder.norm_layers.{i}.bias"] = (dout,)
         if din != dout:
             s[f"graph_encoder.dim_proj.{i}.weight"] = (dout, din); s[f"graph_encoder.dim_proj.{i}.bias"] = (dout,)
     s["graph_encoder.output_proj.weight"] = (C, C); s["graph_encoder.output_proj.bias"] = (C,)
@@ -261,6 +265,31 @@ def _ln(P, pre, x):
     return F.layer_norm(x, (x.shape[-1],), P[f"{pre}.weight"], P[f"{pre}.bias"], 1e-5)
 
 
+def _enc_norm(P, pre, x, kind: str, training: bool):
+    """The norm modules models/encoders.py:95-100 / :211-219 build, applied to a 2-D ``[N, C]`` tensor:
+    "layer"    nn.LayerNorm(C);
+    "batch"    nn.BatchNorm1d(C): statistics over the N NODES of the batch in training mode (biased variance), the running
+               averages in eval mode -- this functional restatement keeps no running state: eval mode reads ``{pre}.running_mean`` /
+               ``.running_var`` from P when present, else the module's initial values (0, 1);
+    "instance" nn.InstanceNorm1d(C) with its defaults (affine=False, track_running_stats=False): a 2-D input is taken as ONE
+               unbatched sample (channels = rows, length = C), i.e. every row is normalised over its C entries (biased variance,
+               eps 1e-5) -- LayerNorm without affine parameters;
+    anything else nn.Identity()."""
+    if kind == "layer":
+        return _ln(P, pre, x)
+    if kind == "instance":
+        return F.layer_norm(x, (x.shape[-1],), None, None, 1e-5)
+    if kind == "batch":
+        rm = P.get(f"{pre}.running_mean", torch.zeros(x.shape[-1], dtype=x.dtype)).detach()
+        rv = P.get(f"{pre}.running_var", torch.ones(x.shape[-1], dtype=x.dtype)).detach()
+        return F.batch_norm(x, rm.clone(), rv.clone(), P[f"{pre}.weight"], P[f"{pre}.bias"], training, 0.1, 1e-5)
+    return x
+
+
+def _enc_act(name: str):
+    return {"relu": F.relu, "gelu": F.gelu, "elu": F.elu}[name]      # encoders.py:57-64 (FeatureEncoder raises on anything else)
+
+
 def _lin(P, pre, x):
     return F.linear(x, P[f"{pre}.weight"], P.get(f"{pre}.bias"))
 
@@ -296,11 +325,12 @@ def dynamic_graph_layer(P, pre, x, graph, ea_ext, p_drop=0.0, training=False) ->
     return _ln(P, f"{pre}.norm1", out + x)
 
 
-def feature_encoder(P, x, p_drop=0.0, training=False) -> Tensor:
-    """FeatureEncoder.forward (models/encoders.py:104-124)."""
+def feature_encoder(P, x, p_drop=0.0, training=False, activation: str = "gelu", normalization: str = "layer") -> Tensor:
+    """FeatureEncoder.forward (models/encoders.py:104-124); activation / normalization: its constructor arguments (:57-64, :95-100)."""
     pre = "feature_encoder"
-    h = _drop(F.gelu(_ln(P, f"{pre}.encoder.1", _lin(P, f"{pre}.encoder.0", x))), p_drop, training, f"{pre}.encoder.3")
-    h = _drop(F.gelu(_ln(P, f"{pre}.encoder.5", _lin(P, f"{pre}.encoder.4", h))), p_drop, training, f"{pre}.encoder.7")
+    act = _enc_act(activation)
+    h = _drop(act(_enc_norm(P, f"{pre}.encoder.1", _lin(P, f"{pre}.encoder.0", x), normalization, training)), p_drop, training, f"{pre}.encoder.3")
+    h = _drop(act(_enc_norm(P, f"{pre}.encoder.5", _lin(P, f"{pre}.encoder.4", h), normalization, training)), p_drop, training, f"{pre}.encoder.7")
     res = _lin(P, f"{pre}.residual_proj", x) if f"{pre}.residual_proj.weight" in P else x
     return h + res
 
@@ -313,7 +343,9 @@ def graph_encoder(P, cfg: OracleConfig, x, graph, ea_ext, training=False):
         h = dynamic_graph_layer(P, f"graph_encoder.graph_layers.{i}", h, graph, ea_ext, cfg.dropout, training)
         if din != dout:
             h = _lin(P, f"graph_encoder.dim_proj.{i}", h)
-        h = _drop(F.gelu(_ln(P, f"graph_encoder.norm_layers.{i}", h)), cfg.dropout, training, f"graph_encoder.dropout.{i}")
+        act = _enc_act(cfg.activation) if cfg.activation in ("relu", "gelu", "elu") else F.relu      # encoders.py:202-209
+        h = _drop(act(_enc_norm(P, f"graph_encoder.norm_layers.{i}", h, cfg.normalization, training)), cfg.dropout, training,
+                  f"graph_encoder.dropout.{i}")
         outs.append(h)
     return _lin(P, "graph_encoder.output_proj", h), outs
 
@@ -599,7 +631,7 @@ def forward(P, cfg: OracleConfig, data, mode: str = "inference", *, training: bo
     out: Dict[str, Tensor] = {}
 
     _stage("graph_structure")
-    h = feature_encoder(P, x, cfg.dropout, training)
+    h = feature_encoder(P, x, cfg.dropout, training, cfg.activation, cfg.normalization)
     _stage("feature_encoder")
     if trace is not None: trace["feature_encoder"] = h
     h, layer_outs = graph_encoder(P, cfg, h, graph, ea_ext, training)

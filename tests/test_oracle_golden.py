@@ -214,3 +214,34 @@ def test_g7_full_model_repaired(tag):
     assert n == 11
     # dead parameters receive no gradient
     assert "spatial_attention.pos_encoding" not in grads and "graph_encoder.graph_layers.0.node_to_qkv.weight" not in grads
+
+
+@pytest.mark.parametrize("tag,act,norm", [("relu_batch", "relu", "batch"), ("elu_instance", "elu", "instance"), ("elu_layer", "elu", "layer"),
+                                          ("relu_none", "relu", "none")])
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_g10_feature_encoder_options_as_is(tag, act, norm, mode):
+    """The restatement's non-default activation / normalization branches against the reference's own FeatureEncoder run with those
+    constructor arguments (models/encoders.py:57-64, 95-100), eval and training mode (BatchNorm1d: batch statistics over the nodes;
+    InstanceNorm1d on a 2-D input: per-row normalisation without affine parameters)."""
+    g = load_golden(f"g10_feature_encoder_{tag}_{mode}")
+    P = {"feature_encoder." + k: (v.requires_grad_(True) if v.is_floating_point() else v) for k, v in weights(g).items()}
+    x = T(g["x"]).requires_grad_(True)
+    y = O.feature_encoder(P, x, 0.0, mode == "train", act, norm)
+    assert_close(y, g["y"], TOL, "y")
+    gx, gw = _grad((y * T(g["gy"])).sum(), [x, P["feature_encoder.encoder.0.weight"]])
+    assert_close(gx, g["gx"], 5e-5, "gx"); assert_close(gw, g["gw"], 5e-5, "gw")
+
+
+def test_product_scheduler_tables_match_the_reference_for_every_schedule():
+    """VERDICT r4 missing 7: the PRODUCT's DiffusionScheduler (dgdm_histopath_lab_amd/core/diffusion.py, host-side tables; the
+    reference: core/diffusion.py:16-61) x {linear, cosine, sigmoid} x T in {10, 20} against the tables the reference's own class
+    produced (g1_scheduler.npz) -- not only the oracle's function."""
+    from dgdm_histopath_lab_amd.core.diffusion import DiffusionScheduler
+    g = load_golden("g1_scheduler")
+    for Tn in (10, 20):
+        for sch in ("linear", "cosine", "sigmoid"):
+            s = DiffusionScheduler(Tn, schedule=sch)
+            for k in ("betas", "alphas", "alphas_cumprod", "alphas_cumprod_prev", "posterior_variance"):
+                np.testing.assert_allclose(getattr(s, k).numpy(), g[f"{sch}.{Tn}.{k}"], rtol=1e-6, atol=1e-7, err_msg=f"{sch}.{Tn}.{k}")
+    with pytest.raises(ValueError):
+        DiffusionScheduler(10, schedule="quadratic")
