@@ -43,6 +43,10 @@ SIGNATURES = {
     "dgdm_spatial_attn_fwd_variant": (C.c_int, [_p, _p, _p, _i64, _p, _p, _i32, _i32, _i32, _i32, C.c_float, C.c_float, C.c_float, C.c_uint32, _p, _i64, _p, _i32, _p]),
     "dgdm_spatial_attn_bwd": (C.c_int, [_p, _p, _p, _i64, _p, _p, _i64, _p, _p, _i32, _i32, _i32, _i32, C.c_float, C.c_float,
                                         _p, C.c_float, C.c_uint32, _p, _p, _p, _i64, _p, _p]),
+    "dgdm_spatial_attn_gen_fwd": (C.c_int, [_p, _p, _p, _i64, _p, _p, _i32, _i32, _i32, _i32, _i32, C.c_float, C.c_float, C.c_float, C.c_uint32, _p, _i64, _p, _p]),
+    "dgdm_spatial_attn_gen_bwd": (C.c_int, [_p, _p, _p, _i64, _p, _p, _i32, _i32, _i32, _i32, _i32, C.c_float, C.c_float, C.c_float, C.c_uint32,
+                                            _p, _p, _i64, _p, _p, _p, _p, _p, _i64, _p]),
+    "dgdm_spatial_attn_gen_mean_weights": (C.c_int, [_p, _p, _i64, _p, _p, _i32, _i32, _i32, _i32, _i32, C.c_float, C.c_float, _p, _p, _p, _p]),
     "dgdm_add_posenc": (C.c_int, [_p, _i64, _p, _p, _i32, _i32, _i32, _p, _p, _i64, _p, _p]),
     "dgdm_spatial_attn_mean_weights": (C.c_int, [_p, _p, _i64, _p, _p, _i32, _i32, _i32, _i32, C.c_float, C.c_float, _p, _p, _p, _p]),
     "dgdm_rownorm_fwd": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, C.c_float, _i32, C.c_float, C.c_uint32, _p, _p, _p, _p, _p]),

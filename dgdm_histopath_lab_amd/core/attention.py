@@ -16,7 +16,7 @@ from torch import Tensor
 
 from .. import ops
 
-KERNEL_HEAD_DIM = 16  # the MFMA tiling of csrc/attn_*.hip
+KERNEL_HEAD_DIM = 16  # the MFMA tiling of csrc/attn_*.hip (DGDMModel's defaults: hidden_dims[-1] / attention_heads = 16)
 
 
 class MultiHeadAttention(nn.Module):
@@ -43,24 +43,31 @@ class MultiHeadAttention(nn.Module):
             if lin.bias is not None:
                 nn.init.constant_(lin.bias, 0.0)
 
+    @property
+    def kernel_head_dim(self) -> int:
+        """The head width the attention kernels run this module at: the next of ops.ATTN_HEAD_DIMS (16 on the MFMA kernels, 32 / 64
+        on csrc/attn_gen.hip); narrower heads are zero-padded (scores and outputs are unchanged by zero columns)."""
+        for D in ops.ATTN_HEAD_DIMS:
+            if self.head_dim <= D:
+                return D
+        raise ops._lib.DGDMKernelError(f"attention kernels support head_dim <= {ops.ATTN_HEAD_DIMS[-1]}, got {self.head_dim}")
+
     def fused_qkv(self, x: Tensor) -> Tensor:
-        """[N, 3*H*16] projection with every head zero-padded to the kernels' head dim 16
-        (scores and outputs are unchanged by zero columns)."""
-        H, d, C = self.num_heads, self.head_dim, self.embed_dim
-        if d > KERNEL_HEAD_DIM:
-            raise ops._lib.DGDMKernelError(f"attention kernels support head_dim <= {KERNEL_HEAD_DIM}, got {d}")
+        """[N, 3*H*D] projection with every head zero-padded to the kernels' head dim D = ``kernel_head_dim``."""
+        H, d, C, D = self.num_heads, self.head_dim, self.embed_dim, self.kernel_head_dim
         w = torch.cat([self.q_proj.weight, self.k_proj.weight, self.v_proj.weight], dim=0)
         b = torch.cat([self.q_proj.bias, self.k_proj.bias, self.v_proj.bias], dim=0) if self.q_proj.bias is not None else None
-        if d != KERNEL_HEAD_DIM:
-            w = F.pad(w.view(3 * H, d, C), (0, 0, 0, KERNEL_HEAD_DIM - d)).reshape(3 * H * KERNEL_HEAD_DIM, C)
+        if d != D:
+            w = F.pad(w.view(3 * H, d, C), (0, 0, 0, D - d)).reshape(3 * H * D, C)
             if b is not None:
-                b = F.pad(b.view(3 * H, d), (0, KERNEL_HEAD_DIM - d)).reshape(-1)
+                b = F.pad(b.view(3 * H, d), (0, D - d)).reshape(-1)
         return ops.linear(x, w, b)
 
     def unpad_heads(self, o: Tensor) -> Tensor:
-        if self.head_dim == KERNEL_HEAD_DIM:
+        D = self.kernel_head_dim
+        if self.head_dim == D:
             return o
-        return o.view(-1, self.num_heads, KERNEL_HEAD_DIM)[:, :, : self.head_dim].reshape(-1, self.embed_dim)
+        return o.view(-1, self.num_heads, D)[:, :, : self.head_dim].reshape(-1, self.embed_dim)
 
     def forward(self, *args, **kwargs):
         raise NotImplementedError("dense MultiHeadAttention.forward is not on the DGDM hot path; use SpatialAttention / "

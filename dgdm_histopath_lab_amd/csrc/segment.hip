@@ -408,6 +408,7 @@ extern "C" int dgdm_segment_max_bwd(const float* gout, const int32_t* arg, const
     case 8: hipLaunchKernelGGL((KERNEL<8>), dim3(H, B), dim3(256), 0, s, __VA_ARGS__); break;                    \
     case 16: hipLaunchKernelGGL((KERNEL<16>), dim3(H, B), dim3(256), 0, s, __VA_ARGS__); break;                  \
     case 32: hipLaunchKernelGGL((KERNEL<32>), dim3(H, B), dim3(256), 0, s, __VA_ARGS__); break;                  \
+    case 64: hipLaunchKernelGGL((KERNEL<64>), dim3(H, B), dim3(256), 0, s, __VA_ARGS__); break;                  \
     default: return DGDM_ERR_UNSUPPORTED;                                                                        \
   }
 
@@ -440,6 +441,7 @@ extern "C" int dgdm_attn_pool_fwd(const float* K, const float* V, int64_t ld, co
     case 8: POOL_FWD(8); break;
     case 16: POOL_FWD(16); break;
     case 32: POOL_FWD(32); break;
+    case 64: POOL_FWD(64); break;
     default: return DGDM_ERR_UNSUPPORTED;
   }
 #undef POOL_FWD

@@ -162,8 +162,8 @@ class DGDMModel(nn.Module):
             if d % attention_heads != 0:
                 raise ValidationError(f"hidden dim {d} not divisible by attention heads {attention_heads} "
                                       "(DynamicGraphLayer asserts this, graph_layers.py:135)")
-        if hidden_dims[-1] // attention_heads > 16:
-            raise ValidationError("the fused attention kernels support head_dim <= 16 "
+        if hidden_dims[-1] // attention_heads > ops.ATTN_HEAD_DIMS[-1]:
+            raise ValidationError(f"the attention kernels support head_dim <= {ops.ATTN_HEAD_DIMS[-1]} "
                                   f"(got {hidden_dims[-1]}/{attention_heads})")
 
     @staticmethod

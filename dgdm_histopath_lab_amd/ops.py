@@ -458,13 +458,58 @@ class _SpatialAttention(torch.autograd.Function):
 ATTN_PRECISION = "fp16x2"
 
 
+ATTN_HEAD_DIMS = (16, 32, 64)     # head widths the attention kernels take (narrower heads are zero-padded to the next one by the caller)
+
+
+class _SpatialAttentionGen(torch.autograd.Function):
+    """Spatial attention for head dims 32 / 64 (csrc/attn_gen.hip: fp32 on the vector units; the MFMA kernels are tiled for 16)."""
+
+    @staticmethod
+    def forward(ctx, qkv, pos, plan: AttnPlan, H: int, D: int, scale: float, inv_tau: float, drop_p: float, seed: int):
+        lib = _lib.load()
+        qkv, pos = _f32c(qkv), _f32c(pos)
+        _lib.require_cuda(qkv, pos)
+        C = H * D
+        q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+        out = torch.empty(qkv.size(0), C, dtype=torch.float32, device=qkv.device)
+        lse = torch.empty(H, max(qkv.size(0), 1), dtype=torch.float32, device=qkv.device)
+        _lib.check(lib.dgdm_spatial_attn_gen_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), qkv.stride(0), pos.data_ptr(), plan.ptr_dev.data_ptr(),
+                                                 plan.B, plan.num_q_tiles, plan.N_tot, H, D, scale, inv_tau, drop_p, seed, out.data_ptr(), C,
+                                                 lse.data_ptr(), _lib.stream_ptr(qkv.device)), "dgdm_spatial_attn_gen_fwd")
+        ctx.save_for_backward(qkv, pos, out, lse)
+        ctx.meta = (plan, H, D, scale, inv_tau, drop_p, seed)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = _lib.load()
+        qkv, pos, out, lse = ctx.saved_tensors
+        plan, H, D, scale, inv_tau, drop_p, seed = ctx.meta
+        C = H * D
+        gout = _f32c(gout)
+        dqkv = torch.empty_like(qkv)
+        delta = torch.empty_like(lse)
+        _lib.check(lib.dgdm_spatial_attn_gen_bwd(qkv[:, :C].data_ptr(), qkv[:, C:2 * C].data_ptr(), qkv[:, 2 * C:].data_ptr(), qkv.stride(0),
+                                                 pos.data_ptr(), plan.ptr_dev.data_ptr(), plan.B, plan.num_q_tiles, plan.N_tot, H, D, scale, inv_tau,
+                                                 drop_p, seed, out.data_ptr(), gout.data_ptr(), C, lse.data_ptr(), delta.data_ptr(),
+                                                 dqkv[:, :C].data_ptr(), dqkv[:, C:2 * C].data_ptr(), dqkv[:, 2 * C:].data_ptr(), dqkv.stride(0),
+                                                 _lib.stream_ptr(qkv.device)), "dgdm_spatial_attn_gen_bwd")
+        return dqkv, None, None, None, None, None, None, None, None
+
+
 def spatial_attention(qkv, pos, plan: AttnPlan, H: int, scale: float, inv_tau: float = 1.0, drop_p: float = 0.0,
                       training: bool = False, seed: Optional[int] = None):
     """dropout(softmax(QK^T*scale - dist*inv_tau)) V per graph; ``drop_p`` applies to the attention
-    weights (core/attention.py:154) in training mode."""
+    weights (core/attention.py:154) in training mode.  ``qkv`` [N, 3 * H * D] with D in ``ATTN_HEAD_DIMS``: 16 runs on the MFMA
+    kernels (``ATTN_PRECISION``), 32 / 64 on the vector-unit kernels of csrc/attn_gen.hip."""
     p = float(drop_p) if training else 0.0
     if p > 0 and seed is None:
         seed = next_dropout_seed()
+    D = qkv.size(1) // (3 * H)
+    if qkv.size(1) != 3 * H * D or D not in ATTN_HEAD_DIMS:
+        raise _lib.DGDMKernelError(f"spatial attention kernels take head dims {ATTN_HEAD_DIMS} (pad narrower heads with zeros), got {qkv.size(1)} / (3 x {H})")
+    if D != 16:
+        return _SpatialAttentionGen.apply(qkv, pos, plan, H, D, scale, inv_tau, p, seed or 0)
     fn = _SpatialAttention if ATTN_PRECISION == "fp32" else _SpatialAttentionH
     return fn.apply(qkv, pos, plan, H, scale, inv_tau, p, seed or 0)
 
@@ -508,13 +553,27 @@ def spatial_attention_mean_weights(qkv, pos, plan: AttnPlan, H: int, scale: floa
     qkv, pos = _f32c(qkv), _f32c(pos)
     C = qkv.size(1) // 3
     q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
-    _, lse2 = spatial_attn_fwd_raw(q, k, v, pos, plan, H, scale, inv_tau)
     sizes = [plan.ptr_host[g + 1] - plan.ptr_host[g] for g in range(plan.B)]
     offs = [0]
     for n in sizes:
         offs.append(offs[-1] + n * n)
     W = torch.empty(max(offs[-1], 1), dtype=torch.float32, device=qkv.device)
     off_dev = device_constant(offs[:-1], torch.int64, qkv.device)
+    D = C // H
+    if D != 16:           # head dims 32 / 64: csrc/attn_gen.hip (its own forward for the row log-sum-exp)
+        if D not in ATTN_HEAD_DIMS:
+            raise _lib.DGDMKernelError(f"spatial attention kernels take head dims {ATTN_HEAD_DIMS}, got {D}")
+        out = torch.empty(qkv.size(0), C, dtype=torch.float32, device=qkv.device)
+        lse = torch.empty(H, max(qkv.size(0), 1), dtype=torch.float32, device=qkv.device)
+        st = _lib.stream_ptr(qkv.device)
+        _lib.check(lib.dgdm_spatial_attn_gen_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), qkv.stride(0), pos.data_ptr(), plan.ptr_dev.data_ptr(),
+                                                 plan.B, plan.num_q_tiles, plan.N_tot, H, D, scale, inv_tau, 0.0, 0, out.data_ptr(), C, lse.data_ptr(), st),
+                   "dgdm_spatial_attn_gen_fwd")
+        _lib.check(lib.dgdm_spatial_attn_gen_mean_weights(q.data_ptr(), k.data_ptr(), qkv.stride(0), pos.data_ptr(), plan.ptr_dev.data_ptr(), plan.B,
+                                                          plan.num_q_tiles, plan.N_tot, H, D, scale, inv_tau, lse.data_ptr(), W.data_ptr(),
+                                                          off_dev.data_ptr(), st), "dgdm_spatial_attn_gen_mean_weights")
+        return [W[offs[g]:offs[g + 1]].view(sizes[g], sizes[g]) for g in range(plan.B)]
+    _, lse2 = spatial_attn_fwd_raw(q, k, v, pos, plan, H, scale, inv_tau)
     _lib.check(lib.dgdm_spatial_attn_mean_weights(q.data_ptr(), k.data_ptr(), q.stride(0), pos.data_ptr(), plan.ptr_dev.data_ptr(),
                                                   plan.B, plan.num_q_tiles, plan.N_tot, H, scale, inv_tau, lse2.data_ptr(),
                                                   W.data_ptr(), off_dev.data_ptr(), _lib.stream_ptr(qkv.device)),
@@ -862,7 +921,7 @@ def segment_bcast_add(x, src, plan: AttnPlan):
     return _SegmentBcastAdd.apply(x, src, plan)
 
 
-POOL_HEAD_DIMS = (4, 8, 16, 32)
+POOL_HEAD_DIMS = (4, 8, 16, 32, 64)
 
 
 class _AttnPool(torch.autograd.Function):

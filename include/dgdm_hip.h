@@ -523,6 +523,25 @@ DGDM_API int dgdm_gemm_tn_split_f16x2(const float* dY, int64_t ldy, const float*
                                       void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * K4-gen  spatial attention for 16 < head_dim <= 64 (csrc/attn_gen.hip).  The reference accepts any embed_dim % num_heads == 0
+ * (core/attention.py:36-40); the MFMA kernels above are tiled for head_dim 16 (smaller heads are zero-padded).  Heads of 32 / 64
+ * channels (hidden_dims[-1] = 128 with attention_heads 4 / 2) run on these fp32 vector-unit kernels: same mathematics
+ * (softmax(Q K^T scale - dist inv_tau), dropout on the weights, row sums before the mask), Q / K / V [N_tot, H * D] views with a
+ * common row stride ld, D in {32, 64} (other head dims: zero-pad to the next one), num_tiles = sum over graphs of ceil(n_g / 64)
+ * (= dgdm_spatial_attn_q_tile_rows() rows per tile), lse [H, N_tot] NATURAL-log sum-exp, delta [H, N_tot] scratch of the backward.
+ * The dropout mask is a hash of (seed, graph, head, query, key) private to this kernel family. */
+DGDM_API int dgdm_spatial_attn_gen_fwd(const float* Q, const float* K, const float* V, int64_t ld, const float* pos, const int32_t* ptr,
+                                       int32_t B, int32_t num_tiles, int32_t N_tot, int32_t H, int32_t D, float scale, float inv_tau,
+                                       float drop_p, uint32_t seed, float* O, int64_t ldo, float* lse, void* stream);
+DGDM_API int dgdm_spatial_attn_gen_bwd(const float* Q, const float* K, const float* V, int64_t ld, const float* pos, const int32_t* ptr,
+                                       int32_t B, int32_t num_tiles, int32_t N_tot, int32_t H, int32_t D, float scale, float inv_tau,
+                                       float drop_p, uint32_t seed, const float* O, const float* dO, int64_t ldo, const float* lse,
+                                       float* delta, float* dQ, float* dK, float* dV, int64_t ldg, void* stream);
+DGDM_API int dgdm_spatial_attn_gen_mean_weights(const float* Q, const float* K, int64_t ld, const float* pos, const int32_t* ptr, int32_t B,
+                                                int32_t num_tiles, int32_t N_tot, int32_t H, int32_t D, float scale, float inv_tau,
+                                                const float* lse, float* W, const int64_t* offsets, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * K3-img  weight images (csrc/gemm_img.hip).  The two contractions whose second operand is a WEIGHT -- y = x W^T + b
  * (core/graph_layers.py:45-49,141-150, models/encoders.py:73-91, core/attention.py:60-63, core/diffusion.py:87-104 of the
  * reference: every nn.Linear forward) and dx = dy W (its input gradient) -- take the weight pre-split: an "image" holds the
