@@ -1106,7 +1106,7 @@ def ensure_amax(t: torch.Tensor) -> int:
     unit column stride, cols % 4 == 0, 16-byte aligned (what the tile GEMMs accept anyway)."""
     slot = amax_of(t)
     if slot is None:
-        if AMAX_FALLBACK_LOG is not None:       # diagnostics (tools/amax_fallbacks.py): who still needs a reduction launch?
+        if AMAX_FALLBACK_LOG is not None:       # diagnostics (tools/attic/amax_fallbacks.py): who still needs a reduction launch?
             import traceback
             fr = [f for f in traceback.extract_stack(limit=12) if "dgdm_histopath_lab_amd" in f.filename][-5:-1]
             AMAX_FALLBACK_LOG.append((tuple(t.shape), " < ".join(f"{f.name}:{f.lineno}" for f in reversed(fr))))
@@ -2290,8 +2290,11 @@ class _UnpoolAddRelu(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xc, skip, node_map, decide=None):
         lib = _lib.load()
+        _lib.require_cuda(xc, skip, node_map)          # safe on its own: no earlier layer has to have raised first
         xc, skip = _rowmajor(xc), _rowmajor(skip)
         N, C = skip.shape
+        if C % 4 or xc.size(1) != C or node_map.numel() != N:
+            raise _lib.DGDMKernelError(f"unpool_add_relu: widths must match and be multiples of 4 (got {tuple(xc.shape)} onto {tuple(skip.shape)})")
         out = torch.empty(N, C, dtype=torch.float32, device=skip.device)
         _lib.check(lib.dgdm_unpool_add_relu_fwd(xc.data_ptr(), xc.stride(0), skip.data_ptr(), skip.stride(0), node_map.data_ptr(), N, C,
                                                 out.data_ptr(), out.stride(0), _lib.ptr(decide), _lib.stream_ptr(skip.device)),

@@ -114,10 +114,24 @@ class DGDMAdamW(torch.optim.Optimizer):
             lr_dev = lr.data_ptr() if isinstance(lr, torch.Tensor) and lr.is_cuda else None
             lr_host = 0.0 if lr_dev is not None else float(lr)
             b1, b2 = group["betas"]
-            for ci, c in enumerate(cohorts):
+            live_ids = {id(p) for p in live}
+            for ci in range(len(cohorts)):
+                c = cohorts[ci]
                 ps = [p for p in live if id(p) in c["ids"]]
                 if not ps:
                     continue
+                if len(ps) < len(c["ids"]):
+                    # Members without a gradient in this step (frozen after a phase switch, a branch the batch did not take with
+                    # zero_grad(set_to_none=True)): torch.optim.AdamW would not advance THEIR step count, and the cohort's one
+                    # counter is about to advance.  They leave with a copy of the count as it stands and form a cohort of
+                    # their own; when they come back they step from where they stopped.
+                    gone = c["ids"] - live_ids
+                    c2 = {"step": c["step"].clone(), "ticket": torch.zeros(1, dtype=torch.int32, device=c["step"].device), "ids": gone}
+                    for q in group["params"]:
+                        if id(q) in gone:
+                            self.state[q]["step"] = c2["step"]
+                    c["ids"] = c["ids"] - gone
+                    cohorts.append(c2)
                 ptrs = []
                 for p in ps:
                     g, st = p.grad, self.state[p]

@@ -177,7 +177,7 @@ class FlatGradAllReducer:
     def reduce_packed(self) -> None:
         """All-reduce the (already packed) buffer as ONE message: between two recorded graphs nothing can overlap with it, and a
         second collective only adds its latency (measured on one MI355X through a single-rank RCCL group,
-        tools/dist_overhead_probe.py: +0.3 ms per step for the second message)."""
+        tools/attic/dist_overhead_probe.py: +0.3 ms per step for the second message)."""
         self._forwards = 0
         if self.flat.numel() == 0:
             return

@@ -214,7 +214,8 @@ class DGDMTrainer(nn.Module):
     def configure_optimizers(self, total_steps: int):
         """``total_steps`` = Lightning's ``trainer.estimated_stepping_batches``."""
         on_gpu = next(self.model.parameters()).is_cuda
-        if on_gpu:      # the same AdamW arithmetic on one HIP launch (optim.py); CPU models (host-logic tests) keep torch's
+        if on_gpu:      # the same AdamW arithmetic on one HIP launch (optim.py).  A model on the CPU has no forward here (the kernels
+                        # raise DGDMKernelError): torch's AdamW is only built so that host-side logic (schedules, phase switch) can be tested
             from .optim import DGDMAdamW
             opt = DGDMAdamW(self.model.parameters(), lr=self.learning_rate, weight_decay=self.weight_decay)
         else:
@@ -406,6 +407,7 @@ class GraphedPretrainStep:
         self._loss = None
         self._calls = 0
         self._side = torch.cuda.Stream(self.dev)
+        self.replay_done = torch.cuda.Event()         # see `input_buffers`: recorded behind every replay of the forward + backward graph
 
     # ------------------------------------------------------------------ static inputs
     # tensors of a batch the step reads (PyG-style objects keep them outside __dict__, so they are named here)
@@ -444,14 +446,23 @@ class GraphedPretrainStep:
             v = getattr(batch, k, None)
             if isinstance(v, torch.Tensor):
                 dst = getattr(self.static, k)
-                if v.data_ptr() != dst.data_ptr():      # a loader that fills `input_buffers` in place hands the buffers back: nothing to copy
+                # a loader that fills `input_buffers` in place hands the buffers back: nothing to copy.  Identity is the tensor object
+                # or the same storage window WITH the same strides (a same-pointer view with other strides is another tensor: copied)
+                same = v is dst or (v.data_ptr() == dst.data_ptr() and v.stride() == dst.stride() and v.dtype == dst.dtype)
+                if not same:
                     dst.copy_(v, non_blocking=True)
 
     @property
     def input_buffers(self):
         """The recording's own input tensors (a ``GraphBatch``; ``None`` before the first call).  A data pipeline that writes the
         next batch of the same layout INTO these tensors (e.g. the host-to-device copy of its loader) and passes this object to
-        ``__call__`` saves the device-to-device copy of the batch (130 MB per step at 4 x 10k nodes x 768 features)."""
+        ``__call__`` saves the device-to-device copy of the batch (130 MB per step at 4 x 10k nodes x 768 features).
+
+        ORDERING CONTRACT: a replay reads these tensors on the stream ``__call__`` ran on.  Whoever writes the next batch into them
+        from another stream (a loader's copy stream) must (i) wait for ``replay_done`` -- an event recorded on the step's stream
+        right behind every replay -- before the write, and (ii) make the step's stream wait for the write before the next
+        ``__call__`` (``torch.cuda.current_stream().wait_stream(copy_stream)``).  Writes issued on the step's own stream need
+        neither."""
         return self.static
 
     def set_lr(self, lr: float, group: int = 0) -> None:
@@ -558,6 +569,7 @@ class GraphedPretrainStep:
         if not self._graphs:
             self._record()          # recording launches nothing: the step itself is the replay below
         self._graphs[0].replay()
+        self.replay_done.record(torch.cuda.current_stream(self.dev))     # the inputs have been consumed once this event has passed
         if self.reducer is not None:
             self.reducer.reduce_packed()    # the one eager piece: ONE all-reduce of the whole buffer graph 0 just packed
             self._graphs[1].replay()

@@ -482,3 +482,34 @@ def test_dgdm_adamw_matches_torch_adamw_and_exchanges_state_dicts():
     torch.cuda.synchronize()
     same(4e-6)
     assert float(o_back.state[own[0]]["step"]) == 12.0
+
+
+@pytest.mark.gpu
+def test_dgdm_adamw_member_that_skips_steps_keeps_its_own_count():
+    """parameters that got their first gradient in the same call share one device step counter.  A member WITHOUT a gradient
+    in a later step (frozen after the pretrain -> finetune switch; a branch the batch did not take under zero_grad(set_to_none=True))
+    must not have its count advanced -- torch.optim.AdamW does not advance it -- and must continue from its own count when it comes
+    back: bias correction and the exported ``step`` then equal torch's.  Parameters 1 and 2 skip steps 2-3 and rejoin at step 4."""
+    from dgdm_histopath_lab_amd.optim import DGDMAdamW
+    DEV = "cuda:0"
+    g = torch.Generator().manual_seed(1)
+    base = [torch.randn(n, generator=g) for n in (257, 1000, 33, 4096)]
+    ref = [torch.nn.Parameter(b.double().clone()) for b in base]
+    own = [torch.nn.Parameter(b.to(DEV).clone()) for b in base]
+    kw = dict(lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
+    o_ref, o_own = torch.optim.AdamW(ref, **kw), DGDMAdamW(own, **kw)
+    for step in range(7):
+        for i, (a, b) in enumerate(zip(ref, own)):
+            if i in (1, 2) and step in (2, 3):
+                a.grad = b.grad = None
+                continue
+            gr = torch.randn(a.shape, generator=g)
+            a.grad, b.grad = gr.double(), gr.to(DEV)
+        o_ref.step(); o_own.step()
+        for i, (a, b) in enumerate(zip(ref, own)):
+            assert float(o_own.state[b]["step"]) == float(o_ref.state[a]["step"]), (step, i)
+            d = (b.detach().cpu().double() - a.detach()).abs().max().item()
+            assert d <= 2e-6 * max(1.0, a.detach().abs().max().item()), (step, i, d)
+    assert float(o_own.state[own[1]]["step"]) == 5.0 and float(o_own.state[own[0]]["step"]) == 7.0
+    sd = o_own.state_dict()["state"]
+    assert [float(sd[i]["step"]) for i in range(4)] == [7.0, 5.0, 5.0, 7.0]
