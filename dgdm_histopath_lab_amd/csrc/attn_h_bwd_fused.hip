@@ -49,8 +49,17 @@
 #define DGDM_FUSED_NBUF 1
 #endif
 
+// 64-key blocks (= waves) per workgroup.  4: 256 keys, 57 KB LDS, two workgroups per CU (round 4).  8 (round 5):
+// 512 keys, 105 KB LDS, ONE workgroup of 8 waves per CU -- the same 2 waves per SIMD -- with HALF the partial dQ tiles to write and
+// to reduce (one 64 x 16 tile per (super-block, query block, head): 0.43 instead of 0.87 GB at 4 x 10k nodes x 8 heads) and half
+// the staging traffic per key; the price is a barrier of 8 waves per query block.  Measured: see DESIGN.md section 4.
+#ifndef DGDM_FUSED_SBW
+#define DGDM_FUSED_SBW 4
+#endif
+
 namespace {
 
+constexpr int SBW = DGDM_FUSED_SBW;
 constexpr float NEG_BIG = -1.0e30f;
 // The transposition tile [key 0..15][query 0..63] of a wave (hi part, lo part).  It is WRITTEN by key rows (lane = key j, 8-byte
 // chunks of 4 queries: a 16-lane store group holds ONE chunk column of 16 rows) and READ transposed (a 32-lane read group holds 8
@@ -102,7 +111,7 @@ __device__ __forceinline__ bool find_sblock(const int32_t* __restrict__ ptr, int
   int64_t pairs = 0;
   for (int g = 0; g < B; ++g) {
     const int a = ptr[g], b = ptr[g + 1];
-    const int nb = (b - a + HB - 1) / HB, nsb = (nb + 3) >> 2;
+    const int nb = (b - a + HB - 1) / HB, nsb = (nb + SBW - 1) / SBW;
     if (sb < sbase + nsb) { *n0 = a; *ng = b - a; *sbl = sb - sbase; *blk0 = base; *sb0 = sbase; *spair0 = pairs; return true; }
     base += nb; sbase += nsb;
     pairs += (int64_t)nsb * nb;
@@ -116,7 +125,7 @@ __device__ __forceinline__ bool find_block_s(const int32_t* __restrict__ ptr, in
   int64_t pairs = 0;
   for (int g = 0; g < B; ++g) {
     const int a = ptr[g], b = ptr[g + 1];
-    const int nb = (b - a + HB - 1) / HB, nsb = (nb + 3) >> 2;
+    const int nb = (b - a + HB - 1) / HB, nsb = (nb + SBW - 1) / SBW;
     if (blk < base + nb) { *n0 = a; *ng = b - a; *lblk = blk - base; *sb0 = sbase; *spair0 = pairs; return true; }
     base += nb; sbase += nsb;
     pairs += (int64_t)nsb * nb;
@@ -128,7 +137,7 @@ __device__ __forceinline__ bool find_block_s(const int32_t* __restrict__ ptr, in
 // the staged query block).  LDS: stage buffer (Rq | Rg | 8 - lse2 | -delta | pos of ONE head) | the four waves' own K row images |
 // T (4 waves) | X[4 waves][64 q][16 d] fp32.
 template <bool DROP, int WPE = 1>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) void k_attn_h_bwd_fused(
+__global__ __launch_bounds__(64 * SBW) __attribute__((amdgpu_waves_per_eu(WPE, 8))) void k_attn_h_bwd_fused(
     const _Float16* __restrict__ Rq, const _Float16* __restrict__ Rk, const _Float16* __restrict__ Rv, const _Float16* __restrict__ Rg,
     const float* __restrict__ pos_b, const float* __restrict__ lse_b, const float* __restrict__ ndelta_b, int H,
     const int32_t* __restrict__ ptr, int B, float kscale, const float* __restrict__ unscale_dev, float* __restrict__ dK,
@@ -138,11 +147,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
   constexpr int NT = HB / 16;
   constexpr int R_BYTES = R_HEAD * 2, SC_BYTES = HB * 4, POS_BYTES = HB * 8;
   constexpr int BUF_BYTES = 2 * R_BYTES + 2 * SC_BYTES + POS_BYTES;
-  constexpr int KOWN_BYTES = 4 * R_BYTES;
-  constexpr int T_BYTES = (DGDM_FUSED_DEFER ? 2 : 1) * 4 * T_WAVE * 2;      // two tiles per wave: the dQ product of key tile kt runs under the score phase of kt + 1
-  constexpr int X_BYTES = 4 * HB * 16 * 4;
+  constexpr int KOWN_BYTES = SBW * R_BYTES;
+  constexpr int T_BYTES = (DGDM_FUSED_DEFER ? 2 : 1) * SBW * T_WAVE * 2;      // two tiles per wave: the dQ product of key tile kt runs under the score phase of kt + 1
+  constexpr int X_BYTES = SBW * HB * 16 * 4;
   constexpr int STG_BYTES = DGDM_FUSED_NBUF * BUF_BYTES;
+#if DGDM_FUSED_SBW > 4
+  extern __shared__ __attribute__((aligned(16))) char smem[];      // 105 KB: beyond the static limit, sized by the launch (fused_lds_bytes)
+#else
   __shared__ __attribute__((aligned(16))) char smem[STG_BYTES + KOWN_BYTES + T_BYTES + X_BYTES];
+#endif
   const DropCfg dc(drop_p);
 
   int n0, ng, sbl, blk0, sb0;
@@ -152,12 +165,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
   const int head = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, G = lane >> 4;
-  const int lblk_w = 4 * sbl + wave;                       // this wave's key block inside the graph ...
+  const int lblk_w = SBW * sbl + wave;                       // this wave's key block inside the graph ...
   const bool blk_ok = lblk_w < nbg;                        // ... which the graph's last super-block may not have
   const int lblk = blk_ok ? lblk_w : nbg - 1;              // (such a wave runs on the last block with every key masked: it takes part
   const int blk = blk0 + lblk;                             //  in the barriers and the cross-wave stage, contributes zeros, stores nothing)
 
   auto stage = [&](int qb) {
+    if (SBW > 4 && wave >= 4) return;       // dma_to_lds hands the 1 KiB pieces to waves 0 .. 3
     const int64_t gb = (int64_t)(blk0 + qb) * H + head;
     char* base = smem + (DGDM_FUSED_NBUF == 2 ? (qb & 1) * BUF_BYTES : 0);
     dma_to_lds<R_BYTES>(Rq + gb * R_HEAD, base, tid);
@@ -370,13 +384,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
     __syncthreads();      // everyone is done with the staged block; every wave's dQ tile (its 64 keys) is in X
     if (DGDM_FUSED_NBUF == 1 && qb + 1 < nbg) stage(qb + 1);
     if (!(DGDM_FUSED_SKIP & 6)) {   // ... and while the next block's DMA is in flight: the four waves' tiles summed (fixed order) and stored
-      const int q = tid >> 2, d4 = tid & 3;
+      const int q = (tid & 255) >> 2, d4 = tid & 3;
       const float* xs = X + q * 16 + 4 * (d4 ^ x_swz(q));
       const f32x4 a0 = *reinterpret_cast<const f32x4*>(xs), a1 = *reinterpret_cast<const f32x4*>(xs + HB * 16);
       const f32x4 a2 = *reinterpret_cast<const f32x4*>(xs + 2 * HB * 16), a3 = *reinterpret_cast<const f32x4*>(xs + 3 * HB * 16);
-      const f32x4 sum = (a0 + a1) + (a2 + a3);
+      f32x4 sum = (a0 + a1) + (a2 + a3);
+      if (SBW == 8) {      // the second four waves' tiles, same association
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(xs + 4 * HB * 16), b1 = *reinterpret_cast<const f32x4*>(xs + 5 * HB * 16);
+        const f32x4 b2 = *reinterpret_cast<const f32x4*>(xs + 6 * HB * 16), b3 = *reinterpret_cast<const f32x4*>(xs + 7 * HB * 16);
+        sum += (b0 + b1) + (b2 + b3);
+      }
       float* o = dq_part + (((slot0 + qb) * H + head) * HB + q) * 16 + 4 * d4;        // [slot][head][64 q][16 d]
-      if (!(DGDM_FUSED_SKIP & 1)) *reinterpret_cast<f32x4*>(o) = sum;
+      if (!(DGDM_FUSED_SKIP & 1) && tid < 256) *reinterpret_cast<f32x4*>(o) = sum;
       else if (sum[0] == 123.456f) dq_part[0] = sum[1];
     }
     // closing barrier: the next block's DMA has landed and every wave has read X.  The partial-tile store was issued AFTER this wave's
@@ -415,7 +434,7 @@ __global__ __launch_bounds__(256) void k_attn_dq_reduce(const float* __restrict_
   int n0, ng, lblk, sb0;
   int64_t spair0;
   if (!find_block_s(ptr, B, blockIdx.x, &n0, &ng, &lblk, &sb0, &spair0)) return;
-  const int nbg = (ng + HB - 1) / HB, nsb = (nbg + 3) >> 2;
+  const int nbg = (ng + HB - 1) / HB, nsb = (nbg + SBW - 1) / SBW;
   const int h = blockIdx.y, tid = threadIdx.x, q = tid >> 2, d4 = tid & 3;
   const int lo = max(sb0, sb_first), hi = min(sb0 + nsb, sb_first + sb_count);      // this graph's super-blocks inside the launch
   if (hi <= lo) return;
@@ -453,7 +472,7 @@ static bool sblock_slots_host(const int32_t* ptr_host, int32_t B, int64_t sb_fir
   for (int g = 0; g < B; ++g) {
     const int64_t nb = ((int64_t)ptr_host[g + 1] - ptr_host[g] + HB - 1) / HB;
     if (nb < 0) return false;
-    const int64_t nsb = (nb + 3) / 4;
+    const int64_t nsb = (nb + SBW - 1) / SBW;
     if (f < 0 && sb_first < sbase + nsb) f = pairs + (sb_first - sbase) * nb;
     if (l < 0 && sb_last < sbase + nsb) l = pairs + (sb_last - sbase) * nb + nb;     // one past the last slot of the last super-block
     sbase += nsb;
@@ -502,12 +521,23 @@ extern "C" int dgdm_spatial_attn_h_bwd_fused(const void* Rq, const void* Rk, con
   const float kscale = 0.6931471805599453f;  // Q' carries scale*log2(e): dK = sum dS Q' / log2(e)
   auto h16 = [](const void* p) { return static_cast<const _Float16*>(p); };
   float* part = static_cast<float*>(workspace);
+  // dynamic LDS of the 8-wave form (the 4-wave form declares its 57 KB statically): stage | K images | T | X
+  constexpr int LDS_DYN = SBW > 4 ? DGDM_FUSED_NBUF * (2 * R_HEAD * 2 + 2 * HB * 4 + HB * 8) + SBW * R_HEAD * 2 +
+                                        (DGDM_FUSED_DEFER ? 2 : 1) * SBW * T_WAVE * 2 + SBW * HB * 16 * 4 : 0;
+  if (LDS_DYN > 0) {
+    static int attr = 1;
+    if (attr == 1)
+      attr = (hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_h_bwd_fused<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DYN) == hipSuccess &&
+              hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_h_bwd_fused<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DYN) == hipSuccess)
+                 ? DGDM_OK : DGDM_ERR_LAUNCH;
+    if (attr != DGDM_OK) return attr;
+  }
   if (drop_p > 0.f)
-    hipLaunchKernelGGL((k_attn_h_bwd_fused<true, 2>), dim3(sb_count, H), dim3(256), 0, s, h16(Rq), h16(Rk), h16(Rv), h16(Rg), pos_b,
+    hipLaunchKernelGGL((k_attn_h_bwd_fused<true, 2>), dim3(sb_count, H), dim3(64 * SBW), LDS_DYN, s, h16(Rq), h16(Rk), h16(Rv), h16(Rg), pos_b,
                        lse_adj_b, ndelta_b, H, ptr, B, kscale, grad_scale2, dK, dV, ldg, part, sb_first, sb_count, slot_first, drop_p,
                        dgdm_seed_arg(seed));
   else
-    hipLaunchKernelGGL((k_attn_h_bwd_fused<false, 2>), dim3(sb_count, H), dim3(256), 0, s, h16(Rq), h16(Rk), h16(Rv), h16(Rg), pos_b,
+    hipLaunchKernelGGL((k_attn_h_bwd_fused<false, 2>), dim3(sb_count, H), dim3(64 * SBW), LDS_DYN, s, h16(Rq), h16(Rk), h16(Rv), h16(Rg), pos_b,
                        lse_adj_b, ndelta_b, H, ptr, B, kscale, grad_scale2, dK, dV, ldg, part, sb_first, sb_count, slot_first, 0.f,
                        dgdm_seed_arg(0u));
   return dgdm_launch_status();

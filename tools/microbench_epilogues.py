@@ -39,6 +39,8 @@ for (m, k, n) in shapes:
     norm_k = lambda src, dst: _lib.check(lib.dgdm_rownorm_fwd(src.data_ptr(), res.data_ptr(), gam.data_ptr(), bet.data_ptr(), m, n, 1, 1e-5, 0, 0.0, 0,
                                                               dst.data_ptr(), mean.data_ptr(), rstd.data_ptr(), None, sp()), "norm")
     r = dict(M=m, K=k, N=n)
+    r["act kernel alone"] = round(t(lambda: act_k(y, y2)), 1)
+    r["act_bwd kernel alone"] = round(t(lambda: actb_k(pre, gy, y2)), 1)
     r["gemm"] = round(t(lambda: ops._gemm_rows_img(x, e0, 0, n, b, y, False)), 1)
     r["gemm+act (2 launches)"] = round(t(lambda: (ops._gemm_rows_img(x, e0, 0, n, b, y, False), act_k(y, y2))), 1)
     r["gemm_act (fused)"] = round(t(lambda: ops.gemm_img_act_raw(x, e0, n, b, 1, P, SEED)), 1)
