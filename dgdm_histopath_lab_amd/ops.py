@@ -251,9 +251,26 @@ ATTN_GRAD_TARGET = 0.25
 ATTN_BWD_CONCURRENT = False     # dQ pass on a side stream beside the dK/dV pass (tools/bench_with.py A/B switch)
 ATTN_BWD_FUSED = True           # dQ, dK, dV in one key-stationary pass + a fixed-order reduction of the partial dQ tiles (False: two passes)
 # bytes of partial-dQ scratch per launch of the one-pass backward.  The scratch grows with N^2 * H / 256 * 64 B (0.8 GB at 4 x 10k nodes x
-# 8 heads; 10 GB for one 50k-node graph x 16 heads) and, inside a recorded step, stays in the recording's private pool for good: the
-# budget bounds it (more groups = a few more launches: 86.6 against 85.8 ms per step at configs[3] with two groups, round 4).
-ATTN_BWD_FUSED_BUDGET = 4 << 30
+# 8 heads; 10 GB for one 50k-node graph x 16 heads) and, inside a recorded step, stays in the recording's private pool for good.  Cutting it
+# into groups is not free: every launch re-streams all query blocks and ends in its own partial round of workgroups (configs[3]: one
+# launch 38 ms, three launches of a 4 GiB budget 3 x 14.3 = 43 ms, 77 -> 86 ms per step).  None = min(16 GiB, a quarter of the memory that
+# is free on the device when the backward runs): one launch for every BASELINE configuration on a 288 GB MI355X, smaller groups when
+# the card is shared or nearly full.  An int fixes the budget (tests force several groups with it).
+ATTN_BWD_FUSED_BUDGET = None
+
+
+_ATTN_BUDGET_SEEN: dict = {}
+
+
+def _attn_bwd_budget(device) -> int:
+    if ATTN_BWD_FUSED_BUDGET is not None:
+        return int(ATTN_BWD_FUSED_BUDGET)
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    if torch.cuda.is_current_stream_capturing():      # no runtime query inside a capture: what the eager warm-up steps of the same step saw
+        return _ATTN_BUDGET_SEEN.get(key, 16 << 30)
+    free, _total = torch.cuda.mem_get_info(device)
+    _ATTN_BUDGET_SEEN[key] = b = max(64 << 20, min(16 << 30, free // 4))
+    return b
 _SIDE_STREAMS: dict = {}
 
 
@@ -335,10 +352,11 @@ def spatial_attn_h_bwd_raw(pk: PackedOperands, out, gout, plan: AttnPlan, H: int
         nsb, sb = lib.dgdm_spatial_attn_h_bwd_fused_superblocks(ph, plan.B), 0
         if nsb == 0:              # no keys at all (an empty batch / only empty graphs): nothing to launch, no gradient
             return dqkv.zero_()
+        budget = _attn_bwd_budget(out.device)
         groups = []
         while sb < nsb:
             cnt = nsb - sb
-            while cnt > 1 and lib.dgdm_spatial_attn_h_bwd_fused_workspace_bytes(ph, plan.B, H, sb, cnt) > ATTN_BWD_FUSED_BUDGET:
+            while cnt > 1 and lib.dgdm_spatial_attn_h_bwd_fused_workspace_bytes(ph, plan.B, H, sb, cnt) > budget:
                 cnt = (cnt + 1) // 2
             groups.append((sb, cnt, lib.dgdm_spatial_attn_h_bwd_fused_workspace_bytes(ph, plan.B, H, sb, cnt)))
             sb += cnt

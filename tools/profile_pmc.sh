@@ -21,5 +21,5 @@ import json
 v = json.load(open("$R/gpurun_out/${TAG}_pmc_valu.json"))["kernels"]
 t = json.load(open("$R/gpurun_out/${TAG}_pmc_traffic.json"))["kernels"]
 for k in list(v)[:8]:
-    print(k, {a: v[k][a] for a in ("valu_busy", "mfma_busy", "valu_insts_per_launch", "occupancy_waves_per_simd")}, t.get(k, {}).get("hbm_bytes_per_launch"))
+    print(k, {a: v[k][a] for a in ("valu_busy", "mfma_busy", "valu_insts_per_launch", "occupancy_waves_per_simd")}, t.get(k, {}).get("fabric_bytes_per_launch"))
 PY
