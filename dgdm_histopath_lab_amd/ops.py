@@ -249,6 +249,10 @@ class PackedOperands:
 # dS' = P' (keep dP - delta) stay ~4x further from fp16's maximum than round 2's (target 256, P unscaled) did
 ATTN_GRAD_TARGET = 0.25
 ATTN_BWD_CONCURRENT = False     # dQ pass on a side stream beside the dK/dV pass (tools/bench_with.py A/B switch)
+# Round 5 experiment: the weight-gradient GEMMs that are already queued when the backward reaches the attention (diffusion, U-Net,
+# out_proj: ~35 of the 50 problems of a step) are launched on a side stream BEHIND the attention backward in host order, so that
+# their workgroups fill the slots the attention kernel's last, partial round of workgroups leaves empty (1 280 workgroups on 512 slots).
+ATTN_BWD_OVERLAP_DW = False
 ATTN_BWD_FUSED = True           # dQ, dK, dV in one key-stationary pass + a fixed-order reduction of the partial dQ tiles (False: two passes)
 # bytes of partial-dQ scratch per launch of the one-pass backward.  The scratch grows with N^2 * H / 256 * 64 B (0.8 GB at 4 x 10k nodes x
 # 8 heads; 10 GB for one 50k-node graph x 16 heads) and, inside a recorded step, stays in the recording's private pool for good.  Cutting it
@@ -345,6 +349,10 @@ def spatial_attn_h_bwd_raw(pk: PackedOperands, out, gout, plan: AttnPlan, H: int
                                             plan.ptr_dev.data_ptr(), plan.B, plan.num_q_tiles, H, drop_p, seed, gs.data_ptr(),
                                             dqkv[:, C:2 * C].data_ptr(), dqkv[:, 2 * C:].data_ptr(), dqkv.stride(0), dkv_variant, stream),
             "dgdm_spatial_attn_h_bwd_dkv")
+    overlap_ev = None
+    if ATTN_BWD_FUSED and ATTN_BWD_OVERLAP_DW and _PENDING_TN and not TIMERS.enabled:
+        overlap_ev = torch.cuda.Event()
+        overlap_ev.record(torch.cuda.current_stream(out.device))       # everything the queued dW GEMMs read exists at this point
     if ATTN_BWD_FUSED:
         # one pass for dQ, dK, dV (csrc/attn_h_bwd_fused.hip): key super-blocks in groups whose partial-dQ scratch stays within the budget
         import ctypes
@@ -371,6 +379,13 @@ def spatial_attn_h_bwd_raw(pk: PackedOperands, out, gout, plan: AttnPlan, H: int
             TIMERS.timed("attn_bwd_dq_reduce", lambda: _lib.check(lib.dgdm_spatial_attn_h_bwd_fused_reduce(
                 plan.ptr_dev.data_ptr(), ph, plan.B, plan.num_q_tiles, H, scale, gs.data_ptr(), dqkv[:, :C].data_ptr(), dqkv.stride(0), sb0, cnt,
                 ws.data_ptr(), ws.numel() * 4, st), "dgdm_spatial_attn_h_bwd_fused_reduce"))
+        if overlap_ev is not None:
+            cur, side = torch.cuda.current_stream(out.device), _side_stream(out.device)
+            side.wait_event(overlap_ev)
+            with torch.cuda.stream(side):
+                held = flush_deferred_tn(on_stream=_lib.stream_ptr(out.device))
+            cur.wait_stream(side)          # join at once: whatever follows is ordered behind the dW launches (and may reuse their memory)
+            del held
     elif ATTN_BWD_CONCURRENT and not TIMERS.enabled:
         # the two passes are independent (dQ | dK, dV: disjoint columns of dqkv) and each leaves the chip partly empty in its last
         # round of workgroups (1256 / 2512 workgroups on 512 / 768 resident slots): side by side the one fills the other's tail.
@@ -1484,13 +1499,18 @@ def _claim_deferred(*params) -> bool:
     return True
 
 
-def flush_deferred_tn() -> None:
-    """Run the held-back dW GEMMs (many-problem launches) and reduce every pending GEMM's chunk partials, all in fixed order."""
+def flush_deferred_tn(on_stream: Optional[int] = None):
+    """Run the held-back dW GEMMs (many-problem launches) and reduce every pending GEMM's chunk partials, all in fixed order.
+    ``on_stream``: launch everything on this stream instead of the streams the problems were queued on (the caller orders it behind
+    their producers and in front of their consumers); the problems' keep-alive references are then RETURNED -- the caller holds them
+    until the join has been enqueued (their memory belongs to the producers' stream)."""
     if not _PENDING_TN:
-        return
+        return None
     lib = _lib.load()
     pend = list(_PENDING_TN)
     _PENDING_TN.clear()
+    if on_stream is not None:
+        pend = [(desc, keep, on_stream, partial) for desc, keep, _s, partial in pend]
     if not _DEFER_TN:
         _DEFER_CLAIMED.clear()
     # on the stream each GEMM's partials were launched on (the engine's end-of-pass callback may run under another current stream
@@ -1518,6 +1538,7 @@ def flush_deferred_tn() -> None:
             for j, desc in enumerate(part):
                 arr[j] = _lib.TnReduce(*desc)
             _lib.check(lib.dgdm_gemm_tn_reduce_many(arr, len(part), stream), "dgdm_gemm_tn_reduce_many")
+    return [keep for _d, keep, _s, _p in pend] if on_stream is not None else None
 
 
 def _defer_tn(desc, keep, stream, partial=None) -> bool:
