@@ -323,12 +323,33 @@ def spawn_ranks(n, argv):
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__), *argv]
-    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)     # stderr is inherited: progress and errors stay visible
+    # (own session: if the ranks hang -- a collective that never completes -- the whole group can be ended; stderr is inherited:
+    # progress and errors stay visible)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True, start_new_session=True)
+    limit = float(os.environ.get("DGDM_BENCH_RANK_TIMEOUT", "1500"))
+    import threading
+    timed_out = []
+
+    def _expire():
+        timed_out.append(True)
+        print(f"bench.py: the {n} ranks did not finish within {limit:.0f} s (DGDM_BENCH_RANK_TIMEOUT); ending them", file=sys.stderr, flush=True)
+        try:
+            os.killpg(proc.pid, 15)
+            time.sleep(10)
+            os.killpg(proc.pid, 9)
+        except ProcessLookupError:
+            pass
+    timer = threading.Timer(limit, _expire)
+    timer.daemon = True
+    timer.start()
     lines = []
     for ln in proc.stdout:
         if ln.strip():
             lines.append(ln.rstrip("\n"))
     rc = proc.wait()
+    timer.cancel()
+    if timed_out:
+        rc = rc or 124
     result = [ln for ln in lines if ln.lstrip().startswith("{")]
     for ln in lines:                 # anything a rank printed beside the result goes to stderr: stdout carries ONE line
         if not result or ln is not result[-1]:
