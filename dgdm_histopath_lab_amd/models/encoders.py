@@ -121,7 +121,7 @@ class GraphEncoder(nn.Module):
         for i, (layer, norm) in enumerate(zip(self.graph_layers, self.norm_layers)):
             h = layer(h, ctx)
             aid = ops.act_id(self.activation)
-            if str(i) in self.dim_proj and isinstance(norm, nn.LayerNorm) and aid is not None:
+            if str(i) in self.dim_proj and isinstance(norm, nn.LayerNorm) and aid is not None and ops.row_norm_supported(norm.normalized_shape[0], 1):
                 dp = self.dim_proj[str(i)]      # Linear -> LayerNorm -> act -> dropout: the norm as the GEMM's epilogue where it fits
                 h = ops.linear_norm(h, dp.weight, dp.bias, norm.weight, norm.bias, eps=norm.eps, act=aid, drop_p=self.dropout.p,
                                     training=self.training)
