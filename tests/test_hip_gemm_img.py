@@ -169,7 +169,7 @@ def _operands(m, k, n, seed):
 
 
 @pytest.mark.parametrize("m,k,n", [(1000, 160, 128), (4100, 544, 512), (300, 288, 256), (257, 64, 36), (40000, 160, 128), (2049, 128, 384)])
-@pytest.mark.parametrize("act,p", [(1, 0.1), (1, 0.0), (3, 0.25), (2, 0.1), (0, 0.5)])
+@pytest.mark.parametrize("act,p", [(1, 0.1), (1, 0.0), (3, 0.25), (2, 0.1), (0, 0.5), (4, 0.1)])
 def test_act_epilogue_is_the_gemm_followed_by_the_activation_kernel(m, k, n, act, p):
     """dgdm_gemm_rows_img_act (core/graph_layers.py:233-239, dropout(GELU(conv(x))) as the GEMM's epilogue) against the two launches
     it replaces: the stored pre-activation equals the plain GEMM's output to fp32 rounding, the output is dgdm_act_dropout_fwd of
@@ -197,7 +197,7 @@ def test_act_epilogue_is_the_gemm_followed_by_the_activation_kernel(m, k, n, act
 
 
 @pytest.mark.parametrize("m,k,n", [(1000, 128, 128), (4100, 512, 512), (300, 256, 256), (40000, 128, 128), (2049, 384, 128)])
-@pytest.mark.parametrize("act,p", [(1, 0.1), (1, 0.0), (3, 0.25), (2, 0.1)])
+@pytest.mark.parametrize("act,p", [(1, 0.1), (1, 0.0), (3, 0.25), (2, 0.1), (4, 0.1)])
 def test_act_backward_epilogue_is_the_gemm_followed_by_the_activation_backward(m, k, n, act, p):
     """dgdm_gemm_rows_img_act_bwd: G = (dY . W) * act'(pre) * mask from one launch, against dgdm_gemm_rows_img followed by
     dgdm_act_dropout_bwd (same derivative code, same mask)."""

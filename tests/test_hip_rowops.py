@@ -7,13 +7,13 @@ from conftest import assert_close
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-ACTS = {0: lambda z: z, 1: F.gelu, 2: F.relu, 3: F.silu}
+ACTS = {0: lambda z: z, 1: F.gelu, 2: F.relu, 3: F.silu, 4: F.elu}
 
 
 @pytest.mark.parametrize("n,c,groups,act,with_res", [
     (1000, 512, 1, 1, False), (777, 256, 1, 0, True), (5, 128, 1, 1, False), (4001, 128, 1, 0, True), (300, 48, 1, 2, False),
     (4000, 512, 8, 3, False), (4000, 256, 8, 3, False), (33, 128, 8, 3, False), (64, 64, 8, 3, True), (10, 32, 8, 3, False),
-    (50, 768, 1, 1, False), (9, 1024, 1, 0, False), (20000, 128, 1, 1, True)])
+    (50, 768, 1, 1, False), (9, 1024, 1, 0, False), (20000, 128, 1, 1, True), (1500, 256, 1, 4, False), (700, 512, 1, 4, True)])
 def test_rownorm_forward_backward(n, c, groups, act, with_res):
     from dgdm_histopath_lab_amd import ops
     g = torch.Generator().manual_seed(n + c)
@@ -66,7 +66,7 @@ def test_rownorm_dropout_statistics_and_backward_mask():
     assert torch.isfinite(g1).all()
 
 
-@pytest.mark.parametrize("act", [0, 1, 2, 3])
+@pytest.mark.parametrize("act", [0, 1, 2, 3, 4])
 def test_act_dropout(act):
     from dgdm_histopath_lab_amd import ops
     g = torch.Generator().manual_seed(act)
@@ -98,7 +98,7 @@ def test_segment_bcast_add_and_sum():
         assert_close(sd.grad, torch.zeros(4, c, dtype=torch.float64).index_add_(0, seg, gy.double()), 1e-5, "segment sum")
 
 
-@pytest.mark.parametrize("H,D,ptr", [(8, 16, [0, 9, 700, 1233]), (4, 8, [0, 9, 700, 1233]), (2, 32, [0, 9, 700, 1233]), (1, 4, [0, 9, 700, 1233]),
+@pytest.mark.parametrize("H,D,ptr", [(8, 16, [0, 9, 700, 1233]), (4, 8, [0, 9, 700, 1233]), (2, 32, [0, 9, 700, 1233]), (2, 64, [0, 9, 700, 1233]), (1, 4, [0, 9, 700, 1233]),
                                      (8, 16, [0, 5000, 5003, 12345]), (4, 16, [0, 512, 1024, 1025])])
 def test_attn_pool_matches_dense(H, D, ptr):
     """Graphs of a few nodes, of exactly one / two 512-node chunks and of many chunks (the forward combines chunk records)."""
