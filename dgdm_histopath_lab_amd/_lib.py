@@ -62,6 +62,9 @@ SIGNATURES = {
     "dgdm_segment_bcast_add": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _p, _p]),
     "dgdm_segment_sum_workspace_bytes": (_sz, [_i32, _i32]),
     "dgdm_segment_sum": (C.c_int, [_p, _p, _i32, _i32, _p, _p, _sz, _p]),
+    "dgdm_colnorm_workspace_bytes": (_sz, [_i32, _i32]),
+    "dgdm_colnorm_fwd": (C.c_int, [_p, _i32, _i32, _p, _p, _p, _p, _i32, C.c_float, C.c_float, _i32, C.c_float, C.c_uint32, _p, _p, _p, _p, _sz, _p, _p]),
+    "dgdm_colnorm_bwd": (C.c_int, [_p, _p, _i32, _i32, _p, _p, _p, _p, _i32, _i32, C.c_float, C.c_uint32, _p, _p, _p, _p, _sz, _p, _p]),
     "dgdm_segment_max_workspace_bytes": (_sz, [_i32, _i32]),
     "dgdm_segment_max_fwd": (C.c_int, [_p, _i64, _p, _i32, _i32, _p, _p, _p, _sz, _p]),
     "dgdm_segment_max_bwd": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _p, _p]),

@@ -33,8 +33,9 @@ def _norm_act_dropout(h: Tensor, norm: nn.Module, act: nn.Module, drop: nn.Dropo
     activations (ReLU / GELU / ELU, encoders.py:57-62).  ``nn.InstanceNorm1d(dim)`` on a 2-D ``[N, dim]`` input (encoders.py:95-100
     builds it with the defaults affine=False, track_running_stats=False) treats the rows as the channels of ONE unbatched sample and
     normalises each row over its ``dim`` entries: a LayerNorm without affine parameters -- the row kernel with gamma = 1, beta = 0.
-    ``nn.BatchNorm1d`` (statistics over the NODES of the batch, running averages in eval mode) stays torch's own module -- an ATen
-    kernel, documented in DESIGN.md 1 -- followed by the fused activation + dropout kernel; Identity: that kernel alone."""
+    ``nn.BatchNorm1d`` (statistics over the NODES of the batch, running averages in eval mode): the column-norm kernels of
+    csrc/colnorm.hip, activation and dropout included (``ops.batch_norm``: the module keeps its parameters, running statistics and
+    ``state_dict`` keys); Identity: the activation + dropout kernel alone."""
     aid = ops.act_id(act)
     if aid is not None and ops.row_norm_supported(h.size(1), 1):
         if isinstance(norm, nn.LayerNorm):
@@ -43,6 +44,8 @@ def _norm_act_dropout(h: Tensor, norm: nn.Module, act: nn.Module, drop: nn.Dropo
             one = ops.device_constant([1.0] * h.size(1), torch.float32, h.device)
             zero = ops.device_constant([0.0] * h.size(1), torch.float32, h.device)
             return ops.row_norm(h, one, zero, eps=norm.eps, act=aid, drop_p=drop.p, training=training)
+    if aid is not None and isinstance(norm, nn.BatchNorm1d) and ops.batch_norm_supported(norm, h):
+        return ops.batch_norm(h, norm, aid, drop.p, training)
     h = norm(h)
     if aid is not None and h.numel() % 4 == 0:
         return ops.act_dropout(h, aid, drop.p, training)

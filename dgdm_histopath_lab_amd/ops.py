@@ -715,6 +715,65 @@ def row_norm(x, weight, bias, *, res=None, groups: int = 1, eps: float = 1e-5, a
     return _RowNorm.apply(x, res, weight, bias, groups, eps, act, p, next_dropout_seed() if p > 0 else 0)
 
 
+class _ColNorm(torch.autograd.Function):
+    """nn.BatchNorm1d over the nodes of a batch + activation + dropout (csrc/colnorm.hip; models/encoders.py:95-100,211-219 with
+    normalization="batch").  ``running_mean`` / ``running_var`` are updated in place in training mode, as the module does."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training: bool, momentum: float, eps: float, act: int, drop_p: float, seed: int):
+        lib = _lib.load()
+        x, gamma, beta = _f32c(x), _f32c(gamma), _f32c(beta)
+        _lib.require_cuda(x, gamma, beta, running_mean, running_var)
+        N, C = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty(C, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        wsb = _lib.workspace_bytes("dgdm_colnorm_workspace_bytes", N, C)
+        ws = torch.empty(max(wsb, 4) // 4, dtype=torch.float32, device=x.device)
+        slot = new_amax_slot(x.device)
+        _lib.check(lib.dgdm_colnorm_fwd(x.data_ptr(), N, C, gamma.data_ptr(), beta.data_ptr(), _lib.ptr(running_mean), _lib.ptr(running_var),
+                                        int(training), momentum, eps, act, drop_p, seed, y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), ws.data_ptr(),
+                                        wsb, slot, _lib.stream_ptr(x.device)), "dgdm_colnorm_fwd")
+        ctx.save_for_backward(x, gamma, beta, mean, rstd)
+        ctx.meta = (bool(training), act, drop_p, seed)
+        return tag_amax(y, slot)
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.load()
+        x, gamma, beta, mean, rstd = ctx.saved_tensors
+        training, act, drop_p, seed = ctx.meta
+        gy = _f32c(gy)
+        N, C = x.shape
+        dx = torch.empty_like(x)
+        dg, db = torch.empty_like(gamma), torch.empty_like(beta)
+        wsb = _lib.workspace_bytes("dgdm_colnorm_workspace_bytes", N, C)
+        ws = torch.empty(max(wsb, 4) // 4, dtype=torch.float32, device=x.device)
+        slot = new_amax_slot(x.device)
+        _lib.check(lib.dgdm_colnorm_bwd(x.data_ptr(), gy.data_ptr(), N, C, gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                        int(training), act, drop_p, seed, dx.data_ptr(), dg.data_ptr(), db.data_ptr(), ws.data_ptr(), wsb, slot,
+                                        _lib.stream_ptr(x.device)), "dgdm_colnorm_bwd")
+        return tag_amax(dx, slot), dg, db, None, None, None, None, None, None, None, None
+
+
+def batch_norm_supported(bn, x) -> bool:
+    return (bn.affine and bn.track_running_stats and bn.momentum is not None and x.dim() == 2 and x.is_cuda and x.dtype == torch.float32
+            and x.size(1) % 4 == 0 and x.size(0) > 0)
+
+
+def batch_norm(x, bn, act: int = ACT_NONE, drop_p: float = 0.0, training: bool = False):
+    """dropout(act(bn(x))) for an ``nn.BatchNorm1d`` module ``bn`` on a 2-D node matrix; the module's running statistics and
+    ``num_batches_tracked`` advance in training mode as they do in ``bn.forward``."""
+    p = float(drop_p) if training else 0.0
+    use_batch = bool(bn.training)
+    if use_batch and x.size(0) < 2:
+        raise ValueError("Expected more than 1 value per channel when training")       # torch's message for a one-row batch
+    if use_batch:
+        bn.num_batches_tracked.add_(1)
+    return _ColNorm.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, use_batch, float(bn.momentum), float(bn.eps), act, p,
+                          next_dropout_seed() if p > 0 else 0)
+
+
 def _decide_arg(decide, like: torch.Tensor):
     """Kink decisions for the ReLU kernels (include/dgdm_hip.h, `decide`): uint8 [N, C] contiguous on the device, or None."""
     if decide is None:

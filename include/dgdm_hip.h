@@ -393,6 +393,21 @@ DGDM_API int dgdm_segment_bcast_add(const float* x, const float* src, const int3
 DGDM_API size_t dgdm_segment_sum_workspace_bytes(int32_t B, int32_t C);
 DGDM_API int dgdm_segment_sum(const float* x, const int32_t* ptr, int32_t B, int32_t C, float* out, void* workspace,
                               size_t workspace_bytes, void* stream);
+/* Column norm = nn.BatchNorm1d over the NODES of a batch, fused with the activation + dropout behind it (csrc/colnorm.hip):
+ *   y = dropout(act((x - mean_c) rstd_c gamma_c + beta_c)),  x, y [N, C] contiguous, C % 4 == 0.
+ * The reference builds it for normalization="batch" (models/encoders.py:95-100,211-219).  training != 0: statistics of the batch
+ * (biased variance), running_mean / running_var (nullable) updated in place with `momentum` (unbiased variance), as torch does;
+ * training == 0: the running averages are the statistics.  mean / rstd [C] are outputs (the backward reads them).  The backward
+ * writes dx [N, C], dgamma, dbeta [C].  workspace: dgdm_colnorm_workspace_bytes(N, C) for both.  Fixed summation order
+ * (bitwise repeatable); the dropout mask is the (seed, element index) function of dgdm_act_dropout_*. */
+DGDM_API size_t dgdm_colnorm_workspace_bytes(int32_t N, int32_t C);
+DGDM_API int dgdm_colnorm_fwd(const float* x, int32_t N, int32_t C, const float* gamma, const float* beta, float* running_mean,
+                              float* running_var, int32_t training, float momentum, float eps, int32_t act, float drop_p, uint32_t seed,
+                              float* y, float* mean, float* rstd, void* workspace, size_t workspace_bytes, uint32_t* amax, void* stream);
+DGDM_API int dgdm_colnorm_bwd(const float* x, const float* dy, int32_t N, int32_t C, const float* gamma, const float* beta, const float* mean,
+                              const float* rstd, int32_t training, int32_t act, float drop_p, uint32_t seed, float* dx, float* dgamma,
+                              float* dbeta, void* workspace, size_t workspace_bytes, uint32_t* amax, void* stream);
+
 /* Segment max (GlobalMaxPool, models/dgdm_model.py:570-585: out[g] = x[batch == g].max(dim=0)[0]): out [B, C] and arg [B, C] (the
  * row that attains the maximum, the first one on ties; -1 and out = 0 for a graph without rows).  The backward writes the whole
  * dx [N, C]: gout[g][c] at row arg[g][c], zero elsewhere (torch.max(dim)'s gradient).  Any C; x rows at stride ldx. */

@@ -20,8 +20,8 @@ DEV = "cuda:0"
 def test_feature_encoder_options_match_reference_golden(tag, act, norm, mode):
     """The product FeatureEncoder built with the reference's non-default arguments, the reference's weights loaded with
     strict=True (BatchNorm1d buffers included; InstanceNorm1d has no parameters), against the reference's own outputs and
-    gradients.  ELU / ReLU and the instance norm run on this library's row kernels (csrc/rownorm.hip, elementwise.hip); BatchNorm1d
-    is torch's module (ATen), followed by the fused activation kernel."""
+    gradients.  ELU / ReLU and the instance norm run on this library's row kernels (csrc/rownorm.hip, elementwise.hip), BatchNorm1d
+    with its activation on the column-norm kernels (csrc/colnorm.hip)."""
     from dgdm_histopath_lab_amd.models.encoders import FeatureEncoder
     g = load_golden(f"g10_feature_encoder_{tag}_{mode}")
     fe = FeatureEncoder(48, 32, dropout=0.0, activation=act, normalization=norm)
@@ -133,3 +133,48 @@ def test_set2set_pooling_is_the_mean_as_in_the_reference():
     pool = GlobalSet2SetPool(32).to(DEV)
     assert torch.equal(pool(x, batch), GlobalMeanPool()(x, batch))
     assert_close(pool(x, batch), g["out"], 1e-6, "set2set == mean")
+
+
+@pytest.mark.parametrize("n,c", [(37, 32), (3000, 512), (40000, 128), (257, 36)])
+@pytest.mark.parametrize("act,p", [(0, 0.0), (2, 0.0), (4, 0.0), (1, 0.2)])
+def test_column_norm_is_batchnorm1d_with_activation(n, c, act, p):
+    """dgdm_colnorm_* (nn.BatchNorm1d over the nodes of a batch + activation + dropout, models/encoders.py:95-100 with
+    normalization="batch") against torch's own module in float64 on the CPU: training mode (batch statistics; running averages and
+    num_batches_tracked advance exactly as the module's), eval mode (running averages), outputs, input / affine gradients; with
+    dropout the mask is taken from the kernels' own (seed, element index) function (dgdm_act_dropout_fwd on ones)."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from dgdm_histopath_lab_amd import _lib, ops
+    acts = {0: lambda z: z, 1: F.gelu, 2: F.relu, 4: F.elu}
+    g = torch.Generator().manual_seed(n + c + act)
+    x = torch.randn(n, c, generator=g) * 1.7 + 0.4
+    gy = torch.randn(n, c, generator=g)
+    ref = nn.BatchNorm1d(c).double()
+    with torch.no_grad():
+        ref.weight.copy_(1 + 0.3 * torch.randn(c, generator=g)); ref.bias.copy_(0.2 * torch.randn(c, generator=g))
+        ref.running_mean.copy_(0.1 * torch.randn(c, generator=g)); ref.running_var.copy_(1 + 0.2 * torch.rand(c, generator=g))
+    own = nn.BatchNorm1d(c)
+    own.load_state_dict({k: (v.float() if v.is_floating_point() else v) for k, v in ref.state_dict().items()})
+    own = own.to(DEV)
+    for mode in ("train", "eval"):
+        ref.train(mode == "train"); own.train(mode == "train")
+        ref.zero_grad(); own.zero_grad()
+        ops._seed_counter = 500
+        xd = x.to(DEV).requires_grad_(True)
+        y = ops.batch_norm(xd, own, act, p, mode == "train")
+        mask = 1.0
+        if p > 0 and mode == "train":
+            seed = (torch.initial_seed() * 0x9E3779B1 + 501 * 0x85EBCA6B) & 0xFFFFFFFF
+            ones, m = torch.ones(n * c, device=DEV), torch.empty(n * c, device=DEV)
+            _lib.check(_lib.load().dgdm_act_dropout_fwd(ones.data_ptr(), n * c, 0, p, seed, m.data_ptr(), None, None, _lib.stream_ptr(ones.device)), "mask")
+            mask = m.view(n, c).cpu().double()
+        xr = x.double().requires_grad_(True)
+        yr = acts[act](ref(xr)) * mask
+        assert_close(y, yr, 2e-5, f"y {mode}")
+        y.backward(gy.to(DEV)); yr.backward(gy.double())
+        assert_close(xd.grad, xr.grad, 5e-5, f"dx {mode}")
+        assert_close(own.weight.grad, ref.weight.grad, 5e-5, f"dgamma {mode}")
+        assert_close(own.bias.grad, ref.bias.grad, 5e-5, f"dbeta {mode}")
+        assert_close(own.running_mean, ref.running_mean, 1e-5, f"running_mean {mode}")
+        assert_close(own.running_var, ref.running_var, 1e-5, f"running_var {mode}")
+        assert int(own.num_batches_tracked) == int(ref.num_batches_tracked)
