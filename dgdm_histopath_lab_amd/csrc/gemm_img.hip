@@ -101,27 +101,32 @@ __device__ unsigned long long* dgdm_stamp_buf;
 #ifndef DGDM_IMG_NARROW_MAX
 #define DGDM_IMG_NARROW_MAX 256
 #endif
-constexpr int NTW = 4;    // 32-column tiles per wave (128 columns)
+// narrow kernel's shape: WM x WN waves per workgroup, NTW 32-column tiles per wave
+#ifndef DGDM_IMG_WM
+#define DGDM_IMG_WM 4
+#define DGDM_IMG_WN 1
+#define DGDM_IMG_NTW 4
+#endif
 constexpr int CPS = 2;    // 32-k chunks per LDS stage (64 k); images are padded to whole stages
 
 // C[M, Ncols] (+)= A[M, K] . B + bias, B = image tiles [t_begin, t_begin + ceil(Ncols / 32)) of an image with T_img tiles per chunk.
 // Workgroup = WM x WN waves; wave (wm, wn) owns rows 32 (WM rowtile + wm) .. +31 and columns 128 (WN colgroup + wn) .. +127.
 // The main loop has no data-dependent branch: a wave always runs its four column tiles (tiles past the end of the matrix
 // multiply whatever the LDS holds and are never stored), A loads past K re-read the row's last float4 (the image is zero there).
-template <int WM, int WN, bool ACCUM, int EPI>
-__global__ __launch_bounds__(64 * WM * WN, 2) void k_gemm_img(const float* __restrict__ A, int64_t lda, int M, int K,
+template <int WM, int WN, int NTW_, bool ACCUM, int EPI>
+__global__ __launch_bounds__(64 * WM * WN, WM * WN > 4 ? 1 : 2) void k_gemm_img(const float* __restrict__ A, int64_t lda, int M, int K,
                                                             const char* __restrict__ img, int T_img, int t_begin, int Ncols,
                                                             const float* __restrict__ bias, float* __restrict__ C, int64_t ldc,
                                                             const unsigned* __restrict__ amax_a, const EpiArgs epi) {
   static_assert(EPI == EPI_NONE || !ACCUM, "the fused epilogues write C, they do not accumulate into it");
   constexpr bool TR = EPI != EPI_NONE;
-  constexpr int WAVES = WM * WN, NT_WG = NTW * WN, STAGE = CPS * NT_WG * BLK;
+  constexpr int WAVES = WM * WN, NT_WG = NTW_ * WN, STAGE = CPS * NT_WG * BLK;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 * STAGE
   const int tid = threadIdx.x, lane = tid & 63;
   DGDM_STAMP(0)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
-  const int gcol = (Ncols + 128 * WN - 1) / (128 * WN);          // column groups
+  const int gcol = (Ncols + 32 * NTW_ * WN - 1) / (32 * NTW_ * WN);          // column groups
   const int rowtile = blockIdx.x / gcol, colgroup = blockIdx.x % gcol;   // column groups of one row tile run side by side
   const int r0 = (rowtile * WM + wm) * 32;
   const int tiles = (Ncols + 31) >> 5;
@@ -182,9 +187,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_gemm_img(const float* __res
     al[cc_][1] = __builtin_bit_cast(f16x8, l__);                                                                    \
   }
 
-  f32x16 acc[NTW];
+  f32x16 acc[NTW_];
 #pragma unroll
-  for (int t = 0; t < NTW; ++t)
+  for (int t = 0; t < NTW_; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
@@ -195,8 +200,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_gemm_img(const float* __res
     scb = *reinterpret_cast<const float*>(img);
     const float sc2 = sca * scb;
 #pragma unroll
-    for (int t = 0; t < NTW; ++t) {
-      const float* p = C + min(32 * (tg0 + wn * NTW + t) + (lane & 31), Ncols - 1);
+    for (int t = 0; t < NTW_; ++t) {
+      const float* p = C + min(32 * (tg0 + wn * NTW_ + t) + (lane & 31), Ncols - 1);
 #pragma unroll
       for (int r = 0; r < 16; ++r)      // unconditional loads from clamped rows (rows past M are never stored): no branch per element
         acc[t][r] = p[(int64_t)min(r0 + 4 * (lane >> 5) + (r & 3) + 8 * (r >> 2), M - 1) * ldc] * sc2;
@@ -219,22 +224,22 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_gemm_img(const float* __res
     __builtin_amdgcn_s_barrier();
     DGDM_STAMP(2 + (s < 5 ? s : 5))
     if (s + 1 < nst) stage_dma(s + 1, (s + 1) & 1);
-    const char* buf = smem + (s & 1) * STAGE + (wn * NTW) * BLK + lane * 16;
+    const char* buf = smem + (s & 1) * STAGE + (wn * NTW_) * BLK + lane * 16;
     f16x8 ah[CPS][2], al[CPS][2];
     // Four batches b = (cc, j) of 8 fragment reads (4 column tiles x hi / lo) + 12 MFMAs.  The reads of batch b + 1 are issued
     // BEFORE the MFMAs of batch b and pinned there (sched_barrier): left alone, hipcc sinks every read to just in front of its
     // MFMA and the wave eats the LDS latency 16 times per stage.
-    f16x8 bh[2][NTW], bl[2][NTW];
+    f16x8 bh[2][NTW_], bl[2][NTW_];
 #define DGDM_READ_BATCH(b_, slot_)                                                                                  \
   {                                                                                                                 \
     const char* q__ = buf + ((b_) >> 1) * NT_WG * BLK + (2 * ((b_) & 1)) * 1024;                                    \
-    _Pragma("unroll") for (int t = 0; t < NTW; ++t) {                                                               \
+    _Pragma("unroll") for (int t = 0; t < NTW_; ++t) {                                                               \
       bh[slot_][t] = *reinterpret_cast<const f16x8*>(q__ + t * BLK);                                                \
       bl[slot_][t] = *reinterpret_cast<const f16x8*>(q__ + t * BLK + 1024);                                         \
     }                                                                                                               \
   }
 #define DGDM_MFMA_BATCH(b_, slot_)                                                                                  \
-  _Pragma("unroll") for (int t = 0; t < NTW; ++t) {                                                                 \
+  _Pragma("unroll") for (int t = 0; t < NTW_; ++t) {                                                                 \
     acc[t] = mfma_o<TR>(al[(b_) >> 1][(b_) & 1], bh[slot_][t], acc[t]);    /* smaller terms first */                 \
     acc[t] = mfma_o<TR>(ah[(b_) >> 1][(b_) & 1], bl[slot_][t], acc[t]);                                             \
     acc[t] = mfma_o<TR>(ah[(b_) >> 1][(b_) & 1], bh[slot_][t], acc[t]);                                             \
@@ -275,23 +280,23 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_gemm_img(const float* __res
   if (TR) {
     unsigned am = 0;
     const EpiVecGlobal vb{bias, Ncols}, vg{epi.gamma, Ncols}, vbe{epi.beta, Ncols};
-    epilogue_tr<NTW, EPI>(acc, inv, r0 + (lane & 31), M, 32 * (tg0 + wn * NTW), Ncols, vb, vg, vbe, C, ldc, epi, lane >> 5, am, seed_v, pseed_v);
+    epilogue_tr<NTW_, EPI>(acc, inv, r0 + (lane & 31), M, 32 * (tg0 + wn * NTW_), Ncols, vb, vg, vbe, C, ldc, epi, lane >> 5, am, seed_v, pseed_v);
     if (epi.amax_out) dgdm_amax_commit(am, epi.amax_out);   // workgroup-uniform condition: every thread reaches the barrier inside
     return;
   }
   const int jc = lane & 31, hi = lane >> 5;
   const int rbase = r0 + 4 * hi;
 #pragma unroll
-  for (int t = 0; t < NTW; ++t) {
-    const int col = 32 * (tg0 + wn * NTW + t) + jc;
+  for (int t = 0; t < NTW_; ++t) {
+    const int col = 32 * (tg0 + wn * NTW_ + t) + jc;
     const float bv = (bias && col < Ncols) ? bias[col] : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = acc[t][r] * inv + bv;
   }
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int t = 0; t < NTW; ++t) {
-    const int col = 32 * (tg0 + wn * NTW + t) + jc;
+  for (int t = 0; t < NTW_; ++t) {
+    const int col = 32 * (tg0 + wn * NTW_ + t) + jc;
     float* p = C + (int64_t)rbase * ldc + col;
     if (col < Ncols) {
       if (r0 + 32 <= M) {          // wave-uniform: all 32 rows exist
@@ -502,18 +507,18 @@ int launch_img8(hipStream_t s, const float* A, int64_t lda, int M, int K, const 
   return dgdm_launch_status();
 }
 
-template <int WM, int WN, int EPI>
+template <int WM, int WN, int NTW_, int EPI>
 int launch_img(hipStream_t s, const float* A, int64_t lda, int M, int K, const char* img, int T_img, int t_begin, int Ncols,
                const float* bias, float* C, int64_t ldc, int accumulate, const unsigned* amax_a, const EpiArgs& epi) {
-  constexpr int LDS = 2 * CPS * NTW * WN * BLK;
+  constexpr int LDS = 2 * CPS * NTW_ * WN * BLK;
   static int status[2] = {1, 1};
-  auto kern = (EPI == EPI_NONE && accumulate) ? k_gemm_img<WM, WN, EPI == EPI_NONE, EPI> : k_gemm_img<WM, WN, false, EPI>;
+  auto kern = (EPI == EPI_NONE && accumulate) ? k_gemm_img<WM, WN, NTW_, EPI == EPI_NONE, EPI> : k_gemm_img<WM, WN, NTW_, false, EPI>;
   int& st = status[accumulate ? 1 : 0];
   if (st == 1)
     st = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess
              ? DGDM_OK : DGDM_ERR_LAUNCH;
   if (st != DGDM_OK) return st;
-  const int gcol = (Ncols + 128 * WN - 1) / (128 * WN), grow = (M + 32 * WM - 1) / (32 * WM);
+  const int gcol = (Ncols + 32 * NTW_ * WN - 1) / (32 * NTW_ * WN), grow = (M + 32 * WM - 1) / (32 * WM);
   hipLaunchKernelGGL(kern, dim3((unsigned)(gcol * grow)), dim3(64 * WM * WN), LDS, s, A, lda, M, K, img, T_img, t_begin, Ncols, bias, C,
                      ldc, amax_a, epi);
   return dgdm_launch_status();
@@ -574,7 +579,7 @@ extern "C" int dgdm_gemm_rows_img(const float* A, int64_t lda, int32_t M, int32_
     if (r != DGDM_ERR_UNSUPPORTED) return r;
   }
   if (ncols <= DGDM_IMG_NARROW_MAX)
-    return launch_img<4, 1, EPI_NONE>(s, A, lda, M, K, img, image_tiles, tile_begin, ncols, bias, C, ldc, accumulate, amax_a, none);
+    return launch_img<DGDM_IMG_WM, DGDM_IMG_WN, DGDM_IMG_NTW, EPI_NONE>(s, A, lda, M, K, img, image_tiles, tile_begin, ncols, bias, C, ldc, accumulate, amax_a, none);
   return launch_img8<EPI_NONE>(s, A, lda, M, K, img, image_tiles, tile_begin, ncols, bias, C, ldc, accumulate, amax_a, none);
 }
 
@@ -612,7 +617,7 @@ extern "C" int dgdm_gemm_rows_img_act(const float* A, int64_t lda, int32_t M, in
     if (r != DGDM_ERR_UNSUPPORTED) return r;
   }
   if (ncols <= DGDM_IMG_NARROW_MAX)
-    return launch_img<4, 1, EPI_ACT>(s, A, lda, M, K, img, image_tiles, tile_begin, ncols, bias, Y, ldy, 0, amax_a, e);
+    return launch_img<DGDM_IMG_WM, DGDM_IMG_WN, DGDM_IMG_NTW, EPI_ACT>(s, A, lda, M, K, img, image_tiles, tile_begin, ncols, bias, Y, ldy, 0, amax_a, e);
   return launch_img8<EPI_ACT>(s, A, lda, M, K, img, image_tiles, tile_begin, ncols, bias, Y, ldy, 0, amax_a, e);
 }
 
@@ -633,7 +638,7 @@ extern "C" int dgdm_gemm_rows_img_act_bwd(const float* A, int64_t lda, int32_t M
     if (r != DGDM_ERR_UNSUPPORTED) return r;
   }
   if (ncols <= DGDM_IMG_NARROW_MAX)
-    return launch_img<4, 1, EPI_ACTBWD>(s, A, lda, M, K, img, image_tiles, tile_begin, ncols, nullptr, G, ldg, 0, amax_a, e);
+    return launch_img<DGDM_IMG_WM, DGDM_IMG_WN, DGDM_IMG_NTW, EPI_ACTBWD>(s, A, lda, M, K, img, image_tiles, tile_begin, ncols, nullptr, G, ldg, 0, amax_a, e);
   return launch_img8<EPI_ACTBWD>(s, A, lda, M, K, img, image_tiles, tile_begin, ncols, nullptr, G, ldg, 0, amax_a, e);
 }
 
@@ -671,6 +676,6 @@ extern "C" int dgdm_gemm_rows_img_norm(const float* A, int64_t lda, int32_t M, i
     if (r != DGDM_ERR_UNSUPPORTED) return r;
   }
   if (ncols <= DGDM_IMG_NARROW_MAX && e.L <= 128)
-    return launch_img<4, 1, EPI_NORM>(s, A, lda, M, K, img, image_tiles, tile_begin, ncols, bias, Y, ldy, 0, amax_a, e);
+    return launch_img<4, 1, 4, EPI_NORM>(s, A, lda, M, K, img, image_tiles, tile_begin, ncols, bias, Y, ldy, 0, amax_a, e);
   return launch_img8<EPI_NORM>(s, A, lda, M, K, img, image_tiles, tile_begin, ncols, bias, Y, ldy, 0, amax_a, e);
 }
