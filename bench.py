@@ -384,6 +384,10 @@ def main():
     ap.add_argument("--large", action="store_true",
                     help="BASELINE configs[3] instead of the headline: the Large model (hidden 1024/512/256, 16 heads, T=20) on 50k-node / "
                          "300k-edge graphs, 1 graph per GPU unless --batch is given; reported under config.workload")
+    ap.add_argument("--pixel-positions", type=float, default=0.0, metavar="PITCH",
+                    help="NOT the headline: replace the synthetic positions (U[0,1)^2, BASELINE's) by patch centres of a slide scanned row "
+                         "by row at PITCH pixels (what the reference's preprocessing stores); with temperature 1 all but a band of the "
+                         "attention's block pairs are exact zeros and the zero-block map walks them over; reported under config.workload")
     ap.add_argument("--sustain-seconds", type=float, default=6.0,
                     help="N=1 only: after the timed K steps, keep replaying the same step for this many seconds and report the rate as "
                          "`sustained` (steady-state clocks; also gives an external GPU-activity sampler a window of pure GPU work well "
@@ -467,6 +471,12 @@ def main():
     # rank r owns slides [r*B, (r+1)*B): independent units, no data-path collective
     batch = synthetic_batch(rank * args.batch, args.batch, args.nodes, args.edges, FEATS).to(dev)
     sizes = [args.nodes] * args.batch
+    if args.pixel_positions > 0:
+        import math as _m
+        w = int(_m.ceil(_m.sqrt(args.nodes)))
+        i = torch.arange(args.nodes, device=dev)
+        one = torch.stack([(i % w).float(), (i // w).float()], 1) * args.pixel_positions
+        batch.pos = one.repeat(args.batch, 1).contiguous()
     stream, balance_note = None, None
     if args.mixed:
         # BASELINE configs[4]: per step a global pool of world x batch graphs with N ~ U{1k..10k}, E = 5 N, assigned to ranks by
@@ -709,6 +719,8 @@ def main():
                                     if args.mixed else
                                     f"DGDM-{'Large (configs[3])' if args.large else 'Base'} pretrain_step fwd+bwd+AdamW, batch={args.batch} x {args.nodes}-node/{args.edges}-edge "
                                     f"graphs per GPU, feat={FEATS}, edge_attr=32, T={cfg['num_diffusion_steps']}, heads={cfg['attention_heads']}, ") +
+                                   (f"positions = raster grid at {args.pixel_positions:g}-pixel pitch (NOT the headline's U[0,1)^2), "
+                                    if args.pixel_positions > 0 else "") +
                                    f"{'eval (dropout off)' if args.eval_mode else 'training mode (dropout 0.1)'}",
                        "global_batch": world * args.batch, "parallelism": f"dp{world}", "final_loss": round(loss_val, 5),
                        "launch": (graph_note or "HIP graph replay (training.GraphedPretrainStep)") if graphed else (graph_note or "eager"),

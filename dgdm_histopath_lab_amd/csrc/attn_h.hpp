@@ -149,6 +149,46 @@ __device__ __forceinline__ f16x8 load_tr_pair(const _Float16* __restrict__ rimg_
   return __builtin_bit_cast(f16x8, r);
 }
 
+// ---- blocks whose weights are EXACTLY zero (round 5) ------------------------------------------------------------------------------
+// The reference feeds raw slide coordinates (pixels) into -distance / temperature (preprocessing/tissue_graph_builder.py:381-384,
+// core/attention.py:261-283): two patches a few hundred pixels apart get exp(-hundreds) = 0.0f in fp32, i.e. on real slides all but a
+// band of (query block, key block) pairs contribute exact zeros.  dgdm_attn_skip_map_build marks a pair "zero" when an upper bound
+// of every score in it (|q'|_max |k|_max - smallest distance between the blocks' bounding boxes) lies more than ZERO_MARGIN
+// (log2 units) below a lower bound of every row maximum of the query block (the row's score with ITSELF: distance 0).  For such a
+// pair every exp2 argument the kernels form is below -150: the weights, and with them every product, are 0.0f -- skipping the
+// pair changes no bit of the result.  Bit k of a row = pair (row's block, k-th block of the same graph) is zero; bits past the
+// graph's last block are set.  One map per FORWARD head group (a pair is skipped only if it is zero for every head of the group).
+#ifndef DGDM_FUSED_SBW
+#define DGDM_FUSED_SBW 4      // 64-key blocks per workgroup of the one-pass backward (attn_h_bwd_fused.hip)
+#endif
+constexpr int ATTN_SBW = DGDM_FUSED_SBW;
+constexpr float ATTN_ZERO_MARGIN = 200.0f;
+__host__ __device__ inline int attn_map_group(int H) { return H % 4 == 0 ? 4 : (H % 2 == 0 ? 2 : 1); }
+__host__ __device__ inline int attn_map_words(int num_blocks) { return 2 * (int)(((int64_t)num_blocks + 63) / 64); }     // words per row (>= any graph's blocks / 32)
+// rows of the map: [0] by query block (bits = key blocks), [1] by key super-block (bits = query blocks; set = zero for all its key blocks)
+__host__ __device__ inline int64_t attn_map_row(int which, int group, int H, int num_blocks, int blk) {
+  return (((int64_t)which * (H / attn_map_group(H)) + group) * num_blocks + blk) * attn_map_words(num_blocks);
+}
+// The live (unmarked) blocks of a row in ascending order, then n for good.  Wave-uniform state in scalar registers; one word of the
+// row is loaded per 32 blocks (a load per block would put a scalar-memory wait -- which also waits for the LDS -- into every
+// iteration of the kernels' loops).  row == nullptr: every block is live.
+struct LiveWalk {
+  const uint32_t* row;
+  int n, base;
+  uint32_t w;
+  __device__ __forceinline__ void init(const uint32_t* __restrict__ r, int n_) { row = r; n = n_; base = 0; w = r ? ~r[0] : 0xffffffffu; }
+  __device__ __forceinline__ int next() {
+    while (w == 0u) {
+      base += 32;
+      if (base >= n) return n;
+      w = row ? ~row[base >> 5] : 0xffffffffu;
+    }
+    const int b = base + __builtin_ctz(w);
+    w &= w - 1u;
+    return b < n ? b : n;
+  }
+};
+
 // Asynchronous copy of BYTES contiguous bytes global -> LDS by a 256-thread workgroup: each wave
 // instruction moves 1 KiB (lane l: 16 B at offset piece*1024 + l*16; LDS destination = wave-uniform
 // base + l*16).  Completion: the issuing wave's vmcnt, then a workgroup barrier (hipcc emits

@@ -53,13 +53,11 @@
 // 512 keys, 105 KB LDS, ONE workgroup of 8 waves per CU -- the same 2 waves per SIMD -- with HALF the partial dQ tiles to write and
 // to reduce (one 64 x 16 tile per (super-block, query block, head): 0.43 instead of 0.87 GB at 4 x 10k nodes x 8 heads) and half
 // the staging traffic per key; the price is a barrier of 8 waves per query block.  Measured: see DESIGN.md section 4.
-#ifndef DGDM_FUSED_SBW
-#define DGDM_FUSED_SBW 4
-#endif
+// (the macro's default, 4, lives in attn_h.hpp: the zero-block map has one row per super-block)
 
 namespace {
 
-constexpr int SBW = DGDM_FUSED_SBW;
+constexpr int SBW = ATTN_SBW;
 constexpr float NEG_BIG = -1.0e30f;
 // The transposition tile [key 0..15][query 0..63] of a wave (hi part, lo part).  It is WRITTEN by key rows (lane = key j, 8-byte
 // chunks of 4 queries: a 16-lane store group holds ONE chunk column of 16 rows) and READ transposed (a 32-lane read group holds 8
@@ -142,7 +140,7 @@ __global__ __launch_bounds__(64 * SBW) __attribute__((amdgpu_waves_per_eu(WPE, 8
     const float* __restrict__ pos_b, const float* __restrict__ lse_b, const float* __restrict__ ndelta_b, int H,
     const int32_t* __restrict__ ptr, int B, float kscale, const float* __restrict__ unscale_dev, float* __restrict__ dK,
     float* __restrict__ dV, int64_t ldg, float* __restrict__ dq_part, int sb_first, int sb_count, int64_t slot_first, float drop_p,
-    DgdmSeed seed_in) {
+    DgdmSeed seed_in, const uint32_t* __restrict__ skip_map, int num_blocks) {
   const uint32_t seed = seed_in.value();
   constexpr int NT = HB / 16;
   constexpr int R_BYTES = R_HEAD * 2, SC_BYTES = HB * 4, POS_BYTES = HB * 8;
@@ -170,10 +168,10 @@ __global__ __launch_bounds__(64 * SBW) __attribute__((amdgpu_waves_per_eu(WPE, 8
   const int lblk = blk_ok ? lblk_w : nbg - 1;              // (such a wave runs on the last block with every key masked: it takes part
   const int blk = blk0 + lblk;                             //  in the barriers and the cross-wave stage, contributes zeros, stores nothing)
 
-  auto stage = [&](int qb) {
+  auto stage = [&](int qb, int b) {
     if (SBW > 4 && wave >= 4) return;       // dma_to_lds hands the 1 KiB pieces to waves 0 .. 3
     const int64_t gb = (int64_t)(blk0 + qb) * H + head;
-    char* base = smem + (DGDM_FUSED_NBUF == 2 ? (qb & 1) * BUF_BYTES : 0);
+    char* base = smem + (DGDM_FUSED_NBUF == 2 ? (b & 1) * BUF_BYTES : 0);
     dma_to_lds<R_BYTES>(Rq + gb * R_HEAD, base, tid);
     dma_to_lds<R_BYTES>(Rg + gb * R_HEAD, base + R_BYTES, tid);
     dma_to_lds<SC_BYTES>(lse_b + gb * HB, base + 2 * R_BYTES, tid);
@@ -193,7 +191,13 @@ __global__ __launch_bounds__(64 * SBW) __attribute__((amdgpu_waves_per_eu(WPE, 8
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + p * 1024 + lane * 16),
                                        (__attribute__((address_space(3))) void*)(l + p * 1024), 16, 0, 0);
   }
-  stage(0);
+  // query blocks whose weights are exactly zero against all of this super-block's keys (every head of the map's group) are walked
+  // over: no staging, no arithmetic, no partial tile (k_attn_dq_reduce consults the same bits)
+  const uint32_t* srow = skip_map ? skip_map + attn_map_row(1, head / attn_map_group(H), H, num_blocks, sb_first + (int)blockIdx.x) : nullptr;
+  LiveWalk live;
+  live.init(srow, nbg);
+  int qb = __builtin_amdgcn_readfirstlane(live.next());
+  if (qb < nbg) stage(qb, 0);
 
   f16x8 vb1[KT], vb2[KT];                 // (keep *) V of the lane's key in key tile kt (K comes out of Kown at every use)
   f32x4 dk[KT], dv[KT];
@@ -225,9 +229,10 @@ __global__ __launch_bounds__(64 * SBW) __attribute__((amdgpu_waves_per_eu(WPE, 8
   const f16x4 zero4 = {zh, zh, zh, zh};
   __syncthreads();
 
-  for (int qb = 0; qb < nbg; ++qb) {
-    if (DGDM_FUSED_NBUF == 2 && qb + 1 < nbg) stage(qb + 1);      // other buffer: every wave left it at the closing barrier of iteration qb - 1
-    const char* base = smem + (DGDM_FUSED_NBUF == 2 ? (qb & 1) * BUF_BYTES : 0);
+  for (int it = 0; qb < nbg; ++it) {
+    const int qb_next = __builtin_amdgcn_readfirstlane(live.next());
+    if (DGDM_FUSED_NBUF == 2 && qb_next < nbg) stage(qb_next, it + 1);      // other buffer: every wave left it at the closing barrier of the iteration before
+    const char* base = smem + (DGDM_FUSED_NBUF == 2 ? (it & 1) * BUF_BYTES : 0);
     const _Float16* Qimg = reinterpret_cast<const _Float16*>(base);
     const _Float16* Gimg = reinterpret_cast<const _Float16*>(base + R_BYTES);
     const float* Ls = reinterpret_cast<const float*>(base + 2 * R_BYTES);
@@ -382,7 +387,7 @@ __global__ __launch_bounds__(64 * SBW) __attribute__((amdgpu_waves_per_eu(WPE, 8
       X[0] = dqp[1][0] + dqp[2][1] + dqp[3][2];      // (diagnostic build: keep the product alive)
     }
     __syncthreads();      // everyone is done with the staged block; every wave's dQ tile (its 64 keys) is in X
-    if (DGDM_FUSED_NBUF == 1 && qb + 1 < nbg) stage(qb + 1);
+    if (DGDM_FUSED_NBUF == 1 && qb_next < nbg) stage(qb_next, 0);
     if (!(DGDM_FUSED_SKIP & 6)) {   // ... and while the next block's DMA is in flight: the four waves' tiles summed (fixed order) and stored
       const int q = (tid & 255) >> 2, d4 = tid & 3;
       const float* xs = X + q * 16 + 4 * (d4 ^ x_swz(q));
@@ -408,6 +413,7 @@ __global__ __launch_bounds__(64 * SBW) __attribute__((amdgpu_waves_per_eu(WPE, 8
 #else
     __syncthreads();
 #endif
+    qb = qb_next;
   }
 
   if (blk_ok) {
@@ -430,7 +436,8 @@ __global__ __launch_bounds__(64 * SBW) __attribute__((amdgpu_waves_per_eu(WPE, 8
 // EARLIER launch (sb0 < sb_first) adds to what that launch left in dQ; one whose graph has none in this launch is left alone.
 __global__ __launch_bounds__(256) void k_attn_dq_reduce(const float* __restrict__ dq_part, const int32_t* __restrict__ ptr, int B, int H,
                                                         int sb_first, int sb_count, int64_t slot_first, float scale,
-                                                        const float* __restrict__ unscale_dev, float* __restrict__ dQ, int64_t ldg) {
+                                                        const float* __restrict__ unscale_dev, float* __restrict__ dQ, int64_t ldg,
+                                                        const uint32_t* __restrict__ skip_map) {
   int n0, ng, lblk, sb0;
   int64_t spair0;
   if (!find_block_s(ptr, B, blockIdx.x, &n0, &ng, &lblk, &sb0, &spair0)) return;
@@ -443,11 +450,29 @@ __global__ __launch_bounds__(256) void k_attn_dq_reduce(const float* __restrict_
   const float* base = dq_part + (((spair0 + lblk - slot_first) * H + h) * HB + q) * 16 + 4 * d4;
   const int64_t stride = (int64_t)nbg * H * HB * 16;
   int sb = lo;
-  for (; sb + 3 < hi; sb += 4) {        // four loads in flight; fixed association
+  if (!skip_map) {
+    for (; sb + 3 < hi; sb += 4) {        // four loads in flight; fixed association
 #pragma unroll
-    for (int u = 0; u < 4; ++u) acc[u] += *reinterpret_cast<const f32x4*>(base + (int64_t)(sb + u - sb0) * stride);
+      for (int u = 0; u < 4; ++u) acc[u] += *reinterpret_cast<const f32x4*>(base + (int64_t)(sb + u - sb0) * stride);
+    }
+    for (; sb < hi; ++sb) acc[0] += *reinterpret_cast<const f32x4*>(base + (int64_t)(sb - sb0) * stride);
+  } else {
+    // a super-block that walked over this query block (all SBW bits of its key blocks set in the block's row of the zero-block map)
+    // wrote no tile; the others are added in the same order and association as above (a tile of zeros would change no bit)
+    const uint32_t* frow = skip_map + attn_map_row(0, h / attn_map_group(H), H, gridDim.x, blockIdx.x);
+    auto live = [&](int s) {
+      const int k0 = SBW * (s - sb0);
+      const uint32_t all = (1u << SBW) - 1u;
+      return ((frow[k0 >> 5] >> (k0 & 31)) & all) != all;
+    };
+    for (; sb + 3 < hi; sb += 4) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (live(sb + u)) acc[u] += *reinterpret_cast<const f32x4*>(base + (int64_t)(sb + u - sb0) * stride);
+    }
+    for (; sb < hi; ++sb)
+      if (live(sb)) acc[0] += *reinterpret_cast<const f32x4*>(base + (int64_t)(sb - sb0) * stride);
   }
-  for (; sb < hi; ++sb) acc[0] += *reinterpret_cast<const f32x4*>(base + (int64_t)(sb - sb0) * stride);
   const f32x4 sum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
   const int q_local = lblk * HB + q;
   if (q_local < ng) {
@@ -503,15 +528,18 @@ extern "C" size_t dgdm_spatial_attn_h_bwd_fused_workspace_bytes(const int32_t* p
   return (size_t)count * (size_t)H * HB * 16 * sizeof(float);
 }
 
-extern "C" int dgdm_spatial_attn_h_bwd_fused(const void* Rq, const void* Rk, const void* Rv, const void* Rg, const float* pos_b,
-                                             const float* lse_adj_b, const float* ndelta_b, const int32_t* ptr, const int32_t* ptr_host,
-                                             int32_t B, int32_t num_blocks, int32_t H, float drop_p, uint32_t seed,
-                                             const float* grad_scale2, float* dK, float* dV, int64_t ldg,
-                                             int32_t sb_first, int32_t sb_count, void* workspace, size_t workspace_bytes, void* stream_) {
+// skip_map (nullable): the zero-block map of the forward (dgdm_attn_skip_map_build); the SAME pointer must go to the reduction
+extern "C" int dgdm_spatial_attn_h_bwd_fused_sparse(const void* Rq, const void* Rk, const void* Rv, const void* Rg, const float* pos_b,
+                                                    const float* lse_adj_b, const float* ndelta_b, const int32_t* ptr, const int32_t* ptr_host,
+                                                    int32_t B, int32_t num_blocks, int32_t H, float drop_p, uint32_t seed,
+                                                    const float* grad_scale2, float* dK, float* dV, int64_t ldg,
+                                                    int32_t sb_first, int32_t sb_count, void* workspace, size_t workspace_bytes,
+                                                    const uint32_t* skip_map, void* stream_) {
   DGDM_REQUIRE(B >= 0 && H > 0 && num_blocks >= 0 && drop_p >= 0.f && drop_p < 1.f && sb_first >= 0 && sb_count >= 0);
   if (num_blocks == 0 || B == 0 || sb_count == 0) return DGDM_OK;
   DGDM_REQUIRE(Rq && Rk && Rv && Rg && pos_b && lse_adj_b && ndelta_b && ptr && ptr_host && dK && dV && grad_scale2 && workspace);
-  if ((ldg & 3) || ldg < H * 16 || !dgdm_aligned16(dK) || !dgdm_aligned16(dV) || !dgdm_aligned16(workspace))
+  if ((ldg & 3) || ldg < H * 16 || !dgdm_aligned16(dK) || !dgdm_aligned16(dV) || !dgdm_aligned16(workspace) ||
+      (skip_map && !dgdm_aligned16(skip_map)))
     return DGDM_ERR_UNSUPPORTED;
   int64_t slot_first, slots, total_sb;
   if (!sblock_slots_host(ptr_host, B, sb_first, sb_count, &slot_first, &slots, &total_sb)) return DGDM_ERR_INVALID_ARG;
@@ -535,19 +563,20 @@ extern "C" int dgdm_spatial_attn_h_bwd_fused(const void* Rq, const void* Rk, con
   if (drop_p > 0.f)
     hipLaunchKernelGGL((k_attn_h_bwd_fused<true, 2>), dim3(sb_count, H), dim3(64 * SBW), LDS_DYN, s, h16(Rq), h16(Rk), h16(Rv), h16(Rg), pos_b,
                        lse_adj_b, ndelta_b, H, ptr, B, kscale, grad_scale2, dK, dV, ldg, part, sb_first, sb_count, slot_first, drop_p,
-                       dgdm_seed_arg(seed));
+                       dgdm_seed_arg(seed), skip_map, num_blocks);
   else
     hipLaunchKernelGGL((k_attn_h_bwd_fused<false, 2>), dim3(sb_count, H), dim3(64 * SBW), LDS_DYN, s, h16(Rq), h16(Rk), h16(Rv), h16(Rg), pos_b,
                        lse_adj_b, ndelta_b, H, ptr, B, kscale, grad_scale2, dK, dV, ldg, part, sb_first, sb_count, slot_first, 0.f,
-                       dgdm_seed_arg(0u));
+                       dgdm_seed_arg(0u), skip_map, num_blocks);
   return dgdm_launch_status();
 }
 
 // second stage of the call above (same sb_first / sb_count / workspace): dQ rows of every query block whose graph has super-blocks in
 // the range (+)= scale * sum of their partial tiles, in super-block order
-extern "C" int dgdm_spatial_attn_h_bwd_fused_reduce(const int32_t* ptr, const int32_t* ptr_host, int32_t B, int32_t num_blocks, int32_t H,
-                                                    float scale, const float* grad_scale2, float* dQ, int64_t ldg, int32_t sb_first,
-                                                    int32_t sb_count, const void* workspace, size_t workspace_bytes, void* stream_) {
+extern "C" int dgdm_spatial_attn_h_bwd_fused_reduce_sparse(const int32_t* ptr, const int32_t* ptr_host, int32_t B, int32_t num_blocks,
+                                                           int32_t H, float scale, const float* grad_scale2, float* dQ, int64_t ldg,
+                                                           int32_t sb_first, int32_t sb_count, const void* workspace,
+                                                           size_t workspace_bytes, const uint32_t* skip_map, void* stream_) {
   DGDM_REQUIRE(B >= 0 && H > 0 && num_blocks >= 0 && sb_first >= 0 && sb_count >= 0);
   if (num_blocks == 0 || B == 0 || sb_count == 0) return DGDM_OK;
   DGDM_REQUIRE(ptr && ptr_host && dQ && grad_scale2 && workspace);
@@ -557,6 +586,22 @@ extern "C" int dgdm_spatial_attn_h_bwd_fused_reduce(const int32_t* ptr, const in
   DGDM_REQUIRE(sb_first + (int64_t)sb_count <= total_sb);
   if (workspace_bytes < (size_t)slots * (size_t)H * HB * 16 * sizeof(float)) return DGDM_ERR_WORKSPACE;
   hipLaunchKernelGGL(k_attn_dq_reduce, dim3(num_blocks, H), dim3(256), 0, static_cast<hipStream_t>(stream_),
-                     static_cast<const float*>(workspace), ptr, B, H, sb_first, sb_count, slot_first, scale, grad_scale2, dQ, ldg);
+                     static_cast<const float*>(workspace), ptr, B, H, sb_first, sb_count, slot_first, scale, grad_scale2, dQ, ldg, skip_map);
   return dgdm_launch_status();
+}
+
+extern "C" int dgdm_spatial_attn_h_bwd_fused(const void* Rq, const void* Rk, const void* Rv, const void* Rg, const float* pos_b,
+                                             const float* lse_adj_b, const float* ndelta_b, const int32_t* ptr, const int32_t* ptr_host,
+                                             int32_t B, int32_t num_blocks, int32_t H, float drop_p, uint32_t seed,
+                                             const float* grad_scale2, float* dK, float* dV, int64_t ldg,
+                                             int32_t sb_first, int32_t sb_count, void* workspace, size_t workspace_bytes, void* stream_) {
+  return dgdm_spatial_attn_h_bwd_fused_sparse(Rq, Rk, Rv, Rg, pos_b, lse_adj_b, ndelta_b, ptr, ptr_host, B, num_blocks, H, drop_p, seed,
+                                              grad_scale2, dK, dV, ldg, sb_first, sb_count, workspace, workspace_bytes, nullptr, stream_);
+}
+
+extern "C" int dgdm_spatial_attn_h_bwd_fused_reduce(const int32_t* ptr, const int32_t* ptr_host, int32_t B, int32_t num_blocks, int32_t H,
+                                                    float scale, const float* grad_scale2, float* dQ, int64_t ldg, int32_t sb_first,
+                                                    int32_t sb_count, const void* workspace, size_t workspace_bytes, void* stream_) {
+  return dgdm_spatial_attn_h_bwd_fused_reduce_sparse(ptr, ptr_host, B, num_blocks, H, scale, grad_scale2, dQ, ldg, sb_first, sb_count,
+                                                     workspace, workspace_bytes, nullptr, stream_);
 }

@@ -98,7 +98,8 @@ template <int HG, bool DROP, int NBUF = 2, int WPE = 2>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) void k_attn_h_fwd(const _Float16* __restrict__ Rq, const _Float16* __restrict__ Rk,
                                                     const _Float16* __restrict__ Rv, const float* __restrict__ pos_b, int H,
                                                     const int32_t* __restrict__ ptr, int B, float* __restrict__ O,
-                                                    int64_t ldo, float* __restrict__ lse2_b, float drop_p, DgdmSeed seed_in) {
+                                                    int64_t ldo, float* __restrict__ lse2_b, float drop_p, DgdmSeed seed_in,
+                                                    const uint32_t* __restrict__ skip_map) {
   const uint32_t seed = seed_in.value();
   constexpr int NT = HB / 16;
   constexpr int RK_BYTES = HG * R_HEAD * 2, TV_BYTES = RK_BYTES, POS_BYTES = HB * 8;      // K and V row images (V^T is read transposed)
@@ -123,7 +124,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
     dma_to_lds<TV_BYTES>(Rv + gb * R_HEAD, base + RK_BYTES, tid);
     dma_to_lds<POS_BYTES>(pos_b + (int64_t)(blk0 + kb) * HB * 2, base + RK_BYTES + TV_BYTES, tid);
   };
-  stage(0, 0);
+  // key blocks whose weights are exactly zero for this query block and every head of its group are walked over (attn_h.hpp;
+  // the block that holds the rows themselves never is: kb < nbg below)
+  const uint32_t* srow = skip_map ? skip_map + attn_map_row(0, head0 / attn_map_group(H), H, gridDim.x, blockIdx.x) : nullptr;
+  LiveWalk live;
+  live.init(srow, nbg);
+  int kb = __builtin_amdgcn_readfirstlane(live.next());
+  if (kb >= nbg) kb = lblk;      // (a map that marks the rows' own block cannot come out of dgdm_attn_skip_map_build)
+  stage(kb, 0);
 
   f16x8 qb1[HG], qb2[HG];
   f32x4 oacc[HG], lacc[HG];  // lacc: every register = sum over keys of the weights (ones . [P_hi + P_lo])
@@ -142,9 +150,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
   const float px = pos_b[((int64_t)blockIdx.x * 2 + 0) * HB + q_in_blk], py = pos_b[((int64_t)blockIdx.x * 2 + 1) * HB + q_in_blk];
   __syncthreads();  // block 0 landed (vmcnt(0) + barrier)
 
-  for (int kb = 0; kb < nbg; ++kb) {
-    const int buf = NBUF == 2 ? (kb & 1) : 0;
-    if (NBUF == 2 && kb + 1 < nbg) stage(kb + 1, buf ^ 1);  // lands under this block's math; its buffer was released by the last barrier
+  for (int it = 0; kb < nbg; ++it) {
+    const int buf = NBUF == 2 ? (it & 1) : 0;
+    const int kb_next = __builtin_amdgcn_readfirstlane(live.next());
+    if (NBUF == 2 && kb_next < nbg) stage(kb_next, buf ^ 1);  // lands under this block's math; its buffer was released by the last barrier
     const _Float16* Kimg = reinterpret_cast<const _Float16*>(smem + buf * BUF_BYTES);
     const _Float16* Vimg = reinterpret_cast<const _Float16*>(smem + buf * BUF_BYTES + RK_BYTES);
     const float* Ps = reinterpret_cast<const float*>(smem + buf * BUF_BYTES + RK_BYTES + TV_BYTES);
@@ -222,10 +231,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
       }
     }
     __syncthreads();  // everyone is done with `buf`; the DMA of the next block has landed
-    if (NBUF == 1 && kb + 1 < nbg) {   // single buffer: other workgroups of the CU (3 per CU) cover this load
-      stage(kb + 1, 0);
+    if (NBUF == 1 && kb_next < nbg) {   // single buffer: other workgroups of the CU (3 per CU) cover this load
+      stage(kb_next, 0);
       __syncthreads();
     }
+    kb = kb_next;
   }
 
 #pragma unroll
@@ -293,14 +303,15 @@ extern "C" int dgdm_attn_pack(const float* X, int64_t ld, int32_t col0, int32_t 
   return dgdm_launch_status();
 }
 
-extern "C" int dgdm_spatial_attn_h_fwd(const void* Rq, const void* Rk, const void* Rv, const float* pos_b, const int32_t* ptr,
-                                       int32_t B, int32_t num_blocks, int32_t H, float drop_p, uint32_t seed, float* O,
-                                       int64_t ldo, float* lse2_b, int32_t variant, void* stream_) {
+// skip_map (nullable): the zero-block map dgdm_attn_skip_map_build made from the same packed operands
+extern "C" int dgdm_spatial_attn_h_fwd_sparse(const void* Rq, const void* Rk, const void* Rv, const float* pos_b, const int32_t* ptr,
+                                              int32_t B, int32_t num_blocks, int32_t H, float drop_p, uint32_t seed, float* O,
+                                              int64_t ldo, float* lse2_b, int32_t variant, const uint32_t* skip_map, void* stream_) {
   DGDM_REQUIRE(B >= 0 && H > 0 && num_blocks >= 0 && drop_p >= 0.f && drop_p < 1.f);
   if (num_blocks == 0 || B == 0) return DGDM_OK;
   DGDM_REQUIRE(Rq && Rk && Rv && pos_b && ptr && O && lse2_b);
   if ((ldo & 3) || ldo < H * 16 || !dgdm_aligned16(Rq) || !dgdm_aligned16(Rk) || !dgdm_aligned16(Rv) || !dgdm_aligned16(O) ||
-      !dgdm_aligned16(pos_b))
+      !dgdm_aligned16(pos_b) || (skip_map && !dgdm_aligned16(skip_map)))
     return DGDM_ERR_UNSUPPORTED;
   hipStream_t s = static_cast<hipStream_t>(stream_);
   const _Float16 *q = static_cast<const _Float16*>(Rq), *k = static_cast<const _Float16*>(Rk), *v = static_cast<const _Float16*>(Rv);
@@ -308,10 +319,10 @@ extern "C" int dgdm_spatial_attn_h_fwd(const void* Rq, const void* Rk, const voi
   do {                                                                                                                      \
     if (drop_p > 0.f)                                                                                                       \
       hipLaunchKernelGGL((k_attn_h_fwd<HG, true, NBUF, WPE>), dim3(num_blocks, H / HG), dim3(256), 0, s, q, k, v, pos_b, H, ptr, B,    \
-                         O, ldo, lse2_b, drop_p, dgdm_seed_arg(seed));                                                             \
+                         O, ldo, lse2_b, drop_p, dgdm_seed_arg(seed), skip_map);                                                   \
     else                                                                                                                    \
       hipLaunchKernelGGL((k_attn_h_fwd<HG, false, NBUF, WPE>), dim3(num_blocks, H / HG), dim3(256), 0, s, q, k, v, pos_b, H, ptr, B,   \
-                         O, ldo, lse2_b, 0.f, dgdm_seed_arg(0u));                                                                  \
+                         O, ldo, lse2_b, 0.f, dgdm_seed_arg(0u), skip_map);                                                        \
   } while (0)
   // variant 0 = default; 1..3 select a tiling explicitly (tools/microbench_attn.py)
   if (H % 4 == 0 && variant == 1) GO(4, 2, 2);        // 4 heads, double-buffered, 2 workgroups per CU
@@ -324,4 +335,10 @@ extern "C" int dgdm_spatial_attn_h_fwd(const void* Rq, const void* Rk, const voi
   else GO(1, 2, 2);
 #undef GO
   return dgdm_launch_status();
+}
+
+extern "C" int dgdm_spatial_attn_h_fwd(const void* Rq, const void* Rk, const void* Rv, const float* pos_b, const int32_t* ptr,
+                                       int32_t B, int32_t num_blocks, int32_t H, float drop_p, uint32_t seed, float* O,
+                                       int64_t ldo, float* lse2_b, int32_t variant, void* stream_) {
+  return dgdm_spatial_attn_h_fwd_sparse(Rq, Rk, Rv, pos_b, ptr, B, num_blocks, H, drop_p, seed, O, ldo, lse2_b, variant, nullptr, stream_);
 }

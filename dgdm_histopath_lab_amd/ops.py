@@ -239,7 +239,7 @@ class PackedOperands:
     """Block-aligned fp16 hi+lo row images of `ntensors` column blocks of one fp32 matrix (csrc/attn_h.hpp), plus (forward pack)
     the block-aligned, pre-scaled positions; (backward pack) -delta and 8 - lse2 per row."""
 
-    __slots__ = ("R", "pos_b", "ndelta_b", "nlse_b", "ntensors", "r_stride")
+    __slots__ = ("R", "pos_b", "ndelta_b", "nlse_b", "ntensors", "r_stride", "skip_map")
 
     def r(self, z):
         return self.R[z * self.r_stride:]
@@ -261,6 +261,11 @@ ATTN_BWD_FUSED = True           # dQ, dK, dV in one key-stationary pass + a fixe
 # is free on the device when the backward runs): one launch for every BASELINE configuration on a 288 GB MI355X, smaller groups when
 # the card is shared or nearly full.  An int fixes the budget (tests force several groups with it).
 ATTN_BWD_FUSED_BUDGET = None
+# The (query block, key block) pairs whose weights are exactly 0.0f -- every score more than 200 log2 units below every row maximum, which
+# is what raw slide coordinates (pixels) in -distance / temperature produce for all but a band of pairs -- are found from per-block
+# bounds (two small launches per attention call) and walked over by the forward and the one-pass backward: the same bits in every
+# output, a band's worth of work on real slides; nothing is skipped for positions in [0, 1) (csrc/attn_h.hpp, attn_skip.hip).
+ATTN_SKIP_ZERO_BLOCKS = True
 
 
 _ATTN_BUDGET_SEEN: dict = {}
@@ -292,6 +297,7 @@ def attn_pack(x, col0: int, cstride: int, ntensors: int, scale0: float, plan: At
     dev, nb = x.device, plan.num_q_tiles
     pk = PackedOperands()
     pk.ntensors = ntensors
+    pk.skip_map = None
     pk.r_stride = lib.dgdm_attn_pack_bytes(nb, H, 0) // 2
     pk.R = torch.empty(max(ntensors * pk.r_stride, 8), dtype=torch.float16, device=dev)
     pk.pos_b = torch.empty(max(lib.dgdm_attn_pack_bytes(nb, H, 2) // 4, 4), dtype=torch.float32, device=dev) if pos is not None else None
@@ -314,11 +320,27 @@ def spatial_attn_h_fwd_raw(qkv, pos, plan: AttnPlan, H: int, scale: float, inv_t
     pk = packed if packed is not None else attn_pack(qkv, 0, C, 3, scale * LOG2E, plan, H, pos=pos, pos_scale=inv_tau * LOG2E)
     out = torch.empty(N, C, dtype=torch.float32, device=qkv.device)
     lse2_b = torch.empty(max(lib.dgdm_attn_pack_bytes(plan.num_q_tiles, H, 3) // 4, 4), dtype=torch.float32, device=qkv.device)
+    if ATTN_SKIP_ZERO_BLOCKS and pk.skip_map is None and plan.num_q_tiles > 0:
+        pk.skip_map = attn_skip_map(pk, plan, H)
     TIMERS.timed("attn_fwd", lambda: _lib.check(
-        lib.dgdm_spatial_attn_h_fwd(pk.r(0).data_ptr(), pk.r(1).data_ptr(), pk.r(2).data_ptr(), pk.pos_b.data_ptr(),
-                                    plan.ptr_dev.data_ptr(), plan.B, plan.num_q_tiles, H, drop_p, seed, out.data_ptr(),
-                                    out.stride(0), lse2_b.data_ptr(), variant, _lib.stream_ptr(qkv.device)), "dgdm_spatial_attn_h_fwd"))
+        lib.dgdm_spatial_attn_h_fwd_sparse(pk.r(0).data_ptr(), pk.r(1).data_ptr(), pk.r(2).data_ptr(), pk.pos_b.data_ptr(),
+                                           plan.ptr_dev.data_ptr(), plan.B, plan.num_q_tiles, H, drop_p, seed, out.data_ptr(),
+                                           out.stride(0), lse2_b.data_ptr(), variant, _lib.ptr(pk.skip_map), _lib.stream_ptr(qkv.device)),
+        "dgdm_spatial_attn_h_fwd_sparse"))
     return out, lse2_b, pk
+
+
+def attn_skip_map(pk: PackedOperands, plan: AttnPlan, H: int) -> torch.Tensor:
+    """The zero-block map of one attention call (csrc/attn_skip.hip) from its packed Q', K and positions: uint32 words, rows by query
+    block and by key super-block.  The forward, the one-pass backward and its reduction must see the same map."""
+    lib = _lib.load()
+    dev, nb = pk.R.device, plan.num_q_tiles
+    m = torch.empty(max(lib.dgdm_attn_skip_map_bytes(nb, H) // 4, 4), dtype=torch.int32, device=dev)
+    ws = torch.empty(max(lib.dgdm_attn_skip_map_workspace_bytes(nb, H) // 4, 4), dtype=torch.float32, device=dev)
+    _lib.check(lib.dgdm_attn_skip_map_build(pk.r(0).data_ptr(), pk.r(1).data_ptr(), pk.pos_b.data_ptr(), plan.ptr_dev.data_ptr(), plan.B, nb, H,
+                                            ws.data_ptr(), ws.numel() * 4, m.data_ptr(), m.numel() * 4, _lib.stream_ptr(dev)),
+               "dgdm_attn_skip_map_build")
+    return m
 
 
 def spatial_attn_h_bwd_raw(pk: PackedOperands, out, gout, plan: AttnPlan, H: int, scale: float, inv_tau: float, lse2_b, dqkv,
@@ -371,14 +393,14 @@ def spatial_attn_h_bwd_raw(pk: PackedOperands, out, gout, plan: AttnPlan, H: int
         ws = torch.empty(max(max(g[2] for g in groups), 16) // 4, dtype=torch.float32, device=out.device)
 
         for sb0, cnt, wsb in groups:
-            TIMERS.timed("attn_bwd_fused", lambda: _lib.check(lib.dgdm_spatial_attn_h_bwd_fused(
+            TIMERS.timed("attn_bwd_fused", lambda: _lib.check(lib.dgdm_spatial_attn_h_bwd_fused_sparse(
                 pk.r(0).data_ptr(), pk.r(1).data_ptr(), pk.r(2).data_ptr(), gk.r(0).data_ptr(), pk.pos_b.data_ptr(), gk.nlse_b.data_ptr(),
                 gk.ndelta_b.data_ptr(), plan.ptr_dev.data_ptr(), ph, plan.B, plan.num_q_tiles, H, drop_p, seed, gs.data_ptr(),
-                dqkv[:, C:2 * C].data_ptr(), dqkv[:, 2 * C:].data_ptr(), dqkv.stride(0), sb0, cnt, ws.data_ptr(), ws.numel() * 4, st),
-                "dgdm_spatial_attn_h_bwd_fused"))
-            TIMERS.timed("attn_bwd_dq_reduce", lambda: _lib.check(lib.dgdm_spatial_attn_h_bwd_fused_reduce(
+                dqkv[:, C:2 * C].data_ptr(), dqkv[:, 2 * C:].data_ptr(), dqkv.stride(0), sb0, cnt, ws.data_ptr(), ws.numel() * 4,
+                _lib.ptr(pk.skip_map), st), "dgdm_spatial_attn_h_bwd_fused_sparse"))
+            TIMERS.timed("attn_bwd_dq_reduce", lambda: _lib.check(lib.dgdm_spatial_attn_h_bwd_fused_reduce_sparse(
                 plan.ptr_dev.data_ptr(), ph, plan.B, plan.num_q_tiles, H, scale, gs.data_ptr(), dqkv[:, :C].data_ptr(), dqkv.stride(0), sb0, cnt,
-                ws.data_ptr(), ws.numel() * 4, st), "dgdm_spatial_attn_h_bwd_fused_reduce"))
+                ws.data_ptr(), ws.numel() * 4, _lib.ptr(pk.skip_map), st), "dgdm_spatial_attn_h_bwd_fused_reduce_sparse"))
         if overlap_ev is not None:
             cur, side = torch.cuda.current_stream(out.device), _side_stream(out.device)
             side.wait_event(overlap_ev)
@@ -411,16 +433,17 @@ class _SpatialAttentionH(torch.autograd.Function):
     def forward(ctx, qkv, pos, plan: AttnPlan, H: int, scale: float, inv_tau: float, drop_p: float, seed: int):
         qkv, pos = _f32c(qkv), _f32c(pos)
         out, lse2_b, pk = spatial_attn_h_fwd_raw(qkv, pos, plan, H, scale, inv_tau, drop_p, seed)
-        ctx.save_for_backward(out, lse2_b, pk.R, pk.pos_b)
+        ctx.save_for_backward(out, lse2_b, pk.R, pk.pos_b, *([pk.skip_map] if pk.skip_map is not None else []))
         ctx.meta = (plan, H, scale, inv_tau, drop_p, seed, pk.r_stride, qkv.shape)
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        out, lse2_b, R, pos_b = ctx.saved_tensors
+        out, lse2_b, R, pos_b, *skip = ctx.saved_tensors
         plan, H, scale, inv_tau, drop_p, seed, rs, shape = ctx.meta
         pk = PackedOperands()
         pk.R, pk.pos_b, pk.ndelta_b, pk.nlse_b, pk.ntensors, pk.r_stride = R, pos_b, None, None, 3, rs
+        pk.skip_map = skip[0] if skip else None
         dqkv = torch.empty(shape, dtype=torch.float32, device=out.device)
         spatial_attn_h_bwd_raw(pk, out, gout, plan, H, scale, inv_tau, lse2_b, dqkv, drop_p, seed)
         return dqkv, None, None, None, None, None, None, None

@@ -137,7 +137,7 @@ def test_set2set_pooling_is_the_mean_as_in_the_reference():
 
 @pytest.mark.parametrize("n,c", [(37, 32), (3000, 512), (40000, 128), (257, 36)])
 @pytest.mark.parametrize("act,p", [(0, 0.0), (2, 0.0), (4, 0.0), (1, 0.2)])
-def test_column_norm_is_batchnorm1d_with_activation(n, c, act, p):
+def test_column_norm_is_batchnorm1d_with_activation(n, c, act, p, monkeypatch):
     """dgdm_colnorm_* (nn.BatchNorm1d over the nodes of a batch + activation + dropout, models/encoders.py:95-100 with
     normalization="batch") against torch's own module in float64 on the CPU: training mode (batch statistics; running averages and
     num_batches_tracked advance exactly as the module's), eval mode (running averages), outputs, input / affine gradients; with
@@ -159,7 +159,7 @@ def test_column_norm_is_batchnorm1d_with_activation(n, c, act, p):
     for mode in ("train", "eval"):
         ref.train(mode == "train"); own.train(mode == "train")
         ref.zero_grad(); own.zero_grad()
-        ops._seed_counter = 500
+        monkeypatch.setattr(ops, "_seed_counter", 500)
         xd = x.to(DEV).requires_grad_(True)
         y = ops.batch_norm(xd, own, act, p, mode == "train")
         mask = 1.0

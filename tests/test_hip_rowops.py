@@ -43,9 +43,10 @@ def test_rownorm_forward_backward(n, c, groups, act, with_res):
     assert_close(bd.grad, xs[3].grad, 5e-5, "dbeta")
 
 
-def test_rownorm_dropout_statistics_and_backward_mask():
+def test_rownorm_dropout_statistics_and_backward_mask(monkeypatch):
     from dgdm_histopath_lab_amd import ops
     torch.manual_seed(0)
+    monkeypatch.setattr(ops, "_seed_counter", 1000)         # the masks below are these draws whatever ran before this test
     n, c, p = 4096, 256, 0.1
     x = torch.randn(n, c, device=DEV, requires_grad=True)
     w = torch.ones(c, device=DEV, requires_grad=True); b = torch.zeros(c, device=DEV, requires_grad=True)
@@ -57,7 +58,7 @@ def test_rownorm_dropout_statistics_and_backward_mask():
     kept = ~dropped
     assert_close(y[kept], y0[kept] / (1 - 6553 / 65536), 1e-5, "kept values scaled by 1/(1-p)")
     # per-row / per-column drop rates are flat (no structure from the hash)
-    assert dropped.float().mean(0).sub(p).abs().max() < 0.03 and dropped.float().mean(1).sub(p).abs().max() < 0.08
+    assert dropped.float().mean(0).sub(p).abs().max() < 0.03 and dropped.float().mean(1).sub(p).abs().max() < 0.1      # 256 draws per row: sigma 0.019, 4 096 rows
     y.backward(torch.ones_like(y))
     g1 = x.grad.clone(); x.grad = None
     y2 = ops.row_norm(x, w, b, act=ops.ACT_GELU, drop_p=p, training=True)
