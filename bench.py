@@ -373,6 +373,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--no-strict", action="store_true", help="skip the strict-fp32-attention leg")
+    ap.add_argument("--no-raster", action="store_true", help="skip the raster-pixel-positions leg (reported beside the headline)")
     ap.add_argument("--eval-mode", action="store_true", help="dropout off (diagnostics only; not the headline)")
     ap.add_argument("--precision", choices=["default", "fp32"], default="default",
                     help="fp32: run the MAIN leg with fp32 operands on the fp32 matrix instructions in the attention and in every dense "
@@ -586,6 +587,39 @@ def main():
         d_s = time.perf_counter() - t1
         sustained = {"value": round(args.batch * n_s / d_s, 3), "unit": "slides/s", "steps": n_s, "seconds": round(d_s, 2),
                      "ms_per_step": round(d_s / n_s * 1e3, 3), "note": "the same step, replayed back to back after the timed region"}
+    # NOT the headline: the same recorded step on positions as the reference's preprocessing stores them (patch centres in pixels, a
+    # row-by-row raster at 224-pixel pitch; preprocessing/tissue_graph_builder.py:381-384).  -distance / temperature then makes all but
+    # a band of the attention weights 0.0f and the zero-block map (csrc/attn_skip.hip, computed inside the recording from whatever
+    # positions the input buffers hold) walks those block pairs over.  The positions are written into the recording's input buffer,
+    # the step replayed, the synthetic positions restored.
+    raster = None
+    if (world == 1 and graphed and stream is None and not args.large and args.pixel_positions == 0 and not args.no_raster
+            and gstep.input_buffers is not None and getattr(gstep.input_buffers, "pos", None) is not None):
+        import math as _m
+        buf = gstep.input_buffers.pos
+        keep = buf.clone()
+        w = int(_m.ceil(_m.sqrt(args.nodes)))
+        i = torch.arange(args.nodes, device=dev)
+        one = torch.stack([(i % w).float(), (i // w).float()], 1) * 224.0
+        buf.copy_(one.repeat(args.batch, 1))
+        for _ in range(3):
+            step()
+        n_r = max(5, min(args.steps, 20))
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        for _ in range(n_r):
+            step()
+        torch.cuda.synchronize()
+        d_r = (time.perf_counter() - t1) / n_r
+        buf.copy_(keep)
+        for _ in range(2):
+            loss = step()
+        torch.cuda.synchronize()
+        raster = {"value": round(args.batch / d_r, 3), "unit": "slides/s", "ms_per_step": round(d_r * 1e3, 3), "steps": n_r,
+                  "positions": "patch centres of a row-by-row raster at 224-pixel pitch (level-0 pixels, as the reference's preprocessing "
+                               "stores them), temperature 1",
+                  "note": "NOT the headline (BASELINE's positions are U[0,1)^2, where no block pair is zero): the same recording replayed; "
+                          "block pairs of the attention whose weights are exactly 0.0f are skipped with bit-identical results "
+                          "(ops.ATTN_SKIP_ZERO_BLOCKS)" if ops.ATTN_SKIP_ZERO_BLOCKS else "zero-block map off"}
     # the same step at the reference's own arithmetic (fp32 operands on the fp32 matrix instructions, in the attention and in every
     # dense layer): measured here, in the same process on the same box, so the two numbers are comparable
     strict = None
@@ -739,6 +773,8 @@ def main():
             result["gradient_exchange"] = {"collective": "all_reduce(AVG) of one flat fp32 buffer (RCCL), live parameters only",
                                            "bytes": reducer.nbytes, "bucket_bytes": reducer.bucket_nbytes,
                                            "messages_per_step": 1 if graphed else 2, "early_launches": reducer.stats.get("early_launches", 0)}
+        if raster is not None:
+            result["raster_positions"] = raster
         if strict is not None:
             result["strict_fp32"] = strict
         if sustained is not None:
