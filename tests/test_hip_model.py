@@ -87,7 +87,7 @@ def test_model_matches_reference_golden(tag, attn, monkeypatch):
     assert_close(outq["graph_embedding"], g["pre_graph_embedding"], TOL, "graph_embedding (own decisions)")
 
 
-def _run_both(cfgd, seed0, trace, nodes=2000, edges=8000, graphs=2, tweak=None):
+def _run_both(cfgd, seed0, trace, nodes=2000, edges=8000, graphs=2, tweak=None, pos_fn=None):
     """One pretrain_step (masking + injected draws) on the HIP path and on the float64 oracle.
     The arbiter runs in float64 (same oracle code): fp32-vs-fp32 would fold the CPU path's own
     rounding into the comparison."""
@@ -97,6 +97,8 @@ def _run_both(cfgd, seed0, trace, nodes=2000, edges=8000, graphs=2, tweak=None):
     if tweak is not None:
         tweak(P)
     batch = synthetic_batch(seed0, graphs, nodes, edges)
+    if pos_fn is not None:
+        batch.pos = pos_fn(batch)
     gen = torch.Generator().manual_seed(11 + seed0)
     n = batch.x.size(0)
     c_last, T = cfgd["hidden_dims"][-1], cfgd["num_diffusion_steps"]
@@ -376,12 +378,12 @@ def test_smooth_model_matches_oracle_2k_nodes_all_params(attn, monkeypatch):
     assert _assert_all_grads(m, gref, 1e-4) > 60
 
 
-def _full_model_against_oracle(cfgd, seed0, nodes, edges, graphs, min_live, tweak=None):
+def _full_model_against_oracle(cfgd, seed0, nodes, edges, graphs, min_live, tweak=None, pos_fn=None):
     """U-Net on (ReLU + top-k): outputs, traced activations, top-k selections and EVERY live parameter gradient against the
     float64 oracle at the 1e-3 contract -- one fixed instance, no retry, no skip.  The oracle's kink decisions are injected into
     the kernels (GraphUNet.forward `decisions`), and every decision the HIP path would have taken differently is held to the
     rounding margin inside _run_both (conftest.check_decision_margins)."""
-    m, out, ref, gref, tr, tr64 = _run_both(cfgd, seed0, trace=True, nodes=nodes, edges=edges, graphs=graphs, tweak=tweak)
+    m, out, ref, gref, tr, tr64 = _run_both(cfgd, seed0, trace=True, nodes=nodes, edges=edges, graphs=graphs, tweak=tweak, pos_fn=pos_fn)
     _full_model_against_oracle.last = (m, tr64)
     for k in ("diffusion_loss", "graph_embedding", "noisy_embeddings"):
         assert_close(out[k], ref[k], TOL, k)
@@ -402,6 +404,22 @@ def test_full_model_matches_oracle_2k_nodes_all_params(attn, monkeypatch):
     cfgd = dict(node_features=768, hidden_dims=[512, 256, 128], num_diffusion_steps=10, attention_heads=8)
     flips, total = _full_model_against_oracle(cfgd, 0, 2000, 8000, 2, 100)
     assert total > 1_000_000
+
+
+def test_full_model_on_raster_pixel_positions_matches_oracle():
+    """Positions as the reference's preprocessing stores them (patch centres in level-0 pixels, row by row, 224 apart;
+    preprocessing/tissue_graph_builder.py:381-384): with temperature 1 every attention row is one-hot up to weights that are 0.0f in
+    fp32, the zero-block map (csrc/attn_skip.hip) walks over 90 % of the block pairs, and outputs, traced activations and every live
+    parameter gradient still meet the float64 oracle at the 1e-3 contract."""
+    cfgd = dict(node_features=768, hidden_dims=[512, 256, 128], num_diffusion_steps=10, attention_heads=8)
+
+    def raster(batch):
+        n = batch.x.size(0) // 2
+        i = torch.arange(n)
+        one = torch.stack([(i % 45).float(), (i // 45).float()], 1) * 224.0
+        return torch.cat([one, one + 1000.0])
+
+    _full_model_against_oracle(cfgd, 5, 2000, 8000, 2, 100, pos_fn=raster)
 
 
 def test_full_model_matches_oracle_at_the_headline_graph_size():
