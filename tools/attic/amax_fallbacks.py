@@ -1,7 +1,7 @@
 """Which GEMM operands of a training step still get their absolute maximum from a separate reduction launch (dgdm_amax_bits)
 instead of from the kernel that produced them?  Prints (count, shape, call chain) for one eager step at the headline size."""
 import collections, os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import bench
 from dgdm_histopath_lab_amd import DGDMModel, ops
 from dgdm_histopath_lab_amd.synthetic import synthetic_batch
