@@ -140,7 +140,7 @@ __global__ __launch_bounds__(64 * SBW) __attribute__((amdgpu_waves_per_eu(WPE, 8
     const float* __restrict__ pos_b, const float* __restrict__ lse_b, const float* __restrict__ ndelta_b, int H,
     const int32_t* __restrict__ ptr, int B, float kscale, const float* __restrict__ unscale_dev, float* __restrict__ dK,
     float* __restrict__ dV, int64_t ldg, float* __restrict__ dq_part, int sb_first, int sb_count, int64_t slot_first, float drop_p,
-    DgdmSeed seed_in, const uint32_t* __restrict__ skip_map, int num_blocks) {
+    DgdmSeed seed_in, const uint32_t* __restrict__ skip_map, int num_blocks, unsigned* __restrict__ amax_out) {
   const uint32_t seed = seed_in.value();
   constexpr int NT = HB / 16;
   constexpr int R_BYTES = R_HEAD * 2, SC_BYTES = HB * 4, POS_BYTES = HB * 8;
@@ -416,6 +416,7 @@ __global__ __launch_bounds__(64 * SBW) __attribute__((amdgpu_waves_per_eu(WPE, 8
     qb = qb_next;
   }
 
+  unsigned am = 0;      // max |dK|, |dV| of the workgroup's rows -> the operand maximum of the QKV projection's input gradient
   if (blk_ok) {
     const float un = unscale_dev[1] * exp2f(-DGDM_ATTN_P_SHIFT);
     const float unk = kscale * un, unv = DROP ? dc.keep * un : un;
@@ -424,11 +425,14 @@ __global__ __launch_bounds__(64 * SBW) __attribute__((amdgpu_waves_per_eu(WPE, 8
       if (k_ok[kt]) {
         const int64_t off = (int64_t)(n0 + lblk * HB + 16 * kt + j) * ldg + head * 16 + 4 * G;
         const f32x4 a = dk[kt] * unk, b = dv[kt] * unv;
-        *reinterpret_cast<float4*>(dK + off) = make_float4(a[0], a[1], a[2], a[3]);
-        *reinterpret_cast<float4*>(dV + off) = make_float4(b[0], b[1], b[2], b[3]);
+        const float4 a4 = make_float4(a[0], a[1], a[2], a[3]), b4 = make_float4(b[0], b[1], b[2], b[3]);
+        *reinterpret_cast<float4*>(dK + off) = a4;
+        *reinterpret_cast<float4*>(dV + off) = b4;
+        am = dgdm_amax4(dgdm_amax4(am, a4), b4);
       }
     }
   }
+  if (amax_out) dgdm_amax_commit(am, amax_out);      // kernel argument: every thread of the workgroup is here
 }
 
 // dQ[q block][head] (+)= scale * sum over the launch's key super-blocks of that graph, in order (fixed order: bitwise repeatable).
@@ -437,7 +441,7 @@ __global__ __launch_bounds__(64 * SBW) __attribute__((amdgpu_waves_per_eu(WPE, 8
 __global__ __launch_bounds__(256) void k_attn_dq_reduce(const float* __restrict__ dq_part, const int32_t* __restrict__ ptr, int B, int H,
                                                         int sb_first, int sb_count, int64_t slot_first, float scale,
                                                         const float* __restrict__ unscale_dev, float* __restrict__ dQ, int64_t ldg,
-                                                        const uint32_t* __restrict__ skip_map) {
+                                                        const uint32_t* __restrict__ skip_map, unsigned* __restrict__ amax_out) {
   int n0, ng, lblk, sb0;
   int64_t spair0;
   if (!find_block_s(ptr, B, blockIdx.x, &n0, &ng, &lblk, &sb0, &spair0)) return;
@@ -475,6 +479,7 @@ __global__ __launch_bounds__(256) void k_attn_dq_reduce(const float* __restrict_
   }
   const f32x4 sum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
   const int q_local = lblk * HB + q;
+  unsigned am = 0;
   if (q_local < ng) {
     const float un = scale * unscale_dev[1] * exp2f(-DGDM_ATTN_P_SHIFT);
     float* o = dQ + (int64_t)(n0 + q_local) * ldg + h * 16 + 4 * d4;
@@ -483,8 +488,12 @@ __global__ __launch_bounds__(256) void k_attn_dq_reduce(const float* __restrict_
       const float4 old = *reinterpret_cast<const float4*>(o);
       r += f32x4{old.x, old.y, old.z, old.w};
     }
-    *reinterpret_cast<float4*>(o) = make_float4(r[0], r[1], r[2], r[3]);
+    const float4 r4 = make_float4(r[0], r[1], r[2], r[3]);
+    *reinterpret_cast<float4*>(o) = r4;
+    am = dgdm_amax4(am, r4);
   }
+  // max |dQ| (with several launches per batch: of every running sum, an upper bound of the final one -- all the consumer needs)
+  if (amax_out) dgdm_amax_commit(am, amax_out);
 }
 
 }  // namespace
@@ -528,13 +537,14 @@ extern "C" size_t dgdm_spatial_attn_h_bwd_fused_workspace_bytes(const int32_t* p
   return (size_t)count * (size_t)H * HB * 16 * sizeof(float);
 }
 
-// skip_map (nullable): the zero-block map of the forward (dgdm_attn_skip_map_build); the SAME pointer must go to the reduction
+// skip_map (nullable): the zero-block map of the forward (dgdm_attn_skip_map_build); the SAME pointer must go to the reduction.
+// amax_out (nullable): a zeroed operand-maximum slot group; this call adds max |dK|, |dV|, the reduction max |dQ|
 extern "C" int dgdm_spatial_attn_h_bwd_fused_sparse(const void* Rq, const void* Rk, const void* Rv, const void* Rg, const float* pos_b,
                                                     const float* lse_adj_b, const float* ndelta_b, const int32_t* ptr, const int32_t* ptr_host,
                                                     int32_t B, int32_t num_blocks, int32_t H, float drop_p, uint32_t seed,
                                                     const float* grad_scale2, float* dK, float* dV, int64_t ldg,
                                                     int32_t sb_first, int32_t sb_count, void* workspace, size_t workspace_bytes,
-                                                    const uint32_t* skip_map, void* stream_) {
+                                                    const uint32_t* skip_map, uint32_t* amax_out, void* stream_) {
   DGDM_REQUIRE(B >= 0 && H > 0 && num_blocks >= 0 && drop_p >= 0.f && drop_p < 1.f && sb_first >= 0 && sb_count >= 0);
   if (num_blocks == 0 || B == 0 || sb_count == 0) return DGDM_OK;
   DGDM_REQUIRE(Rq && Rk && Rv && Rg && pos_b && lse_adj_b && ndelta_b && ptr && ptr_host && dK && dV && grad_scale2 && workspace);
@@ -563,11 +573,11 @@ extern "C" int dgdm_spatial_attn_h_bwd_fused_sparse(const void* Rq, const void* 
   if (drop_p > 0.f)
     hipLaunchKernelGGL((k_attn_h_bwd_fused<true, 2>), dim3(sb_count, H), dim3(64 * SBW), LDS_DYN, s, h16(Rq), h16(Rk), h16(Rv), h16(Rg), pos_b,
                        lse_adj_b, ndelta_b, H, ptr, B, kscale, grad_scale2, dK, dV, ldg, part, sb_first, sb_count, slot_first, drop_p,
-                       dgdm_seed_arg(seed), skip_map, num_blocks);
+                       dgdm_seed_arg(seed), skip_map, num_blocks, amax_out);
   else
     hipLaunchKernelGGL((k_attn_h_bwd_fused<false, 2>), dim3(sb_count, H), dim3(64 * SBW), LDS_DYN, s, h16(Rq), h16(Rk), h16(Rv), h16(Rg), pos_b,
                        lse_adj_b, ndelta_b, H, ptr, B, kscale, grad_scale2, dK, dV, ldg, part, sb_first, sb_count, slot_first, 0.f,
-                       dgdm_seed_arg(0u), skip_map, num_blocks);
+                       dgdm_seed_arg(0u), skip_map, num_blocks, amax_out);
   return dgdm_launch_status();
 }
 
@@ -576,7 +586,8 @@ extern "C" int dgdm_spatial_attn_h_bwd_fused_sparse(const void* Rq, const void* 
 extern "C" int dgdm_spatial_attn_h_bwd_fused_reduce_sparse(const int32_t* ptr, const int32_t* ptr_host, int32_t B, int32_t num_blocks,
                                                            int32_t H, float scale, const float* grad_scale2, float* dQ, int64_t ldg,
                                                            int32_t sb_first, int32_t sb_count, const void* workspace,
-                                                           size_t workspace_bytes, const uint32_t* skip_map, void* stream_) {
+                                                           size_t workspace_bytes, const uint32_t* skip_map, uint32_t* amax_out,
+                                                           void* stream_) {
   DGDM_REQUIRE(B >= 0 && H > 0 && num_blocks >= 0 && sb_first >= 0 && sb_count >= 0);
   if (num_blocks == 0 || B == 0 || sb_count == 0) return DGDM_OK;
   DGDM_REQUIRE(ptr && ptr_host && dQ && grad_scale2 && workspace);
@@ -586,7 +597,7 @@ extern "C" int dgdm_spatial_attn_h_bwd_fused_reduce_sparse(const int32_t* ptr, c
   DGDM_REQUIRE(sb_first + (int64_t)sb_count <= total_sb);
   if (workspace_bytes < (size_t)slots * (size_t)H * HB * 16 * sizeof(float)) return DGDM_ERR_WORKSPACE;
   hipLaunchKernelGGL(k_attn_dq_reduce, dim3(num_blocks, H), dim3(256), 0, static_cast<hipStream_t>(stream_),
-                     static_cast<const float*>(workspace), ptr, B, H, sb_first, sb_count, slot_first, scale, grad_scale2, dQ, ldg, skip_map);
+                     static_cast<const float*>(workspace), ptr, B, H, sb_first, sb_count, slot_first, scale, grad_scale2, dQ, ldg, skip_map, amax_out);
   return dgdm_launch_status();
 }
 
@@ -596,12 +607,12 @@ extern "C" int dgdm_spatial_attn_h_bwd_fused(const void* Rq, const void* Rk, con
                                              const float* grad_scale2, float* dK, float* dV, int64_t ldg,
                                              int32_t sb_first, int32_t sb_count, void* workspace, size_t workspace_bytes, void* stream_) {
   return dgdm_spatial_attn_h_bwd_fused_sparse(Rq, Rk, Rv, Rg, pos_b, lse_adj_b, ndelta_b, ptr, ptr_host, B, num_blocks, H, drop_p, seed,
-                                              grad_scale2, dK, dV, ldg, sb_first, sb_count, workspace, workspace_bytes, nullptr, stream_);
+                                              grad_scale2, dK, dV, ldg, sb_first, sb_count, workspace, workspace_bytes, nullptr, nullptr, stream_);
 }
 
 extern "C" int dgdm_spatial_attn_h_bwd_fused_reduce(const int32_t* ptr, const int32_t* ptr_host, int32_t B, int32_t num_blocks, int32_t H,
                                                     float scale, const float* grad_scale2, float* dQ, int64_t ldg, int32_t sb_first,
                                                     int32_t sb_count, const void* workspace, size_t workspace_bytes, void* stream_) {
   return dgdm_spatial_attn_h_bwd_fused_reduce_sparse(ptr, ptr_host, B, num_blocks, H, scale, grad_scale2, dQ, ldg, sb_first, sb_count,
-                                                     workspace, workspace_bytes, nullptr, stream_);
+                                                     workspace, workspace_bytes, nullptr, nullptr, stream_);
 }

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
                                                     const _Float16* __restrict__ Rv, const float* __restrict__ pos_b, int H,
                                                     const int32_t* __restrict__ ptr, int B, float* __restrict__ O,
                                                     int64_t ldo, float* __restrict__ lse2_b, float drop_p, DgdmSeed seed_in,
-                                                    const uint32_t* __restrict__ skip_map) {
+                                                    const uint32_t* __restrict__ skip_map, unsigned* __restrict__ amax_out) {
   const uint32_t seed = seed_in.value();
   constexpr int NT = HB / 16;
   constexpr int RK_BYTES = HG * R_HEAD * 2, TV_BYTES = RK_BYTES, POS_BYTES = HB * 8;      // K and V row images (V^T is read transposed)
@@ -238,17 +238,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
     kb = kb_next;
   }
 
+  unsigned am = 0;      // max |O| of the workgroup's rows: the operand maximum of the output projection (no reduction launch)
 #pragma unroll
   for (int h = 0; h < HG; ++h) {
     const float lt = lacc[h][0];
     const float inv = (DROP ? dc.keep : 1.0f) / lt;
     if (q_ok) {
       const f32x4 os = oacc[h];
-      *reinterpret_cast<float4*>(O + (int64_t)(n0 + q_local) * ldo + (head0 + h) * 16 + 4 * G) =
-          make_float4(os[0] * inv, os[1] * inv, os[2] * inv, os[3] * inv);
+      const float4 o4 = make_float4(os[0] * inv, os[1] * inv, os[2] * inv, os[3] * inv);
+      *reinterpret_cast<float4*>(O + (int64_t)(n0 + q_local) * ldo + (head0 + h) * 16 + 4 * G) = o4;
+      am = dgdm_amax4(am, o4);
     }
     if (G == 0) lse2_b[((int64_t)blockIdx.x * H + head0 + h) * HB + q_in_blk] = q_ok ? m[h] + log2f(lt) : 0.f;
   }
+  if (amax_out) dgdm_amax_commit(am, amax_out);      // kernel argument: every thread of the workgroup is here
 }
 
 }  // namespace
@@ -303,10 +306,12 @@ extern "C" int dgdm_attn_pack(const float* X, int64_t ld, int32_t col0, int32_t 
   return dgdm_launch_status();
 }
 
-// skip_map (nullable): the zero-block map dgdm_attn_skip_map_build made from the same packed operands
+// skip_map (nullable): the zero-block map dgdm_attn_skip_map_build made from the same packed operands; amax_out (nullable): a zeroed
+// operand-maximum slot group (dgdm_amax_bits' layout) that receives max |O|
 extern "C" int dgdm_spatial_attn_h_fwd_sparse(const void* Rq, const void* Rk, const void* Rv, const float* pos_b, const int32_t* ptr,
                                               int32_t B, int32_t num_blocks, int32_t H, float drop_p, uint32_t seed, float* O,
-                                              int64_t ldo, float* lse2_b, int32_t variant, const uint32_t* skip_map, void* stream_) {
+                                              int64_t ldo, float* lse2_b, int32_t variant, const uint32_t* skip_map, uint32_t* amax_out,
+                                              void* stream_) {
   DGDM_REQUIRE(B >= 0 && H > 0 && num_blocks >= 0 && drop_p >= 0.f && drop_p < 1.f);
   if (num_blocks == 0 || B == 0) return DGDM_OK;
   DGDM_REQUIRE(Rq && Rk && Rv && pos_b && ptr && O && lse2_b);
@@ -319,10 +324,10 @@ extern "C" int dgdm_spatial_attn_h_fwd_sparse(const void* Rq, const void* Rk, co
   do {                                                                                                                      \
     if (drop_p > 0.f)                                                                                                       \
       hipLaunchKernelGGL((k_attn_h_fwd<HG, true, NBUF, WPE>), dim3(num_blocks, H / HG), dim3(256), 0, s, q, k, v, pos_b, H, ptr, B,    \
-                         O, ldo, lse2_b, drop_p, dgdm_seed_arg(seed), skip_map);                                                   \
+                         O, ldo, lse2_b, drop_p, dgdm_seed_arg(seed), skip_map, amax_out);                                                   \
     else                                                                                                                    \
       hipLaunchKernelGGL((k_attn_h_fwd<HG, false, NBUF, WPE>), dim3(num_blocks, H / HG), dim3(256), 0, s, q, k, v, pos_b, H, ptr, B,   \
-                         O, ldo, lse2_b, 0.f, dgdm_seed_arg(0u), skip_map);                                                        \
+                         O, ldo, lse2_b, 0.f, dgdm_seed_arg(0u), skip_map, amax_out);                                                        \
   } while (0)
   // variant 0 = default; 1..3 select a tiling explicitly (tools/microbench_attn.py)
   if (H % 4 == 0 && variant == 1) GO(4, 2, 2);        // 4 heads, double-buffered, 2 workgroups per CU
@@ -340,5 +345,5 @@ extern "C" int dgdm_spatial_attn_h_fwd_sparse(const void* Rq, const void* Rk, co
 extern "C" int dgdm_spatial_attn_h_fwd(const void* Rq, const void* Rk, const void* Rv, const float* pos_b, const int32_t* ptr,
                                        int32_t B, int32_t num_blocks, int32_t H, float drop_p, uint32_t seed, float* O,
                                        int64_t ldo, float* lse2_b, int32_t variant, void* stream_) {
-  return dgdm_spatial_attn_h_fwd_sparse(Rq, Rk, Rv, pos_b, ptr, B, num_blocks, H, drop_p, seed, O, ldo, lse2_b, variant, nullptr, stream_);
+  return dgdm_spatial_attn_h_fwd_sparse(Rq, Rk, Rv, pos_b, ptr, B, num_blocks, H, drop_p, seed, O, ldo, lse2_b, variant, nullptr, nullptr, stream_);
 }

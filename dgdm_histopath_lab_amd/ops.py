@@ -322,11 +322,13 @@ def spatial_attn_h_fwd_raw(qkv, pos, plan: AttnPlan, H: int, scale: float, inv_t
     lse2_b = torch.empty(max(lib.dgdm_attn_pack_bytes(plan.num_q_tiles, H, 3) // 4, 4), dtype=torch.float32, device=qkv.device)
     if ATTN_SKIP_ZERO_BLOCKS and pk.skip_map is None and plan.num_q_tiles > 0:
         pk.skip_map = attn_skip_map(pk, plan, H)
+    slot = new_amax_slot(qkv.device)        # max |O| from the kernel itself: the output projection needs no reduction launch
     TIMERS.timed("attn_fwd", lambda: _lib.check(
         lib.dgdm_spatial_attn_h_fwd_sparse(pk.r(0).data_ptr(), pk.r(1).data_ptr(), pk.r(2).data_ptr(), pk.pos_b.data_ptr(),
                                            plan.ptr_dev.data_ptr(), plan.B, plan.num_q_tiles, H, drop_p, seed, out.data_ptr(),
-                                           out.stride(0), lse2_b.data_ptr(), variant, _lib.ptr(pk.skip_map), _lib.stream_ptr(qkv.device)),
+                                           out.stride(0), lse2_b.data_ptr(), variant, _lib.ptr(pk.skip_map), slot, _lib.stream_ptr(qkv.device)),
         "dgdm_spatial_attn_h_fwd_sparse"))
+    tag_amax(out, slot)
     return out, lse2_b, pk
 
 
@@ -391,16 +393,18 @@ def spatial_attn_h_bwd_raw(pk: PackedOperands, out, gout, plan: AttnPlan, H: int
             groups.append((sb, cnt, lib.dgdm_spatial_attn_h_bwd_fused_workspace_bytes(ph, plan.B, H, sb, cnt)))
             sb += cnt
         ws = torch.empty(max(max(g[2] for g in groups), 16) // 4, dtype=torch.float32, device=out.device)
+        slot = new_amax_slot(out.device)    # max |dQ|, |dK|, |dV| from the kernels that write them (dqkv is the QKV projection's operand)
 
         for sb0, cnt, wsb in groups:
             TIMERS.timed("attn_bwd_fused", lambda: _lib.check(lib.dgdm_spatial_attn_h_bwd_fused_sparse(
                 pk.r(0).data_ptr(), pk.r(1).data_ptr(), pk.r(2).data_ptr(), gk.r(0).data_ptr(), pk.pos_b.data_ptr(), gk.nlse_b.data_ptr(),
                 gk.ndelta_b.data_ptr(), plan.ptr_dev.data_ptr(), ph, plan.B, plan.num_q_tiles, H, drop_p, seed, gs.data_ptr(),
                 dqkv[:, C:2 * C].data_ptr(), dqkv[:, 2 * C:].data_ptr(), dqkv.stride(0), sb0, cnt, ws.data_ptr(), ws.numel() * 4,
-                _lib.ptr(pk.skip_map), st), "dgdm_spatial_attn_h_bwd_fused_sparse"))
+                _lib.ptr(pk.skip_map), slot, st), "dgdm_spatial_attn_h_bwd_fused_sparse"))
             TIMERS.timed("attn_bwd_dq_reduce", lambda: _lib.check(lib.dgdm_spatial_attn_h_bwd_fused_reduce_sparse(
                 plan.ptr_dev.data_ptr(), ph, plan.B, plan.num_q_tiles, H, scale, gs.data_ptr(), dqkv[:, :C].data_ptr(), dqkv.stride(0), sb0, cnt,
-                ws.data_ptr(), ws.numel() * 4, _lib.ptr(pk.skip_map), st), "dgdm_spatial_attn_h_bwd_fused_reduce_sparse"))
+                ws.data_ptr(), ws.numel() * 4, _lib.ptr(pk.skip_map), slot, st), "dgdm_spatial_attn_h_bwd_fused_reduce_sparse"))
+        tag_amax(dqkv, slot)
         if overlap_ev is not None:
             cur, side = torch.cuda.current_stream(out.device), _side_stream(out.device)
             side.wait_event(overlap_ev)
@@ -1223,7 +1227,7 @@ def ensure_amax(t: torch.Tensor) -> int:
     if slot is None:
         if AMAX_FALLBACK_LOG is not None:       # diagnostics (tools/attic/amax_fallbacks.py): who still needs a reduction launch?
             import traceback
-            fr = [f for f in traceback.extract_stack(limit=12) if "dgdm_histopath_lab_amd" in f.filename][-5:-1]
+            fr = [f for f in traceback.extract_stack(limit=30) if "dgdm_histopath_lab_amd" in f.filename][-9:-1]
             AMAX_FALLBACK_LOG.append((tuple(t.shape), " < ".join(f"{f.name}:{f.lineno}" for f in reversed(fr))))
         slot = _arena(t.device).take()
         _lib.check(_lib.load().dgdm_amax_bits(t.data_ptr(), _ld(t), t.size(0), t.size(1), slot, _lib.stream_ptr(t.device)), "dgdm_amax_bits")

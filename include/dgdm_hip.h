@@ -315,7 +315,10 @@ DGDM_API int dgdm_spatial_attn_h_bwd_fused_reduce(const int32_t* ptr, const int3
  * every row maximum of the query block, from per-block bounds of the packed operands (two small launches); the `_sparse` forms of the
  * forward and of the one-pass backward walk those pairs over -- same bits in every output as the plain forms (the skipped products are
  * exact zeros), a band's worth of work on real slides, nothing skipped for positions in [0, 1).  skip_map == NULL: the plain forms.
- * The map of a forward call must be handed unchanged to its backward and to the backward's reduction. */
+ * The map of a forward call must be handed unchanged to its backward and to the backward's reduction.
+ * amax_out (nullable, these three calls): a zeroed operand-maximum slot group (the layout dgdm_amax_bits fills) that receives
+ * max |O| (forward) / max |dK|, |dV| (backward) and max |dQ| (reduction): the projections that consume these tensors then need no
+ * reduction launch of their own. */
 DGDM_API size_t dgdm_attn_skip_map_bytes(int32_t num_blocks, int32_t H);
 DGDM_API size_t dgdm_attn_skip_map_workspace_bytes(int32_t num_blocks, int32_t H);
 DGDM_API int dgdm_attn_skip_map_build(const void* Rq, const void* Rk, const float* pos_b, const int32_t* ptr, int32_t B,
@@ -323,17 +326,19 @@ DGDM_API int dgdm_attn_skip_map_build(const void* Rq, const void* Rk, const floa
                                       size_t map_bytes, void* stream);
 DGDM_API int dgdm_spatial_attn_h_fwd_sparse(const void* Rq, const void* Rk, const void* Rv, const float* pos_b, const int32_t* ptr,
                                             int32_t B, int32_t num_blocks, int32_t H, float drop_p, uint32_t seed, float* O,
-                                            int64_t ldo, float* lse2_b, int32_t variant, const uint32_t* skip_map, void* stream);
+                                            int64_t ldo, float* lse2_b, int32_t variant, const uint32_t* skip_map, uint32_t* amax_out,
+                                            void* stream);
 DGDM_API int dgdm_spatial_attn_h_bwd_fused_sparse(const void* Rq, const void* Rk, const void* Rv, const void* Rg, const float* pos_b,
                                                   const float* lse_adj_b, const float* ndelta_b, const int32_t* ptr,
                                                   const int32_t* ptr_host, int32_t B, int32_t num_blocks, int32_t H, float drop_p,
                                                   uint32_t seed, const float* grad_scale2, float* dK, float* dV, int64_t ldg,
                                                   int32_t sb_first, int32_t sb_count, void* workspace, size_t workspace_bytes,
-                                                  const uint32_t* skip_map, void* stream);
+                                                  const uint32_t* skip_map, uint32_t* amax_out, void* stream);
 DGDM_API int dgdm_spatial_attn_h_bwd_fused_reduce_sparse(const int32_t* ptr, const int32_t* ptr_host, int32_t B, int32_t num_blocks,
                                                          int32_t H, float scale, const float* grad_scale2, float* dQ, int64_t ldg,
                                                          int32_t sb_first, int32_t sb_count, const void* workspace,
-                                                         size_t workspace_bytes, const uint32_t* skip_map, void* stream);
+                                                         size_t workspace_bytes, const uint32_t* skip_map, uint32_t* amax_out,
+                                                         void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K5  out = x + sinusoidal_2d_posenc(pos)  for a whole batch.  Replaces
