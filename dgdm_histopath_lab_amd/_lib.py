@@ -83,7 +83,7 @@ SIGNATURES = {
     "dgdm_qsample": (C.c_int, [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _p]),
     "dgdm_segment_mse_workspace_bytes": (_sz, [_i32]),
     "dgdm_segment_mse_fwd": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _p, _p, _sz, _p]),
-    "dgdm_segment_mse_bwd": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _p, _p]),
+    "dgdm_segment_mse_bwd": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _p]),
     "dgdm_mask_rows": (C.c_int, [_p, _p, _p, _i32, _i32, _p, _p, _p]),
     "dgdm_ddpm_step": (C.c_int, [_p, _p, _p, _i64, C.c_float, C.c_float, C.c_float, C.c_float, _i32, _p, _p]),
     "dgdm_pool_score_fwd": (C.c_int, [_p, _i64, _p, _p, _i32, _i32, _p, _p, _i32, _p]),
@@ -91,7 +91,7 @@ SIGNATURES = {
     "dgdm_vec_softmax_bwd": (C.c_int, [_p, _p, _i32, _p, _p]),
     "dgdm_count_ge": (C.c_int, [_p, _i32, C.c_float, _p, _p]),
     "dgdm_pool_score_bwd_workspace_bytes": (_sz, [_i32, _i32]),
-    "dgdm_pool_score_bwd": (C.c_int, [_p, _i64, _p, _p, _p, _i32, _i32, _p, _i64, _p, _p, _p, _i32, _p, _sz, _p]),
+    "dgdm_pool_score_bwd": (C.c_int, [_p, _i64, _p, _p, _p, _i32, _i32, _p, _i64, _p, _p, _p, _i32, _p, _sz, _p, _p]),
     "dgdm_topk_perm_workspace_bytes": (_sz, [_i32]),
     "dgdm_topk_perm": (C.c_int, [_p, _i32, _i32, _p, _p, _p, _sz, _p]),
     "dgdm_pool_gather_fwd": (C.c_int, [_p, _i64, _p, _p, _i32, _i32, C.c_float, _p, _i64, _p]),

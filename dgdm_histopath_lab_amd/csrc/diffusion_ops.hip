@@ -77,16 +77,20 @@ __global__ __launch_bounds__(64) void k_mse_stage2(const float* __restrict__ par
 
 __global__ __launch_bounds__(256) void k_mse_bwd(const float* __restrict__ pred, const float* __restrict__ target, const float* __restrict__ gloss,
                                                  const int32_t* __restrict__ ptr, int B, int C, int64_t n4total, int c4,
-                                                 float* __restrict__ dpred) {
+                                                 float* __restrict__ dpred, unsigned* __restrict__ amax) {
   const float gl = gloss[0];
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  unsigned am = 0;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4total; i += stride) {
     const int g = graph_of(ptr, B, (int)(i / c4));
     const int n = ptr[g + 1] - ptr[g];
     const float w = 2.f * gl / ((float)B * (float)n * (float)C);
     const float4 p = reinterpret_cast<const float4*>(pred)[i], q = reinterpret_cast<const float4*>(target)[i];
-    reinterpret_cast<float4*>(dpred)[i] = make_float4(w * (p.x - q.x), w * (p.y - q.y), w * (p.z - q.z), w * (p.w - q.w));
+    const float4 d = make_float4(w * (p.x - q.x), w * (p.y - q.y), w * (p.z - q.z), w * (p.w - q.w));
+    reinterpret_cast<float4*>(dpred)[i] = d;
+    am = dgdm_amax4(am, d);
   }
+  if (amax) dgdm_amax_commit(am, amax);     // the gradient is the operand of the denoiser's last dX / dW GEMMs
 }
 
 __global__ __launch_bounds__(256) void k_mask_rows(const float* __restrict__ x, const int32_t* __restrict__ node_map, const float* __restrict__ token,
@@ -138,14 +142,14 @@ extern "C" int dgdm_segment_mse_fwd(const float* pred, const float* target, cons
 }
 
 extern "C" int dgdm_segment_mse_bwd(const float* pred, const float* target, const float* gloss, const int32_t* ptr, int32_t B, int32_t N,
-                                    int32_t C, float* dpred, void* stream) {
+                                    int32_t C, float* dpred, uint32_t* amax, void* stream) {
   DGDM_REQUIRE(B > 0 && N >= 0 && C > 0);
   if (N == 0) return DGDM_OK;
   DGDM_REQUIRE(pred && target && gloss && ptr && dpred);
   if ((C & 3) || !dgdm_aligned16(pred) || !dgdm_aligned16(target) || !dgdm_aligned16(dpred)) return DGDM_ERR_UNSUPPORTED;
   const int64_t n4 = (int64_t)N * (C >> 2);
   hipLaunchKernelGGL(k_mse_bwd, dim3(stream_blocks(n4)), dim3(256), 0, static_cast<hipStream_t>(stream), pred, target, gloss, ptr, B, C, n4,
-                     C >> 2, dpred);
+                     C >> 2, dpred, amax);
   return dgdm_launch_status();
 }
 

@@ -54,12 +54,14 @@ __global__ __launch_bounds__(256) void k_pool_score_fwd(const float* __restrict_
 __global__ __launch_bounds__(256) void k_pool_score_bwd(const float* __restrict__ h, int64_t ldh, const float* __restrict__ w2,
                                                         const float* __restrict__ s, const float* __restrict__ ds, int N, int C,
                                                         int rows_per_block, float* __restrict__ dh, int64_t lddh,
-                                                        double* __restrict__ partial, const uint8_t* __restrict__ decide, int nl) {
+                                                        double* __restrict__ partial, const uint8_t* __restrict__ decide, int nl,
+                                                        unsigned* __restrict__ amax) {
   // thread = (float4 column c4, row lane): C/4 <= 64 columns x (256 / cols) row lanes
   const int cols = C / 4;
   const int c4 = threadIdx.x % cols, rl = threadIdx.x / cols, nrl = 256 / cols;
   const int r0 = blockIdx.x * rows_per_block, r1 = min(N, r0 + rows_per_block);
   double ax = 0., ay = 0., az = 0., aw = 0., tsum = 0.;
+  unsigned am = 0;
   if (rl < nrl) {
     const float4 w = *reinterpret_cast<const float4*>(w2 + 4 * c4);
     for (int r = r0 + rl; r < r1; r += nrl) {
@@ -75,6 +77,7 @@ __global__ __launch_bounds__(256) void k_pool_score_bwd(const float* __restrict_
       g.x = px ? t * w.x : 0.f; g.y = py ? t * w.y : 0.f;
       g.z = pz ? t * w.z : 0.f; g.w = pw ? t * w.w : 0.f;
       *reinterpret_cast<float4*>(dh + (int64_t)r * lddh + 4 * c4) = g;
+      am = dgdm_amax4(am, g);
       const double td = (double)t;
       if (px) ax += td * (double)v.x;
       if (py) ay += td * (double)v.y;
@@ -98,6 +101,7 @@ __global__ __launch_bounds__(256) void k_pool_score_bwd(const float* __restrict_
     P[4 * c4 + 0] = ax; P[4 * c4 + 1] = ay; P[4 * c4 + 2] = az; P[4 * c4 + 3] = aw;
     if (c4 == 0) P[C] = tsum;
   }
+  if (amax) dgdm_amax_commit(am, amax);     // dh is the operand of the score MLP's first-layer dX / dW GEMMs
 }
 
 // column sums of the float64 block partials, rounded to fp32 once: columns [0, C) -> dw2, column C -> db2.  One workgroup per column,
@@ -505,7 +509,7 @@ extern "C" size_t dgdm_pool_score_bwd_workspace_bytes(int32_t N, int32_t C) {
 
 extern "C" int dgdm_pool_score_bwd(const float* h, int64_t ldh, const float* w2, const float* s, const float* ds, int32_t N, int32_t C,
                                    float* dh, int64_t lddh, float* dw2, float* db2, const uint8_t* decide, int32_t nonlinearity,
-                                   void* workspace, size_t workspace_bytes, void* stream_) {
+                                   void* workspace, size_t workspace_bytes, uint32_t* amax, void* stream_) {
   if (N < 0 || C <= 0 || nonlinearity < 0 || nonlinearity > 2) return DGDM_ERR_INVALID_ARG;
   if (!dw2 || !db2) return DGDM_ERR_INVALID_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream_);
@@ -521,7 +525,7 @@ extern "C" int dgdm_pool_score_bwd(const float* h, int64_t ldh, const float* w2,
   const int nb = (N + rpb - 1) / rpb;
   double* partial = static_cast<double*>(workspace);       // torch allocations are 256-byte aligned; checked below
   if (reinterpret_cast<uintptr_t>(workspace) & 7) return DGDM_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(k_pool_score_bwd, dim3(nb), dim3(256), 0, st, h, ldh, w2, s, ds, N, C, rpb, dh, lddh, partial, decide, nonlinearity);
+  hipLaunchKernelGGL(k_pool_score_bwd, dim3(nb), dim3(256), 0, st, h, ldh, w2, s, ds, N, C, rpb, dh, lddh, partial, decide, nonlinearity, amax);
   hipLaunchKernelGGL(k_pool_score_bwd_final, dim3(C + 1), dim3(256), 0, st, partial, nb, C, dw2, db2);
   return dgdm_launch_status();
 }

@@ -906,9 +906,10 @@ class _SegmentMSE(torch.autograd.Function):
         plan = ctx.plan
         gloss = _f32c(gloss.reshape(1))
         dpred = torch.empty_like(pred)
+        slot = new_amax_slot(pred.device)
         _lib.check(lib.dgdm_segment_mse_bwd(pred.data_ptr(), target.data_ptr(), gloss.data_ptr(), plan.ptr_dev.data_ptr(), plan.B, pred.size(0),
-                                            pred.size(1), dpred.data_ptr(), _lib.stream_ptr(pred.device)), "dgdm_segment_mse_bwd")
-        return dpred, None, None
+                                            pred.size(1), dpred.data_ptr(), slot, _lib.stream_ptr(pred.device)), "dgdm_segment_mse_bwd")
+        return tag_amax(dpred, slot), None, None
 
 
 def segment_mse(pred, target, plan: AttnPlan):
@@ -2308,10 +2309,11 @@ class _PoolScore(torch.autograd.Function):
         db2 = torch.empty(1, dtype=torch.float32, device=h.device)
         wsb = _lib.workspace_bytes("dgdm_pool_score_bwd_workspace_bytes", N, C2)
         ws = torch.empty(max(wsb, 4) // 4, dtype=torch.float32, device=h.device)
+        slot = new_amax_slot(h.device)
         _lib.check(lib.dgdm_pool_score_bwd(h.data_ptr(), h.stride(0), w2c.data_ptr(), s.data_ptr(), ds.data_ptr(), N, C2, dh.data_ptr(),
                                            dh.stride(0), dw2.data_ptr(), db2.data_ptr(), _lib.ptr(ctx.decide), ctx.nl, ws.data_ptr(), wsb,
-                                           _lib.stream_ptr(h.device)), "dgdm_pool_score_bwd")
-        return dh, dw2.view(ctx.w2_shape), db2.view(ctx.b2_shape), None, None
+                                           slot, _lib.stream_ptr(h.device)), "dgdm_pool_score_bwd")
+        return tag_amax(dh, slot), dw2.view(ctx.w2_shape), db2.view(ctx.b2_shape), None, None
 
 
 class _VecSoftmax(torch.autograd.Function):

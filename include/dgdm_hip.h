@@ -455,7 +455,8 @@ DGDM_API int dgdm_segment_max_bwd(const float* gout, const int32_t* arg, const i
  *   dgdm_qsample : out[n,:] = tab_a[t_g] * x[n,:] + tab_b[t_g] * eps[n,:]  (tab_a = sqrt(alphas_cumprod),
  *                  tab_b = sqrt(1 - alphas_cumprod), DEVICE tables [T]); eps = NULL: out = tab_a[t_g] * x (the backward).
  *   dgdm_segment_mse_fwd : loss[0] = (1/B) sum_g mse(pred_g, target_g) (dgdm_model.py:430-433), two fixed-order stages.
- *   dgdm_segment_mse_bwd : dpred[n,:] = gloss[0] * 2 / (B n_g C) * (pred[n,:] - target[n,:])   (gloss: DEVICE scalar).
+ *   dgdm_segment_mse_bwd : dpred[n,:] = gloss[0] * 2 / (B n_g C) * (pred[n,:] - target[n,:])   (gloss: DEVICE scalar); amax (nullable):
+ *                  a zeroed operand-maximum slot group that receives max |dpred| (as dgdm_mask_rows' does for its output).
  *   dgdm_mask_rows : out[n,:] = node_map[n] >= 0 ? token[:] : x[n,:]  (entity masking, dgdm_model.py:494-503, with the
  *                  node_map of dgdm_topk_perm over N uniform variates = a uniformly random subset of the masked size).
  * C, F % 4 == 0; float pointers 16-byte aligned. */
@@ -465,7 +466,7 @@ DGDM_API size_t dgdm_segment_mse_workspace_bytes(int32_t B);
 DGDM_API int dgdm_segment_mse_fwd(const float* pred, const float* target, const int32_t* ptr, int32_t B, int32_t N, int32_t C,
                                   float* loss, void* workspace, size_t workspace_bytes, void* stream);
 DGDM_API int dgdm_segment_mse_bwd(const float* pred, const float* target, const float* gloss, const int32_t* ptr, int32_t B,
-                                  int32_t N, int32_t C, float* dpred, void* stream);
+                                  int32_t N, int32_t C, float* dpred, uint32_t* amax, void* stream);
 DGDM_API int dgdm_mask_rows(const float* x, const int32_t* node_map, const float* token, int32_t N, int32_t F, float* out,
                             uint32_t* amax, void* stream);
 
@@ -722,7 +723,7 @@ DGDM_API int dgdm_count_ge(const float* s, int32_t N, float threshold, int32_t* 
 DGDM_API size_t dgdm_pool_score_bwd_workspace_bytes(int32_t N, int32_t C);
 DGDM_API int dgdm_pool_score_bwd(const float* h, int64_t ldh, const float* w2, const float* s, const float* ds, int32_t N, int32_t C,
                                  float* dh, int64_t lddh, float* dw2, float* db2, const uint8_t* decide, int32_t nonlinearity,
-                                 void* workspace, size_t workspace_bytes, void* stream);
+                                 void* workspace, size_t workspace_bytes, uint32_t* amax, void* stream);
 DGDM_API size_t dgdm_topk_perm_workspace_bytes(int32_t N);
 DGDM_API int dgdm_topk_perm(const float* s, int32_t N, int32_t k, int64_t* perm, int32_t* node_map, void* workspace,
                             size_t workspace_bytes, void* stream);
