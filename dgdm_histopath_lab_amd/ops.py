@@ -2055,12 +2055,37 @@ def graph_conv_linear(x, ea_hat, gs: GraphStructure, w, we, b, skip: bool = Fals
 # same instructions over all 1024 SIMDs.  At 5 000 rows: GEMM 7.3 us, + activation kernel 10.5, fused 16.9; at 40 000 rows a draw
 # (22.3 / 22.3); LayerNorm epilogue 29.4 against 25.9; whole step 13.07 against 13.00 ms.  So the default keeps every activation /
 # norm behind a GEMM in a kernel of its own; True selects the fused path (same-box A/B, the parity tests run both).
+# "auto": only what the measurements favour -- DynamicGraphLayer as one autograd node whose two activation BACKWARDS are epilogues of
+# the GEMMs that form their incoming gradients when the layer has at least FUSE_AUTO_MIN_ROWS rows (the bold cells of DESIGN.md
+# section 4 "Round 5": 23.2 against 25.0 us at 40 000 x 128, 135 against 144 at 40 000 x 544 -> 512); every forward activation and
+# every norm stays a kernel of its own.
 FUSE_EPILOGUES = False
+FUSE_AUTO_MIN_ROWS = 20000
 
 
-def epilogues_available(*widths: int) -> bool:
-    """The fused-epilogue GEMMs are the weight-image kernels: fp16 hi+lo arithmetic, every reduction length a multiple of 16."""
-    return FUSE_EPILOGUES and USE_WEIGHT_IMAGES and GEMM_MATH == "f16x2" and all(w % 16 == 0 and w >= 16 for w in widths)
+def epilogues_available(*widths: int, auto_ok: bool = False) -> bool:
+    """The fused-epilogue GEMMs are the weight-image kernels: fp16 hi+lo arithmetic, every reduction length a multiple of 16.
+    ``auto_ok``: the caller has a form for FUSE_EPILOGUES == "auto" (only `_GraphLayer` does)."""
+    on = FUSE_EPILOGUES is True or (auto_ok and FUSE_EPILOGUES == "auto")
+    return on and USE_WEIGHT_IMAGES and GEMM_MATH == "f16x2" and all(w % 16 == 0 and w >= 16 for w in widths)
+
+
+def _act_raw(pre, act: int, drop_p: float, seed: int):
+    """dropout(act(pre)) by the streaming kernel (what a fused forward epilogue replaces); the result carries its operand maximum."""
+    y = torch.empty_like(pre)
+    slot = new_amax_slot(pre.device)
+    _lib.check(_lib.load().dgdm_act_dropout_fwd(pre.data_ptr(), pre.numel(), act, drop_p, seed, y.data_ptr(), None, slot,
+                                                _lib.stream_ptr(pre.device)), "dgdm_act_dropout_fwd")
+    return tag_amax(y, slot)
+
+
+def _act_bwd_raw(pre, g, act: int, drop_p: float, seed: int):
+    """g * act'(pre) * mask in place of g (the streaming backward kernel)."""
+    slot = new_amax_slot(pre.device)
+    _lib.check(_lib.load().dgdm_act_dropout_bwd(pre.data_ptr(), g.data_ptr(), pre.numel(), act, drop_p, seed, g.data_ptr(), None, slot,
+                                                _lib.stream_ptr(pre.device)), "dgdm_act_dropout_bwd")
+    g._dgdm_amax = None
+    return tag_amax(g, slot)
 
 
 def gemm_img_act_raw(a, e: "_WImage", ncols: int, bias, act: int, drop_p: float, seed: int, want_pre: bool = True):
@@ -2208,11 +2233,20 @@ class _GraphLayer(torch.autograd.Function):
         ea_hat = _rowmajor(ea_hat)
         w1, w2, wo = _rm_tagged(w1), _rm_tagged(w2), _rm_tagged(wo)
         hid, node = w1.size(0), wo.size(0)
+        full = FUSE_EPILOGUES is True           # "auto": forward activations and the norm stay kernels of their own
         z1 = _spmm_concat_raw(x, ea_hat, gs)
-        h1, pre1 = gemm_img_act_raw(z1, WEIGHT_IMAGES.get(0, w1, we1), hid, b1, ACT_GELU, drop_p, seeds[0])
+        if full:
+            h1, pre1 = gemm_img_act_raw(z1, WEIGHT_IMAGES.get(0, w1, we1), hid, b1, ACT_GELU, drop_p, seeds[0])
+        else:
+            pre1 = _gemm_rows_img(z1, WEIGHT_IMAGES.get(0, w1, we1), 0, hid, b1, None, False)
+            h1 = _act_raw(pre1, ACT_GELU, drop_p, seeds[0])
         z2 = _spmm_concat_raw(h1, ea_hat, gs)
-        h2, pre2 = gemm_img_act_raw(z2, WEIGHT_IMAGES.get(0, w2, we2), hid, b2, ACT_GELU, drop_p, seeds[1])
-        fused_norm = gemm_img_norm_supported(node, 1)
+        if full:
+            h2, pre2 = gemm_img_act_raw(z2, WEIGHT_IMAGES.get(0, w2, we2), hid, b2, ACT_GELU, drop_p, seeds[1])
+        else:
+            pre2 = _gemm_rows_img(z2, WEIGHT_IMAGES.get(0, w2, we2), 0, hid, b2, None, False)
+            h2 = _act_raw(pre2, ACT_GELU, drop_p, seeds[1])
+        fused_norm = full and gemm_img_norm_supported(node, 1)
         if fused_norm:
             y, ssum, mean, rstd = gemm_img_norm_raw(h2, WEIGHT_IMAGES.get(0, wo), node, bo, x, gamma, beta, 1, eps)
             res = None
@@ -2246,10 +2280,17 @@ class _GraphLayer(torch.autograd.Function):
         claim = lambda *idx: ctx.leaf and _claim_deferred(*(P[i] for i in idx))
         ds, dgam, dbet = rownorm_bwd_raw(ssum, res, gamma, beta, mean, rstd, gy, 1, ACT_NONE, 0.0, 0, (P[8], P[9]) if ctx.leaf else None)
         dwo, dbo = gemm_tn_raw(ds, h2, True, math="f16x2", may_defer=claim(6, 7))
-        dpre2 = gemm_img_act_bwd_raw(ds, WEIGHT_IMAGES.get(1, wo), hid, pre2, ACT_GELU, drop_p, seeds[1])
+        fuse_bwd = FUSE_EPILOGUES is True or ds.size(0) >= FUSE_AUTO_MIN_ROWS      # "auto": only where the epilogue beats the two launches
+        if fuse_bwd:
+            dpre2 = gemm_img_act_bwd_raw(ds, WEIGHT_IMAGES.get(1, wo), hid, pre2, ACT_GELU, drop_p, seeds[1])
+        else:
+            dpre2 = _act_bwd_raw(pre2, _gemm_rows_img(ds, WEIGHT_IMAGES.get(1, wo), 0, hid, None, None, False), ACT_GELU, drop_p, seeds[1])
         (dw2, dwe2), db2 = gemm_tn_raw(dpre2, z2, True, math="f16x2", split=hid, may_defer=claim(3, 4, 5))
         g2 = _spmm_t_amax_raw(dpre2, gs)
-        dpre1 = gemm_img_act_bwd_raw(g2, WEIGHT_IMAGES.get(1, w2), hid, pre1, ACT_GELU, drop_p, seeds[0])
+        if fuse_bwd:
+            dpre1 = gemm_img_act_bwd_raw(g2, WEIGHT_IMAGES.get(1, w2), hid, pre1, ACT_GELU, drop_p, seeds[0])
+        else:
+            dpre1 = _act_bwd_raw(pre1, _gemm_rows_img(g2, WEIGHT_IMAGES.get(1, w2), 0, hid, None, None, False), ACT_GELU, drop_p, seeds[0])
         (dw1, dwe1), db1 = gemm_tn_raw(dpre1, z1, True, math="f16x2", split=cin, may_defer=claim(0, 1, 2))
         dx = None
         if ctx.needs_input_grad[0]:
@@ -2261,7 +2302,7 @@ class _GraphLayer(torch.autograd.Function):
 def graph_layer_supported(x, ea_hat, node_dim: int, hidden: int, edge_dim: int) -> bool:
     return (ea_hat is not None and x.dim() == 2 and x.dtype == torch.float32 and x.is_cuda and x.size(0) >= GEMM_MIN_ROWS
             and x.size(1) == node_dim and ea_hat.size(1) == edge_dim
-            and epilogues_available(node_dim + edge_dim, hidden + edge_dim, hidden, node_dim))
+            and epilogues_available(node_dim + edge_dim, hidden + edge_dim, hidden, node_dim, auto_ok=True))
 
 
 def graph_layer(x, ea_hat, gs: GraphStructure, conv1, conv2, output_proj, norm, drop_p: float, training: bool):

@@ -281,15 +281,21 @@ def test_graph_conv_skip_alias_adds_the_residual_gradient_in_the_backward_kernel
 
 @pytest.mark.parametrize("node,hid,n,e", [(128, 128, 3000, 12000), (512, 256, 1500, 6000), (256, 128, 700, 3000), (64, 32, 300, 900)])
 @pytest.mark.parametrize("training", [False, True])
-def test_graph_layer_as_one_node_is_the_layer_of_separate_kernels(node, hid, n, e, training):
+@pytest.mark.parametrize("mode", [True, "auto", "auto-fused-backward"])
+def test_graph_layer_as_one_node_is_the_layer_of_separate_kernels(node, hid, n, e, training, mode, monkeypatch):
     """DynamicGraphLayer through ops._GraphLayer (activations and LayerNorm as GEMM epilogues, the second convolution's input gradient
     associated as (A^T dpre) . W) against the same module on the separate kernels (ops.FUSE_EPILOGUES = False): output and every
     gradient, eval mode and TRAINING mode -- both paths draw the same two dropout seeds in the same order and the epilogues' mask is
     the streaming kernels' function of (seed, element index), so the training-mode results agree to rounding as well; and against a
-    float64 composition of the reference's formula in eval mode (core/graph_layers.py:207-247)."""
+    float64 composition of the reference's formula in eval mode (core/graph_layers.py:207-247).  mode "auto" (ops.FUSE_EPILOGUES =
+    "auto"): the node with every forward activation and the norm as kernels of their own and the activation backwards as epilogues
+    only from ops.FUSE_AUTO_MIN_ROWS rows on -- both sides of that threshold run here."""
     from dgdm_histopath_lab_amd import ops
     from dgdm_histopath_lab_amd.core.graph_layers import DynamicGraphLayer, GraphContext
     DEV = "cuda:0"
+    if mode == "auto-fused-backward":
+        monkeypatch.setattr(ops, "FUSE_AUTO_MIN_ROWS", 1)
+        mode = "auto"
     torch.manual_seed(node + hid + n)
     layer = DynamicGraphLayer(node, 32, hid, num_heads=8).to(DEV).train(training)
     with torch.no_grad():
@@ -318,7 +324,7 @@ def test_graph_layer_as_one_node_is_the_layer_of_separate_kernels(node, hid, n, 
             ops.FUSE_EPILOGUES = was
         return y.detach(), x.grad, {k: dict(layer.named_parameters())[k].grad.clone() for k in names}, type(y.grad_fn).__name__
 
-    yf, dxf, gf, nf = run(True)
+    yf, dxf, gf, nf = run(mode)
     yu, dxu, gu, nu = run(False)
     assert "GraphLayer" in nf and "GraphLayer" not in nu
     assert_close(yf, yu, 2e-5, "output")

@@ -286,7 +286,7 @@ class _DropoutSites:
         return hook
 
 
-@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("fused", [False, True, "auto"])
 @pytest.mark.parametrize("hierarchical", [False, True])
 def test_training_mode_step_matches_oracle_under_the_kernels_own_masks(hierarchical, fused, monkeypatch):
     """The step bench.py times runs in TRAINING mode: hash dropout at ~35 sites (kernel-level evidence only).
