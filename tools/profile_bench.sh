@@ -14,5 +14,5 @@ rocprofv3 --kernel-trace --stats -d $OUT -- python3 $BENCH --steps 16 --warmup 3
 DB=$(find $OUT -name "*results.db" | head -1)
 python3 $R/tools/kernel_stats_from_db.py $DB "${MARKER:-k_attn_h_fwd}" 60 $R/gpurun_out/${TAG}_launch_sequence.txt > $R/gpurun_out/${TAG}_bench_kernel_stats.txt
 cp $OUT/bench_line.json $R/gpurun_out/${TAG}_bench_kernel_stats_bench_line.json
-rm -f $DB
+[ -n "$KEEP_DB" ] || rm -f $DB
 head -40 $R/gpurun_out/${TAG}_bench_kernel_stats.txt
