@@ -22,6 +22,8 @@ class DGDMKernelError(RuntimeError):
 
 _i32, _i64, _sz, _p = C.c_int32, C.c_int64, C.c_size_t, C.c_void_p
 
+ABI_VERSION = 2      # DGDM_ABI_VERSION of include/dgdm_hip.h that SIGNATURES below was written for
+
 # name -> (restype, argtypes); mirrors include/dgdm_hip.h (tests check the two stay in sync)
 SIGNATURES = {
     "dgdm_abi_version": (C.c_int, []),
@@ -47,6 +49,12 @@ SIGNATURES = {
     "dgdm_spatial_attn_gen_bwd": (C.c_int, [_p, _p, _p, _i64, _p, _p, _i32, _i32, _i32, _i32, _i32, C.c_float, C.c_float, C.c_float, C.c_uint32,
                                             _p, _p, _i64, _p, _p, _p, _p, _p, _i64, _p]),
     "dgdm_spatial_attn_gen_mean_weights": (C.c_int, [_p, _p, _i64, _p, _p, _i32, _i32, _i32, _i32, _i32, C.c_float, C.c_float, _p, _p, _p, _p]),
+    "dgdm_attn_dense_fwd": (C.c_int, [_p, _i64, _p, _p, _i64, _i32, _i32, _i32, _i32, _i32, C.c_float, _p, _p, _i64, _i64, _i64, _i64, _p, _p, _p,
+                                      C.c_float, C.c_float, C.c_uint32, _p, _i64, _p, _p]),
+    "dgdm_attn_dense_bwd": (C.c_int, [_p, _i64, _p, _p, _i64, _i32, _i32, _i32, _i32, _i32, C.c_float, _p, _p, _i64, _i64, _i64, _i64, _p, _p, _p,
+                                      C.c_float, C.c_float, C.c_uint32, _p, _p, _i64, _p, _p, _p, _i64, _p, _p, _i64, _p]),
+    "dgdm_attn_dense_weights": (C.c_int, [_p, _i64, _p, _i64, _i32, _i32, _i32, _i32, _i32, C.c_float, _p, _p, _i64, _i64, _i64, _i64, _p, _p, _p,
+                                          C.c_float, C.c_float, C.c_uint32, _p, _i32, _p, _p]),
     "dgdm_add_posenc": (C.c_int, [_p, _i64, _p, _p, _i32, _i32, _i32, _p, _p, _i64, _p, _p]),
     "dgdm_spatial_attn_mean_weights": (C.c_int, [_p, _p, _i64, _p, _p, _i32, _i32, _i32, _i32, C.c_float, C.c_float, _p, _p, _p, _p]),
     "dgdm_rownorm_fwd": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, C.c_float, _i32, C.c_float, C.c_uint32, _p, _p, _p, _p, _p]),
@@ -218,8 +226,16 @@ def load(build_if_missing: bool = False) -> C.CDLL:
         except AttributeError as e:
             raise DGDMKernelError(f"{LIB_PATH} does not export {name}; rebuild the extension") from e
         fn.restype, fn.argtypes = res, args
+    _check_version(lib, LIB_PATH)
     _lib = lib
     return lib
+
+
+def _check_version(lib: C.CDLL, path: str) -> None:
+    got = lib.dgdm_abi_version()
+    if got != ABI_VERSION:
+        raise DGDMKernelError(f"{path} reports C-ABI version {got}, this binding was written for {ABI_VERSION}: rebuild the extension "
+                              "(python -m dgdm_histopath_lab_amd._build); calling through a shifted argument list is not an error code")
 
 
 def open_library(path: str) -> C.CDLL:
@@ -228,6 +244,7 @@ def open_library(path: str) -> C.CDLL:
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
+    _check_version(lib, path)
     return lib
 
 

@@ -145,13 +145,40 @@ class DiffusionLayer(nn.Module):
             a, b = a.unsqueeze(-1), b.unsqueeze(-1)
         return a * x_start + b * noise
 
+    def condition_features(self, condition: Optional[Tensor], rows: int) -> Optional[Tensor]:
+        """condition_net(condition) (diffusion.py:158-161), [1, hidden] or [rows, hidden]; None without a condition or without a
+        ``condition_net`` (the reference ignores the argument then: ``if condition is not None and self.condition_net is not None``)."""
+        if condition is None or self.condition_net is None:
+            return None
+        c = condition.reshape(1, -1) if condition.dim() == 1 else condition
+        if c.dim() != 2 or c.size(0) not in (1, rows):
+            raise ValueError(f"condition must be [1, {self.condition_net.in_features}] or one row per node [{rows}, ...], got {tuple(condition.shape)}")
+        return ops.lin(self.condition_net, c)
+
+    def _first_layer_rows(self, x: Tensor, emb: Tensor) -> Tensor:
+        """denoise_net[0..3] on [x | emb] with one embedding PER ROW (a per-row condition): the concatenation the reference forms
+        (diffusion.py:165-170), one GEMM over K = node_dim + hidden, then GroupNorm + SiLU + dropout in the row kernel."""
+        lin0, gn, drop = self.denoise_net[0], self.denoise_net[1], self.denoise_net[3]
+        h = ops.lin(lin0, torch.cat([x, emb], dim=1))
+        return ops.row_norm(h, gn.weight, gn.bias, groups=gn.num_groups, eps=gn.eps, act=ops.ACT_SILU, drop_p=drop.p, training=self.training)
+
     def predict_noise(self, x_noisy: Tensor, timesteps: Tensor, condition: Optional[Tensor] = None) -> Tensor:
-        if condition is not None:
-            raise NotImplementedError("conditioning is not used by DGDMModel")
         if x_noisy.dim() != 2:
             raise ValueError("predict_noise expects [N, C] (the 3-D form cannot run in the reference: GroupNorm, D5)")
-        seg = torch.zeros(x_noisy.size(0), dtype=torch.long, device=x_noisy.device)
-        return self.predict_noise_segments(x_noisy, timesteps[:1], seg)
+        ce = self.condition_features(condition, x_noisy.size(0))
+        if ce is None:
+            seg = torch.zeros(x_noisy.size(0), dtype=torch.long, device=x_noisy.device)
+            return self.predict_noise_segments(x_noisy, timesteps[:1], seg)
+        self._check_group_norms()
+        te = self.time_features(timesteps[:1]) + ce                  # t_emb + cond_emb (diffusion.py:160-161)
+        if ce.size(0) == 1:                                          # one condition for every row: it rides in the per-graph bias
+            lin0 = self.denoise_net[0]
+            plan = ops.AttnPlan([0, x_noisy.size(0)], x_noisy.device)
+            h = ops.denoise_first_layer(x_noisy, te, lin0.weight, lin0.bias, plan, norm=self.denoise_net[1], drop_p=self.denoise_net[3].p,
+                                        training=self.training)
+        else:
+            h = self._first_layer_rows(x_noisy, te)
+        return self._denoise_tail(h)
 
     def forward(self, x_start: Tensor, timesteps: Optional[Tensor] = None, noise: Optional[Tensor] = None,
                 condition: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
@@ -172,8 +199,6 @@ class DiffusionLayer(nn.Module):
         update kernel (dgdm_ddpm_step) and one normal draw -- 7 launches, no host synchronisation.  The time-embedding MLP runs
         ONCE for the <= T distinct timesteps before the loop (3 small-M launches).  ``graphed=True`` records the whole loop as one
         HIP graph per (rows, steps) and replays it (fresh draws on every replay through torch's graph-aware generator)."""
-        if condition is not None:
-            raise NotImplementedError("conditioning is not used by DGDMModel")
         if len(shape) != 2 or shape[1] != self.node_dim:
             raise ValueError(f"sample expects shape [N, {self.node_dim}] (the 3-D form cannot run in the reference: GroupNorm, D5)")
         device = torch.device(device)
@@ -182,8 +207,9 @@ class DiffusionLayer(nn.Module):
         x = torch.randn(shape, device=device) if x_init is None else x_init.to(device=device, dtype=torch.float32).contiguous()
         if step_noise is not None:
             step_noise = [z.to(device=device, dtype=torch.float32).contiguous() for z in step_noise]
-        if not graphed:
-            return self._sample_loop(x, ts, step_noise)
+        ce = self.condition_features(None if condition is None else condition.to(device), shape[0])
+        if not graphed or ce is not None:      # a condition is a caller-owned tensor: that loop is not recorded
+            return self._sample_loop(x, ts, step_noise, ce)
         key = (tuple(shape), steps, str(device), self.training, step_noise is not None)
         cache = self.__dict__.setdefault("_sample_graphs", {})
         if key not in cache:
@@ -221,14 +247,22 @@ class DiffusionLayer(nn.Module):
         ops.amax_recording_replayed(amax_rec)
         return out.clone()
 
-    def _sample_loop(self, x: Tensor, ts: List[int], step_noise: Optional[List[Tensor]]) -> Tensor:
+    def _sample_loop(self, x: Tensor, ts: List[int], step_noise: Optional[List[Tensor]], ce: Optional[Tensor] = None) -> Tensor:
         device, C = x.device, self.node_dim
         sch = self.scheduler
         # fp32 table arithmetic as the reference does it on its tensors (diffusion.py:245-270), then host scalars
         s1mac, sac = torch.sqrt(1 - sch.alphas_cumprod).tolist(), torch.sqrt(sch.alphas_cumprod).tolist()
         salpha, svar = torch.sqrt(sch.alphas).tolist(), torch.sqrt(sch.posterior_variance).tolist()
         # first-layer bias of every timestep 0..T-1 in one go (3 small-M launches; no host-to-device copy inside the loop)
-        bias = self.time_bias(ops.device_constant(range(self.num_timesteps), torch.long, device))       # [T, 2*hidden]
+        all_t = ops.device_constant(range(self.num_timesteps), torch.long, device)
+        tf = None
+        if ce is None:
+            bias = self.time_bias(all_t)                                                               # [T, 2*hidden]
+        elif ce.size(0) == 1:      # one condition: t_emb + cond_emb (diffusion.py:160-161) through the time half of the first layer
+            lin0 = self.denoise_net[0]
+            bias = ops.linear_small(self.time_features(all_t) + ce, lin0.weight[:, C:], lin0.bias)
+        else:                      # a condition per row: the embedding enters as columns of the first GEMM's operand
+            tf = self.time_features(all_t)                                                             # [T, hidden]
         row = list(range(self.num_timesteps))
         w0x = self.denoise_net[0].weight[:, :C]
         gn1 = self.denoise_net[1]
@@ -236,8 +270,11 @@ class DiffusionLayer(nn.Module):
         for i, t in enumerate(ts):
             last = i == len(ts) - 1
             # first layer (the time half of its weight enters as the bias) with its GroupNorm + SiLU + dropout
-            h = ops.linear_norm(x, w0x, bias[row[t]], gn1.weight, gn1.bias, groups=gn1.num_groups, eps=gn1.eps, act=ops.ACT_SILU,
-                                drop_p=self.denoise_net[3].p, training=self.training)
+            if tf is not None:
+                h = self._first_layer_rows(x, ce + tf[row[t]])
+            else:
+                h = ops.linear_norm(x, w0x, bias[row[t]], gn1.weight, gn1.bias, groups=gn1.num_groups, eps=gn1.eps, act=ops.ACT_SILU,
+                                    drop_p=self.denoise_net[3].p, training=self.training)
             eps = self._denoise_tail(h)
             z = None if last else (torch.randn_like(x) if step_noise is None else step_noise[i])
             x = ops.ddpm_step(x, eps, z, s1mac[t], sac[t], salpha[t], svar[t], last)

@@ -32,9 +32,16 @@ class GraphContext:
 
     __slots__ = ("gs", "ea_hat", "num_nodes", "edge_index", "edge_attr")
 
-    def __init__(self, edge_index: Tensor, num_nodes: int, edge_attr: Optional[Tensor] = None, add_loops: bool = True):
-        self.gs = GraphStructure(edge_index, num_nodes, add_loops=add_loops)
-        self.ea_hat = ops.aggregate_edge_attr(edge_attr, self.gs)  # None when there are no attributes
+    def __init__(self, edge_index: Tensor, num_nodes: int, edge_attr: Optional[Tensor] = None, add_loops: bool = True,
+                 normalize: bool = True):
+        self.gs = GraphStructure(edge_index, num_nodes, add_loops=add_loops, normalize=normalize)
+        if edge_attr is not None and edge_attr.dim() == 2 and edge_attr.size(1) % 4:
+            # the gather kernels move 16-byte pieces: attribute widths that are not multiples of 4 get zero columns (the matching
+            # zero columns of edge_lin.weight are added by GraphConvolution.forward; the products are unchanged)
+            edge_attr_k = F.pad(edge_attr, (0, -edge_attr.size(1) % 4))
+        else:
+            edge_attr_k = edge_attr
+        self.ea_hat = ops.aggregate_edge_attr(edge_attr_k, self.gs)  # None when there are no attributes
         self.num_nodes = num_nodes
         self.edge_index, self.edge_attr = edge_index, edge_attr
 
@@ -60,8 +67,6 @@ class GraphConvolution(nn.Module):
     def __init__(self, in_channels: int, out_channels: int, edge_dim: Optional[int] = None, bias: bool = True,
                  add_self_loops: bool = True, normalize: bool = True, **kwargs):
         super().__init__()
-        if not normalize:
-            raise NotImplementedError("normalize=False is not on the DGDM path (never used by DGDMModel)")
         self.in_channels, self.out_channels, self.edge_dim = in_channels, out_channels, edge_dim
         self.add_self_loops, self.normalize = add_self_loops, normalize
         self.node_lin = nn.Linear(in_channels, out_channels, bias=False)
@@ -84,14 +89,24 @@ class GraphConvolution(nn.Module):
         """``return_skip=True`` returns ``(out, x_skip)``: ``x_skip`` is ``x`` for a residual connection of the caller; on the
         fused path it is an alias routed through this convolution's autograd node, so the residual's gradient is added inside
         the convolution's backward kernel instead of by a separate element-wise pass."""
-        ctx = _context(edge_index, x, edge_attr, self.add_self_loops)
+        if not self.normalize:
+            # graph_layers.py:76-86: no norm and -- the loops are added inside the ``if self.normalize`` branch -- no self loops:
+            # out[d] = sum over the incoming edges of (x W^T)[src] + W_e a_e.  An index set of its own (unit weights).
+            shared = isinstance(edge_index, GraphContext)
+            ctx = GraphContext(edge_index.edge_index if shared else edge_index, x.size(0), edge_index.edge_attr if shared else edge_attr,
+                               add_loops=False, normalize=False)
+        else:
+            ctx = _context(edge_index, x, edge_attr, self.add_self_loops)
         if self.edge_lin is not None and ctx.ea_hat is not None:
             # one contraction over K = C_in + edge_dim:  [A_hat x | EA_hat] . [W | W_e]^T + b
+            we = self.edge_lin.weight
+            if ctx.ea_hat.size(1) != we.size(1):      # attribute width padded to a multiple of 4 by GraphContext
+                we = F.pad(we, (0, ctx.ea_hat.size(1) - we.size(1)))
             if (x.size(0) >= ops.GEMM_MIN_ROWS and x.size(1) % 4 == 0 and self.out_channels % 4 == 0 and ctx.ea_hat.size(1) % 4 == 0
                     and x.dtype == torch.float32):
-                return ops.graph_conv_linear(x, ctx.ea_hat, ctx.gs, self.node_lin.weight, self.edge_lin.weight, self.bias, skip=return_skip)
+                return ops.graph_conv_linear(x, ctx.ea_hat, ctx.gs, self.node_lin.weight, we, self.bias, skip=return_skip)
             buf = ops.aggregate_concat(x, ctx.ea_hat, ctx.gs)
-            out = ops.linear(buf, torch.cat([self.node_lin.weight, self.edge_lin.weight], dim=1), self.bias)
+            out = ops.linear(buf, torch.cat([self.node_lin.weight, we], dim=1), self.bias)
         else:
             out = ops.linear(ops.aggregate(x, ctx.gs), self.node_lin.weight, self.bias)
         return (out, x) if return_skip else out

@@ -1,7 +1,7 @@
 // ABI bookkeeping for libdgdm_hip.so.
 #include "common.hpp"
 
-extern "C" int dgdm_abi_version(void) { return 1; }
+extern "C" int dgdm_abi_version(void) { return DGDM_ABI_VERSION; }
 
 extern "C" const char* dgdm_error_string(int code) {
   switch (code) {

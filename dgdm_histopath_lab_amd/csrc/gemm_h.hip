@@ -388,6 +388,10 @@ constexpr int PLANE2 = KS2 * RS;         // 10240
 constexpr int OPER2 = 2 * PLANE2;        // hi plane, lo plane
 constexpr int STAGE2 = 2 * OPER2;        // dY image, X image: 40960
 constexpr int LDS2 = 2 * STAGE2;         // 81920: two workgroups per CU
+#ifndef DGDM_TN_FLUSH
+#define DGDM_TN_FLUSH 4
+#endif
+constexpr int TN_FLUSH = DGDM_TN_FLUSH;  // stages (of 2 k16-steps x 3 MFMAs per tile) between two flushes of the accumulators; a power of two
 
 typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
 
@@ -492,13 +496,18 @@ __device__ __forceinline__ void tn32_tile(const float* __restrict__ dY, int64_t 
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra.v[0]), "+v"(ra.v[1]), "+v"(ra.v[2]), "+v"(ra.v[3]), "+v"(rb.v[0]), "+v"(rb.v[1]),       \
                "+v"(rb.v[2]), "+v"(rb.v[3]) :: "memory");
 
-  f32x16 acc[2][2];
+  // Two-level accumulation (round 6).  The matrix pipe adds a block of products into its fp32 accumulator with about TWICE the error of
+  // one correctly rounded add (tools/ubench/mfma_rounding.hip: rms 1.76e-6 against 0.84e-6 over 2 500 accumulating MFMAs, in units of
+  // sqrt(sum p^2)), and a dW chunk is a long chain: rows / 16 steps x 3 MFMAs.  Every TN_FLUSH stages the accumulators are added into
+  // a second set by the vector unit (round to nearest) and start again from zero: the same measurement gives 0.34e-6 with a flush
+  // every 8 MFMAs.  64 v_add + 64 v_mov per 96 MFMAs of this wave.
+  f32x16 acc[2][2], tot[2][2];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+      for (int r = 0; r < 16; ++r) { acc[a][b][r] = 0.f; tot[a][b][r] = 0.f; }
   float bs[4] = {0.f, 0.f, 0.f, 0.f}, nobs[4];
 
   // this lane's block address inside a 32-column tile: lane = 16 g + 4 q + p -> row 8 (g >> 1) + q, byte column 32 (g & 1) + 8 p
@@ -536,6 +545,14 @@ __device__ __forceinline__ void tn32_tile(const float* __restrict__ dY, int64_t 
           acc[mt][nt] = mfma_hf(fa[0][mt], fb[0][nt], acc[mt][nt]);
         }
     }
+    if ((s & (TN_FLUSH - 1)) == TN_FLUSH - 1) {       // wave-uniform
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { tot[mt][nt][r] += acc[mt][nt][r]; acc[mt][nt][r] = 0.f; }
+    }
     DGDM_TN32_RETIRE()
     store_stage<BIAS>(ra, nxt, tid, sca, bs);
     store_stage<false>(rb, nxt + OPER2, tid, scb, nobs);
@@ -550,7 +567,7 @@ __device__ __forceinline__ void tn32_tile(const float* __restrict__ dY, int64_t 
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = (acc[mt][nt][r] * ia) * ib;     // in place first: see k_gemmh_rows
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = ((acc[mt][nt][r] + tot[mt][nt][r]) * ia) * ib;     // in place first: see k_gemmh_rows
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)

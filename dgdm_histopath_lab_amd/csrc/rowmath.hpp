@@ -51,6 +51,11 @@ __device__ __forceinline__ float gelu_df(float z) {                // Phi(z) + z
   return fmaf(z * 0.3989422804014327f, __builtin_amdgcn_exp2f(z * z * -0.72134752044448170f), Phi);
 }
 
+#ifdef DGDM_GELU_ERFF   // diagnostic builds only (tools/build_variant_lib.sh erff -DDGDM_GELU_ERFF): the library erf of rounds 1-4
+#define gelu_f(z) (0.5f * (z) * (1.0f + erff((z) * 0.70710678118654752f)))
+#define gelu_df(z) (0.5f * (1.0f + erff((z) * 0.70710678118654752f)) + (z) * 0.3989422804014327f * __expf(-0.5f * (z) * (z)))
+#endif
+
 template <int ACT>
 __device__ __forceinline__ float act_f(float z) {
   if (ACT == DGDM_ACT_GELU) return gelu_f(z);

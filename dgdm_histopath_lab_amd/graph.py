@@ -163,8 +163,17 @@ class GraphStructure:
                                        g.dinv.data_ptr(), _lib.ptr(ea_out), _lib.stream_ptr(dev)), "dgdm_csr_extend")
         return g, ea_out
 
-    def __init__(self, edge_index: torch.Tensor, num_nodes: int, add_loops: bool = True, pipeline: str = "pair"):
-        """``pipeline``: "pair" (dgdm_csr_build_pair) or "single" (one entry point per array set; same results)."""
+    def __init__(self, edge_index: torch.Tensor, num_nodes: int, add_loops: bool = True, pipeline: str = "pair", normalize: bool = True):
+        """``pipeline``: "pair" (dgdm_csr_build_pair) or "single" (one entry point per array set; same results).
+        ``normalize=False``: the entry weights are 1 instead of deg^-1/2 deg^-1/2 (GraphConvolution(normalize=False): a plain sum
+        over the incoming edges, core/graph_layers.py:76-86)."""
+        self._build(edge_index, num_nodes, add_loops, pipeline)
+        if not normalize and self.num_entries > 0:
+            lib, st = _lib.load(), _lib.stream_ptr(self.w.device)
+            for w in (self.w, self.w_t):
+                _lib.check(lib.dgdm_fill_u32(w.data_ptr(), w.numel(), 0x3F800000, st), "dgdm_fill_u32")       # 1.0f
+
+    def _build(self, edge_index: torch.Tensor, num_nodes: int, add_loops: bool, pipeline: str) -> None:
         _lib.require_cuda(edge_index)
         lib = _lib.load()
         if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.size(0) != 2:

@@ -574,6 +574,133 @@ def spatial_attention(qkv, pos, plan: AttnPlan, H: int, scale: float, inv_tau: f
     return fn.apply(qkv, pos, plan, H, scale, inv_tau, p, seed or 0)
 
 
+# ----------------------------------------------------------------------------- K4-dense: MultiHeadAttention.forward as the reference exposes it
+ATTN_DENSE_HEAD_DIMS = (16, 32, 64, 128)      # csrc/attn_dense.hip (narrower heads are zero-padded to the next one by the caller)
+
+
+class DenseMask:
+    """What the reference adds to its [B, H, Lq, Lk] score tensor before the softmax (core/attention.py:129-142,311-314), as the
+    kernels of csrc/attn_dense.hip take it: ``attn_mask`` through the strides of its broadcast view (float: added; bool: -inf where
+    True), ``key_padding_mask`` [B, Lk] bool, optional positions for the spatial bias.  Holds the tensors it points into."""
+
+    __slots__ = ("bias", "bmask", "strides", "kpm", "posq", "posk", "inv_tau")
+
+    def __init__(self, attn_mask, key_padding_mask, B: int, H: int, Lq: int, Lk: int, device, posq=None, posk=None, inv_tau: float = 0.0):
+        self.bias = self.bmask = self.kpm = None
+        self.strides = (0, 0, 0, 0)
+        if attn_mask is not None:
+            _lib.require_cuda(attn_mask)
+            m = attn_mask
+            if m.dtype == torch.bool:
+                m = m.view(torch.uint8)
+            elif m.dtype != torch.float32:
+                m = m.float()              # attn_scores += attn_mask keeps the scores' fp32 (attention.py:135)
+            # the reference's in-place ops broadcast the mask against [B, H, Lq, Lk]; expand() raises where they would
+            view = m.expand(B, H, Lq, Lk)
+            self.strides = tuple(int(v) for v in view.stride())
+            if attn_mask.dtype == torch.bool:
+                self.bmask = m
+            else:
+                self.bias = m
+        if key_padding_mask is not None:
+            _lib.require_cuda(key_padding_mask)
+            if key_padding_mask.dtype != torch.bool:
+                raise RuntimeError("masked_fill_ only supports boolean masks, but got mask with dtype %s" % key_padding_mask.dtype)
+            if tuple(key_padding_mask.shape) != (B, Lk):
+                raise RuntimeError(f"key_padding_mask must be [batch_size, key_len] = [{B}, {Lk}], got {tuple(key_padding_mask.shape)}")
+            self.kpm = key_padding_mask.contiguous().view(torch.uint8)
+        self.posq = None if posq is None else _f32c(posq)
+        self.posk = None if posk is None else _f32c(posk)
+        self.inv_tau = float(inv_tau)
+
+    def args(self):
+        return (_lib.ptr(self.bias), _lib.ptr(self.bmask), *self.strides, _lib.ptr(self.kpm), _lib.ptr(self.posq), _lib.ptr(self.posk), self.inv_tau)
+
+
+def _dense_rows(t: torch.Tensor) -> torch.Tensor:
+    """A 2-D fp32 row view the dense kernels can address (unit column stride, row stride % 4 == 0, 16-byte aligned), or a copy."""
+    if t.dtype != torch.float32 or t.dim() != 2:
+        raise _lib.DGDMKernelError(f"dense attention takes 2-D fp32 row matrices, got {t.dtype} {tuple(t.shape)}")
+    if t.stride(1) != 1 or t.stride(0) % 4 or t.data_ptr() % 16:
+        t = t.contiguous()
+    return t
+
+
+class _AttnDense(torch.autograd.Function):
+    """dropout(softmax(Q K^T scale + mask)) V for a dense batch (csrc/attn_dense.hip).  q [B * Lq, H * D], k / v [B * Lk, H * D] (row
+    views with unit column stride; k and v share a row stride or are made contiguous).  Returns (O [B * Lq, H * D], lse [B, H, Lq]);
+    the mask gets no gradient."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, B: int, Lq: int, Lk: int, H: int, D: int, scale: float, mask: DenseMask, drop_p: float, seed: int):
+        lib = _lib.load()
+        _lib.require_cuda(q, k, v)
+        q, k, v = _dense_rows(q), _dense_rows(k), _dense_rows(v)
+        if k.stride(0) != v.stride(0):
+            k, v = k.contiguous(), v.contiguous()
+        C = H * D
+        out = torch.empty(B * Lq, C, dtype=torch.float32, device=q.device)
+        lse = torch.empty(B, H, max(Lq, 1), dtype=torch.float32, device=q.device)
+        _lib.check(lib.dgdm_attn_dense_fwd(q.data_ptr(), q.stride(0), k.data_ptr(), v.data_ptr(), k.stride(0), B, Lq, Lk, H, D, scale, *mask.args(),
+                                           drop_p, seed, out.data_ptr(), C, lse.data_ptr(), _lib.stream_ptr(q.device)), "dgdm_attn_dense_fwd")
+        ctx.save_for_backward(q, k, v, out, lse)
+        ctx.meta = (B, Lq, Lk, H, D, scale, mask, drop_p, seed)
+        ctx.mark_non_differentiable(lse)
+        return out, lse
+
+    @staticmethod
+    def backward(ctx, gout, _glse=None):
+        lib = _lib.load()
+        q, k, v, out, lse = ctx.saved_tensors
+        B, Lq, Lk, H, D, scale, mask, drop_p, seed = ctx.meta
+        C = H * D
+        gout = _f32c(gout)
+        dq = torch.empty(B * Lq, C, dtype=torch.float32, device=q.device)
+        dk = torch.empty(B * Lk, C, dtype=torch.float32, device=q.device)
+        dv = torch.empty_like(dk)
+        delta = torch.empty_like(lse)
+        _lib.check(lib.dgdm_attn_dense_bwd(q.data_ptr(), q.stride(0), k.data_ptr(), v.data_ptr(), k.stride(0), B, Lq, Lk, H, D, scale, *mask.args(),
+                                           drop_p, seed, out.data_ptr(), gout.data_ptr(), C, lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), C,
+                                           dk.data_ptr(), dv.data_ptr(), C, _lib.stream_ptr(q.device)), "dgdm_attn_dense_bwd")
+        return dq, dk, dv, None, None, None, None, None, None, None, None, None
+
+
+def attn_dense(q, k, v, B: int, Lq: int, Lk: int, H: int, scale: float, mask: Optional[DenseMask] = None, drop_p: float = 0.0,
+               training: bool = False, seed: Optional[int] = None):
+    """-> (O, lse, seed): see ``_AttnDense``; ``seed`` is the dropout seed the launch used (``attn_dense_weights`` takes it to return
+    the weights the forward applied)."""
+    D = q.size(1) // H
+    if q.size(1) != H * D or D not in ATTN_DENSE_HEAD_DIMS or k.size(1) != H * D or v.size(1) != H * D:
+        raise _lib.DGDMKernelError(f"dense attention kernels take head dims {ATTN_DENSE_HEAD_DIMS} (pad narrower heads with zeros), got "
+                                   f"{tuple(q.shape)} / {tuple(k.shape)} / {tuple(v.shape)} at {H} heads")
+    if q.size(0) != B * Lq or k.size(0) != B * Lk or v.size(0) != B * Lk:
+        raise _lib.DGDMKernelError(f"dense attention: rows {q.size(0)} / {k.size(0)} / {v.size(0)} do not match B = {B}, Lq = {Lq}, Lk = {Lk}")
+    if B * Lq > 0 and Lk == 0:
+        raise _lib.DGDMKernelError("dense attention needs at least one key")
+    p = float(drop_p) if training else 0.0
+    if p > 0 and seed is None:
+        seed = next_dropout_seed()
+    if mask is None:
+        mask = DenseMask(None, None, B, H, Lq, Lk, q.device)
+    out, lse = _AttnDense.apply(q, k, v, B, Lq, Lk, H, D, scale, mask, p, seed or 0)
+    return out, lse, (seed or 0)
+
+
+def attn_dense_weights(q, k, lse, B: int, Lq: int, Lk: int, H: int, scale: float, mask: Optional[DenseMask] = None, drop_p: float = 0.0,
+                       seed: int = 0, per_head: bool = False) -> torch.Tensor:
+    """Attention weights after dropout (core/attention.py:145-146): head mean [B, Lq, Lk] or per head [B * H, Lq, Lk] (no grad)."""
+    lib = _lib.load()
+    with torch.no_grad():
+        q, k = _dense_rows(q.detach()), _dense_rows(k.detach())
+        D = q.size(1) // H
+        if mask is None:
+            mask = DenseMask(None, None, B, H, Lq, Lk, q.device)
+        W = torch.empty(B * H if per_head else B, Lq, Lk, dtype=torch.float32, device=q.device)
+        _lib.check(lib.dgdm_attn_dense_weights(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), B, Lq, Lk, H, D, scale, *mask.args(), drop_p, seed,
+                                               lse.data_ptr(), int(per_head), W.data_ptr(), _lib.stream_ptr(q.device)), "dgdm_attn_dense_weights")
+    return W
+
+
 # ----------------------------------------------------------------------------- K5 positional encoding
 class _AddPosEnc(torch.autograd.Function):
     """x + sinusoid(pos) (core/attention.py:225-259,306); d/dx = identity, pos carries no grad."""

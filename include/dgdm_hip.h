@@ -49,6 +49,10 @@ enum {
 /* activation ids shared by the fused row kernels */
 enum { DGDM_ACT_NONE = 0, DGDM_ACT_GELU = 1, DGDM_ACT_RELU = 2, DGDM_ACT_SILU = 3, DGDM_ACT_ELU = 4 };   /* ELU: alpha = 1 (nn.ELU(), encoders.py:62,207) */
 
+/* Bumped whenever an exported signature changes (round 5 changed dgdm_segment_mse_bwd / dgdm_pool_score_bwd without doing so): a binding
+ * written for one version must refuse a library that reports another -- a shifted argument list is an invalid-stream launch, not an
+ * error code.  _lib.load() / open_library() compare it with _lib.ABI_VERSION. */
+#define DGDM_ABI_VERSION 2
 DGDM_API int dgdm_abi_version(void);
 DGDM_API const char* dgdm_error_string(int code);
 
@@ -568,6 +572,36 @@ DGDM_API int dgdm_gemm_tn_split_f16x2(const float* dY, int64_t ldy, const float*
                                       int32_t K0, float* dW1, int64_t ld1, float* db, int32_t M, int32_t N, int32_t K,
                                       void* workspace, size_t workspace_bytes, const uint32_t* amax_dy, const uint32_t* amax_x,
                                       void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K4-dense  MultiHeadAttention.forward as the reference exposes it (reference: core/attention.py:73-181; csrc/attn_dense.hip): a dense
+ * batch of B sequences, Lq queries against Lk keys / values each, with everything the reference adds to its score tensor:
+ *   S[b,h,q,k] = Q[b,q,h] . K[b,k,h] * scale + bias - |posq[b,q] - posk[b,k]| * inv_tau ;  -inf where bmask or kpm[b,k]
+ *   O = dropout(softmax_k S) V
+ * Q [B * Lq, >= H * D] (row stride ldq), K / V [B * Lk, >= H * D] (common row stride ldk), D in {16, 32, 64, 128} (narrower heads
+ * zero-padded by the caller).  bias (float attn_mask, attention.py:131-135: added) and bmask (bool attn_mask: -inf where nonzero) are
+ * mutually exclusive, either may be NULL; both are addressed through the strides (sb, sh, sq, sk), in elements, of the mask's
+ * broadcast view [B, H, Lq, Lk] (0 for a broadcast dimension: a 2-D [Lq, Lk] mask has sb = sh = 0).  kpm = key_padding_mask [B, Lk]
+ * (attention.py:137-142; nonzero = key ignored) or NULL.  posq [B * Lq, 2] / posk [B * Lk, 2] (both or neither): the spatial bias
+ * of SpatialAttention.forward called with a mask (attention.py:311-314).  lse [B, H, Lq] NATURAL-log sum-exp, delta [B, H, Lq] scratch
+ * of the backward.  A row whose keys are all masked is NaN in O / lse and in the gradients (softmax of all -inf in the reference).
+ * dgdm_attn_dense_weights: the weights AFTER dropout (attention.py:145-146), head mean W [B, Lq, Lk] (per_head = 0, attention.py:172)
+ * or W [B * H, Lq, Lk] (per_head = 1, attention.py:174-176); with drop_p > 0 pass the forward's seed.  The mask gets no gradient.
+ * The dropout mask is a hash of (seed, b, head, query, key) private to this kernel family.  fp32 on the vector units: off the DGDM
+ * hot path (DGDMModel's two uses of the class run on K4 / K10), built for parity with the class's own forward. */
+DGDM_API int dgdm_attn_dense_fwd(const float* Q, int64_t ldq, const float* K, const float* V, int64_t ldk, int32_t B, int32_t Lq, int32_t Lk,
+                                 int32_t H, int32_t D, float scale, const float* bias, const uint8_t* bmask, int64_t sb, int64_t sh,
+                                 int64_t sq, int64_t sk, const uint8_t* kpm, const float* posq, const float* posk, float inv_tau,
+                                 float drop_p, uint32_t seed, float* O, int64_t ldo, float* lse, void* stream);
+DGDM_API int dgdm_attn_dense_bwd(const float* Q, int64_t ldq, const float* K, const float* V, int64_t ldk, int32_t B, int32_t Lq, int32_t Lk,
+                                 int32_t H, int32_t D, float scale, const float* bias, const uint8_t* bmask, int64_t sb, int64_t sh,
+                                 int64_t sq, int64_t sk, const uint8_t* kpm, const float* posq, const float* posk, float inv_tau,
+                                 float drop_p, uint32_t seed, const float* O, const float* dO, int64_t ldo, const float* lse, float* delta,
+                                 float* dQ, int64_t ldgq, float* dK, float* dV, int64_t ldgk, void* stream);
+DGDM_API int dgdm_attn_dense_weights(const float* Q, int64_t ldq, const float* K, int64_t ldk, int32_t B, int32_t Lq, int32_t Lk, int32_t H,
+                                     int32_t D, float scale, const float* bias, const uint8_t* bmask, int64_t sb, int64_t sh, int64_t sq,
+                                     int64_t sk, const uint8_t* kpm, const float* posq, const float* posk, float inv_tau, float drop_p,
+                                     uint32_t seed, const float* lse, int32_t per_head, float* W, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K4-gen  spatial attention for 16 < head_dim <= 64 (csrc/attn_gen.hip).  The reference accepts any embed_dim % num_heads == 0

@@ -17,6 +17,8 @@ Fixture inventory:
   G5b DiffusionLayer.sample at Base widths, 10 and 50 inference steps     as-is
   G6  FeatureEncoder, AdaptiveGraphPooling, GlobalAttentionPool          as-is
   G10 FeatureEncoder x {relu, elu} x {batch, instance, layer, none} (eval + training mode), GlobalMaxPool / GlobalMeanPool   as-is
+  G11 round-6 options: GraphConvolution(normalize=False), DiffusionLayer(conditioning_dim), MultiHeadAttention with bool mask +
+      key_padding_mask / add_zero_attn                                     as-is
   G9  ClassificationHead / RegressionHead forward + every compute_loss branch   models/decoders.py as-is
   G7  DynamicGraphLayer (R1), GraphEncoder (R1+R2), GraphUNet (R1+R5), full model
       forward/pretrain_step (R1-R5): reference leaf classes, repaired wiring
@@ -527,13 +529,81 @@ def g7_repaired(ref):
         save(f"g7_model_{tag}", **arrays)
 
 
+def g11_round6_options(ref):
+    """Constructor / call options closed in round 6, each by running the reference's own class:
+    GraphConvolution(normalize=False) with and without edge attributes (core/graph_layers.py:76-86: no norm, no self loops),
+    DiffusionLayer(conditioning_dim=...) -- predict_noise / forward / sample with a per-row and with a single condition
+    (core/diffusion.py:106-110,158-161), MultiHeadAttention with a bool attn_mask + key_padding_mask and with add_zero_attn
+    (core/attention.py:118-142)."""
+    GC = ref.graph_layers.GraphConvolution
+    torch.manual_seed(31)
+    n, e = 18, 50
+    ei = rand_graph(n, e, 310, self_loops=2, dups=3)
+    conv = GC(12, 20, normalize=False); randomize_(conv, 311)
+    x = torch.randn(n, 12, requires_grad=True)
+    y = conv(x, ei)
+    gy = torch.randn(y.shape)
+    gx, gw, gb = grads_of((y * gy).sum(), [x, conv.node_lin.weight, conv.bias])
+    conv2 = GC(12, 20, edge_dim=8, normalize=False); randomize_(conv2, 312)
+    ea = torch.randn(e, 8)
+    x2 = torch.randn(n, 12, requires_grad=True)
+    y2 = conv2(x2, ei, ea)
+    gx2, gw2, gwe2 = grads_of((y2 * gy).sum(), [x2, conv2.node_lin.weight, conv2.edge_lin.weight])
+    save("g11_graph_conv_unnormalized", edge_index=ei, x=x, gy=gy, y=y, gx=gx, gw=gw, gb=gb, **sd_np(conv, "a."),
+         edge_attr=ea, x2=x2, y2=y2, gx2=gx2, gw2=gw2, gwe2=gwe2, **sd_np(conv2, "b."))
+
+    torch.manual_seed(32)
+    C, Hd, T, cd, n = 32, 64, 10, 12, 30
+    dl = ref.diffusion.DiffusionLayer(C, Hd, num_timesteps=T, conditioning_dim=cd).eval(); randomize_(dl, 321)
+    x0 = torch.randn(n, C, requires_grad=True)
+    noise = torch.randn(n, C)
+    t = torch.tensor([6])
+    out = {}
+    for tag, cond in (("row", torch.randn(n, cd)), ("one", torch.randn(1, cd))):
+        cond = cond.requires_grad_(True)
+        xn, pred = dl(x0, t, noise, cond)
+        gp = torch.randn(pred.shape, generator=torch.Generator().manual_seed(322))
+        gx0, gw0, gwc, gc = grads_of((pred * gp).sum(), [x0, dl.denoise_net[0].weight, dl.condition_net.weight, cond])
+        out.update({f"{tag}.cond": cond, f"{tag}.pred": pred, f"{tag}.gx0": gx0, f"{tag}.gw0": gw0, f"{tag}.gwc": gwc, f"{tag}.gc": gc,
+                    f"{tag}.x_noisy": xn})
+        steps = 6
+        g = torch.Generator().manual_seed(323)
+        x_init = torch.randn(n, C, generator=g)
+        step_noise = [torch.randn(n, C, generator=g) for _ in range(steps - 1)]
+        with injected_rng(randn=[x_init], randn_like=step_noise):
+            out[f"{tag}.sample"] = dl.sample((n, C), torch.device("cpu"), condition=cond.detach(), num_inference_steps=steps)
+    save("g11_diffusion_conditioning", x0=x0, noise=noise, t=t, gp=gp, x_init=x_init, step_noise=torch.stack(step_noise), steps=steps, T=T,
+         **out, **sd_np(dl))
+
+    torch.manual_seed(33)
+    B, L, S, C, H = 3, 9, 14, 48, 3          # B == H: a 3-D mask would meet the head axis; masks here are 2-D / [B, S]
+    gen = torch.Generator().manual_seed(331)
+    query, key, value = (torch.randn(B, m, C, generator=gen) for m in (L, S, S))
+    bmask = torch.rand(L, S, generator=gen) < 0.35
+    bmask[:, 0] = False
+    kpm = torch.rand(B, S, generator=gen) < 0.3
+    kpm[:, 0] = False
+    go = torch.randn(B, L, C, generator=gen)
+    arrays = dict(query=query, key=key, value=value, bmask=bmask, kpm=kpm, go=go)
+    for tag, zero_attn in (("plain", False), ("zero_attn", True)):
+        mha = ref.attention.MultiHeadAttention(C, H, add_zero_attn=zero_attn).eval(); randomize_(mha, 332)
+        q = query.clone().requires_grad_(True)
+        o, w = mha(q, key, value, key_padding_mask=kpm, attn_mask=bmask)
+        gq, gwk = grads_of((o * go).sum(), [q, mha.k_proj.weight])
+        _, w_heads = mha(query, key, value, key_padding_mask=kpm, attn_mask=bmask, average_attn_weights=False)
+        arrays.update({f"{tag}.out": o, f"{tag}.weights": w, f"{tag}.gq": gq, f"{tag}.gwk": gwk, f"{tag}.weights_per_head": w_heads})
+        arrays.update(sd_np(mha, f"{tag}.w."))
+    save("g11_mha_masks", **arrays)
+
+
 def main():
     assert os.path.isdir(REF_ROOT), "golden capture needs /root/reference (dev container only)"
     torch.set_num_threads(4)
     ref = load_reference()
     print("reference modules loaded from", REF_ROOT)
     only = set(sys.argv[1:])
-    for fn in (g1_scheduler, g2_graph_conv, g2b_plain_encoder, g4_attention, g5_diffusion, g5b_sample_base, g6_small_modules, g7_repaired, g9_heads, g10_encoder_options):
+    for fn in (g1_scheduler, g2_graph_conv, g2b_plain_encoder, g4_attention, g5_diffusion, g5b_sample_base, g6_small_modules, g7_repaired, g9_heads, g10_encoder_options,
+               g11_round6_options):
         if not only or fn.__name__ in only:
             fn(ref)
 

@@ -212,14 +212,16 @@ def init_params(cfg: OracleConfig, seed: int = 0, dtype=torch.float32, perturb: 
 class OracleGraph:
     """Loop-extended COO + weights of one (possibly batched) graph, torch tensors on CPU."""
 
-    def __init__(self, edge_index: Tensor, num_nodes: int, dtype=torch.float32):
+    def __init__(self, edge_index: Tensor, num_nodes: int, dtype=torch.float32, add_loops: bool = True, normalize: bool = True):
+        """``normalize=False``: GraphConvolution(normalize=False) (core/graph_layers.py:76-86) -- no self loops (they are added inside
+        the ``if self.normalize`` branch) and no norm: every entry weighs 1."""
         ei = edge_index.detach().cpu().numpy()
-        g = csr_oracle.gcn_csr(ei, num_nodes, add_loops=True)
+        g = csr_oracle.gcn_csr(ei, num_nodes, add_loops=add_loops and normalize)
         self.num_nodes = num_nodes
         self.num_input_edges = ei.shape[1]
         self.src = torch.from_numpy(g["src"])
         self.dst = torch.from_numpy(g["dst"])
-        self.norm = torch.from_numpy(g["norm_coo"]).to(dtype)
+        self.norm = torch.from_numpy(g["norm_coo"]).to(dtype) if normalize else torch.ones(len(g["src"]), dtype=dtype)
         self.csr = g
 
 
@@ -395,6 +397,55 @@ def mha(P, pre, query, key, value, H, bias=None, p_drop=0.0, training=False):
     return o, w.mean(dim=0)
 
 
+def mha_dense(P, pre, query, key=None, value=None, H=8, attn_mask=None, key_padding_mask=None, add_zero_attn=False, drop_mask=None):
+    """MultiHeadAttention.forward for a BATCH with every argument of the reference (core/attention.py:73-181): query [B, L, C],
+    key / value [B, S, C] (default: query / key), ``attn_mask`` float (added after the 1/sqrt(d) scale, :134-135) or bool (-inf where
+    True, :132-133) broadcast against the [B, H, L, S] scores exactly as the reference's in-place ops do, ``key_padding_mask``
+    [B, S] bool (:137-142), ``add_zero_attn`` (:118-126).  ``drop_mask`` [B, H, L, S]: keep-scale factors standing in for
+    ``attn_dropout`` (:146; dropout cannot be matched draw for draw, the kernels' own mask is handed in).
+    Returns (out [B, L, C] BEFORE resid_dropout, per-head weights after dropout [B, H, L, S])."""
+    B, L, C = query.shape
+    key = query if key is None else key
+    value = key if value is None else value
+    d = C // H
+    q = _lin(P, f"{pre}.q_proj", query).view(B, L, H, d).transpose(1, 2)
+    k = _lin(P, f"{pre}.k_proj", key).view(B, -1, H, d).transpose(1, 2)
+    v = _lin(P, f"{pre}.v_proj", value).view(B, -1, H, d).transpose(1, 2)
+    if add_zero_attn:
+        z = torch.zeros(B, H, 1, d, dtype=k.dtype)
+        k, v = torch.cat([k, z], dim=2), torch.cat([v, z], dim=2)
+        if attn_mask is not None:
+            attn_mask = F.pad(attn_mask, (0, 1))
+        if key_padding_mask is not None:
+            key_padding_mask = F.pad(key_padding_mask, (0, 1))
+    s = torch.matmul(q, k.transpose(-2, -1)) / math.sqrt(d)
+    if attn_mask is not None:
+        full = attn_mask.expand(s.shape)          # what masked_fill_ / += broadcast to (in place: the mask cannot enlarge the scores)
+        s = s.masked_fill(full, float("-inf")) if attn_mask.dtype == torch.bool else s + full.to(s.dtype)
+    if key_padding_mask is not None:
+        s = s.masked_fill(key_padding_mask.unsqueeze(1).unsqueeze(2), float("-inf"))
+    w = F.softmax(s, dim=-1)
+    if drop_mask is not None:
+        w = w * drop_mask
+    o = torch.matmul(w, v).transpose(1, 2).reshape(B, L, C)
+    return _lin(P, f"{pre}.out_proj", o), w
+
+
+def spatial_attention_dense(P, x, pos, H, mask=None, temperature=1.0, pre="spatial_attention"):
+    """SpatialAttention.forward (core/attention.py:285-327) for x [B, N, C], pos [B, N, 2] WITH the optional ``mask`` (:311-314:
+    ``attn_mask = mask + spatial_bias``; runs in the reference for B = 1 only, see the note in the product's module).  Positional
+    encodings normalised per sequence (B = 1: the reference's global min / max)."""
+    B, N, C = x.shape
+    pe = torch.stack([sinusoid_pos_encoding(pos[b], C).to(x.dtype) for b in range(B)])
+    p = pos.to(x.dtype)
+    bias = -torch.norm(p.unsqueeze(2) - p.unsqueeze(1), dim=-1) / temperature       # [B, N, N]  (:274-281)
+    am = bias if mask is None else mask.to(x.dtype) + bias
+    if B > 1 and am.dim() == 3:
+        am = am.unsqueeze(1)                                                          # the product's B > 1 extension: one bias per sequence
+    o, w = mha_dense(P, f"{pre}.attention", x + pe, H=H, attn_mask=am)
+    return _ln(P, f"{pre}.norm", x + o), w.mean(dim=1)
+
+
 def spatial_attention_graph(P, x, pos, H, temperature=1.0, p_drop=0.0, training=False, pre="spatial_attention"):
     """SpatialAttention.forward (core/attention.py:285-327) on one graph."""
     C = x.shape[1]
@@ -497,10 +548,13 @@ def timestep_embedding(t: Tensor, dim: int = 128) -> Tensor:
     return torch.cat([torch.sin(e), torch.cos(e)], dim=1)
 
 
-def predict_noise(P, x_noisy: Tensor, t: Tensor, p_drop=0.1, training=False, pre="diffusion_layer") -> Tensor:
-    """DiffusionLayer.predict_noise (core/diffusion.py:147-172) on 2-D [N_g, C], t [1] (R3)."""
+def predict_noise(P, x_noisy: Tensor, t: Tensor, p_drop=0.1, training=False, pre="diffusion_layer", condition: Optional[Tensor] = None) -> Tensor:
+    """DiffusionLayer.predict_noise (core/diffusion.py:147-172) on 2-D [N_g, C], t [1] (R3); ``condition`` [1, cd] or [N_g, cd]:
+    t_emb + condition_net(condition) (:158-161), only with a ``condition_net`` in P (conditioning_dim given, :106-110)."""
     te = timestep_embedding(t).to(x_noisy.dtype)
     te = _lin(P, f"{pre}.time_embed.2", F.silu(_lin(P, f"{pre}.time_embed.0", te)))
+    if condition is not None and f"{pre}.condition_net.weight" in P:
+        te = te + _lin(P, f"{pre}.condition_net", condition)
     inp = torch.cat([x_noisy, te.expand(x_noisy.shape[0], -1)], dim=-1)
     h = _lin(P, f"{pre}.denoise_net.0", inp)
     h = F.group_norm(h, 8, P[f"{pre}.denoise_net.1.weight"], P[f"{pre}.denoise_net.1.bias"], 1e-5)
@@ -520,13 +574,13 @@ def add_noise(sched, x0: Tensor, noise: Tensor, t: Tensor) -> Tensor:
     return a * x0 + b * noise
 
 
-def ddpm_sample(P, sched, T: int, x_init: Tensor, noises: List[Tensor], num_inference_steps: int = 50) -> Tensor:
+def ddpm_sample(P, sched, T: int, x_init: Tensor, noises: List[Tensor], num_inference_steps: int = 50, condition: Optional[Tensor] = None) -> Tensor:
     """DiffusionLayer.sample (core/diffusion.py:214-275) with the random draws injected:
     ``x_init`` replaces the initial randn, ``noises[i]`` the i-th per-step randn_like."""
     x = x_init
     ts = torch.linspace(T - 1, 0, num_inference_steps, dtype=torch.long)
     for i, t in enumerate(ts):
-        eps = predict_noise(P, x, t.view(1), training=False)
+        eps = predict_noise(P, x, t.view(1), training=False, condition=condition)
         alpha, ac = sched["alphas"][t].to(x.dtype), sched["alphas_cumprod"][t].to(x.dtype)
         x0 = (x - torch.sqrt(1 - ac) * eps) / torch.sqrt(ac)
         if i < len(ts) - 1:

@@ -1,0 +1,234 @@
+"""MultiHeadAttention.forward / SpatialAttention.forward(mask=...) as the reference exposes them (core/attention.py:73-181,285-327) on
+csrc/attn_dense.hip, against the reference's own vectors (tests/golden/g4_*.npz) and the float64 oracle (oracle.mha_dense)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import T, assert_close, load_golden, weights
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+def _module(embed_dim, heads, sd=None, seed=0, **kw):
+    from dgdm_histopath_lab_amd.core.attention import MultiHeadAttention
+    torch.manual_seed(seed)
+    m = MultiHeadAttention(embed_dim, heads, **kw)
+    if sd is not None:
+        m.load_state_dict(sd)
+    else:
+        with torch.no_grad():
+            for p in m.parameters():
+                p.copy_(torch.randn_like(p) * (0.3 if p.dim() == 1 else 1.0 / math.sqrt(embed_dim)))
+    return m.cuda().eval()
+
+
+def _P64(m, pre="m"):
+    return {f"{pre}.{k}": v.detach().double().cpu().requires_grad_(True) for k, v in m.state_dict().items()}
+
+
+def test_mha_forward_matches_the_reference_vectors():
+    """g4_mha: [2, 20, 64] self-attention, 8 heads (head_dim 8, zero-padded to 16), 2-D float mask; and the 1-query cross form."""
+    g = load_golden("g4_mha")
+    m = _module(64, 8, weights(g))
+    q = T(g["q"]).cuda().requires_grad_(True)
+    o, w = m(q, attn_mask=T(g["mask"]).cuda())
+    assert o.shape == (2, 20, 64) and w.shape == (2, 20, 20)         # the reference's tests/test_basic.py:119-121
+    assert_close(o, g["out"], TOL, "out"); assert_close(w, g["weights"], TOL, "weights")
+    (o * T(g["go"]).cuda()).sum().backward()
+    assert_close(q.grad, g["gq"], TOL, "gq"); assert_close(m.q_proj.weight.grad, g["gwq"], TOL, "gwq")
+    kv = T(g["kv"]).cuda()
+    o2, w2 = m(T(g["tok"]).cuda(), kv, kv)
+    assert_close(o2, g["out2"], TOL, "out2"); assert_close(w2, g["weights2"], TOL, "weights2")
+
+
+def test_spatial_attention_module_matches_the_reference_vectors_with_and_without_a_mask():
+    """g4_spatial_attention (N = 48, raw positions): the fused path (mask=None) against out / weights / six gradients, then the dense
+    path -- a zero mask must reproduce the same vectors, a random mask the float64 oracle."""
+    from dgdm_histopath_lab_amd.core.attention import SpatialAttention
+    from oracle import dgdm_oracle as O
+    g = load_golden("g4_spatial_attention")
+    sa = SpatialAttention(128, 8)
+    sa.load_state_dict(weights(g), strict=False)
+    sa = sa.cuda().eval()
+    pos = T(g["pos"]).cuda()[None]
+    names = [("attention.q_proj.weight", "gwq"), ("attention.k_proj.weight", "gwk"), ("attention.v_proj.weight", "gwv"),
+             ("attention.out_proj.weight", "gwo"), ("norm.weight", "gnw")]
+    for mask in (None, torch.zeros(48, 48, device="cuda")):
+        sa.zero_grad(set_to_none=True)
+        x = T(g["x"]).cuda()[None].requires_grad_(True)
+        o, w = sa(x, pos, mask)
+        tag = "fused" if mask is None else "dense, zero mask"
+        assert_close(o[0], g["out"], TOL, f"out ({tag})"); assert_close(w[0], g["weights"], TOL, f"weights ({tag})")
+        (o[0] * T(g["go"]).cuda()).sum().backward()
+        assert_close(x.grad[0], g["gx"], TOL, f"gx ({tag})")
+        params = dict(sa.named_parameters())
+        for pn, key in names:
+            assert_close(params[pn].grad, g[key], TOL, f"{key} ({tag})")
+    P = {"spatial_attention." + k: v.double() for k, v in weights(g).items()}
+    gen = torch.Generator().manual_seed(5)
+    for shape in ((48, 48), (1, 48, 48), (8, 48, 48)):      # B = 1: [8, N, N] meets the head axis, as in the reference's broadcast
+        mask = torch.randn(*shape, generator=gen)
+        x = T(g["x"])[None]
+        o64, w64 = O.spatial_attention_dense(P, x.double(), T(g["pos"])[None], 8, mask=mask.double())
+        o, w = sa(x.cuda(), pos, mask.cuda())
+        assert_close(o, o64, TOL, f"out, mask {shape}"); assert_close(w, w64, TOL, f"weights, mask {shape}")
+    # bool mask: added as 0 / 1 (mask + spatial_bias), not -inf
+    bm = torch.rand(48, 48, generator=gen) < 0.3
+    o64, w64 = O.spatial_attention_dense(P, T(g["x"])[None].double(), T(g["pos"])[None], 8, mask=bm)
+    o, w = sa(T(g["x"]).cuda()[None], pos, bm.cuda())
+    assert_close(o, o64, TOL, "out, bool mask"); assert_close(w, w64, TOL, "weights, bool mask")
+
+
+@pytest.mark.parametrize("embed_dim,heads", [(64, 8), (128, 8), (128, 4), (128, 2), (256, 2), (96, 4)])
+def test_mha_self_attention_every_head_dim_matches_float64(embed_dim, heads):
+    """head_dim 8 / 16 / 32 / 64 / 128 / 24 (padded to 32): out, per-head weights and every gradient against float64."""
+    from oracle import dgdm_oracle as O
+    m = _module(embed_dim, heads, seed=embed_dim + heads)
+    B, L = 3, 70                                            # more than one 64-row tile, a ragged last tile
+    gen = torch.Generator().manual_seed(1)
+    q = torch.randn(B, L, embed_dim, generator=gen)
+    mask = torch.randn(L, L, generator=gen)
+    go = torch.randn(B, L, embed_dim, generator=gen)
+    P = _P64(m)
+    q64 = q.double().requires_grad_(True)
+    o64, w64 = O.mha_dense(P, "m", q64, H=heads, attn_mask=mask.double())
+    (o64 * go.double()).sum().backward()
+    qg = q.cuda().requires_grad_(True)
+    o, w = m(qg, attn_mask=mask.cuda(), average_attn_weights=False)
+    assert w.shape == (B * heads, L, L)                     # attention.py:174-176
+    assert_close(o, o64, TOL, "out"); assert_close(w, w64.reshape(B * heads, L, L), TOL, "weights")
+    (o * go.cuda()).sum().backward()
+    assert_close(qg.grad, q64.grad, TOL, "dq")
+    for k, p in m.named_parameters():
+        assert_close(p.grad, P["m." + k].grad, TOL, k)
+
+
+def test_mha_masks_cross_attention_zero_attn_and_sequence_first():
+    """bool attn_mask, key_padding_mask, 3-D / 4-D float masks, cross-attention with S != L, add_zero_attn, batch_first=False."""
+    from oracle import dgdm_oracle as O
+    C, H, B, L, S = 64, 4, 4, 37, 81
+    gen = torch.Generator().manual_seed(3)
+    query, key, value = (torch.randn(B, n, C, generator=gen) for n in (L, S, S))
+    go = torch.randn(B, L, C, generator=gen)
+    kpm = torch.rand(B, S, generator=gen) < 0.3
+    kpm[:, 0] = False                                       # no fully masked row here
+    bmask = torch.rand(L, S, generator=gen) < 0.4
+    bmask[:, 1] = False
+    cases = {"bool 2-D + key padding": dict(attn_mask=bmask, key_padding_mask=kpm),
+             "float [H, L, S] (B == H: the reference's broadcast puts it on the head axis)": dict(attn_mask=torch.randn(H, L, S, generator=gen)),
+             "float [B, 1, L, S]": dict(attn_mask=torch.randn(B, 1, L, S, generator=gen)),
+             "float [B, H, L, S] + key padding": dict(attn_mask=torch.randn(B, H, L, S, generator=gen), key_padding_mask=kpm),
+             "bool [B, H, L, S]": dict(attn_mask=(torch.rand(B, H, L, S, generator=gen) < 0.2) & ~torch.eye(L, S, dtype=torch.bool)),
+             "key padding only": dict(key_padding_mask=kpm),
+             "no mask": dict()}
+    for zero_attn in (False, True):
+        m = _module(C, H, seed=7, add_zero_attn=zero_attn)
+        P = _P64(m)
+        for name, kw in cases.items():
+            for p in P.values():
+                p.grad = None
+            m.zero_grad(set_to_none=True)
+            ins64 = [t.double().requires_grad_(True) for t in (query, key, value)]
+            kw64 = {k: (v.double() if v.is_floating_point() else v) for k, v in kw.items()}
+            o64, w64 = O.mha_dense(P, "m", *ins64, H=H, add_zero_attn=zero_attn, **kw64)
+            (o64 * go.double()).sum().backward()
+            ins = [t.cuda().requires_grad_(True) for t in (query, key, value)]
+            o, w = m(*ins, **{k: v.cuda() for k, v in kw.items()})
+            tag = f"{name}, add_zero_attn={zero_attn}"
+            assert w.shape == (B, L, S + int(zero_attn))
+            assert_close(o, o64, TOL, f"out ({tag})"); assert_close(w, w64.mean(1), TOL, f"weights ({tag})")
+            (o * go.cuda()).sum().backward()
+            for a, b, n in zip(ins, ins64, "qkv"):
+                assert_close(a.grad, b.grad, TOL, f"d{n} ({tag})")
+            for k, p in m.named_parameters():
+                assert_close(p.grad, P["m." + k].grad, TOL, f"{k} ({tag})")
+    # sequence-first layout (attention.py:99-105,160-162)
+    m = _module(C, H, seed=7, batch_first=False)
+    o_sf, w_sf = m(query.transpose(0, 1).cuda(), key.transpose(0, 1).cuda(), value.transpose(0, 1).cuda(), key_padding_mask=kpm.cuda())
+    o64, w64 = O.mha_dense(_P64(m), "m", query.double(), key.double(), value.double(), H=H, key_padding_mask=kpm)
+    assert o_sf.shape == (L, B, C)
+    assert_close(o_sf.transpose(0, 1), o64, TOL, "out (sequence first)"); assert_close(w_sf, w64.mean(1), TOL, "weights (sequence first)")
+
+
+def test_mha_row_with_every_key_masked_is_nan_like_the_reference_and_shapes_that_do_not_broadcast_raise():
+    m = _module(64, 4, seed=9)
+    q = torch.randn(2, 10, 64, device="cuda")
+    kpm = torch.zeros(2, 10, dtype=torch.bool, device="cuda")
+    kpm[1] = True                                           # sequence 1: softmax over all -inf
+    o, w = m(q, key_padding_mask=kpm)
+    assert torch.isfinite(o[0]).all() and torch.isnan(o[1]).all() and torch.isnan(w[1]).all() and torch.isfinite(w[0]).all()
+    bm = torch.zeros(10, 10, dtype=torch.bool, device="cuda")
+    bm[3] = True                                            # one fully masked query row
+    o, _ = m(q, attn_mask=bm)
+    assert torch.isnan(o[:, 3]).all() and torch.isfinite(o[:, :3]).all() and torch.isfinite(o[:, 4:]).all()
+    with pytest.raises(RuntimeError):
+        m(q, attn_mask=torch.zeros(3, 10, 10, device="cuda"))        # 3 does not broadcast against H = 4 (nor B = 2)
+    with pytest.raises(RuntimeError):
+        m(q, key_padding_mask=torch.zeros(2, 10, device="cuda"))     # masked_fill_ takes bool masks only
+    with pytest.raises(ValueError):
+        m(q[0])
+    from dgdm_histopath_lab_amd._lib import DGDMKernelError
+    with pytest.raises(DGDMKernelError):
+        m(q.cpu())
+
+
+def test_mha_training_mode_dropout_is_one_mask_for_forward_weights_and_backward():
+    """Training mode: the returned per-head weights ARE the dropped weights of the forward (O = W V), the rate is the requested one,
+    and the backward differentiates the same mask -- checked by handing the kernels' own mask to the float64 oracle."""
+    from oracle import dgdm_oracle as O
+    C, H, B, L = 64, 4, 2, 150
+    m = _module(C, H, seed=11, dropout=0.25)
+    m.train()
+    m.resid_dropout.p = 0.0                                 # only the attention-weight dropout is under test
+    gen = torch.Generator().manual_seed(4)
+    q = torch.randn(B, L, C, generator=gen)
+    go = torch.randn(B, L, C, generator=gen)
+    qg = q.cuda().requires_grad_(True)
+    o, w = m(qg, average_attn_weights=False)
+    (o * go.cuda()).sum().backward()
+    w = w.view(B, H, L, L).double().cpu()
+    P = _P64(m)
+    q64 = q.double().requires_grad_(True)
+    _, w_plain = O.mha_dense(P, "m", q64, H=H)
+    kept = w != 0
+    rate = 1.0 - kept.double().mean().item()
+    assert abs(rate - 0.25) < 0.01, rate
+    scale = (w[kept] / w_plain.detach()[kept]).median().item()
+    assert abs(scale - 1.0 / (1.0 - 16384 / 65536)) < 1e-3, scale        # 16-bit threshold: p_eff = floor(p * 65536) / 65536
+    for p in P.values():
+        p.grad = None
+    o64, w64 = O.mha_dense(P, "m", q64, H=H, drop_mask=kept.double() * scale)
+    (o64 * go.double()).sum().backward()
+    assert_close(o, o64, TOL, "out"); assert_close(w, w64, TOL, "dropped weights")
+    assert_close(qg.grad, q64.grad, TOL, "dq")
+    for k, p in m.named_parameters():
+        assert_close(p.grad, P["m." + k].grad, TOL, k)
+    # another step draws another mask; eval mode none
+    o_b, w_b = m(q.cuda(), average_attn_weights=False)
+    assert (w_b.view(B, H, L, L).cpu() != 0).ne(kept).any()
+    m.eval()
+    _, w_e = m(q.cuda(), average_attn_weights=False)
+    assert (w_e != 0).all()
+
+
+def test_dense_attention_entry_points_reject_what_they_cannot_run():
+    from dgdm_histopath_lab_amd import _lib
+    lib = _lib.load()
+    z = torch.zeros(64, 64, device="cuda")
+    lse = torch.zeros(64, device="cuda")
+    st = _lib.stream_ptr(z.device)
+    base = lambda D, Lk=16, drop=0.0, bias=None, bmask=None: lib.dgdm_attn_dense_fwd(
+        z.data_ptr(), 64, z.data_ptr(), z.data_ptr(), 64, 1, 16, Lk, 64 // D if D <= 64 else 1, D, 1.0, bias, bmask, 0, 0, 0, 0, None, None, None,
+        0.0, drop, 0, z.data_ptr(), 64, lse.data_ptr(), st)
+    assert base(16) == 0
+    assert base(24) == -2                                   # head dims other than 16 / 32 / 64 / 128: unsupported
+    assert base(16, Lk=0) == -1                             # queries without keys
+    assert base(16, drop=1.0) == -1
+    assert base(16, bias=z.data_ptr(), bmask=z.data_ptr()) == -1      # a mask is float or bool, not both
+    assert lib.dgdm_attn_dense_fwd(None, 64, None, None, 64, 1, 16, 16, 4, 16, 1.0, None, None, 0, 0, 0, 0, None, None, None, 0.0, 0.0, 0,
+                                   None, 64, None, st) == -1
+    torch.cuda.synchronize()

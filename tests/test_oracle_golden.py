@@ -85,6 +85,23 @@ def test_g4_multi_head_attention_as_is():
     assert o.shape == (2, 20, 64) and w.shape == (2, 20, 20)
 
 
+def test_g4_batched_attention_restatement_matches_the_reference_vectors():
+    """oracle.mha_dense / spatial_attention_dense (the batched forms the HIP module tests use as checker) against the same fixtures."""
+    g = load_golden("g4_mha")
+    P = {"m." + k: v.requires_grad_(True) for k, v in weights(g).items()}
+    q = T(g["q"]).requires_grad_(True)
+    o, w = O.mha_dense(P, "m", q, H=8, attn_mask=T(g["mask"]))
+    assert_close(o, g["out"], TOL, "out"); assert_close(w.mean(1), g["weights"], TOL, "weights")
+    gq, gwq = _grad((o * T(g["go"])).sum(), [q, P["m.q_proj.weight"]])
+    assert_close(gq, g["gq"], TOL, "gq"); assert_close(gwq, g["gwq"], TOL, "gwq")
+    o2, w2 = O.mha_dense(P, "m", T(g["tok"]), T(g["kv"]), T(g["kv"]), H=8)
+    assert_close(o2, g["out2"], TOL, "out2"); assert_close(w2.mean(1), g["weights2"], TOL, "weights2")
+    g = load_golden("g4_spatial_attention")
+    P = {"spatial_attention." + k: v for k, v in weights(g).items()}
+    o, w = O.spatial_attention_dense(P, T(g["x"])[None], T(g["pos"])[None], 8)
+    assert_close(o[0], g["out"], TOL, "out"); assert_close(w[0], g["weights"], TOL, "weights")
+
+
 def test_g4_spatial_attention_as_is():
     g = load_golden("g4_spatial_attention")
     P = {"spatial_attention." + k: v.requires_grad_(True) for k, v in weights(g).items()}
@@ -96,6 +113,52 @@ def test_g4_spatial_attention_as_is():
     gs = _grad((o * T(g["go"])).sum(), [x] + [P[f"spatial_attention.attention.{n}.weight"] for n in names] + [P["spatial_attention.norm.weight"]])
     for got, key in zip(gs, ["gx", "gwq", "gwk", "gwv", "gwo", "gnw"]):
         assert_close(got, g[key], 5e-5, key)
+
+
+def test_g11_round6_options_as_is():
+    """GraphConvolution(normalize=False), DiffusionLayer conditioning, MultiHeadAttention with bool mask + key_padding_mask /
+    add_zero_attn: the oracle's restatement against vectors from the reference's classes run with those options."""
+    g = load_golden("g11_graph_conv_unnormalized")
+    ei = T(g["edge_index"])
+    gr = O.OracleGraph(ei, 18, normalize=False)
+    P = {"c." + k: v.requires_grad_(True) for k, v in weights(g, "a.").items()}
+    x = T(g["x"]).requires_grad_(True)
+    y = O.graph_conv(P, "c", x, gr, None)
+    assert_close(y, g["y"], TOL, "y")
+    for got, key in zip(_grad((y * T(g["gy"])).sum(), [x, P["c.node_lin.weight"], P["c.bias"]]), ("gx", "gw", "gb")):
+        assert_close(got, g[key], TOL, key)
+    P2 = {"c." + k: v.requires_grad_(True) for k, v in weights(g, "b.").items()}
+    x2 = T(g["x2"]).requires_grad_(True)
+    y2 = O.graph_conv(P2, "c", x2, gr, T(g["edge_attr"]))
+    assert_close(y2, g["y2"], TOL, "y2")
+    for got, key in zip(_grad((y2 * T(g["gy"])).sum(), [x2, P2["c.node_lin.weight"], P2["c.edge_lin.weight"]]), ("gx2", "gw2", "gwe2")):
+        assert_close(got, g[key], TOL, key)
+
+    g = load_golden("g11_diffusion_conditioning")
+    P = {"diffusion_layer." + k: v.requires_grad_(True) for k, v in weights(g).items()}
+    sched = O.diffusion_schedule(int(g["T"]), "cosine")
+    for tag in ("row", "one"):
+        x0, cond = T(g["x0"]).requires_grad_(True), T(g[f"{tag}.cond"]).requires_grad_(True)
+        xn = O.add_noise(sched, x0, T(g["noise"]), T(g["t"]))
+        assert_close(xn, g[f"{tag}.x_noisy"], TOL, "x_noisy")
+        pred = O.predict_noise(P, xn, T(g["t"]), condition=cond)
+        assert_close(pred, g[f"{tag}.pred"], TOL, f"{tag}.pred")
+        gs = _grad((pred * T(g["gp"])).sum(), [x0, P["diffusion_layer.denoise_net.0.weight"], P["diffusion_layer.condition_net.weight"], cond])
+        for got, key in zip(gs, ("gx0", "gw0", "gwc", "gc")):
+            assert_close(got, g[f"{tag}.{key}"], TOL, f"{tag}.{key}")
+        with torch.no_grad():
+            smp = O.ddpm_sample(P, sched, int(g["T"]), T(g["x_init"]), list(T(g["step_noise"])), int(g["steps"]), condition=cond.detach())
+        assert_close(smp, g[f"{tag}.sample"], 1e-4, f"{tag}.sample")
+
+    g = load_golden("g11_mha_masks")
+    for tag, za in (("plain", False), ("zero_attn", True)):
+        P = {"m." + k: v.requires_grad_(True) for k, v in weights(g, f"{tag}.w.").items()}
+        q = T(g["query"]).requires_grad_(True)
+        o, w = O.mha_dense(P, "m", q, T(g["key"]), T(g["value"]), H=3, attn_mask=T(g["bmask"]), key_padding_mask=T(g["kpm"]), add_zero_attn=za)
+        assert_close(o, g[f"{tag}.out"], TOL, f"{tag}.out"); assert_close(w.mean(1), g[f"{tag}.weights"], TOL, f"{tag}.weights")
+        assert_close(w.reshape(-1, *w.shape[2:]), g[f"{tag}.weights_per_head"], TOL, f"{tag}.weights_per_head")
+        gq, gwk = _grad((o * T(g["go"])).sum(), [q, P["m.k_proj.weight"]])
+        assert_close(gq, g[f"{tag}.gq"], TOL, f"{tag}.gq"); assert_close(gwk, g[f"{tag}.gwk"], TOL, f"{tag}.gwk")
 
 
 def test_g5_diffusion_layer_as_is():

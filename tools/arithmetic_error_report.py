@@ -51,20 +51,28 @@ def decisions_from_trace(trace):
     return dec
 
 
-def run_case(name, nodes=2000, edges=8000, graphs=2):
+TRACE_ORDER = ["graph_unet", "unet.up2.out", "unet.up2.in", "unet.up1.out", "unet.up1.in", "unet.up0.out", "unet.up0.in", "unet.bottom",
+               "relu.bottom", "unet.xs3", "relu.down2", "unet.xs2", "relu.down1", "unet.xs1", "relu.down0", "unet.xs0", "spatial_attention",
+               "graph_encoder", "feature_encoder"]      # backward order of the activations both sides trace
+
+
+def run_case(name, nodes=2000, edges=8000, graphs=2, seed=3, data_seed=0, trace_grads=False):
     """-> dict(rows=[(param, |ref|, err default, err HIP fp32, err torch fp32)], dead=[...], losses=(...), entropy=mean row entropy
-    of the spatial attention in nats or None, note, default=the default arithmetic)."""
+    of the spatial attention in nats or None, note, default=the default arithmetic).  ``trace_grads``: also ``trace_rows`` =
+    [(activation, gradient err default, HIP fp32, torch fp32, value err default, HIP fp32, torch fp32)] -- rel-L2 error of the gradient
+    that ARRIVES at each traced activation and of the activation itself, in backward order: where an arithmetic's error enters
+    (tools/gradient_error_trace.py)."""
     from dgdm_histopath_lab_amd import DGDMModel, ops
     from dgdm_histopath_lab_amd.synthetic import synthetic_batch
     c = cases()[name]
     cfgd = c["cfgd"]
     cfg = O.OracleConfig(**cfgd)
-    P = O.init_params(cfg, seed=3, perturb=0.05)
+    P = O.init_params(cfg, seed=seed, perturb=0.05)
     if c["tweak"] is not None:
         c["tweak"](P)
     hier = cfgd.get("use_hierarchical", True)
-    batch = synthetic_batch(0, graphs, nodes, edges)
-    gen = torch.Generator().manual_seed(11)
+    batch = synthetic_batch(data_seed, graphs, nodes, edges)
+    gen = torch.Generator().manual_seed(11 + data_seed)
     n = batch.x.size(0)
     cl, T = cfgd["hidden_dims"][-1], cfgd["num_diffusion_steps"]
     rng = dict(timesteps=torch.randint(0, T, (graphs,), generator=gen), noise=torch.randn(n, cl, generator=gen),
@@ -75,7 +83,7 @@ def run_case(name, nodes=2000, edges=8000, graphs=2):
     b64 = types.SimpleNamespace(x=batch.x.double(), edge_index=batch.edge_index, edge_attr=batch.edge_attr.double(), pos=batch.pos.double(),
                                 batch=batch.batch)
     kw64 = dict(mask_indices=mask_idx, mask_token=mask_tok.double(), **{k: (v.double() if v.is_floating_point() else v) for k, v in rng.items()})
-    tr64 = {} if hier else None
+    tr64 = {} if (hier or trace_grads) else None
     r64, g64 = O.loss_and_grads({k: v.double() for k, v in P.items()}, cfg, b64, trace=tr64, **kw64)
     dec = decisions_from_trace(tr64) if hier else None
     entropy = None
@@ -95,10 +103,15 @@ def run_case(name, nodes=2000, edges=8000, graphs=2):
             w = torch.softmax(sc, dim=-1)
             entropy = float(-(w * w.clamp_min(1e-300).log()).sum(-1).mean())
     O.DECISIONS = dec
+    tr32 = {} if trace_grads else None
     try:
-        r32, g32 = O.loss_and_grads(P, cfg, batch, mask_indices=mask_idx, mask_token=mask_tok, **rng)
+        r32, g32 = O.loss_and_grads(P, cfg, batch, mask_indices=mask_idx, mask_token=mask_tok, trace=tr32, **rng)
     finally:
         O.DECISIONS = None
+
+    def act_grads(tr):
+        return {k: (t.grad.double().cpu(), t.detach().double().cpu()) for k, t in tr.items()
+                if isinstance(t, torch.Tensor) and t.requires_grad and t.grad is not None}
 
     def gpu(attention, gemm):
         prev = ops.configure(attention=attention, gemm=gemm)
@@ -107,12 +120,19 @@ def run_case(name, nodes=2000, edges=8000, graphs=2):
             m.load_state_dict(P)
             m = m.cuda().eval()
             kw = dict(mask_indices=mask_idx.cuda(), mask_token=mask_tok.cuda(), **{k: v.cuda() for k, v in rng.items()})
-            out = m.pretrain_step(batch.to("cuda"), decisions=dec, **kw)
+            tr = {} if trace_grads else None
+            out = m.pretrain_step(batch.to("cuda"), decisions=dec, trace=tr, **kw)
+            if tr is not None:
+                for t in tr.values():
+                    if isinstance(t, torch.Tensor) and t.requires_grad:
+                        t.retain_grad()
             out["total_pretrain_loss"].backward()
+            traces.append(act_grads(tr) if tr is not None else None)
             return out["diffusion_loss"].item(), {k: p.grad.double().cpu() for k, p in m.named_parameters() if p.grad is not None}
         finally:
             ops.configure(**prev)
 
+    traces = []
     default = ops.configure()
     l_def, g_def = gpu(default["attention"], default["gemm"])
     l_f32, g_f32 = gpu("fp32", "fp32")
@@ -125,8 +145,17 @@ def run_case(name, nodes=2000, edges=8000, graphs=2):
             dead.append((k, g_def[k].abs().max().item(), g_f32[k].abs().max().item(), g32[k].abs().max().item()))
             continue
         rows.append((k, nb, (g_def[k] - g).norm().item() / nb, (g_f32[k] - g).norm().item() / nb, (g32[k].double() - g).norm().item() / nb))
+    trace_rows = None
+    if trace_grads:
+        a64, a32 = act_grads(tr64), act_grads(tr32)
+        trace_rows = []
+        for k in TRACE_ORDER:
+            if k in a64 and all(k in a for a in (traces[0], traces[1], a32)):
+                nb, nv = a64[k][0].norm().item(), a64[k][1].norm().item()
+                trace_rows.append((k, *((a[k][0] - a64[k][0]).norm().item() / nb for a in (traces[0], traces[1], a32)),
+                                   *((a[k][1] - a64[k][1]).norm().item() / nv for a in (traces[0], traces[1], a32))))
     l64 = r64["diffusion_loss"].item()
-    return dict(rows=rows, dead=dead, losses=(l64, l_def, l_f32, r32["diffusion_loss"].item()), entropy=entropy, note=c["note"],
+    return dict(trace_rows=trace_rows, rows=rows, dead=dead, losses=(l64, l_def, l_f32, r32["diffusion_loss"].item()), entropy=entropy, note=c["note"],
                 default=default, shape=(graphs, nodes, edges))
 
 
