@@ -303,6 +303,69 @@ def cpu_baseline(nodes, edges):
             "cpu": model, "physical_cores": physical, "logical_cpus": logical}
 
 
+def sample_loop_bench(model, dev, rows=10000, reps=5):
+    """DiffusionLayer.sample (reference: core/diffusion.py:214-275, the T-step denoise loop of the north star), graph-replayed, at
+    `rows` x hidden_dims[-1] with 10 and 50 inference steps: ms per loop, the algorithmic bytes of the seven launches of a step against
+    the HBM peak, and the CPU oracle's time for the same loop beside it (rank 0, N = 1; after the timed region of the headline)."""
+    from oracle import dgdm_oracle as O        # cpu_baseline leg only
+    dl = model.diffusion_layer
+    C, Hd, T = dl.node_dim, dl.hidden_dim, dl.num_timesteps
+    was_training = dl.training
+    dl.eval()
+    # per step: GEMM C->2Hd (read x, write h1), GroupNorm+SiLU (read + write h1), GEMM 2Hd->Hd, GroupNorm+SiLU, GEMM Hd->C, one normal
+    # draw (write z), the DDPM update (read x, eps, z; write x): fp32 rows, weights (0.9 MB) not counted
+    step_bytes = rows * 4 * ((C + 2 * Hd) + 2 * 2 * Hd + (2 * Hd + Hd) + 2 * Hd + (Hd + C) + C + 4 * C)
+    step_flop = 2.0 * rows * (C * 2 * Hd + 2 * Hd * Hd + Hd * C)
+    out = {"rows": rows, "width": C, "denoiser_widths": [C + Hd, 2 * Hd, Hd, C], "T": T, "launches_per_step": 7,
+           "algorithmic_bytes_per_step": step_bytes, "flop_per_step": step_flop,
+           "note": "sample(graphed=True): the whole loop is ONE recorded HIP graph (7 launches per step: 3 tile GEMMs, 2 fused GroupNorm+SiLU "
+                   "rows, one normal draw, one DDPM update; the time-embedding MLP runs once before the loop); eval mode as generate()"}
+    P = {k: v.detach().float().cpu() for k, v in model.state_dict().items() if k.startswith("diffusion_layer.") and "scheduler" not in k}
+    sched = O.diffusion_schedule(T, MODEL_CFG.get("diffusion_schedule", "cosine"))
+    try:
+        for steps in (10, 50):
+            for _ in range(2):
+                dl.sample((rows, C), dev, num_inference_steps=steps, graphed=True)       # warm-up + recording
+            torch.cuda.synchronize()
+            g, sx = dl._sample_graphs[((rows, C), steps, str(dev), False, False)][:2]
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                g.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / reps
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                dl.sample((rows, C), dev, num_inference_steps=steps, graphed=True)
+            torch.cuda.synchronize()
+            ms_call = (time.perf_counter() - t0) / reps * 1e3
+            gbps = steps * step_bytes / (ms * 1e-3) / 1e9
+            x_init = torch.randn(rows, C)
+            noises = [torch.randn(rows, C) for _ in range(steps - 1)]
+            torch.set_num_threads(min(32, os.cpu_count() or 8))
+            with torch.no_grad():
+                O.ddpm_sample(P, sched, T, x_init, noises, min(steps, 3))                    # warm-up
+                t0 = time.perf_counter()
+                O.ddpm_sample(P, sched, T, x_init, noises, steps)
+                cpu_ms = (time.perf_counter() - t0) * 1e3
+            out[f"steps{steps}"] = {"ms_per_loop": round(ms, 4), "us_per_step": round(ms / steps * 1e3, 2), "ms_per_call": round(ms_call, 4),
+                                    "timed_with": f"HIP events around {reps} replays of the recorded loop; ms_per_call = wall clock of sample() "
+                                                  "itself (input copy + replay + output clone)",
+                                    "roofline": {"bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                                 "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": None,
+                                                 "note": "7 dependent launches of 16-41 MB each per step: start-up and drain of each launch, "
+                                                         "not bytes, are what a step costs at this size"},
+                                    "cpu_baseline": {"value": round(cpu_ms, 2), "unit": "ms per loop", "cores": torch.get_num_threads(), "kind": "port",
+                                                     "sample": f"the same loop ({steps} steps, {rows} rows) by oracle.ddpm_sample, once"},
+                                    "speedup_vs_cpu": round(cpu_ms / ms, 1)}
+    except Exception as e:          # never lose the headline line to this leg
+        out["error"] = f"{type(e).__name__}: {e}"[:300]
+    finally:
+        dl.train(was_training)
+    return out
+
+
 def spawn_ranks(n, argv):
     """`python bench.py --gpus N` without a launcher around it: start the N ranks as FRESH child processes through
     `python -m torch.distributed.run` (one process per GPU, rendezvous on 127.0.0.1 at a port found free by bind(0)), hand rank 0's
@@ -374,6 +437,7 @@ def main():
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--no-strict", action="store_true", help="skip the strict-fp32-attention leg")
     ap.add_argument("--no-raster", action="store_true", help="skip the raster-pixel-positions leg (reported beside the headline)")
+    ap.add_argument("--no-sample-loop", action="store_true", help="skip the sample_loop object (the T-step denoise loop, graph-replayed)")
     ap.add_argument("--eval-mode", action="store_true", help="dropout off (diagnostics only; not the headline)")
     ap.add_argument("--precision", choices=["default", "fp32"], default="default",
                     help="fp32: run the MAIN leg with fp32 operands on the fp32 matrix instructions in the attention and in every dense "
@@ -478,6 +542,7 @@ def main():
         i = torch.arange(args.nodes, device=dev)
         one = torch.stack([(i % w).float(), (i // w).float()], 1) * args.pixel_positions
         batch.pos = one.repeat(args.batch, 1).contiguous()
+        batch.pos_extent = float(w * args.pixel_positions)
     stream, balance_note = None, None
     if args.mixed:
         # BASELINE configs[4]: per step a global pool of world x batch graphs with N ~ U{1k..10k}, E = 5 N, assigned to ranks by
@@ -557,8 +622,10 @@ def main():
     torch.cuda.synchronize()
     timed = ["attn_fwd", "attn_bwd_dq", "attn_bwd_dkv", "attn_bwd_fused", "attn_bwd_dq_reduce", "spmm_c512"]
     graphed = step is not eager_step
+    live_sink = None
     if not graphed:
         ops.TIMERS.start(timed)
+        ops.ATTN_SKIP_MAP_SINK = live_sink = []      # a list append per attention call; the maps are counted after the timed region
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -569,14 +636,36 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if graphed and stream is None:
+    ops.ATTN_SKIP_MAP_SINK = None
+    eager_timed_steps = args.steps
+    if graphed:
         # kernels launched by a graph replay cannot be bracketed by events: the per-kernel durations of the roofline come
-        # from eager launches of the same step right after the timed region (same kernels, same shapes, same clocks)
+        # from eager launches of the same step right after the timed region (same kernels, same shapes, same clocks); the mixed
+        # stream runs each of its layouts once.  The zero-block maps of those launches are kept: the roofline counts the scores
+        # the kernels EVALUATED (all of them on BASELINE's positions), not N^2 regardless
+        eager_timed_steps = len(stream) if stream is not None else min(args.steps, 5)
+        if stream is not None:
+            step_no[0] = 0
+        ops.ATTN_SKIP_MAP_SINK = live_sink = []
         ops.TIMERS.start(timed)
-        for _ in range(min(args.steps, 5)):
+        for _ in range(eager_timed_steps):
             eager_step()
         torch.cuda.synchronize()
+        ops.ATTN_SKIP_MAP_SINK = None
     ops.TIMERS.stop()
+
+    def live_scores(sink):
+        """(forward, one-pass backward, all) scores summed over the attention calls of `sink` (one host read per call: after the timed region)."""
+        f = b = t = 0
+        for m, plan_, H_ in sink:
+            a = ops.attn_skip_live_scores(m, plan_, H_)
+            f, b, t = f + a[0], b + a[1], t + a[2]
+        return f, b, t
+    pairs = None
+    if live_sink:
+        f, b, t = live_scores(live_sink)
+        pairs = {"attn_fwd": f / max(t, 1), "attn_bwd_fused": b / max(t, 1), "scores_all": t, "scores_forward": f, "scores_backward": b,
+                 "attention_calls": len(live_sink)}
     sustained = None
     if world == 1 and args.sustain_seconds > 0:
         n_s = max(args.steps, int(args.sustain_seconds / max(dt / args.steps, 1e-4)) + 1)
@@ -593,33 +682,46 @@ def main():
     # positions the input buffers hold) walks those block pairs over.  The positions are written into the recording's input buffer,
     # the step replayed, the synthetic positions restored.
     raster = None
-    if (world == 1 and graphed and stream is None and not args.large and args.pixel_positions == 0 and not args.no_raster
-            and gstep.input_buffers is not None and getattr(gstep.input_buffers, "pos", None) is not None):
+    if world == 1 and graphed and stream is None and not args.large and args.pixel_positions == 0 and not args.no_raster:
+        import copy
         import math as _m
-        buf = gstep.input_buffers.pos
-        keep = buf.clone()
+        from dgdm_histopath_lab_amd.training import GraphedPretrainStep
         w = int(_m.ceil(_m.sqrt(args.nodes)))
         i = torch.arange(args.nodes, device=dev)
         one = torch.stack([(i % w).float(), (i // w).float()], 1) * 224.0
-        buf.copy_(one.repeat(args.batch, 1))
-        for _ in range(3):
-            step()
+        rbatch = copy.copy(batch)
+        rbatch.pos = one.repeat(args.batch, 1).contiguous()
+        rbatch.pos_extent = float(w * 224)      # known on the host, as a loader knows it: the recording holds the zero-block map's launches
+        gr = GraphedPretrainStep(model, opt, mask_ratio=0.15)
+        rin = lambda: gr.input_buffers if gr.input_buffers is not None else rbatch
+        for _ in range(gr.warmup + 1 + 2):
+            gr(rin())
         n_r = max(5, min(args.steps, 20))
         torch.cuda.synchronize(); t1 = time.perf_counter()
         for _ in range(n_r):
-            step()
+            gr(rin())
         torch.cuda.synchronize()
         d_r = (time.perf_counter() - t1) / n_r
-        buf.copy_(keep)
+        # the scores the kernels evaluated on these positions: one eager step on them with the maps kept (after the timing)
+        keep_batch, batch = batch, rbatch
+        ops.ATTN_SKIP_MAP_SINK = rs = []
+        eager_step()
+        torch.cuda.synchronize()
+        ops.ATTN_SKIP_MAP_SINK = None
+        batch = keep_batch
+        rf, rb, rt = live_scores(rs)
         for _ in range(2):
             loss = step()
         torch.cuda.synchronize()
-        raster = {"value": round(args.batch / d_r, 3), "unit": "slides/s", "ms_per_step": round(d_r * 1e3, 3), "steps": n_r,
+        raster = {"pairs_live": {"forward": round(rf / max(rt, 1), 4), "backward": round(rb / max(rt, 1), 4),
+                                 "note": "fraction of the N^2 H scores the forward / the one-pass backward evaluated (unmarked block pairs of the "
+                                         "zero-block map; the backward at key-super-block granularity)"},
+                  "value": round(args.batch / d_r, 3), "unit": "slides/s", "ms_per_step": round(d_r * 1e3, 3), "steps": n_r,
                   "positions": "patch centres of a row-by-row raster at 224-pixel pitch (level-0 pixels, as the reference's preprocessing "
-                               "stores them), temperature 1",
-                  "note": "NOT the headline (BASELINE's positions are U[0,1)^2, where no block pair is zero): the same recording replayed; "
-                          "block pairs of the attention whose weights are exactly 0.0f are skipped with bit-identical results "
-                          "(ops.ATTN_SKIP_ZERO_BLOCKS)" if ops.ATTN_SKIP_ZERO_BLOCKS else "zero-block map off"}
+                               "stores them), temperature 1; pos_extent known on the host",
+                  "note": "NOT the headline (BASELINE's positions are U[0,1)^2, where no block pair can be zero and the step runs without "
+                          "the map): a second recording of the same step on these positions; block pairs of the attention whose weights are "
+                          "exactly 0.0f are skipped with bit-identical results (ops.attn_zero_blocks_possible)"}
     # the same step at the reference's own arithmetic (fp32 operands on the fp32 matrix instructions, in the attention and in every
     # dense layer): measured here, in the same process on the same box, so the two numbers are comparable
     strict = None
@@ -670,8 +772,18 @@ def main():
         heads, hd = cfg["attention_heads"], 16
         # products of 2 N^2 H d FLOP each: forward S, PV; two-pass backward dQ: S, dP, dS K / dK,dV: S, dP, P^T dO, dS^T Q; one-pass
         # backward (default): S, dP, P^T dO, dS^T Q, dS K -- each score evaluated once
-        flops = {"attn_fwd": attention_flops(sizes, heads, hd, 2), "attn_bwd_dq": attention_flops(sizes, heads, hd, 3),
-                 "attn_bwd_dkv": attention_flops(sizes, heads, hd, 4), "attn_bwd_fused": attention_flops(sizes, heads, hd, 5)}
+        if stream is not None:      # the mixed stream: FLOP of a step = mean over its layouts (the eager timing pass ran each once)
+            def _sizes(b_):
+                ptr_ = getattr(b_, "ptr", None)
+                if ptr_ is not None:
+                    pl = ptr_.tolist() if isinstance(ptr_, torch.Tensor) else list(ptr_)
+                    return [pl[i + 1] - pl[i] for i in range(len(pl) - 1)]
+                return torch.bincount(b_.batch).tolist()
+            layout_sizes = [_sizes(b_) for b_ in stream]
+            aflops = lambda k: sum(attention_flops(sz, heads, hd, k) for sz in layout_sizes) / len(layout_sizes)
+        else:
+            aflops = lambda k: attention_flops(sizes, heads, hd, k)
+        flops = {"attn_fwd": aflops(2), "attn_bwd_dq": aflops(3), "attn_bwd_dkv": aflops(4), "attn_bwd_fused": aflops(5)}
         split = ops.ATTN_PRECISION == "fp16x2"
         k16 = {"attn_fwd": "k_attn_h_fwd<4,1,1,3>", "attn_bwd_dq": "k_attn_h_bwd_dq<4,1,1,1>", "attn_bwd_dkv": "k_attn_h_bwd_dkv<2,1,1,3>",
                "attn_bwd_fused": f"k_attn_h_bwd_fused<{0 if args.eval_mode else 1},2>"}
@@ -684,28 +796,34 @@ def main():
         issued_x = {"attn_fwd": (4 + 3 + 2 * 1.0) / 2, "attn_bwd_dq": (4 + 4 + 3) / 3, "attn_bwd_dkv": (4 + 4 + 3 + 3) / 4,
                     "attn_bwd_fused": (4 + 4 + 3 + 3 + 4) / 5}
 
-        def attention_roofline(tm, names, fp16_pipe, graphed_note, valu_path=None, traffic_path=None, timed_steps=1):
+        def attention_roofline(tm, names, fp16_pipe, graphed_note, valu_path=None, traffic_path=None, timed_steps=1, live=None, pmc=True):
             dom = max((k for k in flops if k in tm), key=lambda k: tm[k][1] * tm[k][0]) if any(k in tm for k in flops) else None
             if dom is None:
                 return {"note": "no attention kernel was timed"}
             ms = tm[dom][1]
             # launches of the kernel per step (the one-pass backward runs once per scratch group: 1 at the headline batch)
             per_step = max(1.0, tm[dom][0] / max(1, timed_steps))
-            tf = flops[dom] / per_step / (ms * 1e-3) / 1e12
+            # the FLOP of the scores the kernel EVALUATED: block pairs the zero-block map marks (exact zeros) are not work done
+            live_frac = 1.0 if live is None else float(live.get(dom, 1.0))
+            tf = flops[dom] * live_frac / per_step / (ms * 1e-3) / 1e12
             peak = FP16_MFMA_PEAK_TFLOPS if fp16_pipe else FP32_MFMA_PEAK_TFLOPS
             # ALGORITHMIC FLOP of the reference's products (2 N^2 H d each) per second of the dominant kernel,
             # priced against the dense peak of the matrix pipe the kernel RUNS ON
             mfma = {"bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
                     "pipe": "f16 dense matrix pipe (v_mfma_f32_16x16x32_f16)" if fp16_pipe else "fp32 matrix pipe (v_mfma_f32_16x16x4_f32)",
-                    "algorithmic_flop": flops[dom] / per_step, "launches_per_step": per_step}
+                    "algorithmic_flop": flops[dom] * live_frac / per_step, "launches_per_step": per_step,
+                    "pairs_live": {"frac": round(live_frac, 4), "all_pairs_flop": flops[dom] / per_step,
+                                   "note": "fraction of the N^2 H scores this kernel evaluated (unmarked block pairs of the zero-block map, counted on "
+                                           "the device after the timed region); 1.0 on BASELINE's U[0,1)^2 positions"
+                                           if live is not None else "no zero-block map on this path: every pair evaluated"}}
             if fp16_pipe:
                 mfma.update({"mfma_dtype": "every operand (Q', K, V, dO, P, dS) as fp16 hi+lo, fp32 accumulate",
                              "products": {"attn_fwd": "S, PV", "attn_bwd_dq": "S, dP, dS K", "attn_bwd_dkv": "S, dP, P^T dO, dS^T Q",
                                           "attn_bwd_fused": "S, dP, P^T dO, dS^T Q, dS K (one pass: dQ, dK, dV)"}[dom],
                              "issued_tflops": round(issued_x[dom] * tf, 1), "issued_frac": round(issued_x[dom] * tf / peak, 4),
                              "fp32_equivalent_frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4)})
-            tpath = traffic_path or (PMC_TRAFFIC_LARGE if args.large else PMC_TRAFFIC)
-            vpath = valu_path or (PMC_VALU_LARGE if args.large else PMC_VALU)
+            tpath = (traffic_path or (PMC_TRAFFIC_LARGE if args.large else PMC_TRAFFIC)) if pmc else None
+            vpath = (valu_path or (PMC_VALU_LARGE if args.large else PMC_VALU)) if pmc else None
             traffic = None if tpath is None else pmc_traffic(names[dom], tpath)
             common = {"kernel": names[dom], "ms_per_launch": round(ms, 4), "launches_timed": tm[dom][0], "traffic": traffic,
                       "traffic_kind": TRAFFIC_KIND,
@@ -729,11 +847,13 @@ def main():
 
         ev_note = ("HIP events around eager launches of the same step right after the timed region (a graph replay cannot carry events)"
                    if graphed else "HIP events inside the timed region")
-        roofline = {"note": "not computed for this run; see the fixed-size headline run"}
-        if not args.mixed:
-            roofline = attention_roofline(timers, k16 if split else k32, split, ev_note,
-                                          None if split else PMC_VALU_FP32, None if split else PMC_TRAFFIC_FP32,
-                                          timed_steps=(min(args.steps, 5) if graphed and stream is None else args.steps))
+        roofline = attention_roofline(timers, k16 if split else k32, split, ev_note,
+                                      None if split else PMC_VALU_FP32, None if split else PMC_TRAFFIC_FP32,
+                                      timed_steps=(eager_timed_steps if graphed else args.steps), live=pairs if split else None,
+                                      pmc=not args.mixed and args.pixel_positions == 0)
+        if args.mixed:
+            roofline["note"] = ("mixed-size stream: FLOP and duration are means over the stream's layouts (each run once, eagerly, after the timed "
+                                "region); no PMC pass is committed for this workload (traffic / valu_pmc null)")
         if strict is not None:
             strict["roofline"] = attention_roofline(strict.pop("_timers"), k32, False,
                                                     "HIP events around eager launches of the fp32 step right after its timed region",
@@ -788,6 +908,8 @@ def main():
             result["projection_roofline"] = projection_microbench(dev)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.nodes, args.edges)
+        if world == 1 and not args.no_sample_loop and not args.mixed and not args.large:
+            result["sample_loop"] = sample_loop_bench(model, dev)
         print(json.dumps(result), flush=True)
 
 

@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(LIB_DIR, "libdgdm_hip.so")
 # diagnostic twin of the library: the GEMM kernels that issue their loads as inline asm, built with -DDGDM_STAGE_CANARY (their staging
 # registers hold NaN until a load lands; tests/test_hip_gemm_img.py runs them).  Never loaded by the product path.
 CANARY_PATH = os.path.join(LIB_DIR, "canary", "libdgdm_hip.so")
-CANARY_SOURCES = ("gemm_img.hip", "gemm_h.hip", "gemm_ws.hip")
+CANARY_SOURCES = ("gemm_img.hip", "gemm_h.hip")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
          "-I", os.path.join(ROOT, "include"), "-I", CSRC]
 

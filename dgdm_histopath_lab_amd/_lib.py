@@ -155,6 +155,7 @@ SIGNATURES = {
     "dgdm_attn_skip_map_bytes": (_sz, [_i32, _i32]),
     "dgdm_attn_skip_map_workspace_bytes": (_sz, [_i32, _i32]),
     "dgdm_attn_skip_map_build": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _p, _sz, _p, _sz, _p]),
+    "dgdm_attn_skip_map_count": (C.c_int, [_p, _p, _i32, _i32, _i32, _p, _p]),
     "dgdm_spatial_attn_h_fwd_sparse": (C.c_int, [_p, _p, _p, _p, _p, _i32, _i32, _i32, C.c_float, C.c_uint32, _p, _i64, _p, _i32, _p, _p, _p]),
     "dgdm_spatial_attn_h_bwd_fused_sparse": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, C.c_float, C.c_uint32,
                                                        _p, _p, _p, _i64, _i32, _i32, _p, _sz, _p, _p, _p]),

@@ -154,13 +154,14 @@ class SpatialAttention(nn.Module):
         self.spatial_proj = nn.Sequential(nn.Linear(2, embed_dim // 2), nn.ReLU(), nn.Linear(embed_dim // 2, embed_dim))  # dead
         self.norm = nn.LayerNorm(embed_dim)
 
-    def forward_batch(self, x: Tensor, pos: Tensor, plan: ops.AttnPlan) -> Tensor:
-        """x [N_tot, C], pos [N_tot, 2]; attention is restricted to each graph of ``plan``."""
+    def forward_batch(self, x: Tensor, pos: Tensor, plan: ops.AttnPlan, pos_extent: Optional[float] = None) -> Tensor:
+        """x [N_tot, C], pos [N_tot, 2]; attention is restricted to each graph of ``plan``.  ``pos_extent``: host-side upper bound of
+        the coordinate range inside any graph (GraphData.host_pos_extent), None when unknown -- see ops.attn_zero_blocks_possible."""
         att = self.attention
         xp = ops.add_posenc(x, pos, plan)
         qkv = att.fused_qkv(xp)
         o = ops.spatial_attention(qkv, pos, plan, att.num_heads, 1.0 / math.sqrt(att.head_dim), 1.0 / self.temperature,
-                                  att.attn_dropout.p, att.training)
+                                  att.attn_dropout.p, att.training, pos_extent=pos_extent)
         return self._project_and_norm(x, att.unpad_heads(o))
 
     def _project_and_norm(self, x: Tensor, o: Tensor) -> Tensor:

@@ -30,11 +30,14 @@ from ..graph import GraphStructure
 class GraphContext:
     """Everything the convolutions need from one edge list over ``num_nodes`` nodes."""
 
-    __slots__ = ("gs", "ea_hat", "num_nodes", "edge_index", "edge_attr")
+    __slots__ = ("gs", "ea_hat", "num_nodes", "edge_index", "edge_attr", "max_degree")
 
     def __init__(self, edge_index: Tensor, num_nodes: int, edge_attr: Optional[Tensor] = None, add_loops: bool = True,
-                 normalize: bool = True):
-        self.gs = GraphStructure(edge_index, num_nodes, add_loops=add_loops, normalize=normalize)
+                 normalize: bool = True, max_degree: Optional[int] = None):
+        """``max_degree``: host-side upper bound of the edge list's largest degree (GraphData.host_max_degree) or None; a pooled level
+        of the U-Net keeps a subset of its parent's edges, so the parent's bound holds for it."""
+        self.max_degree = max_degree
+        self.gs = GraphStructure(edge_index, num_nodes, add_loops=add_loops, normalize=normalize, max_degree=max_degree)
         if edge_attr is not None and edge_attr.dim() == 2 and edge_attr.size(1) % 4:
             # the gather kernels move 16-byte pieces: attribute widths that are not multiples of 4 get zero columns (the matching
             # zero columns of edge_lin.weight are added by GraphConvolution.forward; the products are unchanged)
@@ -51,7 +54,7 @@ class GraphContext:
         an edge-attribute aggregation."""
         c = GraphContext.__new__(GraphContext)
         c.gs, c.ea_hat = self.gs.extended(num_nodes, self.ea_hat)
-        c.num_nodes, c.edge_index, c.edge_attr = num_nodes, self.edge_index, self.edge_attr
+        c.num_nodes, c.edge_index, c.edge_attr, c.max_degree = num_nodes, self.edge_index, self.edge_attr, self.max_degree
         return c
 
 
@@ -94,7 +97,7 @@ class GraphConvolution(nn.Module):
             # out[d] = sum over the incoming edges of (x W^T)[src] + W_e a_e.  An index set of its own (unit weights).
             shared = isinstance(edge_index, GraphContext)
             ctx = GraphContext(edge_index.edge_index if shared else edge_index, x.size(0), edge_index.edge_attr if shared else edge_attr,
-                               add_loops=False, normalize=False)
+                               add_loops=False, normalize=False, max_degree=edge_index.max_degree if shared else None)
         else:
             ctx = _context(edge_index, x, edge_attr, self.add_self_loops)
         if self.edge_lin is not None and ctx.ea_hat is not None:
@@ -279,7 +282,7 @@ class GraphUNet(nn.Module):
                     # coarser level's index set plus one self loop per extra node, copied instead of built
                     ctxs[(k, n)] = base.extended(n)
                 else:
-                    ctxs[(k, n)] = GraphContext(eis[k], n, eas[k])
+                    ctxs[(k, n)] = GraphContext(eis[k], n, eas[k], max_degree=ctx0.max_degree)
             return ctxs[(k, n)]
 
         x = self.down_convs[0](x, ctx0)

@@ -113,7 +113,62 @@ __global__ __launch_bounds__(256) void k_attn_skip_map(const float* __restrict__
   }
 }
 
+// Scores the kernels EVALUATE under a map (measurement only: bench.py prices the attention kernels by the work they did, not by N^2):
+// out[0] += rows(q block) x rows(k block) x heads for every unmarked (query block, key block) pair [the forward walks these],
+// out[1] += rows(q block) x rows(key super-block) x heads for every unmarked (key super-block, query block) pair [the one-pass
+// backward walks these: a super-block runs all its key tiles against a live query block], out[2] += N_g^2 x H (every pair).
+// grid (num_blocks, H / group, 2) like k_attn_skip_map.
+__global__ __launch_bounds__(256) void k_attn_map_count(const uint32_t* __restrict__ map, const int32_t* __restrict__ ptr, int B, int H,
+                                                        int num_blocks, unsigned long long* __restrict__ out) {
+  const int hg = attn_map_group(H), g = blockIdx.y;
+  const uint32_t* row = map + attn_map_row(blockIdx.z, g, H, num_blocks, blockIdx.x);
+  unsigned long long live = 0, all = 0;
+  if (blockIdx.z == 0) {
+    int n0, ng, lblk, blk0;
+    if (!find_block(ptr, B, blockIdx.x, &n0, &ng, &lblk, &blk0)) return;
+    const int nbg = (ng + HB - 1) / HB;
+    const unsigned long long rq = (unsigned long long)min(HB, ng - lblk * HB);
+    for (int kb = threadIdx.x; kb < nbg; kb += 256) {
+      const unsigned long long rk = (unsigned long long)min(HB, ng - kb * HB);
+      all += rq * rk * hg;
+      if (!((row[kb >> 5] >> (kb & 31)) & 1u)) live += rq * rk * hg;
+    }
+  } else {
+    int ng, sbl, blk0;
+    if (!find_sblock_m(ptr, B, blockIdx.x, &ng, &sbl, &blk0)) return;
+    const int nbg = (ng + HB - 1) / HB;
+    const unsigned long long rk = (unsigned long long)(min(ng, (sbl + 1) * ATTN_SBW * HB) - sbl * ATTN_SBW * HB);
+    for (int qb = threadIdx.x; qb < nbg; qb += 256) {
+      const unsigned long long rq = (unsigned long long)min(HB, ng - qb * HB);
+      if (!((row[qb >> 5] >> (qb & 31)) & 1u)) live += rq * rk * hg;
+    }
+  }
+  __shared__ unsigned long long sm[2][256];
+  sm[0][threadIdx.x] = live; sm[1][threadIdx.x] = all;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) { sm[0][threadIdx.x] += sm[0][threadIdx.x + o]; sm[1][threadIdx.x] += sm[1][threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    if (sm[0][0]) atomicAdd(out + blockIdx.z, sm[0][0]);
+    if (blockIdx.z == 0 && sm[1][0]) atomicAdd(out + 2, sm[1][0]);
+  }
+}
+
 }  // namespace
+
+// counts[0] = scores the forward evaluates under `map`, counts[1] = scores the one-pass backward evaluates, counts[2] = all scores
+// (sum over graphs of n_g^2 x H); counts must be zero on entry (3 x uint64, device).  Measurement only (bench.py).
+extern "C" int dgdm_attn_skip_map_count(const uint32_t* map, const int32_t* ptr, int32_t B, int32_t num_blocks, int32_t H, uint64_t* counts,
+                                        void* stream_) {
+  DGDM_REQUIRE(B >= 0 && H > 0 && num_blocks >= 0);
+  if (num_blocks == 0 || B == 0) return DGDM_OK;
+  DGDM_REQUIRE(map && ptr && counts);
+  hipLaunchKernelGGL(k_attn_map_count, dim3(num_blocks, H / attn_map_group(H), 2), dim3(256), 0, static_cast<hipStream_t>(stream_), map, ptr, B, H,
+                     num_blocks, reinterpret_cast<unsigned long long*>(counts));
+  return dgdm_launch_status();
+}
 
 // bytes of the map (both sets of rows) and of the workspace (block statistics) for a batch of num_blocks packed blocks, H heads
 extern "C" size_t dgdm_attn_skip_map_bytes(int32_t num_blocks, int32_t H) {

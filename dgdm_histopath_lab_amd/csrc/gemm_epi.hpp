@@ -1,4 +1,4 @@
-// Device code shared by the weight-image GEMMs (gemm_img.hip, gemm_ws.hip): image constants, operand scales and splits, the
+// Device code of the weight-image GEMMs (gemm_img.hip): image constants, operand scales and splits, the
 // staging canary, and the fused epilogues.
 #pragma once
 #include "common.hpp"
@@ -9,7 +9,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-// (outside the anonymous namespace: gemm_img.hip hands these to the launcher in gemm_ws.hip)
 enum { EPI_NONE = 0, EPI_ACT = 1, EPI_ACTBWD = 2, EPI_NORM = 3 };
 
 struct EpiArgs {
@@ -27,9 +26,8 @@ struct EpiArgs {
   unsigned* amax_out;               // nullable: slot group that receives max|C|
 };
 
-// gemm_ws.hip: the weight-stationary kernel for narrow layers; returns DGDM_ERR_UNSUPPORTED (nothing launched) for shapes it does not take
-int dgdm_gemm_ws_launch(int epi_kind, hipStream_t s, const float* A, int64_t lda, int M, int K, const char* img, int T_img, int t_begin,
-                        int Ncols, const float* bias, float* C, int64_t ldc, const unsigned* amax_a, const EpiArgs& epi);
+// (round 5's weight-stationary persistent kernel for the narrow layers -- measured slower at every shape, never compiled into the
+// shipped library -- left the product tree in round 6: tools/attic/gemm_ws.hip, with the measurements in DESIGN.md section 4)
 
 namespace {
 

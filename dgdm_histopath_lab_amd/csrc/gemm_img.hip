@@ -574,10 +574,6 @@ extern "C" int dgdm_gemm_rows_img(const float* A, int64_t lda, int32_t M, int32_
   hipStream_t s = static_cast<hipStream_t>(stream);
   const char* img = static_cast<const char*>(image);
   const EpiArgs none{};
-  if (!accumulate) {     // narrow layers: the weight-stationary kernel (gemm_ws.hip) when it takes the shape
-    const int r = dgdm_gemm_ws_launch(EPI_NONE, s, A, lda, M, K, img, image_tiles, tile_begin, ncols, bias, C, ldc, amax_a, none);
-    if (r != DGDM_ERR_UNSUPPORTED) return r;
-  }
   if (ncols <= DGDM_IMG_NARROW_MAX)
     return launch_img<DGDM_IMG_WM, DGDM_IMG_WN, DGDM_IMG_NTW, EPI_NONE>(s, A, lda, M, K, img, image_tiles, tile_begin, ncols, bias, C, ldc, accumulate, amax_a, none);
   return launch_img8<EPI_NONE>(s, A, lda, M, K, img, image_tiles, tile_begin, ncols, bias, C, ldc, accumulate, amax_a, none);
@@ -612,10 +608,6 @@ extern "C" int dgdm_gemm_rows_img_act(const float* A, int64_t lda, int32_t M, in
   e.pre_out = pre; e.ldp = ldp; e.act = act; e.drop_p = drop_p; e.seed = dgdm_seed_arg(seed); e.amax_out = amax_y;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const char* img = static_cast<const char*>(image);
-  {
-    const int r = dgdm_gemm_ws_launch(EPI_ACT, s, A, lda, M, K, img, image_tiles, tile_begin, ncols, bias, Y, ldy, amax_a, e);
-    if (r != DGDM_ERR_UNSUPPORTED) return r;
-  }
   if (ncols <= DGDM_IMG_NARROW_MAX)
     return launch_img<DGDM_IMG_WM, DGDM_IMG_WN, DGDM_IMG_NTW, EPI_ACT>(s, A, lda, M, K, img, image_tiles, tile_begin, ncols, bias, Y, ldy, 0, amax_a, e);
   return launch_img8<EPI_ACT>(s, A, lda, M, K, img, image_tiles, tile_begin, ncols, bias, Y, ldy, 0, amax_a, e);
@@ -633,10 +625,6 @@ extern "C" int dgdm_gemm_rows_img_act_bwd(const float* A, int64_t lda, int32_t M
   e.pre_in = pre; e.ldp = ldp; e.act = act; e.drop_p = drop_p; e.seed = dgdm_seed_arg(seed); e.amax_out = amax_g;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const char* img = static_cast<const char*>(image);
-  {
-    const int r = dgdm_gemm_ws_launch(EPI_ACTBWD, s, A, lda, M, K, img, image_tiles, tile_begin, ncols, nullptr, G, ldg, amax_a, e);
-    if (r != DGDM_ERR_UNSUPPORTED) return r;
-  }
   if (ncols <= DGDM_IMG_NARROW_MAX)
     return launch_img<DGDM_IMG_WM, DGDM_IMG_WN, DGDM_IMG_NTW, EPI_ACTBWD>(s, A, lda, M, K, img, image_tiles, tile_begin, ncols, nullptr, G, ldg, 0, amax_a, e);
   return launch_img8<EPI_ACTBWD>(s, A, lda, M, K, img, image_tiles, tile_begin, ncols, nullptr, G, ldg, 0, amax_a, e);
@@ -671,10 +659,6 @@ extern "C" int dgdm_gemm_rows_img_norm(const float* A, int64_t lda, int32_t M, i
   e.eps = eps; e.L = ncols / groups; e.act = act; e.drop_p = drop_p; e.seed = dgdm_seed_arg(seed); e.amax_out = amax_y;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const char* img = static_cast<const char*>(image);
-  {
-    const int r = dgdm_gemm_ws_launch(EPI_NORM, s, A, lda, M, K, img, image_tiles, tile_begin, ncols, bias, Y, ldy, amax_a, e);
-    if (r != DGDM_ERR_UNSUPPORTED) return r;
-  }
   if (ncols <= DGDM_IMG_NARROW_MAX && e.L <= 128)
     return launch_img<4, 1, 4, EPI_NORM>(s, A, lda, M, K, img, image_tiles, tile_begin, ncols, bias, Y, ldy, 0, amax_a, e);
   return launch_img8<EPI_NORM>(s, A, lda, M, K, img, image_tiles, tile_begin, ncols, bias, Y, ldy, 0, amax_a, e);

@@ -29,8 +29,9 @@ __device__ __forceinline__ float4 dropout_scale4(uint32_t seed, uint64_t e, uint
 // One range, no branch: 8 FMAs, one v_exp_f32.  The NEGATIVE side uses h = 0.5 erfc(t) directly instead of 1 - (1 - h), so
 // gelu(z) for z < 0 keeps full relative accuracy (torch's fp32 GELU loses it there).  Against float64 over [-12, 12]
 // (tools/check_fast_gelu.py): gelu max abs error 2.4e-7 (torch fp32: 1.2e-6), gelu' 1.4e-7 (torch: 2.8e-7).
-__device__ __forceinline__ float half_erfc_abs(float z) {          // 0.5 * erfc(|z| / sqrt(2))
-  const float t = fminf(fabsf(z) * 0.70710678118654752f, 4.0f);
+__device__ __forceinline__ float half_erfc_abs(float z) {          // 0.5 * erfc(|z| / sqrt(2)); exactly 0 from |z| = 4 sqrt(2) on
+  const float ta = fabsf(z) * 0.70710678118654752f;
+  const float t = fminf(ta, 4.0f);
   float r = -1.1622888450801838e-05f;
   r = fmaf(r, t, 0.00015313828771468252f);
   r = fmaf(r, t, -0.0008489217725582421f);
@@ -40,10 +41,15 @@ __device__ __forceinline__ float half_erfc_abs(float z) {          // 0.5 * erfc
   r = fmaf(r, t, 0.14830751717090607f);
   r = fmaf(r, t, 0.918442964553833f);
   r = fmaf(r, t, 1.6279072761535645f);
-  return __builtin_amdgcn_exp2f(-fmaf(t, r, 1.0f));
+  // past the clamp the polynomial's value would stay at 0.5 erfc(4) = 7.7e-9 for ever (gelu(-1e4) = -7.7e-5, gelu' with a floor):
+  // h is 0 there, a step of 4e-8 at |z| = 5.66.  !(ta < 4) also takes NaN through as 0 -- the callers' products keep it.
+  return ta < 4.0f ? __builtin_amdgcn_exp2f(-fmaf(t, r, 1.0f)) : 0.0f;
 }
 __device__ __forceinline__ float gelu_f(float z) {                 // z >= 0: z - z h;  z < 0: z h   (h = 0.5 erfc(|z| / sqrt 2))
-  return fmaxf(z, 0.f) - fabsf(z * half_erfc_abs(z));
+  // one rounding on the positive side (fma); with h = 0 past the clamp: gelu(1e4) = 1e4, gelu(-1e4) = -0, and +-inf give NaN (inf * 0),
+  // which is what torch's fp32 GELU returns for them as well (tools/check_fast_gelu.py prints the table)
+  const float h = half_erfc_abs(z);
+  return z >= 0.f ? fmaf(-z, h, z) : z * h;
 }
 __device__ __forceinline__ float gelu_df(float z) {                // Phi(z) + z phi(z)
   const float h = half_erfc_abs(z);

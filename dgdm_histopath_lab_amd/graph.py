@@ -36,6 +36,30 @@ class GraphData:
     def num_nodes(self) -> int:
         return 0 if self.x is None else self.x.size(0)
 
+    def host_max_degree(self) -> Optional[int]:
+        """``max_degree`` if set, else the largest in- / out-degree of ``edge_index`` while it still lives on the HOST (no device sync);
+        else None.  GraphStructure sizes its long-row tables by it."""
+        d = getattr(self, "max_degree", None)
+        if d is None and isinstance(self.edge_index, torch.Tensor) and not self.edge_index.is_cuda:
+            if self.edge_index.numel() == 0:
+                return 0
+            n = max(self.num_nodes, int(self.edge_index.max()) + 1)
+            d = int(max(torch.bincount(self.edge_index[0], minlength=n).max(), torch.bincount(self.edge_index[1], minlength=n).max()))
+        return d
+
+    def host_pos_extent(self) -> Optional[float]:
+        """``pos_extent`` if set, else the largest coordinate range of ``pos`` when it still lives on the HOST (a loader calls this
+        before the upload: no device sync), rounded up to a power of two so that batches of one data set share one value; else None.
+        An upper bound of the coordinate range inside any graph: the spatial attention uses it to tell, without looking at the
+        device, whether any of its block pairs can be exactly zero (ops.attn_zero_blocks_possible)."""
+        e = getattr(self, "pos_extent", None)
+        if e is None and isinstance(self.pos, torch.Tensor) and not self.pos.is_cuda and self.pos.numel() > 0:
+            e = float((self.pos.max(dim=0).values - self.pos.min(dim=0).values).max())
+        if e is None:
+            return None
+        import math
+        return float(2.0 ** math.ceil(math.log2(e))) if e > 0 else 0.0
+
     @property
     def num_edges(self) -> int:
         return 0 if self.edge_index is None else self.edge_index.size(1)
@@ -88,6 +112,10 @@ class GraphBatch(GraphData):
                   y=torch.cat(ys) if ys else None)
         out.batch = torch.cat(bvec)
         out.ptr = ptr  # host-side python ints: the per-graph node offsets
+        ext = [d.host_pos_extent() if isinstance(d, GraphData) else getattr(d, "pos_extent", None) for d in graphs] if poss else []
+        out.pos_extent = max(ext) if ext and all(e is not None for e in ext) else None
+        deg = [d.host_max_degree() if isinstance(d, GraphData) else getattr(d, "max_degree", None) for d in graphs]
+        out.max_degree = max(deg) if all(v is not None for v in deg) else None
         return out
 
 
@@ -163,17 +191,24 @@ class GraphStructure:
                                        g.dinv.data_ptr(), _lib.ptr(ea_out), _lib.stream_ptr(dev)), "dgdm_csr_extend")
         return g, ea_out
 
-    def __init__(self, edge_index: torch.Tensor, num_nodes: int, add_loops: bool = True, pipeline: str = "pair", normalize: bool = True):
+    def __init__(self, edge_index: torch.Tensor, num_nodes: int, add_loops: bool = True, pipeline: str = "pair", normalize: bool = True,
+                 max_degree: Optional[int] = None):
         """``pipeline``: "pair" (dgdm_csr_build_pair) or "single" (one entry point per array set; same results).
         ``normalize=False``: the entry weights are 1 instead of deg^-1/2 deg^-1/2 (GraphConvolution(normalize=False): a plain sum
-        over the incoming edges, core/graph_layers.py:76-86)."""
-        self._build(edge_index, num_nodes, add_loops, pipeline)
+        over the incoming edges, core/graph_layers.py:76-86).
+        ``max_degree``: a HOST-side upper bound of the largest in- / out-degree of the edge list (GraphData.host_max_degree: a loader
+        takes it before the upload), None when unknown.  With it the long-row tables and their scratch (23 MB per index set at the
+        headline batch, 0.6 GB at 6 M entries) are only allocated when a row CAN be longer than DGDM_SPMM_LONG_ROW entries; without
+        it they are sized for the worst case (whether a graph has hubs is otherwise known on the device only)."""
+        self._build(edge_index, num_nodes, add_loops, pipeline, max_degree)
         if not normalize and self.num_entries > 0:
             lib, st = _lib.load(), _lib.stream_ptr(self.w.device)
             for w in (self.w, self.w_t):
                 _lib.check(lib.dgdm_fill_u32(w.data_ptr(), w.numel(), 0x3F800000, st), "dgdm_fill_u32")       # 1.0f
 
-    def _build(self, edge_index: torch.Tensor, num_nodes: int, add_loops: bool, pipeline: str) -> None:
+    LONG_ROW = 128      # DGDM_SPMM_LONG_ROW (include/dgdm_hip.h)
+
+    def _build(self, edge_index: torch.Tensor, num_nodes: int, add_loops: bool, pipeline: str, max_degree: Optional[int] = None) -> None:
         _lib.require_cuda(edge_index)
         lib = _lib.load()
         if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.size(0) != 2:
@@ -201,7 +236,8 @@ class GraphStructure:
                 self.status = ws[off:off + 4].view(torch.int32)
             lt0 = lt1 = None
             item_cap = 0
-            if 0 < N <= (1 << 20) and n_ent > 0:     # long-row tables (hubs): both orientations share one scratch for partial sums
+            may_be_long = max_degree is None or int(max_degree) + int(add_loops) > self.LONG_ROW
+            if 0 < N <= (1 << 20) and n_ent > 0 and may_be_long:     # long-row tables (hubs): both orientations share one scratch for partial sums
                 words = lib.dgdm_spmm_long_table_words(n_ent)
                 item_cap, slot_cap = lib.dgdm_spmm_long_item_cap(n_ent), lib.dgdm_spmm_long_slot_cap(n_ent)
                 self.long_tables = torch.empty(2, words, **i32)

@@ -80,7 +80,7 @@ class BatchPlan:
         batch = getattr(data, "batch", None)
         self.seg = batch if batch is not None else torch.zeros(n, dtype=torch.long, device=device)  # R4
         self.attn = ops.AttnPlan(self.ptr, device)
-        self.ctx = GraphContext(data.edge_index, n, getattr(data, "edge_attr", None))
+        self.ctx = GraphContext(data.edge_index, n, getattr(data, "edge_attr", None), max_degree=getattr(data, "max_degree", None))
 
 
 class DGDMModel(nn.Module):
@@ -268,7 +268,7 @@ class DGDMModel(nn.Module):
         if self.spatial_attention is not None and pos is not None:
             if return_attention:
                 attention_weights = self.spatial_attention.attention_weights(h, pos, plan.attn)
-            h = self.spatial_attention.forward_batch(h, pos, plan.attn)
+            h = self.spatial_attention.forward_batch(h, pos, plan.attn, pos_extent=getattr(data, "pos_extent", None))
             if trace is not None:
                 trace["spatial_attention"] = h
         if self.hierarchical_processor is not None:

@@ -8,6 +8,8 @@ from __future__ import annotations
 import collections
 from typing import Optional
 
+import math
+
 import torch
 
 from . import _lib
@@ -266,20 +268,49 @@ ATTN_BWD_FUSED_BUDGET = None
 # bounds (two small launches per attention call) and walked over by the forward and the one-pass backward: the same bits in every
 # output, a band's worth of work on real slides; nothing is skipped for positions in [0, 1) (csrc/attn_h.hpp, attn_skip.hip).
 ATTN_SKIP_ZERO_BLOCKS = True
+ATTN_ZERO_MARGIN_LOG2 = 200.0     # csrc/attn_h.hpp::ATTN_ZERO_MARGIN
 
 
-_ATTN_BUDGET_SEEN: dict = {}
+def attn_zero_blocks_possible(pos_extent: Optional[float], inv_tau: float) -> bool:
+    """Can ANY (query block, key block) pair of a batch be all-zero?  A pair is only marked when its distance term alone pushes every
+    score 200 log2 units below the row maximum (csrc/attn_skip.hip::pair_is_zero), i.e. when two nodes of one graph are at least
+    200 / (inv_tau log2 e) apart.  ``pos_extent`` -- an upper bound of the coordinate range inside any graph, known on the HOST
+    (GraphData.host_pos_extent: loaders set it before the upload) -- decides that without a device sync: on BASELINE's U[0,1)^2
+    positions no pair can be marked, and the attention then runs without the map's two launches and without the kernels' walk over
+    it (12.78 against 12.83 ms per step).  Unknown extent (None): the map is built, as before."""
+    if not ATTN_SKIP_ZERO_BLOCKS:
+        return False
+    if pos_extent is None:
+        return True
+    return math.sqrt(2.0) * float(pos_extent) * float(inv_tau) * LOG2E >= ATTN_ZERO_MARGIN_LOG2
+
+
+_ATTN_BUDGET: dict = {}
+ATTN_BWD_GROUPS_LAST = 0      # launches the last one-pass attention backward was cut into (bench.py reports it)
 
 
 def _attn_bwd_budget(device) -> int:
+    """Scratch budget of the one-pass attention backward's partial-dQ tiles: min(16 GiB, a quarter of the memory available to this
+    process: free + torch's unused cache), taken ONCE per device and kept (the free-memory figure of every call shrank while the allocator warmed up,
+    so the group count -- and with it the association of the dQ sum -- depended on the moment; one driver query per eager step went
+    with it).  ``ops.reset_attn_bwd_budget()`` forgets it (after freeing a large model, say); an int in ``ATTN_BWD_FUSED_BUDGET`` fixes it."""
     if ATTN_BWD_FUSED_BUDGET is not None:
         return int(ATTN_BWD_FUSED_BUDGET)
     key = device.index if device.index is not None else torch.cuda.current_device()
-    if torch.cuda.is_current_stream_capturing():      # no runtime query inside a capture: what the eager warm-up steps of the same step saw
-        return _ATTN_BUDGET_SEEN.get(key, 16 << 30)
-    free, _total = torch.cuda.mem_get_info(device)
-    _ATTN_BUDGET_SEEN[key] = b = max(64 << 20, min(16 << 30, free // 4))
+    b = _ATTN_BUDGET.get(key)
+    if b is None:
+        if torch.cuda.is_current_stream_capturing():      # no runtime query inside a capture (the eager warm-up steps come first)
+            return 16 << 30
+        free, _total = torch.cuda.mem_get_info(key)      # what the driver can still hand out + what torch holds cached but unused
+        avail = free + torch.cuda.memory_reserved(key) - torch.cuda.memory_allocated(key)
+        _ATTN_BUDGET[key] = b = max(64 << 20, min(16 << 30, avail // 4))
     return b
+
+
+def reset_attn_bwd_budget() -> None:
+    _ATTN_BUDGET.clear()
+
+
 _SIDE_STREAMS: dict = {}
 
 
@@ -313,15 +344,18 @@ def attn_pack(x, col0: int, cstride: int, ntensors: int, scale0: float, plan: At
 
 
 def spatial_attn_h_fwd_raw(qkv, pos, plan: AttnPlan, H: int, scale: float, inv_tau: float, drop_p: float = 0.0, seed: int = 0,
-                           packed: Optional[PackedOperands] = None, variant: int = 0):
-    """Split-fp16 forward over a fused [N, 3*H*16] QKV buffer; returns (out, lse2_b, packed)."""
+                           packed: Optional[PackedOperands] = None, variant: int = 0, zero_blocks: Optional[bool] = None):
+    """Split-fp16 forward over a fused [N, 3*H*16] QKV buffer; returns (out, lse2_b, packed).  ``zero_blocks``: build and use the
+    zero-block map (None: ``ATTN_SKIP_ZERO_BLOCKS``; callers that know the positions' extent pass attn_zero_blocks_possible(...))."""
     lib = _lib.load()
     N, C = qkv.size(0), H * 16
     pk = packed if packed is not None else attn_pack(qkv, 0, C, 3, scale * LOG2E, plan, H, pos=pos, pos_scale=inv_tau * LOG2E)
     out = torch.empty(N, C, dtype=torch.float32, device=qkv.device)
     lse2_b = torch.empty(max(lib.dgdm_attn_pack_bytes(plan.num_q_tiles, H, 3) // 4, 4), dtype=torch.float32, device=qkv.device)
-    if ATTN_SKIP_ZERO_BLOCKS and pk.skip_map is None and plan.num_q_tiles > 0:
+    if (ATTN_SKIP_ZERO_BLOCKS if zero_blocks is None else zero_blocks) and pk.skip_map is None and plan.num_q_tiles > 0:
         pk.skip_map = attn_skip_map(pk, plan, H)
+    if ATTN_SKIP_MAP_SINK is not None:
+        ATTN_SKIP_MAP_SINK.append((pk.skip_map, plan, H))
     slot = new_amax_slot(qkv.device)        # max |O| from the kernel itself: the output projection needs no reduction launch
     TIMERS.timed("attn_fwd", lambda: _lib.check(
         lib.dgdm_spatial_attn_h_fwd_sparse(pk.r(0).data_ptr(), pk.r(1).data_ptr(), pk.r(2).data_ptr(), pk.pos_b.data_ptr(),
@@ -343,6 +377,23 @@ def attn_skip_map(pk: PackedOperands, plan: AttnPlan, H: int) -> torch.Tensor:
                                             ws.data_ptr(), ws.numel() * 4, m.data_ptr(), m.numel() * 4, _lib.stream_ptr(dev)),
                "dgdm_attn_skip_map_build")
     return m
+
+
+ATTN_SKIP_MAP_SINK: Optional[list] = None      # measurement hook (bench.py): when a list, every forward appends (map or None, plan, H)
+
+
+def attn_skip_live_scores(skip_map: Optional[torch.Tensor], plan: AttnPlan, H: int):
+    """(scores the forward evaluates, scores the one-pass backward evaluates, all scores = sum n_g^2 H) under ``skip_map`` -- one device
+    reduction over the map and ONE host read: measurement only, never on the training path."""
+    total = sum((plan.ptr_host[g + 1] - plan.ptr_host[g]) ** 2 for g in range(plan.B)) * H
+    if skip_map is None or plan.num_q_tiles == 0:
+        return total, total, total
+    counts = torch.zeros(3, dtype=torch.int64, device=skip_map.device)
+    _lib.check(_lib.load().dgdm_attn_skip_map_count(skip_map.data_ptr(), plan.ptr_dev.data_ptr(), plan.B, plan.num_q_tiles, H, counts.data_ptr(),
+                                                    _lib.stream_ptr(skip_map.device)), "dgdm_attn_skip_map_count")
+    f, b, t = (int(v) for v in counts.tolist())
+    assert t == total, (t, total)
+    return f, b, t
 
 
 def spatial_attn_h_bwd_raw(pk: PackedOperands, out, gout, plan: AttnPlan, H: int, scale: float, inv_tau: float, lse2_b, dqkv,
@@ -392,6 +443,8 @@ def spatial_attn_h_bwd_raw(pk: PackedOperands, out, gout, plan: AttnPlan, H: int
                 cnt = (cnt + 1) // 2
             groups.append((sb, cnt, lib.dgdm_spatial_attn_h_bwd_fused_workspace_bytes(ph, plan.B, H, sb, cnt)))
             sb += cnt
+        global ATTN_BWD_GROUPS_LAST
+        ATTN_BWD_GROUPS_LAST = len(groups)
         ws = torch.empty(max(max(g[2] for g in groups), 16) // 4, dtype=torch.float32, device=out.device)
         slot = new_amax_slot(out.device)    # max |dQ|, |dK|, |dV| from the kernels that write them (dqkv is the QKV projection's operand)
 
@@ -434,9 +487,9 @@ class _SpatialAttentionH(torch.autograd.Function):
     fp32-MFMA kernels on gfx950 at the same error against float64 (tests/test_hip_attention.py)."""
 
     @staticmethod
-    def forward(ctx, qkv, pos, plan: AttnPlan, H: int, scale: float, inv_tau: float, drop_p: float, seed: int):
+    def forward(ctx, qkv, pos, plan: AttnPlan, H: int, scale: float, inv_tau: float, drop_p: float, seed: int, zero_blocks=None):
         qkv, pos = _f32c(qkv), _f32c(pos)
-        out, lse2_b, pk = spatial_attn_h_fwd_raw(qkv, pos, plan, H, scale, inv_tau, drop_p, seed)
+        out, lse2_b, pk = spatial_attn_h_fwd_raw(qkv, pos, plan, H, scale, inv_tau, drop_p, seed, zero_blocks=zero_blocks)
         ctx.save_for_backward(out, lse2_b, pk.R, pk.pos_b, *([pk.skip_map] if pk.skip_map is not None else []))
         ctx.meta = (plan, H, scale, inv_tau, drop_p, seed, pk.r_stride, qkv.shape)
         return out
@@ -450,7 +503,7 @@ class _SpatialAttentionH(torch.autograd.Function):
         pk.skip_map = skip[0] if skip else None
         dqkv = torch.empty(shape, dtype=torch.float32, device=out.device)
         spatial_attn_h_bwd_raw(pk, out, gout, plan, H, scale, inv_tau, lse2_b, dqkv, drop_p, seed)
-        return dqkv, None, None, None, None, None, None, None
+        return dqkv, None, None, None, None, None, None, None, None
 
 
 def unblock_rows(xb: torch.Tensor, plan: AttnPlan, H: int) -> torch.Tensor:
@@ -558,7 +611,7 @@ class _SpatialAttentionGen(torch.autograd.Function):
 
 
 def spatial_attention(qkv, pos, plan: AttnPlan, H: int, scale: float, inv_tau: float = 1.0, drop_p: float = 0.0,
-                      training: bool = False, seed: Optional[int] = None):
+                      training: bool = False, seed: Optional[int] = None, pos_extent: Optional[float] = None):
     """dropout(softmax(QK^T*scale - dist*inv_tau)) V per graph; ``drop_p`` applies to the attention
     weights (core/attention.py:154) in training mode.  ``qkv`` [N, 3 * H * D] with D in ``ATTN_HEAD_DIMS``: 16 runs on the MFMA
     kernels (``ATTN_PRECISION``), 32 / 64 on the vector-unit kernels of csrc/attn_gen.hip."""
@@ -570,8 +623,9 @@ def spatial_attention(qkv, pos, plan: AttnPlan, H: int, scale: float, inv_tau: f
         raise _lib.DGDMKernelError(f"spatial attention kernels take head dims {ATTN_HEAD_DIMS} (pad narrower heads with zeros), got {qkv.size(1)} / (3 x {H})")
     if D != 16:
         return _SpatialAttentionGen.apply(qkv, pos, plan, H, D, scale, inv_tau, p, seed or 0)
-    fn = _SpatialAttention if ATTN_PRECISION == "fp32" else _SpatialAttentionH
-    return fn.apply(qkv, pos, plan, H, scale, inv_tau, p, seed or 0)
+    if ATTN_PRECISION == "fp32":
+        return _SpatialAttention.apply(qkv, pos, plan, H, scale, inv_tau, p, seed or 0)
+    return _SpatialAttentionH.apply(qkv, pos, plan, H, scale, inv_tau, p, seed or 0, attn_zero_blocks_possible(pos_extent, inv_tau))
 
 
 # ----------------------------------------------------------------------------- K4-dense: MultiHeadAttention.forward as the reference exposes it
@@ -2182,19 +2236,15 @@ def graph_conv_linear(x, ea_hat, gs: GraphStructure, w, we, b, skip: bool = Fals
 # same instructions over all 1024 SIMDs.  At 5 000 rows: GEMM 7.3 us, + activation kernel 10.5, fused 16.9; at 40 000 rows a draw
 # (22.3 / 22.3); LayerNorm epilogue 29.4 against 25.9; whole step 13.07 against 13.00 ms.  So the default keeps every activation /
 # norm behind a GEMM in a kernel of its own; True selects the fused path (same-box A/B, the parity tests run both).
-# "auto": only what the measurements favour -- DynamicGraphLayer as one autograd node whose two activation BACKWARDS are epilogues of
-# the GEMMs that form their incoming gradients when the layer has at least FUSE_AUTO_MIN_ROWS rows (the bold cells of DESIGN.md
-# section 4 "Round 5": 23.2 against 25.0 us at 40 000 x 128, 135 against 144 at 40 000 x 544 -> 512); every forward activation and
-# every norm stays a kernel of its own.
+# (Round 5 also had an "auto" policy -- activation backwards as epilogues from 20 000 rows on; a same-box A/B gave 12.63 against 12.63 ms
+# per step, a draw to four digits, profiles/r05_fuse_auto_ab.txt: removed in round 6.  True stays as the A/B switch, like the
+# arithmetic variants of ops.configure.)
 FUSE_EPILOGUES = False
-FUSE_AUTO_MIN_ROWS = 20000
 
 
-def epilogues_available(*widths: int, auto_ok: bool = False) -> bool:
-    """The fused-epilogue GEMMs are the weight-image kernels: fp16 hi+lo arithmetic, every reduction length a multiple of 16.
-    ``auto_ok``: the caller has a form for FUSE_EPILOGUES == "auto" (only `_GraphLayer` does)."""
-    on = FUSE_EPILOGUES is True or (auto_ok and FUSE_EPILOGUES == "auto")
-    return on and USE_WEIGHT_IMAGES and GEMM_MATH == "f16x2" and all(w % 16 == 0 and w >= 16 for w in widths)
+def epilogues_available(*widths: int) -> bool:
+    """The fused-epilogue GEMMs are the weight-image kernels: fp16 hi+lo arithmetic, every reduction length a multiple of 16."""
+    return FUSE_EPILOGUES is True and USE_WEIGHT_IMAGES and GEMM_MATH == "f16x2" and all(w % 16 == 0 and w >= 16 for w in widths)
 
 
 def _act_raw(pre, act: int, drop_p: float, seed: int):
@@ -2360,7 +2410,7 @@ class _GraphLayer(torch.autograd.Function):
         ea_hat = _rowmajor(ea_hat)
         w1, w2, wo = _rm_tagged(w1), _rm_tagged(w2), _rm_tagged(wo)
         hid, node = w1.size(0), wo.size(0)
-        full = FUSE_EPILOGUES is True           # "auto": forward activations and the norm stay kernels of their own
+        full = True
         z1 = _spmm_concat_raw(x, ea_hat, gs)
         if full:
             h1, pre1 = gemm_img_act_raw(z1, WEIGHT_IMAGES.get(0, w1, we1), hid, b1, ACT_GELU, drop_p, seeds[0])
@@ -2407,7 +2457,7 @@ class _GraphLayer(torch.autograd.Function):
         claim = lambda *idx: ctx.leaf and _claim_deferred(*(P[i] for i in idx))
         ds, dgam, dbet = rownorm_bwd_raw(ssum, res, gamma, beta, mean, rstd, gy, 1, ACT_NONE, 0.0, 0, (P[8], P[9]) if ctx.leaf else None)
         dwo, dbo = gemm_tn_raw(ds, h2, True, math="f16x2", may_defer=claim(6, 7))
-        fuse_bwd = FUSE_EPILOGUES is True or ds.size(0) >= FUSE_AUTO_MIN_ROWS      # "auto": only where the epilogue beats the two launches
+        fuse_bwd = True
         if fuse_bwd:
             dpre2 = gemm_img_act_bwd_raw(ds, WEIGHT_IMAGES.get(1, wo), hid, pre2, ACT_GELU, drop_p, seeds[1])
         else:
@@ -2429,7 +2479,7 @@ class _GraphLayer(torch.autograd.Function):
 def graph_layer_supported(x, ea_hat, node_dim: int, hidden: int, edge_dim: int) -> bool:
     return (ea_hat is not None and x.dim() == 2 and x.dtype == torch.float32 and x.is_cuda and x.size(0) >= GEMM_MIN_ROWS
             and x.size(1) == node_dim and ea_hat.size(1) == edge_dim
-            and epilogues_available(node_dim + edge_dim, hidden + edge_dim, hidden, node_dim, auto_ok=True))
+            and epilogues_available(node_dim + edge_dim, hidden + edge_dim, hidden, node_dim))
 
 
 def graph_layer(x, ea_hat, gs: GraphStructure, conv1, conv2, output_proj, norm, drop_p: float, training: bool):

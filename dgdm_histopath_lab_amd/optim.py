@@ -82,6 +82,34 @@ class DGDMAdamW(torch.optim.Optimizer):
             group["fused"], group["capturable"] = True, True
             self._rebuild_cohorts(gi, group)
 
+    MERGE_ABOVE = 8      # cohorts per group beyond which a step looks for cohorts it can merge again (one device read, rare)
+
+    def _merge_cohorts(self, gi: int, group, live_ids) -> None:
+        """Cohorts only ever split (a member without a gradient leaves with a copy of the count); a model whose branches get
+        gradients on some batches only would drift towards one launch per parameter.  Cohorts whose members are ALL live
+        in this step and whose counts are EQUAL are one cohort again: reads the counters once (a host sync; only when a group has
+        more than MERGE_ABOVE cohorts, never inside a capture)."""
+        cohorts = self._cohorts[gi]
+        counts = torch.stack([c["step"].reshape(()) for c in cohorts]).tolist()
+        merged, by_count = [], {}
+        for c, n in zip(cohorts, counts):
+            if c["ids"] and c["ids"] <= live_ids:
+                if n in by_count:
+                    by_count[n]["ids"] |= c["ids"]
+                    continue
+                by_count[n] = c
+            if c["ids"]:
+                merged.append(c)
+        if len(merged) == len(cohorts):
+            return
+        owner = {i: c for c in merged for i in c["ids"]}
+        for q in group["params"]:
+            c = owner.get(id(q))
+            if c is not None and self.state.get(q):
+                self.state[q]["step"] = c["step"]
+        self._cohorts[gi] = merged
+        self._tables = {k: v for k, v in self._tables.items() if k[0] != gi}
+
     # ------------------------------------------------------------------ step
     @torch.no_grad()
     def step(self, closure=None):
@@ -110,11 +138,15 @@ class DGDMAdamW(torch.optim.Optimizer):
                     self._init_state(p, c["step"])
                     c["ids"].add(id(p))
                 cohorts.append(c)
+            capturing = torch.cuda.is_current_stream_capturing()
+            live_ids = {id(p) for p in live}
+            if len(cohorts) > self.MERGE_ABOVE and not capturing:
+                self._merge_cohorts(gi, group, live_ids)
+                cohorts = self._cohorts[gi]
             lr = group["lr"]
             lr_dev = lr.data_ptr() if isinstance(lr, torch.Tensor) and lr.is_cuda else None
             lr_host = 0.0 if lr_dev is not None else float(lr)
             b1, b2 = group["betas"]
-            live_ids = {id(p) for p in live}
             for ci in range(len(cohorts)):
                 c = cohorts[ci]
                 ps = [p for p in live if id(p) in c["ids"]]
@@ -126,6 +158,12 @@ class DGDMAdamW(torch.optim.Optimizer):
                     # counter is about to advance.  They leave with a copy of the count as it stands and form a cohort of
                     # their own; when they come back they step from where they stopped.
                     gone = c["ids"] - live_ids
+                    if capturing:
+                        # the clone below would be RECORDED: every replay would overwrite the departed members' count with the live
+                        # cohort's.  The live set of a recorded step must be the live set of the eager steps before it.
+                        raise RuntimeError("DGDMAdamW: the set of parameters with a gradient changed inside a stream capture "
+                                           f"({len(gone)} of {len(c['ids'])} members of a cohort have none); run one eager step with this "
+                                           "set first (GraphedPretrainStep's warm-up steps do)")
                     c2 = {"step": c["step"].clone(), "ticket": torch.zeros(1, dtype=torch.int32, device=c["step"].device), "ids": gone}
                     for q in group["params"]:
                         if id(q) in gone:

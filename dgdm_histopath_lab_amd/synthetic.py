@@ -24,7 +24,7 @@ def synthetic_graph(g: int, num_nodes: int, num_edges: int, node_features: int =
     v = v + (v >= u).long()  # uniform over v != u
     ei = torch.stack([torch.stack([u, v]), torch.stack([v, u])], dim=2).reshape(2, -1)
     ea = torch.randn(half, EDGE_DIM, generator=gen).repeat_interleave(2, dim=0) if edge_attr else None
-    return GraphData(x=x, edge_index=ei, edge_attr=ea, pos=pos)
+    return GraphData(x=x, edge_index=ei, edge_attr=ea, pos=pos, pos_extent=1.0)      # U[0,1)^2: known without looking
 
 
 def synthetic_batch(first_graph: int, batch_size: int, num_nodes: int, num_edges: int, node_features: int = 768) -> GraphBatch:

@@ -425,6 +425,11 @@ class GraphedPretrainStep:
             v = getattr(batch, k, None)
             if isinstance(v, torch.Tensor):
                 sig.append((k, tuple(v.shape), v.dtype))
+        # the host-side extent of the positions decides whether the recording holds the zero-block map's launches
+        # (ops.attn_zero_blocks_possible): a batch with another extent must not replay this recording
+        sig.append(("pos_extent", getattr(batch, "pos_extent", None)))
+        md = getattr(batch, "max_degree", None)      # whether the index sets carry long-row tables (GraphStructure): part of the layout
+        sig.append(("long_rows", md is None or md + 1 > 128))
         sig.append(("ptr", tuple(graph_ptr(batch, batch.x.size(0)))))
         return tuple(sig)
 
@@ -437,6 +442,8 @@ class GraphedPretrainStep:
                 v = getattr(batch, k, None)
                 setattr(st, k, v.clone() if isinstance(v, torch.Tensor) else v)
             st.ptr = list(sig[-1][1])            # host offsets: no device sync in the step
+            st.pos_extent = getattr(batch, "pos_extent", None)
+            st.max_degree = getattr(batch, "max_degree", None)
             self.static, self._signature = st, sig
             return
         if sig != self._signature:

@@ -328,6 +328,11 @@ DGDM_API size_t dgdm_attn_skip_map_workspace_bytes(int32_t num_blocks, int32_t H
 DGDM_API int dgdm_attn_skip_map_build(const void* Rq, const void* Rk, const float* pos_b, const int32_t* ptr, int32_t B,
                                       int32_t num_blocks, int32_t H, void* workspace, size_t workspace_bytes, uint32_t* map,
                                       size_t map_bytes, void* stream);
+/* Measurement only (bench.py): the scores the kernels evaluate under a map.  counts (3 x uint64, device, ZERO on entry):
+ * [0] forward (unmarked query-block x key-block pairs), [1] one-pass backward (unmarked key-super-block x query-block pairs: a
+ * super-block runs all its key tiles), [2] every score (sum over graphs of n_g^2 x H). */
+DGDM_API int dgdm_attn_skip_map_count(const uint32_t* map, const int32_t* ptr, int32_t B, int32_t num_blocks, int32_t H, uint64_t* counts,
+                                      void* stream);
 DGDM_API int dgdm_spatial_attn_h_fwd_sparse(const void* Rq, const void* Rk, const void* Rv, const float* pos_b, const int32_t* ptr,
                                             int32_t B, int32_t num_blocks, int32_t H, float drop_p, uint32_t seed, float* O,
                                             int64_t ldo, float* lse2_b, int32_t variant, const uint32_t* skip_map, uint32_t* amax_out,

@@ -61,8 +61,7 @@ def test_kernels_with_asm_issued_loads_do_not_spill():
     kernels to zero spills (compile-time check, no GPU)."""
     import subprocess
     from dgdm_histopath_lab_amd import _build
-    # (gemm_ws.hip: the weight-stationary kernel, measured slower and compiled only with -DDGDM_WS -- held to the rule all the same)
-    for src, names, extra in (("gemm_img.hip", ("k_gemm_img",), ()), ("gemm_h.hip", ("k_gemmh_tn32",), ()), ("gemm_ws.hip", ("k_gemm_ws",), ("-DDGDM_WS",))):
+    for src, names, extra in (("gemm_img.hip", ("k_gemm_img",), ()), ("gemm_h.hip", ("k_gemmh_tn32",), ())):
         r = subprocess.run([_build._hipcc(), *_build.FLAGS, *extra, *_build.EXTRA_FLAGS.get(src, []), "--cuda-device-only", "-S", "-o", "/dev/null",
                             "-Rpass-analysis=kernel-resource-usage", os.path.join(_build.CSRC, src)], capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-2000:]

@@ -641,3 +641,52 @@ def test_zero_blocks_with_scratch_groups_and_large_scores(monkeypatch):
         o.backward(gout.to(DEV))
         grads[skip] = (o.detach(), d.grad)
     assert torch.equal(grads[True][0], grads[False][0]) and torch.equal(grads[True][1], grads[False][1])
+
+
+def test_zero_block_map_is_only_built_when_the_positions_extent_allows_a_zero_pair_and_live_scores_are_counted():
+    """ADVICE r5 / VERDICT r5 weak 8.  ``pos_extent`` (host-side upper bound of the coordinate range inside a graph) decides, without a
+    device sync, whether the attention builds its zero-block map: never on BASELINE's U[0,1)^2 positions, always when unknown or
+    large; the outputs do not depend on it (bit-identical).  ``ops.attn_skip_live_scores`` counts what the kernels evaluated: every
+    score when nothing is marked, a band's worth on raster positions, the backward (key-super-block granularity) at least the forward."""
+    from dgdm_histopath_lab_amd import ops
+    ptr, H = [0, 1500, 1700, 4000], 8
+    g = torch.Generator().manual_seed(10)
+    n, C = ptr[-1], H * 16
+    qkv = torch.randn(n, 3 * C, generator=g).to(DEV)
+    plan = ops.AttnPlan(ptr, DEV)
+    total = sum((ptr[i + 1] - ptr[i]) ** 2 for i in range(3)) * H
+    unit = torch.rand(n, 2, generator=g).to(DEV)
+    raster = torch.cat([_raster_positions(ptr[i + 1] - ptr[i], 300.0, 40, g) for i in range(3)]).to(DEV)
+    assert not ops.attn_zero_blocks_possible(1.0, 1.0) and ops.attn_zero_blocks_possible(None, 1.0)
+    assert ops.attn_zero_blocks_possible(16384.0, 1.0) and not ops.attn_zero_blocks_possible(16384.0, 1e-3)      # temperature 1000
+    outs = {}
+    for name, pos, ext in (("unit, extent known", unit, 1.0), ("unit, extent unknown", unit, None), ("raster, extent known", raster, 16384.0),
+                           ("raster, wrong small extent", raster, 1.0)):
+        ops.ATTN_SKIP_MAP_SINK = sink = []
+        try:
+            outs[name] = ops.spatial_attention(qkv, pos, plan, H, 0.25, 1.0, pos_extent=ext)
+        finally:
+            ops.ATTN_SKIP_MAP_SINK = None
+        (m, pl, h), = sink
+        assert (m is None) == (ext == 1.0), name                     # no map launches at all when the extent rules a zero pair out
+        f, b, t = ops.attn_skip_live_scores(m, pl, h)
+        assert t == total and f <= b <= t, (name, f, b, t)
+        if pos is unit:
+            assert f == b == t, name
+        elif m is not None:
+            assert f < 0.5 * t and b < 0.8 * t, (name, f / t, b / t)
+    assert torch.equal(outs["unit, extent known"], outs["unit, extent unknown"])
+    assert torch.equal(outs["raster, extent known"], outs["raster, wrong small extent"])     # a wrong hint costs time, never bits
+
+
+def test_attention_backward_scratch_budget_is_taken_once_per_device(monkeypatch):
+    """the budget that cuts the one-pass backward into launches (and so fixes the association of the dQ sum) no longer follows
+    the free-memory figure of the moment."""
+    from dgdm_histopath_lab_amd import ops
+    monkeypatch.setattr(ops, "ATTN_BWD_FUSED_BUDGET", None)
+    ops.reset_attn_bwd_budget()
+    b0 = ops._attn_bwd_budget(torch.device(DEV))
+    hog = torch.empty(1 << 30, dtype=torch.uint8, device=DEV)
+    assert ops._attn_bwd_budget(torch.device(DEV)) == b0 and 64 << 20 <= b0 <= 16 << 30
+    del hog
+    ops.reset_attn_bwd_budget()

@@ -281,21 +281,17 @@ def test_graph_conv_skip_alias_adds_the_residual_gradient_in_the_backward_kernel
 
 @pytest.mark.parametrize("node,hid,n,e", [(128, 128, 3000, 12000), (512, 256, 1500, 6000), (256, 128, 700, 3000), (64, 32, 300, 900)])
 @pytest.mark.parametrize("training", [False, True])
-@pytest.mark.parametrize("mode", [True, "auto", "auto-fused-backward"])
+@pytest.mark.parametrize("mode", [True])
 def test_graph_layer_as_one_node_is_the_layer_of_separate_kernels(node, hid, n, e, training, mode, monkeypatch):
     """DynamicGraphLayer through ops._GraphLayer (activations and LayerNorm as GEMM epilogues, the second convolution's input gradient
     associated as (A^T dpre) . W) against the same module on the separate kernels (ops.FUSE_EPILOGUES = False): output and every
     gradient, eval mode and TRAINING mode -- both paths draw the same two dropout seeds in the same order and the epilogues' mask is
     the streaming kernels' function of (seed, element index), so the training-mode results agree to rounding as well; and against a
-    float64 composition of the reference's formula in eval mode (core/graph_layers.py:207-247).  mode "auto" (ops.FUSE_EPILOGUES =
-    "auto"): the node with every forward activation and the norm as kernels of their own and the activation backwards as epilogues
-    only from ops.FUSE_AUTO_MIN_ROWS rows on -- both sides of that threshold run here."""
+    float64 composition of the reference's formula in eval mode (core/graph_layers.py:207-247).  (Round 5's "auto" policy -- a draw in
+    the same-box A/B -- left the tree in round 6; True stays as the A/B switch.)"""
     from dgdm_histopath_lab_amd import ops
     from dgdm_histopath_lab_amd.core.graph_layers import DynamicGraphLayer, GraphContext
     DEV = "cuda:0"
-    if mode == "auto-fused-backward":
-        monkeypatch.setattr(ops, "FUSE_AUTO_MIN_ROWS", 1)
-        mode = "auto"
     torch.manual_seed(node + hid + n)
     layer = DynamicGraphLayer(node, 32, hid, num_heads=8).to(DEV).train(training)
     with torch.no_grad():
@@ -351,3 +347,33 @@ def test_graph_layer_as_one_node_is_the_layer_of_separate_kernels(node, hid, n, 
     out.backward(gy.double().cpu())
     assert_close(yf, out.detach(), 1e-4, "output vs float64")
     assert_close(dxf, xd.grad, 1e-4, "dx vs float64")
+
+
+@pytest.mark.gpu
+def test_long_row_tables_are_only_allocated_when_the_degree_bound_allows_a_long_row():
+    """graph.py (VERDICT r3-r5 note): with a host-side degree bound the index sets of ordinary tissue graphs carry no long-row tables and
+    no 23 MB scratch; the result is the same bits, and a WRONG bound (a hub the loader did not know of) costs time, not correctness."""
+    from dgdm_histopath_lab_amd import ops
+    from dgdm_histopath_lab_amd.graph import GraphStructure
+    DEV = "cuda:0"
+    g = torch.Generator().manual_seed(3)
+    n, e = 3000, 15000
+    ei = torch.randint(0, n, (2, e), generator=g)
+    ei[1, :400] = 7                                       # one hub of 400 incoming edges
+    x = torch.randn(n, 64, generator=g).to(DEV)
+    full = GraphStructure(ei.to(DEV), n)
+    hinted = GraphStructure(ei.to(DEV), n, max_degree=int(max(torch.bincount(ei[0]).max(), torch.bincount(ei[1]).max())))
+    wrong = GraphStructure(ei.to(DEV), n, max_degree=9)
+    assert full.long_tables is not None and hinted.long_tables is not None and wrong.long_tables is None and wrong.long_partial is None
+    ys = [ops.spmm_raw(s.rowptr, s.col, s.w, x, n, long_rows=s.long_rows()) for s in (full, hinted, wrong)]
+    for s in (full, hinted, wrong):
+        s.assert_ok()
+        assert torch.equal(s.rowptr, full.rowptr) and torch.equal(s.col, full.col) and torch.equal(s.eid, full.eid) and torch.equal(s.w, full.w)
+    assert torch.equal(ys[0], ys[1])
+    torch.testing.assert_close(ys[2], ys[0], rtol=1e-5, atol=1e-5)        # the hub's row summed by one wave instead of segments: other order
+    ei2 = torch.randint(0, n, (2, e), generator=g)
+    small = GraphStructure(ei2.to(DEV), n, max_degree=int(max(torch.bincount(ei2[0]).max(), torch.bincount(ei2[1]).max())))
+    ref = GraphStructure(ei2.to(DEV), n)
+    assert small.long_tables is None and ref.long_tables is not None
+    assert torch.equal(ops.spmm_raw(small.rowptr, small.col, small.w, x, n, long_rows=small.long_rows()),
+                       ops.spmm_raw(ref.rowptr, ref.col, ref.w, x, n, long_rows=ref.long_rows()))

@@ -26,6 +26,17 @@ def _module(embed_dim, heads, sd=None, seed=0, **kw):
     return m.cuda().eval()
 
 
+def _param_grads_close(m, P, tag=""):
+    """Every parameter gradient against the float64 run; a gradient that is zero in exact arithmetic (k_proj.bias: the softmax is
+    invariant under a shift of all its scores) is rounding noise on both sides and is held to an absolute bound instead."""
+    for k, p in m.named_parameters():
+        ref = P["m." + k].grad
+        if ref.abs().max().item() < 1e-10:
+            assert p.grad.abs().max().item() < 1e-4, (k, tag, p.grad.abs().max().item())
+        else:
+            assert_close(p.grad, ref, TOL, f"{k} {tag}")
+
+
 def _P64(m, pre="m"):
     return {f"{pre}.{k}": v.detach().double().cpu().requires_grad_(True) for k, v in m.state_dict().items()}
 
@@ -103,8 +114,7 @@ def test_mha_self_attention_every_head_dim_matches_float64(embed_dim, heads):
     assert_close(o, o64, TOL, "out"); assert_close(w, w64.reshape(B * heads, L, L), TOL, "weights")
     (o * go.cuda()).sum().backward()
     assert_close(qg.grad, q64.grad, TOL, "dq")
-    for k, p in m.named_parameters():
-        assert_close(p.grad, P["m." + k].grad, TOL, k)
+    _param_grads_close(m, P)
 
 
 def test_mha_masks_cross_attention_zero_attn_and_sequence_first():
@@ -144,8 +154,7 @@ def test_mha_masks_cross_attention_zero_attn_and_sequence_first():
             (o * go.cuda()).sum().backward()
             for a, b, n in zip(ins, ins64, "qkv"):
                 assert_close(a.grad, b.grad, TOL, f"d{n} ({tag})")
-            for k, p in m.named_parameters():
-                assert_close(p.grad, P["m." + k].grad, TOL, f"{k} ({tag})")
+            _param_grads_close(m, P, tag)
     # sequence-first layout (attention.py:99-105,160-162)
     m = _module(C, H, seed=7, batch_first=False)
     o_sf, w_sf = m(query.transpose(0, 1).cuda(), key.transpose(0, 1).cuda(), value.transpose(0, 1).cuda(), key_padding_mask=kpm.cuda())
@@ -205,8 +214,7 @@ def test_mha_training_mode_dropout_is_one_mask_for_forward_weights_and_backward(
     (o64 * go.double()).sum().backward()
     assert_close(o, o64, TOL, "out"); assert_close(w, w64, TOL, "dropped weights")
     assert_close(qg.grad, q64.grad, TOL, "dq")
-    for k, p in m.named_parameters():
-        assert_close(p.grad, P["m." + k].grad, TOL, k)
+    _param_grads_close(m, P)
     # another step draws another mask; eval mode none
     o_b, w_b = m(q.cuda(), average_attn_weights=False)
     assert (w_b.view(B, H, L, L).cpu() != 0).ne(kept).any()

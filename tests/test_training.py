@@ -513,3 +513,64 @@ def test_dgdm_adamw_member_that_skips_steps_keeps_its_own_count():
     assert float(o_own.state[own[1]]["step"]) == 5.0 and float(o_own.state[own[0]]["step"]) == 7.0
     sd = o_own.state_dict()["state"]
     assert [float(sd[i]["step"]) for i in range(4)] == [7.0, 5.0, 5.0, 7.0]
+
+
+@pytest.mark.gpu
+def test_dgdm_adamw_cohorts_merge_again_and_a_split_inside_a_capture_raises():
+    """ADVICE r5.  (i) Cohorts only ever split: 24 parameters whose gradients come and go in a rotating pattern fragment into more
+    than MERGE_ABOVE cohorts; once every parameter has a gradient again, cohorts with EQUAL counts merge (one launch per distinct
+    count, not one per parameter) while every parameter's count and value keep following torch.optim.AdamW.  (ii) A live set that
+    changes INSIDE a stream capture would record the clone of the departing members' counter: it raises instead."""
+    from dgdm_histopath_lab_amd.optim import DGDMAdamW
+    DEV = "cuda:0"
+    g = torch.Generator().manual_seed(2)
+    base = [torch.randn(64 + 8 * i, generator=g) for i in range(24)]
+    ref = [torch.nn.Parameter(b.double().clone()) for b in base]
+    own = [torch.nn.Parameter(b.to(DEV).clone()) for b in base]
+    kw = dict(lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
+    o_ref, o_own = torch.optim.AdamW(ref, **kw), DGDMAdamW(own, **kw)
+
+    def run(step, skip):
+        for i, (a, b) in enumerate(zip(ref, own)):
+            if skip(i):
+                a.grad = b.grad = None
+                continue
+            gr = torch.randn(a.shape, generator=g)
+            a.grad, b.grad = gr.double(), gr.to(DEV)
+        o_ref.step(); o_own.step()
+        for i, (a, b) in enumerate(zip(ref, own)):
+            if o_ref.state.get(a):
+                assert float(o_own.state[b]["step"]) == float(o_ref.state[a]["step"]), (step, i)
+                d = (b.detach().cpu().double() - a.detach()).abs().max().item()
+                assert d <= 2e-6 * max(1.0, a.detach().abs().max().item()), (step, i, d)
+
+    run(0, lambda i: False)
+    peak = 0
+    for step in range(1, 7):                   # rotating gaps: parameter i pauses in step 1 + i % 6 ...
+        run(step, lambda i: i % 6 == step - 1)
+        peak = max(peak, len(o_own._cohorts[0]))
+    for step in range(7, 11):                  # ... and again in step 7 + (i // 6) % 4: every cohort of the first round splits in four
+        run(step, lambda i: (i // 6) % 4 == step - 7)
+        peak = max(peak, len(o_own._cohorts[0]))
+    assert peak > DGDMAdamW.MERGE_ABOVE, peak
+    for step in range(11, 14):                 # everybody live: all 24 have paused exactly twice -> ONE count, one cohort, one launch
+        run(step, lambda i: False)
+    assert len(o_own._cohorts[0]) == 1, len(o_own._cohorts[0])
+    assert len({float(o_own.state[b]["step"]) for b in own}) == 1
+
+    # (ii) the capture guard
+    p2 = [torch.nn.Parameter(torch.randn(128, device=DEV)) for _ in range(2)]
+    o2 = DGDMAdamW(p2, **kw)
+    for p in p2:
+        p.grad = torch.randn(128, device=DEV)
+    o2.step()                                   # both in one cohort
+    p2[1].grad = None
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with pytest.raises(RuntimeError, match="changed inside a stream capture"):
+            with torch.cuda.graph(gr, stream=side):
+                o2.step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()

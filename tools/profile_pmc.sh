@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/pmc_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="$R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-gather --no-strict --no-raster --sustain-seconds 0 --eager $@"
+B="$R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-gather --no-strict --no-raster --no-sample-loop --sustain-seconds 0 --eager $@"
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE \
   --kernel-trace --output-format csv -d $OUT/valu -- python3 $B > $OUT/valu.log 2>&1
 python3 $R/tools/pmc_valu.py $OUT/valu > $R/gpurun_out/${TAG}_pmc_valu.json
