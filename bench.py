@@ -638,7 +638,7 @@ def main():
     dt = time.perf_counter() - t0
     ops.ATTN_SKIP_MAP_SINK = None
     eager_timed_steps = args.steps
-    if graphed:
+    if graphed and (stream is None or world == 1):     # (the mixed stream's extra eager pass: one rank only -- N > 1 reports no roofline)
         # kernels launched by a graph replay cannot be bracketed by events: the per-kernel durations of the roofline come
         # from eager launches of the same step right after the timed region (same kernels, same shapes, same clocks); the mixed
         # stream runs each of its layouts once.  The zero-block maps of those launches are kept: the roofline counts the scores

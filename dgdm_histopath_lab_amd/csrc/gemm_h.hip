@@ -389,7 +389,7 @@ constexpr int OPER2 = 2 * PLANE2;        // hi plane, lo plane
 constexpr int STAGE2 = 2 * OPER2;        // dY image, X image: 40960
 constexpr int LDS2 = 2 * STAGE2;         // 81920: two workgroups per CU
 #ifndef DGDM_TN_FLUSH
-#define DGDM_TN_FLUSH 4
+#define DGDM_TN_FLUSH 16
 #endif
 constexpr int TN_FLUSH = DGDM_TN_FLUSH;  // stages (of 2 k16-steps x 3 MFMAs per tile) between two flushes of the accumulators; a power of two
 
@@ -498,9 +498,11 @@ __device__ __forceinline__ void tn32_tile(const float* __restrict__ dY, int64_t 
 
   // Two-level accumulation (round 6).  The matrix pipe adds a block of products into its fp32 accumulator with about TWICE the error of
   // one correctly rounded add (tools/ubench/mfma_rounding.hip: rms 1.76e-6 against 0.84e-6 over 2 500 accumulating MFMAs, in units of
-  // sqrt(sum p^2)), and a dW chunk is a long chain: rows / 16 steps x 3 MFMAs.  Every TN_FLUSH stages the accumulators are added into
-  // a second set by the vector unit (round to nearest) and start again from zero: the same measurement gives 0.34e-6 with a flush
-  // every 8 MFMAs.  64 v_add + 64 v_mov per 96 MFMAs of this wave.
+  // sqrt(sum p^2)), and a dW chunk is a long chain: rows / 16 steps x 3 MFMAs (1 875 accumulations per tile at the headline batch).
+  // Every TN_FLUSH stages (16 stages = 96 accumulations per tile) the accumulators are added into a second set by the vector unit
+  // (round to nearest) and start again from zero: the same measurement gives 0.36e-6 against 1.64e-6 for a chain of 1 875 (0.30e-6
+  // with 48, 0.26e-6 with 24: the interval is not critical).  64 v_add + 64 v_mov per 384 MFMAs of this wave: same-box A/B of the
+  // step with a flush every 4 stages + 0.06 ms of 13.0, every 16 stages within the run-to-run spread (profiles/r06_tn_flush_ab.txt).
   f32x16 acc[2][2], tot[2][2];
 #pragma unroll
   for (int a = 0; a < 2; ++a)

@@ -108,6 +108,11 @@ __device__ unsigned long long* dgdm_stamp_buf;
 #define DGDM_IMG_NTW 4
 #endif
 constexpr int CPS = 2;    // 32-k chunks per LDS stage (64 k); images are padded to whole stages
+// 1 (round 6): every column tile's products of a stage / chunk form a block of their own that the vector unit adds to the running
+// accumulator; 0: every MFMA accumulates into the running accumulator (rounds 2-5).  See DGDM_IMG8_INNER.
+#ifndef DGDM_IMG_FRESH
+#define DGDM_IMG_FRESH 1
+#endif
 
 // C[M, Ncols] (+)= A[M, K] . B + bias, B = image tiles [t_begin, t_begin + ceil(Ncols / 32)) of an image with T_img tiles per chunk.
 // Workgroup = WM x WN waves; wave (wm, wn) owns rows 32 (WM rowtile + wm) .. +31 and columns 128 (WN colgroup + wn) .. +127.
@@ -120,6 +125,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN > 4 ? 1 : 2) void k_gemm_img(
                                                             const unsigned* __restrict__ amax_a, const EpiArgs epi) {
   static_assert(EPI == EPI_NONE || !ACCUM, "the fused epilogues write C, they do not accumulate into it");
   constexpr bool TR = EPI != EPI_NONE;
+  constexpr bool FRESH = DGDM_IMG_FRESH && EPI == EPI_NONE;      // the fused-epilogue variants (A/B only) keep round 5's accumulation
   constexpr int WAVES = WM * WN, NT_WG = NTW_ * WN, STAGE = CPS * NT_WG * BLK;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 * STAGE
   const int tid = threadIdx.x, lane = tid & 63;
@@ -192,6 +198,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN > 4 ? 1 : 2) void k_gemm_img(
   for (int t = 0; t < NTW_; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
   float sca, scb;
   if (ACCUM) {   // C += ...: the accumulators START from C (times the operand scales: powers of two, exact), no epilogue pass.
@@ -229,7 +236,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN > 4 ? 1 : 2) void k_gemm_img(
     // Four batches b = (cc, j) of 8 fragment reads (4 column tiles x hi / lo) + 12 MFMAs.  The reads of batch b + 1 are issued
     // BEFORE the MFMAs of batch b and pinned there (sched_barrier): left alone, hipcc sinks every read to just in front of its
     // MFMA and the wave eats the LDS latency 16 times per stage.
-    f16x8 bh[2][NTW_], bl[2][NTW_];
+    f16x8 bh[2][FRESH ? 4 : NTW_], bl[2][FRESH ? 4 : NTW_];      // FRESH: [slot][k16-step of the stage]
 #define DGDM_READ_BATCH(b_, slot_)                                                                                  \
   {                                                                                                                 \
     const char* q__ = buf + ((b_) >> 1) * NT_WG * BLK + (2 * ((b_) & 1)) * 1024;                                    \
@@ -244,6 +251,54 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN > 4 ? 1 : 2) void k_gemm_img(
     acc[t] = mfma_o<TR>(ah[(b_) >> 1][(b_) & 1], bl[slot_][t], acc[t]);                                             \
     acc[t] = mfma_o<TR>(ah[(b_) >> 1][(b_) & 1], bh[slot_][t], acc[t]);                                             \
   }
+    if constexpr (FRESH) {
+    // Round 6 (the accumulate of the matrix pipe: tools/ubench/mfma_rounding.hip).  A column tile's products of the whole stage
+    // (2 chunks x 2 k16-steps x {lo.hi, hi.lo, hi.hi} = 12 MFMAs) are chained from a ZERO accumulator into a block P of their own and
+    // P is added to the running accumulator by the vector unit (round to nearest, one v_pk_add_f32 per two values, one tile late so
+    // that it never waits for the matrix pipe): the long-lived accumulator sees K / 64 correctly rounded adds instead of 3 K / 16
+    // matrix-pipe accumulations of twice the rounding error each.  Tile-major order; both chunks are converted before the first
+    // tile (every tile needs all four A fragments).
+    DGDM_CONVERT(0, a00, a01, a02, a03)
+    DGDM_LOAD_CHUNK(s * CPS + CPS, a00, a01, a02, a03)       // past the end: clamped re-reads, retired after the loop
+    DGDM_CONVERT(1, a10, a11, a12, a13)
+    DGDM_LOAD_CHUNK(s * CPS + CPS + 1, a10, a11, a12, a13)
+#define DGDM_READ_TILE(t_, slot_)                                                                                   \
+  _Pragma("unroll") for (int st = 0; st < 4; ++st) {                                                                 \
+    const char* q__ = buf + (st >> 1) * NT_WG * BLK + (2 * (st & 1)) * 1024 + (t_) * BLK;                            \
+    bh[slot_][st] = *reinterpret_cast<const f16x8*>(q__);                                                           \
+    bl[slot_][st] = *reinterpret_cast<const f16x8*>(q__ + 1024);                                                    \
+  }
+    f32x16 pblk[2];
+    DGDM_READ_TILE(0, 0)
+#pragma unroll
+    for (int t = 0; t < NTW_; ++t) {
+      __builtin_amdgcn_sched_barrier(0);
+      f32x16 pb = mfma_o<TR>(al[0][0], bh[0][0], zero16);    /* smaller terms first */
+      pb = mfma_o<TR>(ah[0][0], bl[0][0], pb);
+      pb = mfma_o<TR>(al[0][1], bh[0][1], pb);
+      pb = mfma_o<TR>(ah[0][1], bl[0][1], pb);
+      pb = mfma_o<TR>(al[1][0], bh[0][2], pb);
+      pb = mfma_o<TR>(ah[1][0], bl[0][2], pb);
+      pb = mfma_o<TR>(al[1][1], bh[0][3], pb);
+      pb = mfma_o<TR>(ah[1][1], bl[0][3], pb);
+      pb = mfma_o<TR>(ah[0][0], bh[0][0], pb);
+      pb = mfma_o<TR>(ah[0][1], bh[0][1], pb);
+      pb = mfma_o<TR>(ah[1][0], bh[0][2], pb);
+      pb = mfma_o<TR>(ah[1][1], bh[0][3], pb);
+      pblk[t & 1] = pb;
+      __builtin_amdgcn_sched_barrier(0);
+      // the fragments are single-buffered: tile t + 1's eight are read right behind the ISSUE of tile t's MFMAs (which have taken
+      // their operands by then) and land while those execute; tile t - 1's block -- complete since this chain started -- is added
+      if (t + 1 < NTW_) DGDM_READ_TILE(t + 1, 0)
+      if (t > 0) {
+        acc[t - 1] += pblk[(t - 1) & 1];
+        asm volatile("" : "+v"(acc[t - 1]));      // pins the add here (a pure node: it would float to the end of the stage and keep every block live)
+      }
+    }
+    acc[NTW_ - 1] += pblk[(NTW_ - 1) & 1];
+    asm volatile("" : "+v"(acc[NTW_ - 1]));
+#undef DGDM_READ_TILE
+    } else {
     DGDM_READ_BATCH(0, 0)
     DGDM_CONVERT(0, a00, a01, a02, a03)
     DGDM_LOAD_CHUNK(s * CPS + CPS, a00, a01, a02, a03)       // past the end: clamped re-reads, retired after the loop
@@ -263,6 +318,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN > 4 ? 1 : 2) void k_gemm_img(
     DGDM_MFMA_BATCH(2, 0)
     __builtin_amdgcn_sched_barrier(0);
     DGDM_MFMA_BATCH(3, 1)
+    }
   }
 #undef DGDM_READ_BATCH
 #undef DGDM_MFMA_BATCH
@@ -312,6 +368,69 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN > 4 ? 1 : 2) void k_gemm_img(
   DGDM_STAMP(9)
 }
 
+// The inner loop of one 32-k chunk.  DGDM_IMG_FRESH (round 6, default): tile-major -- the six MFMAs of a column tile (2 k16-steps x
+// {lo.hi, hi.lo, hi.hi}) are chained from a ZERO accumulator into a block of their own, which the vector unit adds to the running
+// accumulator one tile later (round to nearest): K / 32 correctly rounded adds into the long-lived accumulator instead of 3 K / 16
+// matrix-pipe accumulations with twice the rounding error each (tools/ubench/mfma_rounding.hip).  0: round 5's order (j-major, every
+// MFMA accumulates into the tile's running accumulator).
+#define DGDM_IMG8_INNER                                                                                             \
+    if constexpr (FRESH) {                                                                                          \
+    /* B fragments single-buffered: tile t + 1's four fragments are read right BEHIND the issue of tile t's six MFMAs (which  \
+       have taken their operands by then) and land while those execute; the block of tile t - 1 -- complete since tile t's   \
+       chain started -- is added meanwhile.  Two blocks in rotation: the add never waits for the matrix pipe. */              \
+    f32x16 pblk[2];                                                                                                 \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                 \
+      bh[0][j] = *reinterpret_cast<const f16x8*>(buf + (2 * j) * 1024);                                             \
+      bl[0][j] = *reinterpret_cast<const f16x8*>(buf + (2 * j) * 1024 + 1024);                                      \
+    }                                                                                                               \
+    _Pragma("unroll") for (int t = 0; t < NT8; ++t) {                                                               \
+      __builtin_amdgcn_sched_barrier(0);                                                                            \
+      f32x16 pb = mfma_o<TR>(al[0], bh[0][0], zero16);      /* smaller terms first */                                \
+      pb = mfma_o<TR>(ah[0], bl[0][0], pb);                                                                         \
+      pb = mfma_o<TR>(al[1], bh[0][1], pb);                                                                         \
+      pb = mfma_o<TR>(ah[1], bl[0][1], pb);                                                                         \
+      pb = mfma_o<TR>(ah[0], bh[0][0], pb);                                                                         \
+      pb = mfma_o<TR>(ah[1], bh[0][1], pb);                                                                         \
+      pblk[t & 1] = pb;                                                                                             \
+      __builtin_amdgcn_sched_barrier(0);                                                                            \
+      if (t + 1 < NT8) {                                                                                            \
+        const char* q__ = buf + (t + 1) * BLK;                                                                      \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                             \
+          bh[0][j] = *reinterpret_cast<const f16x8*>(q__ + (2 * j) * 1024);                                         \
+          bl[0][j] = *reinterpret_cast<const f16x8*>(q__ + (2 * j) * 1024 + 1024);                                  \
+        }                                                                                                           \
+      }                                                                                                             \
+      if (t > 0) {                                                                                                  \
+        acc[t - 1] += pblk[(t - 1) & 1];                                                                            \
+        asm volatile("" : "+v"(acc[t - 1]));      /* pins the add HERE (a pure node: it would float to the end of the chunk and keep every block live) */ \
+      }                                                                                                             \
+    }                                                                                                               \
+    acc[NT8 - 1] += pblk[(NT8 - 1) & 1];                                                                            \
+    asm volatile("" : "+v"(acc[NT8 - 1]));                                                                          \
+    } else {                                                                                                        \
+    _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                                 \
+      bh[0][u] = *reinterpret_cast<const f16x8*>(buf + u * BLK);                                                    \
+      bl[0][u] = *reinterpret_cast<const f16x8*>(buf + u * BLK + 1024);                                             \
+    }                                                                                                               \
+    _Pragma("unroll") for (int b = 0; b < 8; ++b) {          /* b = 4 j + tile pair */                               \
+      __builtin_amdgcn_sched_barrier(0);                                                                            \
+      if (b + 1 < 8) {                                                                                              \
+        const char* q__ = buf + (2 * ((b + 1) & 3)) * BLK + (2 * ((b + 1) >> 2)) * 1024;                            \
+        _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                             \
+          bh[(b + 1) & 1][u] = *reinterpret_cast<const f16x8*>(q__ + u * BLK);                                      \
+          bl[(b + 1) & 1][u] = *reinterpret_cast<const f16x8*>(q__ + u * BLK + 1024);                               \
+        }                                                                                                           \
+      }                                                                                                             \
+      __builtin_amdgcn_sched_barrier(0);                                                                            \
+      _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                               \
+        const int t = 2 * (b & 3) + u;                                                                              \
+        acc[t] = mfma_o<TR>(al[b >> 2], bh[b & 1][u], acc[t]);   /* smaller terms first */                          \
+        acc[t] = mfma_o<TR>(ah[b >> 2], bl[b & 1][u], acc[t]);                                                      \
+        acc[t] = mfma_o<TR>(ah[b >> 2], bh[b & 1][u], acc[t]);                                                      \
+      }                                                                                                             \
+    }                                                                                          \
+    }
+
 // ---- the wide variant: a wave owns 32 rows x 256 columns (8 accumulator tiles), a workgroup of four waves 128 x 256, ONE 32-k
 // chunk per LDS stage (32 KiB, two slots) so that TWO workgroups share a CU.  Why two independent workgroups instead of one of
 // eight waves: the two waves of a SIMD that belong to one workgroup run in lockstep behind the stage barrier -- both stage and
@@ -326,6 +445,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_img8(const float* __restrict__ 
                                                       const EpiArgs epi) {
   static_assert(EPI == EPI_NONE || !ACCUM, "the fused epilogues write C, they do not accumulate into it");
   constexpr bool TR = EPI != EPI_NONE;
+  constexpr bool FRESH = DGDM_IMG_FRESH && EPI == EPI_NONE;      // the fused-epilogue variants (A/B only) keep round 5's accumulation
   constexpr int SLOT = NT8 * BLK;                                  // 32 KiB: one chunk of 8 column tiles
   extern __shared__ __attribute__((aligned(16))) char smem[];      // 2 * SLOT
   const int tid = threadIdx.x, lane = tid & 63;
@@ -370,6 +490,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_img8(const float* __restrict__ 
   for (int t = 0; t < NT8; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
   float sca, scb;
   if (ACCUM) {   // C += ...: the accumulators START from C (times the operand scales: powers of two, exact), no epilogue pass.
@@ -423,27 +544,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_img8(const float* __restrict__ 
     }                                                                                                               \
     DGDM_LOAD_CHUNK((c_) + 2, r0_, r1_, r2_, r3_)      /* past the end: clamped re-reads, retired after the loop */  \
     f16x8 bh[2][2], bl[2][2];                                                                                       \
-    _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                                 \
-      bh[0][u] = *reinterpret_cast<const f16x8*>(buf + u * BLK);                                                    \
-      bl[0][u] = *reinterpret_cast<const f16x8*>(buf + u * BLK + 1024);                                             \
-    }                                                                                                               \
-    _Pragma("unroll") for (int b = 0; b < 8; ++b) {          /* b = 4 j + tile pair */                               \
-      __builtin_amdgcn_sched_barrier(0);                                                                            \
-      if (b + 1 < 8) {                                                                                              \
-        const char* q__ = buf + (2 * ((b + 1) & 3)) * BLK + (2 * ((b + 1) >> 2)) * 1024;                            \
-        _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                             \
-          bh[(b + 1) & 1][u] = *reinterpret_cast<const f16x8*>(q__ + u * BLK);                                      \
-          bl[(b + 1) & 1][u] = *reinterpret_cast<const f16x8*>(q__ + u * BLK + 1024);                               \
-        }                                                                                                           \
-      }                                                                                                             \
-      __builtin_amdgcn_sched_barrier(0);                                                                            \
-      _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                               \
-        const int t = 2 * (b & 3) + u;                                                                              \
-        acc[t] = mfma_o<TR>(al[b >> 2], bh[b & 1][u], acc[t]);   /* smaller terms first */                          \
-        acc[t] = mfma_o<TR>(ah[b >> 2], bl[b & 1][u], acc[t]);                                                      \
-        acc[t] = mfma_o<TR>(ah[b >> 2], bh[b & 1][u], acc[t]);                                                      \
-      }                                                                                                             \
-    }                                                                                                               \
+    DGDM_IMG8_INNER                                                                                                 \
   }
   for (int c = 0; c < nchunks; c += 2) {
     DGDM_CHUNK(c, a00, a01, a02, a03)

@@ -425,6 +425,28 @@ class GlobalSet2SetPool(nn.Module):
         return self._mean(x, batch, plan)
 
 
+def _pool_dense(self, x: Tensor, ap) -> Tensor:
+    """GlobalAttentionPool at head widths above the segment kernels' (64 < head_dim <= 128): MultiHeadAttention's own dense kernels,
+    one query per graph (models/dgdm_model.py:596-615 of the reference does exactly this, graph by graph)."""
+    att = self.attention
+    H, d, C, D = att.num_heads, att.head_dim, att.embed_dim, att.dense_head_dim
+    HD = H * D
+    q = ops.linear(self.global_token.view(1, C), *att._padded((att.q_proj,), D))
+    kv = ops.linear(x, *att._padded((att.k_proj, att.v_proj), D))
+    outs = []
+    for g in range(ap.B):
+        a, b = ap.ptr_host[g], ap.ptr_host[g + 1]
+        if b == a:
+            raise _lib.DGDMKernelError("attention pooling at head_dim > 64 needs non-empty graphs")
+        o, _, _ = ops.attn_dense(q, kv[a:b, :HD], kv[a:b, HD:], 1, 1, b - a, H, 1.0 / math.sqrt(d), None, att.attn_dropout.p, att.training)
+        outs.append(o)
+    o = att.unpad_heads(torch.cat(outs), D)
+    o = ops.linear(o, att.out_proj.weight, att.out_proj.bias)
+    if att.training and att.resid_dropout.p > 0:
+        o = ops.act_dropout(o, ops.ACT_NONE, att.resid_dropout.p, True)
+    return o
+
+
 class GlobalAttentionPool(nn.Module):
     """One learned query per graph attends over that graph's nodes (dgdm_model.py:588-615), as a
     segmented softmax over the whole batch instead of a Python loop with boolean masks."""
@@ -434,13 +456,15 @@ class GlobalAttentionPool(nn.Module):
         self.attention = MultiHeadAttention(hidden_dim, num_heads)
         self.global_token = nn.Parameter(torch.randn(1, 1, hidden_dim))
 
+    _forward_dense = _pool_dense
+
     def forward(self, x: Tensor, batch: Optional[Tensor] = None, plan=None) -> Tensor:
         att = self.attention
         ap = _plan_for(x, batch, plan)
         H, d, C = att.num_heads, att.head_dim, att.embed_dim
         D = next((v for v in ops.POOL_HEAD_DIMS if v >= d), None)
         if D is None:
-            raise _lib.DGDMKernelError(f"attention pooling kernels support head_dim <= {ops.POOL_HEAD_DIMS[-1]}, got {d}")
+            return self._forward_dense(x, ap)
         q = ops.linear_small(self.global_token.view(1, C), att.q_proj.weight, att.q_proj.bias).view(C) * (1.0 / math.sqrt(d))
         wkv = torch.cat([att.k_proj.weight, att.v_proj.weight])
         bkv = torch.cat([att.k_proj.bias, att.v_proj.bias])

@@ -571,7 +571,34 @@ class _SpatialAttention(torch.autograd.Function):
 ATTN_PRECISION = "fp16x2"
 
 
-ATTN_HEAD_DIMS = (16, 32, 64)     # head widths the attention kernels take (narrower heads are zero-padded to the next one by the caller)
+ATTN_HEAD_DIMS = (16, 32, 64, 128)     # head widths the attention kernels take (narrower heads are zero-padded to the next one by the caller)
+
+
+def _dense_groups(plan: AttnPlan):
+    """(first graph, graphs, rows per graph) runs of the batch the dense kernels take in one launch each: the whole batch when its graphs
+    have one size, graph by graph otherwise (empty graphs dropped)."""
+    sizes = [plan.ptr_host[g + 1] - plan.ptr_host[g] for g in range(plan.B)]
+    if plan.B > 0 and len(set(sizes)) == 1:
+        return [(0, plan.B, sizes[0])] if sizes[0] > 0 else []
+    return [(g, 1, n) for g, n in enumerate(sizes) if n > 0]
+
+
+def _spatial_attention_dense(qkv, pos, plan: AttnPlan, H: int, D: int, scale: float, inv_tau: float, p: float, seed: int):
+    """Spatial attention at head_dim 128 (hidden_dims[-1] = 128 with ONE head, 256 with two ...: valid in the reference,
+    core/attention.py:36-40): the dense kernels of csrc/attn_dense.hip (two lanes per row) with the positions as their spatial bias,
+    one launch per run of equal-sized graphs.  Correct, not fast -- no default configuration comes here."""
+    C = H * D
+    pos = _f32c(pos)
+    outs = []
+    for g0, b, n in _dense_groups(plan):
+        r0, r1 = plan.ptr_host[g0], plan.ptr_host[g0] + b * n
+        sl, ps = qkv[r0:r1], pos[r0:r1]
+        m = DenseMask(None, None, b, H, n, n, qkv.device, posq=ps, posk=ps, inv_tau=inv_tau)
+        o, _, _ = attn_dense(sl[:, :C], sl[:, C:2 * C], sl[:, 2 * C:], b, n, n, H, scale, m, p, p > 0, seed=(seed + 0x9E3779B1 * g0) & 0xFFFFFFFF)
+        outs.append(o)
+    if not outs:
+        return qkv[:, :C] * 0.0
+    return outs[0] if len(outs) == 1 else torch.cat(outs)
 
 
 class _SpatialAttentionGen(torch.autograd.Function):
@@ -621,6 +648,8 @@ def spatial_attention(qkv, pos, plan: AttnPlan, H: int, scale: float, inv_tau: f
     D = qkv.size(1) // (3 * H)
     if qkv.size(1) != 3 * H * D or D not in ATTN_HEAD_DIMS:
         raise _lib.DGDMKernelError(f"spatial attention kernels take head dims {ATTN_HEAD_DIMS} (pad narrower heads with zeros), got {qkv.size(1)} / (3 x {H})")
+    if D == 128:
+        return _spatial_attention_dense(qkv, pos, plan, H, D, scale, inv_tau, p, seed or 0)
     if D != 16:
         return _SpatialAttentionGen.apply(qkv, pos, plan, H, D, scale, inv_tau, p, seed or 0)
     if ATTN_PRECISION == "fp32":
@@ -801,6 +830,16 @@ def spatial_attention_mean_weights(qkv, pos, plan: AttnPlan, H: int, scale: floa
     W = torch.empty(max(offs[-1], 1), dtype=torch.float32, device=qkv.device)
     off_dev = device_constant(offs[:-1], torch.int64, qkv.device)
     D = C // H
+    if D == 128:          # csrc/attn_dense.hip, as the forward of this head width
+        res = [None] * plan.B
+        for g0, b, n in _dense_groups(plan):
+            r0, r1 = plan.ptr_host[g0], plan.ptr_host[g0] + b * n
+            m = DenseMask(None, None, b, H, n, n, qkv.device, posq=pos[r0:r1], posk=pos[r0:r1], inv_tau=inv_tau)
+            _, lse, _ = attn_dense(q[r0:r1], k[r0:r1], v[r0:r1], b, n, n, H, scale, m)
+            Wd = attn_dense_weights(q[r0:r1], k[r0:r1], lse, b, n, n, H, scale, m)
+            for i in range(b):
+                res[g0 + i] = Wd[i]
+        return [w if w is not None else W[:0].view(0, 0) for w in res]
     if D != 16:           # head dims 32 / 64: csrc/attn_gen.hip (its own forward for the row log-sum-exp)
         if D not in ATTN_HEAD_DIMS:
             raise _lib.DGDMKernelError(f"spatial attention kernels take head dims {ATTN_HEAD_DIMS}, got {D}")

@@ -39,6 +39,7 @@ class DGDMAdamW(torch.optim.Optimizer):
         super().__init__(params, defaults)
         self._cohorts: Dict[int, List[dict]] = {}       # group index -> [{"step": tensor, "ticket": tensor, "ids": set(id(p))}]
         self._tables: Dict[tuple, tuple] = {}           # (group, cohort, pointers) -> (ctypes array, count): rebuilt when a grad moves
+        self._since_split: Dict[int, int] = {}          # group index -> host steps since a cohort of the group last split
 
     # ------------------------------------------------------------------ state
     def _init_state(self, p: torch.nn.Parameter, step: torch.Tensor) -> None:
@@ -77,12 +78,13 @@ class DGDMAdamW(torch.optim.Optimizer):
 
     def load_state_dict(self, state_dict) -> None:
         super().load_state_dict(state_dict)
-        self._cohorts, self._tables = {}, {}
+        self._cohorts, self._tables, self._since_split = {}, {}, {}
         for gi, group in enumerate(self.param_groups):
             group["fused"], group["capturable"] = True, True
             self._rebuild_cohorts(gi, group)
 
-    MERGE_ABOVE = 8      # cohorts per group beyond which a step looks for cohorts it can merge again (one device read, rare)
+    MERGE_ABOVE = 8          # cohorts per group beyond which EVERY step looks for cohorts it can merge again (one device read)
+    MERGE_AFTER_QUIET = 8    # ... and once, this many steps after the last split, whenever more than one cohort is left
 
     def _merge_cohorts(self, gi: int, group, live_ids) -> None:
         """Cohorts only ever split (a member without a gradient leaves with a copy of the count); a model whose branches get
@@ -109,6 +111,7 @@ class DGDMAdamW(torch.optim.Optimizer):
                 self.state[q]["step"] = c["step"]
         self._cohorts[gi] = merged
         self._tables = {k: v for k, v in self._tables.items() if k[0] != gi}
+        self._since_split[gi] = 0
 
     # ------------------------------------------------------------------ step
     @torch.no_grad()
@@ -140,9 +143,11 @@ class DGDMAdamW(torch.optim.Optimizer):
                 cohorts.append(c)
             capturing = torch.cuda.is_current_stream_capturing()
             live_ids = {id(p) for p in live}
-            if len(cohorts) > self.MERGE_ABOVE and not capturing:
+            quiet = self._since_split.get(gi, 0)
+            if not capturing and (len(cohorts) > self.MERGE_ABOVE or (len(cohorts) > 1 and quiet == self.MERGE_AFTER_QUIET)):
                 self._merge_cohorts(gi, group, live_ids)
                 cohorts = self._cohorts[gi]
+            self._since_split[gi] = quiet + 1
             lr = group["lr"]
             lr_dev = lr.data_ptr() if isinstance(lr, torch.Tensor) and lr.is_cuda else None
             lr_host = 0.0 if lr_dev is not None else float(lr)
@@ -170,6 +175,7 @@ class DGDMAdamW(torch.optim.Optimizer):
                             self.state[q]["step"] = c2["step"]
                     c["ids"] = c["ids"] - gone
                     cohorts.append(c2)
+                    self._since_split[gi] = 0
                 ptrs = []
                 for p in ps:
                     g, st = p.grad, self.state[p]

@@ -163,7 +163,7 @@ def test_default_arithmetic_is_at_the_error_level_of_fp32(case):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import arithmetic_error_report as R
     assert ops.configure() == dict(attention="fp16x2", gemm="f16x2")        # the arithmetic bench.py's headline runs on
-    res = R.run_case(case)
+    res = R.run_case(case, trace_grads=(case == "large"))
     rows = res["rows"]
     assert len(rows) >= 80
     (mx_d, md_d), (mx_h, md_h), (mx_c, md_c) = R.summary(rows)
@@ -178,14 +178,28 @@ def test_default_arithmetic_is_at_the_error_level_of_fp32(case):
     #     (observed 0.80 / 0.76 / 0.91 / 1.12 and 0.96 / 0.92 / 0.89 / 0.60 for smooth / unet / sharp / large);
     #   against the NEARER one: <= 2 x both (observed 1.23 / 1.04 / 1.53 / 1.92 and 1.26 / 1.07 / 1.46 / 1.66).
     # An emulation that lost two operand bits fails both (round 4 allowed 4 x / 2.5 x against either run).
-    # At Large widths the step amplifies rounding ~1e3 x (all three runs sit at 1-3e-4) and the two fp32 runs differ from each other by
-    # 2.9 x at the worst gradient and 4.2 x at the median (round 5, after the activation code changed: HIP fp32 3.3e-4 / 1.35e-4, torch
-    # 1.15e-4 / 3.2e-5, default 2.8e-4 / 6.6e-5): against the nearer run the bound there is 3 x -- still inside the fp32 band, which
-    # the first assertion pins from the other side.
+    # At Large widths the step amplifies rounding ~1e3 x (all three runs sit at 1-3e-4); until round 6 the HIP runs sat 2-4 x above
+    # torch's there and round 5 had widened this bound to 3 x.  Round 6 found the cause (tools/gradient_error_trace.py,
+    # tools/ubench/mfma_rounding.hip; profiles/r06_gradient_error_trace*.txt, r06_mfma_rounding.txt): the matrix pipe adds a block of
+    # products into its fp32 accumulator with TWICE the rms error of one correctly rounded add (f16 and fp32 MFMA alike), so every
+    # GEMM output -- in both HIP arithmetics -- carried 2.0 x the error of a CPU sgemm from the first layer on (with the tile GEMMs
+    # replaced by float64 products the HIP runs are 0.3-0.8 x torch's error), and the problem amplifies either run's error by the same
+    # ~1e3 (the top-k pooling's score gradient is a cancelling sum); one (weights, data) draw is one sample.  Round 5's branch-free GELU
+    # was NOT the cause of the r04 -> r05 move (with the library erf back, three draws give default / torch 1.52, 3.50, 3.51 against
+    # 2.05, 4.10, 1.31 with it): it re-drew the sample.  The fix is in the kernels: the default GEMMs now chain each column tile's
+    # products of a stage from a ZERO accumulator and add that block to the running accumulator on the vector unit (csrc/gemm_img.hip
+    # DGDM_IMG_FRESH, csrc/gemm_h.hip TN_FLUSH): every traced activation of the default run is now at 0.6-1.0 x torch's error (was
+    # 1.5-2.1 x) and default / torch at the median gradient is 1.34, 1.69 over the draws.  So the bound against the nearer run is 2 x
+    # again at every case, and the activation-level property is asserted below (default <= 1.5 x torch at all 19 trace points; the
+    # fp32-operand kernels of the strict leg keep the single accumulator: <= 3 x).
     far_mx, far_md, near_mx, near_md = max(mx_h, mx_c), max(md_h, md_c), min(mx_h, mx_c), min(md_h, md_c)
-    near = 3.0 if case == "large" else 2.0
+    near = 2.0
     assert mx_d <= 1.25 * far_mx and md_d <= 1.25 * far_md, (mx_d, far_mx, md_d, far_md)
     assert mx_d <= near * near_mx and md_d <= near * near_md, (mx_d, near_mx, md_d, near_md)
+    if res["trace_rows"]:
+        assert len(res["trace_rows"]) >= 15
+        for k, _gd, _gh, _gt, v_def, v_hip, v_torch in res["trace_rows"]:
+            assert v_def <= 1.5 * v_torch and v_hip <= 3.0 * v_torch, (k, v_def, v_hip, v_torch)
 
 
 class _DropoutSites:

@@ -553,8 +553,8 @@ def test_dgdm_adamw_cohorts_merge_again_and_a_split_inside_a_capture_raises():
         run(step, lambda i: (i // 6) % 4 == step - 7)
         peak = max(peak, len(o_own._cohorts[0]))
     assert peak > DGDMAdamW.MERGE_ABOVE, peak
-    for step in range(11, 14):                 # everybody live: all 24 have paused exactly twice -> ONE count, one cohort, one launch
-        run(step, lambda i: False)
+    for step in range(11, 11 + DGDMAdamW.MERGE_AFTER_QUIET + 2):      # everybody live: all 24 have paused exactly twice -> ONE count;
+        run(step, lambda i: False)                                    # a quiet period after the last split, then one cohort, one launch
     assert len(o_own._cohorts[0]) == 1, len(o_own._cohorts[0])
     assert len({float(o_own.state[b]["step"]) for b in own}) == 1
 

@@ -83,7 +83,7 @@ int main() {
         printf("  %+10.2f\n", (rn - c0) * ldexpf(1.f, 24));
       }
   }
-  for (int steps : {24, 64, 256, 2500}) {
+  for (int steps : {24, 64, 192, 256, 1875, 2500}) {
     const int trials = steps > 256 ? 512 : 4096;
     std::vector<_Float16> a((size_t)trials * steps * 32), b(a.size());
     srand(1234 + steps);
@@ -115,6 +115,12 @@ int main() {
     std::vector<float> got(trials);
     hipLaunchKernelGGL((k_chain<0>), dim3(trials), dim3(64), 0, 0, da, db, steps, dout);
     hipMemcpy(got.data(), dout, trials * 4, hipMemcpyDeviceToHost); stats("(a) one MFMA accumulator", got.data());
+    hipLaunchKernelGGL((k_chain<96>), dim3(trials), dim3(64), 0, 0, da, db, steps, dout);
+    hipMemcpy(got.data(), dout, trials * 4, hipMemcpyDeviceToHost); stats("(b) fresh accumulator every 96 steps + VALU add", got.data());
+    hipLaunchKernelGGL((k_chain<48>), dim3(trials), dim3(64), 0, 0, da, db, steps, dout);
+    hipMemcpy(got.data(), dout, trials * 4, hipMemcpyDeviceToHost); stats("(b) fresh accumulator every 48 steps + VALU add", got.data());
+    hipLaunchKernelGGL((k_chain<24>), dim3(trials), dim3(64), 0, 0, da, db, steps, dout);
+    hipMemcpy(got.data(), dout, trials * 4, hipMemcpyDeviceToHost); stats("(b) fresh accumulator every 24 steps + VALU add", got.data());
     hipLaunchKernelGGL((k_chain<8>), dim3(trials), dim3(64), 0, 0, da, db, steps, dout);
     hipMemcpy(got.data(), dout, trials * 4, hipMemcpyDeviceToHost); stats("(b) fresh accumulator every 8 steps + VALU add", got.data());
     hipLaunchKernelGGL((k_chain<2>), dim3(trials), dim3(64), 0, 0, da, db, steps, dout);
