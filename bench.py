@@ -621,6 +621,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     timed = ["attn_fwd", "attn_bwd_dq", "attn_bwd_dkv", "attn_bwd_fused", "attn_bwd_dq_reduce", "spmm_c512"]
+    TSTAT = "mean" if stream is not None else "median"      # fixed shapes: the median launch (robust against one host hiccup); mixed stream: total / count
     graphed = step is not eager_step
     live_sink = None
     if not graphed:
@@ -743,13 +744,13 @@ def main():
                       "attention": "fp32 operands on v_mfma_f32_16x16x4_f32 (csrc/attn_fwd.hip, attn_bwd.hip)",
                       "dense_layers": "fp32 operands on v_mfma_f32_32x32x2_f32 (csrc/gemm.hip)"}
             # the dominant kernel of THIS leg, timed like the headline's: eager launches of the same step bracketed by HIP events
-            main_timers = ops.TIMERS.summary()
+            main_timers = ops.TIMERS.summary(TSTAT)
             ops.TIMERS.start(timed)
             for _ in range(3):
                 eager_step()
             torch.cuda.synchronize()
             ops.TIMERS.stop()
-            strict["_timers"] = ops.TIMERS.summary()
+            strict["_timers"] = ops.TIMERS.summary(TSTAT)
             ops.TIMERS.events = {}
             strict["_main_timers"] = main_timers
         finally:
@@ -768,7 +769,7 @@ def main():
 
     result = None
     if rank == 0:
-        timers = strict.pop("_main_timers") if strict is not None else ops.TIMERS.summary()
+        timers = strict.pop("_main_timers") if strict is not None else ops.TIMERS.summary(TSTAT)
         heads, hd = cfg["attention_heads"], 16
         # products of 2 N^2 H d FLOP each: forward S, PV; two-pass backward dQ: S, dP, dS K / dK,dV: S, dP, P^T dO, dS^T Q; one-pass
         # backward (default): S, dP, P^T dO, dS^T Q, dS K -- each score evaluated once
@@ -825,7 +826,8 @@ def main():
             tpath = (traffic_path or (PMC_TRAFFIC_LARGE if args.large else PMC_TRAFFIC)) if pmc else None
             vpath = (valu_path or (PMC_VALU_LARGE if args.large else PMC_VALU)) if pmc else None
             traffic = None if tpath is None else pmc_traffic(names[dom], tpath)
-            common = {"kernel": names[dom], "ms_per_launch": round(ms, 4), "launches_timed": tm[dom][0], "traffic": traffic,
+            common = {"kernel": names[dom], "ms_per_launch": round(ms, 4), "ms_per_launch_is": TSTAT + " of the timed launches",
+                      "launches_timed": tm[dom][0], "traffic": traffic,
                       "traffic_kind": TRAFFIC_KIND,
                       "traffic_source": None if traffic is None else f"committed PMC passes {os.path.relpath(tpath, ROOT)}, kernel {names[dom]}",
                       "other_kernels_ms": {k: round(v[1], 4) for k, v in tm.items() if k != dom}, "timed_with": graphed_note}
