@@ -312,14 +312,25 @@ def sample_loop_bench(model, dev, rows=10000, reps=5):
     C, Hd, T = dl.node_dim, dl.hidden_dim, dl.num_timesteps
     was_training = dl.training
     dl.eval()
-    # per step: GEMM C->2Hd (read x, write h1), GroupNorm+SiLU (read + write h1), GEMM 2Hd->Hd, GroupNorm+SiLU, GEMM Hd->C, one normal
-    # draw (write z), the DDPM update (read x, eps, z; write x): fp32 rows, weights (0.9 MB) not counted
-    step_bytes = rows * 4 * ((C + 2 * Hd) + 2 * 2 * Hd + (2 * Hd + Hd) + 2 * Hd + (Hd + C) + C + 4 * C)
+    from dgdm_histopath_lab_amd import ops
+    fused = ops.denoise_ddpm_step_supported(C) and Hd == 2 * C
     step_flop = 2.0 * rows * (C * 2 * Hd + 2 * Hd * Hd + Hd * C)
-    out = {"rows": rows, "width": C, "denoiser_widths": [C + Hd, 2 * Hd, Hd, C], "T": T, "launches_per_step": 7,
+    if fused:
+        # one launch per step (csrc/sample_step.hip): the activations never leave the CU.  HBM bytes of a step: the normal draw writes z,
+        # the step reads x and z and writes x (fp32 rows) + the three weight images once (they stay in L2 afterwards)
+        w_bytes = 4 * (C * 2 * Hd + 2 * Hd * Hd + Hd * C)
+        step_bytes = rows * 4 * 4 * C + w_bytes
+        launches, what = 1, ("ONE launch per step for the whole denoiser + DDPM update (csrc/sample_step.hip: 32 rows per workgroup through three "
+                             "Linear layers, two GroupNorm + SiLU and the update, activations in LDS); the loop's normal draws in one launch up front")
+    else:
+        # per step: GEMM C->2Hd (read x, write h1), GroupNorm+SiLU (read + write h1), GEMM 2Hd->Hd, GroupNorm+SiLU, GEMM Hd->C, one normal
+        # draw (write z), the DDPM update (read x, eps, z; write x): fp32 rows, weights (0.9 MB) not counted
+        step_bytes = rows * 4 * ((C + 2 * Hd) + 2 * 2 * Hd + (2 * Hd + Hd) + 2 * Hd + (Hd + C) + C + 4 * C)
+        launches, what = 7, "7 launches per step: 3 tile GEMMs, 2 fused GroupNorm+SiLU rows, one normal draw, one DDPM update"
+    out = {"rows": rows, "width": C, "denoiser_widths": [C + Hd, 2 * Hd, Hd, C], "T": T, "launches_per_step": launches,
            "algorithmic_bytes_per_step": step_bytes, "flop_per_step": step_flop,
-           "note": "sample(graphed=True): the whole loop is ONE recorded HIP graph (7 launches per step: 3 tile GEMMs, 2 fused GroupNorm+SiLU "
-                   "rows, one normal draw, one DDPM update; the time-embedding MLP runs once before the loop); eval mode as generate()"}
+           "note": "sample(graphed=True): the whole loop is ONE recorded HIP graph (" + what + "; the time-embedding MLP runs once before the "
+                   "loop); eval mode as generate()"}
     P = {k: v.detach().float().cpu() for k, v in model.state_dict().items() if k.startswith("diffusion_layer.") and "scheduler" not in k}
     sched = O.diffusion_schedule(T, MODEL_CFG.get("diffusion_schedule", "cosine"))
     try:
@@ -354,8 +365,12 @@ def sample_loop_bench(model, dev, rows=10000, reps=5):
                                                   "itself (input copy + replay + output clone)",
                                     "roofline": {"bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                                  "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": None,
-                                                 "note": "7 dependent launches of 16-41 MB each per step: start-up and drain of each launch, "
-                                                         "not bytes, are what a step costs at this size"},
+                                                 "mfma_tflops": round(steps * step_flop / (ms * 1e-3) / 1e12, 1),
+                                                 "mfma_frac": round(steps * step_flop / (ms * 1e-3) / 1e12 / FP16_MFMA_PEAK_TFLOPS, 4),
+                                                 "note": ("one launch of %d workgroups per step on 256 CUs: a %d-row problem is 1.2 rounds of workgroups, "
+                                                          "each a chain of three dependent layers -- latency, neither bytes nor FLOP" % ((rows + 31) // 32, rows))
+                                                         if fused else "7 dependent launches of 16-41 MB each per step: start-up and drain of each "
+                                                         "launch, not bytes, are what a step costs at this size"},
                                     "cpu_baseline": {"value": round(cpu_ms, 2), "unit": "ms per loop", "cores": torch.get_num_threads(), "kind": "port",
                                                      "sample": f"the same loop ({steps} steps, {rows} rows) by oracle.ddpm_sample, once"},
                                     "speedup_vs_cpu": round(cpu_ms / ms, 1)}

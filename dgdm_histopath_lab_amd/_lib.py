@@ -94,6 +94,9 @@ SIGNATURES = {
     "dgdm_segment_mse_bwd": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _p]),
     "dgdm_mask_rows": (C.c_int, [_p, _p, _p, _i32, _i32, _p, _p, _p]),
     "dgdm_ddpm_step": (C.c_int, [_p, _p, _p, _i64, C.c_float, C.c_float, C.c_float, C.c_float, _i32, _p, _p]),
+    "dgdm_denoise_ddpm_step_supported": (_i32, [_i32]),
+    "dgdm_denoise_ddpm_step": (C.c_int, [_p, _i64, _p, _i64, _i32, _i32, _p, _i32, _p, _i32, _p, _i32, _p, _p, _p, C.c_float, _p, _p, _p, C.c_float, _p,
+                                         C.c_float, C.c_float, C.c_float, C.c_float, _i32, _p, _i64, _p]),
     "dgdm_pool_score_fwd": (C.c_int, [_p, _i64, _p, _p, _i32, _i32, _p, _p, _i32, _p]),
     "dgdm_vec_softmax_fwd": (C.c_int, [_p, _i32, _p, _p]),
     "dgdm_vec_softmax_bwd": (C.c_int, [_p, _p, _i32, _p, _p]),

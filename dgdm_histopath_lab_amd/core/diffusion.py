@@ -196,7 +196,8 @@ class DiffusionLayer(nn.Module):
         returns x0_hat without noise.  ``x_init`` / ``step_noise`` inject the random draws (tests).
 
         Per step: 3 tile GEMMs (the time half of the first layer enters as that GEMM's bias), 2 fused GroupNorm+SiLU rows, one
-        update kernel (dgdm_ddpm_step) and one normal draw -- 7 launches, no host synchronisation.  The time-embedding MLP runs
+        update kernel (dgdm_ddpm_step) and one normal draw -- 7 launches, no host synchronisation; in eval mode at node_dim 128 / 256 the
+        whole step is ONE launch (csrc/sample_step.hip, `ops.denoise_ddpm_step`) and the loop's draws are one launch up front.  The time-embedding MLP runs
         ONCE for the <= T distinct timesteps before the loop (3 small-M launches).  ``graphed=True`` records the whole loop as one
         HIP graph per (rows, steps) and replays it (fresh draws on every replay through torch's graph-aware generator)."""
         if len(shape) != 2 or shape[1] != self.node_dim:
@@ -247,6 +248,8 @@ class DiffusionLayer(nn.Module):
         ops.amax_recording_replayed(amax_rec)
         return out.clone()
 
+    SAMPLE_NOISE_BYTES = 1 << 30      # the loop's normal draws are made in one launch when they fit this budget
+
     def _sample_loop(self, x: Tensor, ts: List[int], step_noise: Optional[List[Tensor]], ce: Optional[Tensor] = None) -> Tensor:
         device, C = x.device, self.node_dim
         sch = self.scheduler
@@ -267,8 +270,19 @@ class DiffusionLayer(nn.Module):
         w0x = self.denoise_net[0].weight[:, :C]
         gn1 = self.denoise_net[1]
         self._check_group_norms()
+        dn = self.denoise_net
+        fused = (tf is None and not (self.training and (dn[3].p > 0 or dn[7].p > 0)) and dn[1].num_groups == 8 and dn[5].num_groups == 8
+                 and self.hidden_dim == 2 * C and all(m.bias is not None for m in (dn[0], dn[4], dn[8])) and ops.denoise_ddpm_step_supported(C))
+        zs = None
+        if fused and step_noise is None and len(ts) > 1 and (len(ts) - 1) * x.numel() * 4 <= self.SAMPLE_NOISE_BYTES:
+            zs = torch.randn(len(ts) - 1, *x.shape, device=device)      # every step's draw in ONE launch (a launch per step otherwise)
         for i, t in enumerate(ts):
             last = i == len(ts) - 1
+            if fused:      # the whole step in one launch (csrc/sample_step.hip): every operation of it is row-local
+                z = None if last else (zs[i] if zs is not None else (torch.randn_like(x) if step_noise is None else step_noise[i]))
+                x = ops.denoise_ddpm_step(x, z, w0x, dn[4].weight, dn[8].weight, bias[row[t]], gn1, dn[4].bias, dn[5], dn[8].bias,
+                                          s1mac[t], sac[t], salpha[t], svar[t], last)
+                continue
             # first layer (the time half of its weight enters as the bias) with its GroupNorm + SiLU + dropout
             if tf is not None:
                 h = self._first_layer_rows(x, ce + tf[row[t]])

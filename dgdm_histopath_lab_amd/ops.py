@@ -1165,6 +1165,34 @@ def ddpm_step(x, eps, z, sqrt_one_minus_ac: float, sqrt_ac: float, sqrt_alpha: f
 
 
 # ----------------------------------------------------------------------------- segment ops / K10 pooling
+SAMPLE_STEP_FUSED = True      # DiffusionLayer.sample: one launch per step (csrc/sample_step.hip) where the width is taken; False: seven
+
+
+def denoise_ddpm_step_supported(C: int) -> bool:
+    return (SAMPLE_STEP_FUSED and USE_WEIGHT_IMAGES and GEMM_MATH == "f16x2" and bool(_lib.load().dgdm_denoise_ddpm_step_supported(int(C))))
+
+
+def denoise_ddpm_step(x, z, w0x, w1, w2, bias0, gn1, bias1, gn2, bias2, s1mac: float, sac: float, salpha: float, svar: float, last: bool):
+    """One step of DiffusionLayer.sample in ONE launch (csrc/sample_step.hip): eps = denoise_net([x | t_emb]) with the time half as the
+    per-step ``bias0`` [4C], then the DDPM update with ``z`` (None on the last step).  ``w0x`` = denoise_net[0].weight[:, :C], ``w1`` /
+    ``w2`` the other two Linear weights (their images are the training step's), ``gn1`` / ``gn2`` the nn.GroupNorm modules.  Eval only."""
+    lib = _lib.load()
+    x = _f32c(x)
+    _lib.require_cuda(x, z, bias0)
+    N, C = x.shape
+    e0, e1, e2 = WEIGHT_IMAGES.get(0, _rm_tagged(w0x)), WEIGHT_IMAGES.get(0, _rm_tagged(w1)), WEIGHT_IMAGES.get(0, _rm_tagged(w2))
+    out = torch.empty_like(x)
+    if z is not None:
+        z = _f32c(z)
+    bias0 = _f32c(bias0)
+    _lib.check(lib.dgdm_denoise_ddpm_step(x.data_ptr(), x.stride(0), _lib.ptr(z), z.stride(0) if z is not None else 0, N, C,
+                                          e0.img.data_ptr(), e0.tiles, e1.img.data_ptr(), e1.tiles, e2.img.data_ptr(), e2.tiles, bias0.data_ptr(),
+                                          gn1.weight.data_ptr(), gn1.bias.data_ptr(), float(gn1.eps), bias1.data_ptr(), gn2.weight.data_ptr(),
+                                          gn2.bias.data_ptr(), float(gn2.eps), bias2.data_ptr(), s1mac, sac, salpha, svar, int(last),
+                                          out.data_ptr(), out.stride(0), _lib.stream_ptr(x.device)), "dgdm_denoise_ddpm_step")
+    return out
+
+
 def segment_sum_raw(x, plan: AttnPlan) -> torch.Tensor:
     lib = _lib.load()
     x = _f32c(x)

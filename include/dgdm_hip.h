@@ -421,6 +421,22 @@ DGDM_API int dgdm_linear_small_bwd(const float* gy, int64_t ldg, const float* pr
 DGDM_API int dgdm_ddpm_step(const float* x, const float* eps, const float* z, int64_t n, float sqrt_one_minus_ac, float sqrt_ac,
                             float sqrt_alpha, float sqrt_var, int32_t last, float* out, void* stream);
 
+/* K8-fused (round 6): ONE step of DiffusionLayer.sample as ONE launch (reference: core/diffusion.py:214-275, the T-step denoise loop):
+ *   eps = denoise_net([x | t_emb]);  out = last ? x0 : sqrt_alpha * x0 + sqrt_var * z,  x0 = (x - sqrt_one_minus_ac * eps) / sqrt_ac.
+ * Every operation of the step is row-local, so a workgroup takes 32 rows through the three Linear layers, the two GroupNorm(8) + SiLU
+ * and the update with the activations in LDS (csrc/sample_step.hip).  x / z / out [N, C] fp32 (row strides ldx / ldz / ldo; z may be
+ * NULL when last != 0; out may alias x only if no other launch reads x).  img0 / img1 / img2: the weight images (dgdm_gemm_image_build,
+ * kind "forward") of denoise_net[0].weight[:, :C] ([4C, C]: tiles0 = 4C / 32), denoise_net[4].weight ([2C, 4C]: tiles1 = 2C / 32),
+ * denoise_net[8].weight ([C, 2C]: tiles2 = C / 32).  bias0 [4C] = the time half of denoise_net[0] applied to this step's t_emb plus its
+ * bias (what dgdm_linear_small_fwd gives for the timestep); gn*_w / gn*_b / eps*: the two GroupNorm(8) layers; bias1 [2C], bias2 [C].
+ * Eval mode only (no dropout).  C in {128, 256} (dgdm_denoise_ddpm_step_supported), else DGDM_ERR_UNSUPPORTED. */
+DGDM_API int32_t dgdm_denoise_ddpm_step_supported(int32_t C);
+DGDM_API int dgdm_denoise_ddpm_step(const float* x, int64_t ldx, const float* z, int64_t ldz, int32_t N, int32_t C, const void* img0,
+                                    int32_t tiles0, const void* img1, int32_t tiles1, const void* img2, int32_t tiles2, const float* bias0,
+                                    const float* gn1_w, const float* gn1_b, float eps1, const float* bias1, const float* gn2_w,
+                                    const float* gn2_b, float eps2, const float* bias2, float sqrt_one_minus_ac, float sqrt_ac,
+                                    float sqrt_alpha, float sqrt_var, int32_t last, float* out, int64_t ldo, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Per-graph (segment) primitives; graph g owns the contiguous rows [ptr[g], ptr[g+1]) (ptr: int32
  * DEVICE array [B+1]).  They replace the reference's per-graph Python loops with boolean masks
