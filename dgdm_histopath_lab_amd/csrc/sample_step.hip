@@ -38,7 +38,8 @@ struct StepArgs {
   int last;
 };
 
-__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
+// v sigmoid(v) with the hardware reciprocal (1 ulp) in place of the ~10-instruction IEEE division: 96 of these per thread and step
+__device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
 // B fragment (tile t, 32-k chunk c, MFMA j, part p) of an image with T tiles per chunk: csrc/gemm_img.hip "Image layout"
 // diagnostic builds only (tools/build_variant_lib.sh -DDGDM_STEP_DIAG=n): 1 = no weight loads (one fragment reused), 2 = no GroupNorm
@@ -108,19 +109,25 @@ __device__ __forceinline__ void store_prenorm(const f32x16 (&acc)[NT], char* __r
 }
 
 // thread (row = tid >> 3, group = tid & 7): GroupNorm(8) over its W = width / 8 channels of the row, SiLU, then -- after everybody has
-// read -- the hi / lo planes of the whole row over the same bytes (hi at 0, lo at 2 * width)
+// read -- the hi / lo planes of the whole row over the same bytes (hi at 0, lo at 2 * width).
+// The 8 threads of a row start a multiple of 128 bytes apart: read or written in the same order they would all sit on one 16-byte slot of
+// the LDS (a 16-byte store is served 8 consecutive lanes at a time: 8-way; a 16-byte read 4-way).  Thread g therefore walks its 8-channel
+// pieces ROTATED by rot(g): the stores of a row's 8 threads fall on 8 different slots, the reads are at worst 2-way.
 template <int WIDTH, int PITCH>
 __device__ __forceinline__ void group_norm_silu(char* __restrict__ smem, const float* gamma, const float* beta, float eps, int tid) {      // gamma / beta: LDS copies
-  constexpr int W = WIDTH / 8;
+  constexpr int W = WIDTH / 8, NP = W / 8;                // NP pieces of 8 channels
   const int row = tid >> 3, g = tid & 7;
+  const int rot = W == 32 ? (g >> 1) : g;                 // W = 32: threads g and g + 1 are 64 bytes apart already
   float v[W];
   const float* src = reinterpret_cast<const float*>(smem + row * PITCH) + g * W;
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < W; i += 4) {
-    const float4 q = *reinterpret_cast<const float4*>(src + i);
-    v[i] = q.x; v[i + 1] = q.y; v[i + 2] = q.z; v[i + 3] = q.w;
-    s += (q.x + q.y) + (q.z + q.w);
+  for (int j = 0; j < NP; ++j) {
+    const int pc = (j + rot) & (NP - 1);
+    const float4 q0 = *reinterpret_cast<const float4*>(src + 8 * pc), q1 = *reinterpret_cast<const float4*>(src + 8 * pc + 4);
+    v[8 * j] = q0.x; v[8 * j + 1] = q0.y; v[8 * j + 2] = q0.z; v[8 * j + 3] = q0.w;
+    v[8 * j + 4] = q1.x; v[8 * j + 5] = q1.y; v[8 * j + 6] = q1.z; v[8 * j + 7] = q1.w;
+    s += ((q0.x + q0.y) + (q0.z + q0.w)) + ((q1.x + q1.y) + (q1.z + q1.w));
   }
   const float mean = s * (1.0f / W);
   float ss = 0.f;
@@ -128,18 +135,26 @@ __device__ __forceinline__ void group_norm_silu(char* __restrict__ smem, const f
   for (int i = 0; i < W; ++i) { const float d = v[i] - mean; ss = fmaf(d, d, ss); }
   const float rstd = rsqrtf(ss * (1.0f / W) + eps);      // biased variance, as nn.GroupNorm
 #pragma unroll
-  for (int i = 0; i < W; ++i) v[i] = (DGDM_STEP_DIAG & 2) ? v[i] * rstd : silu_f(fmaf((v[i] - mean) * rstd, gamma[g * W + i], beta[g * W + i]));
+  for (int j = 0; j < NP; ++j) {
+    const int pc = (j + rot) & (NP - 1);
+    const float4 ga = *reinterpret_cast<const float4*>(gamma + g * W + 8 * pc), gb = *reinterpret_cast<const float4*>(gamma + g * W + 8 * pc + 4);
+    const float4 ba = *reinterpret_cast<const float4*>(beta + g * W + 8 * pc), bb = *reinterpret_cast<const float4*>(beta + g * W + 8 * pc + 4);
+    const float gm[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w}, bt[8] = {ba.x, ba.y, ba.z, ba.w, bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[8 * j + k] = (DGDM_STEP_DIAG & 2) ? v[8 * j + k] * rstd : silu_f(fmaf((v[8 * j + k] - mean) * rstd, gm[k], bt[k]));
+  }
   __syncthreads();                                       // every thread has its fp32 values: the row's bytes may be overwritten
   char* dst = smem + row * PITCH + g * W * 2;
 #pragma unroll
-  for (int i = 0; i < W; i += 8) {
+  for (int j = 0; j < NP; ++j) {
+    const int pc = (j + rot) & (NP - 1);
     uint4 h, l;
-    split_pair(v[i], v[i + 1], &h.x, &l.x);
-    split_pair(v[i + 2], v[i + 3], &h.y, &l.y);
-    split_pair(v[i + 4], v[i + 5], &h.z, &l.z);
-    split_pair(v[i + 6], v[i + 7], &h.w, &l.w);
-    *reinterpret_cast<uint4*>(dst + i * 2) = h;
-    *reinterpret_cast<uint4*>(dst + 2 * WIDTH + i * 2) = l;
+    split_pair(v[8 * j], v[8 * j + 1], &h.x, &l.x);
+    split_pair(v[8 * j + 2], v[8 * j + 3], &h.y, &l.y);
+    split_pair(v[8 * j + 4], v[8 * j + 5], &h.z, &l.z);
+    split_pair(v[8 * j + 6], v[8 * j + 7], &h.w, &l.w);
+    *reinterpret_cast<uint4*>(dst + pc * 16) = h;
+    *reinterpret_cast<uint4*>(dst + 2 * WIDTH + pc * 16) = l;
   }
 }
 
@@ -270,11 +285,12 @@ __global__ __launch_bounds__(256, C <= 128 ? 2 : 1) void k_denoise_ddpm_step(con
   }
 }
 
-template <typename Kern>
-int allow_lds(Kern kern, int bytes) {
+// one status per kernel (the instances have the same function type: the instance is the template argument)
+template <void (*KERN)(const StepArgs)>
+int allow_lds(int bytes) {
   static int status = 1;
   if (status == 1)
-    status = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess ? DGDM_OK
+    status = hipFuncSetAttribute(reinterpret_cast<const void*>(KERN), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess ? DGDM_OK
                                                                                                                                      : DGDM_ERR_LAUNCH;
   return status;
 }
@@ -303,11 +319,11 @@ extern "C" int dgdm_denoise_ddpm_step(const float* x, int64_t ldx, const float* 
   const dim3 grid((N + 31) / 32);
   if (C == 128) {
     constexpr int LDS = 32 * (4 * 128 * 4 + 16) + 2 * (4 * 128 + 2 * 128) * 4;
-    if (allow_lds(k_denoise_ddpm_step<128>, LDS) != DGDM_OK) return DGDM_ERR_LAUNCH;
+    if (allow_lds<k_denoise_ddpm_step<128>>(LDS) != DGDM_OK) return DGDM_ERR_LAUNCH;
     hipLaunchKernelGGL(k_denoise_ddpm_step<128>, grid, dim3(256), LDS, s, a);
   } else {
     constexpr int LDS = 32 * (4 * 256 * 4 + 16) + 2 * (4 * 256 + 2 * 256) * 4;
-    if (allow_lds(k_denoise_ddpm_step<256>, LDS) != DGDM_OK) return DGDM_ERR_LAUNCH;
+    if (allow_lds<k_denoise_ddpm_step<256>>(LDS) != DGDM_OK) return DGDM_ERR_LAUNCH;
     hipLaunchKernelGGL(k_denoise_ddpm_step<256>, grid, dim3(256), LDS, s, a);
   }
   return dgdm_launch_status();

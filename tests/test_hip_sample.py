@@ -131,10 +131,10 @@ def test_graphed_sample_follows_weight_updates():
     assert_close(new_g, ref, TOL, "graphed sample on the new weights vs oracle")
 
 
-@pytest.mark.parametrize("C,n", [(128, 1003), (128, 31), (256, 330)])
+@pytest.mark.parametrize("C,n", [(128, 1003), (128, 31), (256, 330), (128, 20011)])
 def test_fused_sample_step_matches_float64_and_the_seven_launch_path(C, n, monkeypatch):
     """Round 6: one step of DiffusionLayer.sample as ONE launch (csrc/sample_step.hip; reference core/diffusion.py:147-172,245-273) at
-    node_dim 128 (Base) and 256 (Large), ragged last row tile, large |x| (the early steps divide by sqrt(ac) ~ 0.02: per-workgroup
+    node_dim 128 (Base, up to more workgroups than the chip holds at once) and 256 (Large), ragged last row tile, large |x| (the early steps divide by sqrt(ac) ~ 0.02: per-workgroup
     power-of-two scale), first / middle / last step -- against a float64 composition of the reference's formulas, and against the
     seven-launch path of rounds 2-5 (`ops.SAMPLE_STEP_FUSED = False`) over a whole 10-step loop."""
     from dgdm_histopath_lab_amd import ops
