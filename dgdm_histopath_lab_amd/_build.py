@@ -48,7 +48,9 @@ def _sources():
 
 
 def _digest() -> str:
-    h = hashlib.sha256((" ".join(FLAGS) + repr(sorted(EXTRA_FLAGS.items()))).encode())
+    # the include paths enter relative to the repository: the snapshot on a GPU box lives under another root, and a digest over absolute
+    # paths made every box rebuild the library it had just received
+    h = hashlib.sha256((" ".join(f.replace(ROOT, "<root>") for f in FLAGS) + repr(sorted(EXTRA_FLAGS.items()))).encode())
     for root in (CSRC, os.path.join(ROOT, "include")):
         for f in sorted(os.listdir(root)):
             if f.endswith((".hip", ".hpp", ".h")):
