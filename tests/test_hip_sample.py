@@ -187,3 +187,32 @@ def test_fused_sample_step_matches_float64_and_the_seven_launch_path(C, n, monke
     dl.eval()
     dl.sample((n, C), DEV, num_inference_steps=3)
     assert len(calls) == 3
+
+
+def test_fused_sample_step_is_affine_in_the_draw_at_full_size():
+    """Size-independent property at BASELINE's rows (4 x 10 000, more workgroups than the chip holds at once; nothing the oracle could
+    finish in seconds): the step is x' = f(x) + sqrt(var) z, so two launches on the same x differ by exactly sqrt(var) (z1 - z2) up to the
+    rounding of the last add, row by row, and the last step ignores z.  reference: core/diffusion.py:255-273."""
+    from dgdm_histopath_lab_amd import ops
+    from dgdm_histopath_lab_amd.core.diffusion import DiffusionLayer
+    torch.manual_seed(5)
+    C, n = 128, 40000
+    dl = DiffusionLayer(C, 2 * C, num_timesteps=10).to(DEV).eval()
+    dn = dl.denoise_net
+    x = torch.randn(n, C, device=DEV) * 3
+    z1, z2 = torch.randn(n, C, device=DEV), torch.randn(n, C, device=DEV)
+    bias0 = dl.time_bias(torch.tensor([5], device=DEV))[0]
+    args = (dn[0].weight[:, :C], dn[4].weight, dn[8].weight, bias0, dn[1], dn[4].bias, dn[5], dn[8].bias, 0.6, 0.8, 0.95, 0.3)
+    a = ops.denoise_ddpm_step(x, z1, *args, False)
+    b = ops.denoise_ddpm_step(x, z2, *args, False)
+    c = ops.denoise_ddpm_step(x, torch.zeros_like(z1), *args, False)
+    assert torch.isfinite(a).all() and torch.equal(a, ops.denoise_ddpm_step(x, z1, *args, False))      # repeatable bit for bit
+    scale = float(c.abs().max()) + 0.3 * float(z1.abs().max())
+    assert float(((a - b) - 0.3 * (z1 - z2)).abs().max()) <= 4e-7 * scale
+    assert float(((a - c) - 0.3 * z1).abs().max()) <= 4e-7 * scale
+    last = ops.denoise_ddpm_step(x, None, *args, True)
+    assert_close(last * 0.95, c, 1e-6, "last step = x0 prediction; the others = sqrt(alpha) x0 + sqrt(var) z")
+    # rows are independent: a permutation of the rows permutes the output (up to the workgroups' power-of-two scales of x: another
+    # grouping of rows, another scale, another place where the lo halves end)
+    perm = torch.randperm(n, device=DEV)
+    assert_close(ops.denoise_ddpm_step(x[perm].contiguous(), z1[perm].contiguous(), *args, False), a[perm], 1e-6, "rows permuted")
