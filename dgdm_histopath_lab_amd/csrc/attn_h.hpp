@@ -149,6 +149,21 @@ __device__ __forceinline__ f16x8 load_tr_pair(const _Float16* __restrict__ rimg_
   return __builtin_bit_cast(f16x8, r);
 }
 
+// Workgroup order of the attention kernels.  The hardware deals consecutive workgroups to the 8 XCDs in turn (workgroup L runs on XCD
+// L % 8), and the workgroups that stream the SAME operand tiles -- the query blocks of one (graph, head group) in the forward (they
+// stream that group's K / V), the key super-blocks of one (graph, head) in the backward (they stream its Q' / dO) -- should meet in ONE
+// L2 instead of fetching the stream into all eight.  The kernels number their work stream-major (`logical`) and take
+//     logical(L) = (L % 8) * ceil(total / 8) + L / 8 :
+// XCD r walks the contiguous eighth [r chunk, (r + 1) chunk) of the stream-major order, front to back, in step with the other XCDs
+// (at the headline batch an eighth is exactly one (graph, head group) / one head).  The grid is 8 * chunk; ids >= total do nothing.
+// DGDM_ATTN_XCD 0: logical = L (rounds 1-5: a stream spread over all XCDs).
+#ifndef DGDM_ATTN_XCD
+#define DGDM_ATTN_XCD 1
+#endif
+__host__ __device__ inline int attn_xcd_chunk(int total) { return (total + 7) >> 3; }
+__host__ __device__ inline unsigned attn_xcd_grid(int total) { return DGDM_ATTN_XCD ? 8u * (unsigned)attn_xcd_chunk(total) : (unsigned)total; }
+__device__ __forceinline__ int attn_xcd_logical(int L, int total) { return DGDM_ATTN_XCD ? (L & 7) * attn_xcd_chunk(total) + (L >> 3) : L; }
+
 // ---- blocks whose weights are EXACTLY zero (round 5) ------------------------------------------------------------------------------
 // The reference feeds raw slide coordinates (pixels) into -distance / temperature (preprocessing/tissue_graph_builder.py:381-384,
 // core/attention.py:261-283): two patches a few hundred pixels apart get exp(-hundreds) = 0.0f in fp32, i.e. on real slides all but a

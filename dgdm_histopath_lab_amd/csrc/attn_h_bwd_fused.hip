@@ -158,9 +158,12 @@ __global__ __launch_bounds__(64 * SBW) __attribute__((amdgpu_waves_per_eu(WPE, 8
 
   int n0, ng, sbl, blk0, sb0;
   int64_t spair0;
-  if ((int)blockIdx.x >= sb_count || !find_sblock(ptr, B, sb_first + blockIdx.x, &n0, &ng, &sbl, &blk0, &sb0, &spair0)) return;
+  // workgroup -> (head, super-block), head-major so that a head's super-blocks are contiguous in the logical order (attn_h.hpp)
+  const int logical = attn_xcd_logical((int)blockIdx.x, sb_count * H);
+  if (logical >= sb_count * H) return;
+  const int head = __builtin_amdgcn_readfirstlane(logical / sb_count), sbx = logical - head * sb_count;      // (scalar registers)
+  if (sbx >= sb_count || !find_sblock(ptr, B, sb_first + sbx, &n0, &ng, &sbl, &blk0, &sb0, &spair0)) return;
   const int nbg = (ng + HB - 1) / HB;
-  const int head = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, G = lane >> 4;
   const int lblk_w = SBW * sbl + wave;                       // this wave's key block inside the graph ...
@@ -193,7 +196,7 @@ __global__ __launch_bounds__(64 * SBW) __attribute__((amdgpu_waves_per_eu(WPE, 8
   }
   // query blocks whose weights are exactly zero against all of this super-block's keys (every head of the map's group) are walked
   // over: no staging, no arithmetic, no partial tile (k_attn_dq_reduce consults the same bits)
-  const uint32_t* srow = skip_map ? skip_map + attn_map_row(1, head / attn_map_group(H), H, num_blocks, sb_first + (int)blockIdx.x) : nullptr;
+  const uint32_t* srow = skip_map ? skip_map + attn_map_row(1, head / attn_map_group(H), H, num_blocks, sb_first + sbx) : nullptr;
   LiveWalk live;
   live.init(srow, nbg);
   int qb = __builtin_amdgcn_readfirstlane(live.next());
@@ -571,11 +574,11 @@ extern "C" int dgdm_spatial_attn_h_bwd_fused_sparse(const void* Rq, const void* 
     if (attr != DGDM_OK) return attr;
   }
   if (drop_p > 0.f)
-    hipLaunchKernelGGL((k_attn_h_bwd_fused<true, 2>), dim3(sb_count, H), dim3(64 * SBW), LDS_DYN, s, h16(Rq), h16(Rk), h16(Rv), h16(Rg), pos_b,
+    hipLaunchKernelGGL((k_attn_h_bwd_fused<true, 2>), dim3(attn_xcd_grid(sb_count * H)), dim3(64 * SBW), LDS_DYN, s, h16(Rq), h16(Rk), h16(Rv), h16(Rg), pos_b,
                        lse_adj_b, ndelta_b, H, ptr, B, kscale, grad_scale2, dK, dV, ldg, part, sb_first, sb_count, slot_first, drop_p,
                        dgdm_seed_arg(seed), skip_map, num_blocks, amax_out);
   else
-    hipLaunchKernelGGL((k_attn_h_bwd_fused<false, 2>), dim3(sb_count, H), dim3(64 * SBW), LDS_DYN, s, h16(Rq), h16(Rk), h16(Rv), h16(Rg), pos_b,
+    hipLaunchKernelGGL((k_attn_h_bwd_fused<false, 2>), dim3(attn_xcd_grid(sb_count * H)), dim3(64 * SBW), LDS_DYN, s, h16(Rq), h16(Rk), h16(Rv), h16(Rg), pos_b,
                        lse_adj_b, ndelta_b, H, ptr, B, kscale, grad_scale2, dK, dV, ldg, part, sb_first, sb_count, slot_first, 0.f,
                        dgdm_seed_arg(0u), skip_map, num_blocks, amax_out);
   return dgdm_launch_status();

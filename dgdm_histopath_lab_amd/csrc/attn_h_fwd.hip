@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
                                                     const _Float16* __restrict__ Rv, const float* __restrict__ pos_b, int H,
                                                     const int32_t* __restrict__ ptr, int B, float* __restrict__ O,
                                                     int64_t ldo, float* __restrict__ lse2_b, float drop_p, DgdmSeed seed_in,
-                                                    const uint32_t* __restrict__ skip_map, unsigned* __restrict__ amax_out) {
+                                                    const uint32_t* __restrict__ skip_map, unsigned* __restrict__ amax_out, int num_blocks) {
   const uint32_t seed = seed_in.value();
   constexpr int NT = HB / 16;
   constexpr int RK_BYTES = HG * R_HEAD * 2, TV_BYTES = RK_BYTES, POS_BYTES = HB * 8;      // K and V row images (V^T is read transposed)
@@ -107,10 +107,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
   __shared__ __attribute__((aligned(16))) char smem[NBUF * BUF_BYTES];
   const DropCfg dc(drop_p);
 
+  // workgroup -> (head group, query block), head-group-major: the query blocks of a (graph, head group) are contiguous (attn_h.hpp)
+  const int logical = attn_xcd_logical((int)blockIdx.x, num_blocks * (H / HG));
+  if (logical >= num_blocks * (H / HG)) return;
+  const int hgrp = __builtin_amdgcn_readfirstlane(logical / num_blocks), bx = logical - hgrp * num_blocks;      // (scalar registers)
   int n0, ng, lblk, blk0;
-  if (!find_block(ptr, B, blockIdx.x, &n0, &ng, &lblk, &blk0)) return;
+  if (!find_block(ptr, B, bx, &n0, &ng, &lblk, &blk0)) return;
   const int nbg = (ng + HB - 1) / HB;
-  const int head0 = blockIdx.y * HG;
+  const int head0 = hgrp * HG;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, G = lane >> 4;
   const int q_in_blk = wave * 16 + j;
@@ -126,7 +130,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
   };
   // key blocks whose weights are exactly zero for this query block and every head of its group are walked over (attn_h.hpp;
   // the block that holds the rows themselves never is: kb < nbg below)
-  const uint32_t* srow = skip_map ? skip_map + attn_map_row(0, head0 / attn_map_group(H), H, gridDim.x, blockIdx.x) : nullptr;
+  const uint32_t* srow = skip_map ? skip_map + attn_map_row(0, head0 / attn_map_group(H), H, num_blocks, bx) : nullptr;
   LiveWalk live;
   live.init(srow, nbg);
   int kb = __builtin_amdgcn_readfirstlane(live.next());
@@ -141,13 +145,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
   const f16x8 ones = {one, one, one, one, one, one, one, one};
 #pragma unroll
   for (int h = 0; h < HG; ++h) {
-    load_b_pair(Rq + ((int64_t)blockIdx.x * H + head0 + h) * R_HEAD, q_in_blk, G, &qb1[h], &qb2[h]);
+    load_b_pair(Rq + ((int64_t)bx * H + head0 + h) * R_HEAD, q_in_blk, G, &qb1[h], &qb2[h]);
     oacc[h] = f32x4{0.f, 0.f, 0.f, 0.f}; lacc[h] = f32x4{0.f, 0.f, 0.f, 0.f}; m[h] = NEG_BIG;
     if (DROP) dl[h] = DropLaneQ(DropHead(seed, n0, head0 + h), q_local);
   }
   const uint32_t lck = __umul24(2u * (uint32_t)G, DROP_CK);
   const int aoff = r_lane_off(j, G);
-  const float px = pos_b[((int64_t)blockIdx.x * 2 + 0) * HB + q_in_blk], py = pos_b[((int64_t)blockIdx.x * 2 + 1) * HB + q_in_blk];
+  const float px = pos_b[((int64_t)bx * 2 + 0) * HB + q_in_blk], py = pos_b[((int64_t)bx * 2 + 1) * HB + q_in_blk];
   __syncthreads();  // block 0 landed (vmcnt(0) + barrier)
 
   for (int it = 0; kb < nbg; ++it) {
@@ -249,7 +253,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
       *reinterpret_cast<float4*>(O + (int64_t)(n0 + q_local) * ldo + (head0 + h) * 16 + 4 * G) = o4;
       am = dgdm_amax4(am, o4);
     }
-    if (G == 0) lse2_b[((int64_t)blockIdx.x * H + head0 + h) * HB + q_in_blk] = q_ok ? m[h] + log2f(lt) : 0.f;
+    if (G == 0) lse2_b[((int64_t)bx * H + head0 + h) * HB + q_in_blk] = q_ok ? m[h] + log2f(lt) : 0.f;
   }
   if (amax_out) dgdm_amax_commit(am, amax_out);      // kernel argument: every thread of the workgroup is here
 }
@@ -323,11 +327,11 @@ extern "C" int dgdm_spatial_attn_h_fwd_sparse(const void* Rq, const void* Rk, co
 #define GO(HG, NBUF, WPE)                                                                                                   \
   do {                                                                                                                      \
     if (drop_p > 0.f)                                                                                                       \
-      hipLaunchKernelGGL((k_attn_h_fwd<HG, true, NBUF, WPE>), dim3(num_blocks, H / HG), dim3(256), 0, s, q, k, v, pos_b, H, ptr, B,    \
-                         O, ldo, lse2_b, drop_p, dgdm_seed_arg(seed), skip_map, amax_out);                                                   \
+      hipLaunchKernelGGL((k_attn_h_fwd<HG, true, NBUF, WPE>), dim3(attn_xcd_grid(num_blocks * (H / HG))), dim3(256), 0, s, q, k, v, pos_b, H, ptr, B,    \
+                         O, ldo, lse2_b, drop_p, dgdm_seed_arg(seed), skip_map, amax_out, num_blocks);                                       \
     else                                                                                                                    \
-      hipLaunchKernelGGL((k_attn_h_fwd<HG, false, NBUF, WPE>), dim3(num_blocks, H / HG), dim3(256), 0, s, q, k, v, pos_b, H, ptr, B,   \
-                         O, ldo, lse2_b, 0.f, dgdm_seed_arg(0u), skip_map, amax_out);                                                        \
+      hipLaunchKernelGGL((k_attn_h_fwd<HG, false, NBUF, WPE>), dim3(attn_xcd_grid(num_blocks * (H / HG))), dim3(256), 0, s, q, k, v, pos_b, H, ptr, B,   \
+                         O, ldo, lse2_b, 0.f, dgdm_seed_arg(0u), skip_map, amax_out, num_blocks);                                            \
   } while (0)
   // variant 0 = default; 1..3 select a tiling explicitly (tools/microbench_attn.py)
   if (H % 4 == 0 && variant == 1) GO(4, 2, 2);        // 4 heads, double-buffered, 2 workgroups per CU
