@@ -3,6 +3,7 @@
 // Runs M x K x 128 on random data, prints per-phase deltas of workgroup 0 / wave 0 in shader cycles and in ns (s_memrealtime, 100 MHz).
 #define DGDM_GEMM_IMG_STAMPS 1
 #include "../../dgdm_histopath_lab_amd/csrc/gemm_img.hip"
+const uint32_t* dgdm_seed_epoch_ptr() { return nullptr; }      // api.hip's (the epilogue variants of the file take a dropout seed; none runs here)
 #include <cstdio>
 #include <vector>
 #include <cstdlib>
