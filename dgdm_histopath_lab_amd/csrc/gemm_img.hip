@@ -20,6 +20,7 @@
 // 1 lo, at (2j + p) KiB; lane l's 8 halfs at 16 l: B(col = 32t + (l & 31), k = 32c + 16 (l >> 5) + 8j + i), i = 0..7.
 // The column count is zero-padded to a multiple of 32, K to a multiple of 64 (whole LDS stages).
 #include "gemm_epi.hpp"
+#include <type_traits>
 
 namespace {
 
@@ -98,6 +99,11 @@ __device__ unsigned long long* dgdm_stamp_buf;
 // (tools/build_variant_lib.sh -DDGDM_IMG_NARROW_MAX=128 vs 256, tools/microbench_gemm.py): at N = 256 and M = 40 000 the wide
 // kernel has 313 workgroups for 512 resident slots, the narrow one 626 half-size ones: 54.8 -> 52.2, 36.0 -> 32.8 / 35.5,
 // 48.3 -> 47.0 us (K = 544 / 288 / 512).  A small, consistent gain; beyond 256 columns the wide kernel wins by 25-40 %.
+// register sets of activation rows in flight in the narrow kernel (stages of 64 k).  1 (shipped): stage s + 1 is loaded inside stage s.
+// 2 (round 6, measured and left off): stage s + 2 -- see the kernel.
+#ifndef DGDM_IMG_DEPTH
+#define DGDM_IMG_DEPTH 1
+#endif
 #ifndef DGDM_IMG_NARROW_MAX
 #define DGDM_IMG_NARROW_MAX 256
 #endif
@@ -167,7 +173,16 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN > 4 ? 1 : 2) void k_gemm_img(
   // `s_waitcnt vmcnt(0)` at the top of a stage retires the DMA of that stage and both register sets (issued at least 24
   // MFMAs = 768 matrix-pipe cycles earlier); a set is only read after that wait and only overwritten after its conversion.
   typedef float f32x4 __attribute__((ext_vector_type(4)));
-  f32x4 a00, a01, a02, a03, a10, a11, a12, a13;          // two chunks in flight
+  // DEPTH register sets of one stage (two chunks) each.  The in-kernel stamps (profiles/r06_gemm_img_stamps.txt) show every stage of this
+  // kernel taking a memory round trip (1.6 us alone, 3.2 us with the chip loaded) around 0.8 us of arithmetic, so round 6 tried a second
+  // set -- the loads of stage s + 2 issued inside stage s, the wait at the top of a stage COUNTED (the last 8 loads issued are always the
+  // younger set's, behind the stage's LDS-DMA pieces: `vmcnt(8)` retires exactly this stage's DMA and set).  Correct (canary and parity
+  // tests), 236 registers, and SLOWER: 17.6 against 15.9 us at 40 000 x 160 x 128 alone, 12.90 against 12.71 ms per step (five
+  // alternating pairs, profiles/r06_img_depth_ab.txt).  With twice the loads in flight the first stage arrives later (5.4 against 3.7 us)
+  // and the later ones no sooner: what a stage waits for under load is not the distance of its prefetch but the rate at which these
+  // fragment-shaped loads (64 half-lines per wave instruction) are served.
+  constexpr int DEPTH = DGDM_IMG_DEPTH;
+  f32x4 ar[DEPTH][8];
 #define DGDM_LOAD_CHUNK(c_, r0_, r1_, r2_, r3_)                                                                     \
   {                                                                                                                 \
     const float* p__ = arow + min(32 * (c_) + klane, K - 16);                                                       \
@@ -216,8 +231,11 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN > 4 ? 1 : 2) void k_gemm_img(
     __builtin_amdgcn_sched_barrier(0);
   }
   stage_dma(0, 0);
-  DGDM_LOAD_CHUNK(0, a00, a01, a02, a03)
-  DGDM_LOAD_CHUNK(1, a10, a11, a12, a13)
+#pragma unroll
+  for (int q = 0; q < DEPTH; ++q) {
+    DGDM_LOAD_CHUNK(q * CPS, ar[q][0], ar[q][1], ar[q][2], ar[q][3])
+    DGDM_LOAD_CHUNK(q * CPS + 1, ar[q][4], ar[q][5], ar[q][6], ar[q][7])
+  }
   if (!ACCUM) {  // the operand scales are read AFTER the first stage and the first two chunks are on their way: one memory latency, not two
     sca = scale_of(amax_group(amax_a));
     scb = *reinterpret_cast<const float*>(img);
@@ -225,9 +243,13 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN > 4 ? 1 : 2) void k_gemm_img(
   uint32_t seed_v = 0, pseed_v = 0;     // the fused epilogues' dropout seeds: read here, not behind the main loop
   if (EPI != EPI_NONE) { seed_v = epi.seed.value(); pseed_v = EPI == EPI_NORM ? epi.pre_seed.value() : 0u; }
 
-  for (int s = 0; s < nst; ++s) {
+  auto stage_body = [&](auto SET, const int s) {
+    constexpr int q = decltype(SET)::value;
     // stage s has landed (this wave's pieces: vmcnt; everybody's: the barrier), and every wave is done reading the other buffer
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a00), "+v"(a01), "+v"(a02), "+v"(a03), "+v"(a10), "+v"(a11), "+v"(a12), "+v"(a13) :: "memory");
+    if constexpr (DEPTH == 1)
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(ar[q][0]), "+v"(ar[q][1]), "+v"(ar[q][2]), "+v"(ar[q][3]), "+v"(ar[q][4]), "+v"(ar[q][5]), "+v"(ar[q][6]), "+v"(ar[q][7]) :: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(8)" : "+v"(ar[q][0]), "+v"(ar[q][1]), "+v"(ar[q][2]), "+v"(ar[q][3]), "+v"(ar[q][4]), "+v"(ar[q][5]), "+v"(ar[q][6]), "+v"(ar[q][7]) :: "memory");
     __builtin_amdgcn_s_barrier();
     DGDM_STAMP(2 + (s < 5 ? s : 5))
     if (s + 1 < nst) stage_dma(s + 1, (s + 1) & 1);
@@ -258,10 +280,10 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN > 4 ? 1 : 2) void k_gemm_img(
     // that it never waits for the matrix pipe): the long-lived accumulator sees K / 64 correctly rounded adds instead of 3 K / 16
     // matrix-pipe accumulations of twice the rounding error each.  Tile-major order; both chunks are converted before the first
     // tile (every tile needs all four A fragments).
-    DGDM_CONVERT(0, a00, a01, a02, a03)
-    DGDM_LOAD_CHUNK(s * CPS + CPS, a00, a01, a02, a03)       // past the end: clamped re-reads, retired after the loop
-    DGDM_CONVERT(1, a10, a11, a12, a13)
-    DGDM_LOAD_CHUNK(s * CPS + CPS + 1, a10, a11, a12, a13)
+    DGDM_CONVERT(0, ar[q][0], ar[q][1], ar[q][2], ar[q][3])
+    DGDM_LOAD_CHUNK((s + DEPTH) * CPS, ar[q][0], ar[q][1], ar[q][2], ar[q][3])       // past the end: clamped re-reads, retired after the loop
+    DGDM_CONVERT(1, ar[q][4], ar[q][5], ar[q][6], ar[q][7])
+    DGDM_LOAD_CHUNK((s + DEPTH) * CPS + 1, ar[q][4], ar[q][5], ar[q][6], ar[q][7])
 #define DGDM_READ_TILE(t_, slot_)                                                                                   \
   _Pragma("unroll") for (int st = 0; st < 4; ++st) {                                                                 \
     const char* q__ = buf + (st >> 1) * NT_WG * BLK + (2 * (st & 1)) * 1024 + (t_) * BLK;                            \
@@ -300,14 +322,14 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN > 4 ? 1 : 2) void k_gemm_img(
 #undef DGDM_READ_TILE
     } else {
     DGDM_READ_BATCH(0, 0)
-    DGDM_CONVERT(0, a00, a01, a02, a03)
-    DGDM_LOAD_CHUNK(s * CPS + CPS, a00, a01, a02, a03)       // past the end: clamped re-reads, retired after the loop
+    DGDM_CONVERT(0, ar[q][0], ar[q][1], ar[q][2], ar[q][3])
+    DGDM_LOAD_CHUNK((s + DEPTH) * CPS, ar[q][0], ar[q][1], ar[q][2], ar[q][3])       // past the end: clamped re-reads, retired after the loop
     __builtin_amdgcn_sched_barrier(0);
     DGDM_READ_BATCH(1, 1)
     __builtin_amdgcn_sched_barrier(0);
     DGDM_MFMA_BATCH(0, 0)
-    DGDM_CONVERT(1, a10, a11, a12, a13)                      // scheduled among the MFMAs of batch 0
-    DGDM_LOAD_CHUNK(s * CPS + CPS + 1, a10, a11, a12, a13)
+    DGDM_CONVERT(1, ar[q][4], ar[q][5], ar[q][6], ar[q][7])                      // scheduled among the MFMAs of batch 0
+    DGDM_LOAD_CHUNK((s + DEPTH) * CPS + 1, ar[q][4], ar[q][5], ar[q][6], ar[q][7])
     __builtin_amdgcn_sched_barrier(0);
     DGDM_READ_BATCH(2, 0)
     __builtin_amdgcn_sched_barrier(0);
@@ -319,12 +341,20 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN > 4 ? 1 : 2) void k_gemm_img(
     __builtin_amdgcn_sched_barrier(0);
     DGDM_MFMA_BATCH(3, 1)
     }
+  };
+  for (int s = 0; s < nst; s += DEPTH) {
+    stage_body(std::integral_constant<int, 0>{}, s);
+    if constexpr (DEPTH == 2) {
+      if (s + 1 < nst) stage_body(std::integral_constant<int, 1>{}, s + 1);
+    }
   }
 #undef DGDM_READ_BATCH
 #undef DGDM_MFMA_BATCH
   // nothing may still be in flight into the a-registers when the epilogue reuses them (an asm load completes behind the
   // compiler's back: a late one would land in whatever the register holds by then -- a store address, for instance)
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(a00), "+v"(a01), "+v"(a02), "+v"(a03), "+v"(a10), "+v"(a11), "+v"(a12), "+v"(a13) :: "memory");
+#pragma unroll
+  for (int q = 0; q < DEPTH; ++q)
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(ar[q][0]), "+v"(ar[q][1]), "+v"(ar[q][2]), "+v"(ar[q][3]), "+v"(ar[q][4]), "+v"(ar[q][5]), "+v"(ar[q][6]), "+v"(ar[q][7]) :: "memory");
 #undef DGDM_LOAD_CHUNK
 #undef DGDM_CONVERT
 
